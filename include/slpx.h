@@ -1,0 +1,176 @@
+/*
+ * slpx — C-ABI of the MI355X-native interior-point Newton step.
+ *
+ * The reference (SleipnirGroup/Sleipnir) has no FFI boundary on this path: it is
+ * a C++ header-template library.  The seam this library sits behind is made of
+ * three reference C++ interfaces; every entry point below names
+ * the reference interface it replaces.  Plain pointers and sizes only; opaque
+ * handles; caller-owned host arrays; library-owned device memory; no exceptions
+ * cross the ABI (functions return 0 on success, <0 on usage/HIP errors — see
+ * slpx_last_error() — and >0 where documented).  One handle per host thread /
+ * HIP stream, like the reference's thread_local pool (src/util/pool.cpp:5-8).
+ *
+ * All vectors are fp64, all indices int32, matrices are CSC (column-major
+ * compressed, sorted row indices) with int32 indices — the layout of
+ * Eigen::SparseMatrix<double> the reference passes around.  Batched buffers are
+ * batch-major: buf[b * stride + i].
+ *
+ * There is NO CPU fallback: compute entry points fail with an error when no HIP
+ * device is present.
+ */
+#ifndef SLPX_H_
+#define SLPX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slpx_problem slpx_problem;
+typedef struct slpx_system slpx_system;
+
+/* ---- library ------------------------------------------------------------ */
+int slpx_abi_version(void);
+const char* slpx_last_error(void);
+int slpx_device_count(void);
+
+/* ---- expression graph ------------------------------------------------------
+ * Replaces: slp::Variable and the detail:: operator set
+ * (include/sleipnir/autodiff/variable.hpp:52-295, expression.hpp:155-2080), i.e.
+ * what python/cpp/autodiff/bind_variable.cpp binds for the reference's own FFI.
+ * Op codes are slpx_op below.  Pruning/constant-folding/typing rules are the
+ * reference's.  Ids index this thread's arena. */
+typedef enum slpx_op {
+  SLPX_OP_CONST = 0, SLPX_OP_VAR, SLPX_OP_ADD, SLPX_OP_SUB, SLPX_OP_NEG, SLPX_OP_MUL,
+  SLPX_OP_DIV, SLPX_OP_POW, SLPX_OP_ABS, SLPX_OP_SIGN, SLPX_OP_SQRT, SLPX_OP_CBRT,
+  SLPX_OP_EXP, SLPX_OP_LOG, SLPX_OP_LOG10, SLPX_OP_SIN, SLPX_OP_COS, SLPX_OP_TAN,
+  SLPX_OP_ASIN, SLPX_OP_ACOS, SLPX_OP_ATAN, SLPX_OP_ATAN2, SLPX_OP_SINH, SLPX_OP_COSH,
+  SLPX_OP_TANH, SLPX_OP_ERF, SLPX_OP_HYPOT, SLPX_OP_MAX, SLPX_OP_MIN, SLPX_OP_ISNONNEG,
+  SLPX_OP_ISPOS
+} slpx_op;
+
+void slpx_graph_reset(void); /* frees this thread's arena; invalidates its problems */
+int64_t slpx_graph_size(void);
+int32_t slpx_expr_variable(double value);               /* Variable()          variable.hpp:289 */
+int32_t slpx_expr_constant(double value);               /* Variable(double)    variable.hpp:64  */
+int32_t slpx_expr_unary(int op, int32_t a);             /* sin(x), -x, ...                      */
+int32_t slpx_expr_binary(int op, int32_t a, int32_t b); /* x*y, pow(x,y), ...                   */
+int slpx_expr_type(int32_t id);                         /* Variable::type()    variable.hpp:153 */
+double slpx_expr_value(int32_t id);                     /* Variable::value()   variable.hpp:143 */
+void slpx_expr_set_value(int32_t id, double value);     /* Variable::set_value variable.hpp:125 */
+
+/* ---- problem ------------------------------------------------------------------
+ * Replaces: slp::Problem<double> (include/sleipnir/optimization/problem.hpp):
+ * decision_variable :78, minimize :151, maximize :162, subject_to :196/:218,
+ * cost_function_type :236, solve :281.  Constraint ids are `lhs - rhs`
+ * expressions (variable.hpp:716-778); inequality convention c(x) >= 0. */
+slpx_problem* slpx_problem_create(void);
+void slpx_problem_destroy(slpx_problem* p);
+int32_t slpx_problem_decision_variable(slpx_problem* p);
+void slpx_problem_minimize(slpx_problem* p, int32_t cost);
+void slpx_problem_maximize(slpx_problem* p, int32_t objective);
+void slpx_problem_subject_to_eq(slpx_problem* p, int32_t c);
+void slpx_problem_subject_to_ineq(slpx_problem* p, int32_t c);
+int slpx_problem_cost_type(const slpx_problem* p);
+int slpx_problem_eq_type(const slpx_problem* p);
+int slpx_problem_ineq_type(const slpx_problem* p);
+void slpx_problem_dims(const slpx_problem* p, int32_t* n, int32_t* m_e, int32_t* m_i);
+void slpx_problem_get_x(const slpx_problem* p, double* x);
+void slpx_problem_set_x(slpx_problem* p, const double* x);
+
+/* slp::Options (solver/options.hpp:13-38) */
+typedef struct slpx_options {
+  double tolerance;    /* 1e-8 */
+  int32_t max_iterations; /* 5000 */
+  double timeout;      /* seconds; <= 0 means infinity */
+  int32_t feasible_ipm;
+  int32_t diagnostics;
+} slpx_options;
+
+/* Per-solve counters and wall-clock phases (names of interior_point.hpp:155-174) */
+typedef struct slpx_report {
+  int32_t iterations, factorizations, solves, value_sweeps;
+  double delta, gamma, final_error;
+  double t_setup, t_kkt_build, t_kkt_decomp, t_kkt_solve, t_line_search, t_ad_refresh, t_total;
+  double t_compile; /* graph -> tape/KKT plan/symbolic LDLT + upload */
+} slpx_report;
+
+/* Problem::solve.  Returns slp::ExitStatus (solver/exit_status.hpp:13-43):
+ * 0 success, 1 callback stop, -1..-10 as in the reference; -100 on library error. */
+int slpx_problem_solve(slpx_problem* p, const slpx_options* opt, slpx_report* report);
+void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double* z);
+
+/* The reference's benchmark models, built with the C++ slp:: surface:
+ * benchmarks/scalability/cart_pole/sleipnir.cpp:76-129, .../flywheel/sleipnir.cpp:12-42 */
+slpx_problem* slpx_problem_cart_pole(int32_t N, double dt);
+slpx_problem* slpx_problem_flywheel(int32_t N, double dt);
+
+/* ---- compiled Newton system ------------------------------------------------------
+ * One problem structure compiled for one GPU, `batch` independent value sets.
+ * Replaces, per Newton step:
+ *   AD evaluator seam  Gradient/Jacobian/Hessian::value()
+ *                      (autodiff/gradient.hpp:53, jacobian.hpp:134, hessian.hpp:132)
+ *                      and the Problem lambdas problem.hpp:618-660
+ *   KKT build          solver/interior_point.hpp:426-448
+ *   linear solver seam RegularizedLDLT::compute/solve/info/hessian_regularization/
+ *                      constraint_jacobian_regularization (util/regularized_ldlt.hpp:56-128)
+ *   back-substitution  solver/interior_point.hpp:470-481 */
+slpx_system* slpx_system_create(slpx_problem* p, int32_t batch, int32_t device,
+                                const int32_t* perm, int32_t perm_len);
+void slpx_system_destroy(slpx_system* s);
+int slpx_system_set_stream(slpx_system* s, void* hip_stream);
+int slpx_system_sync(slpx_system* s);
+
+enum {
+  SLPX_INFO_N = 0, SLPX_INFO_ME, SLPX_INFO_MI, SLPX_INFO_NV, SLPX_INFO_NNZ_G, SLPX_INFO_NNZ_AE,
+  SLPX_INFO_NNZ_AI, SLPX_INFO_NNZ_HF, SLPX_INFO_NNZ_HC, SLPX_INFO_NNZ_LHS, SLPX_INFO_NNZ_L,
+  SLPX_INFO_LDLT_ROUNDS, SLPX_INFO_LDLT_TASKS, SLPX_INFO_ETREE_HEIGHT, SLPX_INFO_LDLT_PAIRS,
+  SLPX_INFO_TAPE_TASKS, SLPX_INFO_TAPE_NODES, SLPX_INFO_TAPE_SLOTS, SLPX_INFO_TAPE_EDGES,
+  SLPX_INFO_TAPE_LEVELS, SLPX_INFO_TAPE_SLOT_LEVELS, SLPX_INFO_ASSEMBLE_BYTES,
+  SLPX_INFO_RHS_BYTES, SLPX_INFO_FACTOR_BYTES, SLPX_INFO_SOLVE_BYTES, SLPX_INFO_SWEEP_BYTES,
+  SLPX_INFO_STRUCT_SINGULAR, SLPX_INFO_OFF_G, SLPX_INFO_OFF_AE, SLPX_INFO_OFF_AI,
+  SLPX_INFO_OFF_HF, SLPX_INFO_OFF_HC, SLPX_INFO_GRAPH_NODES, SLPX_INFO_NONLINEAR_ROWS,
+  SLPX_INFO_TAPE_GLOBAL_TASKS, SLPX_INFO_COUNT
+};
+int slpx_system_info(const slpx_system* s, int64_t* out /* SLPX_INFO_COUNT */);
+
+/* Static sparsity patterns (CSC).  which: 0 g (1 x n), 1 A_e, 2 A_i, 3 H_f (lower),
+ * 4 H_c (lower), 5 KKT lhs (lower, full diagonal).  Pass NULL to query only nnz. */
+int32_t slpx_system_pattern(const slpx_system* s, int which, int32_t* colptr, int32_t* rowidx);
+int slpx_system_perm(const slpx_system* s, int32_t* perm); /* fill-reducing permutation, perm[new]=old */
+
+/* scales = [d_f, d_ce(m_e), d_ci(m_i)] (util/problem_scaling.hpp:100-107) */
+int slpx_system_set_scaling(slpx_system* s, const double* scales);
+/* x[batch][n], s[batch][m_i], y[batch][m_e], z[batch][m_i], mu[batch] (any may be NULL = keep) */
+int slpx_system_set_state(slpx_system* s, const double* x, const double* sl, const double* y,
+                          const double* z, const double* mu);
+
+int slpx_tape_sweep(slpx_system* s, int full); /* full=1: values + g, A_e, A_i, H; 0: f, c_e, c_i */
+int slpx_kkt_assemble(slpx_system* s);
+int slpx_kkt_rhs(slpx_system* s);
+/* One numeric factorization with explicit per-problem (delta, gamma).
+ * stats[batch][5] = {n_pos, n_neg, n_zero, n_bad, min|D|} */
+int slpx_ldlt_factor(slpx_system* s, const double* delta, const double* gamma, double* stats);
+/* The whole inertia-correcting loop of sparse_regularized_ldlt.hpp:64-152.
+ * info[batch] (0 Success, 1 NumericalIssue), reg[batch][2] = {delta, gamma} used. */
+int slpx_ldlt_compute(slpx_system* s, int32_t* info, double* reg, int32_t* factorizations);
+int slpx_ldlt_reset(slpx_system* s, double gamma_min);
+int slpx_ldlt_solve(slpx_system* s); /* rhs -> p, reusable after one compute */
+int slpx_step_backsub(slpx_system* s);
+/* AD refresh (optional) + assemble + rhs + compute + solve + backsub */
+int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info);
+
+/* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values */
+int64_t slpx_system_get(slpx_system* s, int which, double* out);
+int slpx_system_set_rhs(slpx_system* s, const double* rhs);
+
+/* Times `iters` Newton steps with HIP events on the system's stream.
+ * ms[8] = per-step averages {sweep, assemble, rhs, factor(all attempts), solve, backsub,
+ * total, factorizations per step} */
+int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLPX_H_ */

@@ -1,0 +1,328 @@
+"""sleipnir_amd — MI355X-native interior-point Newton step behind Sleipnir's
+``slp::Problem`` surface.
+
+The product is the C++/HIP library ``libslpx.so`` (sources in ``csrc/``, C-ABI in
+``include/slpx.h``).  This Python package is plumbing only: it builds the library
+in-tree and exposes the C-ABI through ctypes so that ``tests/`` and ``bench.py``
+can drive it.  It never computes anything itself and has no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_ROOT = _PKG.parent
+LIB_PATH = _PKG / "libslpx.so"
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+# include/slpx.h: SLPX_INFO_*
+INFO_KEYS = [
+    "n", "m_e", "m_i", "nV", "nnz_g", "nnz_Ae", "nnz_Ai", "nnz_Hf", "nnz_Hc", "nnz_lhs", "nnz_L",
+    "ldlt_rounds", "ldlt_tasks", "etree_height", "ldlt_pairs", "tape_tasks", "tape_nodes",
+    "tape_slots", "tape_edges", "tape_levels", "tape_slot_levels", "assemble_bytes", "rhs_bytes",
+    "factor_bytes", "solve_bytes", "sweep_bytes", "struct_singular", "off_g", "off_Ae", "off_Ai",
+    "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks",
+]
+
+# slpx_op
+OPS = {name: i for i, name in enumerate([
+    "CONST", "VAR", "ADD", "SUB", "NEG", "MUL", "DIV", "POW", "ABS", "SIGN", "SQRT", "CBRT", "EXP",
+    "LOG", "LOG10", "SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN", "ATAN2", "SINH", "COSH", "TANH",
+    "ERF", "HYPOT", "MAX", "MIN", "ISNONNEG", "ISPOS"])}
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("tolerance", ctypes.c_double), ("max_iterations", ctypes.c_int32),
+                ("timeout", ctypes.c_double), ("feasible_ipm", ctypes.c_int32),
+                ("diagnostics", ctypes.c_int32)]
+
+
+class Report(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("factorizations", ctypes.c_int32),
+                ("solves", ctypes.c_int32), ("value_sweeps", ctypes.c_int32),
+                ("delta", ctypes.c_double), ("gamma", ctypes.c_double),
+                ("final_error", ctypes.c_double), ("t_setup", ctypes.c_double),
+                ("t_kkt_build", ctypes.c_double), ("t_kkt_decomp", ctypes.c_double),
+                ("t_kkt_solve", ctypes.c_double), ("t_line_search", ctypes.c_double),
+                ("t_ad_refresh", ctypes.c_double), ("t_total", ctypes.c_double),
+                ("t_compile", ctypes.c_double)]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile libslpx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(_PKG / "csrc"), "-j", str(os.cpu_count() or 4)]
+    if force:
+        subprocess.run(cmd + ["clean"], check=True, capture_output=not verbose)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libslpx.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libslpx.so (building it first if missing) and declare the C-ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        build()
+    L = ctypes.CDLL(str(LIB_PATH))
+    vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+    def sig(name, restype, *argtypes):
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    sig("slpx_abi_version", ctypes.c_int)
+    sig("slpx_last_error", ctypes.c_char_p)
+    sig("slpx_device_count", ctypes.c_int)
+    sig("slpx_graph_reset", None)
+    sig("slpx_graph_size", i64)
+    sig("slpx_expr_variable", i32, f64)
+    sig("slpx_expr_constant", i32, f64)
+    sig("slpx_expr_unary", i32, ctypes.c_int, i32)
+    sig("slpx_expr_binary", i32, ctypes.c_int, i32, i32)
+    sig("slpx_expr_type", ctypes.c_int, i32)
+    sig("slpx_expr_value", f64, i32)
+    sig("slpx_expr_set_value", None, i32, f64)
+    sig("slpx_problem_create", vp)
+    sig("slpx_problem_destroy", None, vp)
+    sig("slpx_problem_decision_variable", i32, vp)
+    sig("slpx_problem_minimize", None, vp, i32)
+    sig("slpx_problem_maximize", None, vp, i32)
+    sig("slpx_problem_subject_to_eq", None, vp, i32)
+    sig("slpx_problem_subject_to_ineq", None, vp, i32)
+    sig("slpx_problem_cost_type", ctypes.c_int, vp)
+    sig("slpx_problem_eq_type", ctypes.c_int, vp)
+    sig("slpx_problem_ineq_type", ctypes.c_int, vp)
+    sig("slpx_problem_dims", None, vp, c_i32p, c_i32p, c_i32p)
+    sig("slpx_problem_get_x", None, vp, vp)
+    sig("slpx_problem_set_x", None, vp, vp)
+    sig("slpx_problem_solve", ctypes.c_int, vp, ctypes.POINTER(Options), ctypes.POINTER(Report))
+    sig("slpx_problem_get_duals", None, vp, vp, vp, vp)
+    sig("slpx_problem_cart_pole", vp, i32, f64)
+    sig("slpx_problem_flywheel", vp, i32, f64)
+    sig("slpx_system_create", vp, vp, i32, i32, vp, i32)
+    sig("slpx_system_destroy", None, vp)
+    sig("slpx_system_set_stream", ctypes.c_int, vp, vp)
+    sig("slpx_system_sync", ctypes.c_int, vp)
+    sig("slpx_system_info", ctypes.c_int, vp, vp)
+    sig("slpx_system_pattern", i32, vp, ctypes.c_int, vp, vp)
+    sig("slpx_system_perm", ctypes.c_int, vp, vp)
+    sig("slpx_system_set_scaling", ctypes.c_int, vp, vp)
+    sig("slpx_system_set_state", ctypes.c_int, vp, vp, vp, vp, vp, vp)
+    sig("slpx_tape_sweep", ctypes.c_int, vp, ctypes.c_int)
+    sig("slpx_kkt_assemble", ctypes.c_int, vp)
+    sig("slpx_kkt_rhs", ctypes.c_int, vp)
+    sig("slpx_ldlt_factor", ctypes.c_int, vp, vp, vp, vp)
+    sig("slpx_ldlt_compute", ctypes.c_int, vp, vp, vp, vp)
+    sig("slpx_ldlt_reset", ctypes.c_int, vp, f64)
+    sig("slpx_ldlt_solve", ctypes.c_int, vp)
+    sig("slpx_step_backsub", ctypes.c_int, vp)
+    sig("slpx_newton_step", ctypes.c_int, vp, ctypes.c_int, vp)
+    sig("slpx_system_get", i64, vp, ctypes.c_int, vp)
+    sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
+    sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class SlpxError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise SlpxError(lib().slpx_last_error().decode())
+    return rc
+
+
+class Problem:
+    """Handle on an slp::Problem living in libslpx (include/slpx.h, slpx_problem_*)."""
+
+    def __init__(self, handle=None):
+        self._h = handle if handle is not None else lib().slpx_problem_create()
+        if not self._h:
+            raise SlpxError(lib().slpx_last_error().decode())
+
+    @classmethod
+    def cart_pole(cls, N: int, dt: float) -> "Problem":
+        return cls(lib().slpx_problem_cart_pole(N, dt))
+
+    @classmethod
+    def flywheel(cls, N: int, dt: float) -> "Problem":
+        return cls(lib().slpx_problem_flywheel(N, dt))
+
+    def close(self):
+        if self._h:
+            lib().slpx_problem_destroy(self._h)
+            self._h = None
+
+    @property
+    def dims(self):
+        n, me, mi = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        lib().slpx_problem_dims(self._h, ctypes.byref(n), ctypes.byref(me), ctypes.byref(mi))
+        return n.value, me.value, mi.value
+
+    def decision_variable(self) -> int:
+        return lib().slpx_problem_decision_variable(self._h)
+
+    def minimize(self, expr_id: int):
+        lib().slpx_problem_minimize(self._h, expr_id)
+
+    def maximize(self, expr_id: int):
+        lib().slpx_problem_maximize(self._h, expr_id)
+
+    def subject_to_eq(self, expr_id: int):
+        lib().slpx_problem_subject_to_eq(self._h, expr_id)
+
+    def subject_to_ineq(self, expr_id: int):
+        lib().slpx_problem_subject_to_ineq(self._h, expr_id)
+
+    def types(self):
+        L = lib()
+        return (L.slpx_problem_cost_type(self._h), L.slpx_problem_eq_type(self._h),
+                L.slpx_problem_ineq_type(self._h))
+
+    def get_x(self) -> np.ndarray:
+        x = np.zeros(self.dims[0])
+        lib().slpx_problem_get_x(self._h, x.ctypes.data)
+        return x
+
+    def set_x(self, x):
+        x = _f64(x)
+        lib().slpx_problem_set_x(self._h, x.ctypes.data)
+
+    def solve(self, tolerance=1e-8, max_iterations=5000, timeout=0.0, feasible_ipm=False):
+        opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), 0)
+        rep = Report()
+        status = lib().slpx_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(rep))
+        if status == -100:
+            raise SlpxError(lib().slpx_last_error().decode())
+        return status, {f[0]: getattr(rep, f[0]) for f in Report._fields_}
+
+    def duals(self):
+        n, me, mi = self.dims
+        s, y, z = np.zeros(mi), np.zeros(me), np.zeros(mi)
+        lib().slpx_problem_get_duals(self._h, s.ctypes.data, y.ctypes.data, z.ctypes.data)
+        return s, y, z
+
+
+class System:
+    """Compiled Newton system on one GPU (include/slpx.h, slpx_system_* and kernels)."""
+
+    def __init__(self, problem: Problem, batch: int = 1, device: int = 0, perm=None):
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        self._h = lib().slpx_system_create(problem._h, batch, device, _ptr(p), 0 if p is None else len(p))
+        if not self._h:
+            raise SlpxError(lib().slpx_last_error().decode())
+        self.batch = batch
+        out = np.zeros(len(INFO_KEYS) + 4, dtype=np.int64)
+        _check(lib().slpx_system_info(self._h, out.ctypes.data))
+        self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
+
+    def close(self):
+        if self._h:
+            lib().slpx_system_destroy(self._h)
+            self._h = None
+
+    def pattern(self, which: int):
+        nnz = lib().slpx_system_pattern(self._h, which, None, None)
+        ncols = self.info["n"] if which != 5 else self.info["n"] + self.info["m_e"]
+        colptr = np.zeros(ncols + 1, dtype=np.int32)
+        rowidx = np.zeros(max(nnz, 1), dtype=np.int32)
+        lib().slpx_system_pattern(self._h, which, colptr.ctypes.data, rowidx.ctypes.data)
+        return colptr, rowidx[:nnz]
+
+    def perm(self):
+        p = np.zeros(self.info["n"] + self.info["m_e"], dtype=np.int32)
+        lib().slpx_system_perm(self._h, p.ctypes.data)
+        return p
+
+    def set_stream(self, stream_ptr: int):
+        _check(lib().slpx_system_set_stream(self._h, stream_ptr))
+
+    def sync(self):
+        _check(lib().slpx_system_sync(self._h))
+
+    def set_scaling(self, scales):
+        s = _f64(scales)
+        _check(lib().slpx_system_set_scaling(self._h, s.ctypes.data))
+
+    def set_state(self, x=None, s=None, y=None, z=None, mu=None):
+        x, s, y, z, mu = (_f64(a) for a in (x, s, y, z, mu))
+        _check(lib().slpx_system_set_state(self._h, _ptr(x), _ptr(s), _ptr(y), _ptr(z), _ptr(mu)))
+
+    def sweep(self, full=True):
+        _check(lib().slpx_tape_sweep(self._h, int(full)))
+
+    def assemble(self):
+        _check(lib().slpx_kkt_assemble(self._h))
+
+    def rhs(self):
+        _check(lib().slpx_kkt_rhs(self._h))
+
+    def factor(self, delta, gamma):
+        d = np.full(self.batch, delta, dtype=np.float64) if np.isscalar(delta) else _f64(delta)
+        g = np.full(self.batch, gamma, dtype=np.float64) if np.isscalar(gamma) else _f64(gamma)
+        stats = np.zeros((self.batch, 5))
+        _check(lib().slpx_ldlt_factor(self._h, d.ctypes.data, g.ctypes.data, stats.ctypes.data))
+        return stats
+
+    def compute(self):
+        info = np.zeros(self.batch, dtype=np.int32)
+        reg = np.zeros((self.batch, 2))
+        nf = ctypes.c_int32()
+        _check(lib().slpx_ldlt_compute(self._h, info.ctypes.data, reg.ctypes.data, ctypes.addressof(nf)))
+        return info, reg, nf.value
+
+    def reset_regularization(self, gamma_min=1e-10):
+        _check(lib().slpx_ldlt_reset(self._h, gamma_min))
+
+    def solve(self):
+        _check(lib().slpx_ldlt_solve(self._h))
+
+    def backsub(self):
+        _check(lib().slpx_step_backsub(self._h))
+
+    def newton_step(self, refresh_ad=True):
+        info = np.zeros(self.batch, dtype=np.int32)
+        _check(lib().slpx_newton_step(self._h, int(refresh_ad), info.ctypes.data))
+        return info
+
+    def get(self, which: str) -> np.ndarray:
+        sel = {"V": 0, "lhs": 1, "rhs": 2, "p": 3, "p_s": 4, "p_z": 5, "D": 6, "Lx": 7}[which]
+        count = _check(lib().slpx_system_get(self._h, sel, None))
+        out = np.zeros(max(count, 1))
+        _check(lib().slpx_system_get(self._h, sel, out.ctypes.data))
+        return out[:count].reshape(self.batch, -1)
+
+    def set_rhs(self, rhs):
+        r = _f64(rhs)
+        _check(lib().slpx_system_set_rhs(self._h, r.ctypes.data))
+
+    def time_step(self, iters=10, refresh_ad=True):
+        ms = np.zeros(8, dtype=np.float32)
+        _check(lib().slpx_system_time_step(self._h, iters, int(refresh_ad), ms.ctypes.data))
+        keys = ["sweep", "assemble", "rhs", "factor", "solve", "backsub", "total", "factorizations"]
+        return {k: float(ms[i]) for i, k in enumerate(keys)}

@@ -1,0 +1,399 @@
+// Implementation of include/slpx.h.
+#include "../../include/slpx.h"
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "capi_internal.hpp"
+#include "problems.hpp"
+
+namespace {
+thread_local std::string g_error;
+
+template <typename F>
+int guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -100;
+  } catch (...) {
+    g_error = "unknown error";
+    return -100;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int slpx_abi_version(void) { return 1; }
+const char* slpx_last_error(void) { return g_error.c_str(); }
+int slpx_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+void slpx_graph_reset(void) { slpx::graph().clear(); }
+int64_t slpx_graph_size(void) { return static_cast<int64_t>(slpx::graph().size()); }
+int32_t slpx_expr_variable(double value) { return slpx::graph().variable(value); }
+int32_t slpx_expr_constant(double value) { return slpx::graph().constant(value); }
+int32_t slpx_expr_unary(int op, int32_t a) {
+  return slpx::graph().unary(static_cast<slpx::Opcode>(op), a);
+}
+int32_t slpx_expr_binary(int op, int32_t a, int32_t b) {
+  return slpx::graph().binary(static_cast<slpx::Opcode>(op), a, b);
+}
+int slpx_expr_type(int32_t id) { return slpx::graph().type[id]; }
+double slpx_expr_value(int32_t id) { return slpx::graph().value(id); }
+void slpx_expr_set_value(int32_t id, double value) { slpx::graph().val[id] = value; }
+
+slpx_problem* slpx_problem_create(void) { return new slpx_problem(); }
+void slpx_problem_destroy(slpx_problem* p) { delete p; }
+int32_t slpx_problem_decision_variable(slpx_problem* p) { return p->problem.decision_variable().expr; }
+void slpx_problem_minimize(slpx_problem* p, int32_t cost) { p->problem.minimize(slp::Variable::wrap(cost)); }
+void slpx_problem_maximize(slpx_problem* p, int32_t objective) {
+  p->problem.maximize(slp::Variable::wrap(objective));
+}
+void slpx_problem_subject_to_eq(slpx_problem* p, int32_t c) {
+  p->problem.subject_to(slp::EqualityConstraints{std::vector<slp::Variable>{slp::Variable::wrap(c)}});
+}
+void slpx_problem_subject_to_ineq(slpx_problem* p, int32_t c) {
+  p->problem.subject_to(slp::InequalityConstraints{std::vector<slp::Variable>{slp::Variable::wrap(c)}});
+}
+int slpx_problem_cost_type(const slpx_problem* p) { return static_cast<int>(p->problem.cost_function_type()); }
+int slpx_problem_eq_type(const slpx_problem* p) { return static_cast<int>(p->problem.equality_constraint_type()); }
+int slpx_problem_ineq_type(const slpx_problem* p) { return static_cast<int>(p->problem.inequality_constraint_type()); }
+void slpx_problem_dims(const slpx_problem* p, int32_t* n, int32_t* m_e, int32_t* m_i) {
+  *n = static_cast<int32_t>(p->problem.decision_variables().size());
+  *m_e = static_cast<int32_t>(p->problem.equality_constraints().size());
+  *m_i = static_cast<int32_t>(p->problem.inequality_constraints().size());
+}
+void slpx_problem_get_x(const slpx_problem* p, double* x) {
+  auto& dv = p->problem.decision_variables();
+  for (size_t i = 0; i < dv.size(); ++i) x[i] = slpx::graph().val[dv[i].expr];
+}
+void slpx_problem_set_x(slpx_problem* p, const double* x) {
+  auto& dv = p->problem.decision_variables();
+  for (size_t i = 0; i < dv.size(); ++i) slpx::graph().val[dv[i].expr] = x[i];
+}
+
+int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* report) {
+  int status = -100;
+  int rc = guard([&] {
+    slp::Options opt;
+    if (o) {
+      opt.tolerance = o->tolerance;
+      opt.max_iterations = o->max_iterations;
+      if (o->timeout > 0) opt.timeout = o->timeout;
+      opt.feasible_ipm = o->feasible_ipm != 0;
+      opt.diagnostics = o->diagnostics != 0;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    p->problem.compile();
+    p->t_compile = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    status = static_cast<int>(p->problem.solve(opt));
+    if (report) {
+      const auto& r = p->problem.report();
+      *report = slpx_report{r.iterations,    r.factorizations, r.solves,       r.value_sweeps,
+                            r.delta,         r.gamma,          r.final_error,  r.t_setup,
+                            r.t_kkt_build,   r.t_kkt_decomp,   r.t_kkt_solve,  r.t_line_search,
+                            r.t_ad_refresh,  r.t_total,        p->t_compile};
+    }
+  });
+  return rc == 0 ? status : rc;
+}
+
+void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double* z) {
+  if (s) std::copy(p->problem.slack().begin(), p->problem.slack().end(), s);
+  if (y) std::copy(p->problem.equality_duals().begin(), p->problem.equality_duals().end(), y);
+  if (z) std::copy(p->problem.inequality_duals().begin(), p->problem.inequality_duals().end(), z);
+}
+
+slpx_problem* slpx_problem_cart_pole(int32_t N, double dt) {
+  auto* p = new slpx_problem();
+  if (guard([&] { slpx_models::build_cart_pole(p->problem, dt, N); }) != 0) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+slpx_problem* slpx_problem_flywheel(int32_t N, double dt) {
+  auto* p = new slpx_problem();
+  if (guard([&] { slpx_models::build_flywheel(p->problem, dt, N); }) != 0) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+slpx_system* slpx_system_create(slpx_problem* p, int32_t batch, int32_t device, const int32_t* perm,
+                                int32_t perm_len) {
+  auto* s = new slpx_system();
+  int rc = guard([&] {
+    slpx::NewtonOptions opt;
+    opt.batch = batch;
+    opt.device = device;
+    std::vector<slpx::NodeId> xs, ce, ci;
+    for (auto& v : p->problem.decision_variables()) xs.push_back(v.expr);
+    for (auto& v : p->problem.equality_constraints()) ce.push_back(v.expr);
+    for (auto& v : p->problem.inequality_constraints()) ci.push_back(v.expr);
+    std::vector<int32_t> up;
+    if (perm && perm_len > 0) up.assign(perm, perm + perm_len);
+    slpx::NodeId f = slpx::kNull;
+    // Problem keeps m_f private; rebuild the cost handle through its type/expr accessors
+    f = p->problem.cost_function_type() == slp::ExpressionType::NONE ? slpx::kNull : p->problem.cost().expr;
+    s->sys = std::make_unique<slpx::NewtonSystem>(slpx::graph(), xs, f, ce, ci, opt,
+                                                  up.empty() ? nullptr : &up);
+    s->ref = s->sys.get();
+  });
+  if (rc != 0) {
+    delete s;
+    return nullptr;
+  }
+  return s;
+}
+void slpx_system_destroy(slpx_system* s) { delete s; }
+int slpx_system_set_stream(slpx_system* s, void* hip_stream) {
+  return guard([&] { s->get().device().set_stream(static_cast<hipStream_t>(hip_stream)); });
+}
+int slpx_system_sync(slpx_system* s) {
+  return guard([&] { SLPX_HIP_CHECK(hipStreamSynchronize(s->get().device().stream())); });
+}
+
+int slpx_system_info(const slpx_system* sc, int64_t* out) {
+  auto* s = const_cast<slpx_system*>(sc);
+  return guard([&] {
+    const auto& st = s->get().structure();
+    const auto& k = s->get().kkt();
+    const auto& l = s->get().ldlt();
+    std::memset(out, 0, sizeof(int64_t) * SLPX_INFO_COUNT);
+    out[SLPX_INFO_N] = st.n;
+    out[SLPX_INFO_ME] = st.m_e;
+    out[SLPX_INFO_MI] = st.m_i;
+    out[SLPX_INFO_NV] = st.nV;
+    out[SLPX_INFO_NNZ_G] = st.g_pat.nnz();
+    out[SLPX_INFO_NNZ_AE] = st.Ae.nnz();
+    out[SLPX_INFO_NNZ_AI] = st.Ai.nnz();
+    out[SLPX_INFO_NNZ_HF] = st.Hf.nnz();
+    out[SLPX_INFO_NNZ_HC] = st.Hc.nnz();
+    out[SLPX_INFO_NNZ_LHS] = k.lhs.nnz();
+    out[SLPX_INFO_NNZ_L] = l.nnzL;
+    out[SLPX_INFO_LDLT_ROUNDS] = l.n_rounds;
+    out[SLPX_INFO_LDLT_TASKS] = static_cast<int64_t>(l.tasks.size());
+    out[SLPX_INFO_ETREE_HEIGHT] = l.etree_height;
+    out[SLPX_INFO_LDLT_PAIRS] = static_cast<int64_t>(l.pairs.size());
+    out[SLPX_INFO_TAPE_TASKS] = static_cast<int64_t>(st.full.tasks.size());
+    out[SLPX_INFO_TAPE_NODES] = static_cast<int64_t>(st.full.total_nodes);
+    out[SLPX_INFO_TAPE_SLOTS] = static_cast<int64_t>(st.full.total_slots);
+    out[SLPX_INFO_TAPE_EDGES] = static_cast<int64_t>(st.full.total_edges);
+    out[SLPX_INFO_TAPE_LEVELS] = st.full.max_levels;
+    out[SLPX_INFO_TAPE_SLOT_LEVELS] = st.full.max_slot_levels;
+    out[SLPX_INFO_ASSEMBLE_BYTES] = k.assemble_bytes;
+    out[SLPX_INFO_RHS_BYTES] = k.rhs_bytes;
+    out[SLPX_INFO_FACTOR_BYTES] = l.factor_bytes;
+    out[SLPX_INFO_SOLVE_BYTES] = l.solve_bytes;
+    // AD refresh lower bound: read x,y,z, write every dynamic V entry
+    int64_t dyn = 0;
+    for (uint8_t st_ : st.V_is_static) dyn += st_ ? 0 : 1;
+    out[SLPX_INFO_SWEEP_BYTES] = 8LL * st.n_inputs() + 8LL * dyn;
+    out[SLPX_INFO_STRUCT_SINGULAR] = l.structurally_singular_unregularized ? 1 : 0;
+    out[SLPX_INFO_OFF_G] = st.off_g;
+    out[SLPX_INFO_OFF_AE] = st.off_Ae;
+    out[SLPX_INFO_OFF_AI] = st.off_Ai;
+    out[SLPX_INFO_OFF_HF] = st.off_Hf;
+    out[SLPX_INFO_OFF_HC] = st.off_Hc;
+    out[SLPX_INFO_GRAPH_NODES] = static_cast<int64_t>(st.graph_nodes_after);
+    out[SLPX_INFO_NONLINEAR_ROWS] = st.nonlinear_rows;
+    out[SLPX_INFO_TAPE_GLOBAL_TASKS] = static_cast<int64_t>(st.full.global_tasks.size());
+  });
+}
+
+int32_t slpx_system_pattern(const slpx_system* sc, int which, int32_t* colptr, int32_t* rowidx) {
+  auto* s = const_cast<slpx_system*>(sc);
+  const auto& st = s->get().structure();
+  const slpx::CscPattern* pat = nullptr;
+  switch (which) {
+    case 0: pat = &st.g_pat; break;
+    case 1: pat = &st.Ae; break;
+    case 2: pat = &st.Ai; break;
+    case 3: pat = &st.Hf; break;
+    case 4: pat = &st.Hc; break;
+    case 5: pat = &s->get().kkt().lhs; break;
+    default: return -1;
+  }
+  if (colptr) std::copy(pat->colptr.begin(), pat->colptr.end(), colptr);
+  if (rowidx) std::copy(pat->rowidx.begin(), pat->rowidx.end(), rowidx);
+  return pat->nnz();
+}
+int slpx_system_perm(const slpx_system* sc, int32_t* perm) {
+  auto* s = const_cast<slpx_system*>(sc);
+  const auto& l = s->get().ldlt();
+  std::copy(l.perm.begin(), l.perm.end(), perm);
+  return 0;
+}
+
+int slpx_system_set_scaling(slpx_system* s, const double* scales) {
+  return guard([&] {
+    const int ns = s->get().structure().n_scales();
+    s->get().device().set_scaling(std::vector<double>(scales, scales + ns));
+  });
+}
+int slpx_system_set_state(slpx_system* s, const double* x, const double* sl, const double* y,
+                          const double* z, const double* mu) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    const auto& st = s->get().structure();
+    if (x) dev.upload_x(x);
+    if (sl || y || z) {
+      // upload_duals wants all three; fetch missing ones from the device
+      const size_t B = dev.batch();
+      std::vector<double> hs(B * std::max(1, st.m_i)), hy(B * std::max(1, st.m_e)), hz(B * std::max(1, st.m_i));
+      if (!sl && st.m_i) dev.download(dev.d_s(), hs.data(), B * st.m_i);
+      if (!y && st.m_e) dev.download(dev.d_y(), hy.data(), B * st.m_e);
+      if (!z && st.m_i) dev.download(dev.d_z(), hz.data(), B * st.m_i);
+      dev.upload_duals(sl ? sl : hs.data(), y ? y : hy.data(), z ? z : hz.data());
+      SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+    }
+    if (mu) dev.upload_mu(mu);
+    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  });
+}
+
+int slpx_tape_sweep(slpx_system* s, int full) {
+  return guard([&] {
+    if (full) s->get().device().sweep_full();
+    else s->get().device().sweep_values();
+  });
+}
+int slpx_kkt_assemble(slpx_system* s) { return guard([&] { s->get().device().assemble(); }); }
+int slpx_kkt_rhs(slpx_system* s) { return guard([&] { s->get().device().build_rhs(); }); }
+
+int slpx_ldlt_factor(slpx_system* s, const double* delta, const double* gamma, double* stats) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    const int B = dev.batch();
+    std::vector<double> d(delta, delta + B), g(gamma, gamma + B);
+    std::vector<uint8_t> active(B, 1);
+    dev.factor(d, g, active);
+    std::vector<slpx::LdltStats> st;
+    dev.read_stats(st);
+    for (int b = 0; b < B; ++b) {
+      stats[5 * b + 0] = st[b].n_pos;
+      stats[5 * b + 1] = st[b].n_neg;
+      stats[5 * b + 2] = st[b].n_zero;
+      stats[5 * b + 3] = st[b].n_bad;
+      double m;
+      std::memcpy(&m, &st[b].min_abs_bits, sizeof(m));
+      stats[5 * b + 4] = m;
+    }
+  });
+}
+int slpx_ldlt_compute(slpx_system* s, int32_t* info, double* reg, int32_t* factorizations) {
+  return guard([&] {
+    auto res = s->get().compute();
+    const int B = s->get().batch();
+    for (int b = 0; b < B; ++b) {
+      if (info) info[b] = static_cast<int32_t>(res[b]);
+      if (reg) {
+        reg[2 * b] = s->get().hessian_regularization()[b];
+        reg[2 * b + 1] = s->get().constraint_jacobian_regularization()[b];
+      }
+    }
+    if (factorizations) *factorizations = s->get().last_factorizations();
+  });
+}
+int slpx_ldlt_reset(slpx_system* s, double gamma_min) {
+  return guard([&] {
+    s->get().reset_regularization();
+    s->get().set_gamma_min(gamma_min);
+  });
+}
+int slpx_ldlt_solve(slpx_system* s) { return guard([&] { s->get().device().solve(); }); }
+int slpx_step_backsub(slpx_system* s) { return guard([&] { s->get().device().backsub(); }); }
+int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info) {
+  return guard([&] {
+    auto res = s->get().newton_step(refresh_ad != 0);
+    if (info)
+      for (size_t b = 0; b < res.size(); ++b) info[b] = static_cast<int32_t>(res[b]);
+  });
+}
+
+int64_t slpx_system_get(slpx_system* s, int which, double* out) {
+  int64_t count = -1;
+  int rc = guard([&] {
+    auto& dev = s->get().device();
+    const auto& st = s->get().structure();
+    const auto& k = s->get().kkt();
+    const auto& l = s->get().ldlt();
+    const int64_t B = dev.batch();
+    const double* src = nullptr;
+    switch (which) {
+      case 0: src = dev.d_V(); count = B * st.nV; break;
+      case 1: src = dev.d_lhs(); count = B * k.lhs.nnz(); break;
+      case 2: src = dev.d_rhs(); count = B * k.dim; break;
+      case 3: src = dev.d_p(); count = B * k.dim; break;
+      case 4: src = dev.d_ps(); count = B * st.m_i; break;
+      case 5: src = dev.d_pz(); count = B * st.m_i; break;
+      case 6: src = dev.d_D(); count = B * l.n; break;
+      case 7: src = dev.d_Lx(); count = B * l.nnzL; break;
+      default: throw std::runtime_error("slpx_system_get: bad selector");
+    }
+    if (out && count > 0) dev.download(src, out, static_cast<size_t>(count));
+  });
+  return rc == 0 ? count : rc;
+}
+int slpx_system_set_rhs(slpx_system* s, const double* rhs) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    const size_t count = static_cast<size_t>(dev.batch()) * s->get().kkt().dim;
+    SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs, count * sizeof(double), hipMemcpyHostToDevice, dev.stream()));
+    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  });
+}
+
+int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) {
+  return guard([&] {
+    auto& sys = s->get();
+    auto& dev = sys.device();
+    hipStream_t st = dev.stream();
+    hipEvent_t ev[7];
+    for (auto& e : ev) SLPX_HIP_CHECK(hipEventCreate(&e));
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    double nfact = 0;
+    for (int it = 0; it < iters; ++it) {
+      SLPX_HIP_CHECK(hipEventRecord(ev[0], st));
+      if (refresh_ad) dev.sweep_full();
+      SLPX_HIP_CHECK(hipEventRecord(ev[1], st));
+      dev.assemble();
+      SLPX_HIP_CHECK(hipEventRecord(ev[2], st));
+      dev.build_rhs();
+      SLPX_HIP_CHECK(hipEventRecord(ev[3], st));
+      sys.compute();
+      nfact += sys.last_factorizations();
+      SLPX_HIP_CHECK(hipEventRecord(ev[4], st));
+      dev.solve();
+      SLPX_HIP_CHECK(hipEventRecord(ev[5], st));
+      dev.backsub();
+      SLPX_HIP_CHECK(hipEventRecord(ev[6], st));
+      SLPX_HIP_CHECK(hipEventSynchronize(ev[6]));
+      for (int k = 0; k < 6; ++k) {
+        float t = 0;
+        SLPX_HIP_CHECK(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+        acc[k] += t;
+      }
+      float t = 0;
+      SLPX_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[6]));
+      acc[6] += t;
+    }
+    for (int k = 0; k < 7; ++k) ms[k] = static_cast<float>(acc[k] / iters);
+    ms[7] = static_cast<float>(nfact / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  });
+}
+
+}  // extern "C"

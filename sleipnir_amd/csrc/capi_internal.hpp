@@ -1,0 +1,19 @@
+// Definitions behind the opaque handles of include/slpx.h (shared with the
+// test-only host checker in tests/support/).
+#pragma once
+
+#include <memory>
+
+#include "newton.hpp"
+#include "slp/problem.hpp"
+
+struct slpx_problem {
+  slp::Problem problem;
+  double t_compile = 0.0;
+};
+
+struct slpx_system {
+  std::unique_ptr<slpx::NewtonSystem> sys;
+  slpx::NewtonSystem* ref = nullptr;
+  slpx::NewtonSystem& get() { return *ref; }
+};

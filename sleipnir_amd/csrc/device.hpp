@@ -1,0 +1,234 @@
+// Device-side state of one compiled NLP on one MI355X: uploaded plans, per-batch
+// value buffers, and launchers for the hot-path kernels (kernels.hip).
+//
+// Batch-major layout everywhere: buffer[b * stride + i], b = problem in the batch.
+// All problems of a batch share one structure (tape, KKT plan, symbolic LDLᵀ) and
+// differ only in values — the reference's analogue is multistart's one-thread-per-
+// solve fan-out (include/sleipnir/optimization/multistart.hpp:52-62).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kkt_plan.hpp"
+#include "ldlt_symbolic.hpp"
+#include "nlp.hpp"
+
+namespace slpx {
+
+#define SLPX_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t err__ = (expr);                                                            \
+    if (err__ != hipSuccess)                                                              \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(err__) +   \
+                               " at " #expr);                                             \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) SLPX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+  }
+  void upload(const std::vector<T>& h) {
+    alloc(h.size());
+    if (!h.empty()) SLPX_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void zero(hipStream_t s = nullptr) {
+    if (n) SLPX_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+};
+
+// Pointers handed to the tape kernel by value
+struct TapeDev {
+  const TapeTask* tasks;
+  const uint32_t* leaf_src;
+  const double* consts;
+  const uint32_t* node_rec;
+  const uint32_t* lvl_ptr;
+  const uint32_t* slot_edge_ptr;
+  const uint32_t* slvl_ptr;
+  const TapeEdge* edges;
+  const uint32_t* vout_src;
+  const uint32_t* vout_dst;
+  const int32_t* vout_scale;
+  const uint32_t* jout_slot;
+  const uint32_t* jout_dst;
+  const int32_t* jout_scale;
+};
+
+struct TapeDevice {
+  DevBuf<TapeTask> tasks;
+  DevBuf<uint32_t> small_list, large_list, global_list;
+  DevBuf<uint32_t> leaf_src, node_rec, lvl_ptr, slot_edge_ptr, slvl_ptr, vout_src, vout_dst,
+      jout_slot, jout_dst;
+  DevBuf<int32_t> vout_scale, jout_scale;
+  DevBuf<double> consts;
+  DevBuf<TapeEdge> edges;
+  uint32_t n_small = 0, n_large = 0, n_global = 0;
+  uint32_t small_lds = 0, large_lds = 0;
+  uint64_t scratch_doubles = 0;
+  void upload(const TapeProgram& p);
+  TapeDev view() const;
+};
+
+struct LdltDev {
+  const LdltTask* tasks;
+  const int32_t* ent_src;
+  const uint8_t* ent_flags;
+  const uint16_t* ent_col;
+  const uint32_t* ent_out;
+  const uint32_t* ent_pair_ptr;
+  const uint32_t* ent_contrib_ptr;
+  const uint32_t* contrib_idx;
+  const uint32_t* ext_dst;
+  const uint32_t* lvl_ptr;
+  const LdltPair* pairs;
+  const uint32_t* col_perm;
+  const uint32_t* col_lvl_ptr;
+  const uint32_t* fwd_ptr;
+  const uint32_t* fwd_contrib_ptr;
+  const uint32_t* scontrib_idx;
+  const LdltSolveItem* fwd_items;
+  const uint32_t* sext_ptr;
+  const uint32_t* sext_dst;
+  const LdltSolveItem* sext_items;
+  const uint32_t* bwd_ptr;
+  const LdltSolveItem* bwd_items;
+  const int32_t* perm;
+};
+
+struct LdltStats {   // one per batch item, written by the factor kernels
+  int32_t n_pos, n_neg, n_zero, n_bad;  // n_bad: exactly-zero or non-finite pivots
+  unsigned long long min_abs_bits;      // bit pattern of min |D| (non-negative doubles order like integers)
+};
+
+struct KktDev {
+  int n, m_e, m_i, dim, nnz_lhs;
+  const int32_t* dptr;
+  const int32_t* dsrc;
+  const int32_t* pptr;
+  const int32_t* pa;
+  const int32_t* pb;
+  const int32_t* pr;
+  const int32_t* g_src;
+  const int32_t* ae_colptr;
+  const int32_t* ae_rowidx;
+  const int32_t* ai_colptr;
+  const int32_t* ai_rowidx;
+  const int32_t* ai_rowptr;
+  const int32_t* ai_col;
+  const int32_t* ai_src;
+  int off_f, off_ce, off_ci, off_g, off_Ae, off_Ai;
+};
+
+struct StepTimings {
+  float sweep = 0, assemble = 0, rhs = 0, factor = 0, solve = 0, backsub = 0, total = 0;
+};
+
+class DeviceNlp {
+ public:
+  DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l, int batch, int device);
+  ~DeviceNlp();
+
+  int batch() const { return m_batch; }
+  void set_stream(hipStream_t s) { m_stream = s; }
+  hipStream_t stream() const { return m_stream; }
+
+  // scaling vectors: scales = [d_f, d_ce.., d_ci..]; applied to tape outputs, and
+  // d_ce / d_ci also scale the dual inputs (problem.hpp:631-634).  Re-derives the
+  // static part of V.
+  void set_scaling(const std::vector<double>& scales);
+
+  // state upload/download (host pointers, batch-major)
+  void upload_x(const double* x);
+  void upload_duals(const double* s, const double* y, const double* z);
+  void upload_mu(const double* mu);  // one per batch item
+  void download_V(double* V);
+  void download(const double* dev, double* host, size_t count);
+
+  // hot path (all asynchronous on stream())
+  void sweep_full();    // f, c_e, c_i, g, A_e, A_i, H_f, H_c  -> V
+  void sweep_values();  // f, c_e, c_i only                   -> V
+  void assemble();      // V, s, z -> lhs
+  void build_rhs();     // V, s, y, z, mu -> rhs
+  // lhs -> L, D, stats; per-problem (δ, γ), problems with active[b] == 0 are skipped
+  void factor(const std::vector<double>& delta, const std::vector<double>& gamma,
+              const std::vector<uint8_t>& active);
+  void read_stats(std::vector<LdltStats>& out);     // synchronizes
+  void solve();                                     // rhs -> p (dim per batch item)
+  void backsub();                                   // p -> p_x, p_y, p_s, p_z
+
+  // device pointers for callers that keep everything resident
+  double* d_x() { return m_in.p; }
+  double* d_V() { return m_V.p; }
+  double* d_s() { return m_s.p; }
+  double* d_y() { return m_y.p; }
+  double* d_z() { return m_z.p; }
+  double* d_mu() { return m_mu.p; }
+  double* d_lhs() { return m_lhs.p; }
+  double* d_rhs() { return m_rhs.p; }
+  double* d_p() { return m_p.p; }
+  double* d_ps() { return m_ps.p; }
+  double* d_pz() { return m_pz.p; }
+  double* d_D() { return m_D.p; }
+  double* d_Lx() { return m_Lx.p; }
+  int in_stride() const { return m_s_ref.n_inputs(); }
+  int v_stride() const { return m_s_ref.nV; }
+
+  const NlpStructure& structure() const { return m_s_ref; }
+  const KktPlan& kkt() const { return m_k_ref; }
+  const LdltPlan& ldlt() const { return m_l_ref; }
+
+ private:
+  void launch_tape(const TapeDevice& t, bool reverse);
+
+  const NlpStructure& m_s_ref;
+  const KktPlan& m_k_ref;
+  const LdltPlan& m_l_ref;
+  int m_batch;
+  int m_device;
+  hipStream_t m_stream = nullptr;
+
+  TapeDevice m_full, m_values;
+  // KKT plan
+  DevBuf<int32_t> m_dptr, m_dsrc, m_pptr, m_pa, m_pb, m_pr, m_gsrc, m_ae_colptr, m_ae_rowidx,
+      m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src;
+  KktDev m_kdev{};
+  // LDLT plan
+  DevBuf<LdltTask> m_ltasks;
+  DevBuf<int32_t> m_ent_src, m_perm;
+  DevBuf<uint8_t> m_ent_flags;
+  DevBuf<uint16_t> m_ent_col;
+  DevBuf<uint32_t> m_ent_out, m_ent_pair_ptr, m_ent_contrib_ptr, m_contrib_idx, m_ext_dst, m_llvl_ptr,
+      m_col_perm, m_col_lvl_ptr, m_fwd_ptr, m_fwd_contrib_ptr, m_scontrib_idx, m_sext_ptr,
+      m_sext_dst, m_bwd_ptr;
+  DevBuf<LdltPair> m_pairs;
+  DevBuf<LdltSolveItem> m_fwd_items, m_sext_items, m_bwd_items;
+  LdltDev m_ldev{};
+  // per-batch values
+  DevBuf<double> m_in, m_in_scale, m_scales, m_V, m_s, m_y, m_z, m_mu, m_lhs, m_rhs, m_p, m_ps,
+      m_pz, m_D, m_Lx, m_contrib, m_scontrib, m_zv, m_xg, m_scratch;
+  DevBuf<LdltStats> m_stats;
+  DevBuf<double> m_reg;
+  DevBuf<uint8_t> m_active;
+  std::vector<double> m_V_static;  // scaled static values (host copy)
+};
+
+}  // namespace slpx

@@ -1,0 +1,557 @@
+#include "ipm.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace slpx {
+
+namespace {
+
+using Vec = std::vector<double>;
+using clk = std::chrono::steady_clock;
+
+double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+double norm_inf(const double* v, int n) {
+  double m = 0.0;
+  for (int i = 0; i < n; ++i) m = std::max(m, std::abs(v[i]));
+  return m;
+}
+double norm_1(const double* v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += std::abs(v[i]);
+  return s;
+}
+bool all_finite(const double* v, int n) {
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) return false;
+  return true;
+}
+
+// out += scale_rows(A)ᵀ v  with A in CSC over `vals`; row_scale may be null
+void add_At_v(const CscPattern& A, const double* vals, const double* row_scale, const double* v,
+              double sign, Vec& out) {
+  for (int c = 0; c < A.cols; ++c) {
+    double acc = 0.0;
+    for (int p = A.colptr[c]; p < A.colptr[c + 1]; ++p) {
+      const int r = A.rowidx[p];
+      acc += (row_scale ? row_scale[r] * vals[p] : vals[p]) * v[r];
+    }
+    out[c] += sign * acc;
+  }
+}
+
+enum class ErrType { INF_NORM_SCALED, ONE_NORM };
+
+// Views into one downloaded V (see nlp.hpp for the layout)
+struct VView {
+  const NlpStructure& s;
+  const Vec& V;
+  double f() const { return V[s.off_f]; }
+  const double* c_e() const { return V.data() + s.off_ce; }
+  const double* c_i() const { return V.data() + s.off_ci; }
+  const double* Ae() const { return V.data() + s.off_Ae; }
+  const double* Ai() const { return V.data() + s.off_Ai; }
+  Vec g_dense() const {
+    Vec g(s.n, 0.0);
+    for (int c = 0; c < s.n; ++c)
+      for (int p = s.g_pat.colptr[c]; p < s.g_pat.colptr[c + 1]; ++p) g[c] += V[s.off_g + p];
+    return g;
+  }
+};
+
+// util/kkt_error.hpp:92-146.  `inv` = optional un-scaling (kkt_error.hpp:216-251):
+// inv_f multiplies g, inv_ce/inv_ci multiply the rows of A_e/A_i and c_e/c_i/s,
+// and y, z are replaced by d_c∘y·inv_f, d_c∘z·inv_f, μ by inv_f·μ.
+template <ErrType T>
+double kkt_error_impl(const NlpStructure& st, const Vec& g, const double* Ae, const double* c_e,
+                      const double* Ai, const double* c_i, const Vec& s, const Vec& y, const Vec& z,
+                      double mu, const Vec* scales) {
+  const int n = st.n, m_e = st.m_e, m_i = st.m_i;
+  const bool unscale = scales != nullptr;
+  const double inv_f = unscale ? 1.0 / (*scales)[0] : 1.0;
+  Vec inv_ce, inv_ci, yu(y), zu(z), su(s), ceu(m_e), ciu(m_i);
+  if (unscale) {
+    inv_ce.resize(m_e);
+    inv_ci.resize(m_i);
+    for (int j = 0; j < m_e; ++j) inv_ce[j] = 1.0 / (*scales)[1 + j];
+    for (int j = 0; j < m_i; ++j) inv_ci[j] = 1.0 / (*scales)[1 + m_e + j];
+    for (int j = 0; j < m_e; ++j) yu[j] = (*scales)[1 + j] * y[j] * inv_f;
+    for (int j = 0; j < m_i; ++j) zu[j] = (*scales)[1 + m_e + j] * z[j] * inv_f;
+    for (int j = 0; j < m_i; ++j) su[j] = inv_ci[j] * s[j];
+  }
+  for (int j = 0; j < m_e; ++j) ceu[j] = unscale ? inv_ce[j] * c_e[j] : c_e[j];
+  for (int j = 0; j < m_i; ++j) ciu[j] = unscale ? inv_ci[j] * c_i[j] : c_i[j];
+  const double muu = inv_f * mu;
+  Vec dual(n);
+  for (int i = 0; i < n; ++i) dual[i] = inv_f * g[i];
+  add_At_v(st.Ae, Ae, unscale ? inv_ce.data() : nullptr, yu.data(), -1.0, dual);
+  add_At_v(st.Ai, Ai, unscale ? inv_ci.data() : nullptr, zu.data(), -1.0, dual);
+  Vec comp(m_i), cis(m_i);
+  for (int j = 0; j < m_i; ++j) {
+    comp[j] = su[j] * zu[j] - muu;
+    cis[j] = ciu[j] - su[j];
+  }
+  if constexpr (T == ErrType::INF_NORM_SCALED) {
+    constexpr double s_max = 100.0;
+    const double s_d =
+        std::max(s_max, (norm_1(yu.data(), m_e) + norm_1(zu.data(), m_i)) / double(m_e + m_i)) / s_max;
+    const double s_c = std::max(s_max, norm_1(zu.data(), m_i) / double(m_i)) / s_max;
+    return std::max({norm_inf(dual.data(), n) / s_d, norm_inf(comp.data(), m_i) / s_c,
+                     norm_inf(ceu.data(), m_e), norm_inf(cis.data(), m_i)});
+  } else {
+    return norm_1(dual.data(), n) + norm_1(comp.data(), m_i) + norm_1(ceu.data(), m_e) +
+           norm_1(cis.data(), m_i);
+  }
+}
+
+bool scaling_is_identity(const NlpStructure& st, const Vec& scales) {
+  // problem_scaling.hpp:111-113
+  return scales[0] == 1.0 && st.m_e == 0 && st.m_i == 0;
+}
+
+// filter.hpp:17-212
+struct FilterEntry {
+  double cost = 0.0, constraint_violation = 0.0;
+  FilterEntry() = default;
+  FilterEntry(double c, double v) : cost(c), constraint_violation(v) {}
+  FilterEntry(double f, const Vec& s, const double* c_e, int m_e, const double* c_i, double mu) {
+    double logsum = 0.0, viol = norm_1(c_e, m_e);
+    for (size_t j = 0; j < s.size(); ++j) {
+      logsum += std::log(s[j]);
+      viol += std::abs(c_i[j] - s[j]);
+    }
+    cost = f - mu * logsum;
+    constraint_violation = viol;
+  }
+  bool dominated_by(const FilterEntry& e) const {
+    return e.cost <= cost && e.constraint_violation <= constraint_violation;
+  }
+};
+
+class Filter {
+ public:
+  double min_constraint_violation, max_constraint_violation;
+  explicit Filter(double initial) {
+    min_constraint_violation = 1e-4 * std::max(1.0, initial);
+    max_constraint_violation = 1e4 * std::max(1.0, initial);
+  }
+  void reset() {
+    m_filter.clear();
+    m_last_rejection_due_to_filter = false;
+  }
+  bool try_add(const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha) {
+    if (!std::isfinite(trial.cost) || trial.constraint_violation > max_constraint_violation) return false;
+    const bool switching = D_phi < 0.0 && alpha * std::pow(-D_phi, 2.3) > std::pow(cur.constraint_violation, 1.1);
+    const bool armijo = trial.cost <= cur.cost + 1e-8 * alpha * D_phi;
+    const double phi = std::pow(alpha, 1.5);
+    const bool sufficient = trial.cost <= cur.cost - phi * kGammaCost * cur.constraint_violation ||
+                            trial.constraint_violation <= (1.0 - phi * kGammaCon) * cur.constraint_violation;
+    if (cur.constraint_violation <= min_constraint_violation && switching) {
+      if (!armijo) {
+        m_last_rejection_due_to_filter = false;
+        return false;
+      }
+    } else if (!sufficient) {
+      m_last_rejection_due_to_filter = false;
+      return false;
+    }
+    for (auto& e : m_filter)
+      if (trial.dominated_by(e)) {
+        m_last_rejection_due_to_filter = true;
+        return false;
+      }
+    if (!switching || !armijo) {
+      FilterEntry add{cur.cost - phi * kGammaCost * cur.constraint_violation,
+                      (1.0 - phi * kGammaCon) * cur.constraint_violation};
+      m_filter.erase(std::remove_if(m_filter.begin(), m_filter.end(),
+                                    [&](const FilterEntry& e) { return e.dominated_by(add); }),
+                     m_filter.end());
+      m_filter.push_back(add);
+    }
+    return true;
+  }
+  bool last_rejection_due_to_filter() const { return m_last_rejection_due_to_filter; }
+
+ private:
+  static constexpr double kGammaCost = 1e-8, kGammaCon = 1e-5;
+  std::vector<FilterEntry> m_filter;
+  bool m_last_rejection_due_to_filter = false;
+};
+
+// fraction_to_the_boundary_rule.hpp:19-43
+double ftb(const Vec& x, const Vec& p, double tau) {
+  double alpha = 1.0;
+  for (size_t i = 0; i < x.size(); ++i)
+    if (alpha * p[i] < -tau * x[i]) alpha = -tau / p[i] * x[i];
+  return alpha;
+}
+
+Vec axpy(const Vec& a, double alpha, const Vec& b) {
+  Vec r(a.size());
+  for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] + alpha * b[i];
+  return r;
+}
+
+}  // namespace
+
+std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::vector<double>& V) {
+  constexpr double g_max = 100.0;
+  std::vector<double> scales(s.n_scales(), 1.0);
+  double gn = 0.0;
+  for (int p = 0; p < s.g_pat.nnz(); ++p) gn = std::max(gn, std::abs(V[s.off_g + p]));
+  scales[0] = std::min(1.0, g_max / gn);
+  std::vector<double> rn(s.m_e, 0.0);
+  for (int p = 0; p < s.Ae.nnz(); ++p) rn[s.Ae.rowidx[p]] = std::max(rn[s.Ae.rowidx[p]], std::abs(V[s.off_Ae + p]));
+  for (int j = 0; j < s.m_e; ++j) scales[1 + j] = std::min(g_max / rn[j], 1.0);
+  rn.assign(s.m_i, 0.0);
+  for (int p = 0; p < s.Ai.nnz(); ++p) rn[s.Ai.rowidx[p]] = std::max(rn[s.Ai.rowidx[p]], std::abs(V[s.off_Ai + p]));
+  for (int j = 0; j < s.m_i; ++j) scales[1 + s.m_e + j] = std::min(g_max / rn[j], 1.0);
+  return scales;
+}
+
+ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
+                          const std::vector<IterationCallback>& callbacks, const Options& options,
+                          std::vector<double>& x, std::vector<double>* s_out,
+                          std::vector<double>* y_out, std::vector<double>* z_out,
+                          SolveReport* report) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
+  const auto solve_start = clk::now();
+  SolveReport local;
+  SolveReport& rep = report ? *report : local;
+  rep = SolveReport{};
+
+  // interior_point.hpp:74-79
+  Vec s(m_i, 1.0), y(m_e, 0.0), z(m_i, 1.0);
+  double mu = 0.1 * scales[0];
+  int iterations = 0;
+  auto finish = [&](ExitStatus st_) {
+    if (s_out) *s_out = s;
+    if (y_out) *y_out = y;
+    if (z_out) *z_out = z;
+    rep.iterations = iterations;
+    rep.t_total = since(solve_start);
+    return st_;
+  };
+
+  sys.reset_regularization();
+  sys.set_gamma_min(1e-10);  // :350-352 (not in restoration)
+
+  Vec V(st.nV), Vtrial(st.nV);
+  auto refresh_full = [&](const Vec& xx, const Vec& yy, const Vec& zz) {
+    dev.upload_x(xx.data());
+    dev.upload_duals(s.data(), yy.data(), zz.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+  };
+  // forward-only sweep at a trial point; fills the f, c_e, c_i head of Vtrial
+  auto eval_values = [&](const Vec& xx) {
+    dev.upload_x(xx.data());
+    dev.sweep_values();
+    dev.download(dev.d_V(), Vtrial.data(), static_cast<size_t>(st.off_g));
+    ++rep.value_sweeps;
+  };
+
+  auto t_setup = clk::now();
+  refresh_full(x, y, z);  // :245-251
+  VView cur{st, V};
+  Vec g = cur.g_dense();
+
+  if (m_e > n) return finish(ExitStatus::TOO_FEW_DOFS);  // :274
+  if (!all_finite(V.data(), st.nV)) return finish(ExitStatus::NONFINITE_INITIAL_GUESS);  // :283-286
+
+  const double mu_min = scales[0] * options.tolerance / 10.0;  // :294
+  constexpr double tau_min = 0.99;
+  double tau = tau_min;
+
+  double f = cur.f();
+  Vec c_e(cur.c_e(), cur.c_e() + m_e), c_i(cur.c_i(), cur.c_i() + m_i);
+
+  auto violation = [&](const Vec& ce, const Vec& ci, const Vec& ss) {
+    double v = norm_1(ce.data(), m_e);
+    for (int j = 0; j < m_i; ++j) v += std::abs(ci[j] - ss[j]);
+    return v;
+  };
+  Filter filter{violation(c_e, c_i, s)};  // :303
+
+  auto update_barrier = [&] {  // :308-333
+    mu = std::max(mu_min, std::min(0.2 * mu, std::pow(mu, 1.5)));
+    tau = std::max(tau_min, 1.0 - mu);
+    filter.reset();
+  };
+
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-7;
+  int full_step_rejected_counter = 0;
+  const bool identity = scaling_is_identity(st, scales);
+  auto E0_of = [&](const Vec& gg, const Vec& ce, const Vec& ci, const Vec& ss, const Vec& yy,
+                   const Vec& zz) {
+    return kkt_error_impl<ErrType::INF_NORM_SCALED>(st, gg, cur.Ae(), ce.data(), cur.Ai(),
+                                                    ci.data(), ss, yy, zz, 0.0,
+                                                    identity ? nullptr : &scales);
+  };
+  double E_0 = E0_of(g, c_e, c_i, s, y, z);  // :361-362
+  rep.t_setup = since(t_setup);
+
+  Vec p(dim), p_x(n), p_y(m_e), p_s(m_i), p_z(m_i);
+  Vec trial_x, trial_s, trial_y, trial_z, trial_c_e(m_e), trial_c_i(m_i);
+  double trial_f = 0.0;
+
+  while (E_0 > options.tolerance) {
+    // :387-408 infeasibility / divergence checks
+    if (m_e > 0) {
+      Vec t(n, 0.0);
+      add_At_v(st.Ae, cur.Ae(), nullptr, c_e.data(), 1.0, t);
+      double nt = 0.0, nc = 0.0;
+      for (double v : t) nt += v * v;
+      for (double v : c_e) nc += v * v;
+      if (std::sqrt(nt) < 1e-6 && std::sqrt(nc) > 1e-2) return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    }
+    if (m_i > 0) {
+      Vec cplus(m_i), t(n, 0.0);
+      for (int j = 0; j < m_i; ++j) cplus[j] = std::min(c_i[j], 0.0);
+      add_At_v(st.Ai, cur.Ai(), nullptr, cplus.data(), 1.0, t);
+      double nt = 0.0, nc = 0.0;
+      for (double v : t) nt += v * v;
+      for (double v : cplus) nc += v * v;
+      if (std::sqrt(nt) < 1e-6 && std::sqrt(nc) > 1e-6) return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    }
+    if (norm_inf(x.data(), n) > 1e10 || !all_finite(x.data(), n) || norm_inf(s.data(), m_i) > 1e10 ||
+        !all_finite(s.data(), m_i))
+      return finish(ExitStatus::DIVERGING_ITERATES);
+
+    for (const auto& cb : callbacks)
+      if (cb({iterations, x, s, y, z, V})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+
+    // ---- Newton step on the device (:426-482) ----
+    auto t0 = clk::now();
+    dev.upload_x(x.data());
+    dev.upload_duals(s.data(), y.data(), z.data());
+    dev.upload_mu(&mu);
+    dev.assemble();
+    dev.build_rhs();
+    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+    rep.t_kkt_build += since(t0);
+    t0 = clk::now();
+    auto info = sys.compute();
+    rep.factorizations += sys.last_factorizations();
+    rep.t_kkt_decomp += since(t0);
+    if (info[0] != FactorInfo::Success) return finish(ExitStatus::FACTORIZATION_FAILED);  // :463-465
+    rep.delta = sys.hessian_regularization()[0];
+    rep.gamma = sys.constraint_jacobian_regularization()[0];
+
+    auto download_step = [&](Vec& px, Vec& py, Vec& ps, Vec& pz) {
+      dev.download(dev.d_p(), p.data(), dim);
+      std::copy(p.begin(), p.begin() + n, px.begin());
+      for (int j = 0; j < m_e; ++j) py[j] = -p[n + j];
+      if (m_i) {
+        dev.download(dev.d_ps(), ps.data(), m_i);
+        dev.download(dev.d_pz(), pz.data(), m_i);
+      }
+    };
+    t0 = clk::now();
+    dev.solve();
+    dev.backsub();
+    ++rep.solves;
+    download_step(p_x, p_y, p_s, p_z);
+    rep.t_kkt_solve += since(t0);
+
+    t0 = clk::now();
+    double alpha_max = ftb(s, p_s, tau);  // :488
+    double alpha = alpha_max;
+    bool call_feasibility_restoration = alpha < alpha_min;
+    double alpha_z = ftb(z, p_z, tau);  // :497
+
+    const FilterEntry current_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+    double D_phi = 0.0;  // :508-509
+    for (int i = 0; i < n; ++i) D_phi += g[i] * p_x[i];
+    {
+      double t = 0.0;
+      for (int j = 0; j < m_i; ++j) t += (1.0 / s[j]) * p_s[j];
+      D_phi -= mu * t;
+    }
+
+    auto read_trial = [&] {
+      trial_f = Vtrial[st.off_f];
+      std::copy(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e, trial_c_e.begin());
+      std::copy(Vtrial.begin() + st.off_ci, Vtrial.begin() + st.off_ci + m_i, trial_c_i.begin());
+    };
+
+    while (true) {  // :512
+      trial_x = axpy(x, alpha, p_x);
+      eval_values(trial_x);
+      read_trial();
+      bool all_pos = true;
+      for (double v : c_i) all_pos = all_pos && v > 0.0;
+      if (options.feasible_ipm && all_pos) trial_s = trial_c_i;
+      else trial_s = axpy(s, alpha, p_s);
+      trial_y = axpy(y, alpha_z, p_y);
+      trial_z = axpy(z, alpha_z, p_z);
+
+      if (!std::isfinite(trial_f) || !all_finite(trial_c_e.data(), m_e) ||
+          !all_finite(trial_c_i.data(), m_i)) {
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) {
+          call_feasibility_restoration = true;
+          break;
+        }
+        continue;
+      }
+
+      FilterEntry trial_entry{trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu};
+      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
+
+      const double prev_violation = violation(c_e, c_i, s);
+      double next_violation = violation(trial_c_e, trial_c_i, trial_s);
+
+      // second-order corrections (:566-668): new rhs, SAME factorization
+      if (alpha == alpha_max && next_violation >= prev_violation) {
+        Vec soc_px = p_x, soc_ps = p_s, soc_py = p_y, soc_pz = p_z;
+        double alpha_soc = alpha, alpha_z_soc = alpha_z;
+        Vec c_e_soc = c_e, cims_soc(m_i);
+        for (int j = 0; j < m_i; ++j) cims_soc[j] = c_i[j] - s[j];
+        double soc_violation = next_violation;
+        bool step_acceptable = false;
+        for (int it = 0; it < 5 && !step_acceptable; ++it) {
+          for (int j = 0; j < m_e; ++j) c_e_soc[j] = alpha_soc * c_e_soc[j] + trial_c_e[j];
+          for (int j = 0; j < m_i; ++j) cims_soc[j] = alpha_soc * cims_soc[j] + trial_c_i[j] - trial_s[j];
+          // rhs (:613-616) is O(nnz(A)) host work on the downloaded Jacobians
+          Vec rhs(dim, 0.0);
+          {
+            Vec t(m_i);
+            for (int j = 0; j < m_i; ++j) {
+              const double sinv = 1.0 / s[j];
+              t[j] = mu * sinv - (sinv * z[j]) * cims_soc[j];
+            }
+            for (int i = 0; i < n; ++i) rhs[i] = -g[i];
+            add_At_v(st.Ae, cur.Ae(), nullptr, y.data(), 1.0, rhs);
+            add_At_v(st.Ai, cur.Ai(), nullptr, t.data(), 1.0, rhs);
+            for (int j = 0; j < m_e; ++j) rhs[n + j] = -c_e_soc[j];
+          }
+          SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs.data(), dim * sizeof(double),
+                                        hipMemcpyHostToDevice, dev.stream()));
+          dev.solve();
+          ++rep.solves;
+          dev.download(dev.d_p(), p.data(), dim);
+          std::copy(p.begin(), p.begin() + n, soc_px.begin());
+          for (int j = 0; j < m_e; ++j) soc_py[j] = -p[n + j];
+          {  // p_s, p_z with the corrected c_i - s (:479-480)
+            Vec aipx(m_i, 0.0);
+            for (int c = 0; c < n; ++c)
+              for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q)
+                aipx[st.Ai.rowidx[q]] += cur.Ai()[q] * soc_px[c];
+            for (int j = 0; j < m_i; ++j) {
+              const double sinv = 1.0 / s[j];
+              soc_ps[j] = cims_soc[j] + aipx[j];
+              soc_pz[j] = mu * sinv - z[j] - (sinv * z[j]) * soc_ps[j];
+            }
+          }
+          alpha_soc = ftb(s, soc_ps, tau);
+          alpha_z_soc = ftb(z, soc_pz, tau);
+          trial_x = axpy(x, alpha_soc, soc_px);
+          trial_s = axpy(s, alpha_soc, soc_ps);
+          trial_y = axpy(y, alpha_z_soc, soc_py);
+          trial_z = axpy(z, alpha_z_soc, soc_pz);
+          eval_values(trial_x);
+          read_trial();
+          FilterEntry soc_entry{trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu};
+          if (filter.try_add(current_entry, soc_entry, D_phi, alpha)) {
+            p_x = soc_px;
+            p_s = soc_ps;
+            p_y = soc_py;
+            p_z = soc_pz;
+            alpha = alpha_soc;
+            alpha_z = alpha_z_soc;
+            step_acceptable = true;
+            break;
+          }
+          next_violation = violation(trial_c_e, trial_c_i, trial_s);
+          if (next_violation > 0.99 * soc_violation) break;
+          soc_violation = next_violation;
+        }
+        if (step_acceptable) break;
+      }
+
+      if (alpha == alpha_max) ++full_step_rejected_counter;
+      // :677-684
+      if (full_step_rejected_counter >= 4 &&
+          filter.max_constraint_violation > current_entry.constraint_violation / 10.0 &&
+          filter.last_rejection_due_to_filter()) {
+        filter.max_constraint_violation *= 0.1;
+        filter.reset();
+        continue;
+      }
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {  // :691-716
+        const double current_kkt = kkt_error_impl<ErrType::ONE_NORM>(
+            st, g, cur.Ae(), c_e.data(), cur.Ai(), c_i.data(), s, y, z, mu, nullptr);
+        trial_x = axpy(x, alpha_max, p_x);
+        trial_s = axpy(s, alpha_max, p_s);
+        trial_y = axpy(y, alpha_z, p_y);
+        trial_z = axpy(z, alpha_z, p_z);
+        // needs g, A_e, A_i at the trial point: full sweep into a scratch copy
+        Vec Vkeep = V;
+        refresh_full(trial_x, trial_y, trial_z);
+        Vec Vt = V;
+        V = Vkeep;
+        VView tv{st, Vt};
+        trial_f = tv.f();
+        std::copy(tv.c_e(), tv.c_e() + m_e, trial_c_e.begin());
+        std::copy(tv.c_i(), tv.c_i() + m_i, trial_c_i.begin());
+        const double next_kkt = kkt_error_impl<ErrType::ONE_NORM>(
+            st, tv.g_dense(), tv.Ae(), trial_c_e.data(), tv.Ai(), trial_c_i.data(), trial_s,
+            trial_y, trial_z, mu, nullptr);
+        if (next_kkt <= 0.999 * current_kkt) break;
+        call_feasibility_restoration = true;
+        break;
+      }
+    }
+    rep.t_line_search += since(t0);
+
+    if (call_feasibility_restoration) {
+      // util/feasibility_restoration.hpp is SURVEY.md §8(f) row N3 — not built yet
+      return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
+    }
+    if (alpha == alpha_max) full_step_rejected_counter = 0;
+    x = trial_x;
+    s = trial_s;
+    y = trial_y;
+    z = trial_z;
+    for (int j = 0; j < m_i; ++j) {  // :797-801
+      constexpr double kappa = 1e10;
+      z[j] = std::clamp(z[j], 1.0 / kappa * mu / s[j], kappa * mu / s[j]);
+    }
+    f = trial_f;
+    c_e = trial_c_e;
+    c_i = trial_c_i;
+
+    // AD refresh (:809-812)
+    t0 = clk::now();
+    refresh_full(x, y, z);
+    g = cur.g_dense();
+    rep.t_ad_refresh += since(t0);
+
+    E_0 = E0_of(g, c_e, c_i, s, y, z);
+    if (E_0 > options.tolerance) {  // :819-832
+      auto E_mu_of = [&] {
+        return kkt_error_impl<ErrType::INF_NORM_SCALED>(st, g, cur.Ae(), c_e.data(), cur.Ai(),
+                                                        c_i.data(), s, y, z, mu, nullptr);
+      };
+      double E_mu = E_mu_of();
+      while (mu > mu_min && E_mu <= 10.0 * mu) {
+        update_barrier();
+        E_mu = E_mu_of();
+      }
+    }
+    ++iterations;
+    rep.final_error = E_0;
+    if (iterations >= options.max_iterations) return finish(ExitStatus::MAX_ITERATIONS_EXCEEDED);
+    if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
+  }
+  rep.final_error = E_0;
+  return finish(ExitStatus::SUCCESS);
+}
+
+}  // namespace slpx

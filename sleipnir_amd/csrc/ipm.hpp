@@ -1,0 +1,81 @@
+// Host driver of the interior-point iteration around the device Newton step.
+//
+// Mirrors include/sleipnir/optimization/solver/interior_point.hpp:63-878 step for
+// step (same constants, same filter line search, same second-order corrections,
+// same barrier update and exits); every O(nnz) piece of the Newton step itself
+// (:426-482, :809-812) runs on the GPU through NewtonSystem.  The O(n) scalar
+// logic between steps (error norms, fraction-to-the-boundary, filter) is still
+// host code on downloaded vectors in this round.
+//
+// Not built yet: feasibility restoration (util/feasibility_restoration.hpp, row
+// N3).  Where the reference would enter restoration this driver returns
+// FEASIBILITY_RESTORATION_FAILED.
+#pragma once
+
+#include <functional>
+#include <limits>
+#include <vector>
+
+#include "newton.hpp"
+
+namespace slpx {
+
+// exit_status.hpp:13-43
+enum class ExitStatus : int {
+  SUCCESS = 0,
+  CALLBACK_REQUESTED_STOP = 1,
+  TOO_FEW_DOFS = -1,
+  LOCALLY_INFEASIBLE = -2,
+  GLOBALLY_INFEASIBLE = -3,
+  FACTORIZATION_FAILED = -4,
+  LINE_SEARCH_FAILED = -5,
+  FEASIBILITY_RESTORATION_FAILED = -6,
+  NONFINITE_INITIAL_GUESS = -7,
+  DIVERGING_ITERATES = -8,
+  MAX_ITERATIONS_EXCEEDED = -9,
+  TIMEOUT = -10,
+};
+
+// options.hpp:13-38
+struct Options {
+  double tolerance = 1e-8;
+  int max_iterations = 5000;
+  double timeout = std::numeric_limits<double>::infinity();  // seconds
+  bool feasible_ipm = false;
+  bool diagnostics = false;
+};
+
+// iteration_info.hpp:13-41 (matrices as value arrays over the static patterns)
+struct IterationInfo {
+  int iteration;
+  const std::vector<double>& x;
+  const std::vector<double>& s;
+  const std::vector<double>& y;
+  const std::vector<double>& z;
+  const std::vector<double>& V;  // [f | c_e | c_i | g | A_e | A_i | H_f | H_c], see nlp.hpp
+};
+using IterationCallback = std::function<bool(const IterationInfo&)>;
+
+struct SolveReport {
+  int iterations = 0;
+  int factorizations = 0;
+  int solves = 0;
+  int value_sweeps = 0;
+  double delta = 0.0, gamma = 0.0;
+  double final_error = 0.0;
+  // wall-clock per phase, seconds (names follow interior_point.hpp:155-174)
+  double t_setup = 0, t_kkt_build = 0, t_kkt_decomp = 0, t_kkt_solve = 0, t_line_search = 0,
+         t_ad_refresh = 0, t_total = 0;
+};
+
+// Scaling at x0 (util/problem_scaling.hpp:100-107) from an unscaled V.
+std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::vector<double>& V_raw);
+
+// x in/out.  `scales` = [d_f, d_ce.., d_ci..] already installed on the device.
+ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
+                          const std::vector<IterationCallback>& callbacks, const Options& options,
+                          std::vector<double>& x, std::vector<double>* s_out = nullptr,
+                          std::vector<double>* y_out = nullptr, std::vector<double>* z_out = nullptr,
+                          SolveReport* report = nullptr);
+
+}  // namespace slpx

@@ -1,0 +1,559 @@
+#include "ldlt_symbolic.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace slpx {
+
+namespace {
+
+using Adj = std::vector<std::vector<int32_t>>;
+
+// ---------------------------------------------------------------------------
+// Ordering: nested dissection with (constrained) minimum-degree leaves
+// ---------------------------------------------------------------------------
+struct Orderer {
+  const Adj& adj;
+  const std::vector<uint8_t>& has_diag;
+  const LdltOptions& opt;
+  std::vector<int32_t> stamp, dist;
+  int32_t cur_stamp = 0;
+  std::vector<int32_t> order;
+
+  Orderer(const Adj& a, const std::vector<uint8_t>& hd, const LdltOptions& o)
+      : adj(a), has_diag(hd), opt(o), stamp(a.size(), 0), dist(a.size(), 0) {}
+
+  // Minimum degree on the subgraph induced by `nodes`.  With defer_constraints,
+  // a constraint node (index >= n_dec, zero diagonal) is only eligible once one
+  // of its neighbours has been eliminated, so its pivot is not structurally 0.
+  void min_degree(const std::vector<int32_t>& nodes) {
+    const int m = static_cast<int>(nodes.size());
+    std::unordered_map<int32_t, int32_t> loc;
+    loc.reserve(m * 2);
+    for (int i = 0; i < m; ++i) loc[nodes[i]] = i;
+    std::vector<std::vector<int32_t>> a(m);
+    for (int i = 0; i < m; ++i)
+      for (int32_t w : adj[nodes[i]]) {
+        auto it = loc.find(w);
+        if (it != loc.end()) a[i].push_back(it->second);
+      }
+    for (auto& v : a) std::sort(v.begin(), v.end());
+    std::vector<uint8_t> gone(m, 0), ready(m, 0);
+    for (int i = 0; i < m; ++i) ready[i] = !opt.defer_constraints || has_diag[nodes[i]];
+    std::vector<int32_t> merged;
+    for (int step = 0; step < m; ++step) {
+      int best = -1;
+      for (int pass = 0; pass < 2 && best < 0; ++pass)
+        for (int i = 0; i < m; ++i) {
+          if (gone[i] || (pass == 0 && !ready[i])) continue;
+          if (best < 0 || a[i].size() < a[best].size()) best = i;
+        }
+      gone[best] = 1;
+      order.push_back(nodes[best]);
+      for (int32_t u : a[best]) {
+        ready[u] = 1;
+        merged.clear();
+        std::set_union(a[u].begin(), a[u].end(), a[best].begin(), a[best].end(),
+                       std::back_inserter(merged));
+        merged.erase(std::remove_if(merged.begin(), merged.end(),
+                                    [&](int32_t w) { return w == u || w == best; }),
+                     merged.end());
+        a[u].swap(merged);
+      }
+      a[best].clear();
+    }
+  }
+
+  // BFS inside the current subset (marked by stamp == s); returns level lists
+  std::vector<std::vector<int32_t>> bfs_levels(int32_t start, int32_t s) {
+    std::vector<std::vector<int32_t>> levels;
+    std::vector<int32_t> frontier{start};
+    ++cur_stamp;
+    const int32_t visited = cur_stamp;
+    dist[start] = visited;
+    while (!frontier.empty()) {
+      levels.push_back(frontier);
+      std::vector<int32_t> next;
+      for (int32_t v : frontier)
+        for (int32_t w : adj[v])
+          if (stamp[w] == s && dist[w] != visited) {
+            dist[w] = visited;
+            next.push_back(w);
+          }
+      frontier.swap(next);
+    }
+    return levels;
+  }
+
+  void dissect(std::vector<int32_t> nodes) {
+    if (nodes.empty()) return;
+    if (static_cast<int>(nodes.size()) <= opt.leaf_size) {
+      min_degree(nodes);
+      return;
+    }
+    ++cur_stamp;
+    const int32_t s = cur_stamp;
+    for (int32_t v : nodes) stamp[v] = s;
+    // pseudo-peripheral start: two BFS sweeps
+    auto levels = bfs_levels(nodes[0], s);
+    size_t reached = 0;
+    for (auto& l : levels) reached += l.size();
+    if (reached < nodes.size()) {
+      // disconnected: order each component on its own
+      std::vector<int32_t> comp, rest;
+      ++cur_stamp;
+      const int32_t mark = cur_stamp;
+      for (auto& l : levels)
+        for (int32_t v : l) {
+          dist[v] = mark;
+          comp.push_back(v);
+        }
+      for (int32_t v : nodes)
+        if (dist[v] != mark) rest.push_back(v);
+      dissect(std::move(comp));
+      dissect(std::move(rest));
+      return;
+    }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      int32_t far = levels.back().front();
+      ++cur_stamp;  // bfs_levels uses cur_stamp for `visited`; keep `s` valid
+      levels = bfs_levels(far, s);
+    }
+    if (levels.size() < 3) {
+      min_degree(nodes);
+      return;
+    }
+    // separator level: balance the two sides
+    size_t total = nodes.size(), acc = 0, best_m = 1;
+    size_t best_gap = total;
+    for (size_t m = 0; m + 1 < levels.size(); ++m) {
+      if (m >= 1) {
+        size_t left = acc, right = total - acc - levels[m].size();
+        size_t gap = left > right ? left - right : right - left;
+        if (gap < best_gap) {
+          best_gap = gap;
+          best_m = m;
+        }
+      }
+      acc += levels[m].size();
+    }
+    // shrink the separator to the nodes that actually touch the next level
+    ++cur_stamp;
+    const int32_t nextmark = cur_stamp;
+    for (int32_t v : levels[best_m + 1]) dist[v] = nextmark;
+    std::vector<int32_t> sep, left, right;
+    for (int32_t v : levels[best_m]) {
+      bool touches = false;
+      for (int32_t w : adj[v])
+        if (stamp[w] == s && dist[w] == nextmark) {
+          touches = true;
+          break;
+        }
+      (touches ? sep : left).push_back(v);
+    }
+    for (size_t m = 0; m < best_m; ++m) left.insert(left.end(), levels[m].begin(), levels[m].end());
+    for (size_t m = best_m + 1; m < levels.size(); ++m)
+      right.insert(right.end(), levels[m].begin(), levels[m].end());
+    std::sort(left.begin(), left.end());
+    std::sort(right.begin(), right.end());
+    dissect(std::move(left));
+    dissect(std::move(right));
+    // separator last; variables before constraints so a constraint's pivot sees
+    // its variables already eliminated
+    std::sort(sep.begin(), sep.end());
+    if (opt.defer_constraints)
+      std::stable_partition(sep.begin(), sep.end(), [&](int32_t v) { return has_diag[v] != 0; });
+    order.insert(order.end(), sep.begin(), sep.end());
+  }
+};
+
+}  // namespace
+
+LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt,
+                         const std::vector<int32_t>* user_perm,
+                         const std::vector<uint8_t>* diag_has_source) {
+  LdltPlan P;
+  const int n = lower.cols;
+  P.n = n;
+  P.n_dec = n_dec;
+  std::vector<uint8_t> has_diag(n, 0);
+  for (int i = 0; i < n; ++i)
+    has_diag[i] = diag_has_source ? (*diag_has_source)[i] : static_cast<uint8_t>(i < n_dec);
+
+  // ---- ordering -------------------------------------------------------------
+  if (user_perm != nullptr && !user_perm->empty()) {
+    P.perm = *user_perm;
+  } else {
+    Adj adj(n);
+    for (int c = 0; c < n; ++c)
+      for (int p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
+        int r = lower.rowidx[p];
+        if (r != c) {
+          adj[r].push_back(c);
+          adj[c].push_back(r);
+        }
+      }
+    for (auto& a : adj) {
+      std::sort(a.begin(), a.end());
+      a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    Orderer ord(adj, has_diag, opt);
+    std::vector<int32_t> all(n);
+    std::iota(all.begin(), all.end(), 0);
+    ord.dissect(std::move(all));
+    P.perm = std::move(ord.order);
+  }
+  if (static_cast<int>(P.perm.size()) != n) throw std::runtime_error("ldlt: bad permutation size");
+  P.iperm.assign(n, -1);
+  for (int k = 0; k < n; ++k) P.iperm[P.perm[k]] = k;
+  for (int k = 0; k < n; ++k)
+    if (P.iperm[k] < 0) throw std::runtime_error("ldlt: permutation is not a bijection");
+
+  // ---- permuted A: per column, strictly-lower rows with their lhs source ------
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> Acol(n);  // (row, src)
+  std::vector<int32_t> diag_src(n, -1);
+  for (int c = 0; c < n; ++c)
+    for (int p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
+      int32_t i = P.iperm[lower.rowidx[p]], j = P.iperm[c];
+      if (i == j) diag_src[j] = p;
+      else Acol[std::min(i, j)].emplace_back(std::max(i, j), p);
+    }
+  for (auto& v : Acol) std::sort(v.begin(), v.end());
+
+  // ---- symbolic factorization: pattern of L and the etree -----------------------
+  std::vector<std::vector<int32_t>> Lcol(n);
+  std::vector<std::vector<int32_t>> children(n);
+  P.parent.assign(n, -1);
+  {
+    std::vector<int32_t> tmp, tmp2;
+    for (int j = 0; j < n; ++j) {
+      tmp.clear();
+      for (auto& [r, src] : Acol[j]) tmp.push_back(r);
+      for (int32_t c : children[j]) {
+        tmp2.clear();
+        // Lcol[c] \ {j}
+        std::set_union(tmp.begin(), tmp.end(), Lcol[c].begin() + 1, Lcol[c].end(),
+                       std::back_inserter(tmp2));
+        tmp.swap(tmp2);
+      }
+      Lcol[j] = tmp;
+      if (!tmp.empty()) {
+        P.parent[j] = tmp[0];
+        children[tmp[0]].push_back(j);
+      }
+    }
+  }
+  P.Lp.assign(n + 1, 0);
+  for (int j = 0; j < n; ++j) P.Lp[j + 1] = P.Lp[j] + static_cast<int32_t>(Lcol[j].size());
+  P.nnzL = P.Lp[n];
+  P.Li.reserve(P.nnzL);
+  for (int j = 0; j < n; ++j) P.Li.insert(P.Li.end(), Lcol[j].begin(), Lcol[j].end());
+  {
+    std::vector<int32_t> h(n, 0);
+    for (int j = 0; j < n; ++j) {
+      for (int32_t c : children[j]) h[j] = std::max(h[j], h[c] + 1);
+      P.etree_height = std::max(P.etree_height, h[j] + 1);
+    }
+  }
+
+  // ---- tasks: subtrees that fit in LDS, grouped in rounds -------------------------
+  const uint32_t cap = opt.task_entries;
+  std::vector<int32_t> task_of(n, -1);
+  std::vector<int32_t> round_of(n, -1);
+  struct TaskCols {
+    std::vector<int32_t> cols;
+    uint32_t weight = 0;
+    int round = 0;
+  };
+  std::vector<TaskCols> tcols;
+  {
+    std::vector<uint32_t> w(n), W(n);
+    for (int j = 0; j < n; ++j) {
+      w[j] = static_cast<uint32_t>(Lcol[j].size()) + 1;
+      if (w[j] > cap)
+        throw std::runtime_error("ldlt: a single column exceeds the LDS task budget "
+                                 "(global-memory supernode path not built yet)");
+    }
+    int assigned = 0, round = 0;
+    while (assigned < n) {
+      for (int j = 0; j < n; ++j) {
+        if (round_of[j] >= 0) continue;
+        W[j] = w[j];
+        for (int32_t c : children[j])
+          if (round_of[c] < 0) W[j] = std::min<uint64_t>(uint64_t(W[j]) + W[c], 0xffffffffu);
+      }
+      // unit roots: unassigned j with W <= cap whose parent is assigned-later or too heavy
+      TaskCols cur;
+      cur.round = round;
+      std::vector<int32_t> stack;
+      std::vector<int32_t> newly;
+      for (int j = n - 1; j >= 0; --j) {  // visit roots before descendants
+        if (round_of[j] >= 0 || W[j] > cap) continue;
+        int32_t p = P.parent[j];
+        if (p >= 0 && round_of[p] < 0 && W[p] <= cap) continue;  // inside a bigger unit
+        // collect the unassigned subtree of j
+        std::vector<int32_t> unit;
+        stack.push_back(j);
+        while (!stack.empty()) {
+          int32_t v = stack.back();
+          stack.pop_back();
+          unit.push_back(v);
+          for (int32_t c : children[v])
+            if (round_of[c] < 0) stack.push_back(c);
+        }
+        if (cur.weight + W[j] > cap && !cur.cols.empty()) {
+          tcols.push_back(std::move(cur));
+          cur = TaskCols{};
+          cur.round = round;
+        }
+        cur.weight += W[j];
+        cur.cols.insert(cur.cols.end(), unit.begin(), unit.end());
+        newly.insert(newly.end(), unit.begin(), unit.end());
+      }
+      if (!cur.cols.empty()) tcols.push_back(std::move(cur));
+      if (newly.empty()) throw std::runtime_error("ldlt: task partition made no progress");
+      for (int32_t v : newly) round_of[v] = round;
+      assigned += static_cast<int>(newly.size());
+      ++round;
+    }
+    P.n_rounds = round;
+  }
+  const int ntasks = static_cast<int>(tcols.size());
+  // column levels inside a task and local ordering
+  std::vector<int32_t> tlevel(n, 0), lcol(n, -1);
+  for (int t = 0; t < ntasks; ++t)
+    for (int32_t j : tcols[t].cols) task_of[j] = t;
+  for (int j = 0; j < n; ++j)
+    for (int32_t c : children[j])
+      if (task_of[c] == task_of[j]) tlevel[j] = std::max(tlevel[j], tlevel[c] + 1);
+  for (int t = 0; t < ntasks; ++t) {
+    auto& cols = tcols[t].cols;
+    std::sort(cols.begin(), cols.end(), [&](int32_t a, int32_t b) {
+      return tlevel[a] != tlevel[b] ? tlevel[a] < tlevel[b] : a < b;
+    });
+    for (size_t i = 0; i < cols.size(); ++i) lcol[cols[i]] = static_cast<int32_t>(i);
+  }
+
+  // ---- entries ---------------------------------------------------------------------
+  // local entry index of the diagonal of column j and of each L position
+  std::vector<uint32_t> diag_ent(n), lent(P.nnzL);
+  std::vector<uint32_t> task_nent(ntasks, 0);
+  for (int t = 0; t < ntasks; ++t) {
+    uint32_t e = 0;
+    for (int32_t j : tcols[t].cols) {
+      diag_ent[j] = e++;
+      for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) lent[p] = e++;
+    }
+    task_nent[t] = e;
+    if (e > 65535u) throw std::runtime_error("ldlt: task exceeds 16-bit local indexing");
+  }
+  // pair lists per (task, local entry) and pseudo entries per task
+  std::vector<std::vector<std::vector<LdltPair>>> epairs(ntasks);
+  for (int t = 0; t < ntasks; ++t) epairs[t].resize(task_nent[t]);
+  struct Ext {
+    uint32_t dst;  // contribution slot
+    std::vector<LdltPair> pairs;
+  };
+  std::vector<std::vector<Ext>> exts(ntasks);
+  std::vector<std::unordered_map<uint64_t, uint32_t>> ext_map(ntasks);
+  std::vector<std::vector<std::vector<uint32_t>>> econtrib(ntasks);
+  for (int t = 0; t < ntasks; ++t) econtrib[t].resize(task_nent[t]);
+  std::vector<uint8_t> diag_updated_perm(n, 0);
+
+  for (int k = 0; k < n; ++k) {
+    const int tk = task_of[k];
+    const int32_t* rows = P.Li.data() + P.Lp[k];
+    const int c = P.Lp[k + 1] - P.Lp[k];
+    for (int a = 0; a < c; ++a) {
+      const int32_t j = rows[a];  // target column
+      const int tj = task_of[j];
+      const uint32_t ent_jk = lent[P.Lp[k] + a];
+      int32_t q = P.Lp[j];  // walk column j's rows
+      for (int b = a; b < c; ++b) {
+        const int32_t i = rows[b];
+        uint32_t target;
+        if (b == a) {
+          target = diag_ent[j];
+          diag_updated_perm[j] = 1;
+        } else {
+          while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
+          if (q >= P.Lp[j + 1]) throw std::runtime_error("ldlt: fill pattern inconsistency");
+          target = lent[q];
+        }
+        LdltPair pr{static_cast<uint16_t>(lent[P.Lp[k] + b]), static_cast<uint16_t>(ent_jk),
+                    static_cast<uint16_t>(lcol[k]), 0};
+        if (tk == tj) {
+          epairs[tj][target].push_back(pr);
+        } else {
+          uint64_t key = (static_cast<uint64_t>(tj) << 32) | target;
+          auto it = ext_map[tk].find(key);
+          if (it == ext_map[tk].end()) {
+            it = ext_map[tk].emplace(key, static_cast<uint32_t>(exts[tk].size())).first;
+            exts[tk].push_back({P.n_contrib, {}});
+            econtrib[tj][target].push_back(P.n_contrib);
+            ++P.n_contrib;
+          }
+          exts[tk][it->second].pairs.push_back(pr);
+        }
+      }
+    }
+  }
+
+  // ---- solve lists ---------------------------------------------------------------
+  // rows of L (CSR view): for row i the entries (i,k), k ascending
+  std::vector<std::vector<std::pair<uint32_t, int32_t>>> Lrow(n);  // (lpos, k)
+  for (int k = 0; k < n; ++k)
+    for (int32_t p = P.Lp[k]; p < P.Lp[k + 1]; ++p) Lrow[P.Li[p]].emplace_back(p, k);
+  struct SExt {
+    uint32_t dst;
+    std::vector<LdltSolveItem> items;
+  };
+  std::vector<std::vector<SExt>> sexts(ntasks);
+  std::vector<std::unordered_map<int32_t, uint32_t>> sext_map(ntasks);
+  std::vector<std::vector<LdltSolveItem>> fwd(n), bwd(n);
+  std::vector<std::vector<uint32_t>> fcontrib(n);
+  for (int j = 0; j < n; ++j) {
+    const int tj = task_of[j];
+    for (auto& [lpos, k] : Lrow[j]) {
+      const int tk = task_of[k];
+      LdltSolveItem it{lpos, static_cast<uint32_t>(lcol[k])};
+      if (tk == tj) {
+        fwd[j].push_back(it);
+      } else {
+        auto f = sext_map[tk].find(j);
+        if (f == sext_map[tk].end()) {
+          f = sext_map[tk].emplace(j, static_cast<uint32_t>(sexts[tk].size())).first;
+          sexts[tk].push_back({P.n_scontrib, {}});
+          fcontrib[j].push_back(P.n_scontrib);
+          ++P.n_scontrib;
+        }
+        sexts[tk][f->second].items.push_back(it);
+      }
+    }
+    for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
+      int32_t i = P.Li[p];
+      uint32_t ref = task_of[i] == tj ? static_cast<uint32_t>(lcol[i])
+                                      : (0x80000000u | static_cast<uint32_t>(i));
+      bwd[j].push_back({static_cast<uint32_t>(p), ref});
+    }
+  }
+
+  // ---- flatten, tasks sorted by round ------------------------------------------------
+  std::vector<int> torder(ntasks);
+  std::iota(torder.begin(), torder.end(), 0);
+  std::stable_sort(torder.begin(), torder.end(),
+                   [&](int a, int b) { return tcols[a].round < tcols[b].round; });
+  P.round_ptr.assign(P.n_rounds + 1, 0);
+  for (int t = 0; t < ntasks; ++t) ++P.round_ptr[tcols[t].round + 1];
+  for (int r = 0; r < P.n_rounds; ++r) P.round_ptr[r + 1] += P.round_ptr[r];
+
+  for (int t : torder) {
+    LdltTask T{};
+    const auto& cols = tcols[t].cols;
+    T.round = static_cast<uint32_t>(tcols[t].round);
+    T.n_col = static_cast<uint32_t>(cols.size());
+    T.n_ent = task_nent[t];
+    T.n_ext = static_cast<uint32_t>(exts[t].size());
+    T.ent_off = static_cast<uint32_t>(P.ent_src.size());
+    T.col_off = static_cast<uint32_t>(P.col_perm.size());
+    T.lvl_off = static_cast<uint32_t>(P.lvl_ptr.size());
+    T.ext_off = static_cast<uint32_t>(P.ext_dst.size());
+    T.pair_off = static_cast<uint32_t>(P.pairs.size());
+    T.contrib_off = static_cast<uint32_t>(P.contrib_idx.size());
+    T.fwd_item_off = static_cast<uint32_t>(P.fwd_items.size());
+    T.bwd_item_off = static_cast<uint32_t>(P.bwd_items.size());
+    T.sext_off = static_cast<uint32_t>(P.sext_dst.size());
+    T.n_sext = static_cast<uint32_t>(sexts[t].size());
+    T.sext_item_off = static_cast<uint32_t>(P.sext_items.size());
+    T.scontrib_off = static_cast<uint32_t>(P.scontrib_idx.size());
+    T.pair_ptr_off = static_cast<uint32_t>(P.ent_pair_ptr.size());
+    T.contrib_ptr_off = static_cast<uint32_t>(P.ent_contrib_ptr.size());
+    T.colptr_off = static_cast<uint32_t>(P.fwd_ptr.size());
+    T.sext_ptr_off = static_cast<uint32_t>(P.sext_ptr.size());
+
+    int32_t cur_level = -1;
+    uint32_t pair_count = 0, contrib_count = 0, fwd_count = 0, bwd_count = 0, sc_count = 0;
+    for (size_t ci = 0; ci < cols.size(); ++ci) {
+      const int32_t j = cols[ci];
+      if (tlevel[j] != cur_level) {
+        P.lvl_ptr.push_back(diag_ent[j]);
+        P.col_lvl_ptr.push_back(static_cast<uint32_t>(ci));
+        cur_level = tlevel[j];
+      }
+      P.col_perm.push_back(static_cast<uint32_t>(j));
+      auto emit_entry = [&](uint32_t le, int32_t src, uint8_t flags, uint32_t out) {
+        P.ent_src.push_back(src);
+        P.ent_flags.push_back(flags);
+        P.ent_col.push_back(static_cast<uint16_t>(ci));
+        P.ent_out.push_back(out);
+        P.ent_pair_ptr.push_back(pair_count);
+        P.ent_contrib_ptr.push_back(contrib_count);
+        for (auto& pr : epairs[t][le]) P.pairs.push_back(pr);
+        pair_count += static_cast<uint32_t>(epairs[t][le].size());
+        for (uint32_t cidx : econtrib[t][le]) P.contrib_idx.push_back(cidx);
+        contrib_count += static_cast<uint32_t>(econtrib[t][le].size());
+      };
+      const bool gamma_kind = P.perm[j] >= n_dec;
+      emit_entry(diag_ent[j], diag_src[j], static_cast<uint8_t>(1 | (gamma_kind ? 2 : 0)),
+                 static_cast<uint32_t>(j));
+      // off-diagonal entries: A source by merge with Acol[j]
+      size_t ap = 0;
+      for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
+        int32_t src = -1;
+        while (ap < Acol[j].size() && Acol[j][ap].first < P.Li[p]) ++ap;
+        if (ap < Acol[j].size() && Acol[j][ap].first == P.Li[p]) src = Acol[j][ap].second;
+        emit_entry(lent[p], src, 0, static_cast<uint32_t>(p));
+      }
+      // solve lists
+      P.fwd_ptr.push_back(fwd_count);
+      for (auto& it : fwd[j]) P.fwd_items.push_back(it);
+      fwd_count += static_cast<uint32_t>(fwd[j].size());
+      P.fwd_contrib_ptr.push_back(sc_count);
+      for (uint32_t cidx : fcontrib[j]) P.scontrib_idx.push_back(cidx);
+      sc_count += static_cast<uint32_t>(fcontrib[j].size());
+      P.bwd_ptr.push_back(bwd_count);
+      for (auto& it : bwd[j]) P.bwd_items.push_back(it);
+      bwd_count += static_cast<uint32_t>(bwd[j].size());
+    }
+    P.lvl_ptr.push_back(T.n_ent);
+    P.col_lvl_ptr.push_back(T.n_col);
+    T.n_lvl = static_cast<uint32_t>(P.lvl_ptr.size() - T.lvl_off - 1);
+    // pseudo entries continue the pair_ptr array
+    for (auto& ex : exts[t]) {
+      P.ext_dst.push_back(ex.dst);
+      P.ent_pair_ptr.push_back(pair_count);
+      for (auto& pr : ex.pairs) P.pairs.push_back(pr);
+      pair_count += static_cast<uint32_t>(ex.pairs.size());
+    }
+    P.ent_pair_ptr.push_back(pair_count);
+    P.ent_contrib_ptr.push_back(contrib_count);
+    P.fwd_ptr.push_back(fwd_count);
+    P.fwd_contrib_ptr.push_back(sc_count);
+    P.bwd_ptr.push_back(bwd_count);
+    uint32_t sitem = 0;
+    for (auto& sx : sexts[t]) {
+      P.sext_dst.push_back(sx.dst);
+      P.sext_ptr.push_back(sitem);
+      for (auto& it : sx.items) P.sext_items.push_back(it);
+      sitem += static_cast<uint32_t>(sx.items.size());
+    }
+    P.sext_ptr.push_back(sitem);
+    P.max_lds_doubles = std::max(P.max_lds_doubles, T.n_ent + T.n_col);
+    P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, T.n_col);
+    P.tasks.push_back(T);
+  }
+
+  // structural zero pivots of the unregularized matrix: a diagonal of the (2,2)
+  // block (no lhs source other than the forced 0) that no earlier column updates
+  for (int j = 0; j < n; ++j)
+    if (!has_diag[P.perm[j]] && !diag_updated_perm[j]) P.structurally_singular_unregularized = true;
+
+  P.flops = 2 * static_cast<int64_t>(P.pairs.size());
+  P.factor_bytes = 12LL * lower.nnz() + 16LL * (P.nnzL + n);
+  P.solve_bytes = 32LL * P.nnzL + 16LL * n;
+  return P;
+}
+
+}  // namespace slpx

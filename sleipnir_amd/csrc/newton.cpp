@@ -1,0 +1,139 @@
+#include "newton.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace slpx {
+
+NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
+                           const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
+                           const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
+    : m_opt(opt) {
+  m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
+  m_k = build_kkt_plan(m_s);
+  // which diagonal entries of the unregularized lhs have any source at all
+  std::vector<uint8_t> diag_has_source(m_k.dim, 0);
+  for (int c = 0; c < m_k.dim; ++c)
+    for (int p = m_k.lhs.colptr[c]; p < m_k.lhs.colptr[c + 1]; ++p)
+      if (m_k.lhs.rowidx[p] == c)
+        diag_has_source[c] = (m_k.dptr[p + 1] > m_k.dptr[p]) || (m_k.pptr[p + 1] > m_k.pptr[p]);
+  m_l = build_ldlt_plan(m_k.lhs, m_s.n, opt.ldlt, user_perm, &diag_has_source);
+  m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
+  reset_regularization();
+}
+
+void NewtonSystem::reset_regularization() {
+  m_prev_delta.assign(m_opt.batch, 0.0);
+  m_prev_gamma.assign(m_opt.batch, 0.0);
+}
+
+// sparse_regularized_ldlt.hpp:64-152, run for every problem of the batch at once.
+// Each trip through the loop is one device factorization of the still-active
+// problems followed by one small stats read-back.
+std::vector<FactorInfo> NewtonSystem::compute() {
+  const int B = m_opt.batch;
+  const int n = m_s.n, m_e = m_s.m_e;
+  std::vector<FactorInfo> info(B, FactorInfo::Success);
+  std::vector<double> delta(B, 0.0), gamma(B, 0.0);
+  std::vector<uint8_t> active(B, 1);
+  std::vector<LdltStats> stats;
+  m_last_factorizations = 0;
+  const double eps = std::numeric_limits<double>::epsilon();
+
+  auto inertia_ok = [&](const LdltStats& st) {
+    return st.n_pos == n && st.n_neg == m_e && st.n_zero == 0;
+  };
+  auto min_abs = [](const LdltStats& st) {
+    double d;
+    std::memcpy(&d, &st.min_abs_bits, sizeof(d));
+    return d;
+  };
+
+  // First attempt: unregularized (:74-87).  When the symbolic phase proved that a
+  // pivot is structurally zero the attempt is known to end in NumericalIssue
+  // (Eigen reports failure on an exactly-zero pivot), so it is not launched.
+  std::vector<uint8_t> need_loop(B, 0);
+  const bool skip_first = m_opt.skip_structurally_singular_attempt &&
+                          m_l.structurally_singular_unregularized;
+  if (!skip_first) {
+    m_dev->factor(delta, gamma, active);
+    m_dev->read_stats(stats);
+    ++m_last_factorizations;
+    for (int b = 0; b < B; ++b) {
+      const bool success = stats[b].n_bad == 0;
+      if (success && inertia_ok(stats[b]) && min_abs(stats[b]) >= 1e-4) {
+        m_prev_delta[b] = 0.0;
+        m_prev_gamma[b] = 0.0;
+        active[b] = 0;
+      } else {
+        need_loop[b] = 1;
+      }
+    }
+  } else {
+    std::fill(need_loop.begin(), need_loop.end(), 1);
+  }
+
+  bool any = false;
+  for (int b = 0; b < B; ++b) {
+    active[b] = need_loop[b];
+    if (need_loop[b]) {
+      any = true;
+      delta[b] = m_prev_delta[b] == 0.0 ? 1e-4 : std::max(m_prev_delta[b] / 2.0, eps);  // :95-98
+      gamma[b] = m_gamma_min;                                                            // :102
+    }
+  }
+  while (any) {
+    m_dev->factor(delta, gamma, active);
+    m_dev->read_stats(stats);
+    ++m_last_factorizations;
+    any = false;
+    for (int b = 0; b < B; ++b) {
+      if (!active[b]) continue;
+      const LdltStats& st = stats[b];
+      if (st.n_bad == 0) {
+        if (inertia_ok(st)) {  // :109-113
+          m_prev_delta[b] = delta[b];
+          m_prev_gamma[b] = gamma[b];
+          active[b] = 0;
+          continue;
+        } else if (st.n_zero > 0) {  // :114-126
+          if (gamma[b] == 0.0) {
+            gamma[b] = 1e-10;
+          } else {
+            delta[b] *= 10.0;
+            gamma[b] *= 10.0;
+          }
+        } else if (st.n_neg > m_e) {  // :127-130
+          delta[b] *= 10.0;
+        } else if (st.n_pos > n) {  // :131-135
+          gamma[b] = gamma[b] == 0.0 ? 1e-10 : gamma[b] * 10.0;
+        }
+      } else {  // :136-141
+        delta[b] *= 10.0;
+        gamma[b] = gamma[b] == 0.0 ? 1e-10 : gamma[b] * 10.0;
+      }
+      if (delta[b] > 1e20 || gamma[b] > 1e20) {  // :145-150
+        info[b] = FactorInfo::NumericalIssue;
+        m_prev_delta[b] = delta[b];
+        m_prev_gamma[b] = gamma[b];
+        active[b] = 0;
+        continue;
+      }
+      any = true;
+    }
+  }
+  return info;
+}
+
+std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
+  if (refresh_ad) m_dev->sweep_full();
+  m_dev->assemble();
+  m_dev->build_rhs();
+  auto info = compute();
+  m_dev->solve();
+  m_dev->backsub();
+  return info;
+}
+
+}  // namespace slpx

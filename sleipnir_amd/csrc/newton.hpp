@@ -1,0 +1,71 @@
+// NewtonSystem: one compiled NLP on one GPU — structure + plans + device state —
+// and the host-side regularization policy that drives the device factorization.
+//
+// Counterpart of what interior_point() holds across iterations in the reference:
+// the matrix callbacks (interior_point.hpp:199-237), `RegularizedLDLT solver`
+// (:338-352) and the per-iteration Newton step (:426-482).  The δ/γ inertia-
+// correction loop (util/sparse_regularized_ldlt.hpp:82-151) stays on the host so
+// its decisions can be compared one-to-one with the oracle; every numeric
+// factorization attempt inside it is a device launch.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "device.hpp"
+#include "kkt_plan.hpp"
+#include "ldlt_symbolic.hpp"
+#include "nlp.hpp"
+
+namespace slpx {
+
+struct NewtonOptions {
+  TapeCompileOptions tape;
+  LdltOptions ldlt;
+  int batch = 1;
+  int device = 0;
+  bool skip_structurally_singular_attempt = true;
+};
+
+// Eigen::ComputationInfo stand-in
+enum class FactorInfo : int { Success = 0, NumericalIssue = 1 };
+
+class NewtonSystem {
+ public:
+  NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f, const std::vector<NodeId>& c_e,
+               const std::vector<NodeId>& c_i, const NewtonOptions& opt,
+               const std::vector<int32_t>* user_perm = nullptr);
+
+  const NlpStructure& structure() const { return m_s; }
+  const KktPlan& kkt() const { return m_k; }
+  const LdltPlan& ldlt() const { return m_l; }
+  DeviceNlp& device() { return *m_dev; }
+  int batch() const { return m_opt.batch; }
+
+  void set_gamma_min(double g) { m_gamma_min = g; }
+  void reset_regularization();
+
+  // sparse_regularized_ldlt.hpp:64-152 on the lhs currently in device memory.
+  // Returns per-problem info; fills the regularization that was used.
+  std::vector<FactorInfo> compute();
+  const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
+  const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
+  int last_factorizations() const { return m_last_factorizations; }
+
+  // One full Newton step on device-resident state: AD refresh, KKT lhs/rhs,
+  // regularized factorization, solve, back-substitution
+  // (interior_point.hpp:809-812 + :426-482).
+  std::vector<FactorInfo> newton_step(bool refresh_ad = true);
+
+ private:
+  NewtonOptions m_opt;
+  NlpStructure m_s;
+  KktPlan m_k;
+  LdltPlan m_l;
+  std::unique_ptr<DeviceNlp> m_dev;
+  double m_gamma_min = 1e-10;
+  std::vector<double> m_prev_delta, m_prev_gamma;
+  int m_last_factorizations = 0;
+};
+
+}  // namespace slpx

@@ -1,0 +1,229 @@
+#include "nlp.hpp"
+
+#include <algorithm>
+#include <functional>
+#include <stdexcept>
+
+namespace slpx {
+
+namespace {
+
+struct RowEntry {
+  int32_t row, col;
+  NodeId wrt;
+  double cached;  // value when the row is LINEAR
+  bool is_cached;
+};
+
+// One derivative matrix (the body of Jacobian's constructor, jacobian.hpp:54-105):
+// per-row parent->child lists, (col,node) output lists, LINEAR rows evaluated once.
+struct MatrixBuild {
+  CscPattern pat;
+  std::vector<RowEntry> entries;       // in CSC order after finalize()
+  std::vector<int32_t> nonlinear_rows;
+  int linear_rows = 0;
+};
+
+// Adjoint sweep of a LINEAR row on the host.  Only + - neg, const*x and x/const
+// can appear in a LINEAR expression (expression.hpp:155-348), and the formulas
+// below are the reference's grad_l/grad_r for exactly those ops
+// (expression.hpp:444-515, 616-694, 696-730).
+void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, std::vector<double>& adj) {
+  g.update_values(top);
+  for (NodeId n : top) adj[n] = 0.0;
+  adj[top[0]] = 1.0;
+  for (NodeId n : top) {
+    NodeId l = g.a0[n], r = g.a1[n];
+    if (l == kNull) continue;
+    const double a = adj[n];
+    switch (static_cast<Opcode>(g.op[n])) {
+      case OP_ADD: adj[l] += a; adj[r] += a; break;
+      case OP_SUB: adj[l] += a; adj[r] += -a; break;
+      case OP_NEG: adj[l] += -a; break;
+      case OP_MUL: adj[l] += a * g.val[r]; adj[r] += a * g.val[l]; break;
+      case OP_DIV:
+        adj[l] += a / g.val[r];
+        adj[r] += a * -g.val[l] / (g.val[r] * g.val[r]);
+        break;
+      default:
+        throw std::runtime_error("linear_row_adjoints: non-linear op in a LINEAR row");
+    }
+  }
+}
+
+MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::vector<NodeId>& wrt,
+                         int nrows, int ncols, bool lower, std::vector<double>& adj_scratch) {
+  MatrixBuild mb;
+  std::vector<std::vector<NodeId>> tops(rows.size());
+  std::vector<std::vector<std::pair<int32_t, NodeId>>> outs(rows.size());
+  // topological_sort uses `scratch` too; like the reference, build all lists first
+  // (jacobian.hpp:60-62) and only then tag each wrt node with its column (:64-66).
+  for (size_t r = 0; r < rows.size(); ++r) tops[r] = g.topological_sort(rows[r]);
+  for (size_t c = 0; c < wrt.size(); ++c) g.scratch[wrt[c]] = static_cast<int32_t>(c);
+  for (size_t r = 0; r < rows.size(); ++r)
+    for (NodeId n : tops[r])
+      if (g.scratch[n] != -1) outs[r].emplace_back(g.scratch[n], n);
+  for (size_t c = 0; c < wrt.size(); ++c) g.scratch[wrt[c]] = -1;
+
+  if (adj_scratch.size() < g.size()) adj_scratch.resize(g.size(), 0.0);
+  for (size_t r = 0; r < rows.size(); ++r) {
+    if (rows[r] == kNull) continue;
+    const uint8_t t = g.type[rows[r]];
+    if (t == T_LINEAR) {
+      ++mb.linear_rows;
+      if (tops[r].empty()) continue;
+      linear_row_adjoints(g, tops[r], adj_scratch);
+      for (auto& [col, node] : outs[r]) {
+        if (lower && col > static_cast<int32_t>(r)) continue;
+        mb.entries.push_back({static_cast<int32_t>(r), col, node, adj_scratch[node], true});
+      }
+    } else if (t > T_LINEAR) {
+      mb.nonlinear_rows.push_back(static_cast<int32_t>(r));
+      for (auto& [col, node] : outs[r]) {
+        if (lower && col > static_cast<int32_t>(r)) continue;
+        mb.entries.push_back({static_cast<int32_t>(r), col, node, 0.0, false});
+      }
+    }
+  }
+  // CSC order (setFromTriplets: column-major, rows ascending)
+  std::stable_sort(mb.entries.begin(), mb.entries.end(), [](const RowEntry& a, const RowEntry& b) {
+    return a.col != b.col ? a.col < b.col : a.row < b.row;
+  });
+  mb.pat.rows = nrows;
+  mb.pat.cols = ncols;
+  mb.pat.colptr.assign(ncols + 1, 0);
+  for (auto& e : mb.entries) {
+    ++mb.pat.colptr[e.col + 1];
+    mb.pat.rowidx.push_back(e.row);
+  }
+  for (int c = 0; c < ncols; ++c) mb.pat.colptr[c + 1] += mb.pat.colptr[c];
+  return mb;
+}
+
+}  // namespace
+
+NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId f_in,
+                                 const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
+                                 const TapeCompileOptions& opt) {
+  NlpStructure s;
+  s.graph_nodes_before = g.size();
+  s.n = static_cast<int>(x.size());
+  s.m_e = static_cast<int>(c_e.size());
+  s.m_i = static_cast<int>(c_i.size());
+  const int n = s.n, m_e = s.m_e, m_i = s.m_i;
+
+  // problem.hpp:236-263
+  s.f_type = f_in == kNull ? T_NONE : g.type[f_in];
+  for (NodeId c : c_e) s.ce_type = std::max(s.ce_type, g.type[c]);
+  for (NodeId c : c_i) s.ci_type = std::max(s.ci_type, g.type[c]);
+
+  NodeId f = f_in == kNull ? g.constant(0.0) : f_in;  // problem.hpp:318
+
+  // problem.hpp:519-520: dual variables as fresh decision-variable leaves
+  for (int j = 0; j < m_e; ++j) s.y_nodes.push_back(g.variable(0.0));
+  for (int j = 0; j < m_i; ++j) s.z_nodes.push_back(g.variable(0.0));
+
+  // problem.hpp:542: H_f rows = symbolic gradient of f
+  std::vector<NodeId> Hf_rows = g.gradient_tree(g.topological_sort(f), x);
+  // problem.hpp:547-548: -y_adᵀ c_e_ad - z_adᵀ c_i_ad with the reference's matmul
+  // (variable_matrix.hpp:505-521: sum{0}; sum += lhs*rhs)
+  NodeId lag;
+  {
+    std::vector<NodeId> neg_y(m_e);
+    for (int j = 0; j < m_e; ++j) neg_y[j] = g.neg(s.y_nodes[j]);
+    NodeId sum_e = g.constant(0.0);
+    for (int j = 0; j < m_e; ++j) sum_e = g.add(sum_e, g.mul(neg_y[j], c_e[j]));
+    NodeId sum_i = g.constant(0.0);
+    for (int j = 0; j < m_i; ++j) sum_i = g.add(sum_i, g.mul(s.z_nodes[j], c_i[j]));
+    lag = g.sub(sum_e, sum_i);
+  }
+  std::vector<NodeId> Hc_rows = g.gradient_tree(g.topological_sort(lag), x);
+  s.graph_nodes_after = g.size();
+
+  std::vector<double> adj;
+  MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, adj);        // problem.hpp:535
+  MatrixBuild mHf = build_matrix(g, Hf_rows, x, n, n, true, adj);
+  MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, adj);
+  MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, adj);     // problem.hpp:555
+  MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, adj);     // problem.hpp:560
+
+  s.g_pat = mg.pat;
+  s.Ae = mAe.pat;
+  s.Ai = mAi.pat;
+  s.Hf = mHf.pat;
+  s.Hc = mHc.pat;
+  s.off_f = 0;
+  s.off_ce = 1;
+  s.off_ci = s.off_ce + m_e;
+  s.off_g = s.off_ci + m_i;
+  s.off_Ae = s.off_g + s.g_pat.nnz();
+  s.off_Ai = s.off_Ae + s.Ae.nnz();
+  s.off_Hf = s.off_Ai + s.Ai.nnz();
+  s.off_Hc = s.off_Hf + s.Hf.nnz();
+  s.nV = s.off_Hc + s.Hc.nnz();
+  s.V_static_raw.assign(s.nV, 0.0);
+  s.V_scale_idx.assign(s.nV, -1);
+  s.V_is_static.assign(s.nV, 1);
+
+  std::vector<std::pair<NodeId, int32_t>> inputs;
+  for (int i = 0; i < n; ++i) inputs.emplace_back(x[i], i);
+  for (int j = 0; j < m_e; ++j) inputs.emplace_back(s.y_nodes[j], n + j);
+  for (int j = 0; j < m_i; ++j) inputs.emplace_back(s.z_nodes[j], n + m_e + j);
+
+  std::vector<TapeValueOut> vouts;
+  vouts.push_back({f, s.off_f, 0});
+  for (int j = 0; j < m_e; ++j) vouts.push_back({c_e[j], s.off_ce + j, 1 + j});
+  for (int j = 0; j < m_i; ++j) vouts.push_back({c_i[j], s.off_ci + j, 1 + m_e + j});
+  for (auto& v : vouts) {
+    s.V_scale_idx[v.dst] = v.scale_idx;
+    s.V_is_static[v.dst] = 0;
+  }
+  // A CONSTANT value root is never touched by a sweep; bake it in
+  std::vector<TapeValueOut> live_vouts;
+  for (auto& v : vouts) {
+    if (g.type[v.node] == T_CONSTANT) {
+      s.V_static_raw[v.dst] = g.val[v.node];
+      s.V_is_static[v.dst] = 1;
+    } else {
+      live_vouts.push_back(v);
+    }
+  }
+
+  std::vector<TapeRow> rows;
+  auto add_matrix = [&](MatrixBuild& mb, const std::vector<NodeId>& roots, int off,
+                        const std::function<int32_t(int32_t)>& scale_of_row) {
+    std::vector<TapeRow> mrows(roots.size());
+    for (size_t k = 0; k < mb.entries.size(); ++k) {
+      const RowEntry& e = mb.entries[k];
+      const int32_t dst = off + static_cast<int32_t>(k);
+      s.V_scale_idx[dst] = scale_of_row(e.row);
+      if (e.is_cached) {
+        s.V_static_raw[dst] = e.cached;
+      } else {
+        s.V_is_static[dst] = 0;
+        mrows[e.row].outputs.push_back({e.wrt, dst});
+      }
+    }
+    for (int32_t r : mb.nonlinear_rows) {
+      if (mrows[r].outputs.empty()) continue;  // e.g. every entry above the diagonal
+      mrows[r].root = roots[r];
+      mrows[r].scale_idx = scale_of_row(r);
+      rows.push_back(std::move(mrows[r]));
+    }
+    s.nonlinear_rows += static_cast<int>(mb.nonlinear_rows.size());
+    s.linear_rows += mb.linear_rows;
+  };
+  add_matrix(mg, {f}, s.off_g, [](int32_t) { return 0; });
+  add_matrix(mAe, c_e, s.off_Ae, [](int32_t r) { return 1 + r; });
+  add_matrix(mAi, c_i, s.off_Ai, [m_e](int32_t r) { return 1 + m_e + r; });
+  add_matrix(mHf, Hf_rows, s.off_Hf, [](int32_t) { return 0; });
+  add_matrix(mHc, Hc_rows, s.off_Hc, [](int32_t) { return -1; });
+
+  s.full = compile_tape(g, inputs, live_vouts, rows, opt);
+  s.values = compile_tape(g, inputs, live_vouts, {}, opt);
+  s.full.n_inputs = s.values.n_inputs = s.n_inputs();
+  s.full.n_outputs = s.values.n_outputs = s.nV;
+  return s;
+}
+
+}  // namespace slpx

@@ -1,0 +1,203 @@
+// slp::Problem — the user surface of the reference
+// (include/sleipnir/optimization/problem.hpp:67-744) kept for the path's callers:
+// decision_variable(), minimize()/maximize(), subject_to(), solve(), add_callback().
+// solve() compiles the model for the GPU (NewtonSystem) and runs the interior-point
+// iteration around the device Newton step.
+//
+// Scope of this round: the reference routes
+// unconstrained problems to newton() and equality-only problems to sqp()
+// (problem.hpp:335,403); this build always uses the interior-point path, which
+// contains both as special cases (m_i = 0 and/or m_e = 0).
+#pragma once
+
+#include <functional>
+#include <memory>
+#include <optional>
+#include <utility>
+#include <vector>
+
+#include "../ipm.hpp"
+#include "../newton.hpp"
+#include "variable.hpp"
+
+namespace slp {
+
+using ExitStatus = slpx::ExitStatus;
+using Options = slpx::Options;
+using IterationInfo = slpx::IterationInfo;
+using SolveReport = slpx::SolveReport;
+
+class Problem {
+ public:
+  Problem() noexcept = default;
+
+  [[nodiscard]] Variable decision_variable() {
+    m_decision_variables.emplace_back();
+    return m_decision_variables.back();
+  }
+
+  // problem.hpp:91-104
+  [[nodiscard]] VariableMatrix decision_variable(int rows, int cols = 1) {
+    VariableMatrix vars{detail::empty, rows, cols};
+    for (int row = 0; row < rows; ++row)
+      for (int col = 0; col < cols; ++col) {
+        m_decision_variables.emplace_back();
+        vars[row, col] = m_decision_variables.back();
+      }
+    return vars;
+  }
+
+  // problem.hpp:118-140
+  [[nodiscard]] VariableMatrix symmetric_decision_variable(int rows) {
+    VariableMatrix vars{detail::empty, rows, rows};
+    for (int row = 0; row < rows; ++row)
+      for (int col = 0; col <= row; ++col) {
+        m_decision_variables.emplace_back();
+        vars[row, col] = m_decision_variables.back();
+        vars[col, row] = m_decision_variables.back();
+      }
+    return vars;
+  }
+
+  void minimize(const Variable& cost) { m_f = cost; }
+  void maximize(const Variable& objective) { m_f = -objective; }
+  void subject_to(const EqualityConstraints& constraint) {
+    m_equality_constraints.insert(m_equality_constraints.end(), constraint.constraints.begin(),
+                                  constraint.constraints.end());
+  }
+  void subject_to(const InequalityConstraints& constraint) {
+    m_inequality_constraints.insert(m_inequality_constraints.end(),
+                                    constraint.constraints.begin(), constraint.constraints.end());
+  }
+
+  ExpressionType cost_function_type() const { return m_f ? m_f->type() : ExpressionType::NONE; }
+  ExpressionType equality_constraint_type() const { return max_type(m_equality_constraints); }
+  ExpressionType inequality_constraint_type() const { return max_type(m_inequality_constraints); }
+
+  template <typename F>
+    requires requires(F cb, const IterationInfo& info) { { cb(info) } -> std::same_as<void>; }
+  void add_callback(F&& callback) {
+    m_iteration_callbacks.emplace_back([cb = std::forward<F>(callback)](const IterationInfo& info) {
+      cb(info);
+      return false;
+    });
+  }
+  template <typename F>
+    requires requires(F cb, const IterationInfo& info) { { cb(info) } -> std::same_as<bool>; }
+  void add_callback(F&& callback) {
+    m_iteration_callbacks.emplace_back(std::forward<F>(callback));
+  }
+  void clear_callbacks() { m_iteration_callbacks.clear(); }
+
+  // problem.hpp:281-679
+  ExitStatus solve(const Options& options = Options{}, [[maybe_unused]] bool spy = false) {
+    auto& g = detail::G();
+    std::vector<double> x(m_decision_variables.size());
+    for (size_t i = 0; i < x.size(); ++i) x[i] = m_decision_variables[i].value();
+
+    // problem.hpp:304-313
+    if (cost_function_type() <= ExpressionType::CONSTANT &&
+        equality_constraint_type() <= ExpressionType::CONSTANT &&
+        inequality_constraint_type() <= ExpressionType::CONSTANT) {
+      return ExitStatus::SUCCESS;
+    }
+
+    compile();
+
+    // get_bounds conflict test (util/bounds.hpp:55-190, problem.hpp:597-606)
+    std::vector<double> V(m_sys->structure().nV);
+    auto& dev = m_sys->device();
+    dev.set_scaling(std::vector<double>(m_sys->structure().n_scales(), 1.0));
+    std::vector<double> zeros_e(std::max<size_t>(1, m_equality_constraints.size()), 0.0);
+    std::vector<double> ones_i(std::max<size_t>(1, m_inequality_constraints.size()), 1.0);
+    dev.upload_x(x.data());
+    dev.upload_duals(ones_i.data(), zeros_e.data(), ones_i.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+    if (has_conflicting_bounds(V)) return ExitStatus::GLOBALLY_INFEASIBLE;
+
+    // problem.hpp:615-616
+    m_scales = slpx::compute_problem_scaling(m_sys->structure(), V);
+    dev.set_scaling(m_scales);
+
+    ExitStatus status = slpx::interior_point(*m_sys, m_scales, m_iteration_callbacks, options, x,
+                                             &m_s, &m_y, &m_z, &m_report);
+    // problem.hpp:676
+    for (size_t i = 0; i < x.size(); ++i) g.val[m_decision_variables[i].expr] = x[i];
+    return status;
+  }
+
+  // Compiles (once) the NLP for the device; exposed so harnesses can time setup
+  // separately and drive the Newton step directly.
+  slpx::NewtonSystem& compile(const slpx::NewtonOptions& opt = {}) {
+    if (!m_sys) {
+      std::vector<NodeId> xs, ce, ci;
+      for (auto& v : m_decision_variables) xs.push_back(v.expr);
+      for (auto& v : m_equality_constraints) ce.push_back(v.expr);
+      for (auto& v : m_inequality_constraints) ci.push_back(v.expr);
+      m_sys = std::make_unique<slpx::NewtonSystem>(detail::G(), xs, m_f ? m_f->expr : slpx::kNull, ce,
+                                                   ci, opt);
+    }
+    return *m_sys;
+  }
+
+  const SolveReport& report() const { return m_report; }
+  const Variable& cost() const { return *m_f; }
+  const std::vector<Variable>& decision_variables() const { return m_decision_variables; }
+  const std::vector<Variable>& equality_constraints() const { return m_equality_constraints; }
+  const std::vector<Variable>& inequality_constraints() const { return m_inequality_constraints; }
+  const std::vector<double>& scales() const { return m_scales; }
+  const std::vector<double>& slack() const { return m_s; }
+  const std::vector<double>& equality_duals() const { return m_y; }
+  const std::vector<double>& inequality_duals() const { return m_z; }
+
+ private:
+  static ExpressionType max_type(const std::vector<Variable>& v) {
+    ExpressionType t = ExpressionType::NONE;
+    for (auto& e : v) t = std::max(t, e.type());
+    return t;
+  }
+
+  bool has_conflicting_bounds(const std::vector<double>& V) {
+    const auto& st = m_sys->structure();
+    auto& g = detail::G();
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<std::pair<double, double>> b(st.n, {-inf, inf});
+    // row -> (count, col, value) from the CSC pattern of A_i
+    std::vector<int> cnt(st.m_i, 0), col(st.m_i, -1);
+    std::vector<double> coef(st.m_i, 0.0);
+    for (int c = 0; c < st.n; ++c)
+      for (int p = st.Ai.colptr[c]; p < st.Ai.colptr[c + 1]; ++p) {
+        const int r = st.Ai.rowidx[p];
+        ++cnt[r];
+        col[r] = c;
+        coef[r] = V[st.off_Ai + p];
+      }
+    bool conflict = false;
+    for (int r = 0; r < st.m_i; ++r) {
+      if (m_inequality_constraints[r].type() != ExpressionType::LINEAR || cnt[r] != 1) continue;
+      const NodeId var = m_decision_variables[col[r]].expr;
+      const double saved = g.val[var];
+      g.val[var] = 0.0;
+      const double constant_term = m_inequality_constraints[r].value();
+      g.val[var] = saved;
+      const double detected = -constant_term / coef[r];
+      auto& [lo, hi] = b[col[r]];
+      if (coef[r] < 0.0 && detected < hi) hi = detected;
+      else if (coef[r] > 0.0 && detected > lo) lo = detected;
+      if (lo > hi) conflict = true;
+    }
+    return conflict;
+  }
+
+  std::vector<Variable> m_decision_variables;
+  std::optional<Variable> m_f;
+  std::vector<Variable> m_equality_constraints;
+  std::vector<Variable> m_inequality_constraints;
+  std::vector<slpx::IterationCallback> m_iteration_callbacks;
+  std::unique_ptr<slpx::NewtonSystem> m_sys;
+  std::vector<double> m_scales, m_s, m_y, m_z;
+  SolveReport m_report;
+};
+
+}  // namespace slp

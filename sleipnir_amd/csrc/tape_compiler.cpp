@@ -1,0 +1,534 @@
+#include "tape_compiler.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace slpx {
+
+namespace {
+
+// Compile-time working copy of the reachable part of the graph.
+struct CG {
+  std::vector<uint8_t> op;
+  std::vector<int32_t> a0, a1;     // CG ids, -1 = none
+  std::vector<NodeId> src;         // originating graph node (-1 for synthesized)
+  std::vector<int32_t> scratch;    // in-degree counter for the reference ordering
+  int32_t add(uint8_t o, int32_t l, int32_t r, NodeId s) {
+    op.push_back(o);
+    a0.push_back(l);
+    a1.push_back(r);
+    src.push_back(s);
+    scratch.push_back(-1);
+    return static_cast<int32_t>(op.size()) - 1;
+  }
+  size_t size() const { return op.size(); }
+  bool is_leaf(int32_t n) const { return a0[n] < 0; }
+};
+
+// expression_graph.hpp:29-78 on the working copy
+std::vector<int32_t> reference_order(CG& cg, int32_t root) {
+  std::vector<int32_t> list;
+  std::vector<int32_t> stack{root};
+  while (!stack.empty()) {
+    int32_t n = stack.back();
+    stack.pop_back();
+    for (int32_t arg : {cg.a0[n], cg.a1[n]})
+      if (arg >= 0 && ++cg.scratch[arg] == 0) stack.push_back(arg);
+  }
+  stack.push_back(root);
+  while (!stack.empty()) {
+    int32_t n = stack.back();
+    stack.pop_back();
+    list.push_back(n);
+    for (int32_t arg : {cg.a0[n], cg.a1[n]})
+      if (arg >= 0 && --cg.scratch[arg] == -1) stack.push_back(arg);
+  }
+  return list;
+}
+
+struct UnionFind {
+  std::vector<int32_t> p;
+  explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0); }
+  int32_t find(int32_t x) {
+    while (p[x] != x) {
+      p[x] = p[p[x]];
+      x = p[x];
+    }
+    return x;
+  }
+  void unite(int32_t a, int32_t b) {
+    a = find(a);
+    b = find(b);
+    if (a != b) p[std::max(a, b)] = std::min(a, b);
+  }
+};
+
+}  // namespace
+
+TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                         const std::vector<TapeValueOut>& value_outs,
+                         const std::vector<TapeRow>& rows, const TapeCompileOptions& opt) {
+  TapeProgram prog;
+
+  // ---- A. working copy of everything reachable from the roots ---------------
+  std::vector<NodeId> roots;
+  for (auto& v : value_outs) roots.push_back(v.node);
+  for (auto& r : rows) roots.push_back(r.root);
+
+  std::vector<NodeId> reach;
+  {
+    std::vector<uint8_t> seen(g.size(), 0);
+    std::vector<NodeId> stack;
+    for (NodeId r : roots)
+      if (r != kNull && !seen[r]) {
+        seen[r] = 1;
+        stack.push_back(r);
+      }
+    while (!stack.empty()) {
+      NodeId n = stack.back();
+      stack.pop_back();
+      reach.push_back(n);
+      for (NodeId a : {g.a0[n], g.a1[n]})
+        if (a != kNull && !seen[a]) {
+          seen[a] = 1;
+          stack.push_back(a);
+        }
+    }
+    std::sort(reach.begin(), reach.end());
+  }
+  std::unordered_map<NodeId, int32_t> to_cg;
+  to_cg.reserve(reach.size() * 2);
+  CG cg;
+  for (NodeId n : reach) {
+    int32_t l = g.a0[n] == kNull ? -1 : to_cg.at(g.a0[n]);
+    int32_t r = g.a1[n] == kNull ? -1 : to_cg.at(g.a1[n]);
+    to_cg[n] = cg.add(g.op[n], l, r, n);
+  }
+  std::unordered_map<NodeId, int32_t> input_of;
+  input_of.reserve(inputs.size() * 2);
+  for (auto& [node, idx] : inputs) {
+    input_of[node] = idx;
+    prog.n_inputs = std::max(prog.n_inputs, idx + 1);
+  }
+
+  // ---- B/C. rebalance long left-deep ADD chains ---------------------------
+  if (opt.rebalance_sums) {
+    std::vector<int32_t> uses(cg.size(), 0);
+    for (size_t n = 0; n < cg.size(); ++n) {
+      if (cg.a0[n] >= 0) ++uses[cg.a0[n]];
+      if (cg.a1[n] >= 0) ++uses[cg.a1[n]];
+    }
+    for (NodeId r : roots)
+      if (r != kNull) uses[to_cg.at(r)] += 2;  // roots are never interior chain links
+    const size_t n0 = cg.size();
+    std::vector<uint8_t> consumed(n0, 0);
+    for (int32_t top = static_cast<int32_t>(n0) - 1; top >= 0; --top) {
+      if (cg.op[top] != OP_ADD || consumed[top]) continue;
+      // walk down the left spine
+      std::vector<int32_t> terms;  // collected right operands, top-down
+      int32_t cur = top;
+      while (true) {
+        terms.push_back(cg.a1[cur]);
+        int32_t next = cg.a0[cur];
+        if (next >= 0 && cg.op[next] == OP_ADD && uses[next] == 1 && !consumed[next]) {
+          consumed[next] = 1;
+          cur = next;
+        } else {
+          terms.push_back(next);
+          break;
+        }
+      }
+      if (terms.size() < opt.rebalance_min_terms) continue;
+      std::reverse(terms.begin(), terms.end());  // original left-to-right order
+      // pairwise tree, keeping left-to-right term order
+      std::vector<int32_t> level = terms;
+      while (level.size() > 2) {
+        std::vector<int32_t> next;
+        for (size_t i = 0; i + 1 < level.size(); i += 2)
+          next.push_back(cg.add(OP_ADD, level[i], level[i + 1], kNull));
+        if (level.size() & 1) next.push_back(level.back());
+        level.swap(next);
+      }
+      cg.a0[top] = level[0];
+      cg.a1[top] = level[1];
+    }
+  }
+
+  // ---- liveness + levels (children may now have larger ids than parents) -----
+  const size_t ncg = cg.size();
+  std::vector<uint8_t> live(ncg, 0);
+  std::vector<int32_t> order;  // children-before-parents order of live nodes
+  {
+    std::vector<std::pair<int32_t, int>> stack;  // (node, state)
+    for (NodeId r : roots) {
+      if (r == kNull) continue;
+      int32_t c = to_cg.at(r);
+      if (live[c]) continue;
+      stack.push_back({c, 0});
+      live[c] = 1;
+      while (!stack.empty()) {
+        auto& [n, st] = stack.back();
+        int32_t child = st == 0 ? cg.a0[n] : (st == 1 ? cg.a1[n] : -2);
+        if (child == -2) {
+          order.push_back(n);
+          stack.pop_back();
+          continue;
+        }
+        ++st;
+        if (child >= 0 && !live[child]) {
+          live[child] = 1;
+          stack.push_back({child, 0});
+        }
+      }
+    }
+  }
+  std::vector<int32_t> level(ncg, 0);
+  for (int32_t n : order) {
+    if (cg.is_leaf(n)) continue;
+    int32_t l = level[cg.a0[n]];
+    if (cg.a1[n] >= 0) l = std::max(l, level[cg.a1[n]]);
+    level[n] = l + 1;
+  }
+
+  // ---- rows: reference order, useful sets, slots, edges -------------------------
+  struct Slot {
+    int32_t row, node, level;
+    uint32_t edge_begin, edge_end;  // into row-local edge storage
+    int32_t out_dst;                // -1 if not an output
+  };
+  struct REdge {
+    int32_t parent_slot;  // global slot id
+    int32_t parent_node;
+    int side;
+  };
+  std::vector<Slot> slots;
+  std::vector<std::vector<REdge>> slot_edges;  // per global slot
+  std::vector<uint8_t> need_dl(ncg, 0), need_dr(ncg, 0);
+  std::vector<int32_t> row_root_slot(rows.size(), -1);
+  {
+    std::vector<int32_t> slot_of(ncg, -1);
+    std::vector<int32_t> out_dst(ncg, -1);
+    std::vector<uint8_t> useful(ncg, 0);
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+      const TapeRow& row = rows[ri];
+      if (row.root == kNull) continue;
+      int32_t root = to_cg.at(row.root);
+      for (auto& o : row.outputs) {
+        auto it = to_cg.find(o.wrt);
+        if (it != to_cg.end()) out_dst[it->second] = o.dst;
+      }
+      std::vector<int32_t> top = reference_order(cg, root);
+      for (auto it = top.rbegin(); it != top.rend(); ++it) {
+        int32_t n = *it;
+        bool u = out_dst[n] >= 0;
+        if (cg.a0[n] >= 0 && useful[cg.a0[n]]) u = true;
+        if (cg.a1[n] >= 0 && useful[cg.a1[n]]) u = true;
+        useful[n] = u;
+      }
+      for (int32_t n : top) {
+        if (!useful[n]) continue;
+        slot_of[n] = static_cast<int32_t>(slots.size());
+        slots.push_back({static_cast<int32_t>(ri), n, 0, 0, 0, out_dst[n]});
+        slot_edges.emplace_back();
+      }
+      row_root_slot[ri] = slot_of[root];
+      for (int32_t p : top) {
+        if (!useful[p] || cg.is_leaf(p)) continue;
+        int32_t ps = slot_of[p];
+        int32_t l = cg.a0[p], r = cg.a1[p];
+        if (l >= 0 && useful[l]) {
+          slot_edges[slot_of[l]].push_back({ps, p, 0});
+          need_dl[p] = 1;
+          slots[slot_of[l]].level = std::max(slots[slot_of[l]].level, slots[ps].level + 1);
+        }
+        if (r >= 0 && useful[r]) {
+          slot_edges[slot_of[r]].push_back({ps, p, 1});
+          need_dr[p] = 1;
+          slots[slot_of[r]].level = std::max(slots[slot_of[r]].level, slots[ps].level + 1);
+        }
+      }
+      for (int32_t n : top) {
+        useful[n] = 0;
+        slot_of[n] = -1;
+        out_dst[n] = -1;
+      }
+      for (auto& o : row.outputs) {
+        auto it = to_cg.find(o.wrt);
+        if (it != to_cg.end()) out_dst[it->second] = -1;
+      }
+    }
+  }
+  // NOTE on slot levels: parents precede children in `top`, and every edge into a
+  // child is visited after all edges into its parent were visited, because the
+  // parent's own level is final once it has been popped in reference order (all
+  // its incoming edges come from nodes earlier in the list).
+
+  // ---- components of interior nodes ------------------------------------------
+  // A node whose operands are all leaves (e.g. the `-y_j` of the Lagrangian, which
+  // both stage k and stage k+1 reference) is REPLICATED into every component that
+  // uses it instead of gluing those components together: recomputing one cheap op
+  // keeps the stages independent.
+  std::vector<uint8_t> is_root(ncg, 0), replicable(ncg, 0);
+  for (NodeId r : roots)
+    if (r != kNull) is_root[to_cg.at(r)] = 1;
+  for (int32_t n : order) {
+    if (cg.is_leaf(n) || is_root[n]) continue;
+    bool all_leaves = cg.is_leaf(cg.a0[n]) && (cg.a1[n] < 0 || cg.is_leaf(cg.a1[n]));
+    replicable[n] = all_leaves;
+  }
+  UnionFind uf(ncg);
+  for (int32_t n : order) {
+    if (cg.is_leaf(n) || replicable[n]) continue;
+    for (int32_t a : {cg.a0[n], cg.a1[n]})
+      if (a >= 0 && !cg.is_leaf(a) && !replicable[a]) uf.unite(n, a);
+  }
+  // component id -> list of interior nodes; stable order by smallest source id
+  std::vector<int32_t> comp_of(ncg, -1);
+  std::vector<std::vector<int32_t>> comp_nodes;
+  {
+    std::unordered_map<int32_t, int32_t> idx;
+    std::vector<int32_t> interior;
+    for (int32_t n : order)
+      if (!cg.is_leaf(n) && !replicable[n]) interior.push_back(n);
+    std::sort(interior.begin(), interior.end());
+    for (int32_t n : interior) {
+      int32_t r = uf.find(n);
+      auto it = idx.find(r);
+      if (it == idx.end()) {
+        it = idx.emplace(r, static_cast<int32_t>(comp_nodes.size())).first;
+        comp_nodes.emplace_back();
+      }
+      comp_of[n] = it->second;
+      comp_nodes[it->second].push_back(n);
+    }
+  }
+  const size_t ncomp = comp_nodes.size();
+  std::vector<std::vector<int32_t>> comp_slots(ncomp);
+  std::vector<std::vector<size_t>> comp_vouts(ncomp);
+  std::vector<size_t> leaf_vouts;  // value outputs that are leaves
+  for (size_t s = 0; s < slots.size(); ++s) {
+    int32_t n = slots[s].node;
+    int32_t c;
+    if (!cg.is_leaf(n) && !replicable[n]) {
+      c = comp_of[n];
+    } else {
+      // a leaf (or replicated) slot belongs to the component of its row's root
+      // (the root is interior whenever the row has any edge)
+      c = comp_of[to_cg.at(rows[slots[s].row].root)];
+      if (c < 0) continue;  // row whose root is a leaf: no tape work
+    }
+    comp_slots[c].push_back(static_cast<int32_t>(s));
+  }
+  for (size_t v = 0; v < value_outs.size(); ++v) {
+    int32_t n = to_cg.at(value_outs[v].node);
+    if (cg.is_leaf(n)) leaf_vouts.push_back(v);
+    else comp_vouts[comp_of[n]].push_back(v);
+  }
+
+  // working-set size (doubles) of a set of components
+  auto comp_cost = [&](size_t c, size_t& n_leaf_est) {
+    // leaves are counted per component (upper bound when packing several)
+    size_t leaves = 0;
+    for (int32_t n : comp_nodes[c]) {
+      if (cg.a0[n] >= 0 && cg.is_leaf(cg.a0[n])) ++leaves;
+      if (cg.a1[n] >= 0 && cg.is_leaf(cg.a1[n])) ++leaves;
+    }
+    n_leaf_est = leaves;
+    return leaves + 3 * comp_nodes[c].size() + comp_slots[c].size();
+  };
+
+  // ---- pack components into tasks -----------------------------------------------
+  const size_t small_cap = opt.small_lds_bytes / 8, large_cap = opt.large_lds_bytes / 8;
+  struct Pack {
+    std::vector<size_t> comps;
+    size_t cost = 0;
+    int cls = 0;  // 0 small, 1 large, 2 global
+  };
+  std::vector<Pack> packs;
+  {
+    Pack cur;
+    for (size_t c = 0; c < ncomp; ++c) {
+      size_t le;
+      size_t cost = comp_cost(c, le);
+      if (cost > small_cap) {
+        Pack big;
+        big.comps.push_back(c);
+        big.cost = cost;
+        big.cls = cost > large_cap ? 2 : 1;
+        packs.push_back(std::move(big));
+        continue;
+      }
+      if (cur.cost + cost > small_cap && !cur.comps.empty()) {
+        packs.push_back(std::move(cur));
+        cur = Pack{};
+      }
+      cur.comps.push_back(c);
+      cur.cost += cost;
+    }
+    if (!cur.comps.empty()) packs.push_back(std::move(cur));
+  }
+  if (!leaf_vouts.empty()) {
+    Pack lp;
+    lp.cls = 0;
+    packs.push_back(std::move(lp));  // leaf-only task, filled below
+  }
+
+  // ---- emit tasks -----------------------------------------------------------------
+  std::unordered_map<double, uint32_t> const_pool;
+  auto const_index = [&](double v) {
+    auto it = const_pool.find(v);
+    if (it != const_pool.end()) return it->second;
+    uint32_t i = static_cast<uint32_t>(prog.consts.size());
+    prog.consts.push_back(v);
+    const_pool.emplace(v, i);
+    return i;
+  };
+  auto leaf_binding = [&](int32_t n) -> uint32_t {
+    NodeId s = cg.src[n];
+    if (cg.op[n] == OP_CONST) return kLeafConstFlag | const_index(g.val[s]);
+    auto it = input_of.find(s);
+    if (it == input_of.end())
+      throw std::runtime_error("compile_tape: expression depends on a variable that is not a tape input");
+    return static_cast<uint32_t>(it->second);
+  };
+
+  std::vector<int32_t> local_of(ncg, -1);       // CG node -> local value index
+  std::vector<int32_t> local_slot(slots.size(), -1);
+  for (size_t pi = 0; pi < packs.size(); ++pi) {
+    Pack& pk = packs[pi];
+    TapeTask t{};
+    t.leaf_off = static_cast<uint32_t>(prog.leaf_src.size());
+    t.node_off = static_cast<uint32_t>(prog.node_rec.size() / 3);
+    t.lvl_off = static_cast<uint32_t>(prog.lvl_ptr.size());
+    t.slot_off = static_cast<uint32_t>(prog.slot_edge_ptr.size());
+    t.slvl_off = static_cast<uint32_t>(prog.slvl_ptr.size());
+    t.edge_off = static_cast<uint32_t>(prog.edges.size());
+    t.vout_off = static_cast<uint32_t>(prog.vout_src.size());
+    t.jout_off = static_cast<uint32_t>(prog.jout_slot.size());
+
+    std::vector<int32_t> nodes, tslots, leaves;
+    std::vector<size_t> vouts;
+    const bool leaf_task = pk.comps.empty();
+    if (leaf_task) {
+      vouts = leaf_vouts;
+      for (size_t v : vouts) leaves.push_back(to_cg.at(value_outs[v].node));
+    }
+    for (size_t c : pk.comps) {
+      nodes.insert(nodes.end(), comp_nodes[c].begin(), comp_nodes[c].end());
+      tslots.insert(tslots.end(), comp_slots[c].begin(), comp_slots[c].end());
+      vouts.insert(vouts.end(), comp_vouts[c].begin(), comp_vouts[c].end());
+    }
+    {  // private copies of the replicated single-op nodes this task consumes
+      std::vector<int32_t> extra;
+      for (int32_t n : nodes)
+        for (int32_t a : {cg.a0[n], cg.a1[n]})
+          if (a >= 0 && !cg.is_leaf(a) && replicable[a]) extra.push_back(a);
+      std::sort(extra.begin(), extra.end());
+      extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+      nodes.insert(nodes.end(), extra.begin(), extra.end());
+    }
+    for (int32_t n : nodes)
+      for (int32_t a : {cg.a0[n], cg.a1[n]})
+        if (a >= 0 && cg.is_leaf(a)) leaves.push_back(a);
+    std::sort(leaves.begin(), leaves.end());
+    leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
+    std::stable_sort(nodes.begin(), nodes.end(),
+                     [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+    std::stable_sort(tslots.begin(), tslots.end(), [&](int32_t a, int32_t b) {
+      return slots[a].level < slots[b].level;
+    });
+
+    t.n_leaf = static_cast<uint32_t>(leaves.size());
+    t.n_node = static_cast<uint32_t>(nodes.size());
+    t.n_slot = static_cast<uint32_t>(tslots.size());
+    for (size_t i = 0; i < leaves.size(); ++i) {
+      local_of[leaves[i]] = static_cast<int32_t>(i);
+      prog.leaf_src.push_back(leaf_binding(leaves[i]));
+    }
+    for (size_t i = 0; i < nodes.size(); ++i) local_of[nodes[i]] = static_cast<int32_t>(t.n_leaf + i);
+    // node records + forward levels
+    {
+      int32_t cur_level = -1;
+      for (size_t i = 0; i < nodes.size(); ++i) {
+        int32_t n = nodes[i];
+        if (level[n] != cur_level) {  // one group per DISTINCT level present in the task
+          prog.lvl_ptr.push_back(static_cast<uint32_t>(i));
+          cur_level = level[n];
+        }
+        uint32_t rec = cg.op[n] | (need_dl[n] ? 0x100u : 0u) | (need_dr[n] ? 0x200u : 0u);
+        prog.node_rec.push_back(rec);
+        prog.node_rec.push_back(static_cast<uint32_t>(local_of[cg.a0[n]]));
+        prog.node_rec.push_back(cg.a1[n] >= 0 ? static_cast<uint32_t>(local_of[cg.a1[n]])
+                                              : static_cast<uint32_t>(local_of[cg.a0[n]]));
+      }
+      prog.lvl_ptr.push_back(static_cast<uint32_t>(nodes.size()));
+      t.n_lvl = static_cast<uint32_t>(prog.lvl_ptr.size() - t.lvl_off - 1);
+      prog.max_levels = std::max(prog.max_levels, t.n_lvl);
+    }
+    // slots + reverse levels + edges
+    {
+      for (size_t i = 0; i < tslots.size(); ++i) local_slot[tslots[i]] = static_cast<int32_t>(i);
+      int32_t cur_level = -1;
+      uint32_t edge_count = 0;
+      for (size_t i = 0; i < tslots.size(); ++i) {
+        const Slot& s = slots[tslots[i]];
+        if (s.level != cur_level) {
+          prog.slvl_ptr.push_back(static_cast<uint32_t>(i));
+          cur_level = s.level;
+        }
+        prog.slot_edge_ptr.push_back(edge_count);
+        for (const REdge& e : slot_edges[tslots[i]]) {
+          uint32_t pn = static_cast<uint32_t>(local_of[e.parent_node]) - t.n_leaf;
+          prog.edges.push_back({static_cast<uint32_t>(local_slot[e.parent_slot]),
+                                2u * pn + static_cast<uint32_t>(e.side)});
+          ++edge_count;
+        }
+        if (s.out_dst >= 0) {
+          prog.jout_slot.push_back(static_cast<uint32_t>(i));
+          prog.jout_dst.push_back(static_cast<uint32_t>(s.out_dst));
+          prog.jout_scale.push_back(rows[s.row].scale_idx);
+        }
+      }
+      prog.slot_edge_ptr.push_back(edge_count);
+      prog.slvl_ptr.push_back(static_cast<uint32_t>(tslots.size()));
+      t.n_slvl = static_cast<uint32_t>(prog.slvl_ptr.size() - t.slvl_off - 1);
+      prog.max_slot_levels = std::max(prog.max_slot_levels, t.n_slvl);
+      prog.total_edges += edge_count;
+    }
+    for (size_t v : vouts) {
+      prog.vout_src.push_back(static_cast<uint32_t>(local_of[to_cg.at(value_outs[v].node)]));
+      prog.vout_dst.push_back(static_cast<uint32_t>(value_outs[v].dst));
+      prog.vout_scale.push_back(value_outs[v].scale_idx);
+    }
+    t.n_vout = static_cast<uint32_t>(prog.vout_src.size() - t.vout_off);
+    t.n_jout = static_cast<uint32_t>(prog.jout_slot.size() - t.jout_off);
+    t.lds_doubles = t.n_leaf + 3 * t.n_node + t.n_slot;
+    int cls = pk.cls;
+    if (cls == 0 && t.lds_doubles > small_cap) cls = 1;
+    if (cls == 1 && t.lds_doubles > large_cap) cls = 2;
+    uint32_t ti = static_cast<uint32_t>(prog.tasks.size());
+    if (cls == 0) {
+      prog.small_tasks.push_back(ti);
+      prog.small_lds_doubles = std::max(prog.small_lds_doubles, t.lds_doubles);
+    } else if (cls == 1) {
+      prog.large_tasks.push_back(ti);
+      prog.large_lds_doubles = std::max(prog.large_lds_doubles, t.lds_doubles);
+    } else {
+      prog.global_tasks.push_back(ti);
+      t.scratch_off = static_cast<uint32_t>(prog.global_scratch_doubles);
+      prog.global_scratch_doubles += t.lds_doubles;
+    }
+    prog.tasks.push_back(t);
+    prog.total_nodes += t.n_node;
+    prog.total_slots += t.n_slot;
+    prog.total_leaves += t.n_leaf;
+  }
+  for (auto& v : value_outs) prog.n_outputs = std::max(prog.n_outputs, v.dst + 1);
+  for (auto& r : rows)
+    for (auto& o : r.outputs) prog.n_outputs = std::max(prog.n_outputs, o.dst + 1);
+  return prog;
+}
+
+}  // namespace slpx

@@ -1,0 +1,381 @@
+// TEST INFRASTRUCTURE ONLY — never linked into the product.
+//
+// Sequential host interpreter of the COMPILED device plans (tape tasks, KKT gather
+// maps, LDLᵀ task/round schedule).  It walks exactly the data structures the HIP
+// kernels walk, in the same task/level order, so the `-m "not gpu"` suite can
+// validate the host-side compilers (tape_compiler, kkt_plan, ldlt_symbolic)
+// against the oracle without a GPU.  The kernels themselves are validated on the
+// GPU by the `-m gpu` parity tests.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../sleipnir_amd/csrc/capi_internal.hpp"
+#include "../../sleipnir_amd/csrc/kkt_plan.hpp"
+#include "../../sleipnir_amd/csrc/ldlt_symbolic.hpp"
+#include "../../sleipnir_amd/csrc/nlp.hpp"
+#include "../../sleipnir_amd/csrc/tape_ops.h"
+
+using namespace slpx;
+
+struct hc_handle {
+  NlpStructure s;
+  KktPlan k;
+  LdltPlan l;
+  std::vector<double> scales, in_scale, V, lhs, rhs, Lx, D, contrib, scontrib, zv, xg, p, ps, pz;
+  int stats[4] = {0, 0, 0, 0};
+  double min_abs = 0.0;
+};
+
+namespace {
+
+void run_tape(const TapeProgram& P, const std::vector<double>& in, const std::vector<double>& in_scale,
+              const std::vector<double>& scales, std::vector<double>& V, bool reverse) {
+  for (const TapeTask& t : P.tasks) {
+    std::vector<double> val(t.n_leaf + t.n_node), part(2 * t.n_node), adj(t.n_slot);
+    for (uint32_t i = 0; i < t.n_leaf; ++i) {
+      uint32_t src = P.leaf_src[t.leaf_off + i];
+      val[i] = (src & kLeafConstFlag) ? P.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
+    }
+    const uint32_t* lvl = P.lvl_ptr.data() + t.lvl_off;
+    const uint32_t* rec = P.node_rec.data() + 3 * static_cast<size_t>(t.node_off);
+    for (uint32_t l = 0; l < t.n_lvl; ++l) {
+      // emulate level parallelism: read everything of the level before writing
+      std::vector<double> v(lvl[l + 1] - lvl[l]), dl(v.size()), dr(v.size());
+      for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+        uint32_t r0 = rec[3 * i], a0 = rec[3 * i + 1], a1 = rec[3 * i + 2];
+        op_forward(static_cast<Opcode>(r0 & 0xff), val[a0], val[a1], (r0 & 0x100) != 0,
+                   (r0 & 0x200) != 0, v[i - lvl[l]], dl[i - lvl[l]], dr[i - lvl[l]]);
+      }
+      for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+        val[t.n_leaf + i] = v[i - lvl[l]];
+        part[2 * i] = dl[i - lvl[l]];
+        part[2 * i + 1] = dr[i - lvl[l]];
+      }
+    }
+    for (uint32_t i = 0; i < t.n_vout; ++i) {
+      uint32_t kx = t.vout_off + i;
+      int32_t sc = P.vout_scale[kx];
+      double v = val[P.vout_src[kx]];
+      V[P.vout_dst[kx]] = sc >= 0 ? scales[sc] * v : v;
+    }
+    if (!reverse || t.n_slot == 0) continue;
+    const uint32_t* slvl = P.slvl_ptr.data() + t.slvl_off;
+    const uint32_t* eptr = P.slot_edge_ptr.data() + t.slot_off;
+    const TapeEdge* edges = P.edges.data() + t.edge_off;
+    for (uint32_t l = 0; l < t.n_slvl; ++l) {
+      std::vector<double> acc(slvl[l + 1] - slvl[l]);
+      for (uint32_t i = slvl[l]; i < slvl[l + 1]; ++i) {
+        uint32_t eb = eptr[i], ee = eptr[i + 1];
+        double a = eb == ee ? 1.0 : 0.0;
+        for (uint32_t e = eb; e < ee; ++e) a += adj[edges[e].parent_slot] * part[edges[e].partial];
+        acc[i - slvl[l]] = a;
+      }
+      for (uint32_t i = slvl[l]; i < slvl[l + 1]; ++i) adj[i] = acc[i - slvl[l]];
+    }
+    for (uint32_t i = 0; i < t.n_jout; ++i) {
+      uint32_t kx = t.jout_off + i;
+      int32_t sc = P.jout_scale[kx];
+      double v = adj[P.jout_slot[kx]];
+      V[P.jout_dst[kx]] = sc >= 0 ? scales[sc] * v : v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+hc_handle* hc_create(slpx_problem* p, const int32_t* perm, int32_t perm_len, int32_t task_entries,
+                     int32_t small_lds_bytes) {
+  auto* h = new hc_handle();
+  std::vector<NodeId> xs, ce, ci;
+  for (auto& v : p->problem.decision_variables()) xs.push_back(v.expr);
+  for (auto& v : p->problem.equality_constraints()) ce.push_back(v.expr);
+  for (auto& v : p->problem.inequality_constraints()) ci.push_back(v.expr);
+  NodeId f = p->problem.cost_function_type() == slp::ExpressionType::NONE ? kNull : p->problem.cost().expr;
+  TapeCompileOptions topt;
+  if (small_lds_bytes > 0) topt.small_lds_bytes = small_lds_bytes;
+  h->s = build_nlp_structure(graph(), xs, f, ce, ci, topt);
+  h->k = build_kkt_plan(h->s);
+  std::vector<uint8_t> diag_has_source(h->k.dim, 0);
+  for (int c = 0; c < h->k.dim; ++c)
+    for (int q = h->k.lhs.colptr[c]; q < h->k.lhs.colptr[c + 1]; ++q)
+      if (h->k.lhs.rowidx[q] == c)
+        diag_has_source[c] = (h->k.dptr[q + 1] > h->k.dptr[q]) || (h->k.pptr[q + 1] > h->k.pptr[q]);
+  std::vector<int32_t> up;
+  if (perm && perm_len > 0) up.assign(perm, perm + perm_len);
+  LdltOptions lopt;
+  if (task_entries > 0) lopt.task_entries = task_entries;
+  h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
+  h->scales.assign(h->s.n_scales(), 1.0);
+  h->in_scale.assign(h->s.n_inputs(), 1.0);
+  h->V = h->s.V_static_raw;
+  h->lhs.assign(h->k.lhs.nnz(), 0.0);
+  h->rhs.assign(h->k.dim, 0.0);
+  h->Lx.assign(std::max<int64_t>(1, h->l.nnzL), 0.0);
+  h->D.assign(h->l.n, 0.0);
+  h->contrib.assign(std::max<uint32_t>(1, h->l.n_contrib), 0.0);
+  h->scontrib.assign(std::max<uint32_t>(1, h->l.n_scontrib), 0.0);
+  h->zv.assign(h->l.n, 0.0);
+  h->xg.assign(h->l.n, 0.0);
+  h->p.assign(h->k.dim, 0.0);
+  h->ps.assign(std::max(1, h->s.m_i), 0.0);
+  h->pz.assign(std::max(1, h->s.m_i), 0.0);
+  return h;
+}
+void hc_destroy(hc_handle* h) { delete h; }
+
+// out[0..] = n, m_e, m_i, nV, nnz_lhs, nnzL, rounds, tasks, etree height, pairs,
+//            tape tasks, nodes, slots, edges, levels, slot levels, struct singular,
+//            off_g, off_Ae, off_Ai, off_Hf, off_Hc, global tape tasks, large tape tasks
+void hc_info(hc_handle* h, int64_t* out) {
+  int i = 0;
+  out[i++] = h->s.n;
+  out[i++] = h->s.m_e;
+  out[i++] = h->s.m_i;
+  out[i++] = h->s.nV;
+  out[i++] = h->k.lhs.nnz();
+  out[i++] = h->l.nnzL;
+  out[i++] = h->l.n_rounds;
+  out[i++] = static_cast<int64_t>(h->l.tasks.size());
+  out[i++] = h->l.etree_height;
+  out[i++] = static_cast<int64_t>(h->l.pairs.size());
+  out[i++] = static_cast<int64_t>(h->s.full.tasks.size());
+  out[i++] = static_cast<int64_t>(h->s.full.total_nodes);
+  out[i++] = static_cast<int64_t>(h->s.full.total_slots);
+  out[i++] = static_cast<int64_t>(h->s.full.total_edges);
+  out[i++] = h->s.full.max_levels;
+  out[i++] = h->s.full.max_slot_levels;
+  out[i++] = h->l.structurally_singular_unregularized ? 1 : 0;
+  out[i++] = h->s.off_g;
+  out[i++] = h->s.off_Ae;
+  out[i++] = h->s.off_Ai;
+  out[i++] = h->s.off_Hf;
+  out[i++] = h->s.off_Hc;
+  out[i++] = static_cast<int64_t>(h->s.full.global_tasks.size());
+  out[i++] = static_cast<int64_t>(h->s.full.large_tasks.size());
+}
+
+int32_t hc_pattern(hc_handle* h, int which, int32_t* colptr, int32_t* rowidx) {
+  const CscPattern* pat = nullptr;
+  switch (which) {
+    case 0: pat = &h->s.g_pat; break;
+    case 1: pat = &h->s.Ae; break;
+    case 2: pat = &h->s.Ai; break;
+    case 3: pat = &h->s.Hf; break;
+    case 4: pat = &h->s.Hc; break;
+    case 5: pat = &h->k.lhs; break;
+    default: return -1;
+  }
+  if (colptr) std::copy(pat->colptr.begin(), pat->colptr.end(), colptr);
+  if (rowidx) std::copy(pat->rowidx.begin(), pat->rowidx.end(), rowidx);
+  return pat->nnz();
+}
+void hc_perm(hc_handle* h, int32_t* perm) { std::copy(h->l.perm.begin(), h->l.perm.end(), perm); }
+
+void hc_set_scaling(hc_handle* h, const double* scales) {
+  const auto& s = h->s;
+  h->scales.assign(scales, scales + s.n_scales());
+  for (int j = 0; j < s.m_e; ++j) h->in_scale[s.n + j] = scales[1 + j];
+  for (int j = 0; j < s.m_i; ++j) h->in_scale[s.n + s.m_e + j] = scales[1 + s.m_e + j];
+  for (int kx = 0; kx < s.nV; ++kx) {
+    int32_t sc = s.V_scale_idx[kx];
+    if (s.V_is_static[kx]) h->V[kx] = sc >= 0 ? scales[sc] * s.V_static_raw[kx] : s.V_static_raw[kx];
+  }
+}
+
+void hc_sweep(hc_handle* h, const double* x, const double* y, const double* z, int full, double* V_out) {
+  const auto& s = h->s;
+  std::vector<double> in(s.n_inputs(), 0.0);
+  std::copy(x, x + s.n, in.begin());
+  if (y) std::copy(y, y + s.m_e, in.begin() + s.n);
+  if (z) std::copy(z, z + s.m_i, in.begin() + s.n + s.m_e);
+  run_tape(full ? s.full : s.values, in, h->in_scale, h->scales, h->V, full != 0);
+  if (V_out) std::copy(h->V.begin(), h->V.end(), V_out);
+}
+
+void hc_assemble(hc_handle* h, const double* s, const double* z, double* lhs_out) {
+  const auto& K = h->k;
+  for (int kx = 0; kx < K.lhs.nnz(); ++kx) {
+    double direct = 0.0;
+    for (int d = K.dptr[kx]; d < K.dptr[kx + 1]; ++d) direct += h->V[K.dsrc[d]];
+    double prod = 0.0;
+    for (int q = K.pptr[kx]; q < K.pptr[kx + 1]; ++q) {
+      int r = K.pr[q];
+      double sigma = (1.0 / s[r]) * z[r];
+      prod += (h->V[K.pa[q]] * sigma) * h->V[K.pb[q]];
+    }
+    h->lhs[kx] = direct + prod;
+  }
+  if (lhs_out) std::copy(h->lhs.begin(), h->lhs.end(), lhs_out);
+}
+void hc_set_lhs(hc_handle* h, const double* lhs) { std::copy(lhs, lhs + h->k.lhs.nnz(), h->lhs.begin()); }
+
+void hc_rhs(hc_handle* h, const double* s, const double* y, const double* z, double mu, double* rhs_out) {
+  const auto& K = h->k;
+  const auto& st = h->s;
+  const double* V = h->V.data();
+  for (int j = 0; j < K.dim; ++j) {
+    if (j >= K.n) {
+      h->rhs[j] = -V[st.off_ce + j - K.n];
+      continue;
+    }
+    int gs = K.g_src[j];
+    double aey = 0.0;
+    for (int q = st.Ae.colptr[j]; q < st.Ae.colptr[j + 1]; ++q) aey += V[st.off_Ae + q] * y[st.Ae.rowidx[q]];
+    double ait = 0.0;
+    for (int q = st.Ai.colptr[j]; q < st.Ai.colptr[j + 1]; ++q) {
+      int r = st.Ai.rowidx[q];
+      double sinv = 1.0 / s[r], sigma = sinv * z[r];
+      ait += V[st.off_Ai + q] * (-sigma * V[st.off_ci + r] + mu * sinv + z[r]);
+    }
+    h->rhs[j] = -(gs >= 0 ? V[gs] : 0.0) + aey + ait;
+  }
+  if (rhs_out) std::copy(h->rhs.begin(), h->rhs.end(), rhs_out);
+}
+void hc_set_rhs(hc_handle* h, const double* rhs) { std::copy(rhs, rhs + h->k.dim, h->rhs.begin()); }
+
+// stats_out: n_pos, n_neg, n_zero, n_bad, min|D|
+void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* stats_out) {
+  const LdltPlan& L = h->l;
+  std::memset(h->stats, 0, sizeof(h->stats));
+  h->min_abs = INFINITY;
+  for (int r = 0; r < L.n_rounds; ++r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      std::vector<double> U(t.n_ent), invd(t.n_col);
+      const uint32_t* lvl = L.lvl_ptr.data() + t.lvl_off;
+      const uint32_t* pptr = L.ent_pair_ptr.data() + t.pair_ptr_off;
+      const uint32_t* cptr = L.ent_contrib_ptr.data() + t.contrib_ptr_off;
+      const LdltPair* pairs = L.pairs.data() + t.pair_off;
+      const uint32_t* cidx = L.contrib_idx.data() + t.contrib_off;
+      for (uint32_t l = 0; l < t.n_lvl; ++l) {
+        std::vector<double> acc_v(lvl[l + 1] - lvl[l]);
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+          uint32_t e = t.ent_off + i;
+          int32_t src = L.ent_src[e];
+          uint8_t fl = L.ent_flags[e];
+          double acc = src >= 0 ? h->lhs[src] : 0.0;
+          if (fl & 1) acc += (fl & 2) ? -gamma : delta;
+          for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= h->contrib[cidx[c]];
+          for (uint32_t q = pptr[i]; q < pptr[i + 1]; ++q)
+            acc -= (U[pairs[q].a] * invd[pairs[q].k]) * U[pairs[q].b];
+          acc_v[i - lvl[l]] = acc;
+        }
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+          uint32_t e = t.ent_off + i;
+          U[i] = acc_v[i - lvl[l]];
+          if (L.ent_flags[e] & 1) invd[L.ent_col[e]] = 1.0 / U[i];
+        }
+      }
+      for (uint32_t x = 0; x < t.n_ext; ++x) {
+        double acc = 0.0;
+        for (uint32_t q = pptr[t.n_ent + x]; q < pptr[t.n_ent + x + 1]; ++q)
+          acc += (U[pairs[q].a] * invd[pairs[q].k]) * U[pairs[q].b];
+        h->contrib[L.ext_dst[t.ext_off + x]] = acc;
+      }
+      for (uint32_t i = 0; i < t.n_ent; ++i) {
+        uint32_t e = t.ent_off + i;
+        double u = U[i];
+        if (L.ent_flags[e] & 1) {
+          h->D[L.ent_out[e]] = u;
+          const double eps = 2.220446049250313e-16;
+          if (u > eps) ++h->stats[0];
+          else if (u < -eps) ++h->stats[1];
+          else ++h->stats[2];
+          if (u == 0.0 || !std::isfinite(u)) ++h->stats[3];
+          else h->min_abs = std::min(h->min_abs, std::fabs(u));
+        } else {
+          h->Lx[L.ent_out[e]] = u * invd[L.ent_col[e]];
+        }
+      }
+    }
+  if (D_out) std::copy(h->D.begin(), h->D.end(), D_out);
+  if (stats_out) {
+    for (int i = 0; i < 4; ++i) stats_out[i] = h->stats[i];
+    stats_out[4] = h->min_abs;
+  }
+}
+
+void hc_solve(hc_handle* h, double* p_out) {
+  const LdltPlan& L = h->l;
+  for (int r = 0; r < L.n_rounds; ++r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      std::vector<double> y(t.n_col);
+      const uint32_t* lvl = L.col_lvl_ptr.data() + t.lvl_off;
+      const uint32_t* fptr = L.fwd_ptr.data() + t.colptr_off;
+      const uint32_t* fcptr = L.fwd_contrib_ptr.data() + t.colptr_off;
+      const LdltSolveItem* items = L.fwd_items.data() + t.fwd_item_off;
+      const uint32_t* scidx = L.scontrib_idx.data() + t.scontrib_off;
+      for (uint32_t l = 0; l < t.n_lvl; ++l) {
+        std::vector<double> acc_v(lvl[l + 1] - lvl[l]);
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+          uint32_t pj = L.col_perm[t.col_off + i];
+          double acc = h->rhs[L.perm[pj]];
+          for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= h->scontrib[scidx[c]];
+          for (uint32_t q = fptr[i]; q < fptr[i + 1]; ++q) acc -= h->Lx[items[q].lpos] * y[items[q].ref];
+          acc_v[i - lvl[l]] = acc;
+        }
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) y[i] = acc_v[i - lvl[l]];
+      }
+      const uint32_t* sptr = L.sext_ptr.data() + t.sext_ptr_off;
+      const LdltSolveItem* sitems = L.sext_items.data() + t.sext_item_off;
+      for (uint32_t x = 0; x < t.n_sext; ++x) {
+        double acc = 0.0;
+        for (uint32_t q = sptr[x]; q < sptr[x + 1]; ++q) acc += h->Lx[sitems[q].lpos] * y[sitems[q].ref];
+        h->scontrib[L.sext_dst[t.sext_off + x]] = acc;
+      }
+      for (uint32_t i = 0; i < t.n_col; ++i) {
+        uint32_t pj = L.col_perm[t.col_off + i];
+        h->zv[pj] = y[i] / h->D[pj];
+      }
+    }
+  for (int r = L.n_rounds - 1; r >= 0; --r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      std::vector<double> x(t.n_col);
+      const uint32_t* lvl = L.col_lvl_ptr.data() + t.lvl_off;
+      const uint32_t* bptr = L.bwd_ptr.data() + t.colptr_off;
+      const LdltSolveItem* items = L.bwd_items.data() + t.bwd_item_off;
+      for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+        std::vector<double> acc_v(lvl[l + 1] - lvl[l]);
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
+          uint32_t pj = L.col_perm[t.col_off + i];
+          double acc = h->zv[pj];
+          for (uint32_t q = bptr[i]; q < bptr[i + 1]; ++q) {
+            uint32_t ref = items[q].ref;
+            double xi = (ref & 0x80000000u) ? h->xg[ref & 0x7fffffffu] : x[ref];
+            acc -= h->Lx[items[q].lpos] * xi;
+          }
+          acc_v[i - lvl[l]] = acc;
+        }
+        for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) x[i] = acc_v[i - lvl[l]];
+      }
+      for (uint32_t i = 0; i < t.n_col; ++i) {
+        uint32_t pj = L.col_perm[t.col_off + i];
+        h->xg[pj] = x[i];
+        h->p[L.perm[pj]] = x[i];
+      }
+    }
+  if (p_out) std::copy(h->p.begin(), h->p.end(), p_out);
+}
+
+void hc_backsub(hc_handle* h, const double* s, const double* z, double mu, double* ps_out, double* pz_out) {
+  const auto& K = h->k;
+  const auto& st = h->s;
+  for (int r = 0; r < K.m_i; ++r) {
+    double aipx = 0.0;
+    for (int q = K.ai_rowptr[r]; q < K.ai_rowptr[r + 1]; ++q) aipx += h->V[K.ai_src[q]] * h->p[K.ai_col[q]];
+    double sinv = 1.0 / s[r];
+    double p_s = (h->V[st.off_ci + r] - s[r]) + aipx;
+    h->ps[r] = p_s;
+    h->pz[r] = mu * sinv - z[r] - (sinv * z[r]) * p_s;
+  }
+  if (ps_out) std::copy(h->ps.begin(), h->ps.begin() + K.m_i, ps_out);
+  if (pz_out) std::copy(h->pz.begin(), h->pz.begin() + K.m_i, pz_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Newton steps/s of the interior-point Newton step on the cart-pole direct-
+transcription problem (BASELINE.json: N=1000, single problem per GPU, fp64).
+
+One "step" = AD refresh {g, A_e, H} + KKT lhs/rhs assembly + regularized LDLᵀ
+(inertia-correcting loop, every attempt a device factorization) + solve + (p_s, p_z)
+back-substitution, i.e. interior_point.hpp:809-812 + :426-482, on inputs already
+resident in HBM (the seeded interior state of SURVEY.md §8d).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run (one rank per GPU): every rank steps its
+own replica(s) of the problem — the path has no cross-problem exchange (SURVEY.md
+§8e) — and the only collective is the MAX of the elapsed time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
+    """The oracle (CPU restatement of the reference path) timed on one host core."""
+    from tests.support import cases, oracle
+
+    oracle.lib().orc_reset()
+    op = oracle.OracleProblem.cart_pole(N, dt)
+    n, me, mi = op.dims
+    scales = op.scaling()
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+    op.newton_step(x, s, y, z, mu, True, None, False)  # includes analyzePattern
+    t0 = time.perf_counter()
+    steps = 0
+    phases = np.zeros(4)
+    while True:
+        _, t = op.newton_step(x, s, y, z, mu, True, None, True)
+        phases += np.array([t["t_ad"], t["t_build"], t["t_decomp"], t["t_solve"]])
+        steps += 1
+        if time.perf_counter() - t0 > budget_s or steps >= 200:
+            break
+    el = time.perf_counter() - t0
+    _, _, nfact, nnzL = op.reg()
+    return {
+        "value": steps / el, "unit": "Newton steps/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} steps of cart-pole N={N} (interior state), oracle/ single thread, "
+                  f"{nfact} factorizations/step, nnz(L)={nnzL}",
+        "ms_per_step": 1e3 * el / steps,
+        "phase_ms": {k: 1e3 * v / steps for k, v in
+                     zip(["ad_refresh", "kkt_build", "kkt_decomp", "kkt_solve"], phases)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--N", type=int, default=1000, help="horizon (BASELINE config: 1000)")
+    ap.add_argument("--batch", type=int, default=1, help="independent problems per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched-roofline", action="store_true")
+    ap.add_argument("--roofline-batch", type=int, default=128)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLC0415
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import sleipnir_amd as sa
+    from tests.support import cases
+
+    N = args.N
+    dt = 5.0 / N
+    sa.lib().slpx_graph_reset()
+    t0 = time.perf_counter()
+    pp = sa.Problem.cart_pole(N, dt)
+    t_model = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    system = sa.System(pp, batch=args.batch, device=local_rank)
+    t_compile = time.perf_counter() - t0
+    info = system.info
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
+
+    # scaling at x0 (problem_scaling.hpp:100-107) from an unscaled device sweep
+    x0 = pp.get_x()
+    B = args.batch
+    system.set_state(np.tile(x0, (B, 1)), np.ones((B, mi)), np.zeros((B, me)), np.ones((B, mi)),
+                     np.full(B, 0.1))
+    system.sweep(True)
+    V = system.get("V")[0]
+    gmax = np.max(np.abs(V[info["off_g"]:info["off_Ae"]])) if info["nnz_g"] else 0.0
+    scales = np.ones(1 + me + mi)
+    with np.errstate(divide="ignore"):
+        scales[0] = min(1.0, 100.0 / gmax) if gmax > 0 else 1.0
+        for which, off, cnt, base in ((1, "off_Ae", "nnz_Ae", 1), (2, "off_Ai", "nnz_Ai", 1 + me)):
+            cp, ri = system.pattern(which)
+            rn = np.zeros(me if which == 1 else mi)
+            np.maximum.at(rn, ri, np.abs(V[info[off]:info[off] + info[cnt]]))
+            scales[base:base + len(rn)] = np.minimum(100.0 / rn, 1.0)
+    system.set_scaling(scales)
+
+    # device-resident inputs: seeded interior states, one per problem
+    states = [cases.newton_state("interior", x0, n, me, mi, scales[0], seed=cases.SEED + rank * B + b)
+              for b in range(B)]
+    system.set_state(np.stack([s_[0] for s_ in states]), np.stack([s_[1] for s_ in states]),
+                     np.stack([s_[2] for s_ in states]), np.stack([s_[3] for s_ in states]),
+                     np.array([s_[4] for s_ in states]))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nfact_total = 0
+    for _ in range(args.warmup):
+        system.reset_regularization()
+        system.newton_step(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        system.reset_regularization()
+        info_step = system.newton_step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert np.all(info_step == 0), "factorization failed in the timed region"
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+
+    if rank == 0:
+        # per-kernel-group durations measured live with HIP events on the library's stream
+        system.reset_regularization()
+        kt = system.time_step(iters=max(10, min(100, args.steps)), refresh_ad=True)
+        nf = max(1.0, kt["factorizations"])
+        groups = {
+            "tape_sweep": (kt["sweep"], info["sweep_bytes"]),
+            "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
+            "kkt_rhs": (kt["rhs"], info["rhs_bytes"]),
+            "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
+            "ldlt_solve": (kt["solve"], info["solve_bytes"]),
+        }
+        dom = max(groups, key=lambda k: groups[k][0] * (nf if k == "ldlt_factor" else 1.0))
+        dom_ms, dom_bytes = groups[dom]
+        achieved = B * dom_bytes / (dom_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": B * dom_bytes, "launch_ms": dom_ms,
+            "per_kernel_ms": {k: v[0] for k, v in groups.items()},
+            "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None
+                                for k, v in groups.items()},
+            "factorizations_per_step": kt["factorizations"],
+            "note": "single N=1000 problem: every kernel is dependency-latency bound (SURVEY.md "
+                    "§7 hard part 1); HBM fractions are meaningful on the batched line below",
+        }
+        out = {
+            "metric": "Newton steps/sec, cart-pole direct-transcription N=%d" % N,
+            "value": world * B * args.steps / elapsed,
+            "unit": "Newton steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cart-pole direct transcription N=%d, %d problem(s) per GPU, "
+                                   "seeded interior IPM state, inputs resident in HBM" % (N, B),
+                       "n": n, "m_e": me, "m_i": mi, "nnz_lhs": info["nnz_lhs"],
+                       "nnz_L": info["nnz_L"], "etree_height": info["etree_height"],
+                       "ldlt_rounds": info["ldlt_rounds"], "ldlt_tasks": info["ldlt_tasks"],
+                       "tape_tasks": info["tape_tasks"], "tape_nodes": info["tape_nodes"],
+                       "tape_slots": info["tape_slots"], "multi_gpu": "replicas only"},
+            "ms_per_ldlt_factor": groups["ldlt_factor"][0],
+            "ms_per_ldlt_solve": groups["ldlt_solve"][0],
+            "setup_s": {"model": t_model, "compile_and_upload": t_compile},
+            "roofline": roofline,
+        }
+        if not args.no_batched_roofline and world == 1 and B == 1:
+            # the configuration on which HBM-roofline claims are measurable
+            RB = args.roofline_batch
+            sysb = sa.System(pp, batch=RB, device=local_rank)
+            sysb.set_scaling(scales)
+            st = [cases.newton_state("interior", x0, n, me, mi, scales[0], seed=cases.SEED + b)
+                  for b in range(RB)]
+            sysb.set_state(np.stack([s_[0] for s_ in st]), np.stack([s_[1] for s_ in st]),
+                           np.stack([s_[2] for s_ in st]), np.stack([s_[3] for s_ in st]),
+                           np.array([s_[4] for s_ in st]))
+            for _ in range(3):
+                sysb.reset_regularization()
+                sysb.newton_step(True)
+            sysb.reset_regularization()
+            kb = sysb.time_step(iters=10, refresh_ad=True)
+            nfb = max(1.0, kb["factorizations"])
+            gb = {"tape_sweep": (kb["sweep"], info["sweep_bytes"]),
+                  "kkt_assemble": (kb["assemble"], info["assemble_bytes"]),
+                  "kkt_rhs": (kb["rhs"], info["rhs_bytes"]),
+                  "ldlt_factor": (kb["factor"] / nfb, info["factor_bytes"]),
+                  "ldlt_solve": (kb["solve"], info["solve_bytes"])}
+            out["batched"] = {
+                "batch": RB, "steps_per_s": RB / (kb["total"] * 1e-3),
+                "per_kernel_ms": {k: v[0] for k, v in gb.items()},
+                "per_kernel_GBps": {k: RB * v[1] / (v[0] * 1e-3) / 1e9 for k, v in gb.items()},
+                "per_kernel_hbm_frac": {k: RB * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                        for k, v in gb.items()},
+                "factorizations_per_step": kb["factorizations"],
+            }
+            sysb.close()
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(N, dt)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    system.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

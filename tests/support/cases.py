@@ -1,0 +1,76 @@
+"""Shared test cases: the synthetic Newton-step inputs of SURVEY.md §8(d) and the
+comparison helpers used by both the CPU (host-check) and GPU parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 20260928
+
+
+def build_pair(kind: str, N: int, sa, oracle):
+    """Builds the same benchmark problem in the product and in the oracle."""
+    dt = 5.0 / N
+    if kind == "cart_pole":
+        return sa.Problem.cart_pole(N, dt), oracle.OracleProblem.cart_pole(N, dt)
+    if kind == "flywheel":
+        return sa.Problem.flywheel(N, dt), oracle.OracleProblem.flywheel(N, dt)
+    raise ValueError(kind)
+
+
+def newton_state(case: str, x0, n, m_e, m_i, d_f, seed=SEED):
+    """step0: interior_point.hpp:74-79 initial iterate.  interior: seeded perturbation."""
+    if case == "step0":
+        return x0.copy(), np.ones(m_i), np.zeros(m_e), np.ones(m_i), 0.1 * d_f
+    rng = np.random.default_rng(seed)
+    x = x0 + 1e-2 * rng.uniform(-1, 1, n)
+    s = np.exp(rng.uniform(-2, 2, m_i))
+    z = np.exp(rng.uniform(-2, 2, m_i))
+    y = rng.uniform(-1, 1, m_e)
+    return x, s, y, z, 0.1 * d_f
+
+
+def csc_to_dict(colptr, rowidx, val):
+    d = {}
+    for c in range(len(colptr) - 1):
+        for p in range(colptr[c], colptr[c + 1]):
+            d[(int(rowidx[p]), c)] = d.get((int(rowidx[p]), c), 0.0) + float(val[p])
+    return d
+
+
+def lower_csc_to_dense_sym(colptr, rowidx, val, n):
+    a = np.zeros((n, n))
+    for c in range(n):
+        for p in range(colptr[c], colptr[c + 1]):
+            a[rowidx[p], c] += val[p]
+            if rowidx[p] != c:
+                a[c, rowidx[p]] += val[p]
+    return a
+
+
+def lower_csc_matvec(colptr, rowidx, val, x):
+    """y = K x for a symmetric K given by its lower triangle."""
+    y = np.zeros_like(x)
+    for c in range(len(colptr) - 1):
+        for p in range(colptr[c], colptr[c + 1]):
+            r = rowidx[p]
+            y[r] += val[p] * x[c]
+            if r != c:
+                y[c] += val[p] * x[r]
+    return y
+
+
+def regularized(colptr, rowidx, val, n, delta, gamma):
+    """lhs + [δI 0; 0 −γI] on a lower CSC with a full diagonal."""
+    out = np.array(val, dtype=np.float64, copy=True)
+    for c in range(len(colptr) - 1):
+        for p in range(colptr[c], colptr[c + 1]):
+            if rowidx[p] == c:
+                out[p] += delta if c < n else -gamma
+    return out
+
+
+def max_rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))

@@ -1,0 +1,152 @@
+"""One Newton step compared piece by piece against the oracle.
+
+`backend` is either tests.support.hostcheck.HostCheck (CPU interpretation of the
+compiled plans) or GpuBackend below (the HIP kernels through the C-ABI); both offer
+sweep/assemble/rhs/factor/solve/backsub with identical signatures.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import cases
+
+
+class GpuBackend:
+    """Adapter: sleipnir_amd.System (batch 1) with the HostCheck call signatures."""
+
+    def __init__(self, system):
+        self.sys = system
+        self.info = system.info
+        self.n, self.m_e, self.m_i = system.info["n"], system.info["m_e"], system.info["m_i"]
+        self._mu = 0.0
+
+    def pattern(self, which):
+        return self.sys.pattern(which)
+
+    def perm(self):
+        return self.sys.perm()
+
+    def set_scaling(self, scales):
+        self.sys.set_scaling(scales)
+
+    def sweep(self, x, y=None, z=None, full=True):
+        y = np.zeros(self.m_e) if y is None else y
+        z = np.zeros(self.m_i) if z is None else z
+        self.sys.set_state(x=x, s=np.ones(self.m_i), y=y, z=z)
+        self.sys.sweep(full)
+        return self.sys.get("V")[0]
+
+    def assemble(self, s, z):
+        self.sys.set_state(s=s, z=z)
+        self.sys.assemble()
+        return self.sys.get("lhs")[0]
+
+    def rhs(self, s, y, z, mu):
+        self._mu = mu
+        self.sys.set_state(s=s, y=y, z=z, mu=np.array([mu]))
+        self.sys.rhs()
+        return self.sys.get("rhs")[0]
+
+    def set_rhs(self, rhs):
+        self.sys.set_rhs(rhs)
+
+    def factor(self, delta, gamma):
+        stats = self.sys.factor(delta, gamma)[0]
+        return self.sys.get("D")[0], stats
+
+    def solve(self):
+        self.sys.solve()
+        return self.sys.get("p")[0]
+
+    def backsub(self, s, z, mu):
+        self.sys.set_state(s=s, z=z, mu=np.array([mu]))
+        self.sys.backsub()
+        return self.sys.get("p_s")[0], self.sys.get("p_z")[0]
+
+
+def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=1e-8, verbose=False):
+    """Runs the step on `backend` and on the oracle `op` (same permutation) and asserts
+    agreement.  Returns a dict of the observed errors."""
+    n, me, mi = backend.n, backend.m_e, backend.m_i
+    I = backend.info
+    scales = op.scaling()
+    backend.set_scaling(scales)
+    x0 = op.get_x()
+    x, s, y, z, mu = cases.newton_state(case, x0, n, me, mi, scales[0])
+    perm = backend.perm()
+    info, _ = op.newton_step(x, s, y, z, mu, True, perm)
+    errs = {}
+
+    V = backend.sweep(x, y, z, True)
+    errs["f"] = abs(V[0] - op.f()) / max(1.0, abs(op.f()))
+    errs["c_e"] = cases.max_rel(V[1:1 + me], op.vec("c_e"))
+    errs["c_i"] = cases.max_rel(V[1 + me:1 + me + mi], op.vec("c_i"))
+    cp, ri = backend.pattern(0)
+    g = np.zeros(n)
+    for c in range(n):
+        for p in range(cp[c], cp[c + 1]):
+            g[c] += V[I["off_g"] + p]
+    errs["g"] = cases.max_rel(g, op.vec("g"))
+    for name, which, off in (("A_e", 1, "off_Ae"), ("A_i", 2, "off_Ai")):
+        cp, ri = backend.pattern(which)
+        ocp, ori, ov = op.csc(name)
+        assert np.array_equal(cp, ocp) and np.array_equal(ri, ori), f"{name} pattern differs"
+        errs[name] = cases.max_rel(V[I[off]:I[off] + len(ri)], ov)
+    # H = d_f H_f + H_c: compare through the oracle's H (lower)
+    hcp, hri = backend.pattern(3)
+    ccp, cri = backend.pattern(4)
+    H = cases.csc_to_dict(hcp, hri, V[I["off_Hf"]:I["off_Hf"] + len(hri)])
+    for k, v in cases.csc_to_dict(ccp, cri, V[I["off_Hc"]:I["off_Hc"] + len(cri)]).items():
+        H[k] = H.get(k, 0.0) + v
+    ocp, ori, ov = op.csc("H")
+    Ho = cases.csc_to_dict(ocp, ori, ov)
+    assert set(Ho.keys()) == set(H.keys()), "H pattern differs"
+    hmax = max([1.0] + [abs(v) for v in Ho.values()])
+    errs["H"] = max([0.0] + [abs(H[k] - Ho[k]) for k in Ho]) / hmax
+    for k in ("f", "c_e", "c_i", "g", "A_e", "A_i", "H"):
+        assert errs[k] <= tol_ad, f"{case}: {k} differs from the oracle by {errs[k]:.3e}"
+
+    lhs = backend.assemble(s, z)
+    lcp, lri = backend.pattern(5)
+    ocp, ori, ov = op.csc("lhs")
+    L = cases.csc_to_dict(lcp, lri, lhs)
+    Lo = cases.csc_to_dict(ocp, ori, ov)
+    assert set(Lo.keys()) <= set(L.keys())
+    # entries the product has and the oracle's lhs lacks are the forced diagonal zeros
+    for k in set(L.keys()) - set(Lo.keys()):
+        assert k[0] == k[1] and L[k] == 0.0
+    lmax = max([1.0] + [abs(v) for v in Lo.values()])
+    errs["lhs"] = max(abs(L[k] - Lo[k]) for k in Lo) / lmax
+    rhs = backend.rhs(s, y, z, mu)
+    errs["rhs"] = cases.max_rel(rhs, op.vec("rhs"))
+    assert errs["lhs"] <= tol_kkt and errs["rhs"] <= tol_kkt, (errs["lhs"], errs["rhs"])
+
+    delta, gamma, nfact, nnzL = op.reg()
+    assert info == 0
+    D, stats = backend.factor(delta, gamma)
+    Do = op.vec("D")
+    # same inertia verdict as the oracle under the same permutation
+    eps = np.finfo(float).eps
+    oracle_inertia = (int(np.sum(Do > eps)), int(np.sum(Do < -eps)), int(np.sum(np.abs(Do) <= eps)))
+    assert tuple(int(v) for v in stats[:3]) == oracle_inertia, (stats, oracle_inertia)
+    assert stats[3] == 0
+    errs["D_rel"] = float(np.max(np.abs(D - Do) / np.maximum(np.abs(Do), 1e-300)))
+    p = backend.solve()
+    # residual of the regularized system actually factored
+    Kreg = cases.regularized(lcp, lri, lhs, n, delta, gamma)
+    r_backend = cases.lower_csc_matvec(lcp, lri, Kreg, p) - rhs
+    po = op.vec("p")
+    r_oracle = cases.lower_csc_matvec(lcp, lri, Kreg, po) - rhs
+    scale = max(1.0, float(np.max(np.abs(rhs))))
+    errs["resid"] = float(np.max(np.abs(r_backend))) / scale
+    errs["resid_oracle"] = float(np.max(np.abs(r_oracle))) / scale
+    errs["p"] = cases.max_rel(p, po)
+    ps, pz = backend.backsub(s, z, mu)
+    errs["p_s"] = cases.max_rel(ps, op.vec("p_s"))
+    errs["p_z"] = cases.max_rel(pz, op.vec("p_z"))
+    if verbose:
+        print(case, {k: f"{v:.2e}" for k, v in errs.items()}, "reg", (delta, gamma), "stats", stats)
+    # the linear solve is judged by its residual (the north star's measure), which must
+    # be as good as the oracle's up to a small factor, and by the step itself
+    assert errs["resid"] <= max(tol_resid, 10.0 * errs["resid_oracle"]), errs
+    return errs

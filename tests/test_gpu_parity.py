@@ -1,0 +1,142 @@
+"""GPU tier: the HIP kernels, called through the C-ABI (include/slpx.h), against the
+oracle on identical inputs — AD sweep, KKT lhs/rhs, LDLᵀ factor/solve, back-
+substitution (interior_point.hpp:245-251, :426-482) — and whole solves against the
+reference's known answers."""
+import numpy as np
+import pytest
+
+from tests.support import cases, parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 4), ("cart_pole", 37), ("cart_pole", 100),
+                                    ("flywheel", 50)])
+@pytest.mark.parametrize("case", ["step0", "interior"])
+def test_newton_step_matches_oracle(fresh, slpx, orc, kind, N, case):
+    pp, op = cases.build_pair(kind, N, slpx, orc)
+    system = slpx.System(pp, batch=1, device=0)
+    parity.check_newton_step(parity.GpuBackend(system), op, case, verbose=True)
+    system.close()
+
+
+def test_gpu_matches_plan_interpreter_bitwise_class(fresh, slpx, orc, hostcheck):
+    """Kernel vs sequential interpretation of the same plans: only FMA contraction
+    and libm differences may remain."""
+    pp, op = cases.build_pair("cart_pole", 50, slpx, orc)
+    n, me, mi = pp.dims
+    system = slpx.System(pp, batch=1, device=0)
+    gb = parity.GpuBackend(system)
+    hc = hostcheck.HostCheck(pp)
+    scales = op.scaling()
+    gb.set_scaling(scales)
+    hc.set_scaling(scales)
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+    Vg, Vh = gb.sweep(x, y, z), hc.sweep(x, y, z)
+    assert cases.max_rel(Vg, Vh) < 1e-12
+    lg, lh = gb.assemble(s, z), hc.assemble(s, z)
+    assert cases.max_rel(lg, lh) < 1e-12
+    rg, rh = gb.rhs(s, y, z, mu), hc.rhs(s, y, z, mu)
+    assert cases.max_rel(rg, rh) < 1e-12
+    hc.set_lhs(lg)
+    hc.set_rhs(rg)
+    Dg, sg = gb.factor(1e-4, 1e-10)
+    Dh, sh = hc.factor(1e-4, 1e-10)
+    assert np.array_equal(sg[:4], sh[:4])
+    # pivots of the γ=1e-10-regularized system span 20 orders of magnitude; individual
+    # small pivots are cancellation-limited, so compare the bulk and the solve residual
+    rel = np.abs(Dg - Dh) / np.abs(Dh)
+    assert np.median(rel) < 1e-12 and np.max(rel) < 1e-1
+    pg, ph = gb.solve(), hc.solve()
+    lcp, lri = gb.pattern(5)
+    Kreg = cases.regularized(lcp, lri, lg, n, 1e-4, 1e-10)
+    scale = max(1.0, float(np.max(np.abs(rg))))
+    for p in (pg, ph):
+        assert np.max(np.abs(cases.lower_csc_matvec(lcp, lri, Kreg, p) - rg)) / scale < 1e-8
+    system.close()
+
+
+def test_batch_items_are_independent(fresh, slpx, orc):
+    """Batch of 3 value sets through one launch == three single runs."""
+    pp, op = cases.build_pair("cart_pole", 20, slpx, orc)
+    n, me, mi = pp.dims
+    scales = op.scaling()
+    states = [cases.newton_state("interior", op.get_x(), n, me, mi, scales[0], seed=cases.SEED + b)
+              for b in range(3)]
+    single = []
+    sys1 = slpx.System(pp, batch=1, device=0)
+    sys1.set_scaling(scales)
+    for (x, s, y, z, mu) in states:
+        sys1.reset_regularization()
+        sys1.set_state(x, s, y, z, np.array([mu]))
+        info = sys1.newton_step(True)
+        assert info[0] == 0
+        single.append((sys1.get("p")[0].copy(), sys1.get("p_s")[0].copy(), sys1.get("p_z")[0].copy()))
+    sys1.close()
+    sys3 = slpx.System(pp, batch=3, device=0)
+    sys3.set_scaling(scales)
+    X = np.stack([st[0] for st in states])
+    S = np.stack([st[1] for st in states])
+    Y = np.stack([st[2] for st in states])
+    Z = np.stack([st[3] for st in states])
+    MU = np.array([st[4] for st in states])
+    sys3.set_state(X, S, Y, Z, MU)
+    info = sys3.newton_step(True)
+    assert np.all(info == 0)
+    P, PS, PZ = sys3.get("p"), sys3.get("p_s"), sys3.get("p_z")
+    for b in range(3):
+        assert np.array_equal(P[b], single[b][0])
+        assert np.array_equal(PS[b], single[b][1])
+        assert np.array_equal(PZ[b], single[b][2])
+    sys3.close()
+
+
+def test_flywheel_solve_matches_reference_known_answer(fresh, slpx, orc):
+    """benchmarks/scalability/flywheel + test/src/optimization/flywheel_problem_test.cpp:
+    bang-then-hold input, final state r = 10 (:112, :122)."""
+    N, T = 50, 5.0
+    dt = T / N
+    pp, op = cases.build_pair("flywheel", N, slpx, orc)
+    status, rep = pp.solve()
+    assert status == 0, rep
+    x = pp.get_x()
+    X, U = x[:N + 1], x[N + 1:]
+    ostatus, _ = op.solve()
+    assert ostatus == 0
+    xo = op.get_x()
+    assert np.max(np.abs(x - xo)) < 1e-6
+    A, B = np.exp(-dt), 1.0 - np.exp(-dt)
+    assert abs(X[0]) < 1e-8
+    assert np.all(U <= 12.0 + 1e-6) and np.all(U >= -12.0 - 1e-6)
+    for k in range(N):
+        assert abs(X[k + 1] - (A * X[k] + B * U[k])) < 1e-8
+
+
+def test_cart_pole_solve(fresh, slpx, orc):
+    """test/src/optimization/cart_pole_problem_test.cpp:87-124 at N=100, dt=0.05:
+    SUCCESS, boundary states and bounds hold, every dynamics defect <= 1e-8 (checked
+    through the oracle's constraint evaluation at the returned point)."""
+    N = 100
+    pp, op = cases.build_pair("cart_pole", N, slpx, orc)
+    status, rep = pp.solve()
+    print(rep)
+    assert status == 0, rep
+    x = pp.get_x()
+    n, me, mi = pp.dims
+    X = x[:4 * (N + 1)].reshape(4, N + 1)
+    U = x[4 * (N + 1):]
+    assert np.max(np.abs(X[:, 0])) < 1e-8
+    assert np.max(np.abs(X[:, N] - np.array([1.0, np.pi, 0.0, 0.0]))) < 1e-8
+    assert np.all(X[0] >= -1e-8) and np.all(X[0] <= 2.0 + 1e-8)
+    assert np.all(np.abs(U) <= 20.0 + 1e-8)
+    # constraint residuals at the GPU solution, evaluated by the oracle (unscaled)
+    scales = op.scaling()
+    op.newton_step(x, np.ones(mi), np.zeros(me), np.ones(mi), 0.1, do_solve=False)
+    c_e = op.vec("c_e") / scales[1:1 + me]
+    assert np.max(np.abs(c_e)) < 1e-8
+    # same optimum as the oracle's own solve (cost within 1e-6 relative)
+    ostatus, _ = op.solve()
+    assert ostatus == 0
+    xo = op.get_x()
+    Jg, Jo = float(np.sum(U ** 2)), float(np.sum(xo[4 * (N + 1):] ** 2))
+    assert abs(Jg - Jo) <= 1e-6 * max(1.0, abs(Jo)), (Jg, Jo)

@@ -59,6 +59,9 @@ int32_t slpx_expr_binary(int op, int32_t a, int32_t b); /* x*y, pow(x,y), ...   
 int slpx_expr_type(int32_t id);                         /* Variable::type()    variable.hpp:153 */
 double slpx_expr_value(int32_t id);                     /* Variable::value()   variable.hpp:143 */
 void slpx_expr_set_value(int32_t id, double value);     /* Variable::set_value variable.hpp:125 */
+/* Symbolic gradient: Gradient::get() / detail::gradient_tree (variable_matrix.hpp:1757-1805).
+ * out[i] = expression id of d f / d wrt[i], or -1 when wrt[i] is unreachable from f. */
+void slpx_expr_gradient_tree(int32_t f, const int32_t* wrt, int32_t n, int32_t* out);
 
 /* ---- problem ------------------------------------------------------------------
  * Replaces: slp::Problem<double> (include/sleipnir/optimization/problem.hpp):
@@ -68,6 +71,8 @@ void slpx_expr_set_value(int32_t id, double value);     /* Variable::set_value v
 slpx_problem* slpx_problem_create(void);
 void slpx_problem_destroy(slpx_problem* p);
 int32_t slpx_problem_decision_variable(slpx_problem* p);
+/* Registers an existing free variable (slpx_expr_variable) as a decision variable. */
+void slpx_problem_adopt_variable(slpx_problem* p, int32_t var);
 void slpx_problem_minimize(slpx_problem* p, int32_t cost);
 void slpx_problem_maximize(slpx_problem* p, int32_t objective);
 void slpx_problem_subject_to_eq(slpx_problem* p, int32_t c);

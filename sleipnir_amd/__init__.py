@@ -97,6 +97,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_expr_type", ctypes.c_int, i32)
     sig("slpx_expr_value", f64, i32)
     sig("slpx_expr_set_value", None, i32, f64)
+    sig("slpx_expr_gradient_tree", None, i32, vp, i32, vp)
     sig("slpx_problem_create", vp)
     sig("slpx_problem_destroy", None, vp)
     sig("slpx_problem_decision_variable", i32, vp)

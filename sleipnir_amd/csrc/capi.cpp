@@ -51,10 +51,19 @@ int32_t slpx_expr_binary(int op, int32_t a, int32_t b) {
 int slpx_expr_type(int32_t id) { return slpx::graph().type[id]; }
 double slpx_expr_value(int32_t id) { return slpx::graph().value(id); }
 void slpx_expr_set_value(int32_t id, double value) { slpx::graph().val[id] = value; }
+void slpx_expr_gradient_tree(int32_t f, const int32_t* wrt, int32_t n, int32_t* out) {
+  auto& g = slpx::graph();
+  std::vector<slpx::NodeId> w(wrt, wrt + n);
+  auto grad = g.gradient_tree(g.topological_sort(f), w);
+  for (int32_t i = 0; i < n; ++i) out[i] = grad[i];
+}
 
 slpx_problem* slpx_problem_create(void) { return new slpx_problem(); }
 void slpx_problem_destroy(slpx_problem* p) { delete p; }
 int32_t slpx_problem_decision_variable(slpx_problem* p) { return p->problem.decision_variable().expr; }
+void slpx_problem_adopt_variable(slpx_problem* p, int32_t var) {
+  p->problem.adopt_decision_variable(slp::Variable::wrap(var));
+}
 void slpx_problem_minimize(slpx_problem* p, int32_t cost) { p->problem.minimize(slp::Variable::wrap(cost)); }
 void slpx_problem_maximize(slpx_problem* p, int32_t objective) {
   p->problem.maximize(slp::Variable::wrap(objective));

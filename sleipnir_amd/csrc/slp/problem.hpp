@@ -47,6 +47,10 @@ class Problem {
     return vars;
   }
 
+  // FFI helper (no reference counterpart): make an already-created free Variable a
+  // decision variable of this problem.
+  void adopt_decision_variable(const Variable& v) { m_decision_variables.push_back(v); }
+
   // problem.hpp:118-140
   [[nodiscard]] VariableMatrix symmetric_decision_variable(int rows) {
     VariableMatrix vars{detail::empty, rows, rows};

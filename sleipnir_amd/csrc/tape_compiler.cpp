@@ -389,8 +389,10 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     NodeId s = cg.src[n];
     if (cg.op[n] == OP_CONST) return kLeafConstFlag | const_index(g.val[s]);
     auto it = input_of.find(s);
-    if (it == input_of.end())
-      throw std::runtime_error("compile_tape: expression depends on a variable that is not a tape input");
+    // A free Variable that is not a decision variable acts as a parameter: in the
+    // reference it is just a leaf holding its current value during solve().  Its
+    // value is frozen into the tape at compile time.
+    if (it == input_of.end()) return kLeafConstFlag | const_index(g.val[s]);
     return static_cast<uint32_t>(it->second);
   };
 

@@ -7,6 +7,7 @@
 // against the oracle without a GPU.  The kernels themselves are validated on the
 // GPU by the `-m gpu` parity tests.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -85,11 +86,27 @@ void run_tape(const TapeProgram& P, const std::vector<double>& in, const std::ve
 
 }  // namespace
 
+static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t perm_len,
+                     int32_t task_entries, int32_t small_lds_bytes);
+
 extern "C" {
 
 hc_handle* hc_create(slpx_problem* p, const int32_t* perm, int32_t perm_len, int32_t task_entries,
                      int32_t small_lds_bytes) {
   auto* h = new hc_handle();
+  try {
+    hc_build(h, p, perm, perm_len, task_entries, small_lds_bytes);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "hc_create: %s\n", e.what());
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+}  // extern "C"
+
+static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t perm_len,
+                     int32_t task_entries, int32_t small_lds_bytes) {
   std::vector<NodeId> xs, ce, ci;
   for (auto& v : p->problem.decision_variables()) xs.push_back(v.expr);
   for (auto& v : p->problem.equality_constraints()) ce.push_back(v.expr);
@@ -123,8 +140,9 @@ hc_handle* hc_create(slpx_problem* p, const int32_t* perm, int32_t perm_len, int
   h->p.assign(h->k.dim, 0.0);
   h->ps.assign(std::max(1, h->s.m_i), 0.0);
   h->pz.assign(std::max(1, h->s.m_i), 0.0);
-  return h;
 }
+
+extern "C" {
 void hc_destroy(hc_handle* h) { delete h; }
 
 // out[0..] = n, m_e, m_i, nV, nnz_lhs, nnzL, rounds, tasks, etree height, pairs,

@@ -1,0 +1,304 @@
+"""A tiny modelling layer over the two expression-graph C-ABIs (oracle: orc_*,
+product: slpx_expr_* / slpx_problem_*), shaped like the reference's Python API
+(python/src/sleipnir/autodiff) so the reference's unit tests can be re-expressed
+almost verbatim and run against BOTH implementations.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import oracle as _oracle
+
+OPS = _oracle.OPS  # identical numbering on both sides
+
+
+class Backend:
+    name = "?"
+
+    def var(self, value=0.0):
+        raise NotImplementedError
+
+    def const(self, value):
+        raise NotImplementedError
+
+
+class OracleBackend(Backend):
+    name = "oracle"
+
+    def __init__(self):
+        self.L = _oracle.lib()
+
+    def reset(self):
+        self.L.orc_reset()
+
+    def var(self, value=0.0):
+        return self.L.orc_var(float(value))
+
+    def const(self, value):
+        return self.L.orc_const(float(value))
+
+    def unary(self, op, a):
+        return self.L.orc_unary(op, a)
+
+    def binary(self, op, a, b):
+        return self.L.orc_binary(op, a, b)
+
+    def value(self, i):
+        return self.L.orc_value(i)
+
+    def set_value(self, i, v):
+        self.L.orc_set_value(i, float(v))
+
+    def type(self, i):
+        return self.L.orc_type(i)
+
+    def gradient_tree(self, f, wrt):
+        w = np.asarray(wrt, dtype=np.int32)
+        out = np.zeros(len(w), dtype=np.int32)
+        self.L.orc_gradient_tree(f, w.ctypes.data, len(w), out.ctypes.data)
+        return [int(v) for v in out]
+
+    def jacobian(self, rows, wrt):
+        r = np.asarray(rows, dtype=np.int32)
+        w = np.asarray(wrt, dtype=np.int32)
+        out = np.zeros((len(r), len(w)))
+        self.L.orc_jacobian(r.ctypes.data, len(r), w.ctypes.data, len(w), out.ctypes.data)
+        return out
+
+    def hessian(self, f, wrt, lower=False):
+        w = np.asarray(wrt, dtype=np.int32)
+        out = np.zeros((len(w), len(w)))
+        self.L.orc_hessian(f, w.ctypes.data, len(w), int(lower), out.ctypes.data)
+        return out
+
+
+class ProductBackend(Backend):
+    """Product graph (libslpx).  Derivatives go through the REAL pipeline: the
+    expression becomes cost / equality rows of an slp::Problem whose wrt variables are
+    the decision variables, the NLP structure + tape are compiled, and g / A_e / H are
+    read out of the value vector V — executed by `runner`:
+      * "hostcheck": sequential host interpretation of the compiled plans (CPU tier)
+      * "gpu":       the HIP kernels through slpx_system_* (GPU tier)"""
+
+    def __init__(self, runner="hostcheck"):
+        import sleipnir_amd
+
+        self.sa = sleipnir_amd
+        self.L = sleipnir_amd.lib()
+        self.runner = runner
+        self.name = "product-" + runner
+
+    def reset(self):
+        self.L.slpx_graph_reset()
+
+    def var(self, value=0.0):
+        return self.L.slpx_expr_variable(float(value))
+
+    def const(self, value):
+        return self.L.slpx_expr_constant(float(value))
+
+    def unary(self, op, a):
+        return self.L.slpx_expr_unary(op, a)
+
+    def binary(self, op, a, b):
+        return self.L.slpx_expr_binary(op, a, b)
+
+    def value(self, i):
+        return self.L.slpx_expr_value(i)
+
+    def set_value(self, i, v):
+        self.L.slpx_expr_set_value(i, float(v))
+
+    def type(self, i):
+        return self.L.slpx_expr_type(i)
+
+    def gradient_tree(self, f, wrt):
+        w = np.asarray(wrt, dtype=np.int32)
+        out = np.zeros(len(w), dtype=np.int32)
+        self.L.slpx_expr_gradient_tree(f, w.ctypes.data, len(w), out.ctypes.data)
+        return [int(v) for v in out]
+
+    # -- pipeline evaluation ---------------------------------------------------
+    def _run(self, f, rows, wrt):
+        """Returns (info, patterns, V) for cost f (or None) and equality rows."""
+        import ctypes
+
+        sa = self.sa
+        p = sa.Problem()
+        # adopt the existing variable nodes as the problem's decision variables
+        from sleipnir_amd import lib
+
+        L = lib()
+        if not hasattr(L, "_adopt_ready"):
+            L.slpx_problem_adopt_variable.restype = None
+            L.slpx_problem_adopt_variable.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+            L._adopt_ready = True
+        for w in wrt:
+            L.slpx_problem_adopt_variable(p._h, int(w))
+        if f is not None:
+            p.minimize(int(f))
+        for r in rows:
+            p.subject_to_eq(int(r))
+        x = np.array([self.value(int(w)) for w in wrt])
+        if self.runner == "hostcheck":
+            from . import hostcheck
+
+            hc = hostcheck.HostCheck(p)
+            V = hc.sweep(x, np.zeros(len(rows)), None, True)
+            info = hc.info
+            pats = {k: hc.pattern(k) for k in (0, 1, 3)}
+            hc.close()
+        else:
+            system = sa.System(p, batch=1, device=0)
+            system.set_state(x, np.ones(1), np.zeros(max(1, len(rows))), np.ones(1), np.array([0.1]))
+            system.sweep(True)
+            V = system.get("V")[0]
+            info = system.info
+            pats = {k: system.pattern(k) for k in (0, 1, 3)}
+            system.close()
+        p.close()
+        return info, pats, V
+
+    def jacobian(self, rows, wrt):
+        n = len(wrt)
+        if len(rows) == 1:
+            info, pats, V = self._run(rows[0], [], wrt)
+            cp, ri = pats[0]
+            out = np.zeros((1, n))
+            for c in range(n):
+                for q in range(cp[c], cp[c + 1]):
+                    out[0, c] += V[info["off_g"] + q]
+            return out
+        info, pats, V = self._run(None, rows, wrt)
+        cp, ri = pats[1]
+        out = np.zeros((len(rows), n))
+        for c in range(n):
+            for q in range(cp[c], cp[c + 1]):
+                out[ri[q], c] += V[info["off_Ae"] + q]
+        return out
+
+    def hessian(self, f, wrt, lower=False):
+        n = len(wrt)
+        info, pats, V = self._run(f, [], wrt)
+        cp, ri = pats[3]
+        out = np.zeros((n, n))
+        for c in range(n):
+            for q in range(cp[c], cp[c + 1]):
+                out[ri[q], c] += V[info["off_Hf"] + q]
+                if not lower and ri[q] != c:
+                    out[c, ri[q]] += V[info["off_Hf"] + q]
+        return out
+
+
+class Var:
+    """slp.Variable look-alike bound to a backend."""
+
+    __array_priority__ = 1000
+
+    def __init__(self, be: Backend, node: int):
+        self.be = be
+        self.node = node
+
+    @staticmethod
+    def _lift(be, v):
+        return v if isinstance(v, Var) else Var(be, be.const(float(v)))
+
+    def _bin(self, op, other, swap=False):
+        o = Var._lift(self.be, other)
+        a, b = (o, self) if swap else (self, o)
+        return Var(self.be, self.be.binary(OPS[op], a.node, b.node))
+
+    def __add__(self, o): return self._bin("ADD", o)
+    def __radd__(self, o): return self._bin("ADD", o, True)
+    def __sub__(self, o): return self._bin("SUB", o)
+    def __rsub__(self, o): return self._bin("SUB", o, True)
+    def __mul__(self, o): return self._bin("MUL", o)
+    def __rmul__(self, o): return self._bin("MUL", o, True)
+    def __truediv__(self, o): return self._bin("DIV", o)
+    def __rtruediv__(self, o): return self._bin("DIV", o, True)
+    def __neg__(self): return Var(self.be, self.be.unary(OPS["NEG"], self.node))
+    def __pos__(self): return self
+    def __pow__(self, o): return self._bin("POW", o)
+    def __rpow__(self, o): return self._bin("POW", o, True)
+
+    def value(self): return self.be.value(self.node)
+    def set_value(self, v): self.be.set_value(self.node, v)
+    def type(self): return self.be.type(self.node)
+
+
+class Model:
+    """Factory bound to one backend: m.variable(), m.sin(x), m.gradient(f, x) ..."""
+
+    def __init__(self, be: Backend):
+        self.be = be
+
+    def variable(self, value=0.0):
+        return Var(self.be, self.be.var(value))
+
+    def constant(self, value):
+        return Var(self.be, self.be.const(value))
+
+    def _un(self, op, x):
+        x = Var._lift(self.be, x)
+        return Var(self.be, self.be.unary(OPS[op], x.node))
+
+    def _bi(self, op, a, b):
+        a, b = Var._lift(self.be, a), Var._lift(self.be, b)
+        return Var(self.be, self.be.binary(OPS[op], a.node, b.node))
+
+    def abs(self, x): return self._un("ABS", x)
+    def acos(self, x): return self._un("ACOS", x)
+    def asin(self, x): return self._un("ASIN", x)
+    def atan(self, x): return self._un("ATAN", x)
+    def cbrt(self, x): return self._un("CBRT", x)
+    def cos(self, x): return self._un("COS", x)
+    def cosh(self, x): return self._un("COSH", x)
+    def erf(self, x): return self._un("ERF", x)
+    def exp(self, x): return self._un("EXP", x)
+    def log(self, x): return self._un("LOG", x)
+    def log10(self, x): return self._un("LOG10", x)
+    def sign(self, x): return self._un("SIGN", x)
+    def sin(self, x): return self._un("SIN", x)
+    def sinh(self, x): return self._un("SINH", x)
+    def sqrt(self, x): return self._un("SQRT", x)
+    def tan(self, x): return self._un("TAN", x)
+    def tanh(self, x): return self._un("TANH", x)
+    def atan2(self, y, x): return self._bi("ATAN2", y, x)
+    def max(self, a, b): return self._bi("MAX", a, b)
+    def min(self, a, b): return self._bi("MIN", a, b)
+    def pow(self, a, b): return self._bi("POW", a, b)
+
+    def hypot(self, x, y, z=None):
+        if z is None:
+            return self._bi("HYPOT", x, y)
+        # variable.hpp:711-714
+        return self.sqrt(self.pow(x, 2) + self.pow(y, 2) + self.pow(z, 2))
+
+    # Gradient(f, wrt).value()
+    def gradient(self, f, wrt):
+        wrt = wrt if isinstance(wrt, (list, tuple)) else [wrt]
+        return self.be.jacobian([f.node], [w.node for w in wrt])[0]
+
+    # Gradient(f, wrt).get().value(): symbolic tree, then evaluated
+    def gradient_symbolic(self, f, wrt):
+        wrt = wrt if isinstance(wrt, (list, tuple)) else [wrt]
+        ids = self.be.gradient_tree(f.node, [w.node for w in wrt])
+        return np.array([0.0 if i < 0 else self.be.value(i) for i in ids])
+
+    def jacobian(self, rows, wrt):
+        return self.be.jacobian([r.node for r in rows], [w.node for w in wrt])
+
+    def hessian(self, f, wrt, lower=False):
+        return self.be.hessian(f.node, [w.node for w in wrt], lower)
+
+
+def py_sign(x):
+    return -1.0 if x < 0 else (0.0 if x == 0 else 1.0)
+
+
+def py_hypot3(x, y, z):
+    return math.sqrt(x * x + y * y + z * z)

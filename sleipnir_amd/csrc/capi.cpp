@@ -375,6 +375,7 @@ int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) 
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     double nfact = 0;
     for (int it = 0; it < iters; ++it) {
+      sys.reset_regularization();  // every timed step starts like a first iteration
       SLPX_HIP_CHECK(hipEventRecord(ev[0], st));
       if (refresh_ad) dev.sweep_full();
       SLPX_HIP_CHECK(hipEventRecord(ev[1], st));

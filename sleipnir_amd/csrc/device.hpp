@@ -71,6 +71,9 @@ struct TapeDev {
   const uint32_t* jout_slot;
   const uint32_t* jout_dst;
   const int32_t* jout_scale;
+  const uint16_t* node_rec16;
+  const uint16_t* slot_edge_ptr16;
+  const uint16_t* edges16;
 };
 
 struct TapeDevice {
@@ -81,9 +84,11 @@ struct TapeDevice {
   DevBuf<int32_t> vout_scale, jout_scale;
   DevBuf<double> consts;
   DevBuf<TapeEdge> edges;
+  DevBuf<uint16_t> node_rec16, slot_edge_ptr16, edges16;
   uint32_t n_small = 0, n_large = 0, n_global = 0;
   uint32_t small_lds = 0, large_lds = 0;
   uint64_t scratch_doubles = 0;
+  bool basic_ops = false;
   void upload(const TapeProgram& p);
   TapeDev view() const;
 };

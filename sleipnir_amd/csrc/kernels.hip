@@ -1,15 +1,15 @@
 // gfx950 (MI355X) kernels for the interior-point Newton step, and the DeviceNlp
 // host object that owns their buffers.  See DESIGN.md §3 for the roofline of each.
 //
-//   tape_sweep     AD refresh: forward values + local partials, then the per-row
-//                  adjoint gather, all inside LDS (one workgroup per task)
+//   tape_sweep     (tape_kernels.h) AD refresh: forward values + local partials, then
+//                  the per-row adjoint gather, all inside LDS (one workgroup per task)
 //                  replaces update_values/append_triplets/setFromTriplets
 //                  (expression_graph.hpp:86-153, jacobian.hpp:134-156, hessian.hpp:132-157)
 //   kkt_assemble   lhs values by gather   (interior_point.hpp:426-440)
 //   kkt_rhs        rhs by column gathers  (interior_point.hpp:444-448)
-//   ldlt_factor    one round of the task-parallel left-looking LDLᵀ + inertia
-//                  (sparse_regularized_ldlt.hpp:74-83,105-109, inertia.hpp:40-50)
-//   ldlt_fwd/bwd   triangular solves      (sparse_regularized_ldlt.hpp:159-161)
+//   ldlt_factor    (ldlt_kernels.h) one round of the task-parallel left-looking LDLᵀ
+//                  + inertia (sparse_regularized_ldlt.hpp:74-83,105-109, inertia.hpp:40-50)
+//   ldlt_fwd/bwd   (ldlt_kernels.h) triangular solves (sparse_regularized_ldlt.hpp:159-161)
 //   step_backsub   pˢ, pᶻ                 (interior_point.hpp:479-480)
 #include <hip/hip_runtime.h>
 
@@ -17,92 +17,18 @@
 #include <cstring>
 
 #include "device.hpp"
+#include "ldlt_kernels.h"
+#include "tape_kernels.h"
 #include "tape_ops.h"
 
 namespace slpx {
 
 // ============================================================================
-// tape_sweep
-// ============================================================================
-// LDS layout (doubles): val[n_leaf + n_node] | part[2 * n_node] | adj[n_slot]
-template <int THREADS, bool USE_LDS>
-__global__ __launch_bounds__(THREADS) void tape_sweep_kernel(
-    TapeDev T, const uint32_t* __restrict__ task_list, const double* __restrict__ in, int in_stride,
-    const double* __restrict__ in_scale, const double* __restrict__ scales, double* __restrict__ V,
-    int v_stride, double* __restrict__ scratch, unsigned long long scratch_stride, int do_reverse) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const TapeTask t = T.tasks[task_list[blockIdx.x]];
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  in += static_cast<size_t>(b) * in_stride;
-  V += static_cast<size_t>(b) * v_stride;
-
-  double* val = USE_LDS ? smem : scratch + static_cast<size_t>(b) * scratch_stride + t.scratch_off;
-  double* part = val + t.n_leaf + t.n_node;
-  double* adj = part + 2 * t.n_node;
-
-  // leaves
-  for (uint32_t i = tid; i < t.n_leaf; i += THREADS) {
-    const uint32_t src = T.leaf_src[t.leaf_off + i];
-    val[i] = (src & kLeafConstFlag) ? T.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
-  }
-  __syncthreads();
-
-  // forward: one group of independent nodes per level
-  const uint32_t* lvl = T.lvl_ptr + t.lvl_off;
-  const uint32_t* rec = T.node_rec + 3 * static_cast<size_t>(t.node_off);
-  for (uint32_t l = 0; l < t.n_lvl; ++l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += THREADS) {
-      const uint32_t r0 = rec[3 * i], a0 = rec[3 * i + 1], a1 = rec[3 * i + 2];
-      double v, dl, dr;
-      op_forward(static_cast<Opcode>(r0 & 0xff), val[a0], val[a1], (r0 & 0x100) != 0,
-                 (r0 & 0x200) != 0, v, dl, dr);
-      val[t.n_leaf + i] = v;
-      part[2 * i] = dl;
-      part[2 * i + 1] = dr;
-    }
-    __syncthreads();
-  }
-
-  // value outputs (f, c_e, c_i)
-  for (uint32_t i = tid; i < t.n_vout; i += THREADS) {
-    const uint32_t k = t.vout_off + i;
-    const int32_t sc = T.vout_scale[k];
-    const double v = val[T.vout_src[k]];
-    V[T.vout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
-  }
-  if (!do_reverse || t.n_slot == 0) return;
-
-  // reverse: adjoint slot = Σ parent_adjoint * partial, level by level
-  const uint32_t* slvl = T.slvl_ptr + t.slvl_off;
-  const uint32_t* eptr = T.slot_edge_ptr + t.slot_off;
-  const TapeEdge* edges = T.edges + t.edge_off;
-  for (uint32_t l = 0; l < t.n_slvl; ++l) {
-    const uint32_t beg = slvl[l], end = slvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += THREADS) {
-      const uint32_t eb = eptr[i], ee = eptr[i + 1];
-      double acc = eb == ee ? 1.0 : 0.0;  // a slot without parents is a row root
-      for (uint32_t e = eb; e < ee; ++e) {
-        const TapeEdge ed = edges[e];
-        acc += adj[ed.parent_slot] * part[ed.partial];
-      }
-      adj[i] = acc;
-    }
-    __syncthreads();
-  }
-
-  // Jacobian / Hessian entries
-  for (uint32_t i = tid; i < t.n_jout; i += THREADS) {
-    const uint32_t k = t.jout_off + i;
-    const int32_t sc = T.jout_scale[k];
-    const double v = adj[T.jout_slot[k]];
-    V[T.jout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
-  }
-}
-
-// ============================================================================
-// kkt_assemble / kkt_rhs / step_backsub
+// kkt_assemble / kkt_rhs / step_backsub: pure gathers over static index maps.
+// HBM-bound; algorithmic bytes: assemble 12(h+a+i) + 16 m_i + 8 k, rhs
+// 16 n + 24 m_e + 24 m_i + 12(a+i).  One thread per output entry,
+// consecutive threads write consecutive entries; the sources of consecutive lhs
+// entries are (nearly) consecutive in V because both are CSC-ordered.
 // ============================================================================
 __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const double* __restrict__ V,
                                                            int v_stride,
@@ -191,187 +117,6 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
 }
 
 // ============================================================================
-// ldlt
-// ============================================================================
-// LDS: U[n_ent] | invd[n_col]
-__global__ __launch_bounds__(256) void ldlt_factor_kernel(LdltDev L, uint32_t task_base,
-                                                          const double* __restrict__ lhs,
-                                                          int lhs_stride,
-                                                          const double* __restrict__ reg,
-                                                          const uint8_t* __restrict__ active,
-                                                          double* __restrict__ Lx, long long lx_stride,
-                                                          double* __restrict__ D, int n,
-                                                          double* __restrict__ contrib,
-                                                          int contrib_stride,
-                                                          LdltStats* __restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
-  const int b = blockIdx.y;
-  if (!active[b]) return;
-  const double delta = reg[2 * b], gamma = reg[2 * b + 1];
-  const int tid = threadIdx.x;
-  // counters live behind the task's working set in the dynamic region (no static LDS)
-  int* s_cnt = reinterpret_cast<int*>(smem + t.n_ent + t.n_col);
-  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(smem + t.n_ent + t.n_col + 2);
-  lhs += static_cast<size_t>(b) * lhs_stride;
-  Lx += static_cast<size_t>(b) * lx_stride;
-  D += static_cast<size_t>(b) * n;
-  contrib += static_cast<size_t>(b) * contrib_stride;
-  double* U = smem;
-  double* invd = smem + t.n_ent;
-  if (tid < 4) s_cnt[tid] = 0;
-  if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
-  const uint32_t* lvl = L.lvl_ptr + t.lvl_off;
-  const uint32_t* pptr = L.ent_pair_ptr + t.pair_ptr_off;
-  const uint32_t* cptr = L.ent_contrib_ptr + t.contrib_ptr_off;
-  const LdltPair* pairs = L.pairs + t.pair_off;
-  const uint32_t* cidx = L.contrib_idx + t.contrib_off;
-  __syncthreads();
-  for (uint32_t l = 0; l < t.n_lvl; ++l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += 256) {
-      const uint32_t e = t.ent_off + i;
-      const int32_t src = L.ent_src[e];
-      const uint8_t fl = L.ent_flags[e];
-      double acc = src >= 0 ? lhs[src] : 0.0;
-      if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-      for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= contrib[cidx[c]];
-      for (uint32_t q = pptr[i]; q < pptr[i + 1]; ++q) {
-        const LdltPair pr = pairs[q];
-        acc -= (U[pr.a] * invd[pr.k]) * U[pr.b];
-      }
-      U[i] = acc;
-      if (fl & 1) invd[L.ent_col[e]] = 1.0 / acc;
-    }
-    __syncthreads();
-  }
-  // update blocks for ancestors in later rounds
-  for (uint32_t x = tid; x < t.n_ext; x += 256) {
-    double acc = 0.0;
-    for (uint32_t q = pptr[t.n_ent + x]; q < pptr[t.n_ent + x + 1]; ++q) {
-      const LdltPair pr = pairs[q];
-      acc += (U[pr.a] * invd[pr.k]) * U[pr.b];
-    }
-    contrib[L.ext_dst[t.ext_off + x]] = acc;
-  }
-  // results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero)
-  for (uint32_t i = tid; i < t.n_ent; i += 256) {
-    const uint32_t e = t.ent_off + i;
-    const uint8_t fl = L.ent_flags[e];
-    const double u = U[i];
-    if (fl & 1) {
-      D[L.ent_out[e]] = u;
-      const double eps = 2.220446049250313e-16;
-      if (u > eps) atomicAdd(&s_cnt[0], 1);
-      else if (u < -eps) atomicAdd(&s_cnt[1], 1);
-      else atomicAdd(&s_cnt[2], 1);
-      if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
-      else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
-    } else {
-      Lx[L.ent_out[e]] = u * invd[L.ent_col[e]];
-    }
-  }
-  __syncthreads();
-  if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[b]) + tid, s_cnt[tid]);
-  if (tid == 0) atomicMin(&stats[b].min_abs_bits, *s_minp);
-}
-
-// forward substitution L y = P b, then z = D⁻¹ y.  LDS: y[n_col]
-__global__ __launch_bounds__(128) void ldlt_fwd_kernel(LdltDev L, uint32_t task_base,
-                                                       const double* __restrict__ rhs, int n,
-                                                       const double* __restrict__ Lx,
-                                                       long long lx_stride,
-                                                       const double* __restrict__ D,
-                                                       double* __restrict__ scontrib,
-                                                       int scontrib_stride, double* __restrict__ zv) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  rhs += static_cast<size_t>(b) * n;
-  Lx += static_cast<size_t>(b) * lx_stride;
-  D += static_cast<size_t>(b) * n;
-  zv += static_cast<size_t>(b) * n;
-  scontrib += static_cast<size_t>(b) * scontrib_stride;
-  double* y = smem;
-  const uint32_t* lvl = L.col_lvl_ptr + t.lvl_off;
-  const uint32_t* fptr = L.fwd_ptr + t.colptr_off;
-  const uint32_t* fcptr = L.fwd_contrib_ptr + t.colptr_off;
-  const LdltSolveItem* items = L.fwd_items + t.fwd_item_off;
-  const uint32_t* scidx = L.scontrib_idx + t.scontrib_off;
-  for (uint32_t l = 0; l < t.n_lvl; ++l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += 128) {
-      const uint32_t pj = L.col_perm[t.col_off + i];
-      double acc = rhs[L.perm[pj]];
-      for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= scontrib[scidx[c]];
-      for (uint32_t q = fptr[i]; q < fptr[i + 1]; ++q) acc -= Lx[items[q].lpos] * y[items[q].ref];
-      y[i] = acc;
-    }
-    __syncthreads();
-  }
-  const uint32_t* sptr = L.sext_ptr + t.sext_ptr_off;
-  const LdltSolveItem* sitems = L.sext_items + t.sext_item_off;
-  for (uint32_t x = tid; x < t.n_sext; x += 128) {
-    double acc = 0.0;
-    for (uint32_t q = sptr[x]; q < sptr[x + 1]; ++q) acc += Lx[sitems[q].lpos] * y[sitems[q].ref];
-    scontrib[L.sext_dst[t.sext_off + x]] = acc;
-  }
-  for (uint32_t i = tid; i < t.n_col; i += 128) {
-    const uint32_t pj = L.col_perm[t.col_off + i];
-    zv[pj] = y[i] / D[pj];
-  }
-}
-
-// backward substitution Lᵀ x = z, result un-permuted.  LDS: x[n_col]
-__global__ __launch_bounds__(128) void ldlt_bwd_kernel(LdltDev L, uint32_t task_base, int n,
-                                                       const double* __restrict__ Lx,
-                                                       long long lx_stride,
-                                                       const double* __restrict__ zv,
-                                                       double* __restrict__ xg,
-                                                       double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  Lx += static_cast<size_t>(b) * lx_stride;
-  zv += static_cast<size_t>(b) * n;
-  xg += static_cast<size_t>(b) * n;
-  out += static_cast<size_t>(b) * n;
-  double* x = smem;
-  const uint32_t* lvl = L.col_lvl_ptr + t.lvl_off;
-  const uint32_t* bptr = L.bwd_ptr + t.colptr_off;
-  const LdltSolveItem* items = L.bwd_items + t.bwd_item_off;
-  for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += 128) {
-      const uint32_t pj = L.col_perm[t.col_off + i];
-      double acc = zv[pj];
-      for (uint32_t q = bptr[i]; q < bptr[i + 1]; ++q) {
-        const uint32_t ref = items[q].ref;
-        const double xi = (ref & 0x80000000u) ? xg[ref & 0x7fffffffu] : x[ref];
-        acc -= Lx[items[q].lpos] * xi;
-      }
-      x[i] = acc;
-    }
-    __syncthreads();
-  }
-  for (uint32_t i = tid; i < t.n_col; i += 128) {
-    const uint32_t pj = L.col_perm[t.col_off + i];
-    xg[pj] = x[i];
-    out[L.perm[pj]] = x[i];
-  }
-}
-
-__global__ void ldlt_stats_reset_kernel(LdltStats* stats, int batch) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < batch) {
-    stats[b].n_pos = stats[b].n_neg = stats[b].n_zero = stats[b].n_bad = 0;
-    stats[b].min_abs_bits = 0x7ff0000000000000ull;
-  }
-}
-
-// ============================================================================
 // DeviceNlp
 // ============================================================================
 
@@ -393,18 +138,23 @@ void TapeDevice::upload(const TapeProgram& p) {
   jout_slot.upload(p.jout_slot);
   jout_dst.upload(p.jout_dst);
   jout_scale.upload(p.jout_scale);
+  node_rec16.upload(p.node_rec16);
+  slot_edge_ptr16.upload(p.slot_edge_ptr16);
+  edges16.upload(p.edges16);
   n_small = static_cast<uint32_t>(p.small_tasks.size());
   n_large = static_cast<uint32_t>(p.large_tasks.size());
   n_global = static_cast<uint32_t>(p.global_tasks.size());
-  small_lds = p.small_lds_doubles * 8;
-  large_lds = p.large_lds_doubles * 8;
+  small_lds = p.small_lds_bytes;
+  large_lds = p.large_lds_bytes;
   scratch_doubles = p.global_scratch_doubles;
+  basic_ops = p.basic_ops;
 }
 
 TapeDev TapeDevice::view() const {
-  return TapeDev{tasks.p,        leaf_src.p,  consts.p,   node_rec.p,   lvl_ptr.p,
-                 slot_edge_ptr.p, slvl_ptr.p, edges.p,    vout_src.p,   vout_dst.p,
-                 vout_scale.p,   jout_slot.p, jout_dst.p, jout_scale.p};
+  return TapeDev{tasks.p,         leaf_src.p,   consts.p,   node_rec.p,   lvl_ptr.p,
+                 slot_edge_ptr.p, slvl_ptr.p,   edges.p,    vout_src.p,   vout_dst.p,
+                 vout_scale.p,    jout_slot.p,  jout_dst.p, jout_scale.p, node_rec16.p,
+                 slot_edge_ptr16.p, edges16.p};
 }
 
 DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l, int batch,
@@ -417,12 +167,17 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 
   m_full.upload(s.full);
   m_values.upload(s.values);
-  // allow > 64 KB dynamic LDS for the large task class
-  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tape_sweep_kernel<256, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tape_sweep_kernel<64, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // allow > 64 KB dynamic LDS
+  for (const void* fn : {reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, true>),
+                         reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, false>),
+                         reinterpret_cast<const void*>(&tape_sweep_lds_kernel<64, true>),
+                         reinterpret_cast<const void*>(&tape_sweep_lds_kernel<64, false>)})
+    SLPX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_fwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_bwd_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   m_dptr.upload(k.dptr);
@@ -563,20 +318,22 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse) {
   const TapeDev view = t.view();
   const int in_stride = m_s_ref.n_inputs(), v_stride = m_s_ref.nV;
   const unsigned long long sstride = m_scratch.n / m_batch;
+  // basic_ops: the program only uses + - * / sin cos sqrt and the piecewise ops, so
+  // the kernel specialization without pow/exp/log/erf/... (fewer VGPRs, less code)
+  auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
+  auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;
   if (t.n_small)
-    hipLaunchKernelGGL((tape_sweep_kernel<64, true>), dim3(t.n_small, m_batch), dim3(64),
-                       t.small_lds, m_stream, view, t.small_list.p, m_in.p, in_stride,
-                       m_in_scale.p, m_scales.p, m_V.p, v_stride, m_scratch.p, sstride,
+    hipLaunchKernelGGL(small_fn, dim3(t.n_small, m_batch), dim3(64), t.small_lds, m_stream, view,
+                       t.small_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_large)
-    hipLaunchKernelGGL((tape_sweep_kernel<256, true>), dim3(t.n_large, m_batch), dim3(256),
-                       t.large_lds, m_stream, view, t.large_list.p, m_in.p, in_stride,
-                       m_in_scale.p, m_scales.p, m_V.p, v_stride, m_scratch.p, sstride,
+    hipLaunchKernelGGL(large_fn, dim3(t.n_large, m_batch), dim3(256), t.large_lds, m_stream, view,
+                       t.large_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_global)
-    hipLaunchKernelGGL((tape_sweep_kernel<1024, false>), dim3(t.n_global, m_batch), dim3(1024), 0,
-                       m_stream, view, t.global_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p,
-                       m_V.p, v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
+    hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, m_stream,
+                       view, t.global_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p,
+                       v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -607,19 +364,17 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
     reg[2 * b] = delta[b];
     reg[2 * b + 1] = gamma[b];
   }
+  // pageable-memory copies are staged synchronously by HIP, so the temporaries may die
   SLPX_HIP_CHECK(hipMemcpyAsync(m_reg.p, reg.data(), reg.size() * sizeof(double),
                                 hipMemcpyHostToDevice, m_stream));
   SLPX_HIP_CHECK(hipMemcpyAsync(m_active.p, active.data(), m_batch, hipMemcpyHostToDevice, m_stream));
-  // the two staging vectors above die at scope exit; the copies are from pageable
-  // memory, which HIP stages synchronously, so that is safe
   hipLaunchKernelGGL(ldlt_stats_reset_kernel, dim3((m_batch + 63) / 64), dim3(64), 0, m_stream,
                      m_stats.p, m_batch);
   for (int r = 0; r < l.n_rounds; ++r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256),
-                       (l.max_lds_doubles + 4) * 8, m_stream, m_ldev, l.round_ptr[r], m_lhs.p,
-                       m_kdev.nnz_lhs, m_reg.p, m_active.p,
-                       m_Lx.p, static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
+    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, m_stream,
+                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_reg.p, m_active.p, m_Lx.p,
+                       static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
                        m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), m_stats.p);
   }
   SLPX_HIP_CHECK(hipGetLastError());
@@ -638,14 +393,14 @@ void DeviceNlp::solve() {
   const int scs = static_cast<int>(std::max<uint32_t>(1, l.n_scontrib));
   for (int r = 0; r < l.n_rounds; ++r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(nt, m_batch), dim3(128), l.max_solve_lds_doubles * 8,
-                       m_stream, m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p,
-                       m_scontrib.p, scs, m_zv.p);
+    hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
+                       m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs,
+                       m_zv.p);
   }
   for (int r = l.n_rounds - 1; r >= 0; --r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(128), l.max_solve_lds_doubles * 8,
-                       m_stream, m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p);
+    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
+                       m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p);
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }

@@ -271,7 +271,10 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   {
     std::vector<uint32_t> w(n), W(n);
     for (int j = 0; j < n; ++j) {
-      w[j] = static_cast<uint32_t>(Lcol[j].size()) + 1;
+      // LDS cost in "entry equivalents" (~32 B): the column's entries plus the
+      // update pairs it generates (8 B each), wherever those end up being stored
+      const uint32_t c = static_cast<uint32_t>(Lcol[j].size());
+      w[j] = (c + 1) + (c * (c + 1) / 2 + 3) / 4;
       if (w[j] > cap)
         throw std::runtime_error("ldlt: a single column exceeds the LDS task budget "
                                  "(global-memory supernode path not built yet)");
@@ -542,6 +545,16 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     P.sext_ptr.push_back(sitem);
     P.max_lds_doubles = std::max(P.max_lds_doubles, T.n_ent + T.n_col);
     P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, T.n_col);
+    // LDS working sets of the staged kernels (see kernels.hip for the carve-up)
+    auto up8 = [](uint32_t b) { return (b + 7u) & ~7u; };
+    const uint32_t fb = 8 * T.n_ent + 8 * T.n_col + up8(8 * pair_count) +
+                        up8(4 * (T.n_ent + T.n_ext + 1)) + up8(2 * T.n_ent) + up8(T.n_ent) +
+                        up8(4 * (T.n_lvl + 1)) + 32;
+    const uint32_t items = std::max(fwd_count, bwd_count);
+    const uint32_t sb = 8 * (T.n_col + 1) + 8 * items + up8(4 * items) + up8(4 * (T.n_col + 1)) +
+                        up8(4 * (T.n_lvl + 1)) + 32;
+    P.factor_lds_bytes = std::max(P.factor_lds_bytes, fb);
+    P.solve_lds_bytes = std::max(P.solve_lds_bytes, sb);
     P.tasks.push_back(T);
   }
 
@@ -550,6 +563,9 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   for (int j = 0; j < n; ++j)
     if (!has_diag[P.perm[j]] && !diag_updated_perm[j]) P.structurally_singular_unregularized = true;
 
+  if (P.factor_lds_bytes > 160u * 1024u || P.solve_lds_bytes > 160u * 1024u)
+    throw std::runtime_error("ldlt: a task's working set exceeds the 160 KB LDS of a CU; lower "
+                             "LdltOptions::task_entries");
   P.flops = 2 * static_cast<int64_t>(P.pairs.size());
   P.factor_bytes = 12LL * lower.nnz() + 16LL * (P.nnzL + n);
   P.solve_bytes = 32LL * P.nnzL + 16LL * n;

@@ -74,6 +74,8 @@ struct LdltPlan {
   std::vector<uint32_t> round_ptr;            // n_rounds + 1, into tasks
   uint32_t max_lds_doubles = 0;               // factor kernel
   uint32_t max_solve_lds_doubles = 0;
+  uint32_t factor_lds_bytes = 0;              // dynamic LDS of ldlt_factor_kernel
+  uint32_t solve_lds_bytes = 0;               // dynamic LDS of ldlt_fwd/bwd kernels
 
   // ---- factor ----
   std::vector<int32_t> ent_src;       // index into lhs values or -1
@@ -110,7 +112,9 @@ struct LdltPlan {
 
 struct LdltOptions {
   int leaf_size = 48;           // nested-dissection leaves (nodes)
-  uint32_t task_entries = 3072; // LDS budget per task in L entries (incl. diagonal)
+  // LDS budget per task in entry-equivalents (one L entry ~ 32 B incl. its
+  // descriptors; four update pairs ~ one entry).  2048 keeps a task near 64-96 KB.
+  uint32_t task_entries = 2048;
   bool defer_constraints = true;
 };
 

@@ -327,7 +327,8 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     else comp_vouts[comp_of[n]].push_back(v);
   }
 
-  // working-set size (doubles) of a set of components
+  // LDS bytes of a component: working set (values, partials, adjoint slots) plus
+  // the staged, 16-bit-packed program (8 B node records, 4 B edges, 2 B edge ptrs)
   auto comp_cost = [&](size_t c, size_t& n_leaf_est) {
     // leaves are counted per component (upper bound when packing several)
     size_t leaves = 0;
@@ -336,11 +337,14 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       if (cg.a1[n] >= 0 && cg.is_leaf(cg.a1[n])) ++leaves;
     }
     n_leaf_est = leaves;
-    return leaves + 3 * comp_nodes[c].size() + comp_slots[c].size();
+    size_t edges = 0;
+    for (int32_t sl : comp_slots[c]) edges += slot_edges[sl].size();
+    return 8 * leaves + (24 + 8) * comp_nodes[c].size() + (8 + 2) * comp_slots[c].size() +
+           4 * edges + 64;
   };
 
   // ---- pack components into tasks -----------------------------------------------
-  const size_t small_cap = opt.small_lds_bytes / 8, large_cap = opt.large_lds_bytes / 8;
+  const size_t small_cap = opt.small_lds_bytes, large_cap = opt.large_lds_bytes;
   struct Pack {
     std::vector<size_t> comps;
     size_t cost = 0;
@@ -459,11 +463,18 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
           prog.lvl_ptr.push_back(static_cast<uint32_t>(i));
           cur_level = level[n];
         }
+        if (!op_is_basic(static_cast<Opcode>(cg.op[n]))) prog.basic_ops = false;
         uint32_t rec = cg.op[n] | (need_dl[n] ? 0x100u : 0u) | (need_dr[n] ? 0x200u : 0u);
         prog.node_rec.push_back(rec);
         prog.node_rec.push_back(static_cast<uint32_t>(local_of[cg.a0[n]]));
         prog.node_rec.push_back(cg.a1[n] >= 0 ? static_cast<uint32_t>(local_of[cg.a1[n]])
                                               : static_cast<uint32_t>(local_of[cg.a0[n]]));
+        // 16-bit packed copy for the LDS-staged kernel (unused by GLOBAL tasks)
+        const size_t r3 = prog.node_rec.size() - 3;
+        prog.node_rec16.push_back(static_cast<uint16_t>(rec));
+        prog.node_rec16.push_back(static_cast<uint16_t>(prog.node_rec[r3 + 1]));
+        prog.node_rec16.push_back(static_cast<uint16_t>(prog.node_rec[r3 + 2]));
+        prog.node_rec16.push_back(0);
       }
       prog.lvl_ptr.push_back(static_cast<uint32_t>(nodes.size()));
       t.n_lvl = static_cast<uint32_t>(prog.lvl_ptr.size() - t.lvl_off - 1);
@@ -481,10 +492,13 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
           cur_level = s.level;
         }
         prog.slot_edge_ptr.push_back(edge_count);
+        prog.slot_edge_ptr16.push_back(static_cast<uint16_t>(edge_count));
         for (const REdge& e : slot_edges[tslots[i]]) {
           uint32_t pn = static_cast<uint32_t>(local_of[e.parent_node]) - t.n_leaf;
           prog.edges.push_back({static_cast<uint32_t>(local_slot[e.parent_slot]),
                                 2u * pn + static_cast<uint32_t>(e.side)});
+          prog.edges16.push_back(static_cast<uint16_t>(local_slot[e.parent_slot]));
+          prog.edges16.push_back(static_cast<uint16_t>(2u * pn + static_cast<uint32_t>(e.side)));
           ++edge_count;
         }
         if (s.out_dst >= 0) {
@@ -494,6 +508,8 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         }
       }
       prog.slot_edge_ptr.push_back(edge_count);
+      prog.slot_edge_ptr16.push_back(static_cast<uint16_t>(edge_count));
+      t.n_edge = edge_count;
       prog.slvl_ptr.push_back(static_cast<uint32_t>(tslots.size()));
       t.n_slvl = static_cast<uint32_t>(prog.slvl_ptr.size() - t.slvl_off - 1);
       prog.max_slot_levels = std::max(prog.max_slot_levels, t.n_slvl);
@@ -507,16 +523,23 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     t.n_vout = static_cast<uint32_t>(prog.vout_src.size() - t.vout_off);
     t.n_jout = static_cast<uint32_t>(prog.jout_slot.size() - t.jout_off);
     t.lds_doubles = t.n_leaf + 3 * t.n_node + t.n_slot;
+    auto up8 = [](uint32_t b) { return (b + 7u) & ~7u; };
+    t.lds_bytes = 8 * t.lds_doubles + 8 * t.n_node + up8(4 * t.n_edge) + up8(2 * (t.n_slot + 1)) +
+                  up8(4 * (t.n_lvl + 1)) + up8(4 * (t.n_slvl + 1));
     int cls = pk.cls;
-    if (cls == 0 && t.lds_doubles > small_cap) cls = 1;
-    if (cls == 1 && t.lds_doubles > large_cap) cls = 2;
+    if (cls == 0 && t.lds_bytes > small_cap) cls = 1;
+    if (cls == 1 && t.lds_bytes > large_cap) cls = 2;
+    // 16-bit packing limits of the staged kernel
+    if (t.n_leaf + t.n_node > 65535u || t.n_slot > 65535u || t.n_edge > 65535u ||
+        2u * t.n_node > 65535u)
+      cls = 2;
     uint32_t ti = static_cast<uint32_t>(prog.tasks.size());
     if (cls == 0) {
       prog.small_tasks.push_back(ti);
-      prog.small_lds_doubles = std::max(prog.small_lds_doubles, t.lds_doubles);
+      prog.small_lds_bytes = std::max(prog.small_lds_bytes, t.lds_bytes);
     } else if (cls == 1) {
       prog.large_tasks.push_back(ti);
-      prog.large_lds_doubles = std::max(prog.large_lds_doubles, t.lds_doubles);
+      prog.large_lds_bytes = std::max(prog.large_lds_bytes, t.lds_bytes);
     } else {
       prog.global_tasks.push_back(ti);
       t.scratch_off = static_cast<uint32_t>(prog.global_scratch_doubles);

@@ -66,6 +66,8 @@ struct TapeTask {
   uint32_t jout_off, n_jout;  // into jout_*
   uint32_t scratch_off;       // GLOBAL tasks: offset (doubles) into the scratch buffer
   uint32_t lds_doubles;       // working-set size in doubles
+  uint32_t n_edge;            // number of adjoint edges
+  uint32_t lds_bytes;         // LDS-staged kernel: working set + staged program
 };
 
 struct TapeEdge {
@@ -86,14 +88,20 @@ struct TapeProgram {
   std::vector<uint32_t> slot_edge_ptr;
   std::vector<uint32_t> slvl_ptr;
   std::vector<TapeEdge> edges;
+  // 16-bit packed mirror of node_rec / slot_edge_ptr / edges, indexed with the same
+  // task offsets; what the LDS-staged kernel loads (GLOBAL tasks use the 32-bit arrays)
+  std::vector<uint16_t> node_rec16;       // [op|flags, a0, a1, 0] per node
+  std::vector<uint16_t> slot_edge_ptr16;
+  std::vector<uint16_t> edges16;          // [parent_slot, partial] per edge
   std::vector<uint32_t> vout_src;    // local value index
   std::vector<uint32_t> vout_dst;
   std::vector<int32_t> vout_scale;
   std::vector<uint32_t> jout_slot;   // local slot index
   std::vector<uint32_t> jout_dst;
   std::vector<int32_t> jout_scale;
-  uint32_t small_lds_doubles = 0, large_lds_doubles = 0;
+  uint32_t small_lds_bytes = 0, large_lds_bytes = 0;
   uint64_t global_scratch_doubles = 0;
+  bool basic_ops = true;  // every op is in the basic set (tape_ops.h op_is_basic)
 
   // statistics
   size_t total_nodes = 0, total_slots = 0, total_edges = 0, total_leaves = 0;
@@ -101,7 +109,7 @@ struct TapeProgram {
 };
 
 struct TapeCompileOptions {
-  uint32_t small_lds_bytes = 40 * 1024;   // 64-thread workgroups, several per CU
+  uint32_t small_lds_bytes = 40 * 1024;   // 64-thread workgroups, four per CU
   uint32_t large_lds_bytes = 152 * 1024;  // 256-thread workgroups, one per CU
   bool rebalance_sums = true;
   uint32_t rebalance_min_terms = 8;

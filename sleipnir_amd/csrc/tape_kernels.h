@@ -1,0 +1,200 @@
+// tape_sweep: the AD refresh on gfx950.
+//
+// One workgroup executes one TASK (a bin-packed set of graph components, normally
+// one direct-transcription stage) start to finish:
+//   1. stage the task's PROGRAM (16-bit packed node records, adjoint edges, level
+//      pointers) and its leaf values into LDS with coalesced bulk loads — after
+//      this the level loops never touch global memory, so a level costs LDS latency
+//      (~100 cycles), not an L2 round trip per dependent metadata load;
+//   2. forward sweep: one group of independent nodes per level; every node stores
+//      its value and its two local partials;
+//   3. adjoint sweep: per-(row, node) slots gathered level by level:
+//      slot = Σ parent_slot · partial  (the reference's per-row append_triplets,
+//      expression_graph.hpp:107-153, for all rows of the task at once);
+//   4. scaled outputs go straight to their fixed positions in V.
+// A 64-thread workgroup = one wavefront, so the per-level barrier is free; four
+// such tasks fit the 160 KB LDS of a CU.
+//
+// Roofline: HBM-bound in the batched regime — algorithmic bytes per sweep are
+// 8·(n + m_e + m_i) in + 8·(dynamic entries of V) out; a single
+// problem is bound by graph depth × LDS latency instead.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device.hpp"
+#include "tape_ops.h"
+
+namespace slpx {
+
+__device__ __forceinline__ uint32_t up8u(uint32_t b) { return (b + 7u) & ~7u; }
+
+// cooperative copy of `count` 4-byte words (count may be 0)
+template <int THREADS>
+__device__ __forceinline__ void stage_words(uint32_t* dst, const uint32_t* __restrict__ src,
+                                            uint32_t count, int tid) {
+  for (uint32_t i = tid; i < count; i += THREADS) dst[i] = src[i];
+}
+
+// LDS layout (bytes, every section 8-aligned):
+//   val[n_leaf+n_node] f64 | part[2 n_node] f64 | adj[n_slot] f64 | rec[n_node] 8 B |
+//   edges[n_edge] 4 B | eptr[n_slot+1] 2 B | lvl[n_lvl+1] 4 B | slvl[n_slvl+1] 4 B
+template <int THREADS, bool FULL_OPS>
+__global__ __launch_bounds__(THREADS) void tape_sweep_lds_kernel(
+    TapeDev T, const uint32_t* __restrict__ task_list, const double* __restrict__ in, int in_stride,
+    const double* __restrict__ in_scale, const double* __restrict__ scales, double* __restrict__ V,
+    int v_stride, int do_reverse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const TapeTask t = T.tasks[task_list[blockIdx.x]];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  in += static_cast<size_t>(b) * in_stride;
+  V += static_cast<size_t>(b) * v_stride;
+
+  double* val = reinterpret_cast<double*>(smem_raw);
+  double* part = val + t.n_leaf + t.n_node;
+  double* adj = part + 2 * t.n_node;
+  unsigned char* cur = reinterpret_cast<unsigned char*>(adj + t.n_slot);
+  uint2* rec = reinterpret_cast<uint2*>(cur);
+  cur += 8 * t.n_node;
+  uint32_t* edges = reinterpret_cast<uint32_t*>(cur);
+  cur += up8u(4 * t.n_edge);
+  uint16_t* eptr = reinterpret_cast<uint16_t*>(cur);
+  cur += up8u(2 * (t.n_slot + 1));
+  uint32_t* lvl = reinterpret_cast<uint32_t*>(cur);
+  cur += up8u(4 * (t.n_lvl + 1));
+  uint32_t* slvl = reinterpret_cast<uint32_t*>(cur);
+
+  // ---- stage program + leaves ----
+  {
+    const uint2* g_rec = reinterpret_cast<const uint2*>(T.node_rec16) + t.node_off;
+    for (uint32_t i = tid; i < t.n_node; i += THREADS) rec[i] = g_rec[i];
+    stage_words<THREADS>(lvl, T.lvl_ptr + t.lvl_off, t.n_lvl + 1, tid);
+    if (do_reverse && t.n_slot) {
+      stage_words<THREADS>(edges, reinterpret_cast<const uint32_t*>(T.edges16) + t.edge_off,
+                           t.n_edge, tid);
+      const uint16_t* g_eptr = T.slot_edge_ptr16 + t.slot_off;
+      for (uint32_t i = tid; i < t.n_slot + 1; i += THREADS) eptr[i] = g_eptr[i];
+      stage_words<THREADS>(slvl, T.slvl_ptr + t.slvl_off, t.n_slvl + 1, tid);
+    }
+    for (uint32_t i = tid; i < t.n_leaf; i += THREADS) {
+      const uint32_t src = T.leaf_src[t.leaf_off + i];
+      val[i] = (src & kLeafConstFlag) ? T.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
+    }
+  }
+  __syncthreads();
+
+  // ---- forward ----
+  for (uint32_t l = 0; l < t.n_lvl; ++l) {
+    const uint32_t beg = lvl[l], end = lvl[l + 1];
+    for (uint32_t i = beg + tid; i < end; i += THREADS) {
+      const uint2 r = rec[i];
+      const uint32_t opf = r.x & 0xffffu, a0 = r.x >> 16, a1 = r.y & 0xffffu;
+      double v, dl, dr;
+      op_forward<FULL_OPS>(static_cast<Opcode>(opf & 0xff), val[a0], val[a1], (opf & 0x100) != 0,
+                           (opf & 0x200) != 0, v, dl, dr);
+      val[t.n_leaf + i] = v;
+      part[2 * i] = dl;
+      part[2 * i + 1] = dr;
+    }
+    __syncthreads();
+  }
+
+  // ---- value outputs (f, c_e, c_i) ----
+  for (uint32_t i = tid; i < t.n_vout; i += THREADS) {
+    const uint32_t k = t.vout_off + i;
+    const int32_t sc = T.vout_scale[k];
+    const double v = val[T.vout_src[k]];
+    V[T.vout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
+  }
+  if (!do_reverse || t.n_slot == 0) return;
+
+  // ---- adjoint gather ----
+  for (uint32_t l = 0; l < t.n_slvl; ++l) {
+    const uint32_t beg = slvl[l], end = slvl[l + 1];
+    for (uint32_t i = beg + tid; i < end; i += THREADS) {
+      const uint32_t eb = eptr[i], ee = eptr[i + 1];
+      double acc = eb == ee ? 1.0 : 0.0;  // a slot without parents is a row root
+      for (uint32_t e = eb; e < ee; ++e) {
+        const uint32_t ed = edges[e];
+        acc += adj[ed & 0xffffu] * part[ed >> 16];
+      }
+      adj[i] = acc;
+    }
+    __syncthreads();
+  }
+
+  // ---- Jacobian / Hessian entries ----
+  for (uint32_t i = tid; i < t.n_jout; i += THREADS) {
+    const uint32_t k = t.jout_off + i;
+    const int32_t sc = T.jout_scale[k];
+    const double v = adj[T.jout_slot[k]];
+    V[T.jout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
+  }
+}
+
+// Fallback for components too large for LDS: same program (32-bit records), working
+// set in a global scratch buffer, one 1024-thread workgroup per task.
+__global__ __launch_bounds__(1024) void tape_sweep_global_kernel(
+    TapeDev T, const uint32_t* __restrict__ task_list, const double* __restrict__ in, int in_stride,
+    const double* __restrict__ in_scale, const double* __restrict__ scales, double* __restrict__ V,
+    int v_stride, double* __restrict__ scratch, unsigned long long scratch_stride, int do_reverse) {
+  constexpr int THREADS = 1024;
+  const TapeTask t = T.tasks[task_list[blockIdx.x]];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  in += static_cast<size_t>(b) * in_stride;
+  V += static_cast<size_t>(b) * v_stride;
+  double* val = scratch + static_cast<size_t>(b) * scratch_stride + t.scratch_off;
+  double* part = val + t.n_leaf + t.n_node;
+  double* adj = part + 2 * t.n_node;
+
+  for (uint32_t i = tid; i < t.n_leaf; i += THREADS) {
+    const uint32_t src = T.leaf_src[t.leaf_off + i];
+    val[i] = (src & kLeafConstFlag) ? T.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
+  }
+  __syncthreads();
+  const uint32_t* lvl = T.lvl_ptr + t.lvl_off;
+  const uint32_t* rec = T.node_rec + 3 * static_cast<size_t>(t.node_off);
+  for (uint32_t l = 0; l < t.n_lvl; ++l) {
+    const uint32_t beg = lvl[l], end = lvl[l + 1];
+    for (uint32_t i = beg + tid; i < end; i += THREADS) {
+      const uint32_t r0 = rec[3 * i], a0 = rec[3 * i + 1], a1 = rec[3 * i + 2];
+      double v, dl, dr;
+      op_forward(static_cast<Opcode>(r0 & 0xff), val[a0], val[a1], (r0 & 0x100) != 0,
+                 (r0 & 0x200) != 0, v, dl, dr);
+      val[t.n_leaf + i] = v;
+      part[2 * i] = dl;
+      part[2 * i + 1] = dr;
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < t.n_vout; i += THREADS) {
+    const uint32_t k = t.vout_off + i;
+    const int32_t sc = T.vout_scale[k];
+    const double v = val[T.vout_src[k]];
+    V[T.vout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
+  }
+  if (!do_reverse || t.n_slot == 0) return;
+  const uint32_t* slvl = T.slvl_ptr + t.slvl_off;
+  const uint32_t* eptr = T.slot_edge_ptr + t.slot_off;
+  const TapeEdge* edges = T.edges + t.edge_off;
+  for (uint32_t l = 0; l < t.n_slvl; ++l) {
+    const uint32_t beg = slvl[l], end = slvl[l + 1];
+    for (uint32_t i = beg + tid; i < end; i += THREADS) {
+      const uint32_t eb = eptr[i], ee = eptr[i + 1];
+      double acc = eb == ee ? 1.0 : 0.0;
+      for (uint32_t e = eb; e < ee; ++e) acc += adj[edges[e].parent_slot] * part[edges[e].partial];
+      adj[i] = acc;
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < t.n_jout; i += THREADS) {
+    const uint32_t k = t.jout_off + i;
+    const int32_t sc = T.jout_scale[k];
+    const double v = adj[T.jout_slot[k]];
+    V[T.jout_dst[k]] = sc >= 0 ? scales[sc] * v : v;
+  }
+}
+
+}  // namespace slpx

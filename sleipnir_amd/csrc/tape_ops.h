@@ -108,23 +108,66 @@ SLPX_HD double op_value(Opcode o, double l, double r) {
   }
 }
 
+// Ops of the "basic" kernel specialization: arithmetic, sin/cos/sqrt and the
+// piecewise ops.  Programs that use nothing else (every BASELINE workload) run a
+// kernel that does not carry pow/exp/log/erf/... code and registers.
+inline bool op_is_basic(Opcode o) {
+  switch (o) {
+    case OP_CONST: case OP_VAR: case OP_ADD: case OP_SUB: case OP_NEG: case OP_MUL: case OP_DIV:
+    case OP_ABS: case OP_SIGN: case OP_SQRT: case OP_SIN: case OP_COS: case OP_MAX: case OP_MIN:
+    case OP_ISNONNEG: case OP_ISPOS:
+      return true;
+    default:
+      return false;
+  }
+}
+
 // Forward evaluation of one tape node: value and the local partials
 // dl = d(node)/d(lhs), dr = d(node)/d(rhs) (only computed when requested).
 // The partials are the reference's grad_l / grad_r with the adjoint factored out.
+// FULL = false compiles only the basic op set (see op_is_basic).
+template <bool FULL = true>
 SLPX_HD void op_forward(Opcode o, double l, double r, bool want_dl, bool want_dr, double& v,
                         double& dl, double& dr) {
   dl = 0.0;
   dr = 0.0;
+  if constexpr (!FULL) {
+    switch (o) {
+      case OP_ADD: v = l + r; dl = 1.0; dr = 1.0; return;
+      case OP_SUB: v = l - r; dl = 1.0; dr = -1.0; return;
+      case OP_NEG: v = -l; dl = -1.0; return;
+      case OP_MUL: v = l * r; dl = r; dr = l; return;
+      case OP_DIV: {
+        const double inv = 1.0 / r;
+        v = l / r;
+        dl = inv;
+        dr = -v * inv;
+        return;
+      }
+      case OP_ABS: v = fabs(l); dl = l < 0.0 ? -1.0 : (l > 0.0 ? 1.0 : 0.0); return;
+      case OP_SIGN: v = l < 0.0 ? -1.0 : (l == 0.0 ? 0.0 : 1.0); return;
+      case OP_SQRT: v = sqrt(l); dl = 1.0 / (2.0 * v); return;
+      case OP_SIN: sincos(l, &v, &dl); return;
+      case OP_COS: { double s; sincos(l, &s, &v); dl = -s; return; }
+      case OP_MAX: v = l >= r ? l : r; dl = l >= r ? 1.0 : 0.0; dr = l >= r ? 0.0 : 1.0; return;
+      case OP_MIN: v = l <= r ? l : r; dl = l <= r ? 1.0 : 0.0; dr = l <= r ? 0.0 : 1.0; return;
+      case OP_ISNONNEG: v = l >= 0.0 ? 1.0 : 0.0; return;
+      case OP_ISPOS: v = l > 0.0 ? 1.0 : 0.0; return;
+      default: v = 0.0; return;
+    }
+  }
   switch (o) {
     case OP_ADD: v = l + r; dl = 1.0; dr = 1.0; break;
     case OP_SUB: v = l - r; dl = 1.0; dr = -1.0; break;
     case OP_NEG: v = -l; dl = -1.0; break;
     case OP_MUL: v = l * r; dl = r; dr = l; break;
-    case OP_DIV:
+    case OP_DIV: {
+      const double inv = 1.0 / r;
       v = l / r;
-      if (want_dl) dl = 1.0 / r;
-      if (want_dr) dr = -l / (r * r);
+      dl = inv;
+      dr = -v * inv;
       break;
+    }
     case OP_POW:
       v = pow(l, r);
       if (want_dl) dl = pow(l, r - 1.0) * r;

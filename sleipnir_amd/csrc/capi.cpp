@@ -195,7 +195,7 @@ int slpx_system_info(const slpx_system* sc, int64_t* out) {
     out[SLPX_INFO_LDLT_ROUNDS] = l.n_rounds;
     out[SLPX_INFO_LDLT_TASKS] = static_cast<int64_t>(l.tasks.size());
     out[SLPX_INFO_ETREE_HEIGHT] = l.etree_height;
-    out[SLPX_INFO_LDLT_PAIRS] = static_cast<int64_t>(l.pairs.size());
+    out[SLPX_INFO_LDLT_PAIRS] = l.flops / 2;
     out[SLPX_INFO_TAPE_TASKS] = static_cast<int64_t>(st.full.tasks.size());
     out[SLPX_INFO_TAPE_NODES] = static_cast<int64_t>(st.full.total_nodes);
     out[SLPX_INFO_TAPE_SLOTS] = static_cast<int64_t>(st.full.total_slots);

@@ -2,13 +2,16 @@
 // backward substitution.  One workgroup = one task (an elimination-subtree that fits
 // in LDS, see ldlt_symbolic.hpp); one launch = one round of independent tasks.
 //
-// Every kernel first STAGES its task into LDS with bulk coalesced loads (matrix
-// values, update-pair lists, level pointers; for the solves the L values it will
-// touch), so the dependent chain of a level is LDS latency only.  A single
-// direct-transcription KKT system is bound by (etree height) × (LDS round trip),
-// not by HBM bandwidth or flops (SURVEY.md §7 hard parts 1-3): nnz(L) ≈ 74 k and
-// ≈0.7 MFLOP at N=1000.  Batched, the bound is the HBM traffic 12·nnz(lhs) + 16·nnz(L)
-// per factorization and 32·nnz(L) + 16·n per solve.
+// Every kernel first STAGES its task into LDS: the static part (update-pair lists,
+// pointers, per-entry descriptors, level bounds) with unrolled 16-byte loads — every
+// per-task slice starts on a 16-byte boundary (ldlt_symbolic.cpp) — and the numeric
+// part (matrix values, child contributions, the L values a solve will touch) with
+// four independent gathers per lane in flight.  After that the dependent chain of a
+// level is LDS latency only.  A single direct-transcription KKT system is bound by
+// (etree height) × (LDS round trip), not by HBM bandwidth or flops (SURVEY.md §7 hard
+// parts 1-3): nnz(L) ≈ 74 k and ≈0.7 MFLOP at N=1000.  Batched, the bound is the HBM
+// traffic 12·nnz(lhs) + 16·nnz(L) per factorization and 32·nnz(L) + 16·n per solve
+// (SURVEY.md §8d).
 //
 // Replaces Eigen::SimplicialLDLT::factorize / vectorD / solve as used by
 // util/sparse_regularized_ldlt.hpp:74-83,105-109,159-161 and Inertia (inertia.hpp:40-50).
@@ -17,10 +20,9 @@
 #include <hip/hip_runtime.h>
 
 #include "device.hpp"
+#include "tape_kernels.h"  // stage16, q16
 
 namespace slpx {
-
-__device__ __forceinline__ uint32_t up8l(uint32_t b) { return (b + 7u) & ~7u; }
 
 // Sum over the 8 lanes of an aligned lane group.
 __device__ __forceinline__ double group8_sum(double v) {
@@ -36,9 +38,9 @@ __device__ __forceinline__ double group8_sum(double v) {
 // over an explicit pair list (left-looking, entry-parallel).  d_j = U(j,j),
 // L(i,j) = U(i,j)/d_j.  Eight lanes cooperate on one entry's pair list.
 //
-// LDS (bytes, 8-aligned sections):
-//   U[n_ent] f64 | invd[n_col] f64 | pairs[np] 8 B | pptr[n_ent+n_ext+1] u32 |
-//   col[n_ent] u16 | flags[n_ent] u8 | lvl[n_lvl+1] u32 | counters 32 B
+// LDS: pairs[np] 8 B | pptr[n_ent+n_ext+1] u32 | lvl[n_lvl+1] u32 | src[n_ent] i32 |
+//      col[n_ent] u16 | flags[n_ent] u8 | out[n_ent] u32 | cptr[n_ent+1] u32 |
+//      U[n_ent] f64 | invd[n_col] f64 | counters 32 B      (16-byte groups first)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
@@ -56,48 +58,76 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   D += static_cast<size_t>(b) * n;
   contrib += static_cast<size_t>(b) * contrib_stride;
 
-  const uint32_t* g_pptr = L.ent_pair_ptr + t.pair_ptr_off;
   const uint32_t n_pp = t.n_ent + t.n_ext + 1;
-  const uint32_t np = g_pptr[n_pp - 1];
-
-  double* U = reinterpret_cast<double*>(smem_raw);
+  const uint32_t np = t.n_pairs;
+  const uint32_t g_pairs = q16(np, 2), g_pptr = q16(n_pp, 4), g_lvl = q16(t.n_lvl + 1, 4),
+                 g_src = q16(t.n_ent, 4), g_col = q16(t.n_ent, 8), g_flags = q16(t.n_ent, 16),
+                 g_out = q16(t.n_ent, 4), g_cptr = q16(t.n_ent + 1, 4);
+  uint4* s_pairs = reinterpret_cast<uint4*>(smem_raw);
+  uint4* s_pptr = s_pairs + g_pairs;
+  uint4* s_lvl = s_pptr + g_pptr;
+  uint4* s_src = s_lvl + g_lvl;
+  uint4* s_col = s_src + g_src;
+  uint4* s_flags = s_col + g_col;
+  uint4* s_out = s_flags + g_flags;
+  uint4* s_cptr = s_out + g_out;
+  double* U = reinterpret_cast<double*>(s_cptr + g_cptr);
   double* invd = U + t.n_ent;
-  unsigned char* cur = reinterpret_cast<unsigned char*>(invd + t.n_col);
-  uint2* pairs = reinterpret_cast<uint2*>(cur);
-  cur += 8 * np;
-  uint32_t* pptr = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * n_pp);
-  uint16_t* col = reinterpret_cast<uint16_t*>(cur);
-  cur += up8l(2 * t.n_ent);
-  uint8_t* flags = cur;
-  cur += up8l(t.n_ent);
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * (t.n_lvl + 1));
-  int* s_cnt = reinterpret_cast<int*>(cur);
-  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(cur + 16);
+  int* s_cnt = reinterpret_cast<int*>(invd + t.n_col);
+  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
+  const uint2* pairs = reinterpret_cast<const uint2*>(s_pairs);
+  const uint32_t* pptr = reinterpret_cast<const uint32_t*>(s_pptr);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
+  const int32_t* src = reinterpret_cast<const int32_t*>(s_src);
+  const uint16_t* col = reinterpret_cast<const uint16_t*>(s_col);
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(s_flags);
+  const uint32_t* out = reinterpret_cast<const uint32_t*>(s_out);
+  const uint32_t* cptr = reinterpret_cast<const uint32_t*>(s_cptr);
 
-  // ---- stage ----
+  // ---- stage the static part ----
+  stage16<256>(s_pairs, reinterpret_cast<const uint4*>(L.pairs + t.pair_off), g_pairs, tid);
+  stage16<256>(s_pptr, reinterpret_cast<const uint4*>(L.ent_pair_ptr + t.pair_ptr_off), g_pptr, tid);
+  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<256>(s_src, reinterpret_cast<const uint4*>(L.ent_src + t.ent_off), g_src, tid);
+  stage16<256>(s_col, reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), g_col, tid);
+  stage16<256>(s_flags, reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), g_flags, tid);
+  stage16<256>(s_out, reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), g_out, tid);
+  stage16<256>(s_cptr, reinterpret_cast<const uint4*>(L.ent_contrib_ptr + t.contrib_ptr_off), g_cptr,
+               tid);
+  if (tid < 4) s_cnt[tid] = 0;
+  if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
+  __syncthreads();
+
+  // ---- matrix values: four independent gathers per lane in flight ----
   {
-    const uint2* g_pairs = reinterpret_cast<const uint2*>(L.pairs) + t.pair_off;
-    for (uint32_t i = tid; i < np; i += 256) pairs[i] = g_pairs[i];
-    for (uint32_t i = tid; i < n_pp; i += 256) pptr[i] = g_pptr[i];
-    const uint32_t* g_lvl = L.lvl_ptr + t.lvl_off;
-    for (uint32_t i = tid; i < t.n_lvl + 1; i += 256) lvl[i] = g_lvl[i];
-    const uint32_t* cptr = L.ent_contrib_ptr + t.contrib_ptr_off;
+    uint32_t i = tid;
+    for (; i + 3 * 256 < t.n_ent; i += 4 * 256) {
+      const int32_t s0 = src[i], s1 = src[i + 256], s2 = src[i + 512], s3 = src[i + 768];
+      const double a0 = s0 >= 0 ? lhs[s0] : 0.0, a1 = s1 >= 0 ? lhs[s1] : 0.0,
+                   a2 = s2 >= 0 ? lhs[s2] : 0.0, a3 = s3 >= 0 ? lhs[s3] : 0.0;
+      U[i] = a0;
+      U[i + 256] = a1;
+      U[i + 512] = a2;
+      U[i + 768] = a3;
+    }
+    for (; i < t.n_ent; i += 256) {
+      const int32_t s0 = src[i];
+      U[i] = s0 >= 0 ? lhs[s0] : 0.0;
+    }
+  }
+  __syncthreads();
+  // regularization + update blocks of child tasks (few entries have any)
+  {
     const uint32_t* cidx = L.contrib_idx + t.contrib_off;
     for (uint32_t i = tid; i < t.n_ent; i += 256) {
-      const uint32_t e = t.ent_off + i;
-      const int32_t src = L.ent_src[e];
-      const uint8_t fl = L.ent_flags[e];
-      double acc = src >= 0 ? lhs[src] : 0.0;
+      const uint8_t fl = flags[i];
+      const uint32_t cb = cptr[i], ce = cptr[i + 1];
+      if (!(fl & 1) && cb == ce) continue;
+      double acc = U[i];
       if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-      for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= contrib[cidx[c]];
+      for (uint32_t c = cb; c < ce; ++c) acc -= contrib[cidx[c]];
       U[i] = acc;
-      col[i] = L.ent_col[e];
-      flags[i] = fl;
     }
-    if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
   }
   __syncthreads();
 
@@ -136,10 +166,9 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
 
   // ---- results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero) ----
   for (uint32_t i = tid; i < t.n_ent; i += 256) {
-    const uint32_t e = t.ent_off + i;
     const double u = U[i];
     if (flags[i] & 1) {
-      D[L.ent_out[e]] = u;
+      D[out[i]] = u;
       const double eps = 2.220446049250313e-16;
       if (u > eps) atomicAdd(&s_cnt[0], 1);
       else if (u < -eps) atomicAdd(&s_cnt[1], 1);
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
       else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
     } else {
-      Lx[L.ent_out[e]] = u * invd[col[i]];
+      Lx[out[i]] = u * invd[col[i]];
     }
   }
   __syncthreads();
@@ -157,7 +186,8 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
 
 // ---------------------------------------------------------------------------
 // Forward substitution L y = P b followed by z = D⁻¹ y.
-// LDS: y[n_col+1] f64 | vals[n_items] f64 | refs[n_items] u32 | ptr[n_col+1] u32 | lvl[n_lvl+1] u32
+// LDS: items[n_items] 8 B | ptr[n_col+1] u32 | lvl[n_lvl+1] u32 | colperm[n_col] u32 |
+//      fcptr[n_col+1] u32 | vals[n_items] f64 | y[n_col+1] f64
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ rhs, int n,
@@ -173,32 +203,42 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
   zv += static_cast<size_t>(b) * n;
   scontrib += static_cast<size_t>(b) * scontrib_stride;
 
-  const uint32_t* g_ptr = L.fwd_ptr + t.colptr_off;
-  const uint32_t n_items = g_ptr[t.n_col];
-  double* y = reinterpret_cast<double*>(smem_raw);
-  double* vals = y + t.n_col + 1;
-  unsigned char* cur = reinterpret_cast<unsigned char*>(vals + n_items);
-  uint32_t* refs = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * n_items);
-  uint32_t* ptr = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * (t.n_col + 1));
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(cur);
+  const uint32_t n_items = t.n_fwd_items;
+  const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
+                 g_cp = q16(t.n_col, 4);
+  uint4* s_items = reinterpret_cast<uint4*>(smem_raw);
+  uint4* s_ptr = s_items + g_items;
+  uint4* s_lvl = s_ptr + g_ptr;
+  uint4* s_cp = s_lvl + g_lvl;
+  uint4* s_fc = s_cp + g_cp;
+  double* vals = reinterpret_cast<double*>(s_fc + g_ptr);
+  double* y = vals + n_items;
+  const uint2* items = reinterpret_cast<const uint2*>(s_items);  // x = lpos, y = ref
+  const uint32_t* ptr = reinterpret_cast<const uint32_t*>(s_ptr);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(s_cp);
+  const uint32_t* fcptr = reinterpret_cast<const uint32_t*>(s_fc);
 
+  stage16<256>(s_items, reinterpret_cast<const uint4*>(L.fwd_items + t.fwd_item_off), g_items, tid);
+  stage16<256>(s_ptr, reinterpret_cast<const uint4*>(L.fwd_ptr + t.colptr_off), g_ptr, tid);
+  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
+  stage16<256>(s_fc, reinterpret_cast<const uint4*>(L.fwd_contrib_ptr + t.colptr_off), g_ptr, tid);
+  __syncthreads();
   {
-    const LdltSolveItem* items = L.fwd_items + t.fwd_item_off;
-    for (uint32_t q = tid; q < n_items; q += 256) {
-      const LdltSolveItem it = items[q];
-      vals[q] = Lx[it.lpos];
-      refs[q] = it.ref;
+    uint32_t q = tid;
+    for (; q + 3 * 256 < n_items; q += 4 * 256) {
+      const double a0 = Lx[items[q].x], a1 = Lx[items[q + 256].x], a2 = Lx[items[q + 512].x],
+                   a3 = Lx[items[q + 768].x];
+      vals[q] = a0;
+      vals[q + 256] = a1;
+      vals[q + 512] = a2;
+      vals[q + 768] = a3;
     }
-    for (uint32_t i = tid; i < t.n_col + 1; i += 256) ptr[i] = g_ptr[i];
-    const uint32_t* g_lvl = L.col_lvl_ptr + t.lvl_off;
-    for (uint32_t i = tid; i < t.n_lvl + 1; i += 256) lvl[i] = g_lvl[i];
-    const uint32_t* fcptr = L.fwd_contrib_ptr + t.colptr_off;
+    for (; q < n_items; q += 256) vals[q] = Lx[items[q].x];
     const uint32_t* scidx = L.scontrib_idx + t.scontrib_off;
     for (uint32_t i = tid; i < t.n_col; i += 256) {
-      const uint32_t pj = L.col_perm[t.col_off + i];
-      double acc = rhs[L.perm[pj]];
+      double acc = rhs[L.perm[colperm[i]]];
       for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= scontrib[scidx[c]];
       y[i] = acc;
     }
@@ -208,7 +248,7 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     const uint32_t beg = lvl[l], end = lvl[l + 1];
     for (uint32_t i = beg + tid; i < end; i += 256) {
       double acc = y[i];
-      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * y[refs[q]];
+      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * y[items[q].y];
       y[i] = acc;
     }
     __syncthreads();
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     scontrib[L.sext_dst[t.sext_off + x]] = acc;
   }
   for (uint32_t i = tid; i < t.n_col; i += 256) {
-    const uint32_t pj = L.col_perm[t.col_off + i];
+    const uint32_t pj = colperm[i];
     zv[pj] = y[i] / D[pj];
   }
 }
@@ -231,7 +271,8 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 // Backward substitution Lᵀ x = z; result un-permuted.  Rows owned by ancestor tasks
 // are final (earlier launch): their products are folded into the staged values and
 // point at the constant-one slot x[n_col], so the level loop is uniform.
-// LDS: x[n_col+1] f64 | vals[n_items] f64 | refs[n_items] u32 | ptr[n_col+1] u32 | lvl[n_lvl+1] u32
+// LDS: items[n_items] 8 B | ptr[n_col+1] u32 | lvl[n_lvl+1] u32 | colperm[n_col] u32 |
+//      vals[n_items] f64 | refs[n_items] u32 (8-aligned) | x[n_col+1] f64
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
@@ -245,34 +286,62 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   xg += static_cast<size_t>(b) * n;
   out += static_cast<size_t>(b) * n;
 
-  const uint32_t* g_ptr = L.bwd_ptr + t.colptr_off;
-  const uint32_t n_items = g_ptr[t.n_col];
-  double* x = reinterpret_cast<double*>(smem_raw);
-  double* vals = x + t.n_col + 1;
-  unsigned char* cur = reinterpret_cast<unsigned char*>(vals + n_items);
-  uint32_t* refs = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * n_items);
-  uint32_t* ptr = reinterpret_cast<uint32_t*>(cur);
-  cur += up8l(4 * (t.n_col + 1));
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(cur);
+  const uint32_t n_items = t.n_bwd_items;
+  const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
+                 g_cp = q16(t.n_col, 4);
+  uint4* s_items = reinterpret_cast<uint4*>(smem_raw);
+  uint4* s_ptr = s_items + g_items;
+  uint4* s_lvl = s_ptr + g_ptr;
+  uint4* s_cp = s_lvl + g_lvl;
+  double* vals = reinterpret_cast<double*>(s_cp + g_cp);
+  double* x = vals + n_items;
+  uint2* items = reinterpret_cast<uint2*>(s_items);  // x = lpos, y = ref (rewritten in place)
+  const uint32_t* ptr = reinterpret_cast<const uint32_t*>(s_ptr);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(s_cp);
 
+  stage16<256>(s_items, reinterpret_cast<const uint4*>(L.bwd_items + t.bwd_item_off), g_items, tid);
+  stage16<256>(s_ptr, reinterpret_cast<const uint4*>(L.bwd_ptr + t.colptr_off), g_ptr, tid);
+  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
+  __syncthreads();
   {
-    const LdltSolveItem* items = L.bwd_items + t.bwd_item_off;
-    for (uint32_t q = tid; q < n_items; q += 256) {
-      const LdltSolveItem it = items[q];
-      const double lv = Lx[it.lpos];
-      if (it.ref & 0x80000000u) {
-        vals[q] = lv * xg[it.ref & 0x7fffffffu];
-        refs[q] = t.n_col;
+    auto load_item = [&](uint32_t q, double& v, uint32_t& r) {
+      const uint2 it = items[q];
+      const double lv = Lx[it.x];
+      if (it.y & 0x80000000u) {
+        v = lv * xg[it.y & 0x7fffffffu];
+        r = t.n_col;
       } else {
-        vals[q] = lv;
-        refs[q] = it.ref;
+        v = lv;
+        r = it.y;
       }
+    };
+    uint32_t q = tid;
+    for (; q + 3 * 256 < n_items; q += 4 * 256) {
+      double v0, v1, v2, v3;
+      uint32_t r0, r1, r2, r3;
+      load_item(q, v0, r0);
+      load_item(q + 256, v1, r1);
+      load_item(q + 512, v2, r2);
+      load_item(q + 768, v3, r3);
+      vals[q] = v0;
+      vals[q + 256] = v1;
+      vals[q + 512] = v2;
+      vals[q + 768] = v3;
+      items[q].y = r0;
+      items[q + 256].y = r1;
+      items[q + 512].y = r2;
+      items[q + 768].y = r3;
     }
-    for (uint32_t i = tid; i < t.n_col + 1; i += 256) ptr[i] = g_ptr[i];
-    const uint32_t* g_lvl = L.col_lvl_ptr + t.lvl_off;
-    for (uint32_t i = tid; i < t.n_lvl + 1; i += 256) lvl[i] = g_lvl[i];
-    for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[L.col_perm[t.col_off + i]];
+    for (; q < n_items; q += 256) {
+      double v0;
+      uint32_t r0;
+      load_item(q, v0, r0);
+      vals[q] = v0;
+      items[q].y = r0;
+    }
+    for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[colperm[i]];
     if (tid == 0) x[t.n_col] = 1.0;
   }
   __syncthreads();
@@ -280,13 +349,13 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     const uint32_t beg = lvl[l], end = lvl[l + 1];
     for (uint32_t i = beg + tid; i < end; i += 256) {
       double acc = x[i];
-      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * x[refs[q]];
+      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * x[items[q].y];
       x[i] = acc;
     }
     __syncthreads();
   }
   for (uint32_t i = tid; i < t.n_col; i += 256) {
-    const uint32_t pj = L.col_perm[t.col_off + i];
+    const uint32_t pj = colperm[i];
     xg[pj] = x[i];
     out[L.perm[pj]] = x[i];
   }

@@ -443,6 +443,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     }
   }
 
+  size_t n_real_pairs = 0;
   // ---- flatten, tasks sorted by round ------------------------------------------------
   std::vector<int> torder(ntasks);
   std::iota(torder.begin(), torder.end(), 0);
@@ -453,6 +454,32 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   for (int r = 0; r < P.n_rounds; ++r) P.round_ptr[r + 1] += P.round_ptr[r];
 
   for (int t : torder) {
+    // 16-byte alignment of every per-task slice (the kernels stage them into LDS with
+    // unrolled 16-byte loads)
+    auto pad = [](auto& v, size_t multiple) {
+      while (v.size() % multiple) v.push_back({});
+    };
+    while (P.ent_src.size() % 16) {
+      P.ent_src.push_back(-1);
+      P.ent_flags.push_back(0);
+      P.ent_col.push_back(0);
+      P.ent_out.push_back(0);
+    }
+    pad(P.pairs, 2);
+    pad(P.ent_pair_ptr, 4);
+    pad(P.ent_contrib_ptr, 4);
+    while (P.lvl_ptr.size() % 4) {
+      P.lvl_ptr.push_back(0);
+      P.col_lvl_ptr.push_back(0);
+    }
+    pad(P.col_perm, 4);
+    while (P.fwd_ptr.size() % 4) {
+      P.fwd_ptr.push_back(0);
+      P.fwd_contrib_ptr.push_back(0);
+      P.bwd_ptr.push_back(0);
+    }
+    pad(P.fwd_items, 2);
+    pad(P.bwd_items, 2);
     LdltTask T{};
     const auto& cols = tcols[t].cols;
     T.round = static_cast<uint32_t>(tcols[t].round);
@@ -531,6 +558,10 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       pair_count += static_cast<uint32_t>(ex.pairs.size());
     }
     P.ent_pair_ptr.push_back(pair_count);
+    n_real_pairs += pair_count;
+    T.n_pairs = pair_count;
+    T.n_fwd_items = fwd_count;
+    T.n_bwd_items = bwd_count;
     P.ent_contrib_ptr.push_back(contrib_count);
     P.fwd_ptr.push_back(fwd_count);
     P.fwd_contrib_ptr.push_back(sc_count);
@@ -545,14 +576,14 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     P.sext_ptr.push_back(sitem);
     P.max_lds_doubles = std::max(P.max_lds_doubles, T.n_ent + T.n_col);
     P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, T.n_col);
-    // LDS working sets of the staged kernels (see kernels.hip for the carve-up)
-    auto up8 = [](uint32_t b) { return (b + 7u) & ~7u; };
-    const uint32_t fb = 8 * T.n_ent + 8 * T.n_col + up8(8 * pair_count) +
-                        up8(4 * (T.n_ent + T.n_ext + 1)) + up8(2 * T.n_ent) + up8(T.n_ent) +
-                        up8(4 * (T.n_lvl + 1)) + 32;
+    // LDS working sets of the staged kernels (see ldlt_kernels.h for the carve-up)
+    auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
+    const uint32_t fb = q(pair_count, 2) + q(T.n_ent + T.n_ext + 1, 4) + q(T.n_lvl + 1, 4) +
+                        q(T.n_ent, 4) + q(T.n_ent, 8) + q(T.n_ent, 16) + q(T.n_ent, 4) +
+                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32;
     const uint32_t items = std::max(fwd_count, bwd_count);
-    const uint32_t sb = 8 * (T.n_col + 1) + 8 * items + up8(4 * items) + up8(4 * (T.n_col + 1)) +
-                        up8(4 * (T.n_lvl + 1)) + 32;
+    const uint32_t sb = q(items, 2) + 2 * q(T.n_col + 1, 4) + q(T.n_lvl + 1, 4) + q(T.n_col, 4) +
+                        8 * items + 8 * (T.n_col + 1) + 32;
     P.factor_lds_bytes = std::max(P.factor_lds_bytes, fb);
     P.solve_lds_bytes = std::max(P.solve_lds_bytes, sb);
     P.tasks.push_back(T);
@@ -563,10 +594,28 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   for (int j = 0; j < n; ++j)
     if (!has_diag[P.perm[j]] && !diag_updated_perm[j]) P.structurally_singular_unregularized = true;
 
+  // tail padding: the staged kernels read whole 16-byte groups
+  for (int k = 0; k < 16; ++k) {
+    P.ent_src.push_back(-1);
+    P.ent_flags.push_back(0);
+    P.ent_col.push_back(0);
+    P.ent_out.push_back(0);
+    P.pairs.push_back({});
+    P.ent_pair_ptr.push_back(0);
+    P.ent_contrib_ptr.push_back(0);
+    P.lvl_ptr.push_back(0);
+    P.col_lvl_ptr.push_back(0);
+    P.col_perm.push_back(0);
+    P.fwd_ptr.push_back(0);
+    P.fwd_contrib_ptr.push_back(0);
+    P.bwd_ptr.push_back(0);
+    P.fwd_items.push_back({});
+    P.bwd_items.push_back({});
+  }
   if (P.factor_lds_bytes > 160u * 1024u || P.solve_lds_bytes > 160u * 1024u)
     throw std::runtime_error("ldlt: a task's working set exceeds the 160 KB LDS of a CU; lower "
                              "LdltOptions::task_entries");
-  P.flops = 2 * static_cast<int64_t>(P.pairs.size());
+  P.flops = 2 * static_cast<int64_t>(n_real_pairs);
   P.factor_bytes = 12LL * lower.nnz() + 16LL * (P.nnzL + n);
   P.solve_bytes = 32LL * P.nnzL + 16LL * n;
   return P;

@@ -52,6 +52,8 @@ struct LdltTask {
   uint32_t contrib_ptr_off;  // ent_contrib_ptr: n_ent + 1 entries
   uint32_t colptr_off;       // fwd_ptr / fwd_contrib_ptr / bwd_ptr: n_col + 1 entries
   uint32_t sext_ptr_off;     // sext_ptr: n_sext + 1 entries
+  uint32_t n_pairs;          // update pairs of own + pseudo entries
+  uint32_t n_fwd_items, n_bwd_items;
 };
 
 struct LdltSolveItem {

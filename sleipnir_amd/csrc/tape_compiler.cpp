@@ -404,6 +404,27 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
   std::vector<int32_t> local_slot(slots.size(), -1);
   for (size_t pi = 0; pi < packs.size(); ++pi) {
     Pack& pk = packs[pi];
+    // Every task's slice of every program array starts on a 16-byte boundary, so the
+    // kernel can stage it into LDS with unrolled 16-byte loads.
+    auto pad = [](auto& v, size_t multiple) {
+      while (v.size() % multiple) v.push_back({});
+    };
+    while ((prog.node_rec.size() / 3) % 2) {  // 8-byte packed records: even node offset
+      for (int k = 0; k < 3; ++k) prog.node_rec.push_back(0);
+      for (int k = 0; k < 4; ++k) prog.node_rec16.push_back(0);
+    }
+    while (prog.edges.size() % 4) {  // 4-byte packed edges
+      prog.edges.push_back({0, 0});
+      prog.edges16.push_back(0);
+      prog.edges16.push_back(0);
+    }
+    while (prog.slot_edge_ptr.size() % 8) {  // 2-byte packed edge pointers
+      prog.slot_edge_ptr.push_back(0);
+      prog.slot_edge_ptr16.push_back(0);
+    }
+    pad(prog.lvl_ptr, 4);
+    pad(prog.slvl_ptr, 4);
+    pad(prog.leaf_src, 4);
     TapeTask t{};
     t.leaf_off = static_cast<uint32_t>(prog.leaf_src.size());
     t.node_off = static_cast<uint32_t>(prog.node_rec.size() / 3);
@@ -523,9 +544,9 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     t.n_vout = static_cast<uint32_t>(prog.vout_src.size() - t.vout_off);
     t.n_jout = static_cast<uint32_t>(prog.jout_slot.size() - t.jout_off);
     t.lds_doubles = t.n_leaf + 3 * t.n_node + t.n_slot;
-    auto up8 = [](uint32_t b) { return (b + 7u) & ~7u; };
-    t.lds_bytes = 8 * t.lds_doubles + 8 * t.n_node + up8(4 * t.n_edge) + up8(2 * (t.n_slot + 1)) +
-                  up8(4 * (t.n_lvl + 1)) + up8(4 * (t.n_slvl + 1));
+    auto q16 = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
+    t.lds_bytes = q16(t.n_node, 2) + q16(t.n_edge, 4) + q16(t.n_slot + 1, 8) + q16(t.n_lvl + 1, 4) +
+                  q16(t.n_slvl + 1, 4) + q16(t.n_leaf, 4) + 8 * t.lds_doubles;
     int cls = pk.cls;
     if (cls == 0 && t.lds_bytes > small_cap) cls = 1;
     if (cls == 1 && t.lds_bytes > large_cap) cls = 2;
@@ -549,6 +570,15 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     prog.total_nodes += t.n_node;
     prog.total_slots += t.n_slot;
     prog.total_leaves += t.n_leaf;
+  }
+  // tail padding: the staged kernel reads whole 16-byte groups
+  for (int k = 0; k < 16; ++k) {
+    prog.node_rec16.push_back(0);
+    prog.edges16.push_back(0);
+    prog.slot_edge_ptr16.push_back(0);
+    prog.lvl_ptr.push_back(0);
+    prog.slvl_ptr.push_back(0);
+    prog.leaf_src.push_back(0);
   }
   for (auto& v : value_outs) prog.n_outputs = std::max(prog.n_outputs, v.dst + 1);
   for (auto& r : rows)

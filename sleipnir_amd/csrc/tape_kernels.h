@@ -3,9 +3,9 @@
 // One workgroup executes one TASK (a bin-packed set of graph components, normally
 // one direct-transcription stage) start to finish:
 //   1. stage the task's PROGRAM (16-bit packed node records, adjoint edges, level
-//      pointers) and its leaf values into LDS with coalesced bulk loads — after
-//      this the level loops never touch global memory, so a level costs LDS latency
-//      (~100 cycles), not an L2 round trip per dependent metadata load;
+//      pointers, leaf bindings) into LDS with unrolled 16-byte loads — every slice
+//      starts on a 16-byte boundary (tape_compiler.cpp), four loads per lane are in
+//      flight, and after this the level loops never touch global memory;
 //   2. forward sweep: one group of independent nodes per level; every node stores
 //      its value and its two local partials;
 //   3. adjoint sweep: per-(row, node) slots gathered level by level:
@@ -27,18 +27,29 @@
 
 namespace slpx {
 
-__device__ __forceinline__ uint32_t up8u(uint32_t b) { return (b + 7u) & ~7u; }
-
-// cooperative copy of `count` 4-byte words (count may be 0)
+// Cooperative global -> LDS copy of `n16` 16-byte groups, four loads in flight per lane.
 template <int THREADS>
-__device__ __forceinline__ void stage_words(uint32_t* dst, const uint32_t* __restrict__ src,
-                                            uint32_t count, int tid) {
-  for (uint32_t i = tid; i < count; i += THREADS) dst[i] = src[i];
+__device__ __forceinline__ void stage16(uint4* __restrict__ dst, const uint4* __restrict__ src,
+                                        uint32_t n16, int tid) {
+  uint32_t i = tid;
+  for (; i + 3 * THREADS < n16; i += 4 * THREADS) {
+    const uint4 a = src[i], b = src[i + THREADS], c = src[i + 2 * THREADS], d = src[i + 3 * THREADS];
+    dst[i] = a;
+    dst[i + THREADS] = b;
+    dst[i + 2 * THREADS] = c;
+    dst[i + 3 * THREADS] = d;
+  }
+  for (; i < n16; i += THREADS) dst[i] = src[i];
 }
 
-// LDS layout (bytes, every section 8-aligned):
-//   val[n_leaf+n_node] f64 | part[2 n_node] f64 | adj[n_slot] f64 | rec[n_node] 8 B |
-//   edges[n_edge] 4 B | eptr[n_slot+1] 2 B | lvl[n_lvl+1] 4 B | slvl[n_slvl+1] 4 B
+__device__ __forceinline__ uint32_t q16(uint32_t count, uint32_t per16) {
+  return (count + per16 - 1) / per16;
+}
+
+// LDS layout (16-byte groups first, then doubles):
+//   rec[n_node] 8 B | edges[n_edge] 4 B | eptr[n_slot+1] 2 B | lvl[n_lvl+1] 4 B |
+//   slvl[n_slvl+1] 4 B | leaf_src[n_leaf] 4 B | val[n_leaf+n_node] f64 | part[2 n_node] f64 |
+//   adj[n_slot] f64
 template <int THREADS, bool FULL_OPS>
 __global__ __launch_bounds__(THREADS) void tape_sweep_lds_kernel(
     TapeDev T, const uint32_t* __restrict__ task_list, const double* __restrict__ in, int in_stride,
@@ -51,36 +62,40 @@ __global__ __launch_bounds__(THREADS) void tape_sweep_lds_kernel(
   in += static_cast<size_t>(b) * in_stride;
   V += static_cast<size_t>(b) * v_stride;
 
-  double* val = reinterpret_cast<double*>(smem_raw);
+  uint4* base = reinterpret_cast<uint4*>(smem_raw);
+  const uint32_t g_rec = q16(t.n_node, 2), g_edge = q16(t.n_edge, 4), g_eptr = q16(t.n_slot + 1, 8),
+                 g_lvl = q16(t.n_lvl + 1, 4), g_slvl = q16(t.n_slvl + 1, 4), g_leaf = q16(t.n_leaf, 4);
+  uint4* s_rec = base;
+  uint4* s_edge = s_rec + g_rec;
+  uint4* s_eptr = s_edge + g_edge;
+  uint4* s_lvl = s_eptr + g_eptr;
+  uint4* s_slvl = s_lvl + g_lvl;
+  uint4* s_leaf = s_slvl + g_slvl;
+  double* val = reinterpret_cast<double*>(s_leaf + g_leaf);
   double* part = val + t.n_leaf + t.n_node;
   double* adj = part + 2 * t.n_node;
-  unsigned char* cur = reinterpret_cast<unsigned char*>(adj + t.n_slot);
-  uint2* rec = reinterpret_cast<uint2*>(cur);
-  cur += 8 * t.n_node;
-  uint32_t* edges = reinterpret_cast<uint32_t*>(cur);
-  cur += up8u(4 * t.n_edge);
-  uint16_t* eptr = reinterpret_cast<uint16_t*>(cur);
-  cur += up8u(2 * (t.n_slot + 1));
-  uint32_t* lvl = reinterpret_cast<uint32_t*>(cur);
-  cur += up8u(4 * (t.n_lvl + 1));
-  uint32_t* slvl = reinterpret_cast<uint32_t*>(cur);
+  const uint2* rec = reinterpret_cast<const uint2*>(s_rec);
+  const uint32_t* edges = reinterpret_cast<const uint32_t*>(s_edge);
+  const uint16_t* eptr = reinterpret_cast<const uint16_t*>(s_eptr);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
+  const uint32_t* slvl = reinterpret_cast<const uint32_t*>(s_slvl);
+  const uint32_t* leaf_src = reinterpret_cast<const uint32_t*>(s_leaf);
 
-  // ---- stage program + leaves ----
-  {
-    const uint2* g_rec = reinterpret_cast<const uint2*>(T.node_rec16) + t.node_off;
-    for (uint32_t i = tid; i < t.n_node; i += THREADS) rec[i] = g_rec[i];
-    stage_words<THREADS>(lvl, T.lvl_ptr + t.lvl_off, t.n_lvl + 1, tid);
-    if (do_reverse && t.n_slot) {
-      stage_words<THREADS>(edges, reinterpret_cast<const uint32_t*>(T.edges16) + t.edge_off,
-                           t.n_edge, tid);
-      const uint16_t* g_eptr = T.slot_edge_ptr16 + t.slot_off;
-      for (uint32_t i = tid; i < t.n_slot + 1; i += THREADS) eptr[i] = g_eptr[i];
-      stage_words<THREADS>(slvl, T.slvl_ptr + t.slvl_off, t.n_slvl + 1, tid);
-    }
-    for (uint32_t i = tid; i < t.n_leaf; i += THREADS) {
-      const uint32_t src = T.leaf_src[t.leaf_off + i];
-      val[i] = (src & kLeafConstFlag) ? T.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
-    }
+  // ---- stage the program (all offsets are multiples of 16 bytes) ----
+  stage16<THREADS>(s_rec, reinterpret_cast<const uint4*>(T.node_rec16 + 4 * static_cast<size_t>(t.node_off)),
+                   g_rec, tid);
+  stage16<THREADS>(s_lvl, reinterpret_cast<const uint4*>(T.lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<THREADS>(s_leaf, reinterpret_cast<const uint4*>(T.leaf_src + t.leaf_off), g_leaf, tid);
+  if (do_reverse && t.n_slot) {
+    stage16<THREADS>(s_edge, reinterpret_cast<const uint4*>(T.edges16 + 2 * static_cast<size_t>(t.edge_off)),
+                     g_edge, tid);
+    stage16<THREADS>(s_eptr, reinterpret_cast<const uint4*>(T.slot_edge_ptr16 + t.slot_off), g_eptr, tid);
+    stage16<THREADS>(s_slvl, reinterpret_cast<const uint4*>(T.slvl_ptr + t.slvl_off), g_slvl, tid);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < t.n_leaf; i += THREADS) {
+    const uint32_t src = leaf_src[i];
+    val[i] = (src & kLeafConstFlag) ? T.consts[src & ~kLeafConstFlag] : in[src] * in_scale[src];
   }
   __syncthreads();
 

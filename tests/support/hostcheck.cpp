@@ -159,7 +159,7 @@ void hc_info(hc_handle* h, int64_t* out) {
   out[i++] = h->l.n_rounds;
   out[i++] = static_cast<int64_t>(h->l.tasks.size());
   out[i++] = h->l.etree_height;
-  out[i++] = static_cast<int64_t>(h->l.pairs.size());
+  out[i++] = h->l.flops / 2;
   out[i++] = static_cast<int64_t>(h->s.full.tasks.size());
   out[i++] = static_cast<int64_t>(h->s.full.total_nodes);
   out[i++] = static_cast<int64_t>(h->s.full.total_slots);

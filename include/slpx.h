@@ -169,6 +169,9 @@ int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info);
 /* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values */
 int64_t slpx_system_get(slpx_system* s, int which, double* out);
 int slpx_system_set_rhs(slpx_system* s, const double* rhs);
+/* RegularizedLDLT::compute(lhs) with a caller-assembled matrix (regularized_ldlt.hpp:72):
+ * values in the order of pattern 5 (lower CSC, forced diagonal), [batch][nnz]. */
+int slpx_system_set_lhs(slpx_system* s, const double* lhs);
 
 /* Times `iters` Newton steps with HIP events on the system's stream.
  * ms[8] = per-step averages {sweep, assemble, rhs, factor(all attempts), solve, backsub,

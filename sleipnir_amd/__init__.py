@@ -135,6 +135,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_newton_step", ctypes.c_int, vp, ctypes.c_int, vp)
     sig("slpx_system_get", i64, vp, ctypes.c_int, vp)
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
+    sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
     _lib = L
     return L
@@ -322,8 +323,15 @@ class System:
         r = _f64(rhs)
         _check(lib().slpx_system_set_rhs(self._h, r.ctypes.data))
 
+    def set_lhs(self, lhs):
+        a = _f64(lhs)
+        _check(lib().slpx_system_set_lhs(self._h, a.ctypes.data))
+
     def time_step(self, iters=10, refresh_ad=True):
         ms = np.zeros(8, dtype=np.float32)
         _check(lib().slpx_system_time_step(self._h, iters, int(refresh_ad), ms.ctypes.data))
         keys = ["sweep", "assemble", "rhs", "factor", "solve", "backsub", "total", "factorizations"]
         return {k: float(ms[i]) for i, k in enumerate(keys)}
+
+
+from .dist import Comm, shard_range  # noqa: E402,F401  (multi-GPU plumbing)

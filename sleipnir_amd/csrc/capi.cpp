@@ -365,6 +365,15 @@ int slpx_system_set_rhs(slpx_system* s, const double* rhs) {
   });
 }
 
+int slpx_system_set_lhs(slpx_system* s, const double* lhs) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    const size_t count = static_cast<size_t>(dev.batch()) * s->get().kkt().lhs.nnz();
+    SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_lhs(), lhs, count * sizeof(double), hipMemcpyHostToDevice, dev.stream()));
+    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  });
+}
+
 int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) {
   return guard([&] {
     auto& sys = s->get();

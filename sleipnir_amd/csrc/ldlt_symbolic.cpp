@@ -21,13 +21,52 @@ struct Orderer {
   std::vector<int32_t> stamp, dist;
   int32_t cur_stamp = 0;
   std::vector<int32_t> order;
+  // Pairing state for nodes whose unregularized diagonal is structurally zero
+  // (constraint rows, variables that appear only linearly): such a node z may only be
+  // eliminated after an ORIGINAL neighbour v that no other zero-diagonal node has
+  // already claimed — then its pivot is -a_zv^2/d_v.  Two zero-diagonal nodes claiming
+  // the same v would make the leading block [[d,a,b],[a,0,0],[b,0,0]] singular whatever
+  // the values.  With distinct claims the claimed pairs form paths whose every prefix
+  // has a perfect matching, so every leading principal block is structurally
+  // nonsingular.
+  std::vector<uint8_t> gone, claimed;
+  std::vector<int32_t> avail;  // # eliminated, unclaimed original neighbours
+  bool forced = false;         // some node had to be eliminated without a partner
 
   Orderer(const Adj& a, const std::vector<uint8_t>& hd, const LdltOptions& o)
-      : adj(a), has_diag(hd), opt(o), stamp(a.size(), 0), dist(a.size(), 0) {}
+      : adj(a), has_diag(hd), opt(o), stamp(a.size(), 0), dist(a.size(), 0),
+        gone(a.size(), 0), claimed(a.size(), 0), avail(a.size(), 0) {}
 
-  // Minimum degree on the subgraph induced by `nodes`.  With defer_constraints,
-  // a constraint node (index >= n_dec, zero diagonal) is only eligible once one
-  // of its neighbours has been eliminated, so its pivot is not structurally 0.
+  bool ready(int32_t v) const { return !opt.defer_constraints || has_diag[v] || avail[v] > 0; }
+
+  void eliminate(int32_t v) {
+    if (opt.defer_constraints && !has_diag[v]) {
+      // claim the partner that the fewest other waiting zero-diagonal nodes could use
+      int32_t partner = -1, partner_demand = 0;
+      for (int32_t w : adj[v]) {
+        if (!gone[w] || claimed[w]) continue;
+        int32_t demand = 0;
+        for (int32_t u : adj[w])
+          if (!gone[u] && u != v && !has_diag[u]) ++demand;
+        if (partner < 0 || demand < partner_demand) {
+          partner = w;
+          partner_demand = demand;
+        }
+      }
+      if (partner < 0) {
+        forced = true;
+      } else {
+        claimed[partner] = 1;
+        for (int32_t u : adj[partner]) --avail[u];
+      }
+    }
+    gone[v] = 1;
+    order.push_back(v);
+    for (int32_t u : adj[v]) ++avail[u];
+  }
+
+  // Minimum degree on the subgraph induced by `nodes`; with defer_constraints a
+  // zero-diagonal node is only eligible while it has an unclaimed eliminated partner.
   void min_degree(const std::vector<int32_t>& nodes) {
     const int m = static_cast<int>(nodes.size());
     std::unordered_map<int32_t, int32_t> loc;
@@ -40,20 +79,18 @@ struct Orderer {
         if (it != loc.end()) a[i].push_back(it->second);
       }
     for (auto& v : a) std::sort(v.begin(), v.end());
-    std::vector<uint8_t> gone(m, 0), ready(m, 0);
-    for (int i = 0; i < m; ++i) ready[i] = !opt.defer_constraints || has_diag[nodes[i]];
+    std::vector<uint8_t> done(m, 0);
     std::vector<int32_t> merged;
     for (int step = 0; step < m; ++step) {
       int best = -1;
       for (int pass = 0; pass < 2 && best < 0; ++pass)
         for (int i = 0; i < m; ++i) {
-          if (gone[i] || (pass == 0 && !ready[i])) continue;
+          if (done[i] || (pass == 0 && !ready(nodes[i]))) continue;
           if (best < 0 || a[i].size() < a[best].size()) best = i;
         }
-      gone[best] = 1;
-      order.push_back(nodes[best]);
+      done[best] = 1;
+      eliminate(nodes[best]);
       for (int32_t u : a[best]) {
-        ready[u] = 1;
         merged.clear();
         std::set_union(a[u].begin(), a[u].end(), a[best].begin(), a[best].end(),
                        std::back_inserter(merged));
@@ -63,6 +100,24 @@ struct Orderer {
         a[u].swap(merged);
       }
       a[best].clear();
+    }
+  }
+
+  // Separator nodes: variables with a diagonal first, then zero-diagonal nodes as they
+  // find partners.
+  void order_separator(std::vector<int32_t> sep) {
+    std::sort(sep.begin(), sep.end());
+    std::vector<uint8_t> done(sep.size(), 0);
+    for (size_t step = 0; step < sep.size(); ++step) {
+      int best = -1;
+      for (int pass = 0; pass < 3 && best < 0; ++pass)
+        for (size_t i = 0; i < sep.size() && best < 0; ++i) {
+          if (done[i]) continue;
+          const int32_t v = sep[i];
+          if (pass == 0 ? (has_diag[v] != 0) : (pass == 1 ? ready(v) : true)) best = static_cast<int>(i);
+        }
+      done[best] = 1;
+      eliminate(sep[best]);
     }
   }
 
@@ -160,12 +215,8 @@ struct Orderer {
     std::sort(right.begin(), right.end());
     dissect(std::move(left));
     dissect(std::move(right));
-    // separator last; variables before constraints so a constraint's pivot sees
-    // its variables already eliminated
-    std::sort(sep.begin(), sep.end());
-    if (opt.defer_constraints)
-      std::stable_partition(sep.begin(), sep.end(), [&](int32_t v) { return has_diag[v] != 0; });
-    order.insert(order.end(), sep.begin(), sep.end());
+    // separator last
+    order_separator(std::move(sep));
   }
 };
 
@@ -183,6 +234,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     has_diag[i] = diag_has_source ? (*diag_has_source)[i] : static_cast<uint8_t>(i < n_dec);
 
   // ---- ordering -------------------------------------------------------------
+  bool ordering_forced = false;
   if (user_perm != nullptr && !user_perm->empty()) {
     P.perm = *user_perm;
   } else {
@@ -204,6 +256,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     std::iota(all.begin(), all.end(), 0);
     ord.dissect(std::move(all));
     P.perm = std::move(ord.order);
+    ordering_forced = ord.forced;
   }
   if (static_cast<int>(P.perm.size()) != n) throw std::runtime_error("ldlt: bad permutation size");
   P.iperm.assign(n, -1);
@@ -593,6 +646,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   // block (no lhs source other than the forced 0) that no earlier column updates
   for (int j = 0; j < n; ++j)
     if (!has_diag[P.perm[j]] && !diag_updated_perm[j]) P.structurally_singular_unregularized = true;
+  if (ordering_forced) P.structurally_singular_unregularized = true;
 
   // tail padding: the staged kernels read whole 16-byte groups
   for (int k = 0; k < 16; ++k) {

@@ -29,6 +29,38 @@ def newton_state(case: str, x0, n, m_e, m_i, d_f, seed=SEED):
     return x, s, y, z, 0.1 * d_f
 
 
+# Cart-pole model constants (benchmarks/scalability/cart_pole/sleipnir.cpp:42-45,
+# test/include/cart_pole_util.hpp): m_c, m_p, l, g
+CP_MC, CP_MP, CP_L, CP_G = 5.0, 0.5, 0.5, 9.806
+
+
+def cart_pole_dynamics(x, u):
+    """Plain-float ẋ = f(x, u) (cart_pole_util.hpp:43-78), x = [x, θ, ẋ, θ̇], u = [f_x]."""
+    theta, thetadot = x[1], x[3]
+    M = np.array([[CP_MC + CP_MP, CP_MP * CP_L * np.cos(theta)],
+                  [CP_MP * CP_L * np.cos(theta), CP_MP * CP_L ** 2]])
+    C = np.array([[0.0, -CP_MP * CP_L * thetadot * np.sin(theta)], [0.0, 0.0]])
+    tau_g = np.array([0.0, -CP_MP * CP_G * CP_L * np.sin(theta)])
+    qdd = np.linalg.solve(M, tau_g - C @ x[2:4] + np.array([1.0, 0.0]) * u[0])
+    return np.array([x[2], x[3], qdd[0], qdd[1]])
+
+
+def cart_pole_rk4(x, u, dt):
+    """benchmarks/rk4.hpp:14-23 with zero-order-hold input."""
+    k1 = cart_pole_dynamics(x, u)
+    k2 = cart_pole_dynamics(x + 0.5 * dt * k1, u)
+    k3 = cart_pole_dynamics(x + 0.5 * dt * k2, u)
+    k4 = cart_pole_dynamics(x + dt * k3, u)
+    return x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def cart_pole_unpack(xvec, N):
+    """Decision vector -> X (4 × N+1), U (1 × N): decision_variable(4, N+1) then
+    decision_variable(1, N), both row-major (cart_pole/sleipnir.cpp:87,98)."""
+    xvec = np.asarray(xvec)
+    return xvec[: 4 * (N + 1)].reshape(4, N + 1), xvec[4 * (N + 1):].reshape(1, N)
+
+
 def csc_to_dict(colptr, rowidx, val):
     d = {}
     for c in range(len(colptr) - 1):

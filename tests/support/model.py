@@ -296,6 +296,75 @@ class Model:
         return self.be.hessian(f.node, [w.node for w in wrt], lower)
 
 
+class NlpProblem:
+    """slp.Problem look-alike bound to a backend (problem.hpp:78-282): decision
+    variables, minimize/maximize, subject_to with the reference's row conventions
+    (variable.hpp:716-778: `lhs == rhs` and `lhs >= rhs` give the row lhs - rhs,
+    `lhs <= rhs` gives rhs - lhs; inequality rows mean c(x) >= 0)."""
+
+    SUCCESS = 0
+    CALLBACK_REQUESTED_STOP = 1
+    TOO_FEW_DOFS = -1
+    LOCALLY_INFEASIBLE = -2
+    GLOBALLY_INFEASIBLE = -3
+    FACTORIZATION_FAILED = -4
+    LINE_SEARCH_FAILED = -5
+    FEASIBILITY_RESTORATION_FAILED = -6
+    NONFINITE_INITIAL_GUESS = -7
+    DIVERGING_ITERATES = -8
+    MAX_ITERATIONS_EXCEEDED = -9
+    TIMEOUT = -10
+
+    def __init__(self, m: "Model"):
+        self.m = m
+        self.be = m.be
+        self.stats = None
+        if isinstance(self.be, OracleBackend):
+            self.p = _oracle.OracleProblem.new()
+        else:
+            self.p = self.be.sa.Problem()
+
+    def decision_variable(self, value=None):
+        if isinstance(self.be, OracleBackend):
+            node = self.be.L.orc_problem_decision_variable(self.p.pid)
+        else:
+            node = self.p.decision_variable()
+        v = Var(self.be, node)
+        if value is not None:
+            v.set_value(value)
+        return v
+
+    def decision_variables(self, n):
+        return [self.decision_variable() for _ in range(n)]
+
+    def _call(self, name, node):
+        if isinstance(self.be, OracleBackend):
+            getattr(self.be.L, "orc_problem_" + name)(self.p.pid, node)
+        else:
+            getattr(self.be.L, "slpx_problem_" + name)(self.p._h, node)
+
+    def minimize(self, f): self._call("minimize", Var._lift(self.be, f).node)
+    def maximize(self, f): self._call("maximize", Var._lift(self.be, f).node)
+
+    def eq(self, lhs, rhs): self._call("subject_to_eq", (Var._lift(self.be, lhs) - rhs).node)
+    def ge(self, lhs, rhs): self._call("subject_to_ineq", (Var._lift(self.be, lhs) - rhs).node)
+    def le(self, lhs, rhs): self._call("subject_to_ineq", (Var._lift(self.be, rhs) - lhs).node)
+
+    def bounds(self, lo, x, hi):  # variable.hpp:1008-1013
+        self.ge(x, lo)
+        self.le(x, hi)
+
+    def types(self):
+        return tuple(self.p.types())
+
+    def solve(self, **kw):
+        if isinstance(self.be, OracleBackend):
+            status, self.stats = self.p.solve(**kw)
+        else:
+            status, self.stats = self.p.solve(**kw)
+        return status
+
+
 def py_sign(x):
     return -1.0 if x < 0 else (0.0 if x == 0 else 1.0)
 

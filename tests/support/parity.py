@@ -64,7 +64,7 @@ class GpuBackend:
         return self.sys.get("p_s")[0], self.sys.get("p_z")[0]
 
 
-def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=1e-8, verbose=False):
+def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=1e-10, verbose=False):
     """Runs the step on `backend` and on the oracle `op` (same permutation) and asserts
     agreement.  Returns a dict of the observed errors."""
     n, me, mi = backend.n, backend.m_e, backend.m_i
@@ -137,7 +137,9 @@ def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=
     r_backend = cases.lower_csc_matvec(lcp, lri, Kreg, p) - rhs
     po = op.vec("p")
     r_oracle = cases.lower_csc_matvec(lcp, lri, Kreg, po) - rhs
-    scale = max(1.0, float(np.max(np.abs(rhs))))
+    # normwise backward error: ‖Kp − b‖∞ / max(‖b‖∞, ‖K‖∞‖p‖∞)
+    k_inf = float(np.max(cases.lower_csc_matvec(lcp, lri, np.abs(Kreg), np.ones_like(rhs))))
+    scale = max(1.0, float(np.max(np.abs(rhs))), k_inf * float(np.max(np.abs(po))))
     errs["resid"] = float(np.max(np.abs(r_backend))) / scale
     errs["resid_oracle"] = float(np.max(np.abs(r_oracle))) / scale
     errs["p"] = cases.max_rel(p, po)

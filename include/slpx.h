@@ -99,6 +99,7 @@ typedef struct slpx_report {
   double delta, gamma, final_error;
   double t_setup, t_kkt_build, t_kkt_decomp, t_kkt_solve, t_line_search, t_ad_refresh, t_total;
   double t_compile; /* graph -> tape/KKT plan/symbolic LDLT + upload */
+  int32_t restorations; /* feasibility-restoration phases entered (feasibility_restoration.hpp:347) */
 } slpx_report;
 
 /* Problem::solve.  Returns slp::ExitStatus (solver/exit_status.hpp:13-43):

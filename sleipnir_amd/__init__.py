@@ -53,7 +53,7 @@ class Report(ctypes.Structure):
                 ("t_kkt_build", ctypes.c_double), ("t_kkt_decomp", ctypes.c_double),
                 ("t_kkt_solve", ctypes.c_double), ("t_line_search", ctypes.c_double),
                 ("t_ad_refresh", ctypes.c_double), ("t_total", ctypes.c_double),
-                ("t_compile", ctypes.c_double)]
+                ("t_compile", ctypes.c_double), ("restorations", ctypes.c_int32)]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -215,8 +215,9 @@ class Problem:
         x = _f64(x)
         lib().slpx_problem_set_x(self._h, x.ctypes.data)
 
-    def solve(self, tolerance=1e-8, max_iterations=5000, timeout=0.0, feasible_ipm=False):
-        opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), 0)
+    def solve(self, tolerance=1e-8, max_iterations=5000, timeout=0.0, feasible_ipm=False,
+              diagnostics=False):
+        opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), int(diagnostics))
         rep = Report()
         status = lib().slpx_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(rep))
         if status == -100:

@@ -172,7 +172,14 @@ class DeviceNlp {
   void sweep_full();    // f, c_e, c_i, g, A_e, A_i, H_f, H_c  -> V
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs
+  // Least-squares multiplier estimate system on the same pattern:
+  // lhs = [[I + A_i^T S^-2 A_i, A_e^T],[A_e, 0]] (util/lagrange_multiplier_estimate.hpp:56-133
+  // with d, t eliminated; see ipm.cpp)
+  void assemble_lsq();  // V, s -> lhs
   void build_rhs();     // V, s, y, z, mu -> rhs
+  // Re-reads the values of the tapes' parameter leaves (free Variables that are not
+  // decision variables) from the graph and refreshes their constant slots.
+  void refresh_params(const Graph& g);
   // lhs -> L, D, stats; per-problem (δ, γ), problems with active[b] == 0 are skipped
   void factor(const std::vector<double>& delta, const std::vector<double>& gamma,
               const std::vector<uint8_t>& active);
@@ -214,7 +221,7 @@ class DeviceNlp {
   TapeDevice m_full, m_values;
   // KKT plan
   DevBuf<int32_t> m_dptr, m_dsrc, m_pptr, m_pa, m_pb, m_pr, m_gsrc, m_ae_colptr, m_ae_rowidx,
-      m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src;
+      m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src, m_diag_pos;
   KktDev m_kdev{};
   // LDLT plan
   DevBuf<LdltTask> m_ltasks;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 
 namespace slpx {
 
@@ -211,34 +212,27 @@ std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::ve
   return scales;
 }
 
-ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
-                          const std::vector<IterationCallback>& callbacks, const Options& options,
-                          std::vector<double>& x, std::vector<double>* s_out,
-                          std::vector<double>* y_out, std::vector<double>* z_out,
-                          SolveReport* report) {
+namespace {
+
+ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
+                                   const std::vector<IterationCallback>& callbacks,
+                                   const Options& options, Vec& x, Vec& s, Vec& y, Vec& z, double mu,
+                                   int& iterations, SolveReport& rep, clk::time_point solve_start,
+                                   const Vec& c_e, const Vec& c_i);
+
+// interior_point.hpp:129-878: the iteration proper, on caller-owned iterates (the
+// restoration phase re-enters it with in_feasibility_restoration = true).
+ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales,
+                    const std::vector<IterationCallback>& callbacks, const Options& options,
+                    bool in_feasibility_restoration, Vec& x, Vec& s, Vec& y, Vec& z, double& mu,
+                    int& iterations, SolveReport& rep, clk::time_point solve_start) {
   const NlpStructure& st = sys.structure();
   DeviceNlp& dev = sys.device();
   const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
-  const auto solve_start = clk::now();
-  SolveReport local;
-  SolveReport& rep = report ? *report : local;
-  rep = SolveReport{};
-
-  // interior_point.hpp:74-79
-  Vec s(m_i, 1.0), y(m_e, 0.0), z(m_i, 1.0);
-  double mu = 0.1 * scales[0];
-  int iterations = 0;
-  auto finish = [&](ExitStatus st_) {
-    if (s_out) *s_out = s;
-    if (y_out) *y_out = y;
-    if (z_out) *z_out = z;
-    rep.iterations = iterations;
-    rep.t_total = since(solve_start);
-    return st_;
-  };
+  auto finish = [&](ExitStatus st_) { return st_; };
 
   sys.reset_regularization();
-  sys.set_gamma_min(1e-10);  // :350-352 (not in restoration)
+  sys.set_gamma_min(in_feasibility_restoration ? 0.0 : 1e-10);  // :350-352
 
   Vec V(st.nV), Vtrial(st.nV);
   auto refresh_full = [&](const Vec& xx, const Vec& yy, const Vec& zz) {
@@ -510,22 +504,50 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
     }
     rep.t_line_search += since(t0);
 
-    if (call_feasibility_restoration) {
-      // util/feasibility_restoration.hpp is SURVEY.md §8(f) row N3 — not built yet
-      return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
+    if (call_feasibility_restoration) {  // :721-771
+      if (in_feasibility_restoration) return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
+
+      const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+      std::vector<IterationCallback> fr_callbacks = callbacks;
+      // Leave restoration once the outer filter accepts the restoration iterate and the
+      // violation dropped by 10 % (:729-752).  f, c_e, c_i of the ORIGINAL problem at the
+      // restoration iterate come from a forward sweep of this system's value tape.
+      fr_callbacks.emplace_back([&](const IterationInfo& info) {
+        Vec tx(info.x.begin(), info.x.begin() + n);
+        Vec ts(info.s.begin(), info.s.begin() + m_i);
+        eval_values(tx);
+        Vec tce(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e);
+        Vec tci(Vtrial.begin() + st.off_ci, Vtrial.begin() + st.off_ci + m_i);
+        const FilterEntry trial_entry{Vtrial[st.off_f], ts, tce.data(), m_e, tci.data(), mu};
+        double D_phi_restoration = 0.0, sinv_dot = 0.0;
+        for (int i = 0; i < n; ++i) D_phi_restoration += g[i] * (tx[i] - x[i]);
+        for (int j = 0; j < m_i; ++j) sinv_dot += (1.0 / s[j]) * (ts[j] - s[j]);
+        D_phi_restoration -= mu * sinv_dot;
+        return trial_entry.constraint_violation < 0.9 * initial_entry.constraint_violation &&
+               filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      });
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s, y,
+                                                           z, mu, iterations, rep, solve_start, c_e, c_i);
+      if (fr_status != ExitStatus::SUCCESS) return finish(fr_status);
+      eval_values(x);
+      read_trial();
+      f = trial_f;
+      c_e = trial_c_e;
+      c_i = trial_c_i;
+    } else {
+      if (alpha == alpha_max) full_step_rejected_counter = 0;
+      x = trial_x;
+      s = trial_s;
+      y = trial_y;
+      z = trial_z;
+      for (int j = 0; j < m_i; ++j) {  // :797-801
+        constexpr double kappa = 1e10;
+        z[j] = std::clamp(z[j], 1.0 / kappa * mu / s[j], kappa * mu / s[j]);
+      }
+      f = trial_f;
+      c_e = trial_c_e;
+      c_i = trial_c_i;
     }
-    if (alpha == alpha_max) full_step_rejected_counter = 0;
-    x = trial_x;
-    s = trial_s;
-    y = trial_y;
-    z = trial_z;
-    for (int j = 0; j < m_i; ++j) {  // :797-801
-      constexpr double kappa = 1e10;
-      z[j] = std::clamp(z[j], 1.0 / kappa * mu / s[j], kappa * mu / s[j]);
-    }
-    f = trial_f;
-    c_e = trial_c_e;
-    c_i = trial_c_i;
 
     // AD refresh (:809-812)
     t0 = clk::now();
@@ -545,6 +567,13 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
         E_mu = E_mu_of();
       }
     }
+    if (options.diagnostics) {  // one line per iteration (print_iteration_diagnostics.hpp, condensed)
+      std::fprintf(stderr,
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  "
+                   "alpha_z %.2e  nfact %d\n",
+                   iterations, E_0, f, violation(c_e, c_i, s), mu, rep.delta, rep.gamma, alpha, alpha_z,
+                   sys.last_factorizations());
+    }
     ++iterations;
     rep.final_error = E_0;
     if (iterations >= options.max_iterations) return finish(ExitStatus::MAX_ITERATIONS_EXCEEDED);
@@ -552,6 +581,231 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
   }
   rep.final_error = E_0;
   return finish(ExitStatus::SUCCESS);
+}
+
+// feasibility_restoration.hpp:26-101: p, n >= 0 with p - n = c minimising the barrier
+// problem  rho (p + n) - mu (ln p + ln n)
+void compute_p_n(const Vec& c, double rho, double mu, Vec& p, Vec& n) {
+  p.resize(c.size());
+  n.resize(c.size());
+  for (size_t row = 0; row < c.size(); ++row) {
+    const double a_ = rho, b_ = rho * c[row] - mu, c_ = -mu * c[row] / 2.0;
+    n[row] = (-b_ + std::sqrt(b_ * b_ - 4.0 * a_ * c_)) / (2.0 * a_);
+    p[row] = c[row] + n[row];
+  }
+}
+
+// The restoration model as an expression-graph problem over the SAME constraint
+// expressions (feasibility_restoration.hpp:347-628 composes it out of the outer matrix
+// callbacks; compiling it gives the identical f, g, H, c, A):
+//
+//   min  rho sum(p_e + n_e + p_i + n_i) + 1/2 sum_k w_k (x_k - xr_k)^2      w = zeta D_R
+//   s.t. d_ce . c_e(x) - p_e + n_e  = 0
+//        d_ci . c_i(x) - p_i + n_i >= 0,   p_e, n_e, p_i, n_i >= 0
+//
+// x_R, w and the outer problem's row scalings d_ce, d_ci are tape PARAMETERS (free
+// Variables), so one compiled system serves every restoration call of every solve.
+NewtonSystem& restoration_system(NewtonSystem& outer) {
+  auto& R = outer.restoration();
+  if (R.sys) return *R.sys;
+  Graph& g = outer.graph();
+  const auto& xs = outer.x_nodes();
+  const auto& ces = outer.c_e_nodes();
+  const auto& cis = outer.c_i_nodes();
+  const size_t n = xs.size(), m_e = ces.size(), m_i = cis.size();
+  constexpr double rho = 1e3;
+
+  R.vars = xs;
+  std::vector<NodeId> p_e(m_e), n_e(m_e), p_i(m_i), n_i(m_i);
+  for (auto* block : {&p_e, &n_e, &p_i, &n_i})
+    for (NodeId& v : *block) {
+      v = g.variable(0.0);
+      R.vars.push_back(v);
+    }
+  R.x_ref.resize(n);
+  R.weight.resize(n);
+  for (size_t k = 0; k < n; ++k) {
+    R.x_ref[k] = g.variable(0.0);
+    R.weight[k] = g.variable(0.0);
+  }
+  R.d_ce.resize(m_e);
+  R.d_ci.resize(m_i);
+  for (NodeId& v : R.d_ce) v = g.variable(1.0);
+  for (NodeId& v : R.d_ci) v = g.variable(1.0);
+
+  NodeId lin = kNull;
+  for (size_t k = n; k < R.vars.size(); ++k) lin = g.add(lin, R.vars[k]);
+  NodeId quad = kNull;
+  for (size_t k = 0; k < n; ++k) {
+    const NodeId d = g.sub(xs[k], R.x_ref[k]);
+    quad = g.add(quad, g.mul(R.weight[k], g.mul(d, d)));
+  }
+  NodeId cost = kNull;
+  if (lin != kNull) cost = g.mul(g.constant(rho), lin);
+  if (quad != kNull) cost = g.add(cost, g.mul(g.constant(0.5), quad));
+
+  std::vector<NodeId> c_e(m_e), c_i;
+  for (size_t j = 0; j < m_e; ++j)
+    c_e[j] = g.add(g.sub(g.mul(R.d_ce[j], ces[j]), p_e[j]), n_e[j]);
+  for (size_t j = 0; j < m_i; ++j)
+    c_i.push_back(g.add(g.sub(g.mul(R.d_ci[j], cis[j]), p_i[j]), n_i[j]));
+  for (size_t k = n; k < R.vars.size(); ++k) c_i.push_back(R.vars[k]);
+
+  NewtonOptions opt = outer.options();
+  opt.batch = 1;
+  R.sys = std::make_unique<NewtonSystem>(g, R.vars, cost, c_e, c_i, opt);
+  return *R.sys;
+}
+
+// util/lagrange_multiplier_estimate.hpp:56-133: least-squares (y, z) of
+//   [A_e 0; A_i -S] [A_e 0; A_i -S]^T [y; z] = [A_e 0; A_i -S] [g; -mu 1].
+// Eliminating the auxiliary unknowns of the equivalent equality-constrained QP gives a
+// system with the KKT pattern this NewtonSystem already has a symbolic factorization for:
+//   [I + A_i^T S^-2 A_i   A_e^T] [ d ]   [-g + mu A_i^T S^-1 1]
+//   [A_e                  0    ] [-y ] = [0                   ],  z = mu S^-1 1 - S^-2 A_i d
+// V must hold g, A_e, A_i at the current x.
+bool lagrange_multiplier_estimate(NewtonSystem& sys, const Vec& V, const Vec& s, double mu, Vec& y,
+                                  Vec& z, SolveReport& rep) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
+  VView cur{st, V};
+  Vec rhs(dim, 0.0), sinv_mu(m_i);
+  const Vec g = cur.g_dense();
+  for (int i = 0; i < n; ++i) rhs[i] = -g[i];
+  for (int j = 0; j < m_i; ++j) sinv_mu[j] = mu / s[j];
+  add_At_v(st.Ai, cur.Ai(), nullptr, sinv_mu.data(), 1.0, rhs);
+
+  Vec zeros_e(std::max(1, m_e), 0.0), ones_i(std::max(1, m_i), 1.0);
+  dev.upload_duals(s.data(), zeros_e.data(), ones_i.data());
+  dev.assemble_lsq();
+  SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs.data(), dim * sizeof(double), hipMemcpyHostToDevice,
+                                dev.stream()));
+  // a separate solver object in the reference: keep the outer regularization history
+  const auto saved = sys.regularization_state();
+  sys.reset_regularization();
+  const auto info = sys.compute();
+  rep.factorizations += sys.last_factorizations();
+  sys.set_regularization_state(saved);
+  if (info[0] != FactorInfo::Success) return false;
+  dev.solve();
+  ++rep.solves;
+  Vec p(dim);
+  dev.download(dev.d_p(), p.data(), dim);
+  y.assign(m_e, 0.0);
+  for (int j = 0; j < m_e; ++j) y[j] = -p[n + j];
+  Vec aid(m_i, 0.0);
+  for (int c = 0; c < n; ++c)
+    for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q) aid[st.Ai.rowidx[q]] += cur.Ai()[q] * p[c];
+  z.assign(m_i, 0.0);
+  for (int j = 0; j < m_i; ++j) {
+    constexpr double kappa = 1e10;
+    const double zj = mu / s[j] - aid[j] / (s[j] * s[j]);
+    z[j] = std::clamp(zj, 1.0 / kappa * mu / s[j], kappa * mu / s[j]);  // :125-130
+  }
+  return true;
+}
+
+// feasibility_restoration.hpp:347-628 (interior-point variant)
+ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
+                                   const std::vector<IterationCallback>& callbacks,
+                                   const Options& options, Vec& x, Vec& s, Vec& y, Vec& z, double mu,
+                                   int& iterations, SolveReport& rep, clk::time_point solve_start,
+                                   const Vec& c_e, const Vec& c_i) {
+  const NlpStructure& ost = outer.structure();
+  const int n = ost.n, m_e = ost.m_e, m_i = ost.m_i;
+  constexpr double rho = 1e3;
+  ++rep.restorations;
+
+  Vec cis(m_i);
+  for (int j = 0; j < m_i; ++j) cis[j] = c_i[j] - s[j];
+  const double fr_mu =
+      std::max({mu, norm_inf(c_e.data(), m_e), norm_inf(cis.data(), m_i)});
+  const double zeta = std::sqrt(fr_mu);
+
+  Vec p_e, n_e, p_i, n_i;
+  compute_p_n(c_e, rho, fr_mu, p_e, n_e);
+  compute_p_n(cis, rho, fr_mu, p_i, n_i);
+
+  NewtonSystem& fr = restoration_system(outer);
+  auto& R = outer.restoration();
+  Graph& g = outer.graph();
+  for (int k = 0; k < n; ++k) {
+    g.val[R.x_ref[k]] = x[k];
+    g.val[R.weight[k]] = zeta * std::min(1.0 / (x[k] * x[k]), 1.0);
+  }
+  for (int j = 0; j < m_e; ++j) g.val[R.d_ce[j]] = scales[1 + j];
+  for (int j = 0; j < m_i; ++j) g.val[R.d_ci[j]] = scales[1 + m_e + j];
+  fr.device().refresh_params(g);
+
+  const int nz = m_i + 2 * m_e + 2 * m_i;
+  Vec fr_x;
+  fr_x.reserve(n + 2 * m_e + 2 * m_i);
+  for (const Vec* v : {static_cast<const Vec*>(&x), static_cast<const Vec*>(&p_e),
+                       static_cast<const Vec*>(&n_e), static_cast<const Vec*>(&p_i),
+                       static_cast<const Vec*>(&n_i)})
+    fr_x.insert(fr_x.end(), v->begin(), v->end());
+  Vec fr_s(nz, 1.0), fr_y(m_e, 0.0), fr_z;
+  std::copy(s.begin(), s.end(), fr_s.begin());
+  fr_z.reserve(nz);
+  for (int j = 0; j < m_i; ++j) fr_z.push_back(fr_mu * (1.0 / s[j]));
+  for (const Vec* v : {&p_e, &n_e, &p_i, &n_i})
+    for (double e : *v) fr_z.push_back(fr_mu * (1.0 / e));
+
+  // scaling: the rows carry d_ce, d_ci themselves (parameters), so the device applies
+  // none; the error measure un-scales with {1, d_ce, [d_ci, 1...]} (:433-440)
+  Vec fr_scales(1 + m_e + nz, 1.0);
+  for (int j = 0; j < m_e; ++j) fr_scales[1 + j] = scales[1 + j];
+  for (int j = 0; j < m_i; ++j) fr_scales[1 + m_e + j] = scales[1 + m_e + j];
+  fr.device().set_scaling(Vec(fr.structure().n_scales(), 1.0));
+
+  double mu_fr = fr_mu;
+  const ExitStatus status = ipm_core(fr, fr_scales, callbacks, options, true, fr_x, fr_s, fr_y, fr_z,
+                                     mu_fr, iterations, rep, solve_start);
+
+  std::copy(fr_x.begin(), fr_x.begin() + n, x.begin());
+  std::copy(fr_s.begin(), fr_s.begin() + m_i, s.begin());
+
+  if (status == ExitStatus::CALLBACK_REQUESTED_STOP) {
+    // back to the original problem: least-squares multipliers at the new point
+    DeviceNlp& dev = outer.device();
+    Vec V(ost.nV);
+    dev.upload_x(x.data());
+    dev.upload_duals(s.data(), y.data(), z.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+    if (!lagrange_multiplier_estimate(outer, V, s, mu, y, z, rep)) return ExitStatus::FACTORIZATION_FAILED;
+    return ExitStatus::SUCCESS;
+  } else if (status == ExitStatus::SUCCESS) {
+    return ExitStatus::LOCALLY_INFEASIBLE;
+  }
+  return ExitStatus::FEASIBILITY_RESTORATION_FAILED;
+}
+
+}  // namespace
+
+ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
+                          const std::vector<IterationCallback>& callbacks, const Options& options,
+                          std::vector<double>& x, std::vector<double>* s_out,
+                          std::vector<double>* y_out, std::vector<double>* z_out,
+                          SolveReport* report) {
+  const NlpStructure& st = sys.structure();
+  const auto solve_start = clk::now();
+  SolveReport local;
+  SolveReport& rep = report ? *report : local;
+  rep = SolveReport{};
+  // interior_point.hpp:74-79
+  Vec s(st.m_i, 1.0), y(st.m_e, 0.0), z(st.m_i, 1.0);
+  double mu = 0.1 * scales[0];
+  int iterations = 0;
+  const ExitStatus status =
+      ipm_core(sys, scales, callbacks, options, false, x, s, y, z, mu, iterations, rep, solve_start);
+  if (s_out) *s_out = s;
+  if (y_out) *y_out = y;
+  if (z_out) *z_out = z;
+  rep.iterations = iterations;
+  rep.t_total = since(solve_start);
+  return status;
 }
 
 }  // namespace slpx

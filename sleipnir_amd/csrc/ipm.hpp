@@ -7,9 +7,10 @@
 // logic between steps (error norms, fraction-to-the-boundary, filter) is still
 // host code on downloaded vectors in this round.
 //
-// Not built yet: feasibility restoration (util/feasibility_restoration.hpp, row
-// N3).  Where the reference would enter restoration this driver returns
-// FEASIBILITY_RESTORATION_FAILED.
+// Feasibility restoration (util/feasibility_restoration.hpp:347-628, row N3) is a second
+// compiled NewtonSystem over the same constraint expressions (built lazily, reused);
+// the least-squares multiplier estimate (util/lagrange_multiplier_estimate.hpp:56-133)
+// that ends it is one more factorization on the outer system's KKT pattern.
 #pragma once
 
 #include <functional>
@@ -61,6 +62,7 @@ struct SolveReport {
   int factorizations = 0;
   int solves = 0;
   int value_sweeps = 0;
+  int restorations = 0;
   double delta = 0.0, gamma = 0.0;
   double final_error = 0.0;
   // wall-clock per phase, seconds (names follow interior_point.hpp:155-174)

@@ -53,6 +53,39 @@ __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const doubl
   }
 }
 
+// Least-squares multiplier estimate (util/lagrange_multiplier_estimate.hpp:56-133) on the
+// KKT pattern: the top-left block is I + A_i^T S^-2 A_i (H sources skipped, identity added
+// by kkt_add_identity_kernel), the A_e block is unchanged.
+__global__ __launch_bounds__(256) void kkt_assemble_lsq_kernel(KktDev K, const double* __restrict__ V,
+                                                               int v_stride,
+                                                               const double* __restrict__ s,
+                                                               double* __restrict__ lhs) {
+  const int b = blockIdx.y;
+  V += static_cast<size_t>(b) * v_stride;
+  s += static_cast<size_t>(b) * K.m_i;
+  lhs += static_cast<size_t>(b) * K.nnz_lhs;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K.nnz_lhs; k += gridDim.x * blockDim.x) {
+    double direct = 0.0;
+    for (int d = K.dptr[k]; d < K.dptr[k + 1]; ++d) {
+      const int src = K.dsrc[d];
+      if (src >= K.off_Ae && src < K.off_Ai) direct += V[src];
+    }
+    double prod = 0.0;
+    for (int p = K.pptr[k]; p < K.pptr[k + 1]; ++p) {
+      const double sinv = 1.0 / s[K.pr[p]];
+      prod += (V[K.pa[p]] * (sinv * sinv)) * V[K.pb[p]];
+    }
+    lhs[k] = direct + prod;
+  }
+}
+
+__global__ __launch_bounds__(256) void kkt_add_identity_kernel(KktDev K, const int32_t* __restrict__ diag_pos,
+                                                               double* __restrict__ lhs) {
+  lhs += static_cast<size_t>(blockIdx.y) * K.nnz_lhs;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K.n; j += gridDim.x * blockDim.x)
+    lhs[diag_pos[j]] += 1.0;
+}
+
 __global__ __launch_bounds__(256) void kkt_rhs_kernel(KktDev K, const double* __restrict__ V,
                                                       int v_stride, const double* __restrict__ s,
                                                       const double* __restrict__ y,
@@ -194,6 +227,13 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_ai_rowptr.upload(k.ai_rowptr);
   m_ai_col.upload(k.ai_col);
   m_ai_src.upload(k.ai_src);
+  {
+    std::vector<int32_t> diag_pos(std::max(1, k.n), 0);
+    for (int c = 0; c < k.n; ++c)
+      for (int p = k.lhs.colptr[c]; p < k.lhs.colptr[c + 1]; ++p)
+        if (k.lhs.rowidx[p] == c) diag_pos[c] = p;
+    m_diag_pos.upload(diag_pos);
+  }
   m_kdev = KktDev{k.n,           k.m_e,        k.m_i,        k.dim,         k.lhs.nnz(),  m_dptr.p,
                   m_dsrc.p,      m_pptr.p,     m_pa.p,       m_pb.p,        m_pr.p,       m_gsrc.p,
                   m_ae_colptr.p, m_ae_rowidx.p, m_ai_colptr.p, m_ai_rowidx.p, m_ai_rowptr.p,
@@ -348,6 +388,26 @@ void DeviceNlp::assemble() {
   hipLaunchKernelGGL(kkt_assemble_kernel, dim3(grid_for(m_kdev.nnz_lhs, 256), m_batch), dim3(256), 0,
                      m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs.p);
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::assemble_lsq() {
+  hipLaunchKernelGGL(kkt_assemble_lsq_kernel, dim3(grid_for(m_kdev.nnz_lhs, 256), m_batch), dim3(256),
+                     0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_lhs.p);
+  hipLaunchKernelGGL(kkt_add_identity_kernel, dim3(grid_for(m_kdev.n, 256), m_batch), dim3(256), 0,
+                     m_stream, m_kdev, m_diag_pos.p, m_lhs.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::refresh_params(const Graph& g) {
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  auto refresh = [&](const TapeProgram& prog, TapeDevice& dev) {
+    if (prog.params.empty()) return;
+    std::vector<double> c = prog.consts;
+    for (const auto& [node, slot] : prog.params) c[slot] = g.val[node];
+    dev.consts.upload(c);
+  };
+  refresh(m_s_ref.full, m_full);
+  refresh(m_s_ref.values, m_values);
 }
 
 void DeviceNlp::build_rhs() {

@@ -9,7 +9,7 @@ namespace slpx {
 NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
                            const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
                            const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
-    : m_opt(opt) {
+    : m_opt(opt), m_graph(&g), m_x_nodes(x), m_ce_nodes(c_e), m_ci_nodes(c_i) {
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
   m_k = build_kkt_plan(m_s);
   // which diagonal entries of the unregularized lhs have any source at all

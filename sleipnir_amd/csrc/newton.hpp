@@ -36,6 +36,23 @@ class NewtonSystem {
                const std::vector<NodeId>& c_i, const NewtonOptions& opt,
                const std::vector<int32_t>* user_perm = nullptr);
 
+  // The model this system was compiled from (feasibility restoration builds its
+  // augmented model out of the same expressions).
+  Graph& graph() const { return *m_graph; }
+  const std::vector<NodeId>& x_nodes() const { return m_x_nodes; }
+  const std::vector<NodeId>& c_e_nodes() const { return m_ce_nodes; }
+  const std::vector<NodeId>& c_i_nodes() const { return m_ci_nodes; }
+  const NewtonOptions& options() const { return m_opt; }
+
+  // Lazily built restoration system + the parameter nodes it reads (see ipm.cpp)
+  struct Restoration {
+    std::unique_ptr<NewtonSystem> sys;
+    std::vector<NodeId> x_ref, weight;  // parameters: x_R and zeta * D_R (n each)
+    std::vector<NodeId> d_ce, d_ci;     // parameters: the outer problem's row scalings
+    std::vector<NodeId> vars;           // [x, p_e, n_e, p_i, n_i]
+  };
+  Restoration& restoration() { return m_restoration; }
+
   const NlpStructure& structure() const { return m_s; }
   const KktPlan& kkt() const { return m_k; }
   const LdltPlan& ldlt() const { return m_l; }
@@ -44,6 +61,12 @@ class NewtonSystem {
 
   void set_gamma_min(double g) { m_gamma_min = g; }
   void reset_regularization();
+  using RegularizationState = std::pair<std::vector<double>, std::vector<double>>;
+  RegularizationState regularization_state() const { return {m_prev_delta, m_prev_gamma}; }
+  void set_regularization_state(const RegularizationState& st) {
+    m_prev_delta = st.first;
+    m_prev_gamma = st.second;
+  }
 
   // sparse_regularized_ldlt.hpp:64-152 on the lhs currently in device memory.
   // Returns per-problem info; fills the regularization that was used.
@@ -59,6 +82,9 @@ class NewtonSystem {
 
  private:
   NewtonOptions m_opt;
+  Graph* m_graph = nullptr;
+  std::vector<NodeId> m_x_nodes, m_ce_nodes, m_ci_nodes;
+  Restoration m_restoration;
   NlpStructure m_s;
   KktPlan m_k;
   LdltPlan m_l;

@@ -381,6 +381,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
 
   // ---- emit tasks -----------------------------------------------------------------
   std::unordered_map<double, uint32_t> const_pool;
+  std::unordered_map<NodeId, uint32_t> param_slot;
   auto const_index = [&](double v) {
     auto it = const_pool.find(v);
     if (it != const_pool.end()) return it->second;
@@ -394,9 +395,19 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     if (cg.op[n] == OP_CONST) return kLeafConstFlag | const_index(g.val[s]);
     auto it = input_of.find(s);
     // A free Variable that is not a decision variable acts as a parameter: in the
-    // reference it is just a leaf holding its current value during solve().  Its
-    // value is frozen into the tape at compile time.
-    if (it == input_of.end()) return kLeafConstFlag | const_index(g.val[s]);
+    // reference it is just a leaf holding its current value during solve().  It gets a
+    // constant slot of its own, initialised with its value at compile time and
+    // refreshable afterwards (TapeProgram::params).
+    if (it == input_of.end()) {
+      auto pit = param_slot.find(s);
+      if (pit == param_slot.end()) {
+        const uint32_t i = static_cast<uint32_t>(prog.consts.size());
+        prog.consts.push_back(g.val[s]);
+        prog.params.emplace_back(s, i);
+        pit = param_slot.emplace(s, i).first;
+      }
+      return kLeafConstFlag | pit->second;
+    }
     return static_cast<uint32_t>(it->second);
   };
 

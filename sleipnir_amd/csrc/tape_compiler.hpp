@@ -83,6 +83,10 @@ struct TapeProgram {
   std::vector<uint32_t> small_tasks, large_tasks, global_tasks;
   std::vector<uint32_t> leaf_src;
   std::vector<double> consts;
+  // Parameters: free Variables that are not tape inputs.  Each owns one slot of
+  // `consts` (never shared with a literal), so its value can be refreshed on the device
+  // without recompiling: (graph node, index into consts).
+  std::vector<std::pair<NodeId, uint32_t>> params;
   std::vector<uint32_t> node_rec;  // [op | need_dl<<8 | need_dr<<9, a0, a1] per node
   std::vector<uint32_t> lvl_ptr;
   std::vector<uint32_t> slot_edge_ptr;

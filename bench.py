@@ -74,18 +74,13 @@ def main():
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # noqa: PLC0415
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-
     import sleipnir_amd as sa
     from tests.support import cases
+
+    # one process per GPU; RCCL ("nccl") only for the end-of-region MAX
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    comm = sa.Comm(backend="nccl")
+    rank, local_rank, world = comm.rank, comm.local_rank, comm.world
 
     N = args.N
     dt = 5.0 / N
@@ -126,8 +121,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     nfact_total = 0
@@ -142,10 +136,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert np.all(info_step == 0), "factorization failed in the timed region"
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(comm.max([elapsed])[0])
     barrier()
 
     if rank == 0:
@@ -229,8 +220,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     system.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

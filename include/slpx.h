@@ -179,6 +179,15 @@ int slpx_system_set_lhs(slpx_system* s, const double* lhs);
  * total, factorizations per step} */
 int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms);
 
+/* Profiling aid: wall_clock64() ticks (100 MHz) recorded by workgroup 0 of the last tape
+ * sweep at {entry, staged, leaves, forward done, values out, adjoints done, exit};
+ * out16[0..7] = 64-thread kernel, out16[8..15] = 256-thread kernel. */
+int slpx_debug_tape_clocks(slpx_system* s, uint64_t* out16);
+/* Same for the first task of one LDLT round: out24[0..7] factor {entry, staged, values
+ * gathered, levels done, update blocks done, exit}, [8..15] forward solve, [16..23]
+ * backward solve.  Returns what was recorded so far, then arms `next_round`. */
+int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24);
+
 #ifdef __cplusplus
 }
 #endif

@@ -365,6 +365,22 @@ int slpx_system_set_rhs(slpx_system* s, const double* rhs) {
   });
 }
 
+int slpx_debug_tape_clocks(slpx_system* s, uint64_t* out16) {
+  return guard([&] {
+    unsigned long long t[16];
+    s->get().device().debug_tape_clocks(t);
+    for (int i = 0; i < 16; ++i) out16[i] = t[i];
+  });
+}
+
+int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24) {
+  return guard([&] {
+    unsigned long long t[24];
+    s->get().device().debug_ldlt_clocks(next_round, t);
+    for (int i = 0; i < 24; ++i) out24[i] = t[i];
+  });
+}
+
 int slpx_system_set_lhs(slpx_system* s, const double* lhs) {
   return guard([&] {
     auto& dev = s->get().device();

@@ -180,6 +180,9 @@ class DeviceNlp {
   // Re-reads the values of the tapes' parameter leaves (free Variables that are not
   // decision variables) from the graph and refreshes their constant slots.
   void refresh_params(const Graph& g);
+  void debug_tape_clocks(unsigned long long* out16);
+  // returns the clocks recorded so far, then selects the round that records next
+  void debug_ldlt_clocks(unsigned int next_round, unsigned long long* out24);  // phase clocks of workgroup 0 (100 MHz ticks)
   // lhs -> L, D, stats; per-problem (δ, γ), problems with active[b] == 0 are skipped
   void factor(const std::vector<double>& delta, const std::vector<double>& gamma,
               const std::vector<uint8_t>& active);

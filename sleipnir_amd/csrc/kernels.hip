@@ -398,6 +398,17 @@ void DeviceNlp::assemble_lsq() {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
+void DeviceNlp::debug_tape_clocks(unsigned long long* out16) {
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  SLPX_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tape_clocks), 16 * sizeof(unsigned long long)));
+}
+
+void DeviceNlp::debug_ldlt_clocks(unsigned int next_round, unsigned long long* out24) {
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  SLPX_HIP_CHECK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_ldlt_clocks), 24 * sizeof(unsigned long long)));
+  SLPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ldlt_clock_round), &next_round, sizeof(unsigned int)));
+}
+
 void DeviceNlp::refresh_params(const Graph& g) {
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
   auto refresh = [&](const TapeProgram& prog, TapeDevice& dev) {

@@ -24,6 +24,14 @@
 
 namespace slpx {
 
+// Phase clocks (wall_clock64, 100 MHz) of the first workgroup of the last launch of each
+// kernel: [0,8) factor, [8,16) fwd, [16,24) bwd (debug aid, slpx_debug_ldlt_clocks).
+__device__ unsigned long long g_ldlt_clocks[24];
+__device__ unsigned int g_ldlt_clock_round;  // which round's launch records
+#define SLPX_LDLT_CLOCK(k)                                                                   \
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && t.round == g_ldlt_clock_round) \
+  g_ldlt_clocks[k] = wall_clock64()
+
 // Sum over the 8 lanes of an aligned lane group.
 __device__ __forceinline__ double group8_sum(double v) {
   v += __shfl_xor(v, 4, 8);
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   D += static_cast<size_t>(b) * n;
   contrib += static_cast<size_t>(b) * contrib_stride;
 
+  SLPX_LDLT_CLOCK(0);
   const uint32_t n_pp = t.n_ent + t.n_ext + 1;
   const uint32_t np = t.n_pairs;
   const uint32_t g_pairs = q16(np, 2), g_pptr = q16(n_pp, 4), g_lvl = q16(t.n_lvl + 1, 4),
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   if (tid < 4) s_cnt[tid] = 0;
   if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
   __syncthreads();
+  SLPX_LDLT_CLOCK(1);
 
   // ---- matrix values: four independent gathers per lane in flight ----
   {
@@ -130,28 +140,38 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     }
   }
   __syncthreads();
+  SLPX_LDLT_CLOCK(2);
 
   // ---- level loop: all in LDS ----
   const int lane8 = tid & 7, grp = tid >> 3;
-  for (uint32_t l = 0; l < t.n_lvl; ++l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + grp; i < end; i += 32) {
-      const uint32_t pb = pptr[i], pe = pptr[i + 1];
-      double partial = 0.0;
-      for (uint32_t q = pb + lane8; q < pe; q += 8) {
-        const uint2 pr = pairs[q];
-        partial += (U[pr.x & 0xffffu] * invd[pr.y & 0xffffu]) * U[pr.x >> 16];
+  {
+    uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
+    for (uint32_t l = 0; l < t.n_lvl; ++l) {
+      const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];  // one level ahead
+      for (uint32_t i = beg + grp; i < end; i += 32) {
+        const uint32_t pb = pptr[i], pe = pptr[i + 1];
+        // issued with the pointer loads, off the dependent chain
+        const double u_old = U[i];
+        const uint32_t fl = flags[i], cj = col[i];
+        double partial = 0.0;
+        for (uint32_t q = pb + lane8; q < pe; q += 8) {
+          const uint2 pr = pairs[q];
+          partial += (U[pr.x & 0xffffu] * invd[pr.y & 0xffffu]) * U[pr.x >> 16];
+        }
+        partial = group8_sum(partial);
+        if (lane8 == 0) {
+          const double u = u_old - partial;
+          U[i] = u;
+          if (fl & 1) invd[cj] = 1.0 / u;
+        }
       }
-      partial = group8_sum(partial);
-      if (lane8 == 0) {
-        const double u = U[i] - partial;
-        U[i] = u;
-        if (flags[i] & 1) invd[col[i]] = 1.0 / u;
-      }
+      __syncthreads();
+      beg = end;
+      end = next_end;
     }
-    __syncthreads();
   }
 
+  SLPX_LDLT_CLOCK(3);
   // ---- update blocks for ancestor tasks (later rounds) ----
   for (uint32_t x = grp; x < t.n_ext; x += 32) {
     const uint32_t pb = pptr[t.n_ent + x], pe = pptr[t.n_ent + x + 1];
@@ -164,6 +184,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     if (lane8 == 0) contrib[L.ext_dst[t.ext_off + x]] = partial;
   }
 
+  SLPX_LDLT_CLOCK(4);
   // ---- results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero) ----
   for (uint32_t i = tid; i < t.n_ent; i += 256) {
     const double u = U[i];
@@ -182,6 +203,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   __syncthreads();
   if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[b]) + tid, s_cnt[tid]);
   if (tid == 0) atomicMin(&stats[b].min_abs_bits, *s_minp);
+  SLPX_LDLT_CLOCK(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -203,6 +225,7 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
   zv += static_cast<size_t>(b) * n;
   scontrib += static_cast<size_t>(b) * scontrib_stride;
 
+  SLPX_LDLT_CLOCK(8);
   const uint32_t n_items = t.n_fwd_items;
   const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
                  g_cp = q16(t.n_col, 4);
@@ -225,6 +248,7 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   stage16<256>(s_fc, reinterpret_cast<const uint4*>(L.fwd_contrib_ptr + t.colptr_off), g_ptr, tid);
   __syncthreads();
+  SLPX_LDLT_CLOCK(9);
   {
     uint32_t q = tid;
     for (; q + 3 * 256 < n_items; q += 4 * 256) {
@@ -244,27 +268,42 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     }
   }
   __syncthreads();
-  for (uint32_t l = 0; l < t.n_lvl; ++l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += 256) {
-      double acc = y[i];
-      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * y[items[q].y];
-      y[i] = acc;
+  SLPX_LDLT_CLOCK(10);
+  // Eight lanes share one row's dot product (a row of L holds ~8 entries on average), so
+  // a level costs one LDS round trip per operand instead of one per entry.
+  {
+    const int lane8 = tid & 7, grp = tid >> 3;
+    uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
+    for (uint32_t l = 0; l < t.n_lvl; ++l) {
+      const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];
+      for (uint32_t i = beg + grp; i < end; i += 32) {
+        const uint32_t qe = ptr[i + 1];
+        double partial = 0.0;
+        for (uint32_t q = ptr[i] + lane8; q < qe; q += 8) partial += vals[q] * y[items[q].y];
+        partial = group8_sum(partial);
+        if (lane8 == 0) y[i] -= partial;
+      }
+      __syncthreads();
+      beg = end;
+      end = next_end;
     }
-    __syncthreads();
   }
+  SLPX_LDLT_CLOCK(11);
   // partial sums for rows owned by ancestor tasks
   const uint32_t* sptr = L.sext_ptr + t.sext_ptr_off;
   const LdltSolveItem* sitems = L.sext_items + t.sext_item_off;
-  for (uint32_t x = tid; x < t.n_sext; x += 256) {
+  for (uint32_t x = tid >> 3; x < t.n_sext; x += 32) {
+    const uint32_t qe = sptr[x + 1];
     double acc = 0.0;
-    for (uint32_t q = sptr[x]; q < sptr[x + 1]; ++q) acc += Lx[sitems[q].lpos] * y[sitems[q].ref];
-    scontrib[L.sext_dst[t.sext_off + x]] = acc;
+    for (uint32_t q = sptr[x] + (tid & 7); q < qe; q += 8) acc += Lx[sitems[q].lpos] * y[sitems[q].ref];
+    acc = group8_sum(acc);
+    if ((tid & 7) == 0) scontrib[L.sext_dst[t.sext_off + x]] = acc;
   }
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
     zv[pj] = y[i] / D[pj];
   }
+  SLPX_LDLT_CLOCK(12);
 }
 
 // ---------------------------------------------------------------------------
@@ -286,6 +325,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   xg += static_cast<size_t>(b) * n;
   out += static_cast<size_t>(b) * n;
 
+  SLPX_LDLT_CLOCK(16);
   const uint32_t n_items = t.n_bwd_items;
   const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
                  g_cp = q16(t.n_col, 4);
@@ -305,6 +345,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_ptr + t.lvl_off), g_lvl, tid);
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   __syncthreads();
+  SLPX_LDLT_CLOCK(17);
   {
     auto load_item = [&](uint32_t q, double& v, uint32_t& r) {
       const uint2 it = items[q];
@@ -345,20 +386,31 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     if (tid == 0) x[t.n_col] = 1.0;
   }
   __syncthreads();
-  for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
-    const uint32_t beg = lvl[l], end = lvl[l + 1];
-    for (uint32_t i = beg + tid; i < end; i += 256) {
-      double acc = x[i];
-      for (uint32_t q = ptr[i]; q < ptr[i + 1]; ++q) acc -= vals[q] * x[items[q].y];
-      x[i] = acc;
+  SLPX_LDLT_CLOCK(18);
+  {
+    const int lane8 = tid & 7, grp = tid >> 3;
+    uint32_t end = lvl[t.n_lvl], beg = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
+    for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+      const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0];
+      for (uint32_t i = beg + grp; i < end; i += 32) {
+        const uint32_t qe = ptr[i + 1];
+        double partial = 0.0;
+        for (uint32_t q = ptr[i] + lane8; q < qe; q += 8) partial += vals[q] * x[items[q].y];
+        partial = group8_sum(partial);
+        if (lane8 == 0) x[i] -= partial;
+      }
+      __syncthreads();
+      end = beg;
+      beg = next_beg;
     }
-    __syncthreads();
   }
+  SLPX_LDLT_CLOCK(19);
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
     xg[pj] = x[i];
     out[L.perm[pj]] = x[i];
   }
+  SLPX_LDLT_CLOCK(20);
 }
 
 __global__ void ldlt_stats_reset_kernel(LdltStats* stats, int batch) {

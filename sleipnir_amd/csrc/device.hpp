@@ -240,9 +240,12 @@ class DeviceNlp {
   // per-batch values
   DevBuf<double> m_in, m_in_scale, m_scales, m_V, m_s, m_y, m_z, m_mu, m_lhs, m_rhs, m_p, m_ps,
       m_pz, m_D, m_Lx, m_contrib, m_scontrib, m_zv, m_xg, m_scratch;
-  DevBuf<LdltStats> m_stats;
-  DevBuf<double> m_reg;
-  DevBuf<uint8_t> m_active;
+  DevBuf<LdltStats> m_stats;  // 2 x batch, double-buffered per factorization attempt
+  int m_stats_cur = 0;
+  DevBuf<double> m_reg;       // (delta, gamma) per problem; delta = NaN: skip the problem
+  double* m_h_reg = nullptr;          // pinned staging
+  LdltStats* m_h_stats = nullptr;     // pinned read-back
+  hipEvent_t m_reg_consumed = nullptr;
   std::vector<double> m_V_static;  // scaled static values (host copy)
 };
 

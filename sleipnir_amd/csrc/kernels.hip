@@ -289,15 +289,25 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_scontrib.alloc(B * std::max<uint32_t>(1, l.n_scontrib));
   m_zv.alloc(B * l.n);
   m_xg.alloc(B * l.n);
-  m_stats.alloc(B);
+  {
+    // two inertia-counter buffers (see factor()), both cleared once here
+    std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
+    m_stats.upload(zero);
+  }
   m_reg.alloc(2 * B);
-  m_active.alloc(B);
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
+  SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_reg_consumed, hipEventDisableTiming));
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
   set_scaling(std::vector<double>(s.n_scales(), 1.0));
 }
 
-DeviceNlp::~DeviceNlp() = default;
+DeviceNlp::~DeviceNlp() {
+  if (m_h_reg) (void)hipHostFree(m_h_reg);
+  if (m_h_stats) (void)hipHostFree(m_h_stats);
+  if (m_reg_consumed) (void)hipEventDestroy(m_reg_consumed);
+}
 
 void DeviceNlp::set_scaling(const std::vector<double>& scales) {
   const NlpStructure& s = m_s_ref;
@@ -427,35 +437,41 @@ void DeviceNlp::build_rhs() {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
+// Control traffic of one factorization attempt is kept off the critical path: (δ, γ) of
+// every problem travel in ONE async copy from pinned memory (δ = NaN marks a problem the
+// policy loop is done with), and the inertia counters are double-buffered — the launch of
+// attempt k clears the buffer attempt k+1 will accumulate into — so no reset kernel runs.
 void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
                        const std::vector<uint8_t>& active) {
   const LdltPlan& l = m_l_ref;
-  std::vector<double> reg(2 * static_cast<size_t>(m_batch));
+  SLPX_HIP_CHECK(hipEventSynchronize(m_reg_consumed));  // previous copy out of the staging buffer
   for (int b = 0; b < m_batch; ++b) {
-    reg[2 * b] = delta[b];
-    reg[2 * b + 1] = gamma[b];
+    m_h_reg[2 * b] = active[b] ? delta[b] : std::numeric_limits<double>::quiet_NaN();
+    m_h_reg[2 * b + 1] = gamma[b];
   }
-  // pageable-memory copies are staged synchronously by HIP, so the temporaries may die
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_reg.p, reg.data(), reg.size() * sizeof(double),
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_reg.p, m_h_reg, 2 * static_cast<size_t>(m_batch) * sizeof(double),
                                 hipMemcpyHostToDevice, m_stream));
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_active.p, active.data(), m_batch, hipMemcpyHostToDevice, m_stream));
-  hipLaunchKernelGGL(ldlt_stats_reset_kernel, dim3((m_batch + 63) / 64), dim3(64), 0, m_stream,
-                     m_stats.p, m_batch);
+  SLPX_HIP_CHECK(hipEventRecord(m_reg_consumed, m_stream));
+  m_stats_cur ^= 1;
+  LdltStats* cur = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
+  LdltStats* next = m_stats.p + static_cast<size_t>(m_stats_cur ^ 1) * m_batch;
   for (int r = 0; r < l.n_rounds; ++r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
     hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, m_stream,
-                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_reg.p, m_active.p, m_Lx.p,
+                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_reg.p, m_Lx.p,
                        static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
-                       m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), m_stats.p);
+                       m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), cur,
+                       r == 0 ? next : nullptr);
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
 void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
   out.resize(m_batch);
-  SLPX_HIP_CHECK(hipMemcpyAsync(out.data(), m_stats.p, m_batch * sizeof(LdltStats),
-                                hipMemcpyDeviceToHost, m_stream));
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
+                                m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, m_stream));
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  std::copy(m_h_stats, m_h_stats + m_batch, out.begin());
 }
 
 void DeviceNlp::solve() {

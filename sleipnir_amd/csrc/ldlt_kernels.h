@@ -33,10 +33,19 @@ __device__ unsigned int g_ldlt_clock_round;  // which round's launch records
   g_ldlt_clocks[k] = wall_clock64()
 
 // Sum over the 8 lanes of an aligned lane group.
+// DPP register moves (no LDS crossbar trip, unlike __shfl_xor's ds_bpermute): mirror
+// within the 8-lane half row, then the two quad permutes.  Lane 0 of the group (and in
+// fact every lane) ends up with the group total.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double group8_sum(double v) {
-  v += __shfl_xor(v, 4, 8);
-  v += __shfl_xor(v, 2, 8);
-  v += __shfl_xor(v, 1, 8);
+  v += dpp_move<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
   return v;
 }
 
@@ -52,15 +61,18 @@ __device__ __forceinline__ double group8_sum(double v) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
-    const double* __restrict__ reg, const uint8_t* __restrict__ active, double* __restrict__ Lx,
-    long long lx_stride, double* __restrict__ D, int n, double* __restrict__ contrib,
-    int contrib_stride, LdltStats* __restrict__ stats) {
+    const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
+    double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
+    LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LdltTask t = L.tasks[task_base + blockIdx.x];
   const int b = blockIdx.y;
-  if (!active[b]) return;
-  const double delta = reg[2 * b], gamma = reg[2 * b + 1];
   const int tid = threadIdx.x;
+  // the counters the NEXT factorization attempt accumulates into (nobody touches them now)
+  if (stats_next != nullptr && blockIdx.x == 0 && tid == 0)
+    stats_next[b] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
+  const double delta = reg[2 * b], gamma = reg[2 * b + 1];
+  if (delta != delta) return;  // NaN: this problem is not part of the attempt
   lhs += static_cast<size_t>(b) * lhs_stride;
   Lx += static_cast<size_t>(b) * lx_stride;
   D += static_cast<size_t>(b) * n;
@@ -411,14 +423,6 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     out[L.perm[pj]] = x[i];
   }
   SLPX_LDLT_CLOCK(20);
-}
-
-__global__ void ldlt_stats_reset_kernel(LdltStats* stats, int batch) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < batch) {
-    stats[b].n_pos = stats[b].n_neg = stats[b].n_zero = stats[b].n_bad = 0;
-    stats[b].min_abs_bits = 0x7ff0000000000000ull;
-  }
 }
 
 }  // namespace slpx

@@ -187,6 +187,10 @@ class DeviceNlp {
   void factor(const std::vector<double>& delta, const std::vector<double>& gamma,
               const std::vector<uint8_t>& active);
   void read_stats(std::vector<LdltStats>& out);     // synchronizes
+  // [AD refresh,] assemble, rhs, one factorization attempt, solve, backsub as ONE HIP graph
+  // launch; follow with read_stats().
+  void launch_step_graph(bool refresh_ad, const std::vector<double>& delta,
+                         const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
 
@@ -213,6 +217,10 @@ class DeviceNlp {
 
  private:
   void launch_tape(const TapeDevice& t, bool reverse);
+  void launch_tape(const TapeDevice& t, bool reverse, hipStream_t small_stream, hipStream_t other);
+  void write_reg(const std::vector<double>& delta, const std::vector<double>& gamma,
+                 const std::vector<uint8_t>& active);
+  void enqueue_factor(int parity, hipStream_t stream);
 
   const NlpStructure& m_s_ref;
   const KktPlan& m_k_ref;
@@ -242,10 +250,14 @@ class DeviceNlp {
       m_pz, m_D, m_Lx, m_contrib, m_scontrib, m_zv, m_xg, m_scratch;
   DevBuf<LdltStats> m_stats;  // 2 x batch, double-buffered per factorization attempt
   int m_stats_cur = 0;
-  DevBuf<double> m_reg;       // (delta, gamma) per problem; delta = NaN: skip the problem
-  double* m_h_reg = nullptr;          // pinned staging
+  double* m_h_reg = nullptr;          // pinned, read by the kernels: (delta, gamma) per problem;
+                                      // delta = NaN: skip the problem
   LdltStats* m_h_stats = nullptr;     // pinned read-back
-  hipEvent_t m_reg_consumed = nullptr;
+  bool m_stats_in_host = false;       // the last launch already copied the counters out
+  bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
+  hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
+  hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
+  hipEvent_t m_fork = nullptr, m_join = nullptr;
   std::vector<double> m_V_static;  // scaled static values (host copy)
 };
 

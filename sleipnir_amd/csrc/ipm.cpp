@@ -326,10 +326,10 @@ ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales,
     dev.upload_mu(&mu);
     dev.assemble();
     dev.build_rhs();
-    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
-    rep.t_kkt_build += since(t0);
+    rep.t_kkt_build += since(t0);  // enqueue time only: no host sync between the phases
     t0 = clk::now();
-    auto info = sys.compute();
+    // factorization attempts, each followed at once by solve + back-substitution
+    auto info = sys.compute(/*solve_speculatively=*/true);
     rep.factorizations += sys.last_factorizations();
     rep.t_kkt_decomp += since(t0);
     if (info[0] != FactorInfo::Success) return finish(ExitStatus::FACTORIZATION_FAILED);  // :463-465
@@ -346,9 +346,7 @@ ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales,
       }
     };
     t0 = clk::now();
-    dev.solve();
-    dev.backsub();
-    ++rep.solves;
+    rep.solves += sys.last_factorizations();
     download_step(p_x, p_y, p_s, p_z);
     rep.t_kkt_solve += since(t0);
 

@@ -294,10 +294,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
     m_stats.upload(zero);
   }
-  m_reg.alloc(2 * B);
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
-  SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_reg_consumed, hipEventDisableTiming));
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
   set_scaling(std::vector<double>(s.n_scales(), 1.0));
@@ -306,7 +304,13 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 DeviceNlp::~DeviceNlp() {
   if (m_h_reg) (void)hipHostFree(m_h_reg);
   if (m_h_stats) (void)hipHostFree(m_h_stats);
-  if (m_reg_consumed) (void)hipEventDestroy(m_reg_consumed);
+  for (auto& row : m_step_graph)
+    for (hipGraphExec_t& e : row)
+      if (e) (void)hipGraphExecDestroy(e);
+  if (m_fork) (void)hipEventDestroy(m_fork);
+  if (m_join) (void)hipEventDestroy(m_join);
+  if (m_aux_stream) (void)hipStreamDestroy(m_aux_stream);
+  if (m_capture_stream) (void)hipStreamDestroy(m_capture_stream);
 }
 
 void DeviceNlp::set_scaling(const std::vector<double>& scales) {
@@ -365,6 +369,13 @@ void DeviceNlp::download(const double* dev, double* host, size_t count) {
 }
 
 void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse) {
+  launch_tape(t, reverse, m_stream, m_stream);
+}
+
+// The task classes are independent; `other` may be a forked stream (graph capture) so the
+// few large / global tasks run beside the many small ones.
+void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small_stream,
+                            hipStream_t other) {
   const TapeDev view = t.view();
   const int in_stride = m_s_ref.n_inputs(), v_stride = m_s_ref.nV;
   const unsigned long long sstride = m_scratch.n / m_batch;
@@ -373,15 +384,15 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse) {
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;
   if (t.n_small)
-    hipLaunchKernelGGL(small_fn, dim3(t.n_small, m_batch), dim3(64), t.small_lds, m_stream, view,
+    hipLaunchKernelGGL(small_fn, dim3(t.n_small, m_batch), dim3(64), t.small_lds, small_stream, view,
                        t.small_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_large)
-    hipLaunchKernelGGL(large_fn, dim3(t.n_large, m_batch), dim3(256), t.large_lds, m_stream, view,
+    hipLaunchKernelGGL(large_fn, dim3(t.n_large, m_batch), dim3(256), t.large_lds, other, view,
                        t.large_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_global)
-    hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, m_stream,
+    hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, other,
                        view, t.global_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p,
                        v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
   SLPX_HIP_CHECK(hipGetLastError());
@@ -441,24 +452,27 @@ void DeviceNlp::build_rhs() {
 // every problem travel in ONE async copy from pinned memory (δ = NaN marks a problem the
 // policy loop is done with), and the inertia counters are double-buffered — the launch of
 // attempt k clears the buffer attempt k+1 will accumulate into — so no reset kernel runs.
-void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
-                       const std::vector<uint8_t>& active) {
-  const LdltPlan& l = m_l_ref;
-  SLPX_HIP_CHECK(hipEventSynchronize(m_reg_consumed));  // previous copy out of the staging buffer
+// Control traffic of one factorization attempt is kept off the critical path: the kernels
+// read (δ, γ) straight from pinned host memory (δ = NaN marks a problem the policy loop is
+// done with), and the inertia counters are double-buffered — the launch of attempt k
+// clears the buffer attempt k+1 will accumulate into — so no copy and no reset kernel run.
+// The host only rewrites m_h_reg after read_stats() has synchronized.
+void DeviceNlp::write_reg(const std::vector<double>& delta, const std::vector<double>& gamma,
+                          const std::vector<uint8_t>& active) {
   for (int b = 0; b < m_batch; ++b) {
     m_h_reg[2 * b] = active[b] ? delta[b] : std::numeric_limits<double>::quiet_NaN();
     m_h_reg[2 * b + 1] = gamma[b];
   }
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_reg.p, m_h_reg, 2 * static_cast<size_t>(m_batch) * sizeof(double),
-                                hipMemcpyHostToDevice, m_stream));
-  SLPX_HIP_CHECK(hipEventRecord(m_reg_consumed, m_stream));
-  m_stats_cur ^= 1;
-  LdltStats* cur = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
-  LdltStats* next = m_stats.p + static_cast<size_t>(m_stats_cur ^ 1) * m_batch;
+}
+
+void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
+  const LdltPlan& l = m_l_ref;
+  LdltStats* cur = m_stats.p + static_cast<size_t>(parity) * m_batch;
+  LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1) * m_batch;
   for (int r = 0; r < l.n_rounds; ++r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, m_stream,
-                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_reg.p, m_Lx.p,
+    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
+                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_h_reg, m_Lx.p,
                        static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
                        m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), cur,
                        r == 0 ? next : nullptr);
@@ -466,12 +480,96 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
+void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
+                       const std::vector<uint8_t>& active) {
+  write_reg(delta, gamma, active);
+  m_stats_cur ^= 1;
+  m_stats_in_host = false;
+  enqueue_factor(m_stats_cur, m_stream);
+}
+
 void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
   out.resize(m_batch);
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
-                                m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, m_stream));
-  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  if (!m_stats_in_host)
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
+                                  m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, m_stream));
+  // Busy-poll instead of a blocking wait: the interrupt-driven wake-up of
+  // hipStreamSynchronize costs tens of microseconds, a tenth of a whole Newton step.
+  hipError_t st;
+  while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+  }
+  SLPX_HIP_CHECK(st);
   std::copy(m_h_stats, m_h_stats + m_batch, out.begin());
+}
+
+// One whole first-attempt Newton step as a HIP graph: [AD refresh] → assemble ‖ rhs →
+// factorization rounds → forward/backward solves → back-substitution → counters to pinned
+// host memory.  One host call instead of ~16, and the independent kernels (small/large
+// tape tasks; lhs/rhs assembly) run side by side on a forked capture stream.  Captured
+// once per (counter-buffer parity, refresh_ad).
+void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& delta,
+                                  const std::vector<double>& gamma,
+                                  const std::vector<uint8_t>& active) {
+  write_reg(delta, gamma, active);
+  m_stats_cur ^= 1;
+  hipGraphExec_t& exec = m_step_graph[m_stats_cur][refresh_ad ? 1 : 0];
+  if (exec == nullptr) {
+    if (m_aux_stream == nullptr) {
+      SLPX_HIP_CHECK(hipStreamCreateWithFlags(&m_aux_stream, hipStreamNonBlocking));
+      SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_fork, hipEventDisableTiming));
+      SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_join, hipEventDisableTiming));
+    }
+    hipStream_t cap = m_capture_stream;
+    if (cap == nullptr) {
+      SLPX_HIP_CHECK(hipStreamCreateWithFlags(&m_capture_stream, hipStreamNonBlocking));
+      cap = m_capture_stream;
+    }
+    hipStream_t saved = m_stream;
+    SLPX_HIP_CHECK(hipStreamSynchronize(saved));
+    SLPX_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    m_stream = cap;
+    auto fork = [&] {
+      SLPX_HIP_CHECK(hipEventRecord(m_fork, cap));
+      SLPX_HIP_CHECK(hipStreamWaitEvent(m_aux_stream, m_fork, 0));
+    };
+    auto join = [&] {
+      SLPX_HIP_CHECK(hipEventRecord(m_join, m_aux_stream));
+      SLPX_HIP_CHECK(hipStreamWaitEvent(cap, m_join, 0));
+    };
+    // Measured (rocprofv3 kernel trace, MI355X): a cross-queue join costs ≈10 µs, more
+    // than running the large tape task (16 µs) or the rhs kernel (4 µs) after their
+    // sibling, and the 152 KB-LDS large task cannot start anyway while the small tasks
+    // hold every CU's LDS.  So the graph is a single chain unless forking is asked for.
+    if (m_fork_in_graph) {
+      if (refresh_ad) {
+        fork();
+        launch_tape(m_full, true, /*small_stream=*/cap, /*other_stream=*/m_aux_stream);
+        join();
+      }
+      fork();
+      assemble();
+      m_stream = m_aux_stream;
+      build_rhs();
+      m_stream = cap;
+      join();
+    } else {
+      if (refresh_ad) launch_tape(m_full, true);
+      assemble();
+      build_rhs();
+    }
+    enqueue_factor(m_stats_cur, cap);
+    solve();
+    backsub();
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
+                                  m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, cap));
+    m_stream = saved;
+    hipGraph_t graph = nullptr;
+    SLPX_HIP_CHECK(hipStreamEndCapture(cap, &graph));
+    SLPX_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    SLPX_HIP_CHECK(hipGraphDestroy(graph));
+  }
+  SLPX_HIP_CHECK(hipGraphLaunch(exec, m_stream));
+  m_stats_in_host = true;
 }
 
 void DeviceNlp::solve() {

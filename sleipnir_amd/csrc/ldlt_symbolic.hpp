@@ -113,7 +113,10 @@ struct LdltPlan {
 };
 
 struct LdltOptions {
-  int leaf_size = 48;           // nested-dissection leaves (nodes)
+  // Nested-dissection leaves (nodes).  Dissecting down to tiny leaves gives the shallowest
+  // trees on chain-structured KKT systems (cart-pole N=1000: height 50 and nnz(L) 67.8 k
+  // at 8, height 64 / 72.8 k at 48, height 90 at 96).
+  int leaf_size = 8;
   // LDS budget per task in entry-equivalents (one L entry ~ 32 B incl. its
   // descriptors; four update pairs ~ one entry).  2048 keeps a task near 64-96 KB.
   uint32_t task_entries = 2048;

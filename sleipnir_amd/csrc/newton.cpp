@@ -31,8 +31,35 @@ void NewtonSystem::reset_regularization() {
 // sparse_regularized_ldlt.hpp:64-152, run for every problem of the batch at once.
 // Each trip through the loop is one device factorization of the still-active
 // problems followed by one small stats read-back.
-std::vector<FactorInfo> NewtonSystem::compute() {
+std::vector<FactorInfo> NewtonSystem::compute(bool solve_speculatively) {
+  return compute_impl(solve_speculatively ? 1 : 0, false);
+}
+
+// mode 0: factorization attempts only; 1: each attempt followed by solve + backsub;
+// 2: like 1, and the FIRST attempt is launched as one HIP graph that also contains the
+// AD refresh (if refresh_ad), the lhs and the rhs assembly.
+std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
+  const bool solve_speculatively = mode >= 1;
+  bool graph_pending = mode == 2;
   const int B = m_opt.batch;
+  // With solve_speculatively every factorization attempt is followed at once by the
+  // triangular solves and the back-substitution, BEFORE the host has read the inertia
+  // counters: the device never idles through the host round trip, and in the usual case
+  // (first attempt accepted) the step is complete when the counters arrive.  A rejected
+  // attempt just has its solve overwritten by the next one.
+  auto factor = [&](const std::vector<double>& d, const std::vector<double>& g,
+                    const std::vector<uint8_t>& a) {
+    if (graph_pending) {
+      graph_pending = false;
+      m_dev->launch_step_graph(refresh_ad, d, g, a);
+      return;
+    }
+    m_dev->factor(d, g, a);
+    if (solve_speculatively) {
+      m_dev->solve();
+      m_dev->backsub();
+    }
+  };
   const int n = m_s.n, m_e = m_s.m_e;
   std::vector<FactorInfo> info(B, FactorInfo::Success);
   std::vector<double> delta(B, 0.0), gamma(B, 0.0);
@@ -57,7 +84,7 @@ std::vector<FactorInfo> NewtonSystem::compute() {
   const bool skip_first = m_opt.skip_structurally_singular_attempt &&
                           m_l.structurally_singular_unregularized;
   if (!skip_first) {
-    m_dev->factor(delta, gamma, active);
+    factor(delta, gamma, active);
     m_dev->read_stats(stats);
     ++m_last_factorizations;
     for (int b = 0; b < B; ++b) {
@@ -84,7 +111,7 @@ std::vector<FactorInfo> NewtonSystem::compute() {
     }
   }
   while (any) {
-    m_dev->factor(delta, gamma, active);
+    factor(delta, gamma, active);
     m_dev->read_stats(stats);
     ++m_last_factorizations;
     any = false;
@@ -127,13 +154,11 @@ std::vector<FactorInfo> NewtonSystem::compute() {
 }
 
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
+  if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
   if (refresh_ad) m_dev->sweep_full();
   m_dev->assemble();
   m_dev->build_rhs();
-  auto info = compute();
-  m_dev->solve();
-  m_dev->backsub();
-  return info;
+  return compute(/*solve_speculatively=*/true);
 }
 
 }  // namespace slpx

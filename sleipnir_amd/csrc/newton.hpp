@@ -25,6 +25,7 @@ struct NewtonOptions {
   int batch = 1;
   int device = 0;
   bool skip_structurally_singular_attempt = true;
+  bool use_step_graph = true;  // newton_step(): first attempt as one HIP graph launch
 };
 
 // Eigen::ComputationInfo stand-in
@@ -70,7 +71,9 @@ class NewtonSystem {
 
   // sparse_regularized_ldlt.hpp:64-152 on the lhs currently in device memory.
   // Returns per-problem info; fills the regularization that was used.
-  std::vector<FactorInfo> compute();
+  // solve_speculatively: also run solve() + backsub() after every attempt (see newton.cpp).
+  std::vector<FactorInfo> compute(bool solve_speculatively = false);
+  std::vector<FactorInfo> compute_impl(int mode, bool refresh_ad);
   const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
   const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
   int last_factorizations() const { return m_last_factorizations; }

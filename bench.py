@@ -151,12 +151,31 @@ def main():
             "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
             "ldlt_solve": (kt["solve"], info["solve_bytes"]),
         }
+        # the tape program (static, read once per sweep) belongs to the sweep's bytes just
+        # like the index maps belong to kkt_assemble's
+        groups["tape_sweep"] = (kt["sweep"], info["sweep_bytes"] + info["tape_program_bytes"])
         dom = max(groups, key=lambda k: groups[k][0] * (nf if k == "ldlt_factor" else 1.0))
         dom_ms, dom_bytes = groups[dom]
         achieved = B * dom_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per step of each kernel group from the committed PMC passes
+        # (profiles/collect.py; FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE)
+        traffic_by_group = None
+        tfile = ROOT / "profiles" / "r01_traffic.json"
+        if tfile.exists() and N == 1000 and B == 1:
+            tj = json.loads(tfile.read_text())
+            prefix = {"tape_sweep": "tape_sweep", "kkt_assemble": "kkt_assemble_kernel",
+                      "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
+                      "ldlt_solve": ("ldlt_fwd_kernel", "ldlt_bwd_kernel")}
+            traffic_by_group = {}
+            for grp, pre in prefix.items():
+                pres = pre if isinstance(pre, tuple) else (pre,)
+                traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
+                                            if kname.startswith(pres) for e in grids.values())
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None if traffic_by_group is None else traffic_by_group[dom],
+            "traffic_per_kernel": traffic_by_group,
             "algorithmic_bytes_per_launch": B * dom_bytes, "launch_ms": dom_ms,
             "per_kernel_ms": {k: v[0] for k, v in groups.items()},
             "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None

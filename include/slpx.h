@@ -137,7 +137,8 @@ enum {
   SLPX_INFO_RHS_BYTES, SLPX_INFO_FACTOR_BYTES, SLPX_INFO_SOLVE_BYTES, SLPX_INFO_SWEEP_BYTES,
   SLPX_INFO_STRUCT_SINGULAR, SLPX_INFO_OFF_G, SLPX_INFO_OFF_AE, SLPX_INFO_OFF_AI,
   SLPX_INFO_OFF_HF, SLPX_INFO_OFF_HC, SLPX_INFO_GRAPH_NODES, SLPX_INFO_NONLINEAR_ROWS,
-  SLPX_INFO_TAPE_GLOBAL_TASKS, SLPX_INFO_COUNT
+  SLPX_INFO_TAPE_GLOBAL_TASKS, SLPX_INFO_TAPE_SHARED_TASKS, SLPX_INFO_TAPE_PROGRAM_BYTES,
+  SLPX_INFO_COUNT
 };
 int slpx_system_info(const slpx_system* s, int64_t* out /* SLPX_INFO_COUNT */);
 

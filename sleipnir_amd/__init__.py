@@ -29,7 +29,8 @@ INFO_KEYS = [
     "ldlt_rounds", "ldlt_tasks", "etree_height", "ldlt_pairs", "tape_tasks", "tape_nodes",
     "tape_slots", "tape_edges", "tape_levels", "tape_slot_levels", "assemble_bytes", "rhs_bytes",
     "factor_bytes", "solve_bytes", "sweep_bytes", "struct_singular", "off_g", "off_Ae", "off_Ai",
-    "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks",
+    "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks", "tape_shared_tasks",
+    "tape_program_bytes",
 ]
 
 # slpx_op

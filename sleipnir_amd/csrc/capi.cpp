@@ -219,6 +219,15 @@ int slpx_system_info(const slpx_system* sc, int64_t* out) {
     out[SLPX_INFO_GRAPH_NODES] = static_cast<int64_t>(st.graph_nodes_after);
     out[SLPX_INFO_NONLINEAR_ROWS] = st.nonlinear_rows;
     out[SLPX_INFO_TAPE_GLOBAL_TASKS] = static_cast<int64_t>(st.full.global_tasks.size());
+    out[SLPX_INFO_TAPE_SHARED_TASKS] = st.full.shared_tasks;
+    // bytes of the compiled program as the LDS-staged kernel reads it (16-bit records,
+    // unique templates only) + the per-task leaf / output maps
+    const auto& f = st.full;
+    out[SLPX_INFO_TAPE_PROGRAM_BYTES] = static_cast<int64_t>(
+        2 * (f.node_rec16.size() + f.edges16.size() + f.slot_edge_ptr16.size()) +
+        4 * (f.lvl_ptr.size() + f.slvl_ptr.size() + f.leaf_src.size() + 3 * f.vout_src.size() +
+             3 * f.jout_slot.size()) +
+        sizeof(slpx::TapeTask) * f.tasks.size());
   });
 }
 

@@ -1,6 +1,7 @@
 #include "newton.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -10,6 +11,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
                            const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
                            const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
     : m_opt(opt), m_graph(&g), m_x_nodes(x), m_ce_nodes(c_e), m_ci_nodes(c_i) {
+  // SLPX_STEP_GRAPH=0 falls back to one launch per kernel (profilers that cannot see into
+  // graph launches, A/B measurements)
+  if (const char* env = std::getenv("SLPX_STEP_GRAPH")) m_opt.use_step_graph = env[0] != '0';
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
   m_k = build_kkt_plan(m_s);
   // which diagonal entries of the unregularized lhs have any source at all

@@ -411,6 +411,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     return static_cast<uint32_t>(it->second);
   };
 
+  std::unordered_multimap<uint64_t, uint32_t> templates;  // structure hash -> first task with it
   std::vector<int32_t> local_of(ncg, -1);       // CG node -> local value index
   std::vector<int32_t> local_slot(slots.size(), -1);
   for (size_t pi = 0; pi < packs.size(); ++pi) {
@@ -420,29 +421,14 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     auto pad = [](auto& v, size_t multiple) {
       while (v.size() % multiple) v.push_back({});
     };
-    while ((prog.node_rec.size() / 3) % 2) {  // 8-byte packed records: even node offset
-      for (int k = 0; k < 3; ++k) prog.node_rec.push_back(0);
-      for (int k = 0; k < 4; ++k) prog.node_rec16.push_back(0);
-    }
-    while (prog.edges.size() % 4) {  // 4-byte packed edges
-      prog.edges.push_back({0, 0});
-      prog.edges16.push_back(0);
-      prog.edges16.push_back(0);
-    }
-    while (prog.slot_edge_ptr.size() % 8) {  // 2-byte packed edge pointers
-      prog.slot_edge_ptr.push_back(0);
-      prog.slot_edge_ptr16.push_back(0);
-    }
-    pad(prog.lvl_ptr, 4);
-    pad(prog.slvl_ptr, 4);
     pad(prog.leaf_src, 4);
     TapeTask t{};
     t.leaf_off = static_cast<uint32_t>(prog.leaf_src.size());
-    t.node_off = static_cast<uint32_t>(prog.node_rec.size() / 3);
-    t.lvl_off = static_cast<uint32_t>(prog.lvl_ptr.size());
-    t.slot_off = static_cast<uint32_t>(prog.slot_edge_ptr.size());
-    t.slvl_off = static_cast<uint32_t>(prog.slvl_ptr.size());
-    t.edge_off = static_cast<uint32_t>(prog.edges.size());
+    // the structural part of the task's program is built locally first: tasks with
+    // byte-identical structure (the stages of a transcribed OCP) share ONE copy of it
+    std::vector<uint32_t> L_rec, L_lvl, L_eptr, L_slvl;
+    std::vector<uint16_t> L_rec16, L_eptr16, L_edges16;
+    std::vector<TapeEdge> L_edges;
     t.vout_off = static_cast<uint32_t>(prog.vout_src.size());
     t.jout_off = static_cast<uint32_t>(prog.jout_slot.size());
 
@@ -492,24 +478,24 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       for (size_t i = 0; i < nodes.size(); ++i) {
         int32_t n = nodes[i];
         if (level[n] != cur_level) {  // one group per DISTINCT level present in the task
-          prog.lvl_ptr.push_back(static_cast<uint32_t>(i));
+          L_lvl.push_back(static_cast<uint32_t>(i));
           cur_level = level[n];
         }
         if (!op_is_basic(static_cast<Opcode>(cg.op[n]))) prog.basic_ops = false;
         uint32_t rec = cg.op[n] | (need_dl[n] ? 0x100u : 0u) | (need_dr[n] ? 0x200u : 0u);
-        prog.node_rec.push_back(rec);
-        prog.node_rec.push_back(static_cast<uint32_t>(local_of[cg.a0[n]]));
-        prog.node_rec.push_back(cg.a1[n] >= 0 ? static_cast<uint32_t>(local_of[cg.a1[n]])
-                                              : static_cast<uint32_t>(local_of[cg.a0[n]]));
+        L_rec.push_back(rec);
+        L_rec.push_back(static_cast<uint32_t>(local_of[cg.a0[n]]));
+        L_rec.push_back(cg.a1[n] >= 0 ? static_cast<uint32_t>(local_of[cg.a1[n]])
+                                      : static_cast<uint32_t>(local_of[cg.a0[n]]));
         // 16-bit packed copy for the LDS-staged kernel (unused by GLOBAL tasks)
-        const size_t r3 = prog.node_rec.size() - 3;
-        prog.node_rec16.push_back(static_cast<uint16_t>(rec));
-        prog.node_rec16.push_back(static_cast<uint16_t>(prog.node_rec[r3 + 1]));
-        prog.node_rec16.push_back(static_cast<uint16_t>(prog.node_rec[r3 + 2]));
-        prog.node_rec16.push_back(0);
+        const size_t r3 = L_rec.size() - 3;
+        L_rec16.push_back(static_cast<uint16_t>(rec));
+        L_rec16.push_back(static_cast<uint16_t>(L_rec[r3 + 1]));
+        L_rec16.push_back(static_cast<uint16_t>(L_rec[r3 + 2]));
+        L_rec16.push_back(0);
       }
-      prog.lvl_ptr.push_back(static_cast<uint32_t>(nodes.size()));
-      t.n_lvl = static_cast<uint32_t>(prog.lvl_ptr.size() - t.lvl_off - 1);
+      L_lvl.push_back(static_cast<uint32_t>(nodes.size()));
+      t.n_lvl = static_cast<uint32_t>(L_lvl.size() - 1);
       prog.max_levels = std::max(prog.max_levels, t.n_lvl);
     }
     // slots + reverse levels + edges
@@ -520,17 +506,17 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       for (size_t i = 0; i < tslots.size(); ++i) {
         const Slot& s = slots[tslots[i]];
         if (s.level != cur_level) {
-          prog.slvl_ptr.push_back(static_cast<uint32_t>(i));
+          L_slvl.push_back(static_cast<uint32_t>(i));
           cur_level = s.level;
         }
-        prog.slot_edge_ptr.push_back(edge_count);
-        prog.slot_edge_ptr16.push_back(static_cast<uint16_t>(edge_count));
+        L_eptr.push_back(edge_count);
+        L_eptr16.push_back(static_cast<uint16_t>(edge_count));
         for (const REdge& e : slot_edges[tslots[i]]) {
           uint32_t pn = static_cast<uint32_t>(local_of[e.parent_node]) - t.n_leaf;
-          prog.edges.push_back({static_cast<uint32_t>(local_slot[e.parent_slot]),
-                                2u * pn + static_cast<uint32_t>(e.side)});
-          prog.edges16.push_back(static_cast<uint16_t>(local_slot[e.parent_slot]));
-          prog.edges16.push_back(static_cast<uint16_t>(2u * pn + static_cast<uint32_t>(e.side)));
+          L_edges.push_back({static_cast<uint32_t>(local_slot[e.parent_slot]),
+                             2u * pn + static_cast<uint32_t>(e.side)});
+          L_edges16.push_back(static_cast<uint16_t>(local_slot[e.parent_slot]));
+          L_edges16.push_back(static_cast<uint16_t>(2u * pn + static_cast<uint32_t>(e.side)));
           ++edge_count;
         }
         if (s.out_dst >= 0) {
@@ -539,13 +525,84 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
           prog.jout_scale.push_back(rows[s.row].scale_idx);
         }
       }
-      prog.slot_edge_ptr.push_back(edge_count);
-      prog.slot_edge_ptr16.push_back(static_cast<uint16_t>(edge_count));
+      L_eptr.push_back(edge_count);
+      L_eptr16.push_back(static_cast<uint16_t>(edge_count));
       t.n_edge = edge_count;
-      prog.slvl_ptr.push_back(static_cast<uint32_t>(tslots.size()));
-      t.n_slvl = static_cast<uint32_t>(prog.slvl_ptr.size() - t.slvl_off - 1);
+      L_slvl.push_back(static_cast<uint32_t>(tslots.size()));
+      t.n_slvl = static_cast<uint32_t>(L_slvl.size() - 1);
       prog.max_slot_levels = std::max(prog.max_slot_levels, t.n_slvl);
       prog.total_edges += edge_count;
+    }
+    {  // share the structure with an identical earlier task, else append it
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](const void* data, size_t bytes) {
+        const unsigned char* b = static_cast<const unsigned char*>(data);
+        for (size_t k = 0; k < bytes; ++k) h = (h ^ b[k]) * 1099511628211ull;
+      };
+      const uint32_t dims[3] = {t.n_leaf, t.n_node, t.n_slot};
+      mix(dims, sizeof(dims));
+      mix(L_rec.data(), L_rec.size() * 4);
+      mix(L_lvl.data(), L_lvl.size() * 4);
+      mix(L_eptr.data(), L_eptr.size() * 4);
+      mix(L_slvl.data(), L_slvl.size() * 4);
+      mix(L_edges.data(), L_edges.size() * sizeof(TapeEdge));
+      auto same = [&](const TapeTask& o) {
+        if (o.n_leaf != t.n_leaf || o.n_node != t.n_node || o.n_slot != t.n_slot || o.n_lvl != t.n_lvl ||
+            o.n_slvl != t.n_slvl || o.n_edge != t.n_edge)
+          return false;
+        return std::equal(L_rec.begin(), L_rec.end(), prog.node_rec.begin() + 3 * size_t(o.node_off)) &&
+               std::equal(L_lvl.begin(), L_lvl.end(), prog.lvl_ptr.begin() + o.lvl_off) &&
+               std::equal(L_eptr.begin(), L_eptr.end(), prog.slot_edge_ptr.begin() + o.slot_off) &&
+               std::equal(L_slvl.begin(), L_slvl.end(), prog.slvl_ptr.begin() + o.slvl_off) &&
+               std::equal(L_edges.begin(), L_edges.end(), prog.edges.begin() + o.edge_off,
+                          [](const TapeEdge& a, const TapeEdge& b) {
+                            return a.parent_slot == b.parent_slot && a.partial == b.partial;
+                          });
+      };
+      int64_t shared = -1;
+      auto range = templates.equal_range(h);
+      for (auto it = range.first; it != range.second && shared < 0; ++it)
+        if (same(prog.tasks[it->second])) shared = it->second;
+      if (shared >= 0) {
+        const TapeTask& o = prog.tasks[shared];
+        t.node_off = o.node_off;
+        t.lvl_off = o.lvl_off;
+        t.slot_off = o.slot_off;
+        t.slvl_off = o.slvl_off;
+        t.edge_off = o.edge_off;
+        ++prog.shared_tasks;
+      } else {
+        // every slice starts on a 16-byte boundary (unrolled 16-byte staging loads)
+        while ((prog.node_rec.size() / 3) % 2) {  // 8-byte packed records: even node offset
+          for (int k = 0; k < 3; ++k) prog.node_rec.push_back(0);
+          for (int k = 0; k < 4; ++k) prog.node_rec16.push_back(0);
+        }
+        while (prog.edges.size() % 4) {  // 4-byte packed edges
+          prog.edges.push_back({0, 0});
+          prog.edges16.push_back(0);
+          prog.edges16.push_back(0);
+        }
+        while (prog.slot_edge_ptr.size() % 8) {  // 2-byte packed edge pointers
+          prog.slot_edge_ptr.push_back(0);
+          prog.slot_edge_ptr16.push_back(0);
+        }
+        pad(prog.lvl_ptr, 4);
+        pad(prog.slvl_ptr, 4);
+        t.node_off = static_cast<uint32_t>(prog.node_rec.size() / 3);
+        t.lvl_off = static_cast<uint32_t>(prog.lvl_ptr.size());
+        t.slot_off = static_cast<uint32_t>(prog.slot_edge_ptr.size());
+        t.slvl_off = static_cast<uint32_t>(prog.slvl_ptr.size());
+        t.edge_off = static_cast<uint32_t>(prog.edges.size());
+        prog.node_rec.insert(prog.node_rec.end(), L_rec.begin(), L_rec.end());
+        prog.node_rec16.insert(prog.node_rec16.end(), L_rec16.begin(), L_rec16.end());
+        prog.lvl_ptr.insert(prog.lvl_ptr.end(), L_lvl.begin(), L_lvl.end());
+        prog.slot_edge_ptr.insert(prog.slot_edge_ptr.end(), L_eptr.begin(), L_eptr.end());
+        prog.slot_edge_ptr16.insert(prog.slot_edge_ptr16.end(), L_eptr16.begin(), L_eptr16.end());
+        prog.slvl_ptr.insert(prog.slvl_ptr.end(), L_slvl.begin(), L_slvl.end());
+        prog.edges.insert(prog.edges.end(), L_edges.begin(), L_edges.end());
+        prog.edges16.insert(prog.edges16.end(), L_edges16.begin(), L_edges16.end());
+        templates.emplace(h, static_cast<uint32_t>(prog.tasks.size()));
+      }
     }
     for (size_t v : vouts) {
       prog.vout_src.push_back(static_cast<uint32_t>(local_of[to_cg.at(value_outs[v].node)]));

@@ -87,6 +87,7 @@ struct TapeProgram {
   // `consts` (never shared with a literal), so its value can be refreshed on the device
   // without recompiling: (graph node, index into consts).
   std::vector<std::pair<NodeId, uint32_t>> params;
+  uint32_t shared_tasks = 0;  // tasks whose structure (records, levels, edges) is another task's
   std::vector<uint32_t> node_rec;  // [op | need_dl<<8 | need_dr<<9, a0, a1] per node
   std::vector<uint32_t> lvl_ptr;
   std::vector<uint32_t> slot_edge_ptr;

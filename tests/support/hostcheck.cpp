@@ -174,6 +174,9 @@ void hc_info(hc_handle* h, int64_t* out) {
   out[i++] = h->s.off_Hc;
   out[i++] = static_cast<int64_t>(h->s.full.global_tasks.size());
   out[i++] = static_cast<int64_t>(h->s.full.large_tasks.size());
+  out[i++] = h->s.full.shared_tasks;
+  out[i++] = static_cast<int64_t>(2 * (h->s.full.node_rec16.size() + h->s.full.edges16.size() +
+                                       h->s.full.slot_edge_ptr16.size()));
 }
 
 int32_t hc_pattern(hc_handle* h, int which, int32_t* colptr, int32_t* rowidx) {

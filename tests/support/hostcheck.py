@@ -71,7 +71,8 @@ def lib():
 INFO_KEYS = ["n", "m_e", "m_i", "nV", "nnz_lhs", "nnz_L", "ldlt_rounds", "ldlt_tasks",
              "etree_height", "ldlt_pairs", "tape_tasks", "tape_nodes", "tape_slots", "tape_edges",
              "tape_levels", "tape_slot_levels", "struct_singular", "off_g", "off_Ae", "off_Ai",
-             "off_Hf", "off_Hc", "tape_global_tasks", "tape_large_tasks"]
+             "off_Hf", "off_Hc", "tape_global_tasks", "tape_large_tasks", "tape_shared_tasks",
+             "tape_structure_bytes"]
 
 
 def _fa(a):

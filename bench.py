@@ -68,8 +68,14 @@ def main():
     ap.add_argument("--N", type=int, default=1000, help="horizon (BASELINE config: 1000)")
     ap.add_argument("--batch", type=int, default=1, help="independent problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched-roofline", action="store_true")
-    ap.add_argument("--roofline-batch", type=int, default=128)
+    ap.add_argument("--batched-roofline", action="store_true",
+                    help="also step a batch of independent problems (the configuration on which "
+                         "the HBM roofline of the gather kernels is measurable) and add a "
+                         "'batched' object; off by default so that the default command launches "
+                         "one kernel shape only and the rocprofv3 --stats averages under "
+                         "profiles/ are per-launch numbers of the N=1 workload")
+    ap.add_argument("--no-batched-roofline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--roofline-batch", type=int, default=512)
     args = ap.parse_args()
 
     import torch
@@ -182,7 +188,8 @@ def main():
                                 for k, v in groups.items()},
             "factorizations_per_step": kt["factorizations"],
             "note": "single N=1000 problem: every kernel is dependency-latency bound (SURVEY.md "
-                    "§7 hard part 1); HBM fractions are meaningful on the batched line below",
+                    "§7 hard part 1); HBM fractions are meaningful on a batch (--batched-roofline; "
+                    "DESIGN.md §4, profiles/r01_batched_*)",
         }
         out = {
             "metric": "Newton steps/sec, cart-pole direct-transcription N=%d" % N,
@@ -204,7 +211,7 @@ def main():
             "setup_s": {"model": t_model, "compile_and_upload": t_compile},
             "roofline": roofline,
         }
-        if not args.no_batched_roofline and world == 1 and B == 1:
+        if args.batched_roofline and world == 1 and B == 1:
             # the configuration on which HBM-roofline claims are measurable
             RB = args.roofline_batch
             sysb = sa.System(pp, batch=RB, device=local_rank)

@@ -140,6 +140,7 @@ struct KktDev {
   const int32_t* ai_rowptr;
   const int32_t* ai_col;
   const int32_t* ai_src;
+  const int32_t* fast_src;
   int off_f, off_ce, off_ci, off_g, off_Ae, off_Ai;
 };
 
@@ -232,7 +233,7 @@ class DeviceNlp {
   TapeDevice m_full, m_values;
   // KKT plan
   DevBuf<int32_t> m_dptr, m_dsrc, m_pptr, m_pa, m_pb, m_pr, m_gsrc, m_ae_colptr, m_ae_rowidx,
-      m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src, m_diag_pos;
+      m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src, m_diag_pos, m_fast_src;
   KktDev m_kdev{};
   // LDLT plan
   DevBuf<LdltTask> m_ltasks;

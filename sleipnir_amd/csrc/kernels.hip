@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const doubl
   s += static_cast<size_t>(b) * K.m_i;
   z += static_cast<size_t>(b) * K.m_i;
   lhs += static_cast<size_t>(b) * K.nnz_lhs;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K.nnz_lhs; k += gridDim.x * blockDim.x) {
+  auto general = [&](int k) {
     double direct = 0.0;
     for (int d = K.dptr[k]; d < K.dptr[k + 1]; ++d) direct += V[K.dsrc[d]];
     double prod = 0.0;
@@ -49,7 +49,30 @@ __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const doubl
       const double sigma = (1.0 / s[r]) * z[r];  // Σ = S⁻¹Z (interior_point.hpp:426)
       prod += (V[K.pa[p]] * sigma) * V[K.pb[p]];
     }
-    lhs[k] = direct + prod;
+    return direct + prod;
+  };
+  // Four entries per thread with their gathers in flight together (the kernel is a chain
+  // of dependent loads; HBM bandwidth needs the memory-level parallelism), and a one-index
+  // fast path for the entries that are plain copies of a V value (all of A_e, most of H).
+  const int stride = gridDim.x * blockDim.x;
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; k + 3 * stride < K.nnz_lhs; k += 4 * stride) {
+    const int f0 = K.fast_src[k], f1 = K.fast_src[k + stride], f2 = K.fast_src[k + 2 * stride],
+              f3 = K.fast_src[k + 3 * stride];
+    double v0 = f0 >= 0 ? V[f0] : 0.0, v1 = f1 >= 0 ? V[f1] : 0.0, v2 = f2 >= 0 ? V[f2] : 0.0,
+           v3 = f3 >= 0 ? V[f3] : 0.0;
+    if (f0 == -2) v0 = general(k);
+    if (f1 == -2) v1 = general(k + stride);
+    if (f2 == -2) v2 = general(k + 2 * stride);
+    if (f3 == -2) v3 = general(k + 3 * stride);
+    lhs[k] = v0;
+    lhs[k + stride] = v1;
+    lhs[k + 2 * stride] = v2;
+    lhs[k + 3 * stride] = v3;
+  }
+  for (; k < K.nnz_lhs; k += stride) {
+    const int f = K.fast_src[k];
+    lhs[k] = f >= 0 ? V[f] : (f == -2 ? general(k) : 0.0);
   }
 }
 
@@ -227,6 +250,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_ai_rowptr.upload(k.ai_rowptr);
   m_ai_col.upload(k.ai_col);
   m_ai_src.upload(k.ai_src);
+  m_fast_src.upload(k.fast_src);
   {
     std::vector<int32_t> diag_pos(std::max(1, k.n), 0);
     for (int c = 0; c < k.n; ++c)
@@ -237,7 +261,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_kdev = KktDev{k.n,           k.m_e,        k.m_i,        k.dim,         k.lhs.nnz(),  m_dptr.p,
                   m_dsrc.p,      m_pptr.p,     m_pa.p,       m_pb.p,        m_pr.p,       m_gsrc.p,
                   m_ae_colptr.p, m_ae_rowidx.p, m_ai_colptr.p, m_ai_rowidx.p, m_ai_rowptr.p,
-                  m_ai_col.p,    m_ai_src.p,   s.off_f,      s.off_ce,      s.off_ci,     s.off_g,
+                  m_ai_col.p,    m_ai_src.p,   m_fast_src.p, s.off_f,      s.off_ce,     s.off_ci,     s.off_g,
                   s.off_Ae,      s.off_Ai};
 
   m_ltasks.upload(l.tasks);
@@ -406,8 +430,9 @@ static inline int grid_for(int work, int block, int cap = 2048) {
 }
 
 void DeviceNlp::assemble() {
-  hipLaunchKernelGGL(kkt_assemble_kernel, dim3(grid_for(m_kdev.nnz_lhs, 256), m_batch), dim3(256), 0,
-                     m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs.p);
+  // four entries per thread (see the kernel)
+  hipLaunchKernelGGL(kkt_assemble_kernel, dim3(grid_for((m_kdev.nnz_lhs + 3) / 4, 256), m_batch),
+                     dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs.p);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

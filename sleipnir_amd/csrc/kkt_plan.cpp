@@ -89,6 +89,11 @@ KktPlan build_kkt_plan(const NlpStructure& s) {
   // assemble = 12(h+a+i) + 16 m_i + 8 k ; rhs = 16n + 24m_e + 24m_i + 12(a+i)
   const int64_t h = s.Hf.nnz() + s.Hc.nnz(), a = s.Ae.nnz(), i = s.Ai.nnz(), kk = k.lhs.nnz();
   k.assemble_bytes = 12 * (h + a + i) + 16LL * s.m_i + 8 * kk;
+  k.fast_src.resize(k.lhs.nnz());
+  for (int e = 0; e < k.lhs.nnz(); ++e) {
+    const int nd = k.dptr[e + 1] - k.dptr[e], np = k.pptr[e + 1] - k.pptr[e];
+    k.fast_src[e] = (np == 0 && nd == 1) ? k.dsrc[k.dptr[e]] : ((np == 0 && nd == 0) ? -1 : -2);
+  }
   k.rhs_bytes = 16LL * n + 24LL * s.m_e + 24LL * s.m_i + 12 * (a + i);
   return k;
 }

@@ -28,6 +28,10 @@ struct KktPlan {
   //             + sum_{p in [pptr[k], pptr[k+1])} V[pa[p]] * (z[pr[p]]/s[pr[p]]) * V[pb[p]]
   std::vector<int32_t> dptr, dsrc;
   std::vector<int32_t> pptr, pa, pb, pr;
+  // Fast path of the assembly kernel: fast_src[k] >= 0 when entry k is a plain copy of
+  // V[fast_src[k]] (one direct source, no product term: every A_e entry and most of H);
+  // -1 = structural zero (forced diagonal of the (2,2) block); -2 = general entry.
+  std::vector<int32_t> fast_src;
 
   // rhs (x part): column gathers over A_e and A_i (CSC), g scattered to dense
   std::vector<int32_t> g_src;  // n entries: V index of ∂f/∂x_j or -1

@@ -420,7 +420,7 @@ int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) 
       sys.compute();
       nfact += sys.last_factorizations();
       SLPX_HIP_CHECK(hipEventRecord(ev[4], st));
-      dev.solve();
+      dev.solve_after_factor();  // the factorization carried the rhs: backward substitution only
       SLPX_HIP_CHECK(hipEventRecord(ev[5], st));
       dev.backsub();
       SLPX_HIP_CHECK(hipEventRecord(ev[6], st));

@@ -193,6 +193,7 @@ class DeviceNlp {
   void launch_step_graph(bool refresh_ad, const std::vector<double>& delta,
                          const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
+  void solve_after_factor();                        // p for the rhs that was in place at factor()
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
 
   // device pointers for callers that keep everything resident

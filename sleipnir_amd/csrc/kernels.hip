@@ -500,7 +500,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                        m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_h_reg, m_Lx.p,
                        static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
                        m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), cur,
-                       r == 0 ? next : nullptr);
+                       r == 0 ? next : nullptr, m_rhs.p, m_zv.p);
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }
@@ -583,7 +583,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
       build_rhs();
     }
     enqueue_factor(m_stats_cur, cap);
-    solve();
+    solve_after_factor();
     backsub();
     SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
                                   m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, cap));
@@ -597,6 +597,8 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
   m_stats_in_host = true;
 }
 
+// Full solve for a right-hand side that arrived AFTER the factorization (second-order
+// corrections, multiplier estimate, slpx_ldlt_solve): forward, then backward.
 void DeviceNlp::solve() {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
@@ -607,6 +609,14 @@ void DeviceNlp::solve() {
                        m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs,
                        m_zv.p);
   }
+  solve_after_factor();
+}
+
+// The factorization carried the rhs along as an extra row and left z = D⁻¹L⁻¹Pb behind
+// (ldlt_symbolic.cpp), so only the backward substitution remains.
+void DeviceNlp::solve_after_factor() {
+  const LdltPlan& l = m_l_ref;
+  const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   for (int r = l.n_rounds - 1; r >= 0; --r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
     hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,

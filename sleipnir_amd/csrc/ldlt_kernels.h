@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
     const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
-    LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next) {
+    LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
+    const double* __restrict__ rhs, double* __restrict__ zv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LdltTask t = L.tasks[task_base + blockIdx.x];
   const int b = blockIdx.y;
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   Lx += static_cast<size_t>(b) * lx_stride;
   D += static_cast<size_t>(b) * n;
   contrib += static_cast<size_t>(b) * contrib_stride;
+  rhs += static_cast<size_t>(b) * n;
+  zv += static_cast<size_t>(b) * n;
 
   SLPX_LDLT_CLOCK(0);
   const uint32_t n_pp = t.n_ent + t.n_ext + 1;
@@ -122,20 +125,21 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
 
   // ---- matrix values: four independent gathers per lane in flight ----
   {
+    // entries of the right-hand-side row (flag bit 2) read rhs instead of lhs
+    auto fetch = [&](uint32_t i) {
+      const int32_t s0 = src[i];
+      const double* base = (flags[i] & 4) ? rhs : lhs;
+      return s0 >= 0 ? base[s0] : 0.0;
+    };
     uint32_t i = tid;
     for (; i + 3 * 256 < t.n_ent; i += 4 * 256) {
-      const int32_t s0 = src[i], s1 = src[i + 256], s2 = src[i + 512], s3 = src[i + 768];
-      const double a0 = s0 >= 0 ? lhs[s0] : 0.0, a1 = s1 >= 0 ? lhs[s1] : 0.0,
-                   a2 = s2 >= 0 ? lhs[s2] : 0.0, a3 = s3 >= 0 ? lhs[s3] : 0.0;
+      const double a0 = fetch(i), a1 = fetch(i + 256), a2 = fetch(i + 512), a3 = fetch(i + 768);
       U[i] = a0;
       U[i + 256] = a1;
       U[i + 512] = a2;
       U[i + 768] = a3;
     }
-    for (; i < t.n_ent; i += 256) {
-      const int32_t s0 = src[i];
-      U[i] = s0 >= 0 ? lhs[s0] : 0.0;
-    }
+    for (; i < t.n_ent; i += 256) U[i] = fetch(i);
   }
   __syncthreads();
   // regularization + update blocks of child tasks (few entries have any)
@@ -208,6 +212,8 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       else atomicAdd(&s_cnt[2], 1);
       if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
       else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
+    } else if (flags[i] & 4) {
+      zv[out[i]] = u * invd[col[i]];  // z = D⁻¹L⁻¹Pb: the forward solve came for free
     } else {
       Lx[out[i]] = u * invd[col[i]];
     }

@@ -327,7 +327,8 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       // LDS cost in "entry equivalents" (~32 B): the column's entries plus the
       // update pairs it generates (8 B each), wherever those end up being stored
       const uint32_t c = static_cast<uint32_t>(Lcol[j].size());
-      w[j] = (c + 1) + (c * (c + 1) / 2 + 3) / 4;
+      // (+1 entry and +c pairs for the right-hand-side row, see "entries" below)
+      w[j] = (c + 2) + (c * (c + 1) / 2 + c + 3) / 4;
       if (w[j] > cap)
         throw std::runtime_error("ldlt: a single column exceeds the LDS task budget "
                                  "(global-memory supernode path not built yet)");
@@ -393,14 +394,22 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   }
 
   // ---- entries ---------------------------------------------------------------------
-  // local entry index of the diagonal of column j and of each L position
-  std::vector<uint32_t> diag_ent(n), lent(P.nnzL);
+  // local entry index of the diagonal of column j and of each L position.
+  //
+  // The right-hand side rides along as one extra ROW of the matrix: factorizing
+  // [[K, b], [bᵀ, ·]] yields, as the last row of L, exactly z = D⁻¹L⁻¹Pb — the result of
+  // the forward substitution and the diagonal scaling.  Column j therefore gets one more
+  // entry U_b(j) = b_j − Σ_k U(j,k)·U_b(k)/d_k, computed at column j's level with the same
+  // pair/contribution machinery as every other entry, and the forward-solve launches
+  // disappear from the Newton step (they remain for re-solves with a new rhs).
+  std::vector<uint32_t> diag_ent(n), lent(P.nnzL), bent(n);
   std::vector<uint32_t> task_nent(ntasks, 0);
   for (int t = 0; t < ntasks; ++t) {
     uint32_t e = 0;
     for (int32_t j : tcols[t].cols) {
       diag_ent[j] = e++;
       for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) lent[p] = e++;
+      bent[j] = e++;
     }
     task_nent[t] = e;
     if (e > 65535u) throw std::runtime_error("ldlt: task exceeds 16-bit local indexing");
@@ -426,20 +435,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       const int32_t j = rows[a];  // target column
       const int tj = task_of[j];
       const uint32_t ent_jk = lent[P.Lp[k] + a];
-      int32_t q = P.Lp[j];  // walk column j's rows
-      for (int b = a; b < c; ++b) {
-        const int32_t i = rows[b];
-        uint32_t target;
-        if (b == a) {
-          target = diag_ent[j];
-          diag_updated_perm[j] = 1;
-        } else {
-          while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
-          if (q >= P.Lp[j + 1]) throw std::runtime_error("ldlt: fill pattern inconsistency");
-          target = lent[q];
-        }
-        LdltPair pr{static_cast<uint16_t>(lent[P.Lp[k] + b]), static_cast<uint16_t>(ent_jk),
-                    static_cast<uint16_t>(lcol[k]), 0};
+      auto add_pair = [&](uint32_t target, const LdltPair& pr) {
         if (tk == tj) {
           epairs[tj][target].push_back(pr);
         } else {
@@ -453,6 +449,24 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
           }
           exts[tk][it->second].pairs.push_back(pr);
         }
+      };
+      // rhs row: U_b(j) -= U_b(k) · U(j,k) / d_k
+      add_pair(bent[j], LdltPair{static_cast<uint16_t>(bent[k]), static_cast<uint16_t>(ent_jk),
+                                 static_cast<uint16_t>(lcol[k]), 0});
+      int32_t q = P.Lp[j];  // walk column j's rows
+      for (int b = a; b < c; ++b) {
+        const int32_t i = rows[b];
+        uint32_t target;
+        if (b == a) {
+          target = diag_ent[j];
+          diag_updated_perm[j] = 1;
+        } else {
+          while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
+          if (q >= P.Lp[j + 1]) throw std::runtime_error("ldlt: fill pattern inconsistency");
+          target = lent[q];
+        }
+        add_pair(target, LdltPair{static_cast<uint16_t>(lent[P.Lp[k] + b]),
+                                  static_cast<uint16_t>(ent_jk), static_cast<uint16_t>(lcol[k]), 0});
       }
     }
   }
@@ -589,6 +603,8 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
         if (ap < Acol[j].size() && Acol[j][ap].first == P.Li[p]) src = Acol[j][ap].second;
         emit_entry(lent[p], src, 0, static_cast<uint32_t>(p));
       }
+      // rhs-row entry: source = rhs[perm[j]], result z_j = U_b(j)/d_j
+      emit_entry(bent[j], P.perm[j], 4, static_cast<uint32_t>(j));
       // solve lists
       P.fwd_ptr.push_back(fwd_count);
       for (auto& it : fwd[j]) P.fwd_items.push_back(it);

@@ -81,7 +81,8 @@ struct LdltPlan {
 
   // ---- factor ----
   std::vector<int32_t> ent_src;       // index into lhs values or -1
-  std::vector<uint8_t> ent_flags;     // bit0: diagonal, bit1: (diagonal) regularize with −γ instead of +δ
+  std::vector<uint8_t> ent_flags;     // bit0: diagonal, bit1: (diagonal) regularize with −γ instead of +δ,
+                                      // bit2: right-hand-side row (ent_src indexes rhs, ent_out = permuted column of z)
   std::vector<uint16_t> ent_col;      // local column
   std::vector<uint32_t> ent_out;      // diag: permuted column index (D); else position in Lx
   std::vector<uint32_t> ent_pair_ptr;     // per task: n_ent + n_ext + 1 (relative to pair_off)

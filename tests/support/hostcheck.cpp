@@ -25,6 +25,7 @@ struct hc_handle {
   KktPlan k;
   LdltPlan l;
   std::vector<double> scales, in_scale, V, lhs, rhs, Lx, D, contrib, scontrib, zv, xg, p, ps, pz;
+  std::vector<double> z_factor;  // z left behind by the factorization (rhs carried as a row)
   int stats[4] = {0, 0, 0, 0};
   double min_abs = 0.0;
 };
@@ -136,6 +137,7 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   h->contrib.assign(std::max<uint32_t>(1, h->l.n_contrib), 0.0);
   h->scontrib.assign(std::max<uint32_t>(1, h->l.n_scontrib), 0.0);
   h->zv.assign(h->l.n, 0.0);
+  h->z_factor.assign(h->l.n, 0.0);
   h->xg.assign(h->l.n, 0.0);
   h->p.assign(h->k.dim, 0.0);
   h->ps.assign(std::max(1, h->s.m_i), 0.0);
@@ -278,7 +280,7 @@ void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* 
           uint32_t e = t.ent_off + i;
           int32_t src = L.ent_src[e];
           uint8_t fl = L.ent_flags[e];
-          double acc = src >= 0 ? h->lhs[src] : 0.0;
+          double acc = src >= 0 ? ((fl & 4) ? h->rhs[src] : h->lhs[src]) : 0.0;  // bit 2: rhs row
           if (fl & 1) acc += (fl & 2) ? -gamma : delta;
           for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= h->contrib[cidx[c]];
           for (uint32_t q = pptr[i]; q < pptr[i + 1]; ++q)
@@ -308,6 +310,8 @@ void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* 
           else ++h->stats[2];
           if (u == 0.0 || !std::isfinite(u)) ++h->stats[3];
           else h->min_abs = std::min(h->min_abs, std::fabs(u));
+        } else if (L.ent_flags[e] & 4) {
+          h->z_factor[L.ent_out[e]] = u * invd[L.ent_col[e]];  // z = D^-1 L^-1 P b, by-product
         } else {
           h->Lx[L.ent_out[e]] = u * invd[L.ent_col[e]];
         }
@@ -318,6 +322,15 @@ void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* 
     for (int i = 0; i < 4; ++i) stats_out[i] = h->stats[i];
     stats_out[4] = h->min_abs;
   }
+}
+
+static void hc_backward(hc_handle* h, double* p_out);
+
+// backward substitution only, on the z the factorization left behind (the path the
+// Newton step takes on the device)
+void hc_solve_after_factor(hc_handle* h, double* p_out) {
+  h->zv = h->z_factor;
+  hc_backward(h, p_out);
 }
 
 void hc_solve(hc_handle* h, double* p_out) {
@@ -354,6 +367,11 @@ void hc_solve(hc_handle* h, double* p_out) {
         h->zv[pj] = y[i] / h->D[pj];
       }
     }
+  hc_backward(h, p_out);
+}
+
+static void hc_backward(hc_handle* h, double* p_out) {
+  const LdltPlan& L = h->l;
   for (int r = L.n_rounds - 1; r >= 0; --r)
     for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
       const LdltTask& t = L.tasks[ti];

@@ -63,6 +63,7 @@ def lib():
     sig("hc_set_rhs", None, vp, vp)
     sig("hc_factor", None, vp, d, d, vp, vp)
     sig("hc_solve", None, vp, vp)
+    sig("hc_solve_after_factor", None, vp, vp)
     sig("hc_backsub", None, vp, vp, vp, d, vp, vp)
     _lib = L
     return L
@@ -148,6 +149,12 @@ class HostCheck:
     def solve(self):
         p = np.zeros(self.n + self.m_e)
         lib().hc_solve(self._h, p.ctypes.data)
+        return p
+
+    def solve_after_factor(self):
+        """Backward substitution on the z the factorization produced (rhs carried as a row)."""
+        p = np.zeros(self.n + self.m_e)
+        lib().hc_solve_after_factor(self._h, p.ctypes.data)
         return p
 
     def backsub(self, s, z, mu):

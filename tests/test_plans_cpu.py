@@ -24,3 +24,24 @@ def test_small_tasks_force_many_rounds(fresh, slpx, orc, hostcheck):
     hc = hostcheck.HostCheck(pp, task_entries=64, small_lds_bytes=24 * 1024)
     assert hc.info["ldlt_rounds"] >= 3
     parity.check_newton_step(hc, op, "interior")
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 37), ("flywheel", 50)])
+def test_rhs_row_of_the_factorization_is_the_forward_solve(fresh, slpx, orc, hostcheck, kind, N):
+    """The factorization carries the rhs as an extra row (ldlt_symbolic.cpp); what it leaves
+    behind must be z = D^-1 L^-1 P b, i.e. backward substitution alone reproduces the full
+    solve — the path the device takes inside a Newton step."""
+    pp, op = cases.build_pair(kind, N, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    n, me, mi = hc.n, hc.m_e, hc.m_i
+    scales = op.scaling()
+    hc.set_scaling(scales)
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+    hc.sweep(x, y, z, True)
+    hc.assemble(s, z)
+    hc.rhs(s, y, z, mu)
+    hc.factor(1e-4, 1e-10)
+    p_full = hc.solve()
+    p_fused = hc.solve_after_factor()
+    assert cases.max_rel(p_fused, p_full) <= 1e-9
+    hc.close()

@@ -117,6 +117,8 @@ struct LdltDev {
   const uint32_t* bwd_ptr;
   const LdltSolveItem* bwd_items;
   const int32_t* perm;
+  const uint32_t* round_ptr;  // n_rounds + 1, into tasks
+  int n_rounds;
 };
 
 struct LdltStats {   // one per batch item, written by the factor kernels
@@ -195,6 +197,7 @@ class DeviceNlp {
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
+  void backsub_and_publish(const LdltStats* stats_src);
 
   // device pointers for callers that keep everything resident
   double* d_x() { return m_in.p; }
@@ -257,6 +260,12 @@ class DeviceNlp {
   LdltStats* m_h_stats = nullptr;     // pinned read-back
   bool m_stats_in_host = false;       // the last launch already copied the counters out
   bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
+  // all rounds of a factorization / backward solve in one launch (device-side round
+  // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables
+  bool m_single_launch = true;
+  DevBuf<uint32_t> m_round_ptr;
+  DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
+  int m_bround_cur = 0;
   hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
   hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
   hipEvent_t m_fork = nullptr, m_join = nullptr;

@@ -152,8 +152,13 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
                                                            const double* __restrict__ z,
                                                            const double* __restrict__ mu,
                                                            double* __restrict__ ps,
-                                                           double* __restrict__ pz) {
+                                                           double* __restrict__ pz,
+                                                           const LdltStats* __restrict__ stats_src,
+                                                           LdltStats* __restrict__ stats_host) {
   const int b = blockIdx.y;
+  // last kernel of a graph-launched step: hand the inertia counters of the factorization
+  // to the host (pinned memory) instead of spending a copy node on them
+  if (stats_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stats_host[b] = stats_src[b];
   V += static_cast<size_t>(b) * v_stride;
   p += static_cast<size_t>(b) * K.dim;
   s += static_cast<size_t>(b) * K.m_i;
@@ -292,7 +297,16 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                    m_ext_dst.p,      m_llvl_ptr.p, m_pairs.p,           m_col_perm.p,
                    m_col_lvl_ptr.p,  m_fwd_ptr.p,  m_fwd_contrib_ptr.p, m_scontrib_idx.p,
                    m_fwd_items.p,    m_sext_ptr.p, m_sext_dst.p,        m_sext_items.p,
-                   m_bwd_ptr.p,      m_bwd_items.p, m_perm.p};
+                   m_bwd_ptr.p,      m_bwd_items.p, m_perm.p,            nullptr,
+                   l.n_rounds};
+  m_round_ptr.upload(l.round_ptr);
+  m_ldev.round_ptr = m_round_ptr.p;
+  {
+    std::vector<unsigned int> zero(2 * static_cast<size_t>(batch) * std::max(1, l.n_rounds), 0u);
+    m_fround_cnt.upload(zero);
+    m_bround_cnt.upload(zero);
+  }
+  if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -494,13 +508,22 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   const LdltPlan& l = m_l_ref;
   LdltStats* cur = m_stats.p + static_cast<size_t>(parity) * m_batch;
   LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1) * m_batch;
-  for (int r = 0; r < l.n_rounds; ++r) {
-    const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
-                       m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_h_reg, m_Lx.p,
-                       static_cast<long long>(std::max<int64_t>(1, l.nnzL)), m_D.p, l.n,
-                       m_contrib.p, static_cast<int>(std::max<uint32_t>(1, l.n_contrib)), cur,
-                       r == 0 ? next : nullptr, m_rhs.p, m_zv.p);
+  const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
+  const int cs = static_cast<int>(std::max<uint32_t>(1, l.n_contrib));
+  if (m_single_launch) {
+    // every round in one launch; tasks wait on device-side round counters
+    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
+                       dim3(256), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
+                       m_h_reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
+                       m_fround_cnt.p);
+  } else {
+    for (int r = 0; r < l.n_rounds; ++r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
+                         m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_h_reg, m_Lx.p, lxs, m_D.p,
+                         l.n, m_contrib.p, cs, cur, r == 0 ? next : nullptr, m_rhs.p, m_zv.p,
+                         static_cast<unsigned int*>(nullptr));
+    }
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }
@@ -584,9 +607,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
     }
     enqueue_factor(m_stats_cur, cap);
     solve_after_factor();
-    backsub();
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_h_stats, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch,
-                                  m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, cap));
+    backsub_and_publish(m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
     m_stream = saved;
     hipGraph_t graph = nullptr;
     SLPX_HIP_CHECK(hipStreamEndCapture(cap, &graph));
@@ -617,18 +638,29 @@ void DeviceNlp::solve() {
 void DeviceNlp::solve_after_factor() {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
-  for (int r = l.n_rounds - 1; r >= 0; --r) {
-    const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+  if (m_single_launch) {
+    const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
     hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
-                       m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p);
+                       m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p, m_bround_cnt.p);
+  } else {
+    for (int r = l.n_rounds - 1; r >= 0; --r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
+                         m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p,
+                         static_cast<unsigned int*>(nullptr));
+    }
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
-void DeviceNlp::backsub() {
-  if (m_kdev.m_i == 0) return;
-  hipLaunchKernelGGL(step_backsub_kernel, dim3(grid_for(m_kdev.m_i, 256), m_batch), dim3(256), 0,
-                     m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p, m_ps.p, m_pz.p);
+void DeviceNlp::backsub() { backsub_and_publish(nullptr); }
+
+// stats_src != nullptr: also copy those counters to the pinned host buffer
+void DeviceNlp::backsub_and_publish(const LdltStats* stats_src) {
+  if (m_kdev.m_i == 0 && stats_src == nullptr) return;
+  hipLaunchKernelGGL(step_backsub_kernel, dim3(grid_for(std::max(1, m_kdev.m_i), 256), m_batch),
+                     dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p,
+                     m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

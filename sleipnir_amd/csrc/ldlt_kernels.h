@@ -32,8 +32,61 @@ __device__ unsigned int g_ldlt_clock_round;  // which round's launch records
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && t.round == g_ldlt_clock_round) \
   g_ldlt_clocks[k] = wall_clock64()
 
-// Sum over the 8 lanes of an aligned lane group.
-// DPP register moves (no LDS crossbar trip, unlike __shfl_xor's ds_bpermute): mirror
+// ---------------------------------------------------------------------------
+// Rounds inside ONE launch.  A task of round r needs what the tasks of earlier rounds
+// wrote (contribution slots; finished x of ancestors in the backward solve).  Instead of
+// a kernel boundary per round, tasks of every round are dispatched together and a task
+// waits on a per-problem counter of finished tasks of the previous round.  Tasks are
+// sorted by round and workgroups are dispatched in index order, so whatever a waiting
+// workgroup depends on is already running or finished — it cannot starve them.  A (never
+// expected) time-out marks the factorization bad instead of hanging the GPU.
+// Measured at cart-pole N=1000: factorization 80 -> 66 us, backward solve 36 -> 33 us.
+// ---------------------------------------------------------------------------
+// Values that cross workgroups INSIDE a launch (update blocks, finished x of ancestor tasks)
+// are moved with agent-scope relaxed atomics: they bypass the non-coherent cache levels, so
+// the round hand-over needs no L2 write-back / invalidate (an agent-scope fence does both to
+// the whole XCD L2 and slows every workgroup on it: measured 29 -> 76 us for the backward
+// solve).
+__device__ __forceinline__ double coherent_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void round_wait(const unsigned int* cnt, unsigned int target,
+                                           LdltStats* stats_b) {
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) {
+        if (stats_b != nullptr) atomicAdd(&stats_b->n_bad, 1 << 20);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+// `final_target` != 0 marks the round nobody waits for; its last finisher knows every wait
+// of the launch is over and clears the problem's counters for the next launch.
+__device__ __forceinline__ void round_signal(unsigned int* cnt_base, int round, int n_rounds,
+                                             unsigned int final_target) {
+  // every lane's coherent stores have left the CU before the barrier (workgroup-scope
+  // release = wait for the outstanding stores, no cache maintenance)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(&cnt_base[round], 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+    if (final_target != 0 && old + 1 == final_target)
+      for (int r = 0; r < n_rounds; ++r)
+        __hip_atomic_store(&cnt_base[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Sum over the 8 lanes of an aligned lane group with DPP register moves (no LDS crossbar
+// trip, unlike __shfl_xor's ds_bpermute): mirror
 // within the 8-lane half row, then the two quad permutes.  Lane 0 of the group (and in
 // fact every lane) ends up with the group total.
 template <int kCtrl>
@@ -64,7 +117,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
-    const double* __restrict__ rhs, double* __restrict__ zv) {
+    const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LdltTask t = L.tasks[task_base + blockIdx.x];
   const int b = blockIdx.y;
@@ -142,6 +195,11 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     for (; i < t.n_ent; i += 256) U[i] = fetch(i);
   }
   __syncthreads();
+  // everything above only needed static data and the assembled matrix; the update blocks
+  // come from the tasks of earlier rounds
+  if (round_cnt != nullptr && t.round > 0)
+    round_wait(&round_cnt[b * L.n_rounds + t.round - 1],
+               L.round_ptr[t.round] - L.round_ptr[t.round - 1], &stats[b]);
   // regularization + update blocks of child tasks (few entries have any)
   {
     const uint32_t* cidx = L.contrib_idx + t.contrib_off;
@@ -151,7 +209,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       if (!(fl & 1) && cb == ce) continue;
       double acc = U[i];
       if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-      for (uint32_t c = cb; c < ce; ++c) acc -= contrib[cidx[c]];
+      for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]]);
       U[i] = acc;
     }
   }
@@ -197,7 +255,13 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       partial += (U[pr.x & 0xffffu] * invd[pr.y & 0xffffu]) * U[pr.x >> 16];
     }
     partial = group8_sum(partial);
-    if (lane8 == 0) contrib[L.ext_dst[t.ext_off + x]] = partial;
+    if (lane8 == 0) coherent_store(&contrib[L.ext_dst[t.ext_off + x]], partial);
+  }
+  // the next round only waits for the update blocks, not for L and D going out
+  if (round_cnt != nullptr) {
+    const int last = L.n_rounds - 1;
+    round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
+                 static_cast<int>(t.round) == last ? L.round_ptr[last + 1] - L.round_ptr[last] : 0u);
   }
 
   SLPX_LDLT_CLOCK(4);
@@ -333,9 +397,11 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
-    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out) {
+    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out,
+    unsigned int* __restrict__ round_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
+  // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
+  const LdltTask t = L.tasks[round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   Lx += static_cast<size_t>(b) * lx_stride;
@@ -364,12 +430,16 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   __syncthreads();
   SLPX_LDLT_CLOCK(17);
+  // rows owned by ancestor tasks (later rounds) must be final before they are gathered
+  if (round_cnt != nullptr && static_cast<int>(t.round) + 1 < L.n_rounds)
+    round_wait(&round_cnt[b * L.n_rounds + t.round + 1],
+               L.round_ptr[t.round + 2] - L.round_ptr[t.round + 1], nullptr);
   {
     auto load_item = [&](uint32_t q, double& v, uint32_t& r) {
       const uint2 it = items[q];
       const double lv = Lx[it.x];
       if (it.y & 0x80000000u) {
-        v = lv * xg[it.y & 0x7fffffffu];
+        v = lv * coherent_load(&xg[it.y & 0x7fffffffu]);
         r = t.n_col;
       } else {
         v = lv;
@@ -425,9 +495,12 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   SLPX_LDLT_CLOCK(19);
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
-    xg[pj] = x[i];
+    coherent_store(&xg[pj], x[i]);
     out[L.perm[pj]] = x[i];
   }
+  if (round_cnt != nullptr)
+    round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
+                 t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
   SLPX_LDLT_CLOCK(20);
 }
 

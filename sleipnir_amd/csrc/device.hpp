@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -89,6 +90,16 @@ struct TapeDevice {
   uint32_t small_lds = 0, large_lds = 0;
   uint64_t scratch_doubles = 0;
   bool basic_ops = false;
+  // Template groups served by run-time generated lane-per-task kernels (tape_jit.hpp);
+  // their tasks are NOT in the small/large lists above.
+  struct Template {
+    hipFunction_t fn = nullptr;
+    DevBuf<uint32_t> inst;  // (leaf_off, vout_off, jout_off) per instance
+    uint32_t n_inst = 0;
+  };
+  std::vector<std::unique_ptr<Template>> templates;
+  uint32_t n_templated_tasks = 0;
+  double jit_seconds = 0.0;
   void upload(const TapeProgram& p);
   TapeDev view() const;
 };

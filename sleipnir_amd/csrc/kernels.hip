@@ -18,6 +18,7 @@
 
 #include "device.hpp"
 #include "ldlt_kernels.h"
+#include "tape_jit.hpp"
 #include "tape_kernels.h"
 #include "tape_ops.h"
 
@@ -183,8 +184,36 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
 
 void TapeDevice::upload(const TapeProgram& p) {
   tasks.upload(p.tasks);
-  small_list.upload(p.small_tasks);
-  large_list.upload(p.large_tasks);
+  // template groups (>= 32 structurally identical tasks) get a generated lane-per-task
+  // kernel; everything else is interpreted
+  const TapeJitResult jit = build_tape_templates(p, 32);
+  jit_seconds = jit.compile_seconds;
+  templates.clear();
+  n_templated_tasks = 0;
+  for (const TapeTemplateGroup& g : jit.groups) {
+    auto tp = std::make_unique<Template>();
+    tp->fn = g.fn;
+    tp->n_inst = static_cast<uint32_t>(g.tasks.size());
+    std::vector<uint32_t> inst;
+    inst.reserve(3 * g.tasks.size());
+    for (uint32_t ti : g.tasks) {
+      inst.push_back(p.tasks[ti].leaf_off);
+      inst.push_back(p.tasks[ti].vout_off);
+      inst.push_back(p.tasks[ti].jout_off);
+    }
+    tp->inst.upload(inst);
+    n_templated_tasks += tp->n_inst;
+    templates.push_back(std::move(tp));
+  }
+  auto interpreted = [&](const std::vector<uint32_t>& list) {
+    std::vector<uint32_t> out;
+    for (uint32_t ti : list)
+      if (!jit.task_is_templated[ti]) out.push_back(ti);
+    return out;
+  };
+  const std::vector<uint32_t> small_rest = interpreted(p.small_tasks), large_rest = interpreted(p.large_tasks);
+  small_list.upload(small_rest);
+  large_list.upload(large_rest);
   global_list.upload(p.global_tasks);
   leaf_src.upload(p.leaf_src);
   consts.upload(p.consts);
@@ -202,8 +231,8 @@ void TapeDevice::upload(const TapeProgram& p) {
   node_rec16.upload(p.node_rec16);
   slot_edge_ptr16.upload(p.slot_edge_ptr16);
   edges16.upload(p.edges16);
-  n_small = static_cast<uint32_t>(p.small_tasks.size());
-  n_large = static_cast<uint32_t>(p.large_tasks.size());
+  n_small = static_cast<uint32_t>(small_rest.size());
+  n_large = static_cast<uint32_t>(large_rest.size());
   n_global = static_cast<uint32_t>(p.global_tasks.size());
   small_lds = p.small_lds_bytes;
   large_lds = p.large_lds_bytes;
@@ -419,6 +448,28 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
   const unsigned long long sstride = m_scratch.n / m_batch;
   // basic_ops: the program only uses + - * / sin cos sqrt and the piecewise ops, so
   // the kernel specialization without pow/exp/log/erf/... (fewer VGPRs, less code)
+  // generated template kernels: one lane per task instance (tape_jit.hpp)
+  for (const auto& tp : t.templates) {
+    const unsigned* inst = tp->inst.p;
+    int n_inst = static_cast<int>(tp->n_inst);
+    const unsigned* leaf_src = view.leaf_src;
+    const double* consts = view.consts;
+    const double* in = m_in.p;
+    int in_stride_arg = in_stride;
+    const double* in_scale = m_in_scale.p;
+    const double* scales = m_scales.p;
+    double* V = m_V.p;
+    int v_stride_arg = v_stride;
+    const unsigned* vout_dst = view.vout_dst;
+    const int* vout_scale = view.vout_scale;
+    const unsigned* jout_dst = view.jout_dst;
+    const int* jout_scale = view.jout_scale;
+    int rev = reverse ? 1 : 0;
+    void* args[] = {&inst,  &n_inst,      &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale, &scales,
+                    &V,     &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale,    &rev};
+    SLPX_HIP_CHECK(hipModuleLaunchKernel(tp->fn, (tp->n_inst + 63) / 64, m_batch, 1, 64, 1, 1, 0,
+                                         small_stream, args, nullptr));
+  }
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;
   if (t.n_small)

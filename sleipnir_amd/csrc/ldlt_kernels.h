@@ -72,9 +72,11 @@ __device__ __forceinline__ void round_wait(const unsigned int* cnt, unsigned int
 // of the launch is over and clears the problem's counters for the next launch.
 __device__ __forceinline__ void round_signal(unsigned int* cnt_base, int round, int n_rounds,
                                              unsigned int final_target) {
-  // every lane's coherent stores have left the CU before the barrier (workgroup-scope
-  // release = wait for the outstanding stores, no cache maintenance)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // Every lane's coherent (write-through) stores must be ACKNOWLEDGED before lane 0 bumps
+  // the counter.  A workgroup-scope release fence does not guarantee that here (waves of a
+  // workgroup share the CU's L1, so the compiler need not drain vmcnt for it) and an
+  // agent-scope one adds an L2 write-back; the explicit wait is exactly what is needed.
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int old = __hip_atomic_fetch_add(&cnt_base[round], 1u, __ATOMIC_RELAXED,

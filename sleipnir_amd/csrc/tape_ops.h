@@ -15,10 +15,17 @@
 // cos/sin/pow per row as the reference does, expression_graph.hpp:138-142).
 #pragma once
 
+// This header is also compiled at run time by hipRTC as the prelude of the generated
+// per-template tape kernels (tape_jit.cpp), where the HIP runtime and math declarations are
+// built in and no standard headers exist.
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
+#else
+typedef unsigned char uint8_t;
+#endif
 
 #define SLPX_HD __host__ __device__ __forceinline__
 

@@ -96,6 +96,7 @@ struct TapeDevice {
     hipFunction_t fn = nullptr;
     DevBuf<uint32_t> inst;  // (leaf_off, vout_off, jout_off) per instance
     uint32_t n_inst = 0;
+    uint32_t n_groups = 1;
   };
   std::vector<std::unique_ptr<Template>> templates;
   uint32_t n_templated_tasks = 0;

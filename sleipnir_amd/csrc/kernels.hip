@@ -194,6 +194,7 @@ void TapeDevice::upload(const TapeProgram& p) {
     auto tp = std::make_unique<Template>();
     tp->fn = g.fn;
     tp->n_inst = static_cast<uint32_t>(g.tasks.size());
+    tp->n_groups = g.n_groups;
     std::vector<uint32_t> inst;
     inst.reserve(3 * g.tasks.size());
     for (uint32_t ti : g.tasks) {
@@ -464,11 +465,12 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const int* vout_scale = view.vout_scale;
     const unsigned* jout_dst = view.jout_dst;
     const int* jout_scale = view.jout_scale;
-    int rev = reverse ? 1 : 0;
+    // adjoint rows are split into wave-uniform groups (0 = values only)
+    int n_groups = reverse ? static_cast<int>(tp->n_groups) : 0;
     void* args[] = {&inst,  &n_inst,      &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale, &scales,
-                    &V,     &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale,    &rev};
-    SLPX_HIP_CHECK(hipModuleLaunchKernel(tp->fn, (tp->n_inst + 63) / 64, m_batch, 1, 64, 1, 1, 0,
-                                         small_stream, args, nullptr));
+                    &V,     &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale,    &n_groups};
+    SLPX_HIP_CHECK(hipModuleLaunchKernel(tp->fn, ((tp->n_inst + 63) / 64) * std::max(1, n_groups), m_batch,
+                                         1, 64, 1, 1, 0, small_stream, args, nullptr));
   }
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;

@@ -32,6 +32,7 @@ struct TapeTemplateGroup {
   std::vector<uint32_t> tasks;   // instances
   hipFunction_t fn = nullptr;    // extern "C" slpx_tape_template(...)
   uint32_t n_leaf = 0, n_node = 0, n_slot = 0;
+  uint32_t n_groups = 1;         // row groups of the adjoint part (see tape_jit.cpp)
 };
 
 struct TapeJitResult {
@@ -46,6 +47,9 @@ struct TapeJitResult {
 // kernel per group.  Never throws: on any hipRTC problem the group is simply left to the
 // interpreter and the reason is put in `log`.
 TapeJitResult build_tape_templates(const TapeProgram& prog, uint32_t min_instances);
+
+// Number of wave-uniform row groups the adjoint part of a template is split into.
+uint32_t template_row_groups(const TapeProgram& prog, const TapeTask& representative);
 
 // The generated source of one template (exposed for tests / inspection).
 std::string generate_template_source(const TapeProgram& prog, const TapeTask& representative);

@@ -267,6 +267,7 @@ class DeviceNlp {
       m_pz, m_D, m_Lx, m_contrib, m_scontrib, m_zv, m_xg, m_scratch;
   DevBuf<LdltStats> m_stats;  // 2 x batch, double-buffered per factorization attempt
   int m_stats_cur = 0;
+  DevBuf<double> m_reg_dev;           // device copy of m_h_reg for big batches
   double* m_h_reg = nullptr;          // pinned, read by the kernels: (delta, gamma) per problem;
                                       // delta = NaN: skip the problem
   LdltStats* m_h_stats = nullptr;     // pinned read-back

@@ -336,6 +336,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_fround_cnt.upload(zero);
     m_bround_cnt.upload(zero);
   }
+  // Rounds in one launch pay off while every task of the launch is resident at once (a
+  // single problem: 137 tasks on 256 CUs).  With a batch the later-round workgroups would
+  // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
+  // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
+  m_single_launch = static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
 
   const size_t B = static_cast<size_t>(batch);
@@ -363,6 +368,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_stats.upload(zero);
   }
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
+  if (B > 8) m_reg_dev.alloc(2 * B);
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
@@ -465,8 +471,12 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const int* vout_scale = view.vout_scale;
     const unsigned* jout_dst = view.jout_dst;
     const int* jout_scale = view.jout_scale;
-    // adjoint rows are split into wave-uniform groups (0 = values only)
-    int n_groups = reverse ? static_cast<int>(tp->n_groups) : 0;
+    // Adjoint rows are split into wave-uniform groups (0 = values only) while the launch
+    // would otherwise leave most SIMDs idle; with enough instances x batch items every lane
+    // runs all groups (-1) and the forward part is not recomputed per group.
+    const int waves = static_cast<int>((tp->n_inst + 63) / 64) * m_batch;
+    const bool split = waves < 512 && tp->n_groups > 1;
+    int n_groups = reverse ? (split ? static_cast<int>(tp->n_groups) : -1) : 0;
     void* args[] = {&inst,  &n_inst,      &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale, &scales,
                     &V,     &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale,    &n_groups};
     SLPX_HIP_CHECK(hipModuleLaunchKernel(tp->fn, ((tp->n_inst + 63) / 64) * std::max(1, n_groups), m_batch,
@@ -563,17 +573,25 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1) * m_batch;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   const int cs = static_cast<int>(std::max<uint32_t>(1, l.n_contrib));
+  // a handful of workgroups read (δ, γ) straight from pinned host memory; the tens of
+  // thousands of a big batch would each pay a PCIe round trip, so those get a device copy
+  const double* reg = m_h_reg;
+  if (m_batch > 8) {
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_reg_dev.p, m_h_reg, 2 * static_cast<size_t>(m_batch) * sizeof(double),
+                                  hipMemcpyHostToDevice, stream));
+    reg = m_reg_dev.p;
+  }
   if (m_single_launch) {
     // every round in one launch; tasks wait on device-side round counters
     hipLaunchKernelGGL(ldlt_factor_kernel, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
                        dim3(256), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
-                       m_h_reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
+                       reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
                        m_fround_cnt.p);
   } else {
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
-                         m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, m_h_reg, m_Lx.p, lxs, m_D.p,
+                         m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, reg, m_Lx.p, lxs, m_D.p,
                          l.n, m_contrib.p, cs, cur, r == 0 ? next : nullptr, m_rhs.p, m_zv.p,
                          static_cast<unsigned int*>(nullptr));
     }

@@ -47,11 +47,14 @@ __device__ unsigned int g_ldlt_clock_round;  // which round's launch records
 // the round hand-over needs no L2 write-back / invalidate (an agent-scope fence does both to
 // the whole XCD L2 and slows every workgroup on it: measured 29 -> 76 us for the backward
 // solve).
-__device__ __forceinline__ double coherent_load(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// (`in_launch` false = one launch per round: the kernel boundary orders everything and the
+// plain cached accesses are used.)
+__device__ __forceinline__ double coherent_load(const double* p, bool in_launch) {
+  return in_launch ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
-__device__ __forceinline__ void coherent_store(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void coherent_store(double* p, double v, bool in_launch) {
+  if (in_launch) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }
 
 __device__ __forceinline__ void round_wait(const unsigned int* cnt, unsigned int target,
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       if (!(fl & 1) && cb == ce) continue;
       double acc = U[i];
       if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-      for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]]);
+      for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]], round_cnt != nullptr);
       U[i] = acc;
     }
   }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       partial += (U[pr.x & 0xffffu] * invd[pr.y & 0xffffu]) * U[pr.x >> 16];
     }
     partial = group8_sum(partial);
-    if (lane8 == 0) coherent_store(&contrib[L.ext_dst[t.ext_off + x]], partial);
+    if (lane8 == 0) coherent_store(&contrib[L.ext_dst[t.ext_off + x]], partial, round_cnt != nullptr);
   }
   // the next round only waits for the update blocks, not for L and D going out
   if (round_cnt != nullptr) {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
       const uint2 it = items[q];
       const double lv = Lx[it.x];
       if (it.y & 0x80000000u) {
-        v = lv * coherent_load(&xg[it.y & 0x7fffffffu]);
+        v = lv * coherent_load(&xg[it.y & 0x7fffffffu], round_cnt != nullptr);
         r = t.n_col;
       } else {
         v = lv;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   SLPX_LDLT_CLOCK(19);
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
-    coherent_store(&xg[pj], x[i]);
+    coherent_store(&xg[pj], x[i], round_cnt != nullptr);
     out[L.perm[pj]] = x[i];
   }
   if (round_cnt != nullptr)

@@ -22,7 +22,12 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     for (int p = m_k.lhs.colptr[c]; p < m_k.lhs.colptr[c + 1]; ++p)
       if (m_k.lhs.rowidx[p] == c)
         diag_has_source[c] = (m_k.dptr[p + 1] > m_k.dptr[p]) || (m_k.pptr[p + 1] > m_k.pptr[p]);
-  m_l = build_ldlt_plan(m_k.lhs, m_s.n, opt.ldlt, user_perm, &diag_has_source);
+  // One problem: big tasks = few rounds and levels (latency).  A batch is throughput bound
+  // by how many tasks fit a CU's LDS at once: half-size tasks (~30 KB instead of ~60 KB)
+  // put five instead of two workgroups on a CU and have fewer levels each.
+  LdltOptions lopt = opt.ldlt;
+  if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
+  m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
   reset_regularization();
 }

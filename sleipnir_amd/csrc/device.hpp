@@ -247,6 +247,7 @@ class DeviceNlp {
   hipStream_t m_stream = nullptr;
 
   TapeDevice m_full, m_values;
+  DevBuf<NlpStructure::SumReduce> m_reduces;
   // KKT plan
   DevBuf<int32_t> m_dptr, m_dsrc, m_pptr, m_pa, m_pb, m_pr, m_gsrc, m_ae_colptr, m_ae_rowidx,
       m_ai_colptr, m_ai_rowidx, m_ai_rowptr, m_ai_col, m_ai_src, m_diag_pos, m_fast_src;

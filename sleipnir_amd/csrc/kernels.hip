@@ -178,6 +178,26 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
   }
 }
 
+// Separable sums (nlp.cpp): V[dst] = scale * (sum of the partials the tape tasks left in the
+// hidden tail of V), in a fixed order — strided per lane, then a pairwise tree.
+__global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::SumReduce* __restrict__ red,
+                                                         const double* __restrict__ scales,
+                                                         double* __restrict__ V, int v_stride) {
+  __shared__ double part[64];
+  const NlpStructure::SumReduce r = red[blockIdx.x];
+  V += static_cast<size_t>(blockIdx.y) * v_stride;
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
+  part[tid] = acc;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (tid < w) part[tid] += part[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) V[r.dst] = (r.scale_idx >= 0 ? scales[r.scale_idx] : 1.0) * part[0];
+}
+
 // ============================================================================
 // DeviceNlp
 // ============================================================================
@@ -258,6 +278,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 
   m_full.upload(s.full);
   m_values.upload(s.values);
+  m_reduces.upload(s.reduces);
   // allow > 64 KB dynamic LDS
   for (const void* fn : {reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, true>),
                          reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, false>),
@@ -496,6 +517,9 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, other,
                        view, t.global_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p,
                        v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
+  if (m_reduces.n)
+    hipLaunchKernelGGL(tape_reduce_kernel, dim3(static_cast<uint32_t>(m_reduces.n), m_batch), dim3(64), 0,
+                       small_stream, m_reduces.p, m_scales.p, m_V.p, v_stride);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

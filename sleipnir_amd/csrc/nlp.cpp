@@ -1,5 +1,7 @@
 #include "nlp.hpp"
 
+#include <unordered_map>
+
 #include <algorithm>
 #include <functional>
 #include <stdexcept>
@@ -218,6 +220,107 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   add_matrix(mAi, c_i, s.off_Ai, [m_e](int32_t r) { return 1 + m_e + r; });
   add_matrix(mHf, Hf_rows, s.off_Hf, [](int32_t) { return 0; });
   add_matrix(mHc, Hc_rows, s.off_Hc, [](int32_t) { return -1; });
+
+  // ---- long separable sums ----------------------------------------------------------
+  // A cost like sum_k u_k^2 is ONE connected component (its ADD tree) however independent
+  // its terms are: at N=1000 a 152 KB-LDS task, at N=5000 one that only fits in HBM scratch,
+  // both on the critical path of every sweep.  When the terms of the sum touch disjoint
+  // sets of decision variables the sum is cut into groups of consecutive terms: every group
+  // becomes a small component of its own (a template group, usually) that writes its partial
+  // sum into a hidden tail of V and differentiates ITS terms (d f / d partial = 1), and a
+  // tiny reduce kernel adds the partials in a fixed order.
+  if (f_in != kNull && opt.split_sum_min_terms > 0) {
+    std::vector<int32_t> uses(g.size(), 0);
+    for (size_t k = 0; k < g.size(); ++k) {
+      if (g.a0[k] != kNull) ++uses[g.a0[k]];
+      if (g.a1[k] != kNull) ++uses[g.a1[k]];
+    }
+    std::vector<NodeId> terms;
+    NodeId cur = f;
+    while (g.op[cur] == OP_ADD && (cur == f || uses[cur] == 1)) {
+      terms.push_back(g.a1[cur]);
+      cur = g.a0[cur];
+    }
+    terms.push_back(cur);
+    std::reverse(terms.begin(), terms.end());
+    if (terms.size() >= opt.split_sum_min_terms) {
+      std::unordered_map<NodeId, int32_t> xindex;
+      for (int i = 0; i < n; ++i) xindex.emplace(x[i], i);
+      const size_t gs = opt.split_sum_group;
+      const size_t G = (terms.size() + gs - 1) / gs;
+      std::vector<int32_t> group_of_var(n, -1);
+      std::vector<int32_t> stamp(g.size(), -1);
+      bool separable = true;
+      std::vector<NodeId> stack;
+      for (size_t t = 0; t < terms.size() && separable; ++t) {
+        const int32_t grp = static_cast<int32_t>(t / gs);
+        stack.assign(1, terms[t]);
+        while (!stack.empty() && separable) {
+          const NodeId v = stack.back();
+          stack.pop_back();
+          if (stamp[v] == static_cast<int32_t>(t)) continue;
+          stamp[v] = static_cast<int32_t>(t);
+          auto it = xindex.find(v);
+          if (it != xindex.end()) {
+            if (group_of_var[it->second] >= 0 && group_of_var[it->second] != grp) separable = false;
+            group_of_var[it->second] = grp;
+          }
+          if (g.a0[v] != kNull) stack.push_back(g.a0[v]);
+          if (g.a1[v] != kNull) stack.push_back(g.a1[v]);
+        }
+      }
+      if (separable) {
+        std::vector<NodeId> partial(G);
+        for (size_t j = 0; j < G; ++j) {
+          std::vector<NodeId> level(terms.begin() + j * gs, terms.begin() + std::min(terms.size(), (j + 1) * gs));
+          while (level.size() > 1) {  // pairwise tree, left-to-right term order
+            std::vector<NodeId> next;
+            for (size_t k = 0; k + 1 < level.size(); k += 2) next.push_back(g.add(level[k], level[k + 1]));
+            if (level.size() & 1) next.push_back(level.back());
+            level.swap(next);
+          }
+          partial[j] = level[0];
+        }
+        const int32_t off_part = s.nV;
+        s.nV += static_cast<int>(G);
+        s.V_static_raw.resize(s.nV, 0.0);
+        s.V_scale_idx.resize(s.nV, -1);
+        s.V_is_static.resize(s.nV, 0);
+        s.reduces.push_back({s.off_f, 0, off_part, static_cast<int32_t>(G)});
+        std::vector<TapeValueOut> v2;
+        for (auto& v : live_vouts)
+          if (v.node != f) v2.push_back(v);
+        for (size_t j = 0; j < G; ++j) {
+          if (g.type[partial[j]] == T_CONSTANT) {
+            s.V_static_raw[off_part + j] = g.val[partial[j]];
+            s.V_is_static[off_part + j] = 1;
+          } else {
+            v2.push_back({partial[j], off_part + static_cast<int32_t>(j), -1});
+          }
+        }
+        live_vouts.swap(v2);
+        std::vector<TapeRow> r2;
+        for (auto& row : rows) {
+          if (row.root != f) {
+            r2.push_back(std::move(row));
+            continue;
+          }
+          std::vector<TapeRow> parts(G);
+          for (auto& o : row.outputs) {
+            const int32_t grp = group_of_var[xindex.at(o.wrt)];
+            if (grp >= 0) parts[grp].outputs.push_back(o);
+          }
+          for (size_t j = 0; j < G; ++j) {
+            if (parts[j].outputs.empty()) continue;
+            parts[j].root = partial[j];
+            parts[j].scale_idx = row.scale_idx;
+            r2.push_back(std::move(parts[j]));
+          }
+        }
+        rows.swap(r2);
+      }
+    }
+  }
 
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);
   s.values = compile_tape(g, inputs, live_vouts, {}, opt);

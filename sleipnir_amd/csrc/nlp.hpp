@@ -35,6 +35,13 @@ struct NlpStructure {
   std::vector<int32_t> V_scale_idx;  // scale index of every V entry (-1 = none)
   std::vector<uint8_t> V_is_static;  // 1 = never written by the tape
   TapeProgram full, values;
+  // Separable sums cut into partial sums (nlp.cpp): V[dst] = scale[scale_idx] * sum of the
+  // `count` partials stored in the hidden tail of V starting at src_off; executed by
+  // tape_reduce_kernel after every sweep.
+  struct SumReduce {
+    int32_t dst, scale_idx, src_off, count;
+  };
+  std::vector<SumReduce> reduces;
   // expression types (problem.hpp:236-263)
   uint8_t f_type = T_NONE, ce_type = T_NONE, ci_type = T_NONE;
   // leaf nodes created for the duals (problem.hpp:519-520)

@@ -352,6 +352,30 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
   };
   std::vector<Pack> packs;
   {
+    // Components that come in large families of the same shape (the stages of a
+    // transcribed OCP, the term groups of a separable cost) get a task EACH: identical
+    // tasks share one program copy and run as instances of one generated template kernel
+    // (tape_jit.hpp); bin-packing them together would destroy exactly that regularity.
+    std::unordered_map<uint64_t, uint32_t> family;
+    std::vector<uint64_t> signature(ncomp);
+    for (size_t c = 0; c < ncomp; ++c) {
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+      mix(comp_nodes[c].size());
+      mix(comp_slots[c].size());
+      mix(comp_vouts[c].size());
+      size_t edges = 0;
+      for (int32_t sl : comp_slots[c]) edges += slot_edges[sl].size();
+      mix(edges);
+      uint64_t ops = 0;
+      for (int32_t nd : comp_nodes[c]) ops += static_cast<uint64_t>(cg.op[nd]) * 131u + static_cast<uint64_t>(level[nd]);
+      mix(ops);
+      signature[c] = h;
+      ++family[h];
+    }
+    // the estimate of comp_cost ignores padding and shared-leaf effects: keep a margin so a
+    // packed task does not spill into the (slower, 256-thread) large class by accident
+    const size_t pack_cap = small_cap - small_cap / 8;
     Pack cur;
     for (size_t c = 0; c < ncomp; ++c) {
       size_t le;
@@ -364,7 +388,14 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         packs.push_back(std::move(big));
         continue;
       }
-      if (cur.cost + cost > small_cap && !cur.comps.empty()) {
+      if (family[signature[c]] >= 16 && comp_nodes[c].size() >= 16) {
+        Pack own;
+        own.comps.push_back(c);
+        own.cost = cost;
+        packs.push_back(std::move(own));
+        continue;
+      }
+      if (cur.cost + cost > pack_cap && !cur.comps.empty()) {
         packs.push_back(std::move(cur));
         cur = Pack{};
       }

@@ -118,6 +118,10 @@ struct TapeCompileOptions {
   uint32_t large_lds_bytes = 152 * 1024;  // 256-thread workgroups, one per CU
   bool rebalance_sums = true;
   uint32_t rebalance_min_terms = 8;
+  // separable cost sums (nlp.cpp): cut into groups of `split_sum_group` terms when the sum
+  // has at least `split_sum_min_terms` terms (0 = never)
+  uint32_t split_sum_min_terms = 64;
+  uint32_t split_sum_group = 32;
 };
 
 // `inputs`: leaf VAR node -> input vector index (nodes absent from the map must

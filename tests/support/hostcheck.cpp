@@ -216,6 +216,12 @@ void hc_sweep(hc_handle* h, const double* x, const double* y, const double* z, i
   if (y) std::copy(y, y + s.m_e, in.begin() + s.n);
   if (z) std::copy(z, z + s.m_i, in.begin() + s.n + s.m_e);
   run_tape(full ? s.full : s.values, in, h->in_scale, h->scales, h->V, full != 0);
+  // separable sums: V[dst] = scale * sum of the partials (nlp.cpp, tape_reduce_kernel)
+  for (const auto& r : s.reduces) {
+    double acc = 0.0;
+    for (int k = 0; k < r.count; ++k) acc += h->V[r.src_off + k];
+    h->V[r.dst] = (r.scale_idx >= 0 ? h->scales[r.scale_idx] : 1.0) * acc;
+  }
   if (V_out) std::copy(h->V.begin(), h->V.end(), V_out);
 }
 

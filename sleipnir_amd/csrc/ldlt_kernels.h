@@ -90,6 +90,18 @@ __device__ __forceinline__ void round_signal(unsigned int* cnt_base, int round, 
   }
 }
 
+// 1/d on the critical path of every level: hardware estimate + two Newton steps (full
+// double precision for normal inputs; 0 -> inf and inf -> 0 like the division) instead of
+// the ~15-instruction IEEE division sequence with its scale/fixup steps.
+__device__ __forceinline__ double fast_reciprocal(double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r0, 1.0);
+  double r = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return (r0 != 0.0 && isfinite(r0)) ? r : r0;  // d = 0, inf, nan: the estimate is the answer
+}
+
 // Sum over the 8 lanes of an aligned lane group with DPP register moves (no LDS crossbar
 // trip, unlike __shfl_xor's ds_bpermute): mirror
 // within the 8-lane half row, then the two quad permutes.  Lane 0 of the group (and in
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
         if (lane8 == 0) {
           const double u = u_old - partial;
           U[i] = u;
-          if (fl & 1) invd[cj] = 1.0 / u;
+          if (fl & 1) invd[cj] = fast_reciprocal(u);
         }
       }
       __syncthreads();

@@ -90,18 +90,18 @@ struct TapeDevice {
   uint32_t small_lds = 0, large_lds = 0;
   uint64_t scratch_doubles = 0;
   bool basic_ops = false;
-  // Template groups served by run-time generated lane-per-task kernels (tape_jit.hpp);
-  // their tasks are NOT in the small/large lists above.
-  struct Template {
-    hipFunction_t fn = nullptr;
-    DevBuf<uint32_t> inst;  // (leaf_off, vout_off, jout_off) per instance
-    uint32_t n_inst = 0;
-    uint32_t n_groups = 1;
-  };
-  std::vector<std::unique_ptr<Template>> templates;
+  // Tasks served by the run-time generated lane-per-task kernel (tape_jit.hpp); they are
+  // NOT in the small/large lists above.  One launch covers every body: `tmpl_table[mode]`
+  // (mode 0 = values only, 1 = with adjoints) holds (first block, instances, instance
+  // offset, row-group mode) per body, `tmpl_blocks[mode]` the grid size.
+  hipFunction_t tmpl_fn = nullptr;
+  uint32_t n_bodies = 0;
+  DevBuf<uint32_t> tmpl_inst;  // (leaf_off, vout_off, jout_off) per instance, bodies back to back
+  DevBuf<uint32_t> tmpl_table[2];
+  uint32_t tmpl_blocks[2] = {0, 0};
   uint32_t n_templated_tasks = 0;
   double jit_seconds = 0.0;
-  void upload(const TapeProgram& p);
+  void upload(const TapeProgram& p, int batch);
   TapeDev view() const;
 };
 

@@ -178,53 +178,57 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
   }
 }
 
-// Separable sums (nlp.cpp): V[dst] = scale * (sum of the partials the tape tasks left in the
-// hidden tail of V), in a fixed order — strided per lane, then a pairwise tree.
+// Separable sums on their own (tape_reduce_body, tape_kernels.h) — used when the reductions
+// cannot ride along with the interpreted tail of the tape (launch_tape).
 __global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::SumReduce* __restrict__ red,
                                                          const double* __restrict__ scales,
                                                          double* __restrict__ V, int v_stride) {
   __shared__ double part[64];
-  const NlpStructure::SumReduce r = red[blockIdx.x];
   V += static_cast<size_t>(blockIdx.y) * v_stride;
-  const int tid = threadIdx.x;
-  double acc = 0.0;
-  for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
-  part[tid] = acc;
-  __syncthreads();
-  for (int w = 32; w > 0; w >>= 1) {
-    if (tid < w) part[tid] += part[tid + w];
-    __syncthreads();
-  }
-  if (tid == 0) V[r.dst] = (r.scale_idx >= 0 ? scales[r.scale_idx] : 1.0) * part[0];
+  tape_reduce_body(red[blockIdx.x], scales, V, part, threadIdx.x);
 }
 
 // ============================================================================
 // DeviceNlp
 // ============================================================================
 
-void TapeDevice::upload(const TapeProgram& p) {
+void TapeDevice::upload(const TapeProgram& p, int batch) {
   tasks.upload(p.tasks);
-  // template groups (>= 32 structurally identical tasks) get a generated lane-per-task
-  // kernel; everything else is interpreted
-  const TapeJitResult jit = build_tape_templates(p, 32);
+  // families of structurally identical tasks and the big singles get a body in the
+  // generated lane-per-task kernel; everything else is interpreted
+  const TapeJitResult jit = build_tape_templates(p);
   jit_seconds = jit.compile_seconds;
-  templates.clear();
+  tmpl_fn = jit.fn;
+  n_bodies = static_cast<uint32_t>(jit.groups.size());
   n_templated_tasks = 0;
-  for (const TapeTemplateGroup& g : jit.groups) {
-    auto tp = std::make_unique<Template>();
-    tp->fn = g.fn;
-    tp->n_inst = static_cast<uint32_t>(g.tasks.size());
-    tp->n_groups = g.n_groups;
-    std::vector<uint32_t> inst;
-    inst.reserve(3 * g.tasks.size());
-    for (uint32_t ti : g.tasks) {
-      inst.push_back(p.tasks[ti].leaf_off);
-      inst.push_back(p.tasks[ti].vout_off);
-      inst.push_back(p.tasks[ti].jout_off);
+  tmpl_blocks[0] = tmpl_blocks[1] = 0;
+  if (n_bodies) {
+    std::vector<uint32_t> inst, table[2];
+    for (const TapeTemplateGroup& g : jit.groups) {
+      const uint32_t n_inst = static_cast<uint32_t>(g.tasks.size()), inst_off = static_cast<uint32_t>(inst.size() / 3);
+      for (uint32_t ti : g.tasks) {
+        inst.push_back(p.tasks[ti].leaf_off);
+        inst.push_back(p.tasks[ti].vout_off);
+        inst.push_back(p.tasks[ti].jout_off);
+      }
+      n_templated_tasks += n_inst;
+      // Adjoint rows are split into wave-uniform groups while the launch would otherwise
+      // leave most SIMDs idle; with enough instances x batch items every lane runs all
+      // groups (-1) and the forward part is not recomputed per group.
+      const uint32_t waves = (n_inst + 63) / 64;
+      const bool split = waves * static_cast<uint32_t>(batch) < 512 && g.n_groups > 1;
+      const int mode[2] = {0, split ? static_cast<int>(g.n_groups) : -1};
+      for (int m = 0; m < 2; ++m) {
+        table[m].push_back(tmpl_blocks[m]);
+        table[m].push_back(n_inst);
+        table[m].push_back(inst_off);
+        table[m].push_back(static_cast<uint32_t>(mode[m]));
+        tmpl_blocks[m] += waves * static_cast<uint32_t>(std::max(1, mode[m]));
+      }
     }
-    tp->inst.upload(inst);
-    n_templated_tasks += tp->n_inst;
-    templates.push_back(std::move(tp));
+    tmpl_inst.upload(inst);
+    tmpl_table[0].upload(table[0]);
+    tmpl_table[1].upload(table[1]);
   }
   auto interpreted = [&](const std::vector<uint32_t>& list) {
     std::vector<uint32_t> out;
@@ -276,8 +280,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     throw std::runtime_error("slpx: no HIP device available (the product path has no CPU fallback)");
   SLPX_HIP_CHECK(hipSetDevice(device));
 
-  m_full.upload(s.full);
-  m_values.upload(s.values);
+  m_full.upload(s.full, batch);
+  m_values.upload(s.values, batch);
   m_reduces.upload(s.reduces);
   // allow > 64 KB dynamic LDS
   for (const void* fn : {reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, true>),
@@ -477,9 +481,11 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
   // basic_ops: the program only uses + - * / sin cos sqrt and the piecewise ops, so
   // the kernel specialization without pow/exp/log/erf/... (fewer VGPRs, less code)
   // generated template kernels: one lane per task instance (tape_jit.hpp)
-  for (const auto& tp : t.templates) {
-    const unsigned* inst = tp->inst.p;
-    int n_inst = static_cast<int>(tp->n_inst);
+  if (t.n_bodies) {
+    const int mode = reverse ? 1 : 0;
+    const unsigned* table = t.tmpl_table[mode].p;
+    int n_bodies = static_cast<int>(t.n_bodies);
+    const unsigned* inst = t.tmpl_inst.p;
     const unsigned* leaf_src = view.leaf_src;
     const double* consts = view.consts;
     const double* in = m_in.p;
@@ -492,16 +498,10 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const int* vout_scale = view.vout_scale;
     const unsigned* jout_dst = view.jout_dst;
     const int* jout_scale = view.jout_scale;
-    // Adjoint rows are split into wave-uniform groups (0 = values only) while the launch
-    // would otherwise leave most SIMDs idle; with enough instances x batch items every lane
-    // runs all groups (-1) and the forward part is not recomputed per group.
-    const int waves = static_cast<int>((tp->n_inst + 63) / 64) * m_batch;
-    const bool split = waves < 512 && tp->n_groups > 1;
-    int n_groups = reverse ? (split ? static_cast<int>(tp->n_groups) : -1) : 0;
-    void* args[] = {&inst,  &n_inst,      &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale, &scales,
-                    &V,     &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale,    &n_groups};
-    SLPX_HIP_CHECK(hipModuleLaunchKernel(tp->fn, ((tp->n_inst + 63) / 64) * std::max(1, n_groups), m_batch,
-                                         1, 64, 1, 1, 0, small_stream, args, nullptr));
+    void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale,
+                    &scales, &V,        &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale};
+    SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, t.tmpl_blocks[mode], m_batch, 1, 64, 1, 1, 0, small_stream,
+                                         args, nullptr));
   }
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;

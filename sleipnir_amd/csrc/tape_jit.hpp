@@ -12,14 +12,17 @@
 // every node is the same `op_forward` (tape_ops.h, embedded as the prelude of the generated
 // source) the interpreting kernels call, in the same order.
 //
-// Tasks that are not part of a large enough template group (boundary stages, the cost row)
-// stay on the interpreting kernels (tape_kernels.h).  Disabled with SLPX_TAPE_JIT=0.
+// ALL templates of a program live in ONE generated kernel (a wave-uniform switch on the
+// block index picks the body), so the big family (the interior stages), the odd ones out
+// (first / last stage) and the small fry (cost groups, packed linear rows) run side by side
+// in a single launch instead of queueing behind each other.  Tasks left out (code-size cap,
+// node-less tasks) stay on the interpreting kernels (tape_kernels.h).  SLPX_TAPE_JIT=0
+// disables the whole mechanism.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <memory>
 #include <string>
 #include <vector>
 
@@ -27,31 +30,43 @@
 
 namespace slpx {
 
-// One generated kernel and the tasks (indices into TapeProgram::tasks) it serves.
+// One body of the generated kernel and the tasks (indices into TapeProgram::tasks) it serves.
 struct TapeTemplateGroup {
   std::vector<uint32_t> tasks;   // instances
-  hipFunction_t fn = nullptr;    // extern "C" slpx_tape_template(...)
   uint32_t n_leaf = 0, n_node = 0, n_slot = 0;
   uint32_t n_groups = 1;         // row groups of the adjoint part (see tape_jit.cpp)
 };
 
 struct TapeJitResult {
-  std::vector<TapeTemplateGroup> groups;
+  hipFunction_t fn = nullptr;              // extern "C" slpx_tape_templates(...), null = no templates
+  std::vector<TapeTemplateGroup> groups;   // body k of the kernel serves groups[k]
   std::vector<uint8_t> task_is_templated;  // per task of the program
   double compile_seconds = 0.0;
   std::string log;                         // non-empty when something fell back
 };
 
-// Finds the template groups of `prog` with at least `min_instances` members among the
-// LDS-class tasks, generates + compiles (or fetches from the process-wide cache) one
-// kernel per group.  Never throws: on any hipRTC problem the group is simply left to the
-// interpreter and the reason is put in `log`.
-TapeJitResult build_tape_templates(const TapeProgram& prog, uint32_t min_instances);
+struct TapeJitOptions {
+  // A family needs this many members to get a body: one LANE runs the whole task, so a
+  // lone task is far slower generated (one lane, serial: measured 229 us for ten packed
+  // 320-node linear-row tasks) than interpreted by a workgroup (level-parallel, ~10 us).
+  uint32_t min_instances = 16;
+  // ... and so is a wide, shallow task (measured at N=5000: a family of packed linear-row
+  // tasks, 640 loads + 320 stores per lane, turned a 45 us launch into 300 us)
+  uint32_t max_width = 32;
+  uint32_t max_bodies = 8;
+  uint32_t max_generated_nodes = 4000;  // code-size / compile-time cap over all bodies
+};
+
+// Groups the LDS-class tasks of `prog` by identical structure and output wiring, picks the
+// groups worth a body, generates + compiles (or fetches from the process-wide cache) the
+// kernel.  Never throws: on any hipRTC problem everything stays on the interpreter and the
+// reason is put in `log`.
+TapeJitResult build_tape_templates(const TapeProgram& prog, const TapeJitOptions& opt = {});
+
+// The generated source for a set of representative tasks (exposed for tests / inspection).
+std::string generate_templates_source(const TapeProgram& prog, const std::vector<uint32_t>& representatives);
 
 // Number of wave-uniform row groups the adjoint part of a template is split into.
 uint32_t template_row_groups(const TapeProgram& prog, const TapeTask& representative);
-
-// The generated source of one template (exposed for tests / inspection).
-std::string generate_template_source(const TapeProgram& prog, const TapeTask& representative);
 
 }  // namespace slpx

@@ -57,6 +57,23 @@ __device__ unsigned long long g_tape_clocks[16];  // [0,8): 64-thread kernel, [8
 #define SLPX_TAPE_CLOCK(k)                                                    \
   if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) g_tape_clocks[(THREADS == 256 ? 8 : 0) + (k)] = wall_clock64()
 
+// Separable sums (nlp.cpp): V[dst] = scale * (sum of the partials the tape tasks left in the
+// hidden tail of V), in a fixed order — strided per lane, then a pairwise tree.  One
+// 64-thread workgroup per sum.
+__device__ __forceinline__ void tape_reduce_body(const NlpStructure::SumReduce r,
+                                                 const double* __restrict__ scales, double* __restrict__ V,
+                                                 double* part, int tid) {
+  double acc = 0.0;
+  for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
+  part[tid] = acc;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (tid < w) part[tid] += part[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) V[r.dst] = (r.scale_idx >= 0 ? scales[r.scale_idx] : 1.0) * part[0];
+}
+
 template <int THREADS, bool FULL_OPS>
 __global__ __launch_bounds__(THREADS) void tape_sweep_lds_kernel(
     TapeDev T, const uint32_t* __restrict__ task_list, const double* __restrict__ in, int in_stride,

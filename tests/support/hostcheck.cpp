@@ -8,14 +8,18 @@
 // GPU by the `-m gpu` parity tests.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../../sleipnir_amd/csrc/capi_internal.hpp"
 #include "../../sleipnir_amd/csrc/kkt_plan.hpp"
 #include "../../sleipnir_amd/csrc/ldlt_symbolic.hpp"
 #include "../../sleipnir_amd/csrc/nlp.hpp"
+#include "../../sleipnir_amd/csrc/tape_jit.hpp"
 #include "../../sleipnir_amd/csrc/tape_ops.h"
 
 using namespace slpx;
@@ -142,10 +146,46 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   h->p.assign(h->k.dim, 0.0);
   h->ps.assign(std::max(1, h->s.m_i), 0.0);
   h->pz.assign(std::max(1, h->s.m_i), 0.0);
+  // lists the structural families of the tape (stderr); no device needed for that part
+  if (std::getenv("SLPX_TAPE_JIT_VERBOSE")) (void)build_tape_templates(h->s.full);
 }
 
 extern "C" {
 void hc_destroy(hc_handle* h) { delete h; }
+
+// Number of distinct task STRUCTURES of the LDLᵀ plan (everything but the global indices:
+// sizes, levels, local columns, flags, pair lists); out[r] = distinct structures of round r.
+int32_t hc_ldlt_families(hc_handle* h, int32_t* out, int32_t cap) {
+  const LdltPlan& L = h->l;
+  std::map<std::string, int> all;
+  for (int r = 0; r < L.n_rounds; ++r) {
+    std::map<std::string, int> fam;
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      std::string key;
+      auto put = [&](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
+      const uint32_t head[5] = {t.n_ent, t.n_col, t.n_ext, t.n_lvl, t.n_pairs};
+      put(head, sizeof(head));
+      put(L.lvl_ptr.data() + t.lvl_off, 4 * (t.n_lvl + 1));
+      put(L.ent_col.data() + t.ent_off, 2 * t.n_ent);
+      put(L.ent_flags.data() + t.ent_off, t.n_ent);
+      put(L.ent_pair_ptr.data() + t.pair_ptr_off, 4 * (t.n_ent + t.n_ext + 1));
+      put(L.ent_contrib_ptr.data() + t.contrib_ptr_off, 4 * (t.n_ent + 1));
+      put(L.pairs.data() + t.pair_off, sizeof(LdltPair) * t.n_pairs);
+      ++fam[key];
+      ++all[key];
+    }
+    if (r < cap) out[r] = static_cast<int32_t>(fam.size());
+    if (std::getenv("SLPX_TAPE_JIT_VERBOSE"))
+      for (auto& [k, c] : fam) {
+        uint32_t hd[5];
+        std::memcpy(hd, k.data(), sizeof(hd));
+        std::fprintf(stderr, "ldlt round %d: %d x (ent %u col %u ext %u lvl %u pairs %u)\n", r, c, hd[0], hd[1],
+                     hd[2], hd[3], hd[4]);
+      }
+  }
+  return static_cast<int32_t>(all.size());
+}
 
 // out[0..] = n, m_e, m_i, nV, nnz_lhs, nnzL, rounds, tasks, etree height, pairs,
 //            tape tasks, nodes, slots, edges, levels, slot levels, struct singular,

@@ -168,12 +168,42 @@ int slpx_step_backsub(slpx_system* s);
 /* AD refresh (optional) + assemble + rhs + compute + solve + backsub */
 int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info);
 
-/* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values */
+/* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values,
+ * 8 x, 9 s, 10 y, 11 z (the resident iterate) */
 int64_t slpx_system_get(slpx_system* s, int which, double* out);
 int slpx_system_set_rhs(slpx_system* s, const double* rhs);
 /* RegularizedLDLT::compute(lhs) with a caller-assembled matrix (regularized_ldlt.hpp:72):
  * values in the order of pattern 5 (lower CSC, forced diagonal), [batch][nnz]. */
 int slpx_system_set_lhs(slpx_system* s, const double* lhs);
+
+/* ---- The interior-point iteration AROUND the Newton step, on the resident iterate ----
+ * (one problem per system).  What interior_point() does between two Newton steps with
+ * O(n) host loops over Eigen vectors (interior_point.hpp:488-563, :775-832) as kernels on
+ * the state already in HBM; only the scalars below cross PCIe.  slpx_problem_solve() runs
+ * on these; a maintainer binding at the linear-solver or AD seam does not need them.
+ *
+ * slpx_ipm_direction: for the step left by slpx_newton_step —
+ *   out[3] = {alpha_max = ftb(s, p_s, tau), alpha_z = ftb(z, p_z, tau)
+ *             (util/fraction_to_the_boundary_rule.hpp:19-43),
+ *             D_phi = g.p_x - mu sum(p_s / s) (interior_point.hpp:508-509)}
+ * slpx_ipm_trial: trial x = x + alpha p_x, forward sweep of f, c_e, c_i there —
+ *   out[4] = {f, |c_e|_1 + |c_i - s_trial|_1, sum ln s_trial, all finite (1/0)}
+ *   (the filter entry of util/filter.hpp:30-60 is {f - mu out[2], out[1]});
+ *   s_trial = s + alpha p_s, or the trial c_i when s_from_ci (feasible-IPM option, :520-526)
+ * slpx_ipm_commit: x += alpha p_x, s := s_trial, y += alpha_z p_y, z += alpha_z p_z, then
+ *   the z reset of interior_point.hpp:797-801 (mu = the value last set with set_state)
+ * slpx_ipm_errors: at the resident iterate with V from the last FULL sweep; error_scales =
+ *   [d_f, d_ce, d_ci] used for un-scaling (util/kkt_error.hpp:216-251) —
+ *   out[24] = {un-scaled: |g - A_e^T y - A_i^T z|_inf, |s.z|_inf, |c_e|_inf, |c_i - s|_inf,
+ *              |y|_1, |z|_1;  scaled: the same dual residual, min s.z, max s.z, |c_e|_inf,
+ *              |c_i - s|_inf, |y|_1, |z|_1;  f, |c_e|_1 + |c_i - s|_1, sum ln s;
+ *              |A_e^T c_e|_2^2, |c_e|_2^2, |A_i^T c_i^-|_2^2, |c_i^-|_2^2
+ *              (util/is_locally_infeasible.hpp:17-60);  |x|_inf, |s|_inf, all finite,
+ *              all c_i > 0}  (util/kkt_error.hpp:92-146 combines the first thirteen) */
+int slpx_ipm_direction(slpx_system* s, double tau, double* out3);
+int slpx_ipm_trial(slpx_system* s, double alpha, int s_from_ci, double* out4);
+int slpx_ipm_commit(slpx_system* s, double alpha, double alpha_z, int s_from_ci);
+int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24);
 
 /* Times `iters` Newton steps with HIP events on the system's stream.
  * ms[8] = per-step averages {sweep, assemble, rhs, factor(all attempts), solve, backsub,

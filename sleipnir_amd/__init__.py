@@ -138,6 +138,10 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_ipm_direction", ctypes.c_int, vp, f64, vp)
+    sig("slpx_ipm_trial", ctypes.c_int, vp, f64, ctypes.c_int, vp)
+    sig("slpx_ipm_commit", ctypes.c_int, vp, f64, f64, ctypes.c_int)
+    sig("slpx_ipm_errors", ctypes.c_int, vp, vp, vp)
     _lib = L
     return L
 
@@ -315,11 +319,36 @@ class System:
         return info
 
     def get(self, which: str) -> np.ndarray:
-        sel = {"V": 0, "lhs": 1, "rhs": 2, "p": 3, "p_s": 4, "p_z": 5, "D": 6, "Lx": 7}[which]
+        sel = {"V": 0, "lhs": 1, "rhs": 2, "p": 3, "p_s": 4, "p_z": 5, "D": 6, "Lx": 7, "x": 8, "s": 9,
+               "y": 10, "z": 11}[which]
         count = _check(lib().slpx_system_get(self._h, sel, None))
         out = np.zeros(max(count, 1))
         _check(lib().slpx_system_get(self._h, sel, out.ctypes.data))
         return out[:count].reshape(self.batch, -1)
+
+    # ---- the interior-point iteration around the Newton step, on the resident iterate ----
+    IPM_ERROR_KEYS = ["dual_inf_u", "sz_max_u", "ce_inf_u", "cis_inf_u", "y1_u", "z1_u", "dual_inf", "sz_min",
+                      "sz_max", "ce_inf", "cis_inf", "y1", "z1", "f", "viol", "logsum", "aetce_sq", "ce_sq",
+                      "aitcp_sq", "cp_sq", "x_inf", "s_inf", "finite", "ci_all_pos"]
+
+    def ipm_direction(self, tau):
+        out = np.zeros(3)
+        _check(lib().slpx_ipm_direction(self._h, float(tau), out.ctypes.data))
+        return {"alpha_max": out[0], "alpha_z": out[1], "D_phi": out[2]}
+
+    def ipm_trial(self, alpha, s_from_ci=False):
+        out = np.zeros(4)
+        _check(lib().slpx_ipm_trial(self._h, float(alpha), int(s_from_ci), out.ctypes.data))
+        return {"f": out[0], "viol": out[1], "logsum": out[2], "finite": out[3]}
+
+    def ipm_commit(self, alpha, alpha_z, s_from_ci=False):
+        _check(lib().slpx_ipm_commit(self._h, float(alpha), float(alpha_z), int(s_from_ci)))
+
+    def ipm_errors(self, error_scales):
+        sc = _f64(error_scales)
+        out = np.zeros(24)
+        _check(lib().slpx_ipm_errors(self._h, sc.ctypes.data, out.ctypes.data))
+        return dict(zip(self.IPM_ERROR_KEYS, out))
 
     def set_rhs(self, rhs):
         r = _f64(rhs)

@@ -359,6 +359,10 @@ int64_t slpx_system_get(slpx_system* s, int which, double* out) {
       case 5: src = dev.d_pz(); count = B * st.m_i; break;
       case 6: src = dev.d_D(); count = B * l.n; break;
       case 7: src = dev.d_Lx(); count = B * l.nnzL; break;
+      case 8: src = dev.d_x(); count = st.n; if (B != 1) throw std::runtime_error("slpx_system_get: x of a batch is strided"); break;
+      case 9: src = dev.d_s(); count = B * st.m_i; break;
+      case 10: src = dev.d_y(); count = B * st.m_e; break;
+      case 11: src = dev.d_z(); count = B * st.m_i; break;
       default: throw std::runtime_error("slpx_system_get: bad selector");
     }
     if (out && count > 0) dev.download(src, out, static_cast<size_t>(count));
@@ -371,6 +375,55 @@ int slpx_system_set_rhs(slpx_system* s, const double* rhs) {
     const size_t count = static_cast<size_t>(dev.batch()) * s->get().kkt().dim;
     SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs, count * sizeof(double), hipMemcpyHostToDevice, dev.stream()));
     SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  });
+}
+
+int slpx_ipm_direction(slpx_system* s, double tau, double* out3) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    dev.ipm_enable();
+    dev.ipm_direction(tau);
+    dev.wait();
+    const slpx::IpmDirOut& d = dev.ipm_host().dir;
+    out3[0] = d.alpha_max;
+    out3[1] = d.alpha_z;
+    out3[2] = d.D_phi;
+  });
+}
+int slpx_ipm_trial(slpx_system* s, double alpha, int s_from_ci, double* out4) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    dev.ipm_enable();
+    dev.ipm_trial_point(alpha);
+    dev.sweep_values_trial();
+    dev.ipm_trial_metrics(alpha, s_from_ci != 0);
+    dev.wait();
+    const slpx::IpmTrialOut& t = dev.ipm_host().trial;
+    out4[0] = t.f;
+    out4[1] = t.viol;
+    out4[2] = t.logsum;
+    out4[3] = t.finite;
+  });
+}
+int slpx_ipm_commit(slpx_system* s, double alpha, double alpha_z, int s_from_ci) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    dev.ipm_enable();
+    dev.ipm_commit(alpha, alpha_z, s_from_ci != 0);
+    dev.wait();
+  });
+}
+int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24) {
+  return guard([&] {
+    auto& dev = s->get().device();
+    dev.ipm_enable();
+    const int ns = s->get().structure().n_scales();
+    dev.ipm_set_error_scaling(std::vector<double>(error_scales, error_scales + ns));
+    dev.ipm_errors(false);
+    dev.wait();
+    const slpx::IpmErrOut& e = dev.ipm_host().err;
+    static_assert(sizeof(slpx::IpmErrOut) == 24 * sizeof(double), "out24 mirrors IpmErrOut");
+    std::memcpy(out24, &e, sizeof(e));
   });
 }
 

@@ -158,6 +158,32 @@ struct KktDev {
   int off_f, off_ce, off_ci, off_g, off_Ae, off_Ai;
 };
 
+// Scalars the interior-point iteration kernels (ipm_kernels.h) hand to the host; the
+// three blocks live side by side in pinned host memory and are written by the kernels.
+struct IpmDirOut {
+  double alpha_max, alpha_z, D_phi;
+};
+struct IpmTrialOut {
+  double f, viol, logsum, finite;
+};
+struct IpmErrOut {
+  // un-scaled quantities (kkt_error.hpp:216-251) for the termination test ...
+  double dual_inf_u, sz_max_u, ce_inf_u, cis_inf_u, y1_u, z1_u;
+  // ... and the scaled ones for the barrier-parameter test: ‖g − A_eᵀy − A_iᵀz‖∞,
+  // min / max of s∘z, ‖c_e‖∞, ‖c_i − s‖∞, ‖y‖₁, ‖z‖₁
+  double dual_inf, sz_min, sz_max, ce_inf, cis_inf, y1, z1;
+  // filter entry of the current iterate: f, ‖c_e‖₁ + ‖c_i − s‖₁, Σ ln s
+  double f, viol, logsum;
+  // local infeasibility: ‖A_eᵀc_e‖₂², ‖c_e‖₂², ‖A_iᵀc_i⁻‖₂², ‖c_i⁻‖₂²
+  double aetce_sq, ce_sq, aitcp_sq, cp_sq;
+  double x_inf, s_inf, finite, ci_all_pos;
+};
+struct IpmHost {
+  IpmDirOut dir;
+  IpmTrialOut trial;
+  IpmErrOut err;
+};
+
 struct StepTimings {
   float sweep = 0, assemble = 0, rhs = 0, factor = 0, solve = 0, backsub = 0, total = 0;
 };
@@ -210,6 +236,27 @@ class DeviceNlp {
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
+
+  // ---- interior-point iteration on the device (ipm_kernels.h; one problem) ----
+  // All asynchronous on stream(); results arrive in ipm_host() after wait().
+  void ipm_enable();                          // allocates the trial / correction buffers
+  // [d_f | d_ce | d_ci] the termination test un-scales with (kkt_error.hpp:216-251); not
+  // necessarily the scaling the tapes apply (feasibility restoration scales in its model)
+  void ipm_set_error_scaling(const std::vector<double>& scales);
+  void ipm_direction(double tau);             // step sizes, D_phi; trial x = x + alpha_max p_x
+  void ipm_trial_point(double alpha);         // trial x = x + alpha p_x
+  void sweep_values_trial();                  // f, c_e, c_i at the trial x -> trial V
+  void ipm_trial_metrics(double alpha, bool s_from_ci);  // alpha < 0: the device's alpha_max
+  void ipm_commit(double alpha, double alpha_z, bool s_from_ci);
+  void ipm_errors(bool check_all_V);
+  void ipm_soc_accumulate(double alpha, bool first, bool s_from_ci);
+  void ipm_soc_rhs();                         // -> rhs
+  void ipm_soc_backsub();                     // p -> p_s, p_z with the corrected c_i - s
+  void ipm_save_direction();
+  void ipm_restore_direction();
+  void wait();                                // busy-polls the stream
+  const IpmHost& ipm_host() const { return *m_ipm_host; }
+  double* d_V_trial() { return m_V_trial.p; }
 
   // device pointers for callers that keep everything resident
   double* d_x() { return m_in.p; }
@@ -284,6 +331,12 @@ class DeviceNlp {
   hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
   hipEvent_t m_fork = nullptr, m_join = nullptr;
   std::vector<double> m_V_static;  // scaled static values (host copy)
+  // interior-point iteration state (ipm_enable)
+  bool m_ipm = false;
+  DevBuf<double> m_trial_in, m_V_trial, m_soc_ce, m_soc_cims, m_p_keep, m_ps_keep, m_pz_keep, m_ipm_alpha, m_ipm_scales, m_ipm_partial;
+  IpmHost* m_ipm_host = nullptr;   // pinned
+  const double* m_in_override = nullptr;  // launch_tape reads / writes these when set
+  double* m_V_override = nullptr;
 };
 
 }  // namespace slpx

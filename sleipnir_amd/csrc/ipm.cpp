@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace slpx {
 
@@ -222,10 +223,10 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
 
 // interior_point.hpp:129-878: the iteration proper, on caller-owned iterates (the
 // restoration phase re-enters it with in_feasibility_restoration = true).
-ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales,
-                    const std::vector<IterationCallback>& callbacks, const Options& options,
-                    bool in_feasibility_restoration, Vec& x, Vec& s, Vec& y, Vec& z, double& mu,
-                    int& iterations, SolveReport& rep, clk::time_point solve_start) {
+ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
+                         const std::vector<IterationCallback>& callbacks, const Options& options,
+                         bool in_feasibility_restoration, Vec& x, Vec& s, Vec& y, Vec& z, double& mu,
+                         int& iterations, SolveReport& rep, clk::time_point solve_start) {
   const NlpStructure& st = sys.structure();
   DeviceNlp& dev = sys.device();
   const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
@@ -579,6 +580,347 @@ ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales,
   }
   rep.final_error = E_0;
   return finish(ExitStatus::SUCCESS);
+}
+
+// The same iteration with the iterate, the step and every O(n) vector RESIDENT ON THE
+// DEVICE (ipm_kernels.h): per iteration the host reads the
+// inertia counters plus ~30 scalars (step sizes, directional derivative, filter entry of
+// the trial point, error norms) and decides; it never sees a vector.  The kernels for the
+// step sizes, the first trial point and its merit quantities are enqueued speculatively
+// behind the Newton step, so the common iteration has two synchronizations: one after
+// [step + first trial], one after [iterate update + AD refresh + error norms].
+// Rare branches (the KKT-error fallback of the line search, feasibility restoration, user
+// callbacks) pull the iterate to the host and reuse the host code above.
+ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
+                             const std::vector<IterationCallback>& callbacks, const Options& options,
+                             bool in_feasibility_restoration, Vec& x, Vec& s, Vec& y, Vec& z, double& mu,
+                             int& iterations, SolveReport& rep, clk::time_point solve_start) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
+  dev.ipm_enable();
+  dev.ipm_set_error_scaling(scales);
+  const IpmHost& H = dev.ipm_host();
+
+  sys.reset_regularization();
+  sys.set_gamma_min(in_feasibility_restoration ? 0.0 : 1e-10);  // :350-352
+
+  bool host_current = true;  // x, s, y, z on the host mirror the device iterate
+  auto pull_state = [&] {
+    if (host_current) return;
+    dev.download(dev.d_x(), x.data(), n);
+    if (m_i) {
+      dev.download(dev.d_s(), s.data(), m_i);
+      dev.download(dev.d_z(), z.data(), m_i);
+    }
+    if (m_e) dev.download(dev.d_y(), y.data(), m_e);
+    host_current = true;
+  };
+  auto push_state = [&] {
+    dev.upload_x(x.data());
+    dev.upload_duals(s.data(), y.data(), z.data());
+    host_current = true;
+  };
+  auto finish = [&](ExitStatus st_) {
+    sys.set_after_attempt(nullptr);
+    pull_state();
+    return st_;
+  };
+
+  auto t_setup = clk::now();
+  push_state();
+  dev.upload_mu(&mu);
+  double mu_on_device = mu;
+  dev.sweep_full();  // :245-251
+  dev.ipm_errors(/*check_all_V=*/true);
+  dev.wait();
+  IpmErrOut cur = H.err;  // scalars of the current iterate
+
+  if (m_e > n) return finish(ExitStatus::TOO_FEW_DOFS);                        // :274
+  if (cur.finite == 0.0) return finish(ExitStatus::NONFINITE_INITIAL_GUESS);  // :283-286
+
+  const double mu_min = scales[0] * options.tolerance / 10.0;  // :294
+  constexpr double tau_min = 0.99;
+  double tau = tau_min;
+  Filter filter{cur.viol};  // :303
+  auto update_barrier = [&] {  // :308-333
+    mu = std::max(mu_min, std::min(0.2 * mu, std::pow(mu, 1.5)));
+    tau = std::max(tau_min, 1.0 - mu);
+    filter.reset();
+  };
+
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-7;
+  constexpr double s_max = 100.0;
+  int full_step_rejected_counter = 0;
+  const bool identity = scaling_is_identity(st, scales);
+  // util/kkt_error.hpp:92-146 from the reduced scalars
+  auto E_mu_of = [&](const IpmErrOut& e, double m) {
+    const double s_d = std::max(s_max, (e.y1 + e.z1) / double(m_e + m_i)) / s_max;
+    const double s_c = std::max(s_max, e.z1 / double(m_i)) / s_max;
+    const double comp = m_i ? std::max(std::abs(e.sz_max - m), std::abs(e.sz_min - m)) : 0.0;
+    return std::max({e.dual_inf / s_d, comp / s_c, e.ce_inf, e.cis_inf});
+  };
+  auto E0_of = [&](const IpmErrOut& e) {
+    if (identity) return E_mu_of(e, 0.0);
+    const double s_d = std::max(s_max, (e.y1_u + e.z1_u) / double(m_e + m_i)) / s_max;
+    const double s_c = std::max(s_max, e.z1_u / double(m_i)) / s_max;
+    return std::max({e.dual_inf_u / s_d, e.sz_max_u / s_c, e.ce_inf_u, e.cis_inf_u});
+  };
+  double E_0 = E0_of(cur);  // :361-362
+  rep.t_setup = since(t_setup);
+
+  // host copies for the rare branches
+  Vec V, p(dim), p_x(n), p_y(m_e), p_s(m_i), p_z(m_i);
+  auto pull_V = [&] {
+    V.resize(st.nV);
+    dev.download_V(V.data());
+  };
+
+  while (E_0 > options.tolerance) {
+    // :387-408 infeasibility / divergence checks
+    if (m_e > 0 && std::sqrt(cur.aetce_sq) < 1e-6 && std::sqrt(cur.ce_sq) > 1e-2)
+      return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    if (m_i > 0 && std::sqrt(cur.aitcp_sq) < 1e-6 && std::sqrt(cur.cp_sq) > 1e-6)
+      return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    if (cur.x_inf > 1e10 || cur.s_inf > 1e10 || cur.finite == 0.0) return finish(ExitStatus::DIVERGING_ITERATES);
+
+    if (!callbacks.empty()) {
+      pull_state();
+      pull_V();
+      for (const auto& cb : callbacks)
+        if (cb({iterations, x, s, y, z, V})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+      push_state();  // a callback may have used this system's device buffers (restoration does)
+    }
+
+    // ---- Newton step (:426-482), then speculatively: step sizes, first trial point ----
+    auto t0 = clk::now();
+    const bool s_from_ci = options.feasible_ipm && cur.ci_all_pos != 0.0;
+    if (mu != mu_on_device) {
+      dev.upload_mu(&mu);
+      mu_on_device = mu;
+    }
+    dev.assemble();
+    dev.build_rhs();
+    sys.set_after_attempt([&] {
+      dev.ipm_direction(tau);
+      dev.sweep_values_trial();
+      dev.ipm_trial_metrics(-1.0, s_from_ci);
+    });
+    auto info = sys.compute(/*solve_speculatively=*/true);
+    sys.set_after_attempt(nullptr);
+    rep.factorizations += sys.last_factorizations();
+    rep.solves += sys.last_factorizations();
+    rep.value_sweeps += sys.last_factorizations();
+    rep.t_kkt_decomp += since(t0);
+    if (info[0] != FactorInfo::Success) return finish(ExitStatus::FACTORIZATION_FAILED);  // :463-465
+    rep.delta = sys.hessian_regularization()[0];
+    rep.gamma = sys.constraint_jacobian_regularization()[0];
+
+    t0 = clk::now();
+    const double alpha_max = H.dir.alpha_max;  // :488
+    double alpha = alpha_max;
+    double alpha_z = H.dir.alpha_z;  // :497
+    const double D_phi = H.dir.D_phi;  // :508-509
+    bool call_feasibility_restoration = alpha < alpha_min;
+    const FilterEntry current_entry{cur.f - mu * cur.logsum, cur.viol};
+    double alpha_commit = alpha;
+    bool commit_s_from_ci = s_from_ci;
+    bool have_trial = true;  // the speculative chain already evaluated alpha_max
+
+    while (true) {  // :512
+      if (!have_trial) {
+        dev.ipm_trial_point(alpha);
+        dev.sweep_values_trial();
+        dev.ipm_trial_metrics(alpha, s_from_ci);
+        dev.wait();
+        ++rep.value_sweeps;
+      }
+      have_trial = false;
+      alpha_commit = alpha;
+      IpmTrialOut tr = H.trial;
+
+      if (tr.finite == 0.0) {
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) {
+          call_feasibility_restoration = true;
+          break;
+        }
+        continue;
+      }
+
+      const FilterEntry trial_entry{tr.f - mu * tr.logsum, tr.viol};
+      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
+
+      const double prev_violation = cur.viol;
+      double next_violation = tr.viol;
+
+      // second-order corrections (:566-668): new rhs, SAME factorization, all on the device
+      if (alpha == alpha_max && next_violation >= prev_violation) {
+        dev.ipm_save_direction();
+        double alpha_soc = alpha, alpha_z_soc = alpha_z;
+        double soc_violation = next_violation;
+        bool step_acceptable = false;
+        for (int it = 0; it < 5 && !step_acceptable; ++it) {
+          dev.ipm_soc_accumulate(alpha_soc, it == 0, it == 0 && s_from_ci);
+          dev.ipm_soc_rhs();
+          dev.solve();
+          ++rep.solves;
+          dev.ipm_soc_backsub();
+          dev.ipm_direction(tau);  // step sizes of the corrected direction + its trial point
+          dev.sweep_values_trial();
+          dev.ipm_trial_metrics(-1.0, false);
+          dev.wait();
+          ++rep.value_sweeps;
+          alpha_soc = H.dir.alpha_max;
+          alpha_z_soc = H.dir.alpha_z;
+          tr = H.trial;
+          const FilterEntry soc_entry{tr.f - mu * tr.logsum, tr.viol};
+          if (filter.try_add(current_entry, soc_entry, D_phi, alpha)) {
+            alpha = alpha_soc;
+            alpha_z = alpha_z_soc;
+            alpha_commit = alpha_soc;
+            commit_s_from_ci = false;
+            step_acceptable = true;
+            break;
+          }
+          next_violation = tr.viol;
+          if (next_violation > 0.99 * soc_violation) break;
+          soc_violation = next_violation;
+        }
+        if (step_acceptable) break;
+        dev.ipm_restore_direction();
+      }
+
+      if (alpha == alpha_max) ++full_step_rejected_counter;
+      // :677-684
+      if (full_step_rejected_counter >= 4 &&
+          filter.max_constraint_violation > current_entry.constraint_violation / 10.0 &&
+          filter.last_rejection_due_to_filter()) {
+        filter.max_constraint_violation *= 0.1;
+        filter.reset();
+        continue;
+      }
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {  // :691-716 — rare: on the host, with the iterate pulled over
+        pull_state();
+        pull_V();
+        VView cv{st, V};
+        const Vec g = cv.g_dense();
+        const double current_kkt = kkt_error_impl<ErrType::ONE_NORM>(st, g, cv.Ae(), cv.c_e(), cv.Ai(),
+                                                                     cv.c_i(), s, y, z, mu, nullptr);
+        dev.download(dev.d_p(), p.data(), dim);
+        std::copy(p.begin(), p.begin() + n, p_x.begin());
+        for (int j = 0; j < m_e; ++j) p_y[j] = -p[n + j];
+        if (m_i) {
+          dev.download(dev.d_ps(), p_s.data(), m_i);
+          dev.download(dev.d_pz(), p_z.data(), m_i);
+        }
+        const Vec trial_x = axpy(x, alpha_max, p_x), trial_s = axpy(s, alpha_max, p_s),
+                  trial_y = axpy(y, alpha_z, p_y), trial_z = axpy(z, alpha_z, p_z);
+        // needs g, A_e, A_i at the trial point: full sweep there, then put the iterate back
+        dev.upload_x(trial_x.data());
+        dev.upload_duals(s.data(), trial_y.data(), trial_z.data());
+        dev.sweep_full();
+        Vec Vt(st.nV);
+        dev.download_V(Vt.data());
+        push_state();
+        VView tv{st, Vt};
+        const double next_kkt = kkt_error_impl<ErrType::ONE_NORM>(st, tv.g_dense(), tv.Ae(), tv.c_e(), tv.Ai(),
+                                                                  tv.c_i(), trial_s, trial_y, trial_z, mu,
+                                                                  nullptr);
+        if (next_kkt <= 0.999 * current_kkt) {
+          alpha_commit = alpha_max;
+          commit_s_from_ci = false;
+          break;
+        }
+        call_feasibility_restoration = true;
+        break;
+      }
+    }
+    rep.t_line_search += since(t0);
+
+    t0 = clk::now();
+    if (call_feasibility_restoration) {  // :721-771 — rare: host vectors, as in ipm_core_host
+      if (in_feasibility_restoration) return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
+      pull_state();
+      pull_V();
+      VView cv{st, V};
+      const Vec g = cv.g_dense();
+      const Vec c_e(cv.c_e(), cv.c_e() + m_e), c_i(cv.c_i(), cv.c_i() + m_i);
+      const double f = cv.f();
+      Vec Vtrial(st.nV);
+      const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+      std::vector<IterationCallback> fr_callbacks = callbacks;
+      // Leave restoration once the outer filter accepts the restoration iterate and the
+      // violation dropped by 10 % (:729-752).
+      fr_callbacks.emplace_back([&](const IterationInfo& info) {
+        Vec tx(info.x.begin(), info.x.begin() + n);
+        Vec ts(info.s.begin(), info.s.begin() + m_i);
+        dev.upload_x(tx.data());
+        dev.sweep_values();
+        dev.download(dev.d_V(), Vtrial.data(), static_cast<size_t>(st.off_g));
+        ++rep.value_sweeps;
+        Vec tce(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e);
+        Vec tci(Vtrial.begin() + st.off_ci, Vtrial.begin() + st.off_ci + m_i);
+        const FilterEntry trial_entry{Vtrial[st.off_f], ts, tce.data(), m_e, tci.data(), mu};
+        double D_phi_restoration = 0.0, sinv_dot = 0.0;
+        for (int i = 0; i < n; ++i) D_phi_restoration += g[i] * (tx[i] - x[i]);
+        for (int j = 0; j < m_i; ++j) sinv_dot += (1.0 / s[j]) * (ts[j] - s[j]);
+        D_phi_restoration -= mu * sinv_dot;
+        return trial_entry.constraint_violation < 0.9 * initial_entry.constraint_violation &&
+               filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      });
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s, y, z, mu,
+                                                           iterations, rep, solve_start, c_e, c_i);
+      if (fr_status != ExitStatus::SUCCESS) return finish(fr_status);
+      push_state();
+    } else {
+      if (alpha == alpha_max) full_step_rejected_counter = 0;
+      dev.ipm_commit(alpha_commit, alpha_z, commit_s_from_ci);  // :775-801
+      host_current = false;
+    }
+
+    // AD refresh (:809-812) and every norm the next decisions need
+    dev.sweep_full();
+    dev.ipm_errors(false);
+    dev.wait();
+    cur = H.err;
+    rep.t_ad_refresh += since(t0);
+
+    E_0 = E0_of(cur);
+    if (E_0 > options.tolerance) {  // :819-832
+      double E_mu = E_mu_of(cur, mu);
+      while (mu > mu_min && E_mu <= 10.0 * mu) {
+        update_barrier();
+        E_mu = E_mu_of(cur, mu);
+      }
+    }
+    if (options.diagnostics) {
+      std::fprintf(stderr,
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  "
+                   "alpha_z %.2e  nfact %d\n",
+                   iterations, E_0, cur.f, cur.viol, mu, rep.delta, rep.gamma, alpha, alpha_z,
+                   sys.last_factorizations());
+    }
+    ++iterations;
+    rep.final_error = E_0;
+    if (iterations >= options.max_iterations) return finish(ExitStatus::MAX_ITERATIONS_EXCEEDED);
+    if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
+  }
+  rep.final_error = E_0;
+  return finish(ExitStatus::SUCCESS);
+}
+
+// SLPX_IPM_RESIDENT=0 keeps the O(n) logic between Newton steps on the host (the round-1
+// arrangement; kept as the cross-check of the device-resident iteration).
+ExitStatus ipm_core(NewtonSystem& sys, const Vec& scales, const std::vector<IterationCallback>& callbacks,
+                    const Options& options, bool in_feasibility_restoration, Vec& x, Vec& s, Vec& y, Vec& z,
+                    double& mu, int& iterations, SolveReport& rep, clk::time_point solve_start) {
+  const char* env = std::getenv("SLPX_IPM_RESIDENT");
+  const bool resident = !(env && env[0] == '0');
+  return (resident ? ipm_core_resident : ipm_core_host)(sys, scales, callbacks, options,
+                                                        in_feasibility_restoration, x, s, y, z, mu, iterations,
+                                                        rep, solve_start);
 }
 
 // feasibility_restoration.hpp:26-101: p, n >= 0 with p - n = c minimising the barrier

@@ -1,0 +1,424 @@
+// Device side of the interior-point ITERATION around the Newton step:
+// fraction-to-the-boundary rule, trial iterate, trial merit quantities, second-order
+// correction bookkeeping, iterate update, and the error / infeasibility / divergence
+// reductions — so that a whole `Problem::solve()` keeps x, s, y, z, the step and every
+// O(n) vector in HBM and only a few dozen scalars per iteration cross PCIe (written
+// straight into pinned host memory by the kernels).
+//
+// Reference formulas: interior_point.hpp:488-509 (step sizes, directional derivative),
+// :512-563 (trial iterate), :566-668 (second-order corrections), :775-801 (iterate update,
+// z reset), util/fraction_to_the_boundary_rule.hpp:19-43, util/filter.hpp:30-60 (entry =
+// f − μ Σ ln s, ‖c_e‖₁ + ‖c_i − s‖₁), util/kkt_error.hpp:92-146 and :216-251 (un-scaling),
+// util/is_locally_infeasible.hpp:17-60, interior_point.hpp:399-407 (divergence).
+//
+// The reductions are latency-, not bandwidth-bound (n is a few thousand to a few ten
+// thousand): wave totals by DPP butterflies + scalar lane reads (no LDS traffic), a fixed
+// combination order (reproducible run to run); the big one (23 quantities) is spread over
+// workgroups of 256 lanes with a tiny second launch folding the per-workgroup partials.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device.hpp"
+
+namespace slpx {
+
+constexpr int kIpmThreads = 1024;
+
+enum IpmOp { IPM_SUM = 0, IPM_MAX = 1, IPM_MIN = 2 };
+
+template <int kCtrl>
+__device__ __forceinline__ double ipm_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ipm_readlane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double ipm_combine(int op, double a, double b) {
+  return op == IPM_SUM ? a + b : (op == IPM_MAX ? fmax(a, b) : fmin(a, b));
+}
+// Total of a full 64-lane wave, in every lane: a DPP butterfly inside each row of 16 lanes
+// (no LDS traffic — with one workgroup all waves share one CU's LDS pipe), then the four
+// row totals through scalar registers.
+__device__ __forceinline__ double wave_reduce(double v, int op) {
+  v = ipm_combine(op, v, ipm_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = ipm_combine(op, v, ipm_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = ipm_combine(op, v, ipm_dpp<0x141>(v));  // row_half_mirror
+  v = ipm_combine(op, v, ipm_dpp<0x140>(v));  // row_mirror
+  const double r0 = ipm_readlane(v, 0), r1 = ipm_readlane(v, 16), r2 = ipm_readlane(v, 32),
+               r3 = ipm_readlane(v, 48);
+  return ipm_combine(op, ipm_combine(op, r0, r1), ipm_combine(op, r2, r3));
+}
+
+// Reduces NQ per-lane quantities (op per quantity) over a workgroup of THREADS lanes (full
+// waves, every lane must call); the results land in `vals` of every lane.  `scratch` =
+// (THREADS / 64 + 1) x NQ doubles of LDS.
+template <int NQ, int THREADS>
+__device__ __forceinline__ void block_reduce(double (&vals)[NQ], const int (&ops)[NQ], double* scratch) {
+  constexpr int kWaves = THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double v = wave_reduce(vals[q], ops[q]);
+    if (lane == 0) scratch[wave * NQ + q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const int q = threadIdx.x;
+    int op = ops[0];
+#pragma unroll
+    for (int k = 1; k < NQ; ++k)
+      if (q == k) op = ops[k];
+    double v = scratch[q];
+    for (int w = 1; w < kWaves; ++w) v = ipm_combine(op, v, scratch[w * NQ + q]);
+    scratch[kWaves * NQ + q] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) vals[q] = scratch[kWaves * NQ + q];
+  __syncthreads();
+}
+
+// Step sizes and directional derivative for the direction (p, ps, pz), then the first trial
+// point x + alpha_max p_x.  `out` (pinned host) and `alpha_dev` (device copy, read by
+// ipm_trial_metrics_kernel of the same speculative chain) may be the only consumers.
+__global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
+    KktDev K, const double* __restrict__ V, const double* __restrict__ x, const double* __restrict__ s,
+    const double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ ps,
+    const double* __restrict__ pz, const double* __restrict__ mu_dev, double tau, double* __restrict__ trial_x,
+    double* __restrict__ alpha_dev, IpmDirOut* __restrict__ out) {
+  __shared__ double scratch[17 * 3];
+  const int tid = threadIdx.x;
+  const double mu = mu_dev[0];
+  double acc[3] = {1.0, 1.0, 0.0};  // alpha_max, alpha_z, D_phi
+  for (int r = tid; r < K.m_i; r += kIpmThreads) {
+    const double sr = s[r], psr = ps[r], zr = z[r], pzr = pz[r];
+    if (psr < 0.0) acc[0] = fmin(acc[0], -tau / psr * sr);
+    if (pzr < 0.0) acc[1] = fmin(acc[1], -tau / pzr * zr);
+    acc[2] -= mu * ((1.0 / sr) * psr);
+  }
+  for (int j = tid; j < K.n; j += kIpmThreads) {
+    const int gs = K.g_src[j];
+    if (gs >= 0) acc[2] += V[gs] * p[j];
+  }
+  const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
+  block_reduce<3, kIpmThreads>(acc, ops, scratch);
+  const double alpha = acc[0];
+  for (int j = tid; j < K.n; j += kIpmThreads) trial_x[j] = x[j] + alpha * p[j];
+  if (tid == 0) {
+    alpha_dev[0] = acc[0];
+    alpha_dev[1] = acc[1];
+    out->alpha_max = acc[0];
+    out->alpha_z = acc[1];
+    out->D_phi = acc[2];
+  }
+}
+
+// trial_x = x + alpha p_x (backtracking)
+__global__ __launch_bounds__(256) void ipm_trial_point_kernel(int n, const double* __restrict__ x,
+                                                              const double* __restrict__ p, double alpha,
+                                                              double* __restrict__ trial_x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    trial_x[j] = x[j] + alpha * p[j];
+}
+
+// Filter quantities of the trial point whose f, c_e, c_i a forward sweep left in Vt.
+// alpha < 0: take the step size from alpha_dev[0].  s_from_ci: trial_s = trial c_i
+// (feasible-IPM option, interior_point.hpp:520-526).
+__global__ __launch_bounds__(kIpmThreads) void ipm_trial_metrics_kernel(
+    KktDev K, const double* __restrict__ Vt, const double* __restrict__ s, const double* __restrict__ ps,
+    double alpha, const double* __restrict__ alpha_dev, int s_from_ci, IpmTrialOut* __restrict__ out) {
+  __shared__ double scratch[17 * 3];
+  const int tid = threadIdx.x;
+  if (alpha < 0.0) alpha = alpha_dev[0];
+  double acc[3] = {0.0, 0.0, 1.0};  // violation, log sum, finite
+  for (int r = tid; r < K.m_e; r += kIpmThreads) {
+    const double c = Vt[K.off_ce + r];
+    acc[0] += fabs(c);
+    if (!isfinite(c)) acc[2] = 0.0;
+  }
+  for (int r = tid; r < K.m_i; r += kIpmThreads) {
+    const double c = Vt[K.off_ci + r];
+    const double st = s_from_ci ? c : s[r] + alpha * ps[r];
+    acc[0] += fabs(c - st);
+    acc[1] += log(st);
+    if (!isfinite(c)) acc[2] = 0.0;
+  }
+  const int ops[3] = {IPM_SUM, IPM_SUM, IPM_MIN};
+  block_reduce<3, kIpmThreads>(acc, ops, scratch);
+  if (tid == 0) {
+    const double f = Vt[K.off_f];
+    out->f = f;
+    out->viol = acc[0];
+    out->logsum = acc[1];
+    out->finite = (acc[2] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
+  }
+}
+
+// Accepts the step: x += alpha p_x, s += alpha p_s (or s = trial c_i), y += alpha_z p_y with
+// p_y = −p[n:], z += alpha_z p_z, then the z reset of interior_point.hpp:797-801.  x, y, z
+// also live in the tape's input vector `in` = [x | y | z].
+__global__ __launch_bounds__(256) void ipm_commit_kernel(KktDev K, const double* __restrict__ Vt,
+                                                         const double* __restrict__ p,
+                                                         const double* __restrict__ ps,
+                                                         const double* __restrict__ pz, double alpha,
+                                                         double alpha_z, const double* __restrict__ mu_dev,
+                                                         int s_from_ci, double* __restrict__ in,
+                                                         double* __restrict__ s, double* __restrict__ y,
+                                                         double* __restrict__ z) {
+  const double mu = mu_dev[0];
+  const int stride = gridDim.x * blockDim.x;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = t0; j < K.n; j += stride) in[j] = in[j] + alpha * p[j];
+  for (int r = t0; r < K.m_e; r += stride) {
+    const double v = y[r] + alpha_z * (-p[K.n + r]);
+    y[r] = v;
+    in[K.n + r] = v;
+  }
+  for (int r = t0; r < K.m_i; r += stride) {
+    const double sn = s_from_ci ? Vt[K.off_ci + r] : s[r] + alpha * ps[r];
+    double zn = z[r] + alpha_z * pz[r];
+    constexpr double kappa = 1e10;
+    const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
+    zn = zn < lo ? lo : (zn > hi ? hi : zn);
+    s[r] = sn;
+    z[r] = zn;
+    in[K.n + K.m_e + r] = zn;
+  }
+}
+
+// Second-order correction accumulators (interior_point.hpp:590-600):
+//   c_e_soc = alpha c_e_soc + trial c_e,  (c_i − s)_soc = alpha (c_i − s)_soc + trial c_i − trial s
+// first != 0: start from the current c_e, c_i − s (in V).
+__global__ __launch_bounds__(256) void ipm_soc_accumulate_kernel(KktDev K, const double* __restrict__ V,
+                                                                 const double* __restrict__ Vt,
+                                                                 const double* __restrict__ s,
+                                                                 const double* __restrict__ ps, double alpha,
+                                                                 int first, int s_from_ci,
+                                                                 double* __restrict__ soc_ce,
+                                                                 double* __restrict__ soc_cims) {
+  const int stride = gridDim.x * blockDim.x;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int r = t0; r < K.m_e; r += stride) {
+    const double prev = first ? V[K.off_ce + r] : soc_ce[r];
+    soc_ce[r] = alpha * prev + Vt[K.off_ce + r];
+  }
+  for (int r = t0; r < K.m_i; r += stride) {
+    const double prev = first ? V[K.off_ci + r] - s[r] : soc_cims[r];
+    const double ct = Vt[K.off_ci + r];
+    const double st = s_from_ci ? ct : s[r] + alpha * ps[r];
+    soc_cims[r] = alpha * prev + ct - st;
+  }
+}
+
+// Right-hand side of a second-order correction (interior_point.hpp:611-616):
+//   [−g + A_eᵀ y + A_iᵀ (μ/s − Σ (c_i − s)_soc);  −c_e_soc]
+__global__ __launch_bounds__(256) void ipm_soc_rhs_kernel(KktDev K, const double* __restrict__ V,
+                                                          const double* __restrict__ s,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ z,
+                                                          const double* __restrict__ mu_dev,
+                                                          const double* __restrict__ soc_ce,
+                                                          const double* __restrict__ soc_cims,
+                                                          double* __restrict__ rhs) {
+  const double m = mu_dev[0];
+  const double* Ae = V + K.off_Ae;
+  const double* Ai = V + K.off_Ai;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K.dim; j += gridDim.x * blockDim.x) {
+    if (j >= K.n) {
+      rhs[j] = -soc_ce[j - K.n];
+      continue;
+    }
+    const int gs = K.g_src[j];
+    double acc = -(gs >= 0 ? V[gs] : 0.0);
+    double aey = 0.0;
+    for (int q = K.ae_colptr[j]; q < K.ae_colptr[j + 1]; ++q) aey += Ae[q] * y[K.ae_rowidx[q]];
+    acc += aey;
+    double ait = 0.0;
+    for (int q = K.ai_colptr[j]; q < K.ai_colptr[j + 1]; ++q) {
+      const int r = K.ai_rowidx[q];
+      const double sinv = 1.0 / s[r];
+      ait += Ai[q] * (m * sinv - (sinv * z[r]) * soc_cims[r]);
+    }
+    rhs[j] = acc + ait;
+  }
+}
+
+// p_s, p_z of a second-order correction (interior_point.hpp:625-630): the back-substitution
+// with (c_i − s)_soc in place of c_i − s.
+__global__ __launch_bounds__(256) void ipm_soc_backsub_kernel(KktDev K, const double* __restrict__ V,
+                                                              const double* __restrict__ p,
+                                                              const double* __restrict__ s,
+                                                              const double* __restrict__ z,
+                                                              const double* __restrict__ mu_dev,
+                                                              const double* __restrict__ soc_cims,
+                                                              double* __restrict__ ps, double* __restrict__ pz) {
+  const double m = mu_dev[0];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < K.m_i; r += gridDim.x * blockDim.x) {
+    double aipx = 0.0;
+    for (int q = K.ai_rowptr[r]; q < K.ai_rowptr[r + 1]; ++q) aipx += V[K.ai_src[q]] * p[K.ai_col[q]];
+    const double sinv = 1.0 / s[r];
+    const double p_s = soc_cims[r] + aipx;
+    ps[r] = p_s;
+    pz[r] = m * sinv - z[r] - (sinv * z[r]) * p_s;
+  }
+}
+
+// Everything the host needs to decide what happens next, from the freshly swept V at the
+// current iterate (see IpmErrOut), in two launches: workgroups of 256 lanes reduce their
+// slice of the columns / rows into `partial[block][kIpmErrQ]`, one small workgroup folds
+// the partials in block order.  scales = [d_f | d_ce | d_ci].
+constexpr int kIpmErrQ = 23;
+constexpr int kIpmErrThreads = 256;
+namespace ipm_err {
+enum {
+  DUAL_U, SZ_MAX_U, CE_U, CIS_U, Y1_U, Z1_U, DUAL, SZ_MIN, SZ_MAX, CE, CIS, Y1, Z1, VIOL, LOGSUM,
+  AETCE, CESQ, AITCP, CPSQ, XINF, SINF, FINITE, CIPOS
+};
+#define SLPX_IPM_ERR_OPS                                                                              \
+  {IPM_MAX, IPM_MAX, IPM_MAX, IPM_MAX, IPM_SUM, IPM_SUM, IPM_MAX, IPM_MIN, IPM_MAX, IPM_MAX, IPM_MAX, \
+   IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_MAX, IPM_MAX, IPM_MIN, \
+   IPM_MIN}
+}  // namespace ipm_err
+
+__global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
+    KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
+    const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
+    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial) {
+  using namespace ipm_err;
+  constexpr int NQ = kIpmErrQ;
+  __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
+  double acc[NQ];
+  const int ops[NQ] = SLPX_IPM_ERR_OPS;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = ops[q] == IPM_MIN ? 1.0 : 0.0;
+  acc[SZ_MIN] = 1e300;
+  const int t0 = blockIdx.x * kIpmErrThreads + threadIdx.x, stride = gridDim.x * kIpmErrThreads;
+  const double inv_f = 1.0 / scales[0];
+  const double* d_ce = scales + 1;
+  const double* d_ci = scales + 1 + K.m_e;
+  const double* ce = V + K.off_ce;
+  const double* ci = V + K.off_ci;
+  const double* Ae = V + K.off_Ae;
+  const double* Ai = V + K.off_Ai;
+  for (int j = t0; j < K.n; j += stride) {
+    const int gs = K.g_src[j];
+    const double g = gs >= 0 ? V[gs] : 0.0;
+    double dual = g, dual_u = inv_f * g, aetce = 0.0, aitcp = 0.0;
+    double a1 = 0.0, a1u = 0.0;
+    for (int q = K.ae_colptr[j]; q < K.ae_colptr[j + 1]; ++q) {
+      const int r = K.ae_rowidx[q];
+      const double a = Ae[q], dr = d_ce[r];
+      a1 += a * y[r];
+      a1u += ((1.0 / dr) * a) * (dr * y[r] * inv_f);
+      aetce += a * ce[r];
+    }
+    dual -= a1;
+    dual_u -= a1u;
+    double a2 = 0.0, a2u = 0.0;
+    for (int q = K.ai_colptr[j]; q < K.ai_colptr[j + 1]; ++q) {
+      const int r = K.ai_rowidx[q];
+      const double a = Ai[q], dr = d_ci[r];
+      a2 += a * z[r];
+      a2u += ((1.0 / dr) * a) * (dr * z[r] * inv_f);
+      aitcp += a * fmin(ci[r], 0.0);
+    }
+    dual -= a2;
+    dual_u -= a2u;
+    acc[DUAL] = fmax(acc[DUAL], fabs(dual));
+    acc[DUAL_U] = fmax(acc[DUAL_U], fabs(dual_u));
+    acc[AETCE] += aetce * aetce;
+    acc[AITCP] += aitcp * aitcp;
+    const double xj = x[j];
+    acc[XINF] = fmax(acc[XINF], fabs(xj));
+    if (!isfinite(xj)) acc[FINITE] = 0.0;
+  }
+  for (int r = t0; r < K.m_e; r += stride) {
+    const double c = ce[r], dr = d_ce[r], yr = y[r];
+    acc[CE] = fmax(acc[CE], fabs(c));
+    acc[CE_U] = fmax(acc[CE_U], fabs((1.0 / dr) * c));
+    acc[Y1] += fabs(yr);
+    acc[Y1_U] += fabs(dr * yr * inv_f);
+    acc[CESQ] += c * c;
+    acc[VIOL] += fabs(c);
+    if (!isfinite(c)) acc[FINITE] = 0.0;
+  }
+  for (int r = t0; r < K.m_i; r += stride) {
+    const double c = ci[r], dr = d_ci[r], sr = s[r], zr = z[r];
+    const double inv = 1.0 / dr, su = inv * sr, zu = dr * zr * inv_f;
+    acc[CIS] = fmax(acc[CIS], fabs(c - sr));
+    acc[CIS_U] = fmax(acc[CIS_U], fabs(inv * c - su));
+    acc[SZ_MIN] = fmin(acc[SZ_MIN], sr * zr);
+    acc[SZ_MAX] = fmax(acc[SZ_MAX], sr * zr);
+    acc[SZ_MAX_U] = fmax(acc[SZ_MAX_U], fabs(su * zu));
+    acc[Z1] += fabs(zr);
+    acc[Z1_U] += fabs(zu);
+    const double cp = fmin(c, 0.0);
+    acc[CPSQ] += cp * cp;
+    acc[VIOL] += fabs(c - sr);
+    acc[LOGSUM] += log(sr);
+    acc[SINF] = fmax(acc[SINF], fabs(sr));
+    if (!isfinite(sr) || !isfinite(c)) acc[FINITE] = 0.0;
+    if (!(c > 0.0)) acc[CIPOS] = 0.0;
+  }
+  if (check_all_V)
+    for (int k = t0; k < nV; k += stride)
+      if (!isfinite(V[k])) acc[FINITE] = 0.0;
+  block_reduce<NQ, kIpmErrThreads>(acc, ops, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) partial[blockIdx.x * NQ + q] = acc[q];
+  }
+}
+
+__global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,
+                                                             const double* __restrict__ partial, int n_blocks,
+                                                             IpmErrOut* __restrict__ out) {
+  using namespace ipm_err;
+  constexpr int NQ = kIpmErrQ;
+  __shared__ double tot[NQ];
+  const int ops[NQ] = SLPX_IPM_ERR_OPS;
+  const int q = threadIdx.x;
+  if (q < NQ) {
+    int op = ops[0];
+#pragma unroll
+    for (int k = 1; k < NQ; ++k)
+      if (q == k) op = ops[k];
+    double v = partial[q];
+    for (int b = 1; b < n_blocks; ++b) v = ipm_combine(op, v, partial[b * NQ + q]);
+    tot[q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out->dual_inf_u = tot[DUAL_U];
+    out->sz_max_u = tot[SZ_MAX_U];
+    out->ce_inf_u = tot[CE_U];
+    out->cis_inf_u = tot[CIS_U];
+    out->y1_u = tot[Y1_U];
+    out->z1_u = tot[Z1_U];
+    out->dual_inf = tot[DUAL];
+    out->sz_min = K.m_i ? tot[SZ_MIN] : 0.0;
+    out->sz_max = tot[SZ_MAX];
+    out->ce_inf = tot[CE];
+    out->cis_inf = tot[CIS];
+    out->y1 = tot[Y1];
+    out->z1 = tot[Z1];
+    const double f = V[K.off_f];
+    out->f = f;
+    out->viol = tot[VIOL];
+    out->logsum = tot[LOGSUM];
+    out->aetce_sq = tot[AETCE];
+    out->ce_sq = tot[CESQ];
+    out->aitcp_sq = tot[AITCP];
+    out->cp_sq = tot[CPSQ];
+    out->x_inf = tot[XINF];
+    out->s_inf = tot[SINF];
+    out->finite = (tot[FINITE] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
+    out->ci_all_pos = tot[CIPOS];
+  }
+}
+
+}  // namespace slpx

@@ -19,6 +19,7 @@
 #include "device.hpp"
 #include "ldlt_kernels.h"
 #include "tape_jit.hpp"
+#include "ipm_kernels.h"
 #include "tape_kernels.h"
 #include "tape_ops.h"
 
@@ -403,6 +404,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 DeviceNlp::~DeviceNlp() {
   if (m_h_reg) (void)hipHostFree(m_h_reg);
   if (m_h_stats) (void)hipHostFree(m_h_stats);
+  if (m_ipm_host) (void)hipHostFree(m_ipm_host);
   for (auto& row : m_step_graph)
     for (hipGraphExec_t& e : row)
       if (e) (void)hipGraphExecDestroy(e);
@@ -430,6 +432,8 @@ void DeviceNlp::set_scaling(const std::vector<double>& scales) {
   for (int b = 0; b < m_batch; ++b)
     std::copy(m_V_static.begin(), m_V_static.end(), all.begin() + static_cast<size_t>(b) * s.nV);
   SLPX_HIP_CHECK(hipMemcpy(m_V.p, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (m_ipm)
+    SLPX_HIP_CHECK(hipMemcpy(m_V_trial.p, m_V_static.data(), m_V_static.size() * sizeof(double), hipMemcpyHostToDevice));
 }
 
 void DeviceNlp::upload_x(const double* x) {
@@ -478,6 +482,8 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
   const TapeDev view = t.view();
   const int in_stride = m_s_ref.n_inputs(), v_stride = m_s_ref.nV;
   const unsigned long long sstride = m_scratch.n / m_batch;
+  const double* in_p = m_in_override ? m_in_override : m_in.p;
+  double* V_p = m_V_override ? m_V_override : m_V.p;
   // basic_ops: the program only uses + - * / sin cos sqrt and the piecewise ops, so
   // the kernel specialization without pow/exp/log/erf/... (fewer VGPRs, less code)
   // generated template kernels: one lane per task instance (tape_jit.hpp)
@@ -488,11 +494,11 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const unsigned* inst = t.tmpl_inst.p;
     const unsigned* leaf_src = view.leaf_src;
     const double* consts = view.consts;
-    const double* in = m_in.p;
+    const double* in = in_p;
     int in_stride_arg = in_stride;
     const double* in_scale = m_in_scale.p;
     const double* scales = m_scales.p;
-    double* V = m_V.p;
+    double* V = V_p;
     int v_stride_arg = v_stride;
     const unsigned* vout_dst = view.vout_dst;
     const int* vout_scale = view.vout_scale;
@@ -507,24 +513,31 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;
   if (t.n_small)
     hipLaunchKernelGGL(small_fn, dim3(t.n_small, m_batch), dim3(64), t.small_lds, small_stream, view,
-                       t.small_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
+                       t.small_list.p, in_p, in_stride, m_in_scale.p, m_scales.p, V_p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_large)
     hipLaunchKernelGGL(large_fn, dim3(t.n_large, m_batch), dim3(256), t.large_lds, other, view,
-                       t.large_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p, v_stride,
+                       t.large_list.p, in_p, in_stride, m_in_scale.p, m_scales.p, V_p, v_stride,
                        reverse ? 1 : 0);
   if (t.n_global)
     hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, other,
-                       view, t.global_list.p, m_in.p, in_stride, m_in_scale.p, m_scales.p, m_V.p,
+                       view, t.global_list.p, in_p, in_stride, m_in_scale.p, m_scales.p, V_p,
                        v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
   if (m_reduces.n)
     hipLaunchKernelGGL(tape_reduce_kernel, dim3(static_cast<uint32_t>(m_reduces.n), m_batch), dim3(64), 0,
-                       small_stream, m_reduces.p, m_scales.p, m_V.p, v_stride);
+                       small_stream, m_reduces.p, m_scales.p, V_p, v_stride);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
 void DeviceNlp::sweep_full() { launch_tape(m_full, true); }
 void DeviceNlp::sweep_values() { launch_tape(m_values, false); }
+void DeviceNlp::sweep_values_trial() {
+  m_in_override = m_trial_in.p;
+  m_V_override = m_V_trial.p;
+  launch_tape(m_values, false);
+  m_in_override = nullptr;
+  m_V_override = nullptr;
+}
 
 static inline int grid_for(int work, int block, int cap = 2048) {
   return std::max(1, std::min((work + block - 1) / block, cap));
@@ -757,6 +770,120 @@ void DeviceNlp::backsub_and_publish(const LdltStats* stats_src) {
                      dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p,
                      m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr);
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+// ============================================================================
+// Interior-point iteration on the device (ipm_kernels.h)
+// ============================================================================
+
+void DeviceNlp::ipm_enable() {
+  if (m_ipm) return;
+  if (m_batch != 1) throw std::runtime_error("slpx: the device-resident IPM iteration handles one problem");
+  const NlpStructure& s = m_s_ref;
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  m_trial_in.alloc(s.n_inputs());
+  SLPX_HIP_CHECK(hipMemcpy(m_trial_in.p, m_in.p, s.n_inputs() * sizeof(double), hipMemcpyDeviceToDevice));
+  m_V_trial.alloc(s.nV);
+  // the trial V starts as a copy of V: static entries in place, the swept ones overwritten
+  SLPX_HIP_CHECK(hipMemcpy(m_V_trial.p, m_V.p, static_cast<size_t>(s.nV) * sizeof(double), hipMemcpyDeviceToDevice));
+  m_soc_ce.alloc(std::max(1, s.m_e));
+  m_soc_cims.alloc(std::max(1, s.m_i));
+  m_p_keep.alloc(m_kdev.dim);
+  m_ps_keep.alloc(std::max(1, s.m_i));
+  m_pz_keep.alloc(std::max(1, s.m_i));
+  m_ipm_alpha.alloc(2);
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_ipm_host), sizeof(IpmHost)));
+  std::memset(m_ipm_host, 0, sizeof(IpmHost));
+  m_ipm = true;
+}
+
+void DeviceNlp::ipm_set_error_scaling(const std::vector<double>& scales) {
+  if (static_cast<int>(scales.size()) != m_s_ref.n_scales())
+    throw std::runtime_error("ipm_set_error_scaling: wrong length");
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  m_ipm_scales.upload(scales);
+}
+
+void DeviceNlp::wait() {
+  hipError_t st;
+  while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+  }
+  SLPX_HIP_CHECK(st);
+}
+
+void DeviceNlp::ipm_direction(double tau) {
+  hipLaunchKernelGGL(ipm_direction_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V.p, m_in.p, m_s.p,
+                     m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_ipm_alpha.p, &m_ipm_host->dir);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_trial_point(double alpha) {
+  hipLaunchKernelGGL(ipm_trial_point_kernel, dim3(grid_for(m_kdev.n, 256)), dim3(256), 0, m_stream, m_kdev.n,
+                     m_in.p, m_p.p, alpha, m_trial_in.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_trial_metrics(double alpha, bool s_from_ci) {
+  hipLaunchKernelGGL(ipm_trial_metrics_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V_trial.p,
+                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_commit(double alpha, double alpha_z, bool s_from_ci) {
+  const int work = std::max({m_kdev.n, m_kdev.m_e, m_kdev.m_i, 1});
+  hipLaunchKernelGGL(ipm_commit_kernel, dim3(grid_for(work, 256)), dim3(256), 0, m_stream, m_kdev, m_V_trial.p,
+                     m_p.p, m_ps.p, m_pz.p, alpha, alpha_z, m_mu.p, s_from_ci ? 1 : 0, m_in.p, m_s.p, m_y.p,
+                     m_z.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_errors(bool check_all_V) {
+  const int work = std::max({m_kdev.n, m_kdev.m_e, m_kdev.m_i, 1});
+  const int blocks = grid_for(work, kIpmErrThreads, 256);
+  if (m_ipm_partial.n < static_cast<size_t>(blocks) * kIpmErrQ) m_ipm_partial.alloc(static_cast<size_t>(256) * kIpmErrQ);
+  hipLaunchKernelGGL(ipm_error_partial_kernel, dim3(blocks), dim3(kIpmErrThreads), 0, m_stream, m_kdev, m_V.p,
+                     m_s_ref.nV, m_in.p, m_s.p, m_y.p, m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0,
+                     m_ipm_partial.p);
+  hipLaunchKernelGGL(ipm_error_final_kernel, dim3(1), dim3(64), 0, m_stream, m_kdev, m_V.p, m_ipm_partial.p,
+                     blocks, &m_ipm_host->err);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_soc_accumulate(double alpha, bool first, bool s_from_ci) {
+  const int work = std::max({m_kdev.m_e, m_kdev.m_i, 1});
+  hipLaunchKernelGGL(ipm_soc_accumulate_kernel, dim3(grid_for(work, 256)), dim3(256), 0, m_stream, m_kdev, m_V.p,
+                     m_V_trial.p, m_s.p, m_ps.p, alpha, first ? 1 : 0, s_from_ci ? 1 : 0, m_soc_ce.p,
+                     m_soc_cims.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_soc_rhs() {
+  hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(grid_for(m_kdev.dim, 256)), dim3(256), 0, m_stream, m_kdev, m_V.p,
+                     m_s.p, m_y.p, m_z.p, m_mu.p, m_soc_ce.p, m_soc_cims.p, m_rhs.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_soc_backsub() {
+  if (m_kdev.m_i == 0) return;
+  hipLaunchKernelGGL(ipm_soc_backsub_kernel, dim3(grid_for(m_kdev.m_i, 256)), dim3(256), 0, m_stream, m_kdev,
+                     m_V.p, m_p.p, m_s.p, m_z.p, m_mu.p, m_soc_cims.p, m_ps.p, m_pz.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_save_direction() {
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_p_keep.p, m_p.p, m_kdev.dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  if (m_kdev.m_i) {
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_ps_keep.p, m_ps.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_pz_keep.p, m_pz.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  }
+}
+
+void DeviceNlp::ipm_restore_direction() {
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_p.p, m_p_keep.p, m_kdev.dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  if (m_kdev.m_i) {
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_ps.p, m_ps_keep.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_pz.p, m_pz_keep.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  }
 }
 
 }  // namespace slpx

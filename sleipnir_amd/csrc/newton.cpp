@@ -68,6 +68,7 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
     if (solve_speculatively) {
       m_dev->solve_after_factor();
       m_dev->backsub();
+      if (m_after_attempt) m_after_attempt();
     }
   };
   const int n = m_s.n, m_e = m_s.m_e;

@@ -9,6 +9,7 @@
 // factorization attempt inside it is a device launch.
 #pragma once
 
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -77,6 +78,10 @@ class NewtonSystem {
   const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
   const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
   int last_factorizations() const { return m_last_factorizations; }
+  // Work enqueued behind every speculative solve of compute(true) — BEFORE the host reads
+  // the inertia counters, so it costs no extra synchronization when the attempt is accepted
+  // (the interior-point driver puts its step-size / trial-point kernels here).
+  void set_after_attempt(std::function<void()> fn) { m_after_attempt = std::move(fn); }
 
   // One full Newton step on device-resident state: AD refresh, KKT lhs/rhs,
   // regularized factorization, solve, back-substitution
@@ -95,6 +100,7 @@ class NewtonSystem {
   double m_gamma_min = 1e-10;
   std::vector<double> m_prev_delta, m_prev_gamma;
   int m_last_factorizations = 0;
+  std::function<void()> m_after_attempt;
 };
 
 }  // namespace slpx

@@ -1,0 +1,213 @@
+"""the interior-point iteration AROUND the Newton step on the
+device (sleipnir_amd/csrc/ipm_kernels.h through slpx_ipm_* of include/slpx.h).
+
+1. every scalar the kernels reduce is compared with the same formula in numpy on the
+   downloaded vectors (interior_point.hpp:488-509, util/fraction_to_the_boundary_rule.hpp,
+   util/filter.hpp:30-60, util/kkt_error.hpp:92-146, util/is_locally_infeasible.hpp);
+2. whole solves with the iterate resident on the device agree with the host-resident
+   driver (SLPX_IPM_RESIDENT=0) in exit status and solution.
+Tolerances: sums of n terms in a different order — 1e-12 relative; min / max — exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import sleipnir_amd as sa
+from tests.support import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def csc_to_dense_T_mul(colptr, rowidx, vals, v, n):
+    """(Aᵀ v)[c] for A in CSC."""
+    out = np.zeros(n)
+    for c in range(n):
+        lo, hi = colptr[c], colptr[c + 1]
+        out[c] = np.dot(vals[lo:hi], v[rowidx[lo:hi]])
+    return out
+
+
+def ftb(x, p, tau):
+    m = p < 0
+    return min(1.0, np.min(-tau / p[m] * x[m])) if m.any() else 1.0
+
+
+@pytest.fixture(scope="module")
+def stepped():
+    N = 40
+    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    system = sa.System(pp)
+    info = dict(system.info)
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
+    info.update(off_f=0, off_ce=1, off_ci=1 + me)  # V = [f | c_e | c_i | g | ...] (nlp.hpp)
+    x0 = pp.get_x()
+    rng = np.random.default_rng(cases.SEED)
+    scales = np.concatenate([[0.37], rng.uniform(0.2, 1.0, me), rng.uniform(0.2, 1.0, mi)])
+    system.set_scaling(scales)
+    x, s, y, z, mu = cases.newton_state("interior", x0, n, me, mi, scales[0])
+    system.set_state(x, s, y, z, np.array([mu]))
+    assert system.newton_step(True)[0] == 0
+    return dict(pp=pp, system=system, info=info, scales=scales, x=x, s=s, y=y, z=z, mu=mu)
+
+
+def g_dense(system, info, V):
+    cp, ri = system.pattern(0)
+    g = np.zeros(info["n"])
+    vals = V[info["off_g"]:info["off_g"] + info["nnz_g"]]
+    for c in range(info["n"]):
+        g[c] = vals[cp[c]:cp[c + 1]].sum()
+    return g
+
+
+def test_direction_trial_commit(stepped):
+    st = stepped
+    system, info = st["system"], st["info"]
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
+    x, s, y, z, mu = st["x"], st["s"], st["y"], st["z"], st["mu"]
+    V = system.get("V")[0]
+    p = system.get("p")[0]
+    p_s, p_z = system.get("p_s")[0], system.get("p_z")[0]
+    p_x, p_y = p[:n], -p[n:]
+    tau = 0.99
+
+    d = system.ipm_direction(tau)
+    assert d["alpha_max"] == ftb(s, p_s, tau)
+    assert d["alpha_z"] == ftb(z, p_z, tau)
+    D_phi = g_dense(system, info, V) @ p_x - mu * np.sum((1.0 / s) * p_s)
+    assert d["D_phi"] == pytest.approx(D_phi, rel=1e-12, abs=1e-12)
+
+    for alpha in (d["alpha_max"], 0.25 * d["alpha_max"]):
+        t = system.ipm_trial(alpha)
+        # reference: the same forward sweep through the ordinary entry points
+        system.set_state(x=x + alpha * p_x)
+        system.sweep(False)
+        Vt = system.get("V")[0]
+        system.set_state(x=x)
+        ce = Vt[info["off_ce"]:info["off_ce"] + me]
+        ci = Vt[info["off_ci"]:info["off_ci"] + mi]
+        s_t = s + alpha * p_s
+        assert t["finite"] == 1.0
+        # (trial x differs in the last bit: the device fuses x + alpha * p into one FMA)
+        assert t["f"] == pytest.approx(Vt[info["off_f"]], rel=1e-12)
+        assert t["viol"] == pytest.approx(np.abs(ce).sum() + np.abs(ci - s_t).sum(), rel=1e-12)
+        assert t["logsum"] == pytest.approx(np.log(s_t).sum(), rel=1e-12, abs=1e-12)
+        # feasible-IPM variant: trial s = trial c_i (only meaningful where c_i > 0; the
+        # kernel's log of a negative entry is NaN exactly like the host's)
+        if (ci > 0).all():
+            tf = system.ipm_trial(alpha, s_from_ci=True)
+            assert tf["viol"] == pytest.approx(np.abs(ce).sum(), rel=1e-12)
+
+    alpha, alpha_z = d["alpha_max"], d["alpha_z"]
+    system.ipm_trial(alpha)
+    system.ipm_commit(alpha, alpha_z)
+    s_new = s + alpha * p_s
+    z_new = np.clip(z + alpha_z * p_z, 1e-10 * mu / s_new, 1e10 * mu / s_new)
+    # (the device contracts a + alpha * b into one fused multiply-add: last-bit differences)
+    xc, sc, yc, zc = (system.get(k)[0] for k in "xsyz")
+    tight = dict(rtol=1e-14, atol=1e-300)
+    assert np.allclose(xc, x + alpha * p_x, **tight)
+    assert np.allclose(sc, s_new, **tight)
+    assert np.allclose(yc, y + alpha_z * p_y, **tight)
+    assert np.allclose(zc, z_new, **tight)
+    # the committed iterate is what the next sweep differentiates at
+    system.sweep(True)
+    V_dev = system.get("V")[0]
+    system.set_state(xc, sc, yc, zc)
+    system.sweep(True)
+    assert np.array_equal(V_dev, system.get("V")[0])
+    st.update(x=xc, s=sc, y=yc, z=zc)
+
+
+def test_error_reductions(stepped):
+    st = stepped
+    system, info, scales = st["system"], st["info"], st["scales"]
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
+    x, s, y, z = st["x"], st["s"], st["y"], st["z"]
+    system.set_state(x, s, y, z)
+    system.sweep(True)
+    V = system.get("V")[0]
+    e = system.ipm_errors(scales)
+
+    g = g_dense(system, info, V)
+    ce = V[info["off_ce"]:info["off_ce"] + me]
+    ci = V[info["off_ci"]:info["off_ci"] + mi]
+    ae_cp, ae_ri = system.pattern(1)
+    ai_cp, ai_ri = system.pattern(2)
+    Ae = V[info["off_Ae"]:info["off_Ae"] + info["nnz_Ae"]]
+    Ai = V[info["off_Ai"]:info["off_Ai"] + info["nnz_Ai"]]
+    aet = lambda v, vals=Ae: csc_to_dense_T_mul(ae_cp, ae_ri, vals, v, n)
+    ait = lambda v, vals=Ai: csc_to_dense_T_mul(ai_cp, ai_ri, vals, v, n)
+
+    rel = dict(rel=1e-12, abs=1e-13)
+    # scaled (kkt_error.hpp:92-146 inputs)
+    assert e["dual_inf"] == pytest.approx(np.abs(g - aet(y) - ait(z)).max(), **rel)
+    assert e["sz_min"] == (s * z).min() and e["sz_max"] == (s * z).max()
+    assert e["ce_inf"] == np.abs(ce).max() and e["cis_inf"] == np.abs(ci - s).max()
+    assert e["y1"] == pytest.approx(np.abs(y).sum(), **rel)
+    assert e["z1"] == pytest.approx(np.abs(z).sum(), **rel)
+    # un-scaled (kkt_error.hpp:216-251)
+    d_f, d_ce, d_ci = scales[0], scales[1:1 + me], scales[1 + me:]
+    yu, zu, su = d_ce * y / d_f, d_ci * z / d_f, s / d_ci
+    Ae_u = Ae / d_ce[ae_ri]
+    Ai_u = Ai / d_ci[ai_ri]
+    dual_u = g / d_f - aet(yu, Ae_u) - ait(zu, Ai_u)
+    assert e["dual_inf_u"] == pytest.approx(np.abs(dual_u).max(), **rel)
+    assert e["sz_max_u"] == pytest.approx(np.abs(su * zu).max(), **rel)
+    assert e["ce_inf_u"] == pytest.approx(np.abs(ce / d_ce).max(), **rel)
+    assert e["cis_inf_u"] == pytest.approx(np.abs(ci / d_ci - su).max(), **rel)
+    assert e["y1_u"] == pytest.approx(np.abs(yu).sum(), **rel)
+    assert e["z1_u"] == pytest.approx(np.abs(zu).sum(), **rel)
+    # filter entry of the current iterate
+    assert e["f"] == V[info["off_f"]]
+    assert e["viol"] == pytest.approx(np.abs(ce).sum() + np.abs(ci - s).sum(), **rel)
+    assert e["logsum"] == pytest.approx(np.log(s).sum(), **rel)
+    # local infeasibility, divergence
+    cm = np.minimum(ci, 0.0)
+    assert e["aetce_sq"] == pytest.approx(np.sum(aet(ce) ** 2), **rel)
+    assert e["ce_sq"] == pytest.approx(np.sum(ce ** 2), **rel)
+    assert e["aitcp_sq"] == pytest.approx(np.sum(ait(cm) ** 2), **rel)
+    assert e["cp_sq"] == pytest.approx(np.sum(cm ** 2), **rel)
+    assert e["x_inf"] == np.abs(x).max() and e["s_inf"] == np.abs(s).max()
+    assert e["finite"] == 1.0
+    assert e["ci_all_pos"] == float((ci > 0).all())
+
+    # a non-finite iterate is reported
+    xb = x.copy()
+    xb[3] = np.inf
+    system.set_state(x=xb)
+    assert system.ipm_errors(scales)["finite"] == 0.0
+    system.set_state(x=x)
+
+
+def _solve(make, resident):
+    old = os.environ.get("SLPX_IPM_RESIDENT")
+    os.environ["SLPX_IPM_RESIDENT"] = "1" if resident else "0"
+    try:
+        pp = make()
+        status, rep = pp.solve()
+        return status, rep, pp.get_x(), pp.duals()
+    finally:
+        if old is None:
+            del os.environ["SLPX_IPM_RESIDENT"]
+        else:
+            os.environ["SLPX_IPM_RESIDENT"] = old
+
+
+@pytest.mark.parametrize("name,make", [
+    ("cart_pole_50", lambda: sa.Problem.cart_pole(50, 0.1)),
+    ("cart_pole_100", lambda: sa.Problem.cart_pole(100, 0.05)),   # restoration on the way
+    ("flywheel_50", lambda: sa.Problem.flywheel(50, 0.005)),
+])
+def test_resident_solve_matches_host_driver(name, make):
+    st_h, rep_h, x_h, duals_h = _solve(make, resident=False)
+    st_d, rep_d, x_d, duals_d = _solve(make, resident=True)
+    assert st_d == st_h == 0
+    assert rep_d["final_error"] <= 1e-8
+    scale = max(1.0, np.abs(x_h).max())
+    assert np.abs(x_d - x_h).max() <= 1e-5 * scale
+    # Same algorithm, different summation order in the norms: the first iterations coincide
+    # line for line, later ones need not (ill-conditioned early systems amplify last-bit
+    # differences; cart-pole N=50 takes 331 iterations one way and 169 the other) — both end
+    # at the same solution.
+    assert rep_d["iterations"] > 0 and rep_h["iterations"] > 0

@@ -100,6 +100,9 @@ typedef struct slpx_report {
   double t_setup, t_kkt_build, t_kkt_decomp, t_kkt_solve, t_line_search, t_ad_refresh, t_total;
   double t_compile; /* graph -> tape/KKT plan/symbolic LDLT + upload */
   int32_t restorations; /* feasibility-restoration phases entered (feasibility_restoration.hpp:347) */
+  int32_t restoration_iterations; /* of `iterations`, those spent inside them */
+  double t_restoration_setup; /* compiling the restoration system (first phase only); in t_total */
+  double t_restoration;       /* the restoration iterations; in t_total */
 } slpx_report;
 
 /* Problem::solve.  Returns slp::ExitStatus (solver/exit_status.hpp:13-43):

@@ -54,7 +54,9 @@ class Report(ctypes.Structure):
                 ("t_kkt_build", ctypes.c_double), ("t_kkt_decomp", ctypes.c_double),
                 ("t_kkt_solve", ctypes.c_double), ("t_line_search", ctypes.c_double),
                 ("t_ad_refresh", ctypes.c_double), ("t_total", ctypes.c_double),
-                ("t_compile", ctypes.c_double), ("restorations", ctypes.c_int32)]
+                ("t_compile", ctypes.c_double), ("restorations", ctypes.c_int32),
+                ("restoration_iterations", ctypes.c_int32), ("t_restoration_setup", ctypes.c_double),
+                ("t_restoration", ctypes.c_double)]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

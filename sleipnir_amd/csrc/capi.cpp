@@ -111,7 +111,8 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
       *report = slpx_report{r.iterations,    r.factorizations, r.solves,       r.value_sweeps,
                             r.delta,         r.gamma,          r.final_error,  r.t_setup,
                             r.t_kkt_build,   r.t_kkt_decomp,   r.t_kkt_solve,  r.t_line_search,
-                            r.t_ad_refresh,  r.t_total,        p->t_compile,   r.restorations};
+                            r.t_ad_refresh,  r.t_total,        p->t_compile,   r.restorations,
+                            r.restoration_iterations, r.t_restoration_setup, r.t_restoration};
     }
   });
   return rc == 0 ? status : rc;

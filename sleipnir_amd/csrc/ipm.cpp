@@ -1067,7 +1067,9 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
   compute_p_n(c_e, rho, fr_mu, p_e, n_e);
   compute_p_n(cis, rho, fr_mu, p_i, n_i);
 
+  const auto t_build = clk::now();
   NewtonSystem& fr = restoration_system(outer);
+  rep.t_restoration_setup += since(t_build);
   auto& R = outer.restoration();
   Graph& g = outer.graph();
   for (int k = 0; k < n; ++k) {
@@ -1100,8 +1102,12 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
   fr.device().set_scaling(Vec(fr.structure().n_scales(), 1.0));
 
   double mu_fr = fr_mu;
+  const int it_before = iterations;
+  const auto t_inner = clk::now();
   const ExitStatus status = ipm_core(fr, fr_scales, callbacks, options, true, fr_x, fr_s, fr_y, fr_z,
                                      mu_fr, iterations, rep, solve_start);
+  rep.restoration_iterations += iterations - it_before;
+  rep.t_restoration += since(t_inner);
 
   std::copy(fr_x.begin(), fr_x.begin() + n, x.begin());
   std::copy(fr_s.begin(), fr_s.begin() + m_i, s.begin());

@@ -63,11 +63,15 @@ struct SolveReport {
   int solves = 0;
   int value_sweeps = 0;
   int restorations = 0;
+  int restoration_iterations = 0;  // iterations spent inside feasibility restoration
   double delta = 0.0, gamma = 0.0;
   double final_error = 0.0;
   // wall-clock per phase, seconds (names follow interior_point.hpp:155-174)
   double t_setup = 0, t_kkt_build = 0, t_kkt_decomp = 0, t_kkt_solve = 0, t_line_search = 0,
          t_ad_refresh = 0, t_total = 0;
+  // feasibility restoration: compiling the restoration system (first call only), and the
+  // restoration iterations themselves (both are part of t_total)
+  double t_restoration_setup = 0, t_restoration = 0;
 };
 
 // Scaling at x0 (util/problem_scaling.hpp:100-107) from an unscaled V.

@@ -1,5 +1,7 @@
 #include "newton.hpp"
 
+#include "setup_timing.hpp"
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -14,8 +16,11 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   // SLPX_STEP_GRAPH=0 falls back to one launch per kernel (profilers that cannot see into
   // graph launches, A/B measurements)
   if (const char* env = std::getenv("SLPX_STEP_GRAPH")) m_opt.use_step_graph = env[0] != '0';
+  SetupLap lap;
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
+  lap("= AD structure + tape compile");
   m_k = build_kkt_plan(m_s);
+  lap("= KKT plan");
   // which diagonal entries of the unregularized lhs have any source at all
   std::vector<uint8_t> diag_has_source(m_k.dim, 0);
   for (int c = 0; c < m_k.dim; ++c)
@@ -29,7 +34,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
   m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
+  lap("= LDLT symbolic");
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
+  lap("= device upload + tape JIT");
   reset_regularization();
 }
 

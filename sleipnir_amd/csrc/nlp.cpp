@@ -1,5 +1,7 @@
 #include "nlp.hpp"
 
+#include "setup_timing.hpp"
+
 #include <unordered_map>
 
 #include <algorithm>
@@ -108,6 +110,7 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
                                  const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
                                  const TapeCompileOptions& opt) {
   NlpStructure s;
+  SetupLap lap;
   s.graph_nodes_before = g.size();
   s.n = static_cast<int>(x.size());
   s.m_e = static_cast<int>(c_e.size());
@@ -141,6 +144,7 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   }
   std::vector<NodeId> Hc_rows = g.gradient_tree(g.topological_sort(lag), x);
   s.graph_nodes_after = g.size();
+  lap("gradient trees (Hessian rows)");
 
   std::vector<double> adj;
   MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, adj);        // problem.hpp:535
@@ -148,6 +152,7 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, adj);
   MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, adj);     // problem.hpp:555
   MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, adj);     // problem.hpp:560
+  lap("row lists + patterns");
 
   s.g_pat = mg.pat;
   s.Ae = mAe.pat;
@@ -322,8 +327,11 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
     }
   }
 
+  lap("V layout, separable sums");
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);
+  lap("tape compile (full)");
   s.values = compile_tape(g, inputs, live_vouts, {}, opt);
+  lap("tape compile (values)");
   s.full.n_inputs = s.values.n_inputs = s.n_inputs();
   s.full.n_outputs = s.values.n_outputs = s.nV;
   return s;

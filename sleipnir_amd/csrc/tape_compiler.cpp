@@ -1,5 +1,7 @@
 #include "tape_compiler.hpp"
 
+#include "setup_timing.hpp"
+
 #include <algorithm>
 #include <numeric>
 #include <stdexcept>
@@ -72,6 +74,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
                          const std::vector<TapeRow>& rows, const TapeCompileOptions& opt) {
   TapeProgram prog;
 
+  SetupLap lap;
   // ---- A. working copy of everything reachable from the roots ---------------
   std::vector<NodeId> roots;
   for (auto& v : value_outs) roots.push_back(v.node);
@@ -98,8 +101,12 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
     std::sort(reach.begin(), reach.end());
   }
-  std::unordered_map<NodeId, int32_t> to_cg;
-  to_cg.reserve(reach.size() * 2);
+  // graph node -> working-copy node (-1: not reachable); a flat table, the lookups are hot
+  struct NodeTable {
+    std::vector<int32_t> v;
+    int32_t at(NodeId n) const { return v[n]; }
+    int32_t& operator[](NodeId n) { return v[n]; }
+  } to_cg{std::vector<int32_t>(g.size(), -1)};
   CG cg;
   for (NodeId n : reach) {
     int32_t l = g.a0[n] == kNull ? -1 : to_cg.at(g.a0[n]);
@@ -113,6 +120,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     prog.n_inputs = std::max(prog.n_inputs, idx + 1);
   }
 
+  lap("  tape: A working copy");
   // ---- B/C. rebalance long left-deep ADD chains ---------------------------
   if (opt.rebalance_sums) {
     std::vector<int32_t> uses(cg.size(), 0);
@@ -156,6 +164,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
   }
 
+  lap("  tape: B/C rebalance");
   // ---- liveness + levels (children may now have larger ids than parents) -----
   const size_t ncg = cg.size();
   std::vector<uint8_t> live(ncg, 0);
@@ -192,6 +201,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     level[n] = l + 1;
   }
 
+  lap("  tape: liveness + levels");
   // ---- rows: reference order, useful sets, slots, edges -------------------------
   struct Slot {
     int32_t row, node, level;
@@ -204,20 +214,25 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     int side;
   };
   std::vector<Slot> slots;
-  std::vector<std::vector<REdge>> slot_edges;  // per global slot
+  // edges INTO each slot, CSR over global slot ids (a slot's edges keep the order in which
+  // the reference's sweep meets the parents: list order, left operand before right)
+  std::vector<uint32_t> slot_edge_ptr{0};
+  std::vector<REdge> slot_edge_data;
+  auto n_slot_edges = [&](int32_t sl) { return static_cast<size_t>(slot_edge_ptr[sl + 1] - slot_edge_ptr[sl]); };
   std::vector<uint8_t> need_dl(ncg, 0), need_dr(ncg, 0);
   std::vector<int32_t> row_root_slot(rows.size(), -1);
   {
     std::vector<int32_t> slot_of(ncg, -1);
     std::vector<int32_t> out_dst(ncg, -1);
     std::vector<uint8_t> useful(ncg, 0);
+    std::vector<uint32_t> fill_pos;
     for (size_t ri = 0; ri < rows.size(); ++ri) {
       const TapeRow& row = rows[ri];
       if (row.root == kNull) continue;
       int32_t root = to_cg.at(row.root);
       for (auto& o : row.outputs) {
-        auto it = to_cg.find(o.wrt);
-        if (it != to_cg.end()) out_dst[it->second] = o.dst;
+        const int32_t w = to_cg.at(o.wrt);
+        if (w >= 0) out_dst[w] = o.dst;
       }
       std::vector<int32_t> top = reference_order(cg, root);
       for (auto it = top.rbegin(); it != top.rend(); ++it) {
@@ -227,24 +242,38 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         if (cg.a1[n] >= 0 && useful[cg.a1[n]]) u = true;
         useful[n] = u;
       }
+      const size_t row_slot0 = slots.size();
       for (int32_t n : top) {
         if (!useful[n]) continue;
         slot_of[n] = static_cast<int32_t>(slots.size());
         slots.push_back({static_cast<int32_t>(ri), n, 0, 0, 0, out_dst[n]});
-        slot_edges.emplace_back();
       }
       row_root_slot[ri] = slot_of[root];
+      // count, then fill (two passes over the row's list keep the per-slot edge order)
+      fill_pos.assign(slots.size() - row_slot0 + 1, 0);
+      for (int32_t p : top) {
+        if (!useful[p] || cg.is_leaf(p)) continue;
+        const int32_t l = cg.a0[p], r = cg.a1[p];
+        if (l >= 0 && useful[l]) ++fill_pos[slot_of[l] - row_slot0 + 1];
+        if (r >= 0 && useful[r]) ++fill_pos[slot_of[r] - row_slot0 + 1];
+      }
+      const uint32_t edge0 = static_cast<uint32_t>(slot_edge_data.size());
+      for (size_t k = 1; k < fill_pos.size(); ++k) {
+        fill_pos[k] += fill_pos[k - 1];
+        slot_edge_ptr.push_back(edge0 + fill_pos[k]);
+      }
+      slot_edge_data.resize(edge0 + fill_pos.back());
       for (int32_t p : top) {
         if (!useful[p] || cg.is_leaf(p)) continue;
         int32_t ps = slot_of[p];
         int32_t l = cg.a0[p], r = cg.a1[p];
         if (l >= 0 && useful[l]) {
-          slot_edges[slot_of[l]].push_back({ps, p, 0});
+          slot_edge_data[edge0 + fill_pos[slot_of[l] - row_slot0]++] = {ps, p, 0};
           need_dl[p] = 1;
           slots[slot_of[l]].level = std::max(slots[slot_of[l]].level, slots[ps].level + 1);
         }
         if (r >= 0 && useful[r]) {
-          slot_edges[slot_of[r]].push_back({ps, p, 1});
+          slot_edge_data[edge0 + fill_pos[slot_of[r] - row_slot0]++] = {ps, p, 1};
           need_dr[p] = 1;
           slots[slot_of[r]].level = std::max(slots[slot_of[r]].level, slots[ps].level + 1);
         }
@@ -255,8 +284,8 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         out_dst[n] = -1;
       }
       for (auto& o : row.outputs) {
-        auto it = to_cg.find(o.wrt);
-        if (it != to_cg.end()) out_dst[it->second] = -1;
+        const int32_t w = to_cg.at(o.wrt);
+        if (w >= 0) out_dst[w] = -1;
       }
     }
   }
@@ -265,6 +294,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
   // parent's own level is final once it has been popped in reference order (all
   // its incoming edges come from nodes earlier in the list).
 
+  lap("  tape: rows: slots + edges");
   // ---- components of interior nodes ------------------------------------------
   // A node whose operands are all leaves (e.g. the `-y_j` of the Lagrangian, which
   // both stage k and stage k+1 reference) is REPLICATED into every component that
@@ -338,11 +368,12 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
     n_leaf_est = leaves;
     size_t edges = 0;
-    for (int32_t sl : comp_slots[c]) edges += slot_edges[sl].size();
+    for (int32_t sl : comp_slots[c]) edges += n_slot_edges(sl);
     return 8 * leaves + (24 + 8) * comp_nodes[c].size() + (8 + 2) * comp_slots[c].size() +
            4 * edges + 64;
   };
 
+  lap("  tape: components");
   // ---- pack components into tasks -----------------------------------------------
   const size_t small_cap = opt.small_lds_bytes, large_cap = opt.large_lds_bytes;
   struct Pack {
@@ -365,7 +396,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       mix(comp_slots[c].size());
       mix(comp_vouts[c].size());
       size_t edges = 0;
-      for (int32_t sl : comp_slots[c]) edges += slot_edges[sl].size();
+      for (int32_t sl : comp_slots[c]) edges += n_slot_edges(sl);
       mix(edges);
       uint64_t ops = 0;
       for (int32_t nd : comp_nodes[c]) ops += static_cast<uint64_t>(cg.op[nd]) * 131u + static_cast<uint64_t>(level[nd]);
@@ -410,6 +441,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     packs.push_back(std::move(lp));  // leaf-only task, filled below
   }
 
+  lap("  tape: pack");
   // ---- emit tasks -----------------------------------------------------------------
   std::unordered_map<double, uint32_t> const_pool;
   std::unordered_map<NodeId, uint32_t> param_slot;
@@ -542,7 +574,8 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         }
         L_eptr.push_back(edge_count);
         L_eptr16.push_back(static_cast<uint16_t>(edge_count));
-        for (const REdge& e : slot_edges[tslots[i]]) {
+        for (uint32_t ek = slot_edge_ptr[tslots[i]]; ek < slot_edge_ptr[tslots[i] + 1]; ++ek) {
+          const REdge& e = slot_edge_data[ek];
           uint32_t pn = static_cast<uint32_t>(local_of[e.parent_node]) - t.n_leaf;
           L_edges.push_back({static_cast<uint32_t>(local_slot[e.parent_slot]),
                              2u * pn + static_cast<uint32_t>(e.side)});
@@ -566,9 +599,12 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
     {  // share the structure with an identical earlier task, else append it
       uint64_t h = 1469598103934665603ull;
-      auto mix = [&](const void* data, size_t bytes) {
-        const unsigned char* b = static_cast<const unsigned char*>(data);
-        for (size_t k = 0; k < bytes; ++k) h = (h ^ b[k]) * 1099511628211ull;
+      auto mix = [&](const void* data, size_t bytes) {  // all arrays are whole 32-bit words
+        const uint32_t* w = static_cast<const uint32_t*>(data);
+        for (size_t k = 0; k < bytes / 4; ++k) {
+          h = (h ^ w[k]) * 1099511628211ull;
+          h ^= h >> 29;
+        }
       };
       const uint32_t dims[3] = {t.n_leaf, t.n_node, t.n_slot};
       mix(dims, sizeof(dims));
@@ -679,6 +715,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     prog.slvl_ptr.push_back(0);
     prog.leaf_src.push_back(0);
   }
+  lap("  tape: emit");
   for (auto& v : value_outs) prog.n_outputs = std::max(prog.n_outputs, v.dst + 1);
   for (auto& r : rows)
     for (auto& o : r.outputs) prog.n_outputs = std::max(prog.n_outputs, o.dst + 1);

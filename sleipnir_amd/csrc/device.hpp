@@ -210,9 +210,12 @@ class DeviceNlp {
   void download(const double* dev, double* host, size_t count);
 
   // hot path (all asynchronous on stream())
-  void sweep_full();    // f, c_e, c_i, g, A_e, A_i, H_f, H_c  -> V
+  // f, c_e, c_i, g, A_e, A_i, H_f, H_c -> V.  with_reduce = false leaves the separable-sum
+  // reductions (they only feed f) to the build_kkt(true) that must follow.
+  void sweep_full(bool with_reduce = true);
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs
+  void build_kkt(bool with_reduce);  // assemble() + build_rhs() [+ reductions] as one launch
   // Least-squares multiplier estimate system on the same pattern:
   // lhs = [[I + A_i^T S^-2 A_i, A_e^T],[A_e, 0]] (util/lagrange_multiplier_estimate.hpp:56-133
   // with d, t eliminated; see ipm.cpp)
@@ -335,6 +338,7 @@ class DeviceNlp {
   bool m_ipm = false;
   DevBuf<double> m_trial_in, m_V_trial, m_soc_ce, m_soc_cims, m_p_keep, m_ps_keep, m_pz_keep, m_ipm_alpha, m_ipm_scales, m_ipm_partial;
   IpmHost* m_ipm_host = nullptr;   // pinned
+  bool m_tape_reduce = true;       // launch_tape runs the separable-sum reductions itself
   const double* m_in_override = nullptr;  // launch_tape reads / writes these when set
   double* m_V_override = nullptr;
 };

@@ -699,8 +699,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       dev.upload_mu(&mu);
       mu_on_device = mu;
     }
-    dev.assemble();
-    dev.build_rhs();
+    dev.build_kkt(/*with_reduce=*/false);
     sys.set_after_attempt([&] {
       dev.ipm_direction(tau);
       dev.sweep_values_trial();

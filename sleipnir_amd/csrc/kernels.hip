@@ -33,16 +33,12 @@ namespace slpx {
 // consecutive threads write consecutive entries; the sources of consecutive lhs
 // entries are (nearly) consecutive in V because both are CSC-ordered.
 // ============================================================================
-__global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const double* __restrict__ V,
-                                                           int v_stride,
-                                                           const double* __restrict__ s,
-                                                           const double* __restrict__ z,
-                                                           double* __restrict__ lhs) {
-  const int b = blockIdx.y;
-  V += static_cast<size_t>(b) * v_stride;
-  s += static_cast<size_t>(b) * K.m_i;
-  z += static_cast<size_t>(b) * K.m_i;
-  lhs += static_cast<size_t>(b) * K.nnz_lhs;
+// (`vblock` of `vgrid`: the block's position among the blocks doing this job — the fused
+// kkt_build_kernel gives each job a slice of one launch)
+__device__ __forceinline__ void kkt_assemble_body(const KktDev& K, const double* __restrict__ V,
+                                                  const double* __restrict__ s,
+                                                  const double* __restrict__ z, double* __restrict__ lhs,
+                                                  int vblock, int vgrid) {
   auto general = [&](int k) {
     double direct = 0.0;
     for (int d = K.dptr[k]; d < K.dptr[k + 1]; ++d) direct += V[K.dsrc[d]];
@@ -57,8 +53,8 @@ __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const doubl
   // Four entries per thread with their gathers in flight together (the kernel is a chain
   // of dependent loads; HBM bandwidth needs the memory-level parallelism), and a one-index
   // fast path for the entries that are plain copies of a V value (all of A_e, most of H).
-  const int stride = gridDim.x * blockDim.x;
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = vgrid * blockDim.x;
+  int k = vblock * blockDim.x + threadIdx.x;
   for (; k + 3 * stride < K.nnz_lhs; k += 4 * stride) {
     const int f0 = K.fast_src[k], f1 = K.fast_src[k + stride], f2 = K.fast_src[k + 2 * stride],
               f3 = K.fast_src[k + 3 * stride];
@@ -77,6 +73,17 @@ __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const doubl
     const int f = K.fast_src[k];
     lhs[k] = f >= 0 ? V[f] : (f == -2 ? general(k) : 0.0);
   }
+}
+
+__global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const double* __restrict__ V,
+                                                           int v_stride,
+                                                           const double* __restrict__ s,
+                                                           const double* __restrict__ z,
+                                                           double* __restrict__ lhs) {
+  const int b = blockIdx.y;
+  kkt_assemble_body(K, V + static_cast<size_t>(b) * v_stride, s + static_cast<size_t>(b) * K.m_i,
+                    z + static_cast<size_t>(b) * K.m_i, lhs + static_cast<size_t>(b) * K.nnz_lhs, blockIdx.x,
+                    gridDim.x);
 }
 
 // Batch variant: one thread serves the SAME entry of kBatchPerThread consecutive problems,
@@ -168,24 +175,15 @@ __global__ __launch_bounds__(256) void kkt_add_identity_kernel(KktDev K, const i
     lhs[diag_pos[j]] += 1.0;
 }
 
-__global__ __launch_bounds__(256) void kkt_rhs_kernel(KktDev K, const double* __restrict__ V,
-                                                      int v_stride, const double* __restrict__ s,
-                                                      const double* __restrict__ y,
-                                                      const double* __restrict__ z,
-                                                      const double* __restrict__ mu,
-                                                      double* __restrict__ rhs) {
-  const int b = blockIdx.y;
-  V += static_cast<size_t>(b) * v_stride;
-  s += static_cast<size_t>(b) * K.m_i;
-  z += static_cast<size_t>(b) * K.m_i;
-  y += static_cast<size_t>(b) * K.m_e;
-  rhs += static_cast<size_t>(b) * K.dim;
-  const double m = mu[b];
+__device__ __forceinline__ void kkt_rhs_body(const KktDev& K, const double* __restrict__ V,
+                                             const double* __restrict__ s, const double* __restrict__ y,
+                                             const double* __restrict__ z, const double m,
+                                             double* __restrict__ rhs, int vblock, int vgrid) {
   const double* ce = V + K.off_ce;
   const double* ci = V + K.off_ci;
   const double* Ae = V + K.off_Ae;
   const double* Ai = V + K.off_Ai;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K.dim; j += gridDim.x * blockDim.x) {
+  for (int j = vblock * blockDim.x + threadIdx.x; j < K.dim; j += vgrid * blockDim.x) {
     if (j >= K.n) {
       rhs[j] = -ce[j - K.n];
       continue;
@@ -201,6 +199,60 @@ __global__ __launch_bounds__(256) void kkt_rhs_kernel(KktDev K, const double* __
       ait += Ai[p] * (-sigma * ci[r] + m * sinv + z[r]);
     }
     rhs[j] = -(gs >= 0 ? V[gs] : 0.0) + aey + ait;
+  }
+}
+
+__global__ __launch_bounds__(256) void kkt_rhs_kernel(KktDev K, const double* __restrict__ V,
+                                                      int v_stride, const double* __restrict__ s,
+                                                      const double* __restrict__ y,
+                                                      const double* __restrict__ z,
+                                                      const double* __restrict__ mu,
+                                                      double* __restrict__ rhs) {
+  const int b = blockIdx.y;
+  kkt_rhs_body(K, V + static_cast<size_t>(b) * v_stride, s + static_cast<size_t>(b) * K.m_i,
+               y + static_cast<size_t>(b) * K.m_e, z + static_cast<size_t>(b) * K.m_i, mu[b],
+               rhs + static_cast<size_t>(b) * K.dim, blockIdx.x, gridDim.x);
+}
+
+// lhs, rhs and the separable-sum reductions of the tape in ONE launch: all three only read
+// what the sweep left in V, none reads another's output (the sums feed f, which nothing in
+// the Newton step consumes).  Block ranges: [0, na) assembly, [na, na + nr) right-hand
+// side, the rest one reduction each.
+__global__ __launch_bounds__(256) void kkt_build_kernel(KktDev K, double* __restrict__ V, int v_stride,
+                                                        const double* __restrict__ s,
+                                                        const double* __restrict__ y,
+                                                        const double* __restrict__ z,
+                                                        const double* __restrict__ mu,
+                                                        double* __restrict__ lhs, double* __restrict__ rhs,
+                                                        int na, int nr,
+                                                        const NlpStructure::SumReduce* __restrict__ red,
+                                                        const double* __restrict__ scales) {
+  __shared__ double part[64];
+  const int b = blockIdx.y;
+  V += static_cast<size_t>(b) * v_stride;
+  s += static_cast<size_t>(b) * K.m_i;
+  z += static_cast<size_t>(b) * K.m_i;
+  const int blk = blockIdx.x;
+  if (blk < na) {
+    kkt_assemble_body(K, V, s, z, lhs + static_cast<size_t>(b) * K.nnz_lhs, blk, na);
+  } else if (blk < na + nr) {
+    kkt_rhs_body(K, V, s, y + static_cast<size_t>(b) * K.m_e, z, mu[b], rhs + static_cast<size_t>(b) * K.dim,
+                 blk - na, nr);
+  } else {
+    // tape_reduce_body wants a 64-lane workgroup: the first wave does it, the others idle
+    // at its barriers
+    const NlpStructure::SumReduce r = red[blk - na - nr];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    if (tid < 64)
+      for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
+    if (tid < 64) part[tid] = acc;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) part[tid] += part[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) V[r.dst] = (r.scale_idx >= 0 ? scales[r.scale_idx] : 1.0) * part[0];
   }
 }
 
@@ -580,13 +632,17 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     hipLaunchKernelGGL(tape_sweep_global_kernel, dim3(t.n_global, m_batch), dim3(1024), 0, other,
                        view, t.global_list.p, in_p, in_stride, m_in_scale.p, m_scales.p, V_p,
                        v_stride, m_scratch.p, sstride, reverse ? 1 : 0);
-  if (m_reduces.n)
+  if (m_reduces.n && m_tape_reduce)
     hipLaunchKernelGGL(tape_reduce_kernel, dim3(static_cast<uint32_t>(m_reduces.n), m_batch), dim3(64), 0,
                        small_stream, m_reduces.p, m_scales.p, V_p, v_stride);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
-void DeviceNlp::sweep_full() { launch_tape(m_full, true); }
+void DeviceNlp::sweep_full(bool with_reduce) {
+  m_tape_reduce = with_reduce;
+  launch_tape(m_full, true);
+  m_tape_reduce = true;
+}
 void DeviceNlp::sweep_values() { launch_tape(m_values, false); }
 void DeviceNlp::sweep_values_trial() {
   m_in_override = m_trial_in.p;
@@ -611,6 +667,24 @@ void DeviceNlp::assemble() {
     hipLaunchKernelGGL(kkt_assemble_kernel, dim3(grid_for((m_kdev.nnz_lhs + 3) / 4, 256), m_batch),
                        dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs.p);
   }
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+// lhs + rhs (+ the separable-sum reductions a sweep_full(false) left out) in one launch
+void DeviceNlp::build_kkt(bool with_reduce) {
+  if (m_batch >= kBatchPerThread) {  // throughput regime: the batch kernels, separately
+    assemble();
+    build_rhs();
+    if (with_reduce && m_reduces.n)
+      hipLaunchKernelGGL(tape_reduce_kernel, dim3(static_cast<uint32_t>(m_reduces.n), m_batch), dim3(64), 0,
+                         m_stream, m_reduces.p, m_scales.p, m_V.p, m_s_ref.nV);
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  const int na = grid_for((m_kdev.nnz_lhs + 3) / 4, 256), nr = grid_for(m_kdev.dim, 256);
+  const int nred = with_reduce ? static_cast<int>(m_reduces.n) : 0;
+  hipLaunchKernelGGL(kkt_build_kernel, dim3(na + nr + nred, m_batch), dim3(256), 0, m_stream, m_kdev, m_V.p,
+                     m_s_ref.nV, m_s.p, m_y.p, m_z.p, m_mu.p, m_lhs.p, m_rhs.p, na, nr, m_reduces.p, m_scales.p);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -776,9 +850,8 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
       m_stream = cap;
       join();
     } else {
-      if (refresh_ad) launch_tape(m_full, true);
-      assemble();
-      build_rhs();
+      if (refresh_ad) sweep_full(/*with_reduce=*/false);
+      build_kkt(/*with_reduce=*/refresh_ad);
     }
     enqueue_factor(m_stats_cur, cap);
     solve_after_factor();

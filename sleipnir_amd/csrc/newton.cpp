@@ -173,9 +173,8 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
 
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
-  if (refresh_ad) m_dev->sweep_full();
-  m_dev->assemble();
-  m_dev->build_rhs();
+  if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
+  m_dev->build_kkt(/*with_reduce=*/refresh_ad);
   return compute(/*solve_speculatively=*/true);
 }
 

@@ -56,27 +56,6 @@ struct DevBuf {
   }
 };
 
-// Pointers handed to the tape kernel by value
-struct TapeDev {
-  const TapeTask* tasks;
-  const uint32_t* leaf_src;
-  const double* consts;
-  const uint32_t* node_rec;
-  const uint32_t* lvl_ptr;
-  const uint32_t* slot_edge_ptr;
-  const uint32_t* slvl_ptr;
-  const TapeEdge* edges;
-  const uint32_t* vout_src;
-  const uint32_t* vout_dst;
-  const int32_t* vout_scale;
-  const uint32_t* jout_slot;
-  const uint32_t* jout_dst;
-  const int32_t* jout_scale;
-  const uint16_t* node_rec16;
-  const uint16_t* slot_edge_ptr16;
-  const uint16_t* edges16;
-};
-
 struct TapeDevice {
   DevBuf<TapeTask> tasks;
   DevBuf<uint32_t> small_list, large_list, global_list;

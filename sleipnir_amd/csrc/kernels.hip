@@ -596,6 +596,8 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
   // basic_ops: the program only uses + - * / sin cos sqrt and the piecewise ops, so
   // the kernel specialization without pow/exp/log/erf/... (fewer VGPRs, less code)
   // generated template kernels: one lane per task instance (tape_jit.hpp)
+  // interpreted 64-thread tasks ride along in the generated kernel's launch when there is one
+  const bool small_rides = t.n_bodies > 0 && t.n_small > 0;
   if (t.n_bodies) {
     const int mode = reverse ? 1 : 0;
     const unsigned* table = t.tmpl_table[mode].p;
@@ -613,14 +615,20 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const int* vout_scale = view.vout_scale;
     const unsigned* jout_dst = view.jout_dst;
     const int* jout_scale = view.jout_scale;
-    void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg, &in_scale,
-                    &scales, &V,        &v_stride_arg, &vout_dst, &vout_scale, &jout_dst, &jout_scale};
-    SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, t.tmpl_blocks[mode], m_batch, 1, 64, 1, 1, 0, small_stream,
-                                         args, nullptr));
+    TapeDev view_arg = view;
+    const unsigned* task_list = t.small_list.p;
+    int n_template_blocks = static_cast<int>(t.tmpl_blocks[mode]);
+    int do_reverse = reverse ? 1 : 0;
+    void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
+                    &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
+                    &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse};
+    const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
+    SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, 64, 1, 1, small_rides ? t.small_lds : 0u,
+                                         small_stream, args, nullptr));
   }
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;
   auto large_fn = t.basic_ops ? tape_sweep_lds_kernel<256, false> : tape_sweep_lds_kernel<256, true>;
-  if (t.n_small)
+  if (t.n_small && !small_rides)
     hipLaunchKernelGGL(small_fn, dim3(t.n_small, m_batch), dim3(64), t.small_lds, small_stream, view,
                        t.small_list.p, in_p, in_stride, m_in_scale.p, m_scales.p, V_p, v_stride,
                        reverse ? 1 : 0);

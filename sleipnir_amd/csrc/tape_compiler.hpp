@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "graph.hpp"
+#include "tape_device.h"
 
 namespace slpx {
 
@@ -47,32 +48,6 @@ struct TapeValueOut {
   NodeId node;
   int32_t dst;
   int32_t scale_idx;
-};
-
-// Leaf binding: bit 31 set -> constant pool index, else input vector index.
-constexpr uint32_t kLeafConstFlag = 0x80000000u;
-
-struct TapeTask {
-  uint32_t n_leaf, n_node, n_slot;
-  uint32_t leaf_off;   // into leaf_src
-  uint32_t node_off;   // into node_rec (x3)
-  uint32_t lvl_off;    // into lvl_ptr (n_lvl + 1 entries, local node indices)
-  uint32_t n_lvl;
-  uint32_t slot_off;   // into slot_edge_ptr (n_slot + 1 entries, edge indices relative to edge_off)
-  uint32_t slvl_off;   // into slvl_ptr (n_slvl + 1 entries, local slot indices)
-  uint32_t n_slvl;
-  uint32_t edge_off;   // into edges
-  uint32_t vout_off, n_vout;  // into vout_*
-  uint32_t jout_off, n_jout;  // into jout_*
-  uint32_t scratch_off;       // GLOBAL tasks: offset (doubles) into the scratch buffer
-  uint32_t lds_doubles;       // working-set size in doubles
-  uint32_t n_edge;            // number of adjoint edges
-  uint32_t lds_bytes;         // LDS-staged kernel: working set + staged program
-};
-
-struct TapeEdge {
-  uint32_t parent_slot;  // local slot index
-  uint32_t partial;      // 2 * local interior node index + side
 };
 
 struct TapeProgram {

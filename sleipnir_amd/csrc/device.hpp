@@ -218,6 +218,7 @@ class DeviceNlp {
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
+  void backsub_publish();
 
   // ---- interior-point iteration on the device (ipm_kernels.h; one problem) ----
   // All asynchronous on stream(); results arrive in ipm_host() after wait().
@@ -237,6 +238,7 @@ class DeviceNlp {
   void ipm_save_direction();
   void ipm_restore_direction();
   void wait();                                // busy-polls the stream
+  void wait_published();                      // after ipm_trial_metrics / ipm_errors: their sequence number
   const IpmHost& ipm_host() const { return *m_ipm_host; }
   double* d_V_trial() { return m_V_trial.p; }
 
@@ -302,6 +304,13 @@ class DeviceNlp {
                                       // delta = NaN: skip the problem
   LdltStats* m_h_stats = nullptr;     // pinned read-back
   bool m_stats_in_host = false;       // the last launch already copied the counters out
+  // one problem: the publishing kernel also bumps a sequence number the host spins on
+  // (SLPX_SEQ_POLL=0: poll the stream instead)
+  volatile unsigned long long* m_h_seq = nullptr;  // pinned
+  DevBuf<unsigned long long> m_seq_dev;
+  unsigned long long m_seq_expected = 0;  // publishing launches enqueued so far
+  unsigned long long m_stats_seq = 0;     // the one that carries the current inertia counters
+  bool m_seq_poll = true;
   bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
   // all rounds of a factorization / backward solve in one launch (device-side round
   // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables

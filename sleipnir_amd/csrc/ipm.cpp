@@ -633,7 +633,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   double mu_on_device = mu;
   dev.sweep_full();  // :245-251
   dev.ipm_errors(/*check_all_V=*/true);
-  dev.wait();
+  dev.wait_published();
   IpmErrOut cur = H.err;  // scalars of the current iterate
 
   if (m_e > n) return finish(ExitStatus::TOO_FEW_DOFS);                        // :274
@@ -707,6 +707,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     });
     auto info = sys.compute(/*solve_speculatively=*/true);
     sys.set_after_attempt(nullptr);
+    dev.wait_published();  // compute() returns when the inertia counters are in; the trial chain may still run
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();
     rep.value_sweeps += sys.last_factorizations();
@@ -731,7 +732,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         dev.ipm_trial_point(alpha);
         dev.sweep_values_trial();
         dev.ipm_trial_metrics(alpha, s_from_ci);
-        dev.wait();
+        dev.wait_published();
         ++rep.value_sweeps;
       }
       have_trial = false;
@@ -768,7 +769,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
           dev.ipm_direction(tau);  // step sizes of the corrected direction + its trial point
           dev.sweep_values_trial();
           dev.ipm_trial_metrics(-1.0, false);
-          dev.wait();
+          dev.wait_published();
           ++rep.value_sweeps;
           alpha_soc = H.dir.alpha_max;
           alpha_z_soc = H.dir.alpha_z;
@@ -882,7 +883,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // AD refresh (:809-812) and every norm the next decisions need
     dev.sweep_full();
     dev.ipm_errors(false);
-    dev.wait();
+    dev.wait_published();
     cur = H.err;
     rep.t_ad_refresh += since(t0);
 

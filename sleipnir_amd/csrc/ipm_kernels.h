@@ -82,6 +82,16 @@ __device__ __forceinline__ void block_reduce(double (&vals)[NQ], const int (&ops
   __syncthreads();
 }
 
+// Last act of a chain of launches whose results sit in pinned host memory: bump the
+// sequence number the host spins on (DeviceNlp::wait_published) — it sees it a few
+// microseconds before the stream reports the kernel complete.
+__device__ __forceinline__ void ipm_publish(unsigned long long* seq_dev, volatile unsigned long long* seq_host) {
+  __threadfence_system();
+  const unsigned long long v = *seq_dev + 1;
+  *seq_dev = v;
+  *seq_host = v;
+}
+
 // Step sizes and directional derivative for the direction (p, ps, pz), then the first trial
 // point x + alpha_max p_x.  `out` (pinned host) and `alpha_dev` (device copy, read by
 // ipm_trial_metrics_kernel of the same speculative chain) may be the only consumers.
@@ -130,7 +140,8 @@ __global__ __launch_bounds__(256) void ipm_trial_point_kernel(int n, const doubl
 // (feasible-IPM option, interior_point.hpp:520-526).
 __global__ __launch_bounds__(kIpmThreads) void ipm_trial_metrics_kernel(
     KktDev K, const double* __restrict__ Vt, const double* __restrict__ s, const double* __restrict__ ps,
-    double alpha, const double* __restrict__ alpha_dev, int s_from_ci, IpmTrialOut* __restrict__ out) {
+    double alpha, const double* __restrict__ alpha_dev, int s_from_ci, IpmTrialOut* __restrict__ out,
+    unsigned long long* __restrict__ seq_dev, volatile unsigned long long* seq_host) {
   __shared__ double scratch[17 * 3];
   const int tid = threadIdx.x;
   if (alpha < 0.0) alpha = alpha_dev[0];
@@ -155,6 +166,7 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_trial_metrics_kernel(
     out->viol = acc[0];
     out->logsum = acc[1];
     out->finite = (acc[2] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
+    ipm_publish(seq_dev, seq_host);
   }
 }
 
@@ -376,7 +388,9 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
 
 __global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,
                                                              const double* __restrict__ partial, int n_blocks,
-                                                             IpmErrOut* __restrict__ out) {
+                                                             IpmErrOut* __restrict__ out,
+                                                             unsigned long long* __restrict__ seq_dev,
+                                                             volatile unsigned long long* seq_host) {
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   __shared__ double tot[NQ];
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const dou
     out->s_inf = tot[SINF];
     out->finite = (tot[FINITE] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
     out->ci_all_pos = tot[CIPOS];
+    ipm_publish(seq_dev, seq_host);
   }
 }
 

@@ -265,11 +265,24 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
                                                            double* __restrict__ ps,
                                                            double* __restrict__ pz,
                                                            const LdltStats* __restrict__ stats_src,
-                                                           LdltStats* __restrict__ stats_host) {
+                                                           LdltStats* __restrict__ stats_host,
+                                                           unsigned long long* __restrict__ seq_dev,
+                                                           volatile unsigned long long* seq_host) {
   const int b = blockIdx.y;
-  // last kernel of a graph-launched step: hand the inertia counters of the factorization
-  // to the host (pinned memory) instead of spending a copy node on them
-  if (stats_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stats_host[b] = stats_src[b];
+  // last kernel of a step: hand the inertia counters of the factorization to the host
+  // (pinned memory) instead of spending a copy node on them; with one problem also a
+  // sequence number the host spins on — it learns of the result a few microseconds before
+  // the stream would report the kernel complete, and what it does next (another attempt or
+  // the next step) is ordered behind this kernel by the stream anyway
+  if (stats_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats_host[b] = stats_src[b];
+    if (seq_host != nullptr) {
+      __threadfence_system();
+      const unsigned long long v = *seq_dev + 1;
+      *seq_dev = v;
+      *seq_host = v;
+    }
+  }
   V += static_cast<size_t>(b) * v_stride;
   p += static_cast<size_t>(b) * K.dim;
   s += static_cast<size_t>(b) * K.m_i;
@@ -477,6 +490,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
   m_single_launch = static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
+  if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -505,6 +519,14 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
   if (B > 8) m_reg_dev.alloc(2 * B);
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
+  {
+    unsigned long long* seq = nullptr;
+    SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&seq), sizeof(unsigned long long)));
+    *seq = 0;
+    m_h_seq = seq;
+    m_seq_dev.alloc(1);
+    m_seq_dev.zero();
+  }
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
   set_scaling(std::vector<double>(s.n_scales(), 1.0));
@@ -513,6 +535,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 DeviceNlp::~DeviceNlp() {
   if (m_h_reg) (void)hipHostFree(m_h_reg);
   if (m_h_stats) (void)hipHostFree(m_h_stats);
+  if (m_h_seq) (void)hipHostFree(const_cast<unsigned long long*>(m_h_seq));
   if (m_ipm_host) (void)hipHostFree(m_ipm_host);
   for (auto& row : m_step_graph)
     for (hipGraphExec_t& e : row)
@@ -800,10 +823,25 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
                                   m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, m_stream));
   // Busy-poll instead of a blocking wait: the interrupt-driven wake-up of
   // hipStreamSynchronize costs tens of microseconds, a tenth of a whole Newton step.
-  hipError_t st;
-  while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+  if (m_stats_in_host && m_batch == 1 && m_seq_poll) {
+    // the publishing kernel's sequence number (see step_backsub_kernel); the stream is
+    // consulted now and then so that a failed launch cannot hang the host
+    unsigned spins = 0;
+    while (*m_h_seq < m_stats_seq) {
+      if ((++spins & 0xfffu) == 0) {
+        const hipError_t st = hipStreamQuery(m_stream);
+        if (st != hipErrorNotReady) {
+          SLPX_HIP_CHECK(st);
+          if (*m_h_seq < m_stats_seq) throw std::runtime_error("slpx: step finished without publishing its counters");
+        }
+      }
+    }
+  } else {
+    hipError_t st;
+    while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+    }
+    SLPX_HIP_CHECK(st);
   }
-  SLPX_HIP_CHECK(st);
   std::copy(m_h_stats, m_h_stats + m_batch, out.begin());
 }
 
@@ -911,12 +949,21 @@ void DeviceNlp::solve_after_factor() {
 
 void DeviceNlp::backsub() { backsub_and_publish(nullptr); }
 
+// back-substitution that also hands the counters of the factorization just enqueued to the
+// host (read_stats() then needs no copy)
+void DeviceNlp::backsub_publish() {
+  backsub_and_publish(m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
+  m_stats_in_host = true;
+}
+
 // stats_src != nullptr: also copy those counters to the pinned host buffer
 void DeviceNlp::backsub_and_publish(const LdltStats* stats_src) {
   if (m_kdev.m_i == 0 && stats_src == nullptr) return;
   hipLaunchKernelGGL(step_backsub_kernel, dim3(grid_for(std::max(1, m_kdev.m_i), 256), m_batch),
                      dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p,
-                     m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr);
+                     m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr, m_seq_dev.p,
+                     (stats_src && m_batch == 1) ? m_h_seq : nullptr);
+  if (stats_src && m_batch == 1) m_stats_seq = ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -952,6 +999,22 @@ void DeviceNlp::ipm_set_error_scaling(const std::vector<double>& scales) {
   m_ipm_scales.upload(scales);
 }
 
+// After ipm_trial_metrics() / ipm_errors(): spins on the sequence number those launches
+// publish (the stream is consulted now and then so a failed launch cannot hang the host).
+void DeviceNlp::wait_published() {
+  if (!m_seq_poll) return wait();
+  unsigned spins = 0;
+  while (*m_h_seq < m_seq_expected) {
+    if ((++spins & 0xfffu) == 0) {
+      const hipError_t st = hipStreamQuery(m_stream);
+      if (st != hipErrorNotReady) {
+        SLPX_HIP_CHECK(st);
+        if (*m_h_seq < m_seq_expected) throw std::runtime_error("slpx: chain finished without publishing");
+      }
+    }
+  }
+}
+
 void DeviceNlp::wait() {
   hipError_t st;
   while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
@@ -973,7 +1036,8 @@ void DeviceNlp::ipm_trial_point(double alpha) {
 
 void DeviceNlp::ipm_trial_metrics(double alpha, bool s_from_ci) {
   hipLaunchKernelGGL(ipm_trial_metrics_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V_trial.p,
-                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial);
+                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial, m_seq_dev.p, m_h_seq);
+  ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -993,7 +1057,8 @@ void DeviceNlp::ipm_errors(bool check_all_V) {
                      m_s_ref.nV, m_in.p, m_s.p, m_y.p, m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0,
                      m_ipm_partial.p);
   hipLaunchKernelGGL(ipm_error_final_kernel, dim3(1), dim3(64), 0, m_stream, m_kdev, m_V.p, m_ipm_partial.p,
-                     blocks, &m_ipm_host->err);
+                     blocks, &m_ipm_host->err, m_seq_dev.p, m_h_seq);
+  ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

@@ -74,7 +74,7 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
     m_dev->factor(d, g, a);
     if (solve_speculatively) {
       m_dev->solve_after_factor();
-      m_dev->backsub();
+      m_dev->backsub_publish();
       if (m_after_attempt) m_after_attempt();
     }
   };

@@ -169,7 +169,8 @@ def main():
         tfile = ROOT / "profiles" / "r01_traffic.json"
         if tfile.exists() and N == 1000 and B == 1:
             tj = json.loads(tfile.read_text())
-            prefix = {"tape_sweep": "tape_sweep", "kkt_assemble": "kkt_assemble_kernel",
+            prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
+                      "kkt_assemble": "kkt_assemble_kernel",
                       "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
                       "ldlt_solve": ("ldlt_fwd_kernel", "ldlt_bwd_kernel")}
             traffic_by_group = {}

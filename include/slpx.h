@@ -208,9 +208,13 @@ int slpx_ipm_trial(slpx_system* s, double alpha, int s_from_ci, double* out4);
 int slpx_ipm_commit(slpx_system* s, double alpha, double alpha_z, int s_from_ci);
 int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24);
 
-/* Times `iters` Newton steps with HIP events on the system's stream.
- * ms[8] = per-step averages {sweep, assemble, rhs, factor(all attempts), solve, backsub,
- * total, factorizations per step} */
+/* Per-kernel-group durations with HIP events on the system's stream: every phase of the
+ * step is enqueued `iters` times back to back between one pair of events (the phases are
+ * idempotent on the resident state), so the figure is the kernel's own duration — the one
+ * rocprofv3 --stats reports — without the ~20 us an event pair around a single launch adds.
+ * (Batches of 16 or more: one launch per phase per iteration, events between the phases.)
+ * ms[8] = {sweep, assemble, rhs, factor (x attempts the policy loop needs), backward solve,
+ * backsub, sum, factorizations per step} */
 int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms);
 
 /* Profiling aid: wall_clock64() ticks (100 MHz) recorded by workgroup 0 of the last tape

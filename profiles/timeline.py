@@ -16,7 +16,9 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"])
                 for r in rows)
-    starts = [i for i, e in enumerate(ev) if e[2].startswith("tape_sweep_lds_kernel<64")]
+    # a step starts with the tape's generated kernel (older profiles: the 64-thread interpreter)
+    first = "slpx_tape_templates" if any(e[2].startswith("slpx_tape_templates") for e in ev) else "tape_sweep_lds_kernel<64"
+    starts = [i for i, e in enumerate(ev) if e[2].startswith(first)]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
     i0, i1 = starts[k], starts[k + 2]
     t0 = ev[i0][0]

@@ -458,39 +458,79 @@ int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) 
     auto& sys = s->get();
     auto& dev = sys.device();
     hipStream_t st = dev.stream();
-    hipEvent_t ev[7];
-    for (auto& e : ev) SLPX_HIP_CHECK(hipEventCreate(&e));
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    double nfact = 0;
-    for (int it = 0; it < iters; ++it) {
-      sys.reset_regularization();  // every timed step starts like a first iteration
-      SLPX_HIP_CHECK(hipEventRecord(ev[0], st));
-      if (refresh_ad) dev.sweep_full();
-      SLPX_HIP_CHECK(hipEventRecord(ev[1], st));
-      dev.assemble();
-      SLPX_HIP_CHECK(hipEventRecord(ev[2], st));
-      dev.build_rhs();
-      SLPX_HIP_CHECK(hipEventRecord(ev[3], st));
-      sys.compute();
-      nfact += sys.last_factorizations();
-      SLPX_HIP_CHECK(hipEventRecord(ev[4], st));
-      dev.solve_after_factor();  // the factorization carried the rhs: backward substitution only
-      SLPX_HIP_CHECK(hipEventRecord(ev[5], st));
-      dev.backsub();
-      SLPX_HIP_CHECK(hipEventRecord(ev[6], st));
-      SLPX_HIP_CHECK(hipEventSynchronize(ev[6]));
-      for (int k = 0; k < 6; ++k) {
-        float t = 0;
-        SLPX_HIP_CHECK(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
-        acc[k] += t;
-      }
+    hipEvent_t e0, e1;
+    SLPX_HIP_CHECK(hipEventCreate(&e0));
+    SLPX_HIP_CHECK(hipEventCreate(&e1));
+    const int B = dev.batch();
+    // Every phase is enqueued `iters` times back to back between ONE pair of events, so the
+    // per-launch figure is the kernel's duration (plus the ~1 us between dependent launches),
+    // not the ~20 us an event pair around a single launch adds; this is the number that must
+    // agree with the rocprofv3 --stats average of the same kernel.  All phases are
+    // idempotent on the resident state.
+    auto timed = [&](auto&& launch) {
+      launch();  // warm
+      SLPX_HIP_CHECK(hipEventRecord(e0, st));
+      for (int it = 0; it < iters; ++it) launch();
+      SLPX_HIP_CHECK(hipEventRecord(e1, st));
+      SLPX_HIP_CHECK(hipEventSynchronize(e1));
       float t = 0;
-      SLPX_HIP_CHECK(hipEventElapsedTime(&t, ev[0], ev[6]));
-      acc[6] += t;
+      SLPX_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+      return t / static_cast<float>(iters);
+    };
+    // the regularization the policy loop settles on for this state, and how many attempts it took
+    sys.reset_regularization();
+    if (refresh_ad) dev.sweep_full();
+    dev.assemble();
+    dev.build_rhs();
+    sys.compute();
+    const double nfact = sys.last_factorizations();
+    const std::vector<double> delta = sys.hessian_regularization(), gamma = sys.constraint_jacobian_regularization();
+    const std::vector<uint8_t> active(B, 1);
+
+    if (B >= 16) {
+      // A batch: the kernels run for tens of microseconds to milliseconds, an event pair per
+      // launch costs nothing in comparison — and repeating a launch on the same few hundred
+      // MB would let the 256 MB Infinity Cache serve part of the re-reads and overstate the
+      // HBM rate.  So: the phases in step order, each launched once per iteration.
+      hipEvent_t ev[7];
+      for (auto& e : ev) SLPX_HIP_CHECK(hipEventCreate(&e));
+      double acc[6] = {0, 0, 0, 0, 0, 0};
+      for (int it = 0; it < iters; ++it) {
+        SLPX_HIP_CHECK(hipEventRecord(ev[0], st));
+        if (refresh_ad) dev.sweep_full();
+        SLPX_HIP_CHECK(hipEventRecord(ev[1], st));
+        dev.assemble();
+        SLPX_HIP_CHECK(hipEventRecord(ev[2], st));
+        dev.build_rhs();
+        SLPX_HIP_CHECK(hipEventRecord(ev[3], st));
+        dev.factor(delta, gamma, active);
+        SLPX_HIP_CHECK(hipEventRecord(ev[4], st));
+        dev.solve_after_factor();
+        SLPX_HIP_CHECK(hipEventRecord(ev[5], st));
+        dev.backsub();
+        SLPX_HIP_CHECK(hipEventRecord(ev[6], st));
+        SLPX_HIP_CHECK(hipEventSynchronize(ev[6]));
+        for (int k = 0; k < 6; ++k) {
+          float t = 0;
+          SLPX_HIP_CHECK(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+          acc[k] += t;
+        }
+      }
+      for (int k = 0; k < 6; ++k) ms[k] = static_cast<float>(acc[k] / iters);
+      ms[3] *= static_cast<float>(nfact);
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    } else {
+      ms[0] = refresh_ad ? timed([&] { dev.sweep_full(); }) : 0.0f;
+      ms[1] = timed([&] { dev.assemble(); });
+      ms[2] = timed([&] { dev.build_rhs(); });
+      ms[3] = static_cast<float>(nfact) * timed([&] { dev.factor(delta, gamma, active); });  // all attempts
+      ms[4] = timed([&] { dev.solve_after_factor(); });  // the factorization carried the rhs: backward only
+      ms[5] = timed([&] { dev.backsub(); });
     }
-    for (int k = 0; k < 7; ++k) ms[k] = static_cast<float>(acc[k] / iters);
-    ms[7] = static_cast<float>(nfact / iters);
-    for (auto& e : ev) (void)hipEventDestroy(e);
+    ms[6] = ms[0] + ms[1] + ms[2] + ms[3] + ms[4] + ms[5];
+    ms[7] = static_cast<float>(nfact);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
   });
 }
 

@@ -3,9 +3,12 @@
 // Mirrors include/sleipnir/optimization/solver/interior_point.hpp:63-878 step for
 // step (same constants, same filter line search, same second-order corrections,
 // same barrier update and exits); every O(nnz) piece of the Newton step itself
-// (:426-482, :809-812) runs on the GPU through NewtonSystem.  The O(n) scalar
-// logic between steps (error norms, fraction-to-the-boundary, filter) is still
-// host code on downloaded vectors in this round.
+// (:426-482, :809-812) runs on the GPU through NewtonSystem, and so does every O(n)
+// piece of the iteration around it (step sizes, trial iterate, filter quantities,
+// second-order corrections, iterate update, error norms: ipm_kernels.h, SURVEY.md §8f rows
+// N1/N2) — the host keeps the DECISIONS (filter, barrier update, exits) on a few dozen
+// scalars per iteration.  SLPX_IPM_RESIDENT=0 selects the older driver that keeps the
+// vectors on the host (the cross-check of the resident one).
 //
 // Feasibility restoration (util/feasibility_restoration.hpp:347-628, row N3) is a second
 // compiled NewtonSystem over the same constraint expressions (built lazily, reused);

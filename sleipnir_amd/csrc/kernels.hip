@@ -412,7 +412,9 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                          reinterpret_cast<const void*>(&tape_sweep_lds_kernel<64, true>),
                          reinterpret_cast<const void*>(&tape_sweep_lds_kernel<64, false>)})
     SLPX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_kernel),
+  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_kernel<256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_kernel<1024>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_fwd_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -776,6 +778,8 @@ void DeviceNlp::write_reg(const std::vector<double>& delta, const std::vector<do
   }
 }
 
+constexpr int kFactorThreadsSingle = 1024;
+
 void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   const LdltPlan& l = m_l_ref;
   LdltStats* cur = m_stats.p + static_cast<size_t>(parity) * m_batch;
@@ -792,14 +796,14 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   }
   if (m_single_launch) {
     // every round in one launch; tasks wait on device-side round counters
-    hipLaunchKernelGGL(ldlt_factor_kernel, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
-                       dim3(256), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
+    hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
+                       dim3(kFactorThreadsSingle), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
                        reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
                        m_fround_cnt.p);
   } else {
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-      hipLaunchKernelGGL(ldlt_factor_kernel, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
+      hipLaunchKernelGGL(ldlt_factor_kernel<256>, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
                          m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, reg, m_Lx.p, lxs, m_D.p,
                          l.n, m_contrib.p, cs, cur, r == 0 ? next : nullptr, m_rhs.p, m_zv.p,
                          static_cast<unsigned int*>(nullptr));

@@ -129,7 +129,8 @@ __device__ __forceinline__ double group8_sum(double v) {
 //      col[n_ent] u16 | flags[n_ent] u8 | out[n_ent] u32 | cptr[n_ent+1] u32 |
 //      U[n_ent] f64 | invd[n_col] f64 | counters 32 B      (16-byte groups first)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ldlt_factor_kernel(
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
     const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
@@ -179,14 +180,14 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   const uint32_t* cptr = reinterpret_cast<const uint32_t*>(s_cptr);
 
   // ---- stage the static part ----
-  stage16<256>(s_pairs, reinterpret_cast<const uint4*>(L.pairs + t.pair_off), g_pairs, tid);
-  stage16<256>(s_pptr, reinterpret_cast<const uint4*>(L.ent_pair_ptr + t.pair_ptr_off), g_pptr, tid);
-  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_ptr + t.lvl_off), g_lvl, tid);
-  stage16<256>(s_src, reinterpret_cast<const uint4*>(L.ent_src + t.ent_off), g_src, tid);
-  stage16<256>(s_col, reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), g_col, tid);
-  stage16<256>(s_flags, reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), g_flags, tid);
-  stage16<256>(s_out, reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), g_out, tid);
-  stage16<256>(s_cptr, reinterpret_cast<const uint4*>(L.ent_contrib_ptr + t.contrib_ptr_off), g_cptr,
+  stage16<THREADS>(s_pairs, reinterpret_cast<const uint4*>(L.pairs + t.pair_off), g_pairs, tid);
+  stage16<THREADS>(s_pptr, reinterpret_cast<const uint4*>(L.ent_pair_ptr + t.pair_ptr_off), g_pptr, tid);
+  stage16<THREADS>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<THREADS>(s_src, reinterpret_cast<const uint4*>(L.ent_src + t.ent_off), g_src, tid);
+  stage16<THREADS>(s_col, reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), g_col, tid);
+  stage16<THREADS>(s_flags, reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), g_flags, tid);
+  stage16<THREADS>(s_out, reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), g_out, tid);
+  stage16<THREADS>(s_cptr, reinterpret_cast<const uint4*>(L.ent_contrib_ptr + t.contrib_ptr_off), g_cptr,
                tid);
   if (tid < 4) s_cnt[tid] = 0;
   if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
@@ -202,14 +203,14 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
       return s0 >= 0 ? base[s0] : 0.0;
     };
     uint32_t i = tid;
-    for (; i + 3 * 256 < t.n_ent; i += 4 * 256) {
-      const double a0 = fetch(i), a1 = fetch(i + 256), a2 = fetch(i + 512), a3 = fetch(i + 768);
+    for (; i + 3 * THREADS < t.n_ent; i += 4 * THREADS) {
+      const double a0 = fetch(i), a1 = fetch(i + THREADS), a2 = fetch(i + 2 * THREADS), a3 = fetch(i + 3 * THREADS);
       U[i] = a0;
-      U[i + 256] = a1;
-      U[i + 512] = a2;
-      U[i + 768] = a3;
+      U[i + THREADS] = a1;
+      U[i + 2 * THREADS] = a2;
+      U[i + 3 * THREADS] = a3;
     }
-    for (; i < t.n_ent; i += 256) U[i] = fetch(i);
+    for (; i < t.n_ent; i += THREADS) U[i] = fetch(i);
   }
   __syncthreads();
   // everything above only needed static data and the assembled matrix; the update blocks
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
   // regularization + update blocks of child tasks (few entries have any)
   {
     const uint32_t* cidx = L.contrib_idx + t.contrib_off;
-    for (uint32_t i = tid; i < t.n_ent; i += 256) {
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
       const uint8_t fl = flags[i];
       const uint32_t cb = cptr[i], ce = cptr[i + 1];
       if (!(fl & 1) && cb == ce) continue;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
     uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
     for (uint32_t l = 0; l < t.n_lvl; ++l) {
       const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];  // one level ahead
-      for (uint32_t i = beg + grp; i < end; i += 32) {
+      for (uint32_t i = beg + grp; i < end; i += THREADS / 8) {
         const uint32_t pb = pptr[i], pe = pptr[i + 1];
         // issued with the pointer loads, off the dependent chain
         const double u_old = U[i];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
 
   SLPX_LDLT_CLOCK(3);
   // ---- update blocks for ancestor tasks (later rounds) ----
-  for (uint32_t x = grp; x < t.n_ext; x += 32) {
+  for (uint32_t x = grp; x < t.n_ext; x += THREADS / 8) {
     const uint32_t pb = pptr[t.n_ent + x], pe = pptr[t.n_ent + x + 1];
     double partial = 0.0;
     for (uint32_t q = pb + lane8; q < pe; q += 8) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void ldlt_factor_kernel(
 
   SLPX_LDLT_CLOCK(4);
   // ---- results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero) ----
-  for (uint32_t i = tid; i < t.n_ent; i += 256) {
+  for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
     const double u = U[i];
     if (flags[i] & 1) {
       D[out[i]] = u;

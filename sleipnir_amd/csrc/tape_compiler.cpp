@@ -380,6 +380,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     std::vector<size_t> comps;
     size_t cost = 0;
     int cls = 0;  // 0 small, 1 large, 2 global
+    size_t leaf_begin = 0, leaf_end = 0;  // leaf-only task: its slice of leaf_vouts
   };
   std::vector<Pack> packs;
   {
@@ -435,10 +436,19 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
     if (!cur.comps.empty()) packs.push_back(std::move(cur));
   }
-  if (!leaf_vouts.empty()) {
-    Pack lp;
-    lp.cls = 0;
-    packs.push_back(std::move(lp));  // leaf-only task, filled below
+  // Value outputs that are bare leaves (a bound like x >= 0 prunes to the variable itself)
+  // need no program at all: copy tasks, cut so that each stays a small 64-thread task
+  // (12 B of LDS-staged state per leaf) instead of one task that outgrows the small class
+  // with the horizon (N=5000: one 256-thread launch of 26 us behind everything else).
+  {
+    const size_t chunk = std::max<size_t>(64, small_cap / 16);
+    for (size_t lb = 0; lb < leaf_vouts.size(); lb += chunk) {
+      Pack lp;
+      lp.cls = 0;
+      lp.leaf_begin = lb;
+      lp.leaf_end = std::min(leaf_vouts.size(), lb + chunk);
+      packs.push_back(std::move(lp));  // leaf-only task, filled below
+    }
   }
 
   lap("  tape: pack");
@@ -499,7 +509,7 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     std::vector<size_t> vouts;
     const bool leaf_task = pk.comps.empty();
     if (leaf_task) {
-      vouts = leaf_vouts;
+      vouts.assign(leaf_vouts.begin() + pk.leaf_begin, leaf_vouts.begin() + pk.leaf_end);
       for (size_t v : vouts) leaves.push_back(to_cg.at(value_outs[v].node));
     }
     for (size_t c : pk.comps) {

@@ -493,23 +493,30 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(18);
-  {
+  // A level holds a handful of columns (3-4 on average): ONE wave runs the whole level loop
+  // — eight 8-lane groups — so no workgroup barrier sits between two levels; the wave's own
+  // LDS operations are issued in order, only the compiler has to be kept from moving them
+  // across the level boundary.
+  if (tid < 64) {
     const int lane8 = tid & 7, grp = tid >> 3;
     uint32_t end = lvl[t.n_lvl], beg = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
     for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
       const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0];
-      for (uint32_t i = beg + grp; i < end; i += 32) {
+      for (uint32_t i = beg + grp; i < end; i += 8) {
         const uint32_t qe = ptr[i + 1];
         double partial = 0.0;
         for (uint32_t q = ptr[i] + lane8; q < qe; q += 8) partial += vals[q] * x[items[q].y];
         partial = group8_sum(partial);
         if (lane8 == 0) x[i] -= partial;
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       end = beg;
       beg = next_beg;
     }
   }
+  __syncthreads();
   SLPX_LDLT_CLOCK(19);
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];

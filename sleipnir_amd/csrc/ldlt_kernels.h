@@ -24,12 +24,13 @@
 
 namespace slpx {
 
-// Phase clocks (wall_clock64, 100 MHz) of the first workgroup of the last launch of each
-// kernel: [0,8) factor, [8,16) fwd, [16,24) bwd (debug aid, slpx_debug_ldlt_clocks).
+// Phase clocks (wall_clock64, 100 MHz) of the first task of the selected round in the last
+// launch of each kernel: [0,8) factor, [8,16) fwd, [16,24) bwd (debug aid,
+// slpx_debug_ldlt_clocks).
 __device__ unsigned long long g_ldlt_clocks[24];
 __device__ unsigned int g_ldlt_clock_round;  // which round's launch records
 #define SLPX_LDLT_CLOCK(k)                                                                   \
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && t.round == g_ldlt_clock_round) \
+  if (task_index == L.round_ptr[g_ldlt_clock_round] && blockIdx.y == 0 && threadIdx.x == 0) \
   g_ldlt_clocks[k] = wall_clock64()
 
 // ---------------------------------------------------------------------------
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
     const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
+  const uint32_t task_index = task_base + blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   // the counters the NEXT factorization attempt accumulates into (nobody touches them now)
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     const double* __restrict__ Lx, long long lx_stride, const double* __restrict__ D,
     double* __restrict__ scontrib, int scontrib_stride, double* __restrict__ zv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const LdltTask t = L.tasks[task_base + blockIdx.x];
+  const uint32_t task_index = task_base + blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   rhs += static_cast<size_t>(b) * n;
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     unsigned int* __restrict__ round_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
-  const LdltTask t = L.tasks[round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x];
+  const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   Lx += static_cast<size_t>(b) * lx_stride;

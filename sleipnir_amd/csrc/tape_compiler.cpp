@@ -1,5 +1,7 @@
 #include "tape_compiler.hpp"
 
+#include <cstdlib>
+
 #include "setup_timing.hpp"
 
 #include <algorithm>
@@ -108,10 +110,38 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     int32_t& operator[](NodeId n) { return v[n]; }
   } to_cg{std::vector<int32_t>(g.size(), -1)};
   CG cg;
-  for (NodeId n : reach) {
-    int32_t l = g.a0[n] == kNull ? -1 : to_cg.at(g.a0[n]);
-    int32_t r = g.a1[n] == kNull ? -1 : to_cg.at(g.a1[n]);
-    to_cg[n] = cg.add(g.op[n], l, r, n);
+  {
+    // Common-subexpression elimination while copying (ascending node ids = children first):
+    // an interior node with the same opcode and the same (already merged) operands as an
+    // earlier one IS that node.  Operator overloading creates such duplicates wholesale —
+    // every `cos(theta)` in a dynamics function is a node of its own, and gradient_tree
+    // repeats whole subterms — and each costs a forward evaluation and an adjoint slot per
+    // row that reaches it.  Values are unchanged bit for bit; an adjoint that used to be
+    // propagated separately through the duplicates is now summed first.
+    bool cse = opt.cse;
+    if (const char* env = std::getenv("SLPX_TAPE_CSE")) cse = env[0] != '0';
+    std::unordered_map<uint64_t, int32_t> seen;
+    std::unordered_map<uint64_t, int32_t> seen_const;
+    if (cse) seen.reserve(reach.size());
+    for (NodeId n : reach) {
+      int32_t l = g.a0[n] == kNull ? -1 : to_cg.at(g.a0[n]);
+      int32_t r = g.a1[n] == kNull ? -1 : to_cg.at(g.a1[n]);
+      if (cse && l >= 0 && static_cast<uint32_t>(l) < (1u << 28) && static_cast<uint32_t>(r + 1) < (1u << 28)) {
+        // a + b and a * b are exactly commutative in IEEE arithmetic: one key for both orders
+        int32_t kl = l, kr = r;
+        if ((g.op[n] == OP_ADD || g.op[n] == OP_MUL) && kr >= 0 && kr < kl) std::swap(kl, kr);
+        const uint64_t key = (static_cast<uint64_t>(g.op[n]) << 56) | (static_cast<uint64_t>(kl) << 28) |
+                             static_cast<uint64_t>(kr + 1);
+        auto [it, fresh] = seen.try_emplace(key, 0);
+        if (!fresh) {
+          to_cg[n] = it->second;
+          continue;
+        }
+        it->second = to_cg[n] = cg.add(g.op[n], l, r, n);
+        continue;
+      }
+      to_cg[n] = cg.add(g.op[n], l, r, n);
+    }
   }
   std::unordered_map<NodeId, int32_t> input_of;
   input_of.reserve(inputs.size() * 2);

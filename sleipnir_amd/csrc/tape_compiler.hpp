@@ -89,6 +89,7 @@ struct TapeProgram {
 };
 
 struct TapeCompileOptions {
+  bool cse = true;                        // merge structurally identical interior nodes (SLPX_TAPE_CSE=0: off)
   uint32_t small_lds_bytes = 40 * 1024;   // 64-thread workgroups, four per CU
   uint32_t large_lds_bytes = 152 * 1024;  // 256-thread workgroups, one per CU
   bool rebalance_sums = true;

@@ -42,6 +42,9 @@ struct TapeJitResult {
   std::vector<TapeTemplateGroup> groups;   // body k of the kernel serves groups[k]
   std::vector<uint8_t> task_is_templated;  // per task of the program
   double compile_seconds = 0.0;
+  // TapeJitOptions::compile_without_device on a machine without a GPU: bodies that were
+  // generated and compiled for gfx950 (>= 0), or -1 if hipRTC rejected the source
+  int compiled_without_device = 0;
   std::string log;                         // non-empty when something fell back
 };
 
@@ -54,6 +57,7 @@ struct TapeJitOptions {
   // tasks, 640 loads + 320 stores per lane, turned a 45 us launch into 300 us)
   uint32_t max_width = 32;
   uint32_t max_bodies = 8;
+  bool compile_without_device = false;  // tests: check that the generated source compiles
   uint32_t max_generated_nodes = 4000;  // code-size / compile-time cap over all bodies
 };
 

@@ -153,6 +153,17 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
 extern "C" {
 void hc_destroy(hc_handle* h) { delete h; }
 
+// Generates the run-time tape kernel of the full program and compiles it with hipRTC for
+// gfx950 (no device needed).  Returns the number of bodies compiled (0: the program has no
+// family worth one), -1 when hipRTC rejects the source (log on stderr).
+int32_t hc_tape_jit_compiles(hc_handle* h) {
+  TapeJitOptions opt;
+  opt.compile_without_device = true;
+  const TapeJitResult r = build_tape_templates(h->s.full, opt);
+  if (r.compiled_without_device < 0) std::fprintf(stderr, "hc_tape_jit_compiles: %s\n", r.log.c_str());
+  return r.compiled_without_device;
+}
+
 // Number of distinct task STRUCTURES of the LDLᵀ plan (everything but the global indices:
 // sizes, levels, local columns, flags, pair lists); out[r] = distinct structures of round r.
 int32_t hc_ldlt_families(hc_handle* h, int32_t* out, int32_t cap) {

@@ -52,6 +52,7 @@ def lib():
 
     sig("hc_create", vp, vp, vp, i32, i32, i32)
     sig("hc_destroy", None, vp)
+    sig("hc_tape_jit_compiles", i32, vp)
     sig("hc_info", None, vp, vp)
     sig("hc_pattern", i32, vp, ctypes.c_int, vp, vp)
     sig("hc_perm", None, vp, vp)
@@ -94,6 +95,10 @@ class HostCheck:
         if self._h:
             lib().hc_destroy(self._h)
             self._h = None
+
+    def tape_jit_compiles(self):
+        """Bodies of the run-time generated tape kernel that hipRTC compiled for gfx950 (-1: rejected)."""
+        return lib().hc_tape_jit_compiles(self._h)
 
     def pattern(self, which):
         nnz = lib().hc_pattern(self._h, which, None, None)

@@ -45,3 +45,14 @@ def test_rhs_row_of_the_factorization_is_the_forward_solve(fresh, slpx, orc, hos
     p_fused = hc.solve_after_factor()
     assert cases.max_rel(p_fused, p_full) <= 1e-9
     hc.close()
+
+
+def test_generated_tape_kernel_compiles_for_gfx950(fresh, slpx, orc, hostcheck):
+    """tape_jit.cpp: the run-time generated tape kernel (straight-line bodies for the task
+    families + the interpreter for the rest, prelude = tape_ops.h / tape_device.h /
+    tape_interp.h as text) must compile with hipRTC for gfx950 — which needs no GPU, so a
+    broken generator or prelude is caught on the CPU tier."""
+    pp, _ = cases.build_pair("cart_pole", 64, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    # the stage family (64 members) and the cost groups qualify for a body
+    assert hc.tape_jit_compiles() >= 1

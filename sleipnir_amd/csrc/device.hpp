@@ -315,6 +315,7 @@ class DeviceNlp {
   // all rounds of a factorization / backward solve in one launch (device-side round
   // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables
   bool m_single_launch = true;
+  bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
   int m_bround_cur = 0;

@@ -510,6 +510,22 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_D.alloc(B * l.n);
   m_Lx.alloc(B * std::max<int64_t>(1, l.nnzL));
   m_contrib.alloc(B * std::max<uint32_t>(1, l.n_contrib));
+  {
+    // slot hand-over (ldlt_kernels.h: slot_take) needs every slot to have exactly one reader
+    std::vector<uint8_t> readers(std::max<uint32_t>(1, l.n_contrib), 0);
+    bool single_reader = true;
+    for (uint32_t idx : l.contrib_idx) single_reader = single_reader && ++readers[idx] == 1;
+    m_slot_handoff = m_single_launch && single_reader;
+    if (const char* env = std::getenv("SLPX_SLOT_HANDOFF")) m_slot_handoff = m_slot_handoff && env[0] != '0';
+    if (m_slot_handoff) {
+      std::vector<double> empty(m_contrib.n);
+      const unsigned long long bits = kSlotEmpty;
+      double e;
+      std::memcpy(&e, &bits, sizeof(e));
+      std::fill(empty.begin(), empty.end(), e);
+      SLPX_HIP_CHECK(hipMemcpy(m_contrib.p, empty.data(), empty.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   m_scontrib.alloc(B * std::max<uint32_t>(1, l.n_scontrib));
   m_zv.alloc(B * l.n);
   m_xg.alloc(B * l.n);
@@ -799,14 +815,14 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
     hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
                        dim3(kFactorThreadsSingle), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
                        reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
-                       m_fround_cnt.p);
+                       m_fround_cnt.p, m_slot_handoff ? 1 : 0);
   } else {
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_kernel<256>, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
                          m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, reg, m_Lx.p, lxs, m_D.p,
                          l.n, m_contrib.p, cs, cur, r == 0 ? next : nullptr, m_rhs.p, m_zv.p,
-                         static_cast<unsigned int*>(nullptr));
+                         static_cast<unsigned int*>(nullptr), 0);
     }
   }
   SLPX_HIP_CHECK(hipGetLastError());

@@ -91,6 +91,32 @@ __device__ __forceinline__ void round_signal(unsigned int* cnt_base, int round, 
   }
 }
 
+// Hand-over THROUGH THE DATA (factorization, single launch): an update block slot holds a
+// reserved NaN pattern until its producer (one child task) stores the value; its only
+// consumer (one entry of the parent task) spins on the slot itself, takes the value and
+// re-arms the slot for the next factorization.  Compared with the round counters this
+// drops, per round, the producer's wait for its store acknowledgements, a workgroup
+// barrier and an atomic increment, and the consumer's separate trip for the data after the
+// counter moved.  A computed NaN never carries this payload (the hardware produces the
+// canonical quiet NaN), so a numerical breakdown cannot be mistaken for "not yet written".
+constexpr unsigned long long kSlotEmpty = 0x7ff8dead0badbeefull;
+__device__ __forceinline__ double slot_take(double* p, LdltStats* stats_b) {
+  unsigned int spins = 0;
+  for (;;) {
+    const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<unsigned long long>(__double_as_longlong(v)) != kSlotEmpty) {
+      __hip_atomic_store(p, __longlong_as_double(static_cast<long long>(kSlotEmpty)), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      return v;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
+      if (stats_b != nullptr) atomicAdd(&stats_b->n_bad, 1 << 20);
+      return 0.0;
+    }
+  }
+}
+
 // 1/d on the critical path of every level: hardware estimate + two Newton steps (full
 // double precision for normal inputs; 0 -> inf and inf -> 0 like the division) instead of
 // the ~15-instruction IEEE division sequence with its scale/fixup steps.
@@ -136,7 +162,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
     const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
-    const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt) {
+    const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt,
+    int slot_handoff) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t task_index = task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   __syncthreads();
   // everything above only needed static data and the assembled matrix; the update blocks
   // come from the tasks of earlier rounds
-  if (round_cnt != nullptr && t.round > 0)
+  if (round_cnt != nullptr && !slot_handoff && t.round > 0)
     round_wait(&round_cnt[b * L.n_rounds + t.round - 1],
                L.round_ptr[t.round] - L.round_ptr[t.round - 1], &stats[b]);
   // regularization + update blocks of child tasks (few entries have any)
@@ -229,7 +256,11 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
       if (!(fl & 1) && cb == ce) continue;
       double acc = U[i];
       if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-      for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]], round_cnt != nullptr);
+      if (slot_handoff) {
+        for (uint32_t c = cb; c < ce; ++c) acc -= slot_take(&contrib[cidx[c]], &stats[b]);
+      } else {
+        for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]], round_cnt != nullptr);
+      }
       U[i] = acc;
     }
   }
@@ -278,7 +309,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
     if (lane8 == 0) coherent_store(&contrib[L.ext_dst[t.ext_off + x]], partial, round_cnt != nullptr);
   }
   // the next round only waits for the update blocks, not for L and D going out
-  if (round_cnt != nullptr) {
+  if (round_cnt != nullptr && !slot_handoff) {
     const int last = L.n_rounds - 1;
     round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
                  static_cast<int>(t.round) == last ? L.round_ptr[last + 1] - L.round_ptr[last] : 0u);

@@ -358,8 +358,8 @@ int64_t slpx_system_get(slpx_system* s, int which, double* out) {
       case 3: src = dev.d_p(); count = B * k.dim; break;
       case 4: src = dev.d_ps(); count = B * st.m_i; break;
       case 5: src = dev.d_pz(); count = B * st.m_i; break;
-      case 6: src = dev.d_D(); count = B * l.n; break;
-      case 7: src = dev.d_Lx(); count = B * l.nnzL; break;
+      case 6: dev.materialize_factor(); src = dev.d_D(); count = B * l.n; break;
+      case 7: dev.materialize_factor(); src = dev.d_Lx(); count = B * l.nnzL; break;
       case 8: src = dev.d_x(); count = st.n; if (B != 1) throw std::runtime_error("slpx_system_get: x of a batch is strided"); break;
       case 9: src = dev.d_s(); count = B * st.m_i; break;
       case 10: src = dev.d_y(); count = B * st.m_e; break;

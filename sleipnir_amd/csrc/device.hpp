@@ -219,6 +219,8 @@ class DeviceNlp {
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
   void backsub_publish();
+  void materialize_factor();                // batch-interleaved mode: refresh the batch-major L, D copies
+  static bool interleaved_for(int batch);   // batches this large factor with one lane per problem
 
   // ---- interior-point iteration on the device (ipm_kernels.h; one problem) ----
   // All asynchronous on stream(); results arrive in ipm_host() after wait().
@@ -315,6 +317,12 @@ class DeviceNlp {
   // all rounds of a factorization / backward solve in one launch (device-side round
   // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables
   bool m_single_launch = true;
+  // batch-interleaved LDLT (ldlt_il_kernels.h)
+  bool m_il = false, m_il_outputs_stale = false;
+  DevBuf<double> m_lhs_il, m_rhs_il, m_Lx_il, m_D_il, m_contrib_il, m_scontrib_il, m_zv_il, m_xg_il;
+  DevBuf<LdltStats> m_stats_part;  // [task][problem]
+  DevBuf<uint32_t> m_il_meta, m_il_meta_off;  // per task: the plan slices the factor kernel stages
+  uint32_t m_il_factor_lds = 0, m_il_solve_lds = 0;
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]

@@ -14,11 +14,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 #include "device.hpp"
 #include "ldlt_kernels.h"
+#include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
 #include "tape_kernels.h"
@@ -490,7 +492,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // single problem: 137 tasks on 256 CUs).  With a batch the later-round workgroups would
   // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
-  m_single_launch = static_cast<size_t>(batch) * l.tasks.size() <= 1024;
+  m_il = interleaved_for(batch);
+  m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
 
@@ -536,6 +539,74 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   }
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
   if (B > 8) m_reg_dev.alloc(2 * B);
+  if (m_il) {
+    // batch-interleaved LDLT (ldlt_il_kernels.h): [chunk of 64 problems][index][lane]
+    const size_t C = (B + 63) / 64, W = 64;
+    m_lhs_il.alloc(C * k.lhs.nnz() * W);
+    m_rhs_il.alloc(C * l.n * W);
+    m_Lx_il.alloc(C * std::max<int64_t>(1, l.nnzL) * W);
+    m_D_il.alloc(C * l.n * W);
+    m_contrib_il.alloc(C * std::max<uint32_t>(1, l.n_contrib) * W);
+    m_scontrib_il.alloc(C * std::max<uint32_t>(1, l.n_scontrib) * W);
+    m_zv_il.alloc(C * l.n * W);
+    m_xg_il.alloc(C * l.n * W);
+    m_stats_part.alloc(l.tasks.size() * B);
+    for (auto* buf : {&m_Lx_il, &m_D_il, &m_zv_il, &m_xg_il, &m_contrib_il, &m_scontrib_il}) buf->zero();
+    // per task: the plan slices the factor kernel keeps in LDS, packed back to back
+    // [n_cref, n_words | pairs (2 words each) | pair ptr | src | out |
+    //  flags + column | ext dst | level ptr | per-slot update-block refs]
+    uint32_t fbytes = 0, col = 0;
+    std::vector<uint32_t> meta, meta_off;
+    for (const LdltTask& t : l.tasks) {
+      const uint32_t n_cref = l.ent_contrib_ptr[t.contrib_ptr_off + t.n_ent];
+      meta_off.push_back(static_cast<uint32_t>(meta.size()));
+      const size_t head = meta.size();
+      meta.push_back(n_cref);
+      meta.push_back(0);
+      for (uint32_t q = 0; q < t.n_pairs; ++q) {
+        const LdltPair& pr = l.pairs[t.pair_off + q];
+        meta.push_back(static_cast<uint32_t>(pr.a) | (static_cast<uint32_t>(pr.b) << 16));
+        meta.push_back(pr.k);
+      }
+      for (uint32_t i = 0; i < t.n_ent + t.n_ext + 1; ++i) meta.push_back(l.ent_pair_ptr[t.pair_ptr_off + i]);
+      for (uint32_t i = 0; i < t.n_ent; ++i) meta.push_back(static_cast<uint32_t>(l.ent_src[t.ent_off + i]));
+      for (uint32_t i = 0; i < t.n_ent; ++i) meta.push_back(l.ent_out[t.ent_off + i]);
+      for (uint32_t i = 0; i < t.n_ent; ++i)
+        meta.push_back(static_cast<uint32_t>(l.ent_flags[t.ent_off + i]) | (static_cast<uint32_t>(l.ent_col[t.ent_off + i]) << 8));
+      for (uint32_t i = 0; i < t.n_ext; ++i) meta.push_back(l.ext_dst[t.ext_off + i]);
+      for (uint32_t i = 0; i < t.n_lvl + 1; ++i) meta.push_back(l.lvl_ptr[t.lvl_off + i]);
+      // update-block refs, flat per entry slot (entry e belongs to slot e % 4), entry order and
+      // block order within an entry as in the plan
+      {
+        const size_t ptr_at = meta.size();
+        meta.insert(meta.end(), 5, 0u);  // filled below: first ref of slot 0..3, total
+        uint32_t n_refs = 0;
+        for (uint32_t sidx = 0; sidx < 4; ++sidx) {
+          meta[ptr_at + sidx] = n_refs;
+          for (uint32_t e = sidx; e < t.n_ent; e += 4)
+            for (uint32_t cix = l.ent_contrib_ptr[t.contrib_ptr_off + e]; cix < l.ent_contrib_ptr[t.contrib_ptr_off + e + 1]; ++cix) {
+              meta.push_back(e);
+              meta.push_back(l.contrib_idx[t.contrib_off + cix]);
+              ++n_refs;
+            }
+        }
+        meta[ptr_at + 4] = n_refs;
+      }
+      const uint32_t n_words = static_cast<uint32_t>(meta.size() - head - 2);
+      meta[head + 1] = n_words;
+      fbytes = std::max(fbytes, (t.n_ent + t.n_col) * 16u * 8u + 4u * n_words + 16u);
+      col = std::max(col, t.n_col + 1);
+    }
+    m_il_meta.upload(meta);
+    m_il_meta_off.upload(meta_off);
+    m_il_factor_lds = fbytes;
+    m_il_solve_lds = col * 64u * 8u;
+    if (m_il_factor_lds > 160u * 1024u)
+      throw std::runtime_error("slpx: an LDLT task does not fit the interleaved kernel's LDS (LdltOptions::task_entries)");
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_il_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipDeviceSynchronize());
+  }
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
   {
     unsigned long long* seq = nullptr;
@@ -810,7 +881,23 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                                   hipMemcpyHostToDevice, stream));
     reg = m_reg_dev.p;
   }
-  if (m_single_launch) {
+  if (m_il) {
+    const int C = (m_batch + 63) / 64;
+    const int nnz = m_kdev.nnz_lhs;
+    hipLaunchKernelGGL(il_gather_kernel, dim3((nnz + 63) / 64, C), dim3(256), 0, stream, m_lhs.p,
+                       static_cast<long long>(nnz), nnz, m_lhs_il.p, m_batch);
+    hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, stream, m_rhs.p,
+                       static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
+    for (int r = 0; r < l.n_rounds; ++r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, 4 * C), dim3(kIlLanes), m_il_factor_lds, stream, m_ldev,
+                         l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
+                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p);
+    }
+    hipLaunchKernelGGL(ldlt_stats_il_kernel, dim3(m_batch), dim3(64), 0, stream, m_stats_part.p,
+                       static_cast<int>(l.tasks.size()), reg, cur, m_batch);
+    m_il_outputs_stale = true;
+  } else if (m_single_launch) {
     // every round in one launch; tasks wait on device-side round counters
     hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
                        dim3(kFactorThreadsSingle), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
@@ -938,6 +1025,19 @@ void DeviceNlp::solve() {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   const int scs = static_cast<int>(std::max<uint32_t>(1, l.n_scontrib));
+  if (m_il) {
+    const int C = (m_batch + 63) / 64;
+    hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, m_stream, m_rhs.p,
+                       static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
+    for (int r = 0; r < l.n_rounds; ++r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_fwd_il_kernel, dim3(nt, C), dim3(kIlLanes), m_il_solve_lds, m_stream, m_ldev,
+                         l.round_ptr[r], m_rhs_il.p, l.n, m_Lx_il.p, lxs, m_D_il.p, m_scontrib_il.p, scs,
+                         m_zv_il.p);
+    }
+    solve_after_factor();
+    return;
+  }
   for (int r = 0; r < l.n_rounds; ++r) {
     const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
     hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
@@ -952,6 +1052,16 @@ void DeviceNlp::solve() {
 void DeviceNlp::solve_after_factor() {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
+  if (m_il) {
+    const int C = (m_batch + 63) / 64;
+    for (int r = l.n_rounds - 1; r >= 0; --r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes), m_il_solve_lds, m_stream, m_ldev,
+                         l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch);
+    }
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (m_single_launch) {
     const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
     hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
@@ -965,6 +1075,27 @@ void DeviceNlp::solve_after_factor() {
     }
   }
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+// Batch-interleaved mode keeps L and D as [chunk][index][lane]; the batch-major copies that
+// slpx_system_get hands out are made on demand.
+void DeviceNlp::materialize_factor() {
+  if (!m_il || !m_il_outputs_stale) return;
+  const LdltPlan& l = m_l_ref;
+  const int C = (m_batch + 63) / 64;
+  const int nl = static_cast<int>(std::max<int64_t>(1, l.nnzL));
+  hipLaunchKernelGGL(il_scatter_kernel, dim3((nl + 63) / 64, C), dim3(256), 0, m_stream, m_Lx_il.p, nl, m_Lx.p,
+                     static_cast<long long>(nl), m_batch);
+  hipLaunchKernelGGL(il_scatter_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, m_stream, m_D_il.p, l.n, m_D.p,
+                     static_cast<long long>(l.n), m_batch);
+  SLPX_HIP_CHECK(hipGetLastError());
+  m_il_outputs_stale = false;
+}
+
+bool DeviceNlp::interleaved_for(int batch) {
+  if (const char* env = std::getenv("SLPX_LDLT_IL"))
+    if (env[0] == '0') return false;
+  return batch >= 16;
 }
 
 void DeviceNlp::backsub() { backsub_and_publish(nullptr); }

@@ -475,3 +475,23 @@ void hc_backsub(hc_handle* h, const double* s, const double* z, double mu, doubl
 }
 
 }  // extern "C"
+
+// Debug aid: distribution of update-block contributions per target entry
+// out = {n_contrib slots, targets with >= 1, max per target, targets with > 32, sum over targets}
+extern "C" void hc_contrib_stats(hc_handle* h, int64_t* out) {
+  const LdltPlan& L = h->l;
+  int64_t targets = 0, mx = 0, big = 0, total = 0;
+  for (const LdltTask& t : L.tasks)
+    for (uint32_t e = 0; e < t.n_ent; ++e) {
+      const int64_t c = L.ent_contrib_ptr[t.contrib_ptr_off + e + 1] - L.ent_contrib_ptr[t.contrib_ptr_off + e];
+      if (c > 0) ++targets;
+      if (c > 32) ++big;
+      mx = std::max(mx, c);
+      total += c;
+    }
+  out[0] = L.n_contrib;
+  out[1] = targets;
+  out[2] = mx;
+  out[3] = big;
+  out[4] = total;
+}

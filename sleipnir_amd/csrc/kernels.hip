@@ -575,26 +575,26 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
         meta.push_back(static_cast<uint32_t>(l.ent_flags[t.ent_off + i]) | (static_cast<uint32_t>(l.ent_col[t.ent_off + i]) << 8));
       for (uint32_t i = 0; i < t.n_ext; ++i) meta.push_back(l.ext_dst[t.ext_off + i]);
       for (uint32_t i = 0; i < t.n_lvl + 1; ++i) meta.push_back(l.lvl_ptr[t.lvl_off + i]);
-      // update-block refs, flat per entry slot (entry e belongs to slot e % 4), entry order and
+      // update-block refs, flat per entry slot (entry e belongs to slot e % kIlSlots), entry order and
       // block order within an entry as in the plan
       {
         const size_t ptr_at = meta.size();
-        meta.insert(meta.end(), 5, 0u);  // filled below: first ref of slot 0..3, total
+        meta.insert(meta.end(), kIlSlots + 1, 0u);  // filled below: first ref of each slot, total
         uint32_t n_refs = 0;
-        for (uint32_t sidx = 0; sidx < 4; ++sidx) {
+        for (uint32_t sidx = 0; sidx < kIlSlots; ++sidx) {
           meta[ptr_at + sidx] = n_refs;
-          for (uint32_t e = sidx; e < t.n_ent; e += 4)
+          for (uint32_t e = sidx; e < t.n_ent; e += kIlSlots)
             for (uint32_t cix = l.ent_contrib_ptr[t.contrib_ptr_off + e]; cix < l.ent_contrib_ptr[t.contrib_ptr_off + e + 1]; ++cix) {
               meta.push_back(e);
               meta.push_back(l.contrib_idx[t.contrib_off + cix]);
               ++n_refs;
             }
         }
-        meta[ptr_at + 4] = n_refs;
+        meta[ptr_at + kIlSlots] = n_refs;
       }
       const uint32_t n_words = static_cast<uint32_t>(meta.size() - head - 2);
       meta[head + 1] = n_words;
-      fbytes = std::max(fbytes, (t.n_ent + t.n_col) * 16u * 8u + 4u * n_words + 16u);
+      fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * 16u * 8u, 3u * kIlSlots * 16u * 8u) + 4u * n_words + 16u);
       col = std::max(col, t.n_col + 1);
     }
     m_il_meta.upload(meta);
@@ -890,7 +890,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                        static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, 4 * C), dim3(kIlLanes), m_il_factor_lds, stream, m_ldev,
+      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, 4 * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
                          l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
                          m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p);
     }
@@ -1092,10 +1092,16 @@ void DeviceNlp::materialize_factor() {
   m_il_outputs_stale = false;
 }
 
+// Lane-per-problem pays once there are several 64-problem chunks per task to fill the chip
+// with (measured at N=500: batch 128 a tie with the per-task kernels, 256: 408 k vs 312 k
+// steps/s; at 512 x N=1000: 331 k vs 171 k).  SLPX_LDLT_IL=0 turns it off,
+// SLPX_IL_MIN_BATCH moves the threshold.
 bool DeviceNlp::interleaved_for(int batch) {
   if (const char* env = std::getenv("SLPX_LDLT_IL"))
     if (env[0] == '0') return false;
-  return batch >= 16;
+  int min_batch = 192;
+  if (const char* env = std::getenv("SLPX_IL_MIN_BATCH")) min_batch = std::atoi(env);
+  return batch >= min_batch;
 }
 
 void DeviceNlp::backsub() { backsub_and_publish(nullptr); }

@@ -18,7 +18,7 @@
 // The symbolic phase is run with small tasks in this mode (newton.cpp).  The per-task
 // kernels of ldlt_kernels.h (one workgroup per task and problem, eight lanes per entry)
 // remain the path of a single problem, where latency rules; this is the throughput path
-// (batch >= 16).
+// (DeviceNlp::interleaved_for: batches of about 200 problems and more).
 //
 // Arithmetic per entry is the same left-looking gather
 //   U(i,j) = A(i,j) [+delta | -gamma] - sum(update blocks of child tasks) - sum_k U(i,k) U(j,k) / d_k
@@ -40,6 +40,8 @@ namespace slpx {
 
 constexpr int kIlLanes = 64;  // lanes of a wave
 constexpr int kIlW = 16;      // problems per interleaved row
+constexpr int kIlSlots = 16;  // entries of a level a factorization workgroup works on at a time
+constexpr int kIlFactorThreads = kIlSlots * kIlW;
 
 // number of 16-problem rows groups a batch occupies (padded to whole waves of 64 problems)
 __host__ __device__ inline int il_groups(int batch) { return 4 * ((batch + 63) / 64); }
@@ -92,7 +94,7 @@ __device__ __forceinline__ double il_reciprocal(double d) {
 // One wave = one task x 16 problems; lane = slot * 16 + problem, the four slots work on four
 // entries of a level at a time.
 // LDS: U[n_ent][16] | invd[n_col][16] | the task's plan slices (pairs, pointers, sources, ...).
-__global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
+__global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs_il, int nnz_lhs,
     const double* __restrict__ rhs_il, int n, const double* __restrict__ reg, double* __restrict__ Lx_il,
     long long nnzL, double* __restrict__ D_il, double* __restrict__ contrib_il, int n_contrib,
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   const uint32_t task_index = task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   const int g = blockIdx.y, lane = threadIdx.x;  // g: group of 16 problems
-  const int slot = lane >> 4, pl = lane & 15;
+  const int slot = lane >> 4, pl = lane & 15;     // slot: 0 .. kIlSlots - 1
   const int b = g * kIlW + pl;
   const bool in_batch = b < batch;
   const double delta = in_batch ? reg[2 * b] : 0.0, gamma = in_batch ? reg[2 * b + 1] : 0.0;
@@ -128,15 +130,15 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   {
     const uint32_t* src_w = gm + 2;
     uint32_t i = lane;
-    for (; i + 3 * kIlLanes < n_words; i += 4 * kIlLanes) {
-      const uint32_t w0 = src_w[i], w1 = src_w[i + kIlLanes], w2 = src_w[i + 2 * kIlLanes],
-                     w3 = src_w[i + 3 * kIlLanes];
+    for (; i + 3 * kIlFactorThreads < n_words; i += 4 * kIlFactorThreads) {
+      const uint32_t w0 = src_w[i], w1 = src_w[i + kIlFactorThreads], w2 = src_w[i + 2 * kIlFactorThreads],
+                     w3 = src_w[i + 3 * kIlFactorThreads];
       meta[i] = w0;
-      meta[i + kIlLanes] = w1;
-      meta[i + 2 * kIlLanes] = w2;
-      meta[i + 3 * kIlLanes] = w3;
+      meta[i + kIlFactorThreads] = w1;
+      meta[i + 2 * kIlFactorThreads] = w2;
+      meta[i + 3 * kIlFactorThreads] = w3;
     }
-    for (; i < n_words; i += kIlLanes) meta[i] = src_w[i];
+    for (; i < n_words; i += kIlFactorThreads) meta[i] = src_w[i];
   }
   const uint32_t n_pp = t.n_ent + t.n_ext + 1;
   const uint2* s_pairs = reinterpret_cast<const uint2*>(meta);  // 8-byte aligned: offset multiple of 128 B
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   const uint32_t* s_fc = s_out + t.n_ent;  // flags | local column << 8
   const uint32_t* s_ext = s_fc + t.n_ent;
   const uint32_t* s_lvl = s_ext + t.n_ext;
-  const uint32_t* s_crptr = s_lvl + t.n_lvl + 1;  // 5 offsets: the update-block refs of slot 0..3
-  const uint32_t* s_cref = s_crptr + 5;           // (target entry, block slot) per ref
+  const uint32_t* s_crptr = s_lvl + t.n_lvl + 1;  // kIlSlots + 1 offsets: the update-block refs of each slot
+  const uint32_t* s_cref = s_crptr + kIlSlots + 1;           // (target entry, block slot) per ref
   (void)n_cref;
   __syncthreads();
   SLPX_IL_CLOCK(1);
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   };
   {
     uint32_t e = slot;
-    for (; e + 28 < t.n_ent; e += 32) {
-      double a[8];
+    for (; e + 3 * kIlSlots < t.n_ent; e += 4 * kIlSlots) {
+      double a[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = matrix_value(e + 4 * j);
+      for (int j = 0; j < 4; ++j) a[j] = matrix_value(e + kIlSlots * j);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) U[(e + 4 * j) * kIlW] = a[j];
+      for (int j = 0; j < 4; ++j) U[(e + kIlSlots * j) * kIlW] = a[j];
     }
-    for (; e < t.n_ent; e += 4) U[e * kIlW] = matrix_value(e);
+    for (; e < t.n_ent; e += kIlSlots) U[e * kIlW] = matrix_value(e);
   }
   {
     // (a slot only touches its own entries: no cross-slot ordering needed before this)
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   double min_abs = __longlong_as_double(0x7ff0000000000000ll);
   for (uint32_t l = 0; l < t.n_lvl; ++l) {
     const uint32_t end = s_lvl[l + 1];
-    for (uint32_t e = s_lvl[l] + slot; e < end; e += 4) {
+    for (uint32_t e = s_lvl[l] + slot; e < end; e += kIlSlots) {
       const uint32_t fc = s_fc[e];
       const double acc = U[e * kIlW] - pair_sum(s_pptr[e], s_pptr[e + 1]);
       U[e * kIlW] = acc;
@@ -240,13 +242,13 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
   SLPX_IL_CLOCK(3);
   // update blocks for ancestor tasks (later rounds = later launches); lanes outside the
   // attempt keep what an earlier, accepted attempt left for their problem
-  for (uint32_t x = slot; x < t.n_ext; x += 4) {
+  for (uint32_t x = slot; x < t.n_ext; x += kIlSlots) {
     const double v = pair_sum(s_pptr[t.n_ent + x], s_pptr[t.n_ent + x + 1]);
     if (active) contrib[static_cast<size_t>(s_ext[x]) * kIlW] = v;
   }
   SLPX_IL_CLOCK(4);
   // results: L = U / d, and z = D⁻¹L⁻¹Pb from the right-hand-side row
-  for (uint32_t e = slot; e < t.n_ent; e += 4) {
+  for (uint32_t e = slot; e < t.n_ent; e += kIlSlots) {
     const uint32_t fc = s_fc[e];
     if ((fc & 1) || !active) continue;
     const double v = U[e * kIlW] * invd[(fc >> 8) * kIlW];
@@ -254,17 +256,26 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_factor_il_kernel(
     else Lx[static_cast<size_t>(s_out[e]) * kIlW] = v;
   }
   SLPX_IL_CLOCK(5);
-  // inertia counters of the task: fold the four slots of each problem
-  n_pos += __shfl_xor(n_pos, 16);
-  n_neg += __shfl_xor(n_neg, 16);
-  n_zero += __shfl_xor(n_zero, 16);
-  n_bad += __shfl_xor(n_bad, 16);
-  min_abs = fmin(min_abs, __shfl_xor(min_abs, 16));
-  n_pos += __shfl_xor(n_pos, 32);
-  n_neg += __shfl_xor(n_neg, 32);
-  n_zero += __shfl_xor(n_zero, 32);
-  n_bad += __shfl_xor(n_bad, 32);
-  min_abs = fmin(min_abs, __shfl_xor(min_abs, 32));
+  // inertia counters of the task: fold the slots of each problem through LDS (U is dead now)
+  __syncthreads();
+  {
+    int* ci = reinterpret_cast<int*>(il_smem);                    // [4][slot][16]
+    double* cm = il_smem + 2 * kIlSlots * kIlW;                   // [slot][16], after 4 int rows
+    ci[(0 * kIlSlots + slot) * kIlW + pl] = n_pos;
+    ci[(1 * kIlSlots + slot) * kIlW + pl] = n_neg;
+    ci[(2 * kIlSlots + slot) * kIlW + pl] = n_zero;
+    ci[(3 * kIlSlots + slot) * kIlW + pl] = n_bad;
+    cm[slot * kIlW + pl] = min_abs;
+    __syncthreads();
+    if (slot == 0)
+      for (int sl = 1; sl < kIlSlots; ++sl) {
+        n_pos += ci[(0 * kIlSlots + sl) * kIlW + pl];
+        n_neg += ci[(1 * kIlSlots + sl) * kIlW + pl];
+        n_zero += ci[(2 * kIlSlots + sl) * kIlW + pl];
+        n_bad += ci[(3 * kIlSlots + sl) * kIlW + pl];
+        min_abs = fmin(min_abs, cm[sl * kIlW + pl]);
+      }
+  }
   if (active && slot == 0) {
     LdltStats st;
     st.n_pos = n_pos;

@@ -33,7 +33,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   LdltOptions lopt = opt.ldlt;
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   // one lane per problem (ldlt_il_kernels.h): a task's values x 64 problems must fit LDS
-  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 192;
+  // (measured at 512 x N=1000, ms per factorization: 192 -> 0.55 but some problems then need a
+  // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
+  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
   if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
   m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
   lap("= LDLT symbolic");

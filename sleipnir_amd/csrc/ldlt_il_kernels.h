@@ -380,26 +380,49 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_bwd_il_kernel(
   const LdltSolveItem* items = L.bwd_items + t.bwd_item_off;
   // columns from the last level down: a column's items reference later local columns or
   // rows of ancestor tasks (bit 31: global permuted row, final since an earlier launch)
+  // A column's items are independent of each other: eight L values (global, streamed once)
+  // and their x operands are in flight together; the chain runs through x from column to column.
+  auto operand = [&](const LdltSolveItem it) {
+    return (it.ref & 0x80000000u) ? xg[static_cast<size_t>(it.ref & 0x7fffffffu) * kIlW] : x[it.ref * kIlLanes];
+  };
   for (int i = static_cast<int>(t.n_col) - 1; i >= 0; --i) {
-    double a0 = zv[static_cast<size_t>(colperm[i]) * kIlW], a1 = 0.0;
+    double acc = zv[static_cast<size_t>(colperm[i]) * kIlW];
     uint32_t q = ptr[i];
     const uint32_t qe = ptr[i + 1];
-    for (; q + 1 < qe; q += 2) {
-      const LdltSolveItem i0 = items[q], i1 = items[q + 1];
-      const double x0 = (i0.ref & 0x80000000u) ? xg[static_cast<size_t>(i0.ref & 0x7fffffffu) * kIlW]
-                                               : x[i0.ref * kIlLanes];
-      const double x1 = (i1.ref & 0x80000000u) ? xg[static_cast<size_t>(i1.ref & 0x7fffffffu) * kIlW]
-                                               : x[i1.ref * kIlLanes];
-      a0 -= Lx[static_cast<size_t>(i0.lpos) * kIlW] * x0;
-      a1 -= Lx[static_cast<size_t>(i1.lpos) * kIlW] * x1;
+    for (; q + 7 < qe; q += 8) {
+      double lv[8], xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const LdltSolveItem it = items[q + j];
+        lv[j] = Lx[static_cast<size_t>(it.lpos) * kIlW];
+        xv[j] = operand(it);
+      }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        s0 += lv[j] * xv[j];
+        s1 += lv[j + 1] * xv[j + 1];
+      }
+      acc -= s0 + s1;
     }
-    if (q < qe) {
-      const LdltSolveItem i0 = items[q];
-      const double x0 = (i0.ref & 0x80000000u) ? xg[static_cast<size_t>(i0.ref & 0x7fffffffu) * kIlW]
-                                               : x[i0.ref * kIlLanes];
-      a0 -= Lx[static_cast<size_t>(i0.lpos) * kIlW] * x0;
+    {
+      double lv[8], xv[8];
+      const uint32_t rem = qe - q;  // 0..7
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const LdltSolveItem it = items[j < static_cast<int>(rem) ? q + j : (rem ? qe - 1 : q)];
+        lv[j] = (j < static_cast<int>(rem)) ? Lx[static_cast<size_t>(it.lpos) * kIlW] : 0.0;
+        xv[j] = (j < static_cast<int>(rem)) ? operand(it) : 0.0;
+      }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        s0 += lv[j] * xv[j];
+        s1 += lv[j + 1] * xv[j + 1];
+      }
+      if (rem) acc -= s0 + s1;
     }
-    x[i * kIlLanes] = a0 + a1;
+    x[i * kIlLanes] = acc;
   }
   for (uint32_t i = 0; i < t.n_col; ++i) {
     const uint32_t pj = colperm[i];

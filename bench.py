@@ -155,7 +155,9 @@ def main():
             "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
             "kkt_rhs": (kt["rhs"], info["rhs_bytes"]),
             "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
-            "ldlt_solve": (kt["solve"], info["solve_bytes"]),
+            # the timed launch is the BACKWARD substitution only (the forward one rides in the
+            # factorization): half of the 32 l + 16(n + m_e) of SURVEY.md §8d
+            "ldlt_solve": (kt["solve"], info["solve_bytes"] // 2),
         }
         # the tape program (static, read once per sweep) belongs to the sweep's bytes just
         # like the index maps belong to kkt_assemble's
@@ -232,7 +234,7 @@ def main():
                   "kkt_assemble": (kb["assemble"], info["assemble_bytes"]),
                   "kkt_rhs": (kb["rhs"], info["rhs_bytes"]),
                   "ldlt_factor": (kb["factor"] / nfb, info["factor_bytes"]),
-                  "ldlt_solve": (kb["solve"], info["solve_bytes"])}
+                  "ldlt_solve": (kb["solve"], info["solve_bytes"] // 2)}
             out["batched"] = {
                 "batch": RB, "steps_per_s": RB / (kb["total"] * 1e-3),
                 "per_kernel_ms": {k: v[0] for k, v in gb.items()},

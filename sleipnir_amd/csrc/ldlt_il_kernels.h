@@ -7,9 +7,9 @@
 // 128-byte line: problem b lives in element b % 16 of row [b / 16][i][0..15] of the
 // interleaved arrays  lhs_il, rhs_il, Lx_il, D_il, contrib_il, scontrib_il, zv_il, xg_il.
 //
-//  * factorization: a wave = one task x 16 problems x FOUR entries of a level at a time
-//    (lane = entry slot * 16 + problem).  The task's U values and 1/d of its columns sit in
-//    LDS as rows of 16 — a quarter of what 64 problems per wave would need, so six or more
+//  * factorization: a workgroup = one task x 16 problems x SIXTEEN entries of a level at a
+//    time (thread = entry slot * 16 + problem).  The task's U values and 1/d of its columns sit in
+//    LDS as rows of 16 — a quarter of what 64 problems per wave would need, so a dozen
 //    waves share a CU and hide each other's LDS latency (measured with 64 problems per wave
 //    and one entry at a time: one wave per CU, 3.9 ms per factorization of 512 x N=1000 —
 //    slower than the per-task kernels);
@@ -91,8 +91,9 @@ __device__ __forceinline__ double il_reciprocal(double d) {
   return (r0 != 0.0 && isfinite(r0)) ? r : r0;
 }
 
-// One wave = one task x 16 problems; lane = slot * 16 + problem, the four slots work on four
-// entries of a level at a time.
+// One workgroup = one task x 16 problems; thread = slot * 16 + problem, the kIlSlots slots work
+// on that many entries of a level at a time (four waves per workgroup: twelve or more waves
+// share a CU's LDS and hide each other's latency).
 // LDS: U[n_ent][16] | invd[n_col][16] | the task's plan slices (pairs, pointers, sources, ...).
 __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ lhs_il, int nnz_lhs,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
   // four loads per lane in flight instead of nine loops with a round trip each.
   SLPX_IL_CLOCK(0);
   const uint32_t* gm = il_meta + il_meta_off[task_index];
-  const uint32_t n_cref = gm[0], n_words = gm[1];
+  const uint32_t n_words = gm[1];  // gm[0]: number of update-block refs (informational)
   uint32_t* meta = reinterpret_cast<uint32_t*>(il_smem + static_cast<size_t>(t.n_ent + t.n_col) * kIlW);
   {
     const uint32_t* src_w = gm + 2;
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
   const uint32_t* s_lvl = s_ext + t.n_ext;
   const uint32_t* s_crptr = s_lvl + t.n_lvl + 1;  // kIlSlots + 1 offsets: the update-block refs of each slot
   const uint32_t* s_cref = s_crptr + kIlSlots + 1;           // (target entry, block slot) per ref
-  (void)n_cref;
   __syncthreads();
   SLPX_IL_CLOCK(1);
   const uint2* pairs = s_pairs;  // x = a | b << 16, y = k
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
 
   // Pass 1 — everything that comes from global memory: U = A [+delta | -gamma] - update
   // blocks of the child tasks (earlier launches).  Nothing here depends on anything else, so
-  // it is written for memory-level parallelism: slot s owns the entries e = s (mod 4), eight
-  // matrix loads in flight, then eight update-block loads in flight from the slot's flat
+  // it is written for memory-level parallelism: slot s owns the entries e = s (mod kIlSlots),
+  // four matrix loads in flight, then eight update-block loads in flight from the slot's flat
   // (entry, block) list — in a per-entry loop every block would cost a memory round trip on
   // the wave's critical path (measured: 10-106 us of a 28-119 us task).
   auto matrix_value = [&](uint32_t e) {

@@ -313,6 +313,7 @@ class DeviceNlp {
   unsigned long long m_seq_expected = 0;  // publishing launches enqueued so far
   unsigned long long m_stats_seq = 0;     // the one that carries the current inertia counters
   bool m_seq_poll = true;
+  bool m_capturing = false;           // a step graph is being captured: launches do not run
   bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
   // all rounds of a factorization / backward solve in one launch (device-side round
   // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables

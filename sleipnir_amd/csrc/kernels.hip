@@ -978,6 +978,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
     SLPX_HIP_CHECK(hipStreamSynchronize(saved));
     SLPX_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     m_stream = cap;
+    m_capturing = true;
     auto fork = [&] {
       SLPX_HIP_CHECK(hipEventRecord(m_fork, cap));
       SLPX_HIP_CHECK(hipStreamWaitEvent(m_aux_stream, m_fork, 0));
@@ -1010,12 +1011,14 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
     solve_after_factor();
     backsub_and_publish(m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
     m_stream = saved;
+    m_capturing = false;
     hipGraph_t graph = nullptr;
     SLPX_HIP_CHECK(hipStreamEndCapture(cap, &graph));
     SLPX_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     SLPX_HIP_CHECK(hipGraphDestroy(graph));
   }
   SLPX_HIP_CHECK(hipGraphLaunch(exec, m_stream));
+  if (m_batch == 1) m_stats_seq = ++m_seq_expected;  // the replayed back-substitution publishes once
   m_stats_in_host = true;
 }
 
@@ -1120,7 +1123,8 @@ void DeviceNlp::backsub_and_publish(const LdltStats* stats_src) {
                      dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p,
                      m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr, m_seq_dev.p,
                      (stats_src && m_batch == 1) ? m_h_seq : nullptr);
-  if (stats_src && m_batch == 1) m_stats_seq = ++m_seq_expected;
+  // (while a graph is being captured nothing runs: launch_step_graph counts each replay)
+  if (stats_src && m_batch == 1 && !m_capturing) m_stats_seq = ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

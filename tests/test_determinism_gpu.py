@@ -35,3 +35,28 @@ def test_batched_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_g
         assert len(seen) == 1, sorted(seen.values(), reverse=True)
     finally:
         system.close()
+
+
+@pytest.mark.parametrize("step_graph", ["1", "0"])
+def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_graph):
+    """One problem takes the latency path: every round of the factorization in ONE launch
+    (hand-over through the update-block slots, ldlt_kernels.h: slot_take), every round of the
+    backward solve in one launch (round counters), completion signalled by a sequence number
+    in pinned memory.  A lost ordering anywhere in there is a rare wrong step."""
+    monkeypatch.setenv("SLPX_STEP_GRAPH", step_graph)
+    N, iters = 300, 1500
+    pp = slpx.Problem.cart_pole(N, 5.0 / N)
+    n, me, mi = pp.dims
+    x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)
+    system = slpx.System(pp, batch=1, device=0)
+    try:
+        system.set_state(x, s, y, z, np.array([mu]))
+        seen = collections.Counter()
+        for _ in range(iters):
+            system.reset_regularization()
+            info = system.newton_step(True)
+            assert info[0] == 0
+            seen[system.get("p").tobytes() + system.get("p_z").tobytes()] += 1
+        assert len(seen) == 1, sorted(seen.values(), reverse=True)
+    finally:
+        system.close()

@@ -973,16 +973,20 @@ NewtonSystem& restoration_system(NewtonSystem& outer) {
   for (NodeId& v : R.d_ce) v = g.variable(1.0);
   for (NodeId& v : R.d_ci) v = g.variable(1.0);
 
-  NodeId lin = kNull;
-  for (size_t k = n; k < R.vars.size(); ++k) lin = g.add(lin, R.vars[k]);
-  NodeId quad = kNull;
+  // The cost as ONE flat sum of single-variable terms, constants folded into the terms:
+  //   sum_k (w_k / 2) (x_k - xr_k)^2 + sum_v rho v.
+  // In this shape the tape compiler's separable-sum splitting applies (nlp.cpp): groups of
+  // consecutive terms become small identical tasks (a template family in the generated
+  // kernel).  Written as rho * (sum v) + 1/2 * (sum w d^2) the two sums are single
+  // components with tens of thousands of nodes — one 1024-thread workgroup walking them in
+  // HBM scratch, measured 0.68 ms per sweep, 57 % of the GPU time of a cart-pole N=750 solve.
+  const NodeId half = g.constant(0.5), rho_c = g.constant(rho);
+  NodeId cost = kNull;
   for (size_t k = 0; k < n; ++k) {
     const NodeId d = g.sub(xs[k], R.x_ref[k]);
-    quad = g.add(quad, g.mul(R.weight[k], g.mul(d, d)));
+    cost = g.add(cost, g.mul(g.mul(half, R.weight[k]), g.mul(d, d)));
   }
-  NodeId cost = kNull;
-  if (lin != kNull) cost = g.mul(g.constant(rho), lin);
-  if (quad != kNull) cost = g.add(cost, g.mul(g.constant(0.5), quad));
+  for (size_t k = n; k < R.vars.size(); ++k) cost = g.add(cost, g.mul(rho_c, R.vars[k]));
 
   std::vector<NodeId> c_e(m_e), c_i;
   for (size_t j = 0; j < m_e; ++j)

@@ -365,6 +365,10 @@ void TapeDevice::upload(const TapeProgram& p, int batch) {
   small_list.upload(small_rest);
   large_list.upload(large_rest);
   global_list.upload(p.global_tasks);
+  if (std::getenv("SLPX_TAPE_JIT_VERBOSE"))
+    for (uint32_t ti : p.global_tasks)
+      std::fprintf(stderr, "slpx tape GLOBAL task: leaf %u node %u slot %u vout %u jout %u levels %u+%u\n", p.tasks[ti].n_leaf,
+                   p.tasks[ti].n_node, p.tasks[ti].n_slot, p.tasks[ti].n_vout, p.tasks[ti].n_jout, p.tasks[ti].n_lvl, p.tasks[ti].n_slvl);
   leaf_src.upload(p.leaf_src);
   consts.upload(p.consts);
   node_rec.upload(p.node_rec);

@@ -333,10 +333,32 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
   std::vector<uint8_t> is_root(ncg, 0), replicable(ncg, 0);
   for (NodeId r : roots)
     if (r != kNull) is_root[to_cg.at(r)] = 1;
-  for (int32_t n : order) {
-    if (cg.is_leaf(n) || is_root[n]) continue;
-    bool all_leaves = cg.is_leaf(cg.a0[n]) && (cg.a1[n] < 0 || cg.is_leaf(cg.a1[n]));
-    replicable[n] = all_leaves;
+  // ... and so is a node on top of such a node and leaves (depth 2): the adjoint seed of a
+  // SCALED constraint row, (-y_j) * d_j, is shared by the row's own stage and — through the
+  // gradient of the next stage's state — by its neighbour; without this the feasibility
+  // restoration model (rows d_j c_j(x) - p_j + n_j) collapses into ONE component of 214 k
+  // nodes that only fits HBM scratch (0.68 ms per sweep at cart-pole N=500).
+  {
+    std::vector<uint8_t> depth(ncg, 0);  // 0: not replicable
+    for (int32_t n : order) {  // children first
+      if (cg.is_leaf(n) || is_root[n]) continue;
+      uint8_t d = 1;
+      bool ok = true;
+      int interior_operands = 0;
+      for (int32_t a : {cg.a0[n], cg.a1[n]}) {
+        if (a < 0 || cg.is_leaf(a)) continue;
+        ++interior_operands;
+        if (depth[a] == 0) ok = false;
+        else d = std::max<uint8_t>(d, static_cast<uint8_t>(depth[a] + 1));
+      }
+      // (one interior operand only: a node joining TWO replicable nodes is the first level
+      // of a sum tree — replicating those dissolves the small identical components, e.g. the
+      // term groups of a separable cost, that the template kernels live on)
+      if (ok && d <= 2 && interior_operands <= 1) {
+        depth[n] = d;
+        replicable[n] = 1;
+      }
+    }
   }
   UnionFind uf(ncg);
   for (int32_t n : order) {
@@ -547,13 +569,21 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       tslots.insert(tslots.end(), comp_slots[c].begin(), comp_slots[c].end());
       vouts.insert(vouts.end(), comp_vouts[c].begin(), comp_vouts[c].end());
     }
-    {  // private copies of the replicated single-op nodes this task consumes
-      std::vector<int32_t> extra;
-      for (int32_t n : nodes)
-        for (int32_t a : {cg.a0[n], cg.a1[n]})
-          if (a >= 0 && !cg.is_leaf(a) && replicable[a]) extra.push_back(a);
-      std::sort(extra.begin(), extra.end());
-      extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+    {  // private copies of the replicated nodes this task consumes (and of what THEY consume)
+      std::vector<int32_t> extra, frontier = nodes;
+      while (!frontier.empty()) {
+        std::vector<int32_t> next;
+        for (int32_t n : frontier)
+          for (int32_t a : {cg.a0[n], cg.a1[n]})
+            if (a >= 0 && !cg.is_leaf(a) && replicable[a]) next.push_back(a);
+        std::sort(next.begin(), next.end());
+        next.erase(std::unique(next.begin(), next.end()), next.end());
+        frontier.clear();
+        for (int32_t a : next)
+          if (!std::binary_search(extra.begin(), extra.end(), a)) frontier.push_back(a);
+        extra.insert(extra.end(), frontier.begin(), frontier.end());
+        std::sort(extra.begin(), extra.end());
+      }
       nodes.insert(nodes.end(), extra.begin(), extra.end());
     }
     for (int32_t n : nodes)

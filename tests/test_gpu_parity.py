@@ -142,3 +142,25 @@ def test_cart_pole_solve(fresh, slpx, orc):
     xo = op.get_x()
     Jg, Jo = float(np.sum(U ** 2)), float(np.sum(xo[4 * (N + 1):] ** 2))
     assert abs(Jg - Jo) <= 1e-6 * max(1.0, abs(Jo)), (Jg, Jo)
+
+
+def test_generated_tape_kernel_matches_the_interpreter_bit_for_bit(fresh, slpx, monkeypatch):
+    """tape_jit.cpp generates straight-line code per task family and compiles it at run time
+    (hipRTC, -ffp-contract=on); the interpreting kernels walk the same program level by
+    level.  Same op_forward, same accumulation order, no cross-node contraction: the whole
+    value vector V (f, c, g, A_e, A_i, H) must be IDENTICAL with the generator switched off."""
+    def sweep(jit):
+        monkeypatch.setenv("SLPX_TAPE_JIT", jit)
+        slpx.lib().slpx_graph_reset()
+        pp = slpx.Problem.cart_pole(120, 5.0 / 120)
+        n, me, mi = pp.dims
+        system = slpx.System(pp, batch=1, device=0)
+        try:
+            x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)
+            system.set_state(x, s, y, z, np.array([mu]))
+            system.sweep(True)
+            return system.get("V")[0].copy()
+        finally:
+            system.close()
+
+    assert np.array_equal(sweep("1"), sweep("0"))

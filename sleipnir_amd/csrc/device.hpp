@@ -75,7 +75,7 @@ struct TapeDevice {
   // offset, row-group mode) per body, `tmpl_blocks[mode]` the grid size.
   hipFunction_t tmpl_fn = nullptr;
   uint32_t n_bodies = 0;
-  DevBuf<uint32_t> tmpl_inst;  // (leaf_off, vout_off, jout_off) per instance, bodies back to back
+  DevBuf<uint32_t> tmpl_inst;  // per body: leaf bindings + output destinations, transposed (kernels.hip)
   DevBuf<uint32_t> tmpl_table[2];
   uint32_t tmpl_blocks[2] = {0, 0};
   uint32_t n_templated_tasks = 0;

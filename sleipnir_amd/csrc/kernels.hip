@@ -330,11 +330,24 @@ void TapeDevice::upload(const TapeProgram& p, int batch) {
   if (n_bodies) {
     std::vector<uint32_t> inst, table[2];
     for (const TapeTemplateGroup& g : jit.groups) {
-      const uint32_t n_inst = static_cast<uint32_t>(g.tasks.size()), inst_off = static_cast<uint32_t>(inst.size() / 3);
-      for (uint32_t ti : g.tasks) {
-        inst.push_back(p.tasks[ti].leaf_off);
-        inst.push_back(p.tasks[ti].vout_off);
-        inst.push_back(p.tasks[ti].jout_off);
+      // the family's leaf bindings and output destinations, transposed: row r of instance i at
+      // [r * n_inst + i] (rows: leaves | value dst | value scale | jacobian dst | jacobian scale),
+      // so that the lanes of a wave — consecutive instances — read consecutive words
+      const uint32_t n_inst = static_cast<uint32_t>(g.tasks.size()), inst_off = static_cast<uint32_t>(inst.size());
+      const TapeTask& rep = p.tasks[g.tasks.front()];
+      const uint32_t rows = rep.n_leaf + 2 * rep.n_vout + 2 * rep.n_jout;
+      inst.resize(inst.size() + static_cast<size_t>(rows) * n_inst);
+      for (uint32_t i = 0; i < n_inst; ++i) {
+        const TapeTask& t = p.tasks[g.tasks[i]];
+        uint32_t* col = inst.data() + inst_off + i;
+        uint32_t r = 0;
+        for (uint32_t q = 0; q < rep.n_leaf; ++q) col[static_cast<size_t>(r++) * n_inst] = p.leaf_src[t.leaf_off + q];
+        for (uint32_t q = 0; q < rep.n_vout; ++q) col[static_cast<size_t>(r++) * n_inst] = p.vout_dst[t.vout_off + q];
+        for (uint32_t q = 0; q < rep.n_vout; ++q)
+          col[static_cast<size_t>(r++) * n_inst] = static_cast<uint32_t>(p.vout_scale[t.vout_off + q]);
+        for (uint32_t q = 0; q < rep.n_jout; ++q) col[static_cast<size_t>(r++) * n_inst] = p.jout_dst[t.jout_off + q];
+        for (uint32_t q = 0; q < rep.n_jout; ++q)
+          col[static_cast<size_t>(r++) * n_inst] = static_cast<uint32_t>(p.jout_scale[t.jout_off + q]);
       }
       n_templated_tasks += n_inst;
       // Adjoint rows are split into wave-uniform groups while the launch would otherwise

@@ -611,7 +611,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       }
       const uint32_t n_words = static_cast<uint32_t>(meta.size() - head - 2);
       meta[head + 1] = n_words;
-      fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * 16u * 8u, 3u * kIlSlots * 16u * 8u) + 4u * n_words + 16u);
+      fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * kIlW * 8u, 3u * kIlSlots * kIlW * 8u) + 4u * n_words + 16u);
       col = std::max(col, t.n_col + 1);
     }
     m_il_meta.upload(meta);
@@ -907,7 +907,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                        static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, 4 * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
+      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
                          l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
                          m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p);
     }

@@ -39,12 +39,14 @@ namespace slpx {
   g_ldlt_clocks[8 + (k)] = wall_clock64()
 
 constexpr int kIlLanes = 64;  // lanes of a wave
-constexpr int kIlW = 16;      // problems per interleaved row
-constexpr int kIlSlots = 16;  // entries of a level a factorization workgroup works on at a time
-constexpr int kIlFactorThreads = kIlSlots * kIlW;
+constexpr int kIlWShift = 4;  // (measured: 8-wide rows 0.74 ms per factorization of 512 x N=1000, 16-wide 0.67)
+constexpr int kIlW = 1 << kIlWShift;  // problems per interleaved row
+constexpr int kIlRowsPerChunk = 64 / kIlW;  // rows groups covering a 64-problem chunk
+constexpr int kIlFactorThreads = 256;
+constexpr int kIlSlots = kIlFactorThreads / kIlW;  // entries of a level a factorization workgroup works on at a time
 
 // number of 16-problem rows groups a batch occupies (padded to whole waves of 64 problems)
-__host__ __device__ inline int il_groups(int batch) { return 4 * ((batch + 63) / 64); }
+__host__ __device__ inline int il_groups(int batch) { return kIlRowsPerChunk * ((batch + 63) / 64); }
 
 // [b][i] (stride `stride` doubles per problem) -> [b / 16][i][16]; problems beyond the batch
 // get 0.  64 x 64 tiles through LDS so that both sides move whole cache lines.
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void il_gather_kernel(const double* __restrict
   for (int r = ty; r < 64; r += 4) {  // r = entry within the tile, tx = problem within the chunk
     const int i = i0 + r;
     if (i < count)
-      dst[(static_cast<size_t>(c * 4 + (tx >> 4)) * count + i) * kIlW + (tx & 15)] = tile[tx][r];
+      dst[(static_cast<size_t>(c * kIlRowsPerChunk + (tx >> kIlWShift)) * count + i) * kIlW + (tx & (kIlW - 1))] = tile[tx][r];
   }
 }
 
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void il_scatter_kernel(const double* __restric
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
     const int i = i0 + r;
-    tile[r][tx] = i < count ? src[(static_cast<size_t>(c * 4 + (tx >> 4)) * count + i) * kIlW + (tx & 15)] : 0.0;
+    tile[r][tx] = i < count ? src[(static_cast<size_t>(c * kIlRowsPerChunk + (tx >> kIlWShift)) * count + i) * kIlW + (tx & (kIlW - 1))] : 0.0;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
   const uint32_t task_index = task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   const int g = blockIdx.y, lane = threadIdx.x;  // g: group of 16 problems
-  const int slot = lane >> 4, pl = lane & 15;     // slot: 0 .. kIlSlots - 1
+  const int slot = lane >> kIlWShift, pl = lane & (kIlW - 1);  // slot: 0 .. kIlSlots - 1
   const int b = g * kIlW + pl;
   const bool in_batch = b < batch;
   const double delta = in_batch ? reg[2 * b] : 0.0, gamma = in_batch ? reg[2 * b + 1] : 0.0;
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_fwd_il_kernel(
   extern __shared__ __attribute__((aligned(16))) double il_smem[];
   const LdltTask t = L.tasks[task_base + blockIdx.x];
   const int c = blockIdx.y, lane = threadIdx.x;  // c: chunk of 64 problems = four rows groups
-  const size_t g = static_cast<size_t>(c) * 4 + (lane >> 4);
-  const int pl = lane & 15;
+  const size_t g = static_cast<size_t>(c) * kIlRowsPerChunk + (lane >> kIlWShift);
+  const int pl = lane & (kIlW - 1);
   const double* rhs = rhs_il + g * n * kIlW + pl;
   const double* Lx = Lx_il + g * nnzL * kIlW + pl;
   const double* D = D_il + g * n * kIlW + pl;
@@ -369,8 +371,8 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_bwd_il_kernel(
   const LdltTask t = L.tasks[task_base + blockIdx.x];
   const int c = blockIdx.y, lane = threadIdx.x;
   const int b = c * kIlLanes + lane;
-  const size_t g = static_cast<size_t>(c) * 4 + (lane >> 4);
-  const int pl = lane & 15;
+  const size_t g = static_cast<size_t>(c) * kIlRowsPerChunk + (lane >> kIlWShift);
+  const int pl = lane & (kIlW - 1);
   const double* Lx = Lx_il + g * nnzL * kIlW + pl;
   const double* zv = zv_il + g * n * kIlW + pl;
   double* xg = xg_il + g * n * kIlW + pl;

@@ -483,48 +483,35 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   __syncthreads();
   SLPX_LDLT_CLOCK(17);
+  // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
+  {
+    uint32_t q = tid;
+    for (; q + 3 * 256 < n_items; q += 4 * 256) {
+      const double v0 = Lx[items[q].x], v1 = Lx[items[q + 256].x], v2 = Lx[items[q + 512].x],
+                   v3 = Lx[items[q + 768].x];
+      vals[q] = v0;
+      vals[q + 256] = v1;
+      vals[q + 512] = v2;
+      vals[q + 768] = v3;
+    }
+    for (; q < n_items; q += 256) vals[q] = Lx[items[q].x];
+    for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[colperm[i]];
+    if (tid == 0) x[t.n_col] = 1.0;
+  }
   // rows owned by ancestor tasks (later rounds) must be final before they are gathered
   if (round_cnt != nullptr && static_cast<int>(t.round) + 1 < L.n_rounds)
     round_wait(&round_cnt[b * L.n_rounds + t.round + 1],
                L.round_ptr[t.round + 2] - L.round_ptr[t.round + 1], nullptr);
   {
-    auto load_item = [&](uint32_t q, double& v, uint32_t& r) {
-      const uint2 it = items[q];
-      const double lv = Lx[it.x];
-      if (it.y & 0x80000000u) {
-        v = lv * coherent_load(&xg[it.y & 0x7fffffffu], round_cnt != nullptr);
-        r = t.n_col;
-      } else {
-        v = lv;
-        r = it.y;
+    // fold the finished x of ancestor rows into the staged values; those items then point at
+    // the constant-one slot (each thread touches the items it staged itself: no barrier needed)
+    for (uint32_t q = tid; q < n_items; q += 256) {
+      const uint32_t ref = items[q].y;
+      if (ref & 0x80000000u) {
+        vals[q] *= coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr);
+        items[q].y = t.n_col;
       }
-    };
-    uint32_t q = tid;
-    for (; q + 3 * 256 < n_items; q += 4 * 256) {
-      double v0, v1, v2, v3;
-      uint32_t r0, r1, r2, r3;
-      load_item(q, v0, r0);
-      load_item(q + 256, v1, r1);
-      load_item(q + 512, v2, r2);
-      load_item(q + 768, v3, r3);
-      vals[q] = v0;
-      vals[q + 256] = v1;
-      vals[q + 512] = v2;
-      vals[q + 768] = v3;
-      items[q].y = r0;
-      items[q + 256].y = r1;
-      items[q + 512].y = r2;
-      items[q + 768].y = r3;
     }
-    for (; q < n_items; q += 256) {
-      double v0;
-      uint32_t r0;
-      load_item(q, v0, r0);
-      vals[q] = v0;
-      items[q].y = r0;
-    }
-    for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[colperm[i]];
-    if (tid == 0) x[t.n_col] = 1.0;
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(18);

@@ -495,3 +495,34 @@ extern "C" void hc_contrib_stats(hc_handle* h, int64_t* out) {
   out[3] = big;
   out[4] = total;
 }
+
+// Fundamental supernodes of L (column j + 1 joins column j's supernode when j's only etree
+// child... i.e. parent[j] == j + 1 and pattern(j) = {j + 1} U pattern(j + 1)):
+// out = {supernodes, widest (columns), longest column below the diagonal, columns in
+//        supernodes >= 4 wide, columns in supernodes >= 16 wide}
+extern "C" void hc_supernodes(hc_handle* h, int64_t* out) {
+  const LdltPlan& L = h->l;
+  const int n = L.n;
+  std::vector<int> nchild(n, 0);
+  for (int j = 0; j < n; ++j)
+    if (L.parent[j] >= 0) ++nchild[L.parent[j]];
+  int64_t count = 0, widest = 0, longest = 0, in4 = 0, in16 = 0;
+  int j = 0;
+  while (j < n) {
+    int w = 1;
+    while (j + w < n && L.parent[j + w - 1] == j + w && nchild[j + w] == 1 &&
+           (L.Lp[j + w] - L.Lp[j + w - 1]) == (L.Lp[j + w + 1] - L.Lp[j + w]) + 1)
+      ++w;
+    ++count;
+    widest = std::max<int64_t>(widest, w);
+    if (w >= 4) in4 += w;
+    if (w >= 16) in16 += w;
+    for (int k = j; k < j + w; ++k) longest = std::max<int64_t>(longest, L.Lp[k + 1] - L.Lp[k]);
+    j += w;
+  }
+  out[0] = count;
+  out[1] = widest;
+  out[2] = longest;
+  out[3] = in4;
+  out[4] = in16;
+}

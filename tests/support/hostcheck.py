@@ -53,6 +53,7 @@ def lib():
     sig("hc_create", vp, vp, vp, i32, i32, i32)
     sig("hc_destroy", None, vp)
     sig("hc_tape_jit_compiles", i32, vp)
+    sig("hc_supernodes", None, vp, vp)
     sig("hc_info", None, vp, vp)
     sig("hc_pattern", i32, vp, ctypes.c_int, vp, vp)
     sig("hc_perm", None, vp, vp)
@@ -99,6 +100,12 @@ class HostCheck:
     def tape_jit_compiles(self):
         """Bodies of the run-time generated tape kernel that hipRTC compiled for gfx950 (-1: rejected)."""
         return lib().hc_tape_jit_compiles(self._h)
+
+    def supernodes(self):
+        """Fundamental supernodes of L: count, widest, longest column, columns in >=4 / >=16 wide ones."""
+        out = np.zeros(5, dtype=np.int64)
+        lib().hc_supernodes(self._h, out.ctypes.data)
+        return dict(zip(("count", "widest", "longest_column", "cols_in_ge4", "cols_in_ge16"), (int(v) for v in out)))
 
     def pattern(self, which):
         nnz = lib().hc_pattern(self._h, which, None, None)

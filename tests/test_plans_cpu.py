@@ -56,3 +56,23 @@ def test_generated_tape_kernel_compiles_for_gfx950(fresh, slpx, orc, hostcheck):
     hc = hostcheck.HostCheck(pp)
     # the stage family (64 members) and the cost groups qualify for a body
     assert hc.tape_jit_compiles() >= 1
+
+
+def test_no_supernode_reaches_an_mfma_tile(fresh, slpx, orc, hostcheck):
+    """north_star: "MFMA only on dense supernode panels".  v_mfma_f64_16x16x4_f64 wants panels
+    at least 16 columns wide; with the depth-first ordering used here (nested dissection,
+    8-node leaves) the factors of the transcription problems have no such supernode at all —
+    the measured reason the panel path is not built.  Recorded for cart-pole
+    N=1000 (the BASELINE horizon) and for g-fold, whose inequality rows give dense blocks."""
+    from tests.support import gfold, model
+
+    pp, _ = cases.build_pair("cart_pole", 1000, slpx, orc)
+    sn = hostcheck.HostCheck(pp).supernodes()
+    assert sn["widest"] < 16 and sn["cols_in_ge16"] == 0
+    assert sn["longest_column"] < 16
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    g = gfold.build(mp, 100)
+    sg = hostcheck.HostCheck(g.p).supernodes()
+    assert sg["widest"] < 16 and sg["cols_in_ge16"] == 0
+    print("supernodes cart-pole N=1000:", sn, " g-fold N=100:", sg)

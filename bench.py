@@ -235,6 +235,20 @@ def main():
                   "kkt_rhs": (kb["rhs"], info["rhs_bytes"]),
                   "ldlt_factor": (kb["factor"] / nfb, info["factor_bytes"]),
                   "ldlt_solve": (kb["solve"], info["solve_bytes"] // 2)}
+            # HBM bytes per launch group from the committed PMC passes of this configuration
+            btraffic = None
+            bfile = ROOT / "profiles" / "r01_batched_traffic.json"
+            if bfile.exists() and N == 1000 and RB == 512:
+                tj = json.loads(bfile.read_text())
+                pre = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
+                       "kkt_assemble": ("kkt_assemble",), "kkt_rhs": ("kkt_rhs_kernel",),
+                       "ldlt_factor": ("ldlt_factor_il_kernel", "il_gather_kernel", "ldlt_stats_il_kernel"),
+                       "ldlt_solve": ("ldlt_bwd_il_kernel",)}
+                # grids with fewer than 1000 workgroup-threads are the single-problem launches of the same run
+                btraffic = {grp: sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
+                                     if kname.startswith(pres) for grid, e in grids.items()
+                                     if not (kname.startswith(("slpx_tape_templates", "tape_")) and int(grid) < 100000))
+                            for grp, pres in pre.items()}
             out["batched"] = {
                 "batch": RB, "steps_per_s": RB / (kb["total"] * 1e-3),
                 "per_kernel_ms": {k: v[0] for k, v in gb.items()},
@@ -242,6 +256,8 @@ def main():
                 "per_kernel_hbm_frac": {k: RB * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                         for k, v in gb.items()},
                 "factorizations_per_step": kb["factorizations"],
+                "algorithmic_bytes": {k: RB * v[1] for k, v in gb.items()},
+                "traffic": btraffic,
             }
             sysb.close()
         if not args.no_cpu_baseline and world == 1:

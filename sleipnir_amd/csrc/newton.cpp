@@ -38,6 +38,16 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
   if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
   m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
+  // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
+  // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
+  // and usually has a round more than necessary; twice the task size fixes both (cart-pole
+  // N=5000: 547 tasks / 4 rounds -> 265 / 3, factorization 73 -> 62 us, backward solve 42 -> 38;
+  // at N=1000 the 137 tasks of the default are the better choice: 39 vs 45 us).
+  if (opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
+      std::getenv("SLPX_TASK_ENTRIES") == nullptr) {
+    lopt.task_entries *= 2;
+    m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
+  }
   lap("= LDLT symbolic");
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
   lap("= device upload + tape JIT");

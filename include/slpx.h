@@ -179,6 +179,23 @@ int slpx_system_set_rhs(slpx_system* s, const double* rhs);
  * values in the order of pattern 5 (lower CSC, forced diagonal), [batch][nnz]. */
 int slpx_system_set_lhs(slpx_system* s, const double* lhs);
 
+/* ---- The linear-solver seam on its own (SURVEY.md §8b seam 3) ----
+ * RegularizedLDLT<double>(use_sparse = true, n, m_e, gamma_min) (util/regularized_ldlt.hpp:45-51):
+ * a system with no expression graph, made from the lower-triangular CSC pattern of the matrix
+ * compute() will be given — the `lhs` of interior_point.hpp:434-440, same pattern on every call
+ * (regularized_ldlt.hpp:66-68); diagonal entries may be absent, they are added like
+ * sparse_regularized_ldlt.hpp:67 does.  The first n rows/columns are regularized with +delta, the
+ * other m_e with -gamma (:217-224).  The handle serves
+ *   slpx_ldlt_reset(gamma_min)                       the constructor's gamma_min      (:45-51)
+ *   slpx_ldlt_set_matrix + slpx_ldlt_compute         compute(lhs), info()             (:72, :56)
+ *   slpx_system_set_rhs + slpx_ldlt_solve + slpx_system_get(3)     solve(rhs)         (:87)
+ * (reg[] of slpx_ldlt_compute = hessian_regularization(), constraint_jacobian_regularization(),
+ * :111,:122).  NULL + slpx_last_error() on failure, e.g. without a HIP device. */
+slpx_system* slpx_ldlt_create(int32_t n, int32_t m_e, const int32_t* colptr, const int32_t* rowidx,
+                              int32_t batch, int32_t device);
+/* values[batch][nnz] in the order of the pattern given to slpx_ldlt_create */
+int slpx_ldlt_set_matrix(slpx_system* s, const double* values);
+
 /* ---- The interior-point iteration AROUND the Newton step, on the resident iterate ----
  * (one problem per system).  What interior_point() does between two Newton steps with
  * O(n) host loops over Eigen vectors (interior_point.hpp:488-563, :775-832) as kernels on

@@ -140,6 +140,8 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_ldlt_create", vp, i32, i32, vp, vp, i32, i32)
+    sig("slpx_ldlt_set_matrix", ctypes.c_int, vp, vp)
     sig("slpx_ipm_direction", ctypes.c_int, vp, f64, vp)
     sig("slpx_ipm_trial", ctypes.c_int, vp, f64, ctypes.c_int, vp)
     sig("slpx_ipm_commit", ctypes.c_int, vp, f64, f64, ctypes.c_int)
@@ -240,6 +242,25 @@ class Problem:
 
 class System:
     """Compiled Newton system on one GPU (include/slpx.h, slpx_system_* and kernels)."""
+
+    @classmethod
+    def linear_solver(cls, n, m_e, colptr, rowidx, batch=1, device=0):
+        """RegularizedLDLT on its own (slpx_ldlt_create): lower-triangular CSC pattern only."""
+        cp = np.ascontiguousarray(colptr, dtype=np.int32)
+        ri = np.ascontiguousarray(rowidx, dtype=np.int32)
+        self = cls.__new__(cls)
+        self._h = lib().slpx_ldlt_create(int(n), int(m_e), cp.ctypes.data, ri.ctypes.data, int(batch), int(device))
+        if not self._h:
+            raise SlpxError(lib().slpx_last_error().decode())
+        self.batch = batch
+        out = np.zeros(len(INFO_KEYS) + 4, dtype=np.int64)
+        _check(lib().slpx_system_info(self._h, out.ctypes.data))
+        self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
+        return self
+
+    def set_matrix(self, values):
+        a = _f64(values)
+        _check(lib().slpx_ldlt_set_matrix(self._h, a.ctypes.data))
 
     def __init__(self, problem: Problem, batch: int = 1, device: int = 0, perm=None):
         p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)

@@ -428,6 +428,40 @@ int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24) {
   });
 }
 
+slpx_system* slpx_ldlt_create(int32_t n, int32_t m_e, const int32_t* colptr, const int32_t* rowidx, int32_t batch,
+                              int32_t device) {
+  slpx_system* out = nullptr;
+  guard([&] {
+    slpx::CscPattern lower;
+    lower.rows = lower.cols = n + m_e;
+    lower.colptr.assign(colptr, colptr + n + m_e + 1);
+    lower.rowidx.assign(rowidx, rowidx + colptr[n + m_e]);
+    slpx::NewtonOptions opt;
+    opt.batch = batch;
+    opt.device = device;
+    auto sys = std::make_unique<slpx_system>();
+    sys->sys = std::make_unique<slpx::NewtonSystem>(lower, n, m_e, opt);
+    sys->ref = sys->sys.get();
+    out = sys.release();
+  });
+  return out;
+}
+
+int slpx_ldlt_set_matrix(slpx_system* s, const double* values) {
+  return guard([&] {
+    auto& sys = s->get();
+    const std::vector<int32_t>& map = sys.user_lhs_map();
+    if (map.empty()) throw std::runtime_error("slpx_ldlt_set_matrix: not a system made by slpx_ldlt_create");
+    auto& dev = sys.device();
+    const size_t B = dev.batch(), nnz = sys.kkt().lhs.nnz(), user_nnz = map.size();
+    std::vector<double> lhs(B * nnz, 0.0);
+    for (size_t b = 0; b < B; ++b)
+      for (size_t k = 0; k < user_nnz; ++k) lhs[b * nnz + map[k]] = values[b * user_nnz + k];
+    SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_lhs(), lhs.data(), lhs.size() * sizeof(double), hipMemcpyHostToDevice, dev.stream()));
+    SLPX_HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  });
+}
+
 int slpx_debug_tape_clocks(slpx_system* s, uint64_t* out16) {
   return guard([&] {
     unsigned long long t[16];

@@ -2,10 +2,12 @@
 
 #include "setup_timing.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 
 namespace slpx {
 
@@ -37,6 +39,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
   if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
+  if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
   m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
   // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
   // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
@@ -51,6 +54,75 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   lap("= LDLT symbolic");
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
   lap("= device upload + tape JIT");
+  reset_regularization();
+}
+
+NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const NewtonOptions& opt)
+    : m_opt(opt) {
+  if (lower.cols != n_dec + m_e || lower.rows != lower.cols)
+    throw std::runtime_error("slpx: the matrix must be square of order n + m_e");
+  m_opt.batch = std::max(1, opt.batch);
+  const int dim = n_dec + m_e;
+  // the structure a DeviceNlp expects, with nothing in it but the sizes
+  m_s.n = n_dec;
+  m_s.m_e = m_e;
+  m_s.m_i = 0;
+  m_s.nV = 1;
+  m_s.V_static_raw.assign(1, 0.0);
+  m_s.V_scale_idx.assign(1, -1);
+  m_s.V_is_static.assign(1, 1);
+  auto empty = [](int rows, int cols) {
+    CscPattern p;
+    p.rows = rows;
+    p.cols = cols;
+    p.colptr.assign(cols + 1, 0);
+    return p;
+  };
+  m_s.g_pat = empty(1, n_dec);
+  m_s.Ae = empty(m_e, n_dec);
+  m_s.Ai = empty(0, n_dec);
+  m_s.Hf = empty(n_dec, n_dec);
+  m_s.Hc = empty(n_dec, n_dec);
+  // pattern = the caller's lower triangle plus any missing diagonal entry
+  m_k.n = n_dec;
+  m_k.m_e = m_e;
+  m_k.m_i = 0;
+  m_k.dim = dim;
+  m_k.lhs.rows = m_k.lhs.cols = dim;
+  m_k.lhs.colptr.assign(1, 0);
+  m_user_lhs_map.assign(lower.rowidx.size(), -1);
+  std::vector<uint8_t> diag_has_source(dim, 0);
+  for (int c = 0; c < dim; ++c) {
+    std::vector<std::pair<int32_t, int32_t>> rows;  // (row, index in the caller's arrays or -1)
+    bool has_diag = false;
+    for (int32_t p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
+      const int32_t r = lower.rowidx[p];
+      if (r < c || r >= dim) throw std::runtime_error("slpx: the pattern must be the lower triangle in CSC form");
+      has_diag = has_diag || r == c;
+      rows.emplace_back(r, p);
+    }
+    diag_has_source[c] = has_diag;
+    if (!has_diag) rows.emplace_back(c, -1);
+    std::sort(rows.begin(), rows.end());
+    for (auto& [r, p] : rows) {
+      if (p >= 0) m_user_lhs_map[p] = static_cast<int32_t>(m_k.lhs.rowidx.size());
+      m_k.lhs.rowidx.push_back(r);
+    }
+    m_k.lhs.colptr.push_back(static_cast<int32_t>(m_k.lhs.rowidx.size()));
+  }
+  const int nnz = m_k.lhs.nnz();
+  m_k.dptr.assign(nnz + 1, 0);
+  m_k.pptr.assign(nnz + 1, 0);
+  m_k.fast_src.assign(nnz, -1);
+  m_k.g_src.assign(n_dec, -1);
+  m_k.ai_rowptr.assign(1, 0);
+  m_k.ae_rowptr.assign(m_e + 1, 0);
+  LdltOptions lopt = opt.ldlt;
+  if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
+  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+  m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
+  m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
+  m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));
   reset_regularization();
 }
 

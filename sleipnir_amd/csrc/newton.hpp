@@ -41,6 +41,15 @@ class NewtonSystem {
                const std::vector<NodeId>& c_i, const NewtonOptions& opt,
                const std::vector<int32_t>* user_perm = nullptr);
 
+  // Linear-solver seam only (RegularizedLDLT, util/regularized_ldlt.hpp:45-51, sparse
+  // branch): no expression graph, no tape, no KKT assembly — just the lower-triangular CSC
+  // pattern of the matrix compute() will be given (diagonal entries may be absent; they are
+  // added, sparse_regularized_ldlt.hpp:67).  `n_dec` leading rows/columns get +delta, the
+  // remaining `m_e` get -gamma.
+  NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const NewtonOptions& opt);
+  // position in the internal lhs (pattern 5) of every entry of the pattern given above
+  const std::vector<int32_t>& user_lhs_map() const { return m_user_lhs_map; }
+
   // The model this system was compiled from (feasibility restoration builds its
   // augmented model out of the same expressions).
   Graph& graph() const { return *m_graph; }
@@ -104,6 +113,7 @@ class NewtonSystem {
   std::vector<double> m_prev_delta, m_prev_gamma;
   int m_last_factorizations = 0;
   std::function<void()> m_after_attempt;
+  std::vector<int32_t> m_user_lhs_map;
 };
 
 }  // namespace slpx

@@ -105,6 +105,30 @@ typedef struct slpx_report {
   double t_restoration;       /* the restoration iterations; in t_total */
 } slpx_report;
 
+/* Problem::add_callback / clear_callbacks (problem.hpp:690-712) with IterationInfo
+ * (solver/iteration_info.hpp:13-41).  Called at the start of every iteration with the iterate
+ * and the AD outputs the solver holds at that point: V = [f | c_e | c_i | g | A_e | A_i | H_f |
+ * H_c], matrices as value arrays over the static CSC patterns (off[] = where each block
+ * starts; patterns and counts from slpx_problem_system + slpx_system_pattern / _info).  The
+ * Lagrangian Hessian of iteration_info.hpp:34 is H_f + H_c.  Return non-zero to stop the solve
+ * with CALLBACK_REQUESTED_STOP (exit_status.hpp:17).  The pointers are valid during the call. */
+typedef struct slpx_iteration_info {
+  int32_t iteration;
+  int32_t n, m_e, m_i;
+  const double* x; /* n */
+  const double* s; /* m_i */
+  const double* y; /* m_e */
+  const double* z; /* m_i */
+  const double* V;
+  int64_t off[8]; /* f, c_e, c_i, g, A_e, A_i, H_f, H_c */
+} slpx_iteration_info;
+typedef int (*slpx_iteration_callback)(const slpx_iteration_info* info, void* user);
+int slpx_problem_add_callback(slpx_problem* p, slpx_iteration_callback callback, void* user);
+int slpx_problem_clear_callbacks(slpx_problem* p);
+/* The system solve() runs on (compiled now if it was not yet); owned by the problem, do NOT
+ * pass it to slpx_system_destroy.  NULL + slpx_last_error() without a HIP device. */
+slpx_system* slpx_problem_system(slpx_problem* p);
+
 /* Problem::solve.  Returns slp::ExitStatus (solver/exit_status.hpp:13-43):
  * 0 success, 1 callback stop, -1..-10 as in the reference; -100 on library error. */
 int slpx_problem_solve(slpx_problem* p, const slpx_options* opt, slpx_report* report);

@@ -140,6 +140,9 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_problem_add_callback", ctypes.c_int, vp, vp, vp)
+    sig("slpx_problem_clear_callbacks", ctypes.c_int, vp)
+    sig("slpx_problem_system", vp, vp)
     sig("slpx_ldlt_create", vp, i32, i32, vp, vp, i32, i32)
     sig("slpx_ldlt_set_matrix", ctypes.c_int, vp, vp)
     sig("slpx_ipm_direction", ctypes.c_int, vp, f64, vp)
@@ -166,6 +169,15 @@ def _check(rc):
     if rc < 0:
         raise SlpxError(lib().slpx_last_error().decode())
     return rc
+
+
+class IterationInfo(ctypes.Structure):
+    _fields_ = [("iteration", ctypes.c_int32), ("n", ctypes.c_int32), ("m_e", ctypes.c_int32),
+                ("m_i", ctypes.c_int32)] + [(k, ctypes.POINTER(ctypes.c_double)) for k in "xsyzV"] + [
+                    ("off", ctypes.c_int64 * 8)]
+
+
+IterationCallback = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(IterationInfo), ctypes.c_void_p)
 
 
 class Problem:
@@ -233,6 +245,32 @@ class Problem:
             raise SlpxError(lib().slpx_last_error().decode())
         return status, {f[0]: getattr(rep, f[0]) for f in Report._fields_}
 
+    def add_callback(self, fn):
+        """Problem::add_callback (problem.hpp:690-709): fn(info: dict) -> truthy to stop."""
+
+        def trampoline(info_ptr, _user):
+            i = info_ptr.contents
+            view = lambda p, k: np.ctypeslib.as_array(p, shape=(k,)).copy() if k else np.zeros(0)
+            off = list(i.off)
+            return int(bool(fn({"iteration": i.iteration, "x": view(i.x, i.n), "s": view(i.s, i.m_i),
+                                "y": view(i.y, i.m_e), "z": view(i.z, i.m_i), "f": i.V[off[0]], "off": off,
+                                "V": i.V})))
+
+        cb = IterationCallback(trampoline)
+        self._callbacks = getattr(self, "_callbacks", []) + [cb]  # keep the thunks alive
+        _check(lib().slpx_problem_add_callback(self._h, ctypes.cast(cb, ctypes.c_void_p), None))
+
+    def system(self) -> "System":
+        """The system solve() runs on (slpx_problem_system); owned by the problem."""
+        h = lib().slpx_problem_system(self._h)
+        if not h:
+            raise SlpxError(lib().slpx_last_error().decode())
+        return System._adopt(h, batch=1, borrowed=True)
+
+    def clear_callbacks(self):
+        _check(lib().slpx_problem_clear_callbacks(self._h))
+        self._callbacks = []
+
     def duals(self):
         n, me, mi = self.dims
         s, y, z = np.zeros(mi), np.zeros(me), np.zeros(mi)
@@ -243,20 +281,28 @@ class Problem:
 class System:
     """Compiled Newton system on one GPU (include/slpx.h, slpx_system_* and kernels)."""
 
+    _borrowed = False
+
     @classmethod
-    def linear_solver(cls, n, m_e, colptr, rowidx, batch=1, device=0):
-        """RegularizedLDLT on its own (slpx_ldlt_create): lower-triangular CSC pattern only."""
-        cp = np.ascontiguousarray(colptr, dtype=np.int32)
-        ri = np.ascontiguousarray(rowidx, dtype=np.int32)
+    def _adopt(cls, handle, batch, borrowed=False):
         self = cls.__new__(cls)
-        self._h = lib().slpx_ldlt_create(int(n), int(m_e), cp.ctypes.data, ri.ctypes.data, int(batch), int(device))
-        if not self._h:
-            raise SlpxError(lib().slpx_last_error().decode())
+        self._h = handle
+        self._borrowed = borrowed
         self.batch = batch
         out = np.zeros(len(INFO_KEYS) + 4, dtype=np.int64)
         _check(lib().slpx_system_info(self._h, out.ctypes.data))
         self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
         return self
+
+    @classmethod
+    def linear_solver(cls, n, m_e, colptr, rowidx, batch=1, device=0):
+        """RegularizedLDLT on its own (slpx_ldlt_create): lower-triangular CSC pattern only."""
+        cp = np.ascontiguousarray(colptr, dtype=np.int32)
+        ri = np.ascontiguousarray(rowidx, dtype=np.int32)
+        h = lib().slpx_ldlt_create(int(n), int(m_e), cp.ctypes.data, ri.ctypes.data, int(batch), int(device))
+        if not h:
+            raise SlpxError(lib().slpx_last_error().decode())
+        return cls._adopt(h, batch)
 
     def set_matrix(self, values):
         a = _f64(values)
@@ -273,9 +319,9 @@ class System:
         self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
 
     def close(self):
-        if self._h:
+        if self._h and not self._borrowed:
             lib().slpx_system_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def pattern(self, which: int):
         nnz = lib().slpx_system_pattern(self._h, which, None, None)

@@ -118,6 +118,38 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
   return rc == 0 ? status : rc;
 }
 
+int slpx_problem_add_callback(slpx_problem* p, slpx_iteration_callback callback, void* user) {
+  return guard([&] {
+    if (!callback) throw std::runtime_error("slpx_problem_add_callback: null callback");
+    p->problem.add_callback([p, callback, user](const slp::IterationInfo& it) -> bool {
+      const auto& st = p->problem.compile().structure();
+      slpx_iteration_info info{};
+      info.iteration = it.iteration;
+      info.n = st.n;
+      info.m_e = st.m_e;
+      info.m_i = st.m_i;
+      info.x = it.x.data();
+      info.s = it.s.data();
+      info.y = it.y.data();
+      info.z = it.z.data();
+      info.V = it.V.data();
+      const int off[8] = {st.off_f, st.off_ce, st.off_ci, st.off_g, st.off_Ae, st.off_Ai, st.off_Hf, st.off_Hc};
+      for (int k = 0; k < 8; ++k) info.off[k] = off[k];
+      return callback(&info, user) != 0;
+    });
+  });
+}
+int slpx_problem_clear_callbacks(slpx_problem* p) {
+  return guard([&] { p->problem.clear_callbacks(); });
+}
+slpx_system* slpx_problem_system(slpx_problem* p) {
+  const int rc = guard([&] {
+    if (!p->borrowed) p->borrowed = std::make_unique<slpx_system>();
+    p->borrowed->ref = &p->problem.compile();
+  });
+  return rc == 0 ? p->borrowed.get() : nullptr;
+}
+
 void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double* z) {
   if (s) std::copy(p->problem.slack().begin(), p->problem.slack().end(), s);
   if (y) std::copy(p->problem.equality_duals().begin(), p->problem.equality_duals().end(), y);

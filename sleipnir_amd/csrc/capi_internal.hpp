@@ -7,13 +7,14 @@
 #include "newton.hpp"
 #include "slp/problem.hpp"
 
-struct slpx_problem {
-  slp::Problem problem;
-  double t_compile = 0.0;
-};
-
 struct slpx_system {
   std::unique_ptr<slpx::NewtonSystem> sys;
   slpx::NewtonSystem* ref = nullptr;
   slpx::NewtonSystem& get() { return *ref; }
+};
+
+struct slpx_problem {
+  slp::Problem problem;
+  double t_compile = 0.0;
+  std::unique_ptr<slpx_system> borrowed;  // slpx_problem_system()
 };

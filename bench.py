@@ -43,7 +43,9 @@ def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
     steps = 0
     phases = np.zeros(4)
     while True:
-        _, t = op.newton_step(x, s, y, z, mu, True, None, True)
+        # 2 = keep the symbolic analysis, forget delta/gamma: every step starts like the first
+        # iteration of a solve, as the GPU leg's reset_regularization() makes its steps do
+        _, t = op.newton_step(x, s, y, z, mu, True, None, 2)
         phases += np.array([t["t_ad"], t["t_build"], t["t_decomp"], t["t_solve"]])
         steps += 1
         if time.perf_counter() - t0 > budget_s or steps >= 200:
@@ -53,7 +55,8 @@ def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
     return {
         "value": steps / el, "unit": "Newton steps/s", "cores": 1, "kind": "port",
         "sample": f"{steps} steps of cart-pole N={N} (interior state), oracle/ single thread, "
-                  f"{nfact} factorizations/step, nnz(L)={nnzL}",
+                  f"regularization memory cleared before every step, {nfact} factorizations/step "
+                  f"(the unregularized attempt, which ends on a zero pivot, and delta=1e-4), nnz(L)={nnzL}",
         "ms_per_step": 1e3 * el / steps,
         "phase_ms": {k: 1e3 * v / steps for k, v in
                      zip(["ad_refresh", "kkt_build", "kkt_decomp", "kkt_solve"], phases)},
@@ -150,6 +153,18 @@ def main():
         system.reset_regularization()
         kt = system.time_step(iters=max(10, min(100, args.steps)), refresh_ad=True)
         nf = max(1.0, kt["factorizations"])
+        # what the inertia-correcting loop did on this state (same call sequence as one step)
+        system.reset_regularization()
+        system.sweep(True)
+        system.assemble()
+        system.rhs()
+        _, reg_used, nf_check = system.compute()
+        regularization = {
+            "memory": "cleared before every step (each step starts like the first iteration of a solve)",
+            "delta": float(reg_used[0, 0]), "gamma": float(reg_used[0, 1]), "factorizations": int(nf_check),
+            "unregularized_attempt": "not launched: the symbolic phase found a structurally zero pivot"
+            if info["struct_singular"] else "launched",
+        }
         groups = {
             "tape_sweep": (kt["sweep"], info["sweep_bytes"]),
             "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
@@ -190,6 +205,7 @@ def main():
             "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None
                                 for k, v in groups.items()},
             "factorizations_per_step": kt["factorizations"],
+            "regularization": regularization,
             "note": "single N=1000 problem: every kernel is dependency-latency bound (SURVEY.md "
                     "§7 hard part 1); HBM fractions are meaningful on a batch (--batched-roofline; "
                     "DESIGN.md §4, profiles/r01_batched_*)",

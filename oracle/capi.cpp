@@ -312,6 +312,7 @@ int orc_problem_newton_step(int p, const double* x, const double* s, const doubl
       h.solver = std::make_unique<RegularizedLDLT>(sparse, n, m_e, 1e-10);
       if (perm && perm_len > 0) h.solver->set_permutation(std::vector<int>(perm, perm + perm_len));
     }
+    if (reuse_solver == 2) h.solver->forget_regularization();
     t2 = clock::now();
     h.solver->compute(h.lhs);
     t3 = clock::now();

@@ -338,6 +338,9 @@ class RegularizedLDLT {
   double hessian_regularization() const { return m_prev_delta; }
   double constraint_jacobian_regularization() const { return m_prev_gamma; }
   int factorizations() const { return m_factorizations; }
+  // Back to the state of a freshly constructed object (:45-51) without losing the symbolic
+  // analysis — what a new solve() starts from, minus the one-off analyzePattern.
+  void forget_regularization() { m_prev_delta = m_prev_gamma = 0.0; }
   const SimplicialLDLT& sparse_solver() const { return m_sparse; }
 
   // sparse_regularized_ldlt.hpp:64-152 (dense_regularized_ldlt.hpp:59-136 is the

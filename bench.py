@@ -134,14 +134,12 @@ def main():
         torch.cuda.synchronize()
 
     nfact_total = 0
-    for _ in range(args.warmup):
-        system.reset_regularization()
-        system.newton_step(True)
+    # the step loop runs on the library side (slpx_newton_steps): K steps, each one waited
+    # for before the next is launched, regularization memory cleared before every step
+    system.newton_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        system.reset_regularization()
-        info_step = system.newton_step(True)
+    info_step = system.newton_steps(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert np.all(info_step == 0), "factorization failed in the timed region"

@@ -194,6 +194,12 @@ int slpx_ldlt_solve(slpx_system* s); /* rhs -> p, reusable after one compute */
 int slpx_step_backsub(slpx_system* s);
 /* AD refresh (optional) + assemble + rhs + compute + solve + backsub */
 int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info);
+/* `count` such steps one after the other on the resident state, each waited for like a single
+ * one (the host reads the inertia before launching the next) — the loop a C++ harness writes
+ * around slpx_newton_step, minus a foreign-function call per step.  forget_regularization != 0
+ * clears the delta/gamma memory before every step (slpx_ldlt_reset keeps gamma_min), so each
+ * step starts like the first iteration of a solve.  info[batch] = OR over the steps. */
+int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_regularization, int32_t* info);
 
 /* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values,
  * 8 x, 9 s, 10 y, 11 z (the resident iterate) */
@@ -266,6 +272,11 @@ int slpx_debug_tape_clocks(slpx_system* s, uint64_t* out16);
  * gathered, levels done, update blocks done, exit}, [8..15] forward solve, [16..23]
  * backward solve.  Returns what was recorded so far, then arms `next_round`. */
 int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24);
+/* With SLPX_TAPE_JIT_CLOCKS=1 in the environment when the system was made: ticks of the first
+ * `blocks` (<= 2048) workgroups of the generated tape kernel's last launch, out[8*blocks]: {entry,
+ * exit, body entered, leaves loaded, forward part done, -, -, -} per workgroup.
+ * Returns the number of workgroups that run generated bodies (the rest interpret), or -1. */
+int slpx_debug_tmpl_clocks(slpx_system* s, uint64_t* out, int32_t blocks);
 
 #ifdef __cplusplus
 }

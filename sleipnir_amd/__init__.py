@@ -140,6 +140,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_newton_steps", ctypes.c_int, vp, i32, ctypes.c_int, ctypes.c_int, vp)
     sig("slpx_problem_add_callback", ctypes.c_int, vp, vp, vp)
     sig("slpx_problem_clear_callbacks", ctypes.c_int, vp)
     sig("slpx_problem_system", vp, vp)
@@ -385,6 +386,12 @@ class System:
     def newton_step(self, refresh_ad=True):
         info = np.zeros(self.batch, dtype=np.int32)
         _check(lib().slpx_newton_step(self._h, int(refresh_ad), info.ctypes.data))
+        return info
+
+    def newton_steps(self, count, refresh_ad=True, forget_regularization=True):
+        info = np.zeros(self.batch, dtype=np.int32)
+        _check(lib().slpx_newton_steps(self._h, int(count), int(refresh_ad), int(forget_regularization),
+                                       info.ctypes.data))
         return info
 
     def get(self, which: str) -> np.ndarray:

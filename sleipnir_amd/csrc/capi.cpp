@@ -374,6 +374,19 @@ int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info) {
   });
 }
 
+int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_regularization, int32_t* info) {
+  return guard([&] {
+    auto& sys = s->get();
+    std::vector<int32_t> worst(sys.batch(), 0);
+    for (int32_t k = 0; k < count; ++k) {
+      if (forget_regularization) sys.reset_regularization();
+      auto res = sys.newton_step(refresh_ad != 0);
+      for (size_t b = 0; b < res.size(); ++b) worst[b] |= static_cast<int32_t>(res[b]);
+    }
+    if (info) std::copy(worst.begin(), worst.end(), info);
+  });
+}
+
 int64_t slpx_system_get(slpx_system* s, int which, double* out) {
   int64_t count = -1;
   int rc = guard([&] {
@@ -500,6 +513,14 @@ int slpx_debug_tape_clocks(slpx_system* s, uint64_t* out16) {
     s->get().device().debug_tape_clocks(t);
     for (int i = 0; i < 16; ++i) out16[i] = t[i];
   });
+}
+
+int slpx_debug_tmpl_clocks(slpx_system* s, uint64_t* out, int32_t blocks) {
+  int n = -1;
+  const int rc = guard([&] {
+    n = s->get().device().debug_tmpl_clocks(reinterpret_cast<unsigned long long*>(out), blocks);
+  });
+  return rc == 0 ? n : rc;
 }
 
 int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24) {

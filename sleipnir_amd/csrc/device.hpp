@@ -74,6 +74,7 @@ struct TapeDevice {
   // (mode 0 = values only, 1 = with adjoints) holds (first block, instances, instance
   // offset, row-group mode) per body, `tmpl_blocks[mode]` the grid size.
   hipFunction_t tmpl_fn = nullptr;
+  hipModule_t tmpl_mod = nullptr;
   uint32_t n_bodies = 0;
   DevBuf<uint32_t> tmpl_inst;  // per body: leaf bindings + output destinations, transposed (kernels.hip)
   DevBuf<uint32_t> tmpl_table[2];
@@ -204,6 +205,9 @@ class DeviceNlp {
   // decision variables) from the graph and refreshes their constant slots.
   void refresh_params(const Graph& g);
   void debug_tape_clocks(unsigned long long* out16);
+  // SLPX_TAPE_JIT_CLOCKS=1: 8 wall clocks (tape_jit.cpp) for each of the first `blocks` workgroups of the
+  // generated kernel's last launch; returns the number of template workgroups, -1 if absent
+  int debug_tmpl_clocks(unsigned long long* out, int blocks);
   // returns the clocks recorded so far, then selects the round that records next
   void debug_ldlt_clocks(unsigned int next_round, unsigned long long* out24);  // phase clocks of workgroup 0 (100 MHz ticks)
   // lhs -> L, D, stats; per-problem (δ, γ), problems with active[b] == 0 are skipped

@@ -324,6 +324,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch) {
   const TapeJitResult jit = build_tape_templates(p);
   jit_seconds = jit.compile_seconds;
   tmpl_fn = jit.fn;
+  tmpl_mod = jit.mod;
   n_bodies = static_cast<uint32_t>(jit.groups.size());
   n_templated_tasks = 0;
   tmpl_blocks[0] = tmpl_blocks[1] = 0;
@@ -383,7 +384,8 @@ void TapeDevice::upload(const TapeProgram& p, int batch) {
       std::fprintf(stderr, "slpx tape GLOBAL task: leaf %u node %u slot %u vout %u jout %u levels %u+%u\n", p.tasks[ti].n_leaf,
                    p.tasks[ti].n_node, p.tasks[ti].n_slot, p.tasks[ti].n_vout, p.tasks[ti].n_jout, p.tasks[ti].n_lvl, p.tasks[ti].n_slvl);
   leaf_src.upload(p.leaf_src);
-  consts.upload(p.consts);
+  // never empty: the generated bodies read consts[0] in lanes whose leaf is not a constant
+  consts.upload(p.consts.empty() ? std::vector<double>{0.0} : p.consts);
   node_rec.upload(p.node_rec);
   lvl_ptr.upload(p.lvl_ptr);
   slot_edge_ptr.upload(p.slot_edge_ptr);
@@ -831,6 +833,19 @@ void DeviceNlp::assemble_lsq() {
   hipLaunchKernelGGL(kkt_add_identity_kernel, dim3(grid_for(m_kdev.n, 256), m_batch), dim3(256), 0,
                      m_stream, m_kdev, m_diag_pos.p, m_lhs.p);
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+int DeviceNlp::debug_tmpl_clocks(unsigned long long* out, int blocks) {
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  hipDeviceptr_t p = nullptr;
+  size_t bytes = 0;
+  if (!m_full.tmpl_mod || hipModuleGetGlobal(&p, &bytes, m_full.tmpl_mod, "slpx_tmpl_clocks") != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  const size_t want = std::min<size_t>(bytes, static_cast<size_t>(blocks) * 8 * sizeof(unsigned long long));
+  SLPX_HIP_CHECK(hipMemcpy(out, p, want, hipMemcpyDeviceToHost));
+  return static_cast<int>(m_full.tmpl_blocks[1]);
 }
 
 void DeviceNlp::debug_tape_clocks(unsigned long long* out16) {

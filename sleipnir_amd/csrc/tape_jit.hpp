@@ -38,6 +38,7 @@ struct TapeTemplateGroup {
 };
 
 struct TapeJitResult {
+  hipModule_t mod = nullptr;               // owner of fn (debug: slpx_tmpl_clocks lives in it)
   hipFunction_t fn = nullptr;              // extern "C" slpx_tape_templates(...), null = no templates
   std::vector<TapeTemplateGroup> groups;   // body k of the kernel serves groups[k]
   std::vector<uint8_t> task_is_templated;  // per task of the program

@@ -187,8 +187,11 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
   auto matrix_value = [&](uint32_t e) {
     const int32_t s0 = s_src[e];
     const uint32_t fl = s_fc[e] & 0xffu;
-    double acc = 0.0;
-    if (s0 >= 0) acc = (fl & 4) ? rhs[static_cast<size_t>(s0) * kIlW] : lhs[static_cast<size_t>(s0) * kIlW];
+    // unconditional load (entry 0 where there is no source): a branch around it would put the
+    // four loads of a trip one after the other instead of in flight together
+    const double* from = (fl & 4) ? rhs : lhs;
+    const double v = from[static_cast<size_t>(s0 >= 0 ? s0 : 0) * kIlW];
+    double acc = s0 >= 0 ? v : 0.0;
     if (fl & 1) acc += (fl & 2) ? -gamma : delta;
     return acc;
   };

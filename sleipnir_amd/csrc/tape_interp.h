@@ -37,20 +37,24 @@ __device__ __forceinline__ uint32_t q16(uint32_t count, uint32_t per16) {
 #endif
 
 // V[dst[k]] = scale >= 0 ? scales[scale] * from[src[k]] : from[src[k]] for the `count` outputs at
-// `off`: four per trip, every load unconditional (scale index clamped), so that the three
+// `off`: kTapeUnroll per trip, every load unconditional (scale index clamped), so that the three
 // binding words, the scale factor and the LDS value of four outputs are in flight together
 // instead of one dependent round trip after the other.
+// trips of the leaf / output loops cost a memory round trip (two for leaves) each, whatever
+// their width: eight items per lane per trip
+constexpr int kTapeUnroll = 8;
+
 template <int THREADS>
 __device__ __forceinline__ void tape_write_outputs(uint32_t count, uint32_t off, const int32_t* __restrict__ scale_idx,
                                                    const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst,
                                                    const double* from, const double* __restrict__ scales,
                                                    double* __restrict__ V, int tid) {
-  for (uint32_t i0 = tid; i0 < count; i0 += 4 * THREADS) {
-    int32_t sc[4];
-    uint32_t d[4];
-    double v[4], w[4];
+  for (uint32_t i0 = tid; i0 < count; i0 += kTapeUnroll * THREADS) {
+    int32_t sc[kTapeUnroll];
+    uint32_t d[kTapeUnroll];
+    double v[kTapeUnroll], w[kTapeUnroll];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kTapeUnroll; ++u) {
       const uint32_t i = i0 + u * THREADS;
       const uint32_t k = off + (i < count ? i : i0);
       sc[u] = scale_idx[k];
@@ -58,9 +62,9 @@ __device__ __forceinline__ void tape_write_outputs(uint32_t count, uint32_t off,
       v[u] = from[src[k]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) w[u] = scales[sc[u] >= 0 ? sc[u] : 0];
+    for (int u = 0; u < kTapeUnroll; ++u) w[u] = scales[sc[u] >= 0 ? sc[u] : 0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kTapeUnroll; ++u)
       if (i0 + u * THREADS < count) V[d[u]] = sc[u] >= 0 ? w[u] * v[u] : v[u];
   }
 }
@@ -108,20 +112,20 @@ __device__ __forceinline__ void tape_sweep_lds_body(const TapeDev& T, const Tape
   }
   __syncthreads();
   SLPX_TAPE_CLOCK(1);
-  // Branch-free and four leaves per trip: `flag ? consts[..] : in[..]` compiles to a divergent
+  // Branch-free and kTapeUnroll leaves per trip: `flag ? consts[..] : in[..]` compiles to a divergent
   // branch around dependent loads, one memory round trip per trip of the loop (measured: 6 us
   // for a task of 640 leaves and ONE level).  All candidate operands are loaded (index 0
   // where a lane does not use one; consts is never empty), then selected.
-  for (uint32_t i0 = tid; i0 < t.n_leaf; i0 += 4 * THREADS) {
-    uint32_t src[4];
-    double c[4], x[4], w[4];
+  for (uint32_t i0 = tid; i0 < t.n_leaf; i0 += kTapeUnroll * THREADS) {
+    uint32_t src[kTapeUnroll];
+    double c[kTapeUnroll], x[kTapeUnroll], w[kTapeUnroll];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kTapeUnroll; ++u) {
       const uint32_t i = i0 + u * THREADS;
       src[u] = leaf_src[i < t.n_leaf ? i : i0];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kTapeUnroll; ++u) {
       const bool is_const = (src[u] & kLeafConstFlag) != 0u;
       const uint32_t xi = is_const ? 0u : src[u];
       c[u] = T.consts[is_const ? (src[u] & ~kLeafConstFlag) : 0u];
@@ -129,7 +133,7 @@ __device__ __forceinline__ void tape_sweep_lds_body(const TapeDev& T, const Tape
       w[u] = in_scale[xi];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kTapeUnroll; ++u) {
       const uint32_t i = i0 + u * THREADS;
       if (i < t.n_leaf) val[i] = (src[u] & kLeafConstFlag) ? c[u] : x[u] * w[u];
     }

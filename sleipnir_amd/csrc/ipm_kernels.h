@@ -138,12 +138,32 @@ __global__ __launch_bounds__(256) void ipm_trial_point_kernel(int n, const doubl
 // Filter quantities of the trial point whose f, c_e, c_i a forward sweep left in Vt.
 // alpha < 0: take the step size from alpha_dev[0].  s_from_ci: trial_s = trial c_i
 // (feasible-IPM option, interior_point.hpp:520-526).
+// The separable sums the forward sweep left as partial terms (the cost: one term per stage
+// group) are finished here, in the order tape_reduce_body uses (same bits), instead of by a
+// launch of their own between the sweep and this kernel.
 __global__ __launch_bounds__(kIpmThreads) void ipm_trial_metrics_kernel(
-    KktDev K, const double* __restrict__ Vt, const double* __restrict__ s, const double* __restrict__ ps,
+    KktDev K, double* __restrict__ Vt, const double* __restrict__ s, const double* __restrict__ ps,
     double alpha, const double* __restrict__ alpha_dev, int s_from_ci, IpmTrialOut* __restrict__ out,
-    unsigned long long* __restrict__ seq_dev, volatile unsigned long long* seq_host) {
+    unsigned long long* __restrict__ seq_dev, volatile unsigned long long* seq_host,
+    const NlpStructure::SumReduce* __restrict__ red, int n_red, const double* __restrict__ scales) {
   __shared__ double scratch[17 * 3];
+  __shared__ double part[64];
   const int tid = threadIdx.x;
+  for (int q = 0; q < n_red; ++q) {
+    const NlpStructure::SumReduce r = red[q];
+    if (tid < 64) {
+      double acc = 0.0;
+      for (int k = tid; k < r.count; k += 64) acc += Vt[r.src_off + k];
+      part[tid] = acc;
+    }
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) part[tid] += part[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) Vt[r.dst] = (r.scale_idx >= 0 ? scales[r.scale_idx] : 1.0) * part[0];
+    __syncthreads();
+  }
   if (alpha < 0.0) alpha = alpha_dev[0];
   double acc[3] = {0.0, 0.0, 1.0};  // violation, log sum, finite
   for (int r = tid; r < K.m_e; r += kIpmThreads) {

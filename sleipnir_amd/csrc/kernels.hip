@@ -786,7 +786,9 @@ void DeviceNlp::sweep_values() { launch_tape(m_values, false); }
 void DeviceNlp::sweep_values_trial() {
   m_in_override = m_trial_in.p;
   m_V_override = m_V_trial.p;
+  m_tape_reduce = false;  // ipm_trial_metrics_kernel, the only reader of these values, finishes the sums
   launch_tape(m_values, false);
+  m_tape_reduce = true;
   m_in_override = nullptr;
   m_V_override = nullptr;
 }
@@ -1229,7 +1231,8 @@ void DeviceNlp::ipm_trial_point(double alpha) {
 
 void DeviceNlp::ipm_trial_metrics(double alpha, bool s_from_ci) {
   hipLaunchKernelGGL(ipm_trial_metrics_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V_trial.p,
-                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial, m_seq_dev.p, m_h_seq);
+                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial, m_seq_dev.p, m_h_seq,
+                     m_reduces.p, static_cast<int>(m_reduces.n), m_scales.p);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }

@@ -61,4 +61,9 @@ def test_no_cpu_fallback(slpx, fresh):
         slpx.System(p)
     with pytest.raises(slpx.SlpxError):
         p.solve()
+    with pytest.raises(slpx.SlpxError):
+        p.system()  # slpx_problem_system compiles for the device as well
     p.close()
+    # the linear-solver seam on its own (slpx_ldlt_create): 2x2 lower-triangular pattern
+    with pytest.raises(slpx.SlpxError):
+        slpx.System.linear_solver(1, 1, [0, 2, 3], [0, 1, 1])

@@ -7,16 +7,30 @@ One "step" = AD refresh {g, A_e, H} + KKT lhs/rhs assembly + regularized LDLᵀ
 back-substitution, i.e. interior_point.hpp:809-812 + :426-482, on inputs already
 resident in HBM (the seeded interior state of SURVEY.md §8d).
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run (one rank per GPU): every rank steps its
-own replica(s) of the problem — the path has no cross-problem exchange (SURVEY.md
-§8e) — and the only collective is the MAX of the elapsed time.
+  python bench.py --gpus N --steps K --warmup W [--workload single|batch512]
+
+--gpus N > 1 without a torchrun environment re-executes this script under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); under a
+launcher the flag must equal WORLD_SIZE.  Workloads:
+  single    (default, BASELINE config 2) every rank steps its own replica of ONE N=1000
+            problem — the path has no cross-problem exchange ("replicas only")
+  batch512  (BASELINE config 4) 512 independent cart-pole N=500 problems, problem b seeded
+            with SEED + b, sharded contiguously over the ranks (sleipnir_amd.dist.shard_range:
+            64 per GPU at 8 GPUs; multistart.hpp:45-74 hands whole solves to threads the same
+            way); the per-problem {status, delta, gamma} table is all-gathered at the end.
+The only collectives are the barrier, the MAX of the elapsed time and that gather.
+
+The timed region is `--repeats` (default 5) blocks of EXACTLY K steps, each bracketed by
+barrier + synchronize on both sides and MAX-reduced over the ranks; the line reports the
+MEDIAN block (all block times are in `block_ms`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,6 +41,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_TAG = "r02"    # profiles/<tag>_traffic.json feeds roofline.traffic
 
 
 def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
@@ -63,49 +78,24 @@ def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--N", type=int, default=1000, help="horizon (BASELINE config: 1000)")
-    ap.add_argument("--batch", type=int, default=1, help="independent problems per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batched-roofline", action="store_true",
-                    help="also step a batch of independent problems (the configuration on which "
-                         "the HBM roofline of the gather kernels is measurable) and add a "
-                         "'batched' object; off by default so that the default command launches "
-                         "one kernel shape only and the rocprofv3 --stats averages under "
-                         "profiles/ are per-launch numbers of the N=1 workload")
-    ap.add_argument("--no-batched-roofline", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--roofline-batch", type=int, default=512)
-    args = ap.parse_args()
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    import torch
 
-    import sleipnir_amd as sa
-    from tests.support import cases
+def respawn_under_launcher(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: become N ranks (one per GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())]
+    cmd += sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    # one process per GPU; RCCL ("nccl") only for the end-of-region MAX
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    comm = sa.Comm(backend="nccl")
-    rank, local_rank, world = comm.rank, comm.local_rank, comm.world
 
-    N = args.N
-    dt = 5.0 / N
-    sa.lib().slpx_graph_reset()
-    t0 = time.perf_counter()
-    pp = sa.Problem.cart_pole(N, dt)
-    t_model = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    system = sa.System(pp, batch=args.batch, device=local_rank)
-    t_compile = time.perf_counter() - t0
-    info = system.info
-    n, me, mi = info["n"], info["m_e"], info["m_i"]
-
-    # scaling at x0 (problem_scaling.hpp:100-107) from an unscaled device sweep
-    x0 = pp.get_x()
-    B = args.batch
+def scaling_at_x0(system, info, x0, me, mi, B):
+    """problem_scaling.hpp:100-107 from an unscaled device sweep at the initial guess."""
     system.set_state(np.tile(x0, (B, 1)), np.ones((B, mi)), np.zeros((B, me)), np.ones((B, mi)),
                      np.full(B, 0.1))
     system.sweep(True)
@@ -119,38 +109,197 @@ def main():
             rn = np.zeros(me if which == 1 else mi)
             np.maximum.at(rn, ri, np.abs(V[info[off]:info[off] + info[cnt]]))
             scales[base:base + len(rn)] = np.minimum(100.0 / rn, 1.0)
-    system.set_scaling(scales)
+    return scales
 
-    # device-resident inputs: seeded interior states, one per problem
-    states = [cases.newton_state("interior", x0, n, me, mi, scales[0], seed=cases.SEED + rank * B + b)
-              for b in range(B)]
-    system.set_state(np.stack([s_[0] for s_ in states]), np.stack([s_[1] for s_ in states]),
-                     np.stack([s_[2] for s_ in states]), np.stack([s_[3] for s_ in states]),
-                     np.array([s_[4] for s_ in states]))
+
+def make_system(sa, cases, N, problem_ids, device):
+    """Compiles cart-pole N for `device` with one value set per problem id (seeded interior
+    states) resident in HBM."""
+    dt = 5.0 / N
+    sa.lib().slpx_graph_reset()
+    t0 = time.perf_counter()
+    pp = sa.Problem.cart_pole(N, dt)
+    t_model = time.perf_counter() - t0
+    B = len(problem_ids)
+    t0 = time.perf_counter()
+    system = sa.System(pp, batch=B, device=device)
+    t_compile = time.perf_counter() - t0
+    info = system.info
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
+    x0 = pp.get_x()
+    scales = scaling_at_x0(system, info, x0, me, mi, B)
+    system.set_scaling(scales)
+    st = [cases.newton_state("interior", x0, n, me, mi, scales[0], seed=cases.SEED + b) for b in problem_ids]
+    system.set_state(np.stack([s_[0] for s_ in st]), np.stack([s_[1] for s_ in st]),
+                     np.stack([s_[2] for s_ in st]), np.stack([s_[3] for s_ in st]),
+                     np.array([s_[4] for s_ in st]))
+    return pp, system, {"model": t_model, "compile_and_upload": t_compile}
+
+
+def kernel_groups(system, iters):
+    """Per-kernel-group launch durations (HIP events on the library's stream) and the
+    algorithmic bytes of SURVEY.md §8d evaluated on the actual patterns."""
+    info = system.info
+    system.reset_regularization()
+    kt = system.time_step(iters=iters, refresh_ad=True)
+    nf = max(1.0, kt["factorizations"])
+    return kt, nf, {
+        # the tape program (static, read once per sweep) belongs to the sweep's bytes just
+        # like the index maps belong to kkt_assemble's (SURVEY.md §8d)
+        "tape_sweep": (kt["sweep"], info["sweep_bytes"] + info["tape_program_bytes"]),
+        "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
+        "kkt_rhs": (kt["rhs"], info["rhs_bytes"]),
+        "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
+        # the timed launch is the BACKWARD substitution only (the forward one rides in the
+        # factorization): half of the 32 l + 16(n + m_e) of SURVEY.md §8d
+        "ldlt_solve": (kt["solve"], info["solve_bytes"] // 2),
+    }
+
+
+def batched_probe(sa, cases, N, B, device):
+    """HBM-roofline evidence on a batch: per-kernel ms, algorithmic bytes and fraction of the
+    HBM peak for B problems of cart-pole N stepped together (run AFTER the timed region)."""
+    pp, sysb, _ = make_system(sa, cases, N, list(range(B)), device)
+    for _ in range(3):
+        sysb.reset_regularization()
+        sysb.newton_step(True)
+    kb, nfb, gb = kernel_groups(sysb, iters=10)
+    out = {
+        "workload": f"{B} x cart-pole N={N}", "batch": B, "N": N,
+        "ldlt_path": "lane-per-problem interleaved" if B >= 192 else "workgroup per task",
+        "steps_per_s": B / (kb["total"] * 1e-3),
+        "per_kernel_ms": {k: v[0] for k, v in gb.items()},
+        "algorithmic_bytes": {k: B * v[1] for k, v in gb.items()},
+        "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 for k, v in gb.items()},
+        "hbm_frac": {k: B * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for k, v in gb.items()},
+        "factorizations_per_step": kb["factorizations"],
+    }
+    tfile = ROOT / "profiles" / f"{PROFILE_TAG}_batched_traffic.json"
+    if tfile.exists() and N == 1000 and B == 512:
+        tj = json.loads(tfile.read_text())
+        pre = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
+               "kkt_assemble": ("kkt_assemble",), "kkt_rhs": ("kkt_rhs_kernel",),
+               "ldlt_factor": ("ldlt_factor_il_kernel", "il_gather_kernel", "ldlt_stats_il_kernel"),
+               "ldlt_solve": ("ldlt_bwd_il_kernel",)}
+        # grids with fewer than 100000 threads are the single-problem launches of the same run
+        out["traffic"] = {grp: sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
+                                   if kname.startswith(pres) for grid, e in grids.items()
+                                   if not (kname.startswith(("slpx_tape_templates", "tape_")) and int(grid) < 100000))
+                          for grp, pres in pre.items()}
+    sysb.close()
+    pp.close()
+    return out
+
+
+def whole_solve(sa, N):
+    """Problem::solve() at the BASELINE horizon (status, iterations, wall time) — outside the
+    timed region; the iteration path is the product's resident IPM (csrc/ipm.cpp)."""
+    sa.lib().slpx_graph_reset()
+    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    status, rep = pp.solve()
+    pp.close()
+    return {"N": N, "status": int(status), "iterations": int(rep["iterations"]),
+            "factorizations": int(rep["factorizations"]), "restorations": int(rep["restorations"]),
+            "t_total_s": rep["t_total"], "t_compile_s": rep["t_compile"], "final_error": rep["final_error"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed K-step blocks; the median is reported")
+    ap.add_argument("--workload", choices=["single", "batch512"], default="single")
+    ap.add_argument("--N", type=int, default=None, help="horizon (single: 1000, batch512: 500)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="single: independent replicas per GPU (1); batch512: total problems (512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", "--no-batched-roofline", dest="no_batched", action="store_true",
+                    help="skip the after-the-timed-region batch probes (64 x N=500, 512 x N=1000) that "
+                         "carry the HBM-roofline evidence; profiling passes use this so that the "
+                         "rocprofv3 averages are per-launch numbers of the timed workload")
+    ap.add_argument("--no-whole-solve", action="store_true")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="launch self-test (runs without a GPU, gloo): every rank joins the process group, "
+                         "rank 0 prints how many ranks answered and how the batch would be sharded")
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(respawn_under_launcher(args))
+    if world_env is not None and int(world_env) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+
+    if args.spawn_check:
+        from sleipnir_amd.dist import Comm, shard_range
+
+        comm = Comm(backend="gloo")
+        seen = comm.sum([1.0])[0]
+        shards = comm.gather_rows(np.array([[comm.rank, len(shard_range(args.batch or 512, comm.rank, comm.world))]],
+                                           dtype=np.float64), comm.world)
+        if comm.rank == 0:
+            print(json.dumps({"n_gpus": comm.world, "ranks_seen": int(seen), "pids_distinct": True,
+                              "shard_sizes": [int(v) for v in shards[:, 1]]}))
+        comm.close()
+        return
+
+    import torch
+
+    import sleipnir_amd as sa
+    from tests.support import cases
+
+    # one process per GPU; RCCL ("nccl") for the barrier, the end-of-region MAX and the gather
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    comm = sa.Comm(backend="nccl")
+    rank, local_rank, world = comm.rank, comm.local_rank, comm.world
+
+    if args.workload == "single":
+        N = args.N or 1000
+        B = args.batch or 1
+        ids = [rank * B + b for b in range(B)]
+        total_problems = world * B
+        scaling = "weak"
+    else:
+        N = args.N or 500
+        total_problems = args.batch or 512
+        ids = list(sa.shard_range(total_problems, rank, world))
+        B = len(ids)
+        scaling = "strong"
+    dt = 5.0 / N
+    pp, system, setup_s = make_system(sa, cases, N, ids, local_rank)
+    info = system.info
+    n, me, mi = info["n"], info["m_e"], info["m_i"]
 
     def barrier():
         torch.cuda.synchronize()
         comm.barrier()
         torch.cuda.synchronize()
 
-    nfact_total = 0
     # the step loop runs on the library side (slpx_newton_steps): K steps, each one waited
     # for before the next is launched, regularization memory cleared before every step
     system.newton_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    info_step = system.newton_steps(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert np.all(info_step == 0), "factorization failed in the timed region"
-    elapsed = float(comm.max([elapsed])[0])
-    barrier()
+    blocks = []
+    failed = np.zeros(B, dtype=np.int32)
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        info_step = system.newton_steps(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        blocks.append(float(comm.max([el])[0]))
+        failed |= info_step
+        barrier()
+    assert np.all(failed == 0), "factorization failed in the timed region"
+    elapsed = float(np.median(blocks))
+
+    # per-problem results of the last step, in problem order (the only data-path-adjacent
+    # collective: an all-gather of B x 4 doubles per rank)
+    reg = system.regularization()
+    rows = np.column_stack([np.array(ids, dtype=np.float64), failed.astype(np.float64), reg[:, 0], reg[:, 1]])
+    table = comm.gather_rows(rows, total_problems)
 
     if rank == 0:
-        # per-kernel-group durations measured live with HIP events on the library's stream
-        system.reset_regularization()
-        kt = system.time_step(iters=max(10, min(100, args.steps)), refresh_ad=True)
-        nf = max(1.0, kt["factorizations"])
+        kt, nf, groups = kernel_groups(system, iters=max(10, min(100, args.steps)))
         # what the inertia-correcting loop did on this state (same call sequence as one step)
         system.reset_regularization()
         system.sweep(True)
@@ -163,36 +312,25 @@ def main():
             "unregularized_attempt": "not launched: the symbolic phase found a structurally zero pivot"
             if info["struct_singular"] else "launched",
         }
-        groups = {
-            "tape_sweep": (kt["sweep"], info["sweep_bytes"]),
-            "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
-            "kkt_rhs": (kt["rhs"], info["rhs_bytes"]),
-            "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
-            # the timed launch is the BACKWARD substitution only (the forward one rides in the
-            # factorization): half of the 32 l + 16(n + m_e) of SURVEY.md §8d
-            "ldlt_solve": (kt["solve"], info["solve_bytes"] // 2),
-        }
-        # the tape program (static, read once per sweep) belongs to the sweep's bytes just
-        # like the index maps belong to kkt_assemble's
-        groups["tape_sweep"] = (kt["sweep"], info["sweep_bytes"] + info["tape_program_bytes"])
         dom = max(groups, key=lambda k: groups[k][0] * (nf if k == "ldlt_factor" else 1.0))
         dom_ms, dom_bytes = groups[dom]
         achieved = B * dom_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per step of each kernel group from the committed PMC passes
         # (profiles/collect.py; FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE)
         traffic_by_group = None
-        tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists() and N == 1000 and B == 1:
+        tfile = ROOT / "profiles" / f"{PROFILE_TAG}_traffic.json"
+        if tfile.exists() and args.workload == "single" and N == 1000 and B == 1:
             tj = json.loads(tfile.read_text())
             prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
                       "kkt_assemble": "kkt_assemble_kernel",
-                      "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
-                      "ldlt_solve": ("ldlt_fwd_kernel", "ldlt_bwd_kernel")}
+                      "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor",
+                      "ldlt_solve": ("ldlt_fwd", "ldlt_bwd")}
             traffic_by_group = {}
             for grp, pre in prefix.items():
                 pres = pre if isinstance(pre, tuple) else (pre,)
                 traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
                                             if kname.startswith(pres) for e in grids.values())
+        single = args.workload == "single" and B == 1
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -202,83 +340,71 @@ def main():
             "per_kernel_ms": {k: v[0] for k, v in groups.items()},
             "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None
                                 for k, v in groups.items()},
+            "per_kernel_hbm_frac": {k: B * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else None
+                                    for k, v in groups.items()},
             "factorizations_per_step": kt["factorizations"],
             "regularization": regularization,
-            "note": "single N=1000 problem: every kernel is dependency-latency bound (SURVEY.md "
-                    "§7 hard part 1); HBM fractions are meaningful on a batch (--batched-roofline; "
-                    "DESIGN.md §4, profiles/r01_batched_*)",
+            "note": (f"single N={N} problem: every kernel is dependency-latency bound (SURVEY.md §7 hard "
+                     "part 1); the HBM fractions that mean something are in `batched` (same kernels' "
+                     "batch variants on 64 x N=500 and 512 x N=1000)") if single else
+                    f"{B} problems of N={N} per launch on this rank",
         }
+        workload = ("cart-pole direct transcription N=%d, %d problem(s) per GPU (replicas), seeded interior "
+                    "IPM state, inputs resident in HBM" % (N, B)) if args.workload == "single" else (
+                    "batch of %d independent cart-pole N=%d problems (seed + b), sharded contiguously: %d on "
+                    "rank 0, inputs resident in HBM" % (total_problems, N, B))
         out = {
             "metric": "Newton steps/sec, cart-pole direct-transcription N=%d" % N,
-            "value": world * B * args.steps / elapsed,
+            "value": total_problems * args.steps / elapsed,
             "unit": "Newton steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cart-pole direct transcription N=%d, %d problem(s) per GPU, "
-                                   "seeded interior IPM state, inputs resident in HBM" % (N, B),
+            "timing": {"repeats": len(blocks), "statistic": "median of the K-step blocks",
+                       "block_ms": [1e3 * b for b in blocks]},
+            "config": {"workload": workload, "problems_total": total_problems,
                        "n": n, "m_e": me, "m_i": mi, "nnz_lhs": info["nnz_lhs"],
                        "nnz_L": info["nnz_L"], "etree_height": info["etree_height"],
+                       "ldlt_levels": info.get("ldlt_levels"), "ldlt_supernodes": info.get("ldlt_supernodes"),
                        "ldlt_rounds": info["ldlt_rounds"], "ldlt_tasks": info["ldlt_tasks"],
                        "tape_tasks": info["tape_tasks"], "tape_nodes": info["tape_nodes"],
-                       "tape_slots": info["tape_slots"], "multi_gpu": "replicas only"},
+                       "tape_slots": info["tape_slots"],
+                       "multi_gpu": "replicas only" if args.workload == "single" else
+                                    "problems sharded, no data-path collective"},
             "ms_per_ldlt_factor": groups["ldlt_factor"][0],
             "ms_per_ldlt_solve": groups["ldlt_solve"][0],
-            "setup_s": {"model": t_model, "compile_and_upload": t_compile},
+            "setup_s": setup_s,
             "roofline": roofline,
         }
-        if args.batched_roofline and world == 1 and B == 1:
-            # the configuration on which HBM-roofline claims are measurable
-            RB = args.roofline_batch
-            sysb = sa.System(pp, batch=RB, device=local_rank)
-            sysb.set_scaling(scales)
-            st = [cases.newton_state("interior", x0, n, me, mi, scales[0], seed=cases.SEED + b)
-                  for b in range(RB)]
-            sysb.set_state(np.stack([s_[0] for s_ in st]), np.stack([s_[1] for s_ in st]),
-                           np.stack([s_[2] for s_ in st]), np.stack([s_[3] for s_ in st]),
-                           np.array([s_[4] for s_ in st]))
-            for _ in range(3):
-                sysb.reset_regularization()
-                sysb.newton_step(True)
-            sysb.reset_regularization()
-            kb = sysb.time_step(iters=10, refresh_ad=True)
-            nfb = max(1.0, kb["factorizations"])
-            gb = {"tape_sweep": (kb["sweep"], info["sweep_bytes"]),
-                  "kkt_assemble": (kb["assemble"], info["assemble_bytes"]),
-                  "kkt_rhs": (kb["rhs"], info["rhs_bytes"]),
-                  "ldlt_factor": (kb["factor"] / nfb, info["factor_bytes"]),
-                  "ldlt_solve": (kb["solve"], info["solve_bytes"] // 2)}
-            # HBM bytes per launch group from the committed PMC passes of this configuration
-            btraffic = None
-            bfile = ROOT / "profiles" / "r01_batched_traffic.json"
-            if bfile.exists() and N == 1000 and RB == 512:
-                tj = json.loads(bfile.read_text())
-                pre = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
-                       "kkt_assemble": ("kkt_assemble",), "kkt_rhs": ("kkt_rhs_kernel",),
-                       "ldlt_factor": ("ldlt_factor_il_kernel", "il_gather_kernel", "ldlt_stats_il_kernel"),
-                       "ldlt_solve": ("ldlt_bwd_il_kernel",)}
-                # grids with fewer than 1000 workgroup-threads are the single-problem launches of the same run
-                btraffic = {grp: sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
-                                     if kname.startswith(pres) for grid, e in grids.items()
-                                     if not (kname.startswith(("slpx_tape_templates", "tape_")) and int(grid) < 100000))
-                            for grp, pres in pre.items()}
-            out["batched"] = {
-                "batch": RB, "steps_per_s": RB / (kb["total"] * 1e-3),
-                "per_kernel_ms": {k: v[0] for k, v in gb.items()},
-                "per_kernel_GBps": {k: RB * v[1] / (v[0] * 1e-3) / 1e9 for k, v in gb.items()},
-                "per_kernel_hbm_frac": {k: RB * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                        for k, v in gb.items()},
-                "factorizations_per_step": kb["factorizations"],
-                "algorithmic_bytes": {k: RB * v[1] for k, v in gb.items()},
-                "traffic": btraffic,
+        if args.workload == "batch512":
+            out["per_problem"] = {
+                "columns": ["problem", "status", "delta", "gamma"],
+                "failed": int(np.sum(table[:, 1] != 0)),
+                "delta_histogram": {f"{d:.0e}": int(c) for d, c in zip(*np.unique(table[:, 2], return_counts=True))},
+                "gamma_histogram": {f"{g:.0e}": int(c) for g, c in zip(*np.unique(table[:, 3], return_counts=True))},
+                "first_rows": table[:8].tolist(),
             }
-            sysb.close()
+    system.close()
+    pp.close()
+    if rank == 0:
+        if world == 1 and single:
+            # warm setup: the same model compiled a second time in this process (hipRTC code
+            # objects cached, HIP runtime up)
+            pp2, sys2, setup2 = make_system(sa, cases, N, [0], local_rank)
+            out["setup_s"] = {"model": setup_s["model"], "compile_and_upload": setup_s["compile_and_upload"],
+                              "compile_and_upload_warm": setup2["compile_and_upload"]}
+            sys2.close()
+            pp2.close()
+            if not args.no_batched:
+                out["batched"] = [batched_probe(sa, cases, 500, 64, local_rank),
+                                  batched_probe(sa, cases, 1000, 512, local_rank)]
+            if not args.no_whole_solve:
+                out["whole_solve"] = whole_solve(sa, N)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, dt)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / (out["cpu_baseline"]["value"] * 1.0)
         print(json.dumps(out))
-    system.close()
     comm.close()
 
 

@@ -200,6 +200,9 @@ int slpx_newton_step(slpx_system* s, int refresh_ad, int32_t* info);
  * clears the delta/gamma memory before every step (slpx_ldlt_reset keeps gamma_min), so each
  * step starts like the first iteration of a solve.  info[batch] = OR over the steps. */
 int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_regularization, int32_t* info);
+/* reg[batch][2] = {hessian_regularization(), constraint_jacobian_regularization()}
+ * (util/regularized_ldlt.hpp:111,122) the last compute / Newton step settled on, per problem. */
+int slpx_system_regularization(slpx_system* s, double* reg);
 
 /* Device -> host copies.  which: 0 V, 1 lhs, 2 rhs, 3 p, 4 p_s, 5 p_z, 6 D (pivot order), 7 L values,
  * 8 x, 9 s, 10 y, 11 z (the resident iterate) */

@@ -141,6 +141,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
     sig("slpx_newton_steps", ctypes.c_int, vp, i32, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_system_regularization", ctypes.c_int, vp, vp)
     sig("slpx_problem_add_callback", ctypes.c_int, vp, vp, vp)
     sig("slpx_problem_clear_callbacks", ctypes.c_int, vp)
     sig("slpx_problem_system", vp, vp)
@@ -393,6 +394,12 @@ class System:
         _check(lib().slpx_newton_steps(self._h, int(count), int(refresh_ad), int(forget_regularization),
                                        info.ctypes.data))
         return info
+
+    def regularization(self) -> np.ndarray:
+        """[batch, 2] = (delta, gamma) the last compute / Newton step settled on."""
+        reg = np.zeros((self.batch, 2))
+        _check(lib().slpx_system_regularization(self._h, reg.ctypes.data))
+        return reg
 
     def get(self, which: str) -> np.ndarray:
         sel = {"V": 0, "lhs": 1, "rhs": 2, "p": 3, "p_s": 4, "p_z": 5, "D": 6, "Lx": 7, "x": 8, "s": 9,

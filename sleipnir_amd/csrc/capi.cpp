@@ -387,6 +387,16 @@ int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_
   });
 }
 
+int slpx_system_regularization(slpx_system* s, double* reg) {
+  return guard([&] {
+    const int B = s->get().batch();
+    for (int b = 0; b < B; ++b) {
+      reg[2 * b] = s->get().hessian_regularization()[b];
+      reg[2 * b + 1] = s->get().constraint_jacobian_regularization()[b];
+    }
+  });
+}
+
 int64_t slpx_system_get(slpx_system* s, int which, double* out) {
   int64_t count = -1;
   int rc = guard([&] {

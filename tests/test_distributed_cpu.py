@@ -95,3 +95,25 @@ def test_two_rank_gloo_sharded_steps(tmp_path, slpx, hostcheck):
     assert res["table"].shape == want.shape
     assert np.array_equal(res["table"][:, 0], np.arange(n_problems))
     assert np.allclose(res["table"], want, rtol=1e-12, atol=0)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` outside a launcher must become two ranks (the flag
+    used to be parsed and ignored).  --spawn-check stops after the process group is up, so it runs
+    without a GPU (gloo)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--spawn-check", "--batch", "513"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["shard_sizes"] == [257, 256]
+    # under a launcher the flag must agree with the world size instead of being ignored
+    env["WORLD_SIZE"] = "4"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--spawn-check"],
+                         capture_output=True, text=True, env=env, timeout=60)
+    assert res.returncode != 0 and "WORLD_SIZE=4" in res.stderr

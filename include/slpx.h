@@ -165,6 +165,9 @@ enum {
   SLPX_INFO_STRUCT_SINGULAR, SLPX_INFO_OFF_G, SLPX_INFO_OFF_AE, SLPX_INFO_OFF_AI,
   SLPX_INFO_OFF_HF, SLPX_INFO_OFF_HC, SLPX_INFO_GRAPH_NODES, SLPX_INFO_NONLINEAR_ROWS,
   SLPX_INFO_TAPE_GLOBAL_TASKS, SLPX_INFO_TAPE_SHARED_TASKS, SLPX_INFO_TAPE_PROGRAM_BYTES,
+  /* supernodal LDLT: levels on the critical path (sum over rounds of the deepest task),
+   * supernodes (singletons included), widest supernode in columns */
+  SLPX_INFO_LDLT_LEVELS, SLPX_INFO_LDLT_SUPERNODES, SLPX_INFO_LDLT_WIDEST,
   SLPX_INFO_COUNT
 };
 int slpx_system_info(const slpx_system* s, int64_t* out /* SLPX_INFO_COUNT */);

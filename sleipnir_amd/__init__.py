@@ -30,7 +30,7 @@ INFO_KEYS = [
     "tape_slots", "tape_edges", "tape_levels", "tape_slot_levels", "assemble_bytes", "rhs_bytes",
     "factor_bytes", "solve_bytes", "sweep_bytes", "struct_singular", "off_g", "off_Ae", "off_Ai",
     "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks", "tape_shared_tasks",
-    "tape_program_bytes",
+    "tape_program_bytes", "ldlt_levels", "ldlt_supernodes", "ldlt_widest_supernode",
 ]
 
 # slpx_op

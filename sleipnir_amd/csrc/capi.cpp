@@ -261,6 +261,9 @@ int slpx_system_info(const slpx_system* sc, int64_t* out) {
         4 * (f.lvl_ptr.size() + f.slvl_ptr.size() + f.leaf_src.size() + 3 * f.vout_src.size() +
              3 * f.jout_slot.size()) +
         sizeof(slpx::TapeTask) * f.tasks.size());
+    out[SLPX_INFO_LDLT_LEVELS] = l.critical_levels;
+    out[SLPX_INFO_LDLT_SUPERNODES] = l.n_supernodes;
+    out[SLPX_INFO_LDLT_WIDEST] = l.widest_supernode;
   });
 }
 

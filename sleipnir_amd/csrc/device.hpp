@@ -111,6 +111,14 @@ struct LdltDev {
   const int32_t* perm;
   const uint32_t* round_ptr;  // n_rounds + 1, into tasks
   int n_rounds;
+  // supernodes (ldlt_symbolic.hpp: LdltSn)
+  const LdltSn* sn_desc;
+  const uint32_t* sn_lvl_ptr;
+  const uint32_t* col_sn;
+  // the hot loops' own copies (one LDS word instead of two per level / per column):
+  const uint32_t* lvl_pack;      // lvl_ptr | sn_lvl_ptr << 16
+  const uint32_t* col_lvl_pack;  // col_lvl_ptr | sn_lvl_ptr << 16
+  const uint2* bwd_range;        // per column {first item below its own chain, end}; shares col_off
 };
 
 struct LdltStats {   // one per batch item, written by the factor kernels
@@ -298,6 +306,9 @@ class DeviceNlp {
       m_col_perm, m_col_lvl_ptr, m_fwd_ptr, m_fwd_contrib_ptr, m_scontrib_idx, m_sext_ptr,
       m_sext_dst, m_bwd_ptr;
   DevBuf<LdltPair> m_pairs;
+  DevBuf<LdltSn> m_sn_desc;
+  DevBuf<uint32_t> m_sn_lvl_ptr, m_col_sn, m_lvl_pack, m_col_lvl_pack;
+  DevBuf<uint2> m_bwd_range;
   DevBuf<LdltSolveItem> m_fwd_items, m_sext_items, m_bwd_items;
   LdltDev m_ldev{};
   // per-batch values

@@ -502,6 +502,34 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                    l.n_rounds};
   m_round_ptr.upload(l.round_ptr);
   m_ldev.round_ptr = m_round_ptr.p;
+  m_sn_desc.upload(l.sn_desc);
+  m_sn_lvl_ptr.upload(l.sn_lvl_ptr);
+  m_col_sn.upload(l.col_sn);
+  m_ldev.sn_desc = m_sn_desc.p;
+  m_ldev.sn_lvl_ptr = m_sn_lvl_ptr.p;
+  m_ldev.col_sn = m_col_sn.p;
+  {
+    std::vector<uint32_t> lp(l.lvl_ptr.size()), cp(l.col_lvl_ptr.size());
+    for (size_t i = 0; i < lp.size(); ++i) {
+      if (l.lvl_ptr[i] > 0xffffu || l.col_lvl_ptr[i] > 0xffffu || l.sn_lvl_ptr[i] > 0xffffu)
+        throw std::runtime_error("slpx: an LDLT task exceeds the 16-bit packing of its level table");
+      lp[i] = l.lvl_ptr[i] | (l.sn_lvl_ptr[i] << 16);
+      cp[i] = l.col_lvl_ptr[i] | (l.sn_lvl_ptr[i] << 16);
+    }
+    m_lvl_pack.upload(lp);
+    m_col_lvl_pack.upload(cp);
+    std::vector<uint2> rng(l.col_perm.size(), uint2{0, 0});
+    for (const LdltTask& t : l.tasks)
+      for (uint32_t i = 0; i < t.n_col; ++i) {
+        const uint32_t cs = l.col_sn[t.col_off + i];
+        rng[t.col_off + i] = uint2{l.bwd_ptr[t.colptr_off + i] + ((cs >> 8) - (cs & 0xffu) - 1u),
+                                   l.bwd_ptr[t.colptr_off + i + 1]};
+      }
+    m_bwd_range.upload(rng);
+  }
+  m_ldev.lvl_pack = m_lvl_pack.p;
+  m_ldev.col_lvl_pack = m_col_lvl_pack.p;
+  m_ldev.bwd_range = m_bwd_range.p;
   {
     std::vector<unsigned int> zero(2 * static_cast<size_t>(batch) * std::max(1, l.n_rounds), 0u);
     m_fround_cnt.upload(zero);

@@ -146,6 +146,134 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/d for the pivots INSIDE a supernode: the same estimate + two Newton steps without the
+// special-case select (three more dependent operations on the chain): d = 0 gives NaN instead
+// of inf — either way every later pivot is non-finite, and the zero pivot itself is counted
+// as bad (n_bad), which is all the policy loop looks at.
+__device__ __forceinline__ double chain_reciprocal(double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r0, 1.0);
+  double r = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+// ---------------------------------------------------------------------------
+// Supernodes (LdltSn, ldlt_symbolic.hpp).  When the level loop reaches a chain of w >= 2
+// columns, every entry of its (w + |R| + 1) x w trapezoid already holds A - (updates of the
+// columns below the chain).  What is left is dense: U(t,j) -= sum_{c<j} U(t,c) U(j,c) / d_c.
+// ONE WAVE PER CHAIN, a lane per row with its row in registers; the pivot row's entries reach
+// the other lanes as scalars (v_readlane), so the whole elimination is register traffic —
+// w(w-1)/2 broadcast + FMA steps, no LDS round trip and no barrier between two columns.
+// Lanes [0, w) hold the block's rows, lanes [w, nr) the rows below it and the
+// right-hand-side row (nr <= 64).  The wave is the only reader of the chain's entries in this
+// pass, so it stores everything back to U itself; nothing goes to global memory here (a global
+// store inside the level loop costs its acknowledgement at the next barrier: measured 82 vs
+// 59 us per factorization).
+//
+// What this buys, measured (profiles/microbench/{latency,chain}.hip on the MI355X): a lone wave
+// issues one instruction of such a dependent sequence every ~9 clocks, whatever the
+// instruction (a dependent v_fma_f64 alone is 4-6 clocks, a v_readlane pair + FMA 25, an LDS
+// round trip 60, a barrier of sixteen waves 64): a column level of the generic gather costs
+// ~1140 clocks because it EXECUTES ~75 instructions per wave, not because it waits.  A chain
+// finished here costs 1480 (w = 4), 2600 (w = 8) clocks warm and ~1100 more the first time a
+// CU runs that width (instruction-cache misses after the jump), against w x 1140 as w levels.
+// Variants tried and dropped, clocks per level at N=1000 in the kernel: every row lane factors
+// the block itself, no communication (~2800: 150 instructions per lane); one 16-wide body with
+// `c < w` guards (5700: every guard is executed); a rolled loop with the row registers indexed
+// through M0 (4000-10000); a rolled loop with shifted registers and bodies of 4 / 8 / 16 steps
+// (300-780 per COLUMN: each column runs all steps of its body).  Kept: exact-width
+// straight-line code per w, reached by one scalar jump, out of line so that its registers do
+// not weigh on the level loop.
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void sn_finish_wave_exact(double* __restrict__ U, double* __restrict__ invd, uint32_t base0,
+                                                     uint32_t nr, uint32_t col0, uint32_t lane) {
+  const uint32_t t = lane;
+  const bool live = t < nr;
+  double a[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    const uint32_t offc = base0 + c * nr - (c * (c - 1)) / 2;
+    a[c] = (live && static_cast<uint32_t>(c) <= t) ? U[offc + (t - c)] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    const double inv = chain_reciprocal(readlane_f64(a[c], c));
+    const double lc = a[c] * inv;
+    if (lane == static_cast<uint32_t>(c)) invd[col0 + c] = inv;
+#pragma unroll
+    for (int j = c + 1; j < W; ++j) a[j] = __builtin_fma(-lc, readlane_f64(a[c], j), a[j]);
+  }
+#pragma unroll
+  for (int c = 0; c < W; ++c)
+    if (live && static_cast<uint32_t>(c) <= t) U[base0 + c * nr - (c * (c - 1)) / 2 + (t - c)] = a[c];
+}
+
+// (all arguments but `lane` are wave-uniform: the caller passes them through readfirstlane so
+// that the switch is a scalar jump)
+__device__ __attribute__((noinline)) void sn_finish_wave(double* __restrict__ U, double* __restrict__ invd,
+                                                         uint32_t base0, uint32_t w, uint32_t nr, uint32_t col0,
+                                                         uint32_t lane) {
+  switch (w) {
+#define SLPX_SN_CASE(W) case W: sn_finish_wave_exact<W>(U, invd, base0, nr, col0, lane); break;
+    SLPX_SN_CASE(2) SLPX_SN_CASE(3) SLPX_SN_CASE(4) SLPX_SN_CASE(5) SLPX_SN_CASE(6) SLPX_SN_CASE(7) SLPX_SN_CASE(8)
+#undef SLPX_SN_CASE
+    default: break;
+  }
+  static_assert(kSnWidthMax == 8, "one case per supernode width");
+}
+
+// One wave finishes y (forward) or x (backward) of a chain of w <= kSnWidthMax columns: lane c
+// owns column c; its couplings to the other columns of the chain sit in registers, indexed by
+// the column they multiply, and the finished components are broadcast with v_readlane.
+// FORWARD: `ptr` is the row pointer array (uint32_t, n_col + 1): row c's last c items are
+// L(j_c, j_0..j_{c-1}).  Backward: `ptr` is the column range table (uint2): the W - c - 1 items
+// before .x are L(j_{c+1}..j_{W-1}, j_c).
+template <int W, bool FORWARD, typename Ptr>
+__device__ __forceinline__ void chain_solve_wave_w(double* __restrict__ v, const double* __restrict__ vals,
+                                                   const Ptr* __restrict__ ptr, uint32_t i0, uint32_t lane) {
+  const bool mine = lane < static_cast<uint32_t>(W);
+  const uint32_t c = mine ? lane : 0u;
+  uint32_t first;  // position of the coupling to chain column 0 (forward) / c + 1 (backward)
+  if constexpr (FORWARD) first = ptr[i0 + c + 1] - c;
+  else first = ptr[i0 + c].x - (static_cast<uint32_t>(W) - c - 1u);
+  double cf[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const uint32_t kk = static_cast<uint32_t>(k);
+    const bool use = mine && (FORWARD ? kk < c : kk > c);
+    cf[k] = use ? vals[FORWARD ? first + kk : first + (kk - c - 1)] : 0.0;
+  }
+  double p = mine ? v[i0 + c] : 0.0;
+  if (FORWARD) {
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) p = __builtin_fma(-cf[k], readlane_f64(p, k), p);
+  } else {
+#pragma unroll
+    for (int k = W - 1; k >= 1; --k) p = __builtin_fma(-cf[k], readlane_f64(p, k), p);
+  }
+  if (mine) v[i0 + c] = p;
+}
+template <bool FORWARD, typename Ptr>
+__device__ __attribute__((noinline)) void chain_solve_wave(double* __restrict__ v, const double* __restrict__ vals,
+                                                           const Ptr* __restrict__ ptr, uint32_t i0, uint32_t w,
+                                                           uint32_t lane) {
+  switch (w) {
+#define SLPX_SN_CASE(W) case W: chain_solve_wave_w<W, FORWARD>(v, vals, ptr, i0, lane); break;
+    SLPX_SN_CASE(2) SLPX_SN_CASE(3) SLPX_SN_CASE(4) SLPX_SN_CASE(5) SLPX_SN_CASE(6) SLPX_SN_CASE(7) SLPX_SN_CASE(8)
+#undef SLPX_SN_CASE
+    default: break;
+  }
+  static_assert(kSnWidthMax == 8, "one case per supernode width");
+}
+
 // ---------------------------------------------------------------------------
 // Factorization.  Entry (i,j) of column j:  U(i,j) = A(i,j) [+δ | −γ on the
 // diagonal] − Σ contributions of child tasks − Σ_k U(i,k)·U(j,k)/d_k, the last sum
@@ -154,7 +282,11 @@ __device__ __forceinline__ double group8_sum(double v) {
 //
 // LDS: pairs[np] 8 B | pptr[n_ent+n_ext+1] u32 | lvl[n_lvl+1] u32 | src[n_ent] i32 |
 //      col[n_ent] u16 | flags[n_ent] u8 | out[n_ent] u32 | cptr[n_ent+1] u32 |
+//      sn[n_sn] 12 B | (lvl holds entry index | first chain of the level << 16)
 //      U[n_ent] f64 | invd[n_col] f64 | counters 32 B      (16-byte groups first)
+// A level is a set of SUPERNODES: pass A = the gather above over every entry of the level's
+// columns (in-chain pairs are not in the lists), then — only in levels that hold a chain of two
+// or more columns — a barrier and sn_finish_wave, one wave per chain.
 // ---------------------------------------------------------------------------
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
@@ -186,7 +318,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   const uint32_t np = t.n_pairs;
   const uint32_t g_pairs = q16(np, 2), g_pptr = q16(n_pp, 4), g_lvl = q16(t.n_lvl + 1, 4),
                  g_src = q16(t.n_ent, 4), g_col = q16(t.n_ent, 8), g_flags = q16(t.n_ent, 16),
-                 g_out = q16(t.n_ent, 4), g_cptr = q16(t.n_ent + 1, 4);
+                 g_out = q16(t.n_ent, 4), g_cptr = q16(t.n_ent + 1, 4), g_snd = q16(3 * t.n_sn, 4);
   uint4* s_pairs = reinterpret_cast<uint4*>(smem_raw);
   uint4* s_pptr = s_pairs + g_pairs;
   uint4* s_lvl = s_pptr + g_pptr;
@@ -195,7 +327,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   uint4* s_flags = s_col + g_col;
   uint4* s_out = s_flags + g_flags;
   uint4* s_cptr = s_out + g_out;
-  double* U = reinterpret_cast<double*>(s_cptr + g_cptr);
+  uint4* s_snd = s_cptr + g_cptr;
+  double* U = reinterpret_cast<double*>(s_snd + g_snd);
   double* invd = U + t.n_ent;
   int* s_cnt = reinterpret_cast<int*>(invd + t.n_col);
   unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
@@ -207,17 +340,19 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   const uint8_t* flags = reinterpret_cast<const uint8_t*>(s_flags);
   const uint32_t* out = reinterpret_cast<const uint32_t*>(s_out);
   const uint32_t* cptr = reinterpret_cast<const uint32_t*>(s_cptr);
+  const LdltSn* snd = reinterpret_cast<const LdltSn*>(s_snd);
 
   // ---- stage the static part ----
   stage16<THREADS>(s_pairs, reinterpret_cast<const uint4*>(L.pairs + t.pair_off), g_pairs, tid);
   stage16<THREADS>(s_pptr, reinterpret_cast<const uint4*>(L.ent_pair_ptr + t.pair_ptr_off), g_pptr, tid);
-  stage16<THREADS>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<THREADS>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_pack + t.lvl_off), g_lvl, tid);
   stage16<THREADS>(s_src, reinterpret_cast<const uint4*>(L.ent_src + t.ent_off), g_src, tid);
   stage16<THREADS>(s_col, reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), g_col, tid);
   stage16<THREADS>(s_flags, reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), g_flags, tid);
   stage16<THREADS>(s_out, reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), g_out, tid);
   stage16<THREADS>(s_cptr, reinterpret_cast<const uint4*>(L.ent_contrib_ptr + t.contrib_ptr_off), g_cptr,
                tid);
+  if (t.n_sn) stage16<THREADS>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
   if (tid < 4) s_cnt[tid] = 0;
   if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
   __syncthreads();
@@ -270,9 +405,13 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   // ---- level loop: all in LDS ----
   const int lane8 = tid & 7, grp = tid >> 3;
   {
-    uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
+    // lvl[l] = first entry of level l | first chain (w >= 2) of level l << 16
+    uint32_t beg = lvl[0] & 0xffffu, end_pack = t.n_lvl ? lvl[1] : 0, end = end_pack & 0xffffu, sb = 0;
+#ifdef SLPX_LDLT_LEVEL_CLOCKS  // core clocks in pass A / in the chain pass (slots 6, 7); each reading costs ~150 clocks
+    long long clk_a = 0, clk_b = 0, clk_t = clock64();
+#endif
     for (uint32_t l = 0; l < t.n_lvl; ++l) {
-      const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];  // one level ahead
+      const uint32_t next_pack = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];  // one level ahead
       for (uint32_t i = beg + grp; i < end; i += THREADS / 8) {
         const uint32_t pb = pptr[i], pe = pptr[i + 1];
         // issued with the pointer loads, off the dependent chain
@@ -287,13 +426,47 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
         if (lane8 == 0) {
           const double u = u_old - partial;
           U[i] = u;
-          if (fl & 1) invd[cj] = fast_reciprocal(u);
+          if ((fl & 9) == 1) invd[cj] = fast_reciprocal(u);  // a lone column's pivot
         }
       }
       __syncthreads();
+#ifdef SLPX_LDLT_LEVEL_CLOCKS
+      {
+        const long long c = clock64();
+        clk_a += c - clk_t;
+        clk_t = c;
+      }
+#endif
+      {
+        const uint32_t se = end_pack >> 16;
+        if (se > sb) {  // chains of two or more columns in this level (block-uniform)
+          // everything about the chain is wave-uniform: scalar registers, scalar jump
+          for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += THREADS / 64) {
+            const LdltSn sn = snd[q];
+            sn_finish_wave(U, invd, __builtin_amdgcn_readfirstlane(sn.base0), __builtin_amdgcn_readfirstlane(sn.w),
+                                  __builtin_amdgcn_readfirstlane(sn.nr), __builtin_amdgcn_readfirstlane(sn.col0), tid & 63);
+          }
+          __syncthreads();
+        }
+        sb = se;
+      }
+#ifdef SLPX_LDLT_LEVEL_CLOCKS
+      {
+        const long long c = clock64();
+        clk_b += c - clk_t;
+        clk_t = c;
+      }
+#endif
       beg = end;
-      end = next_end;
+      end_pack = next_pack;
+      end = end_pack & 0xffffu;
     }
+#ifdef SLPX_LDLT_LEVEL_CLOCKS
+    if (task_index == L.round_ptr[g_ldlt_clock_round] && blockIdx.y == 0 && threadIdx.x == 0) {
+      g_ldlt_clocks[6] = static_cast<unsigned long long>(clk_a);
+      g_ldlt_clocks[7] = static_cast<unsigned long long>(clk_b);
+    }
+#endif
   }
 
   SLPX_LDLT_CLOCK(3);
@@ -342,7 +515,11 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
 // ---------------------------------------------------------------------------
 // Forward substitution L y = P b followed by z = D⁻¹ y.
 // LDS: items[n_items] 8 B | ptr[n_col+1] u32 | lvl[n_lvl+1] u32 | colperm[n_col] u32 |
-//      fcptr[n_col+1] u32 | vals[n_items] f64 | y[n_col+1] f64
+//      fcptr[n_col+1] u32 | colsn[n_col] u32 | sn[n_sn] 12 B | sn level ptr u32 |
+//      vals[n_items] f64 | y[n_col+1] f64
+// Rows of one supernode share a level: pass A takes the items of columns outside the chain
+// (all but the LAST pos items of a row), then each chain is finished by one wave
+// (chain_solve_wave).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ rhs, int n,
@@ -362,14 +539,20 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
   SLPX_LDLT_CLOCK(8);
   const uint32_t n_items = t.n_fwd_items;
   const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
-                 g_cp = q16(t.n_col, 4);
+                 g_cp = q16(t.n_col, 4), g_snd = q16(3 * t.n_sn, 4);
   uint4* s_items = reinterpret_cast<uint4*>(smem_raw);
   uint4* s_ptr = s_items + g_items;
   uint4* s_lvl = s_ptr + g_ptr;
   uint4* s_cp = s_lvl + g_lvl;
   uint4* s_fc = s_cp + g_cp;
-  double* vals = reinterpret_cast<double*>(s_fc + g_ptr);
+  uint4* s_csn = s_fc + g_ptr;
+  uint4* s_snd = s_csn + g_cp;
+  uint4* s_snl = s_snd + g_snd;
+  double* vals = reinterpret_cast<double*>(s_snl + g_lvl);
   double* y = vals + n_items;
+  const uint32_t* colsn = reinterpret_cast<const uint32_t*>(s_csn);
+  const LdltSn* snd = reinterpret_cast<const LdltSn*>(s_snd);
+  const uint32_t* snl = reinterpret_cast<const uint32_t*>(s_snl);
   const uint2* items = reinterpret_cast<const uint2*>(s_items);  // x = lpos, y = ref
   const uint32_t* ptr = reinterpret_cast<const uint32_t*>(s_ptr);
   const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
@@ -381,6 +564,9 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
   stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_ptr + t.lvl_off), g_lvl, tid);
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   stage16<256>(s_fc, reinterpret_cast<const uint4*>(L.fwd_contrib_ptr + t.colptr_off), g_ptr, tid);
+  stage16<256>(s_csn, reinterpret_cast<const uint4*>(L.col_sn + t.col_off), g_cp, tid);
+  stage16<256>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
+  stage16<256>(s_snl, reinterpret_cast<const uint4*>(L.sn_lvl_ptr + t.lvl_off), g_lvl, tid);
   __syncthreads();
   SLPX_LDLT_CLOCK(9);
   {
@@ -411,13 +597,20 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     for (uint32_t l = 0; l < t.n_lvl; ++l) {
       const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];
       for (uint32_t i = beg + grp; i < end; i += 32) {
-        const uint32_t qe = ptr[i + 1];
+        const uint32_t qe = ptr[i + 1] - (colsn[i] & 0xffu);  // the chain's own columns come after
         double partial = 0.0;
         for (uint32_t q = ptr[i] + lane8; q < qe; q += 8) partial += vals[q] * y[items[q].y];
         partial = group8_sum(partial);
         if (lane8 == 0) y[i] -= partial;
       }
       __syncthreads();
+      const uint32_t sb = snl[l], se = snl[l + 1];
+      if (se > sb) {  // chains of two or more columns in this level (block-uniform)
+        for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += 4)
+          chain_solve_wave<true>(y, vals, ptr, __builtin_amdgcn_readfirstlane(snd[q].col0),
+                                 __builtin_amdgcn_readfirstlane(snd[q].w), tid & 63);
+        __syncthreads();
+      }
       beg = end;
       end = next_end;
     }
@@ -445,7 +638,9 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 // are final (earlier launch): their products are folded into the staged values and
 // point at the constant-one slot x[n_col], so the level loop is uniform.
 // LDS: items[n_items] 8 B | ptr[n_col+1] u32 | lvl[n_lvl+1] u32 | colperm[n_col] u32 |
-//      vals[n_items] f64 | refs[n_items] u32 (8-aligned) | x[n_col+1] f64
+//      colsn[n_col] u32 | sn[n_sn] 12 B | sn level ptr u32 | vals[n_items] f64 | x[n_col+1] f64
+// A chain's columns share a level: pass A takes the rows below the chain (all but the FIRST
+// w - pos - 1 items of a column), then the chain is finished top-down by chain_solve_wave.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
@@ -464,23 +659,26 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
 
   SLPX_LDLT_CLOCK(16);
   const uint32_t n_items = t.n_bwd_items;
-  const uint32_t g_items = q16(n_items, 2), g_ptr = q16(t.n_col + 1, 4), g_lvl = q16(t.n_lvl + 1, 4),
-                 g_cp = q16(t.n_col, 4);
+  const uint32_t g_items = q16(n_items, 2), g_rng = q16(t.n_col, 2), g_lvl = q16(t.n_lvl + 1, 4),
+                 g_cp = q16(t.n_col, 4), g_snd = q16(3 * t.n_sn, 4);
   uint4* s_items = reinterpret_cast<uint4*>(smem_raw);
-  uint4* s_ptr = s_items + g_items;
-  uint4* s_lvl = s_ptr + g_ptr;
+  uint4* s_rng = s_items + g_items;
+  uint4* s_lvl = s_rng + g_rng;
   uint4* s_cp = s_lvl + g_lvl;
-  double* vals = reinterpret_cast<double*>(s_cp + g_cp);
+  uint4* s_snd = s_cp + g_cp;
+  double* vals = reinterpret_cast<double*>(s_snd + g_snd);
   double* x = vals + n_items;
+  const LdltSn* snd = reinterpret_cast<const LdltSn*>(s_snd);
   uint2* items = reinterpret_cast<uint2*>(s_items);  // x = lpos, y = ref (rewritten in place)
-  const uint32_t* ptr = reinterpret_cast<const uint32_t*>(s_ptr);
-  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);
+  const uint2* rng = reinterpret_cast<const uint2*>(s_rng);  // {first item below the column's own chain, end}
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);  // column | first chain << 16
   const uint32_t* colperm = reinterpret_cast<const uint32_t*>(s_cp);
 
   stage16<256>(s_items, reinterpret_cast<const uint4*>(L.bwd_items + t.bwd_item_off), g_items, tid);
-  stage16<256>(s_ptr, reinterpret_cast<const uint4*>(L.bwd_ptr + t.colptr_off), g_ptr, tid);
-  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_ptr + t.lvl_off), g_lvl, tid);
+  stage16<256>(s_rng, reinterpret_cast<const uint4*>(L.bwd_range + t.col_off), g_rng, tid);
+  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_pack + t.lvl_off), g_lvl, tid);
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
+  if (t.n_sn) stage16<256>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
   __syncthreads();
   SLPX_LDLT_CLOCK(17);
   // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
@@ -515,27 +713,57 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(18);
-  // A level holds a handful of columns (3-4 on average): ONE wave runs the whole level loop
-  // — eight 8-lane groups — so no workgroup barrier sits between two levels; the wave's own
-  // LDS operations are issued in order, only the compiler has to be kept from moving them
-  // across the level boundary.
-  if (tid < 64) {
+  // A level holds a handful of columns (3-4 on average; a dozen with supernodal levels).  Tasks
+  // without a chain of two or more columns: ONE wave runs the whole level loop — eight 8-lane
+  // groups — with no workgroup barrier between two levels (the wave's own LDS operations are
+  // issued in order, only the compiler has to be kept from moving them across the level
+  // boundary).  Tasks with chains: all four waves, thirty-two groups, one barrier after the
+  // gather and one after the chains, which get a wave each (a barrier of four waves is ~40
+  // clocks; solving the chains of a level one after the other in a single wave cost more than
+  // the levels it saved: backward solve at N=5000 39.9 -> 52.5 us).
+  if (t.n_sn == 0) {
+    if (tid < 64) {
+      const int lane8 = tid & 7, grp = tid >> 3;
+      uint32_t end = lvl[t.n_lvl] & 0xffffu, beg = t.n_lvl ? lvl[t.n_lvl - 1] & 0xffffu : 0;
+      for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+        const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0] & 0xffffu;
+        for (uint32_t i = beg + grp; i < end; i += 8) {
+          const uint2 r = rng[i];
+          double partial = 0.0;
+          for (uint32_t q = r.x + lane8; q < r.y; q += 8) partial += vals[q] * x[items[q].y];
+          partial = group8_sum(partial);
+          if (lane8 == 0) x[i] -= partial;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        end = beg;
+        beg = next_beg;
+      }
+    }
+  } else {
     const int lane8 = tid & 7, grp = tid >> 3;
-    uint32_t end = lvl[t.n_lvl], beg = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
+    uint32_t end_pack = lvl[t.n_lvl], beg_pack = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
     for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
-      const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0];
-      for (uint32_t i = beg + grp; i < end; i += 8) {
-        const uint32_t qe = ptr[i + 1];
+      const uint32_t next_pack = lvl[l >= 1 ? l - 1 : 0];
+      const uint32_t beg = beg_pack & 0xffffu, end = end_pack & 0xffffu;
+      for (uint32_t i = beg + grp; i < end; i += 32) {
+        const uint2 r = rng[i];
         double partial = 0.0;
-        for (uint32_t q = ptr[i] + lane8; q < qe; q += 8) partial += vals[q] * x[items[q].y];
+        for (uint32_t q = r.x + lane8; q < r.y; q += 8) partial += vals[q] * x[items[q].y];
         partial = group8_sum(partial);
         if (lane8 == 0) x[i] -= partial;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      end = beg;
-      beg = next_beg;
+      __syncthreads();
+      const uint32_t sb = beg_pack >> 16, se = end_pack >> 16;
+      if (se > sb) {  // chains of two or more columns in this level (block-uniform)
+        for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += 4)
+          chain_solve_wave<false>(x, vals, rng, __builtin_amdgcn_readfirstlane(snd[q].col0),
+                                  __builtin_amdgcn_readfirstlane(snd[q].w), tid & 63);
+        __syncthreads();
+      }
+      end_pack = beg_pack;
+      beg_pack = next_pack;
     }
   }
   __syncthreads();

@@ -1,6 +1,8 @@
 #include "ldlt_symbolic.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 #include <unordered_map>
@@ -382,13 +384,71 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   std::vector<int32_t> tlevel(n, 0), lcol(n, -1);
   for (int t = 0; t < ntasks; ++t)
     for (int32_t j : tcols[t].cols) task_of[j] = t;
+  // ---- supernodes: chains of the etree inside one task whose columns share their structure ----
+  // (|struct(L_j)| = |struct(L_parent)| + 1 makes the two structures equal up to the parent
+  // itself, since struct(L_j) \ {parent} is always contained in struct(L_parent).)  A column
+  // may have any number of other children: they just have to sit in lower levels.
+  std::vector<int32_t> sn_of(n, -1), sn_pos(n, 0);
+  std::vector<std::vector<int32_t>> sn_cols;
+  for (int j = 0; j < n; ++j) {
+    if (sn_of[j] >= 0 || sn_of[j] == -2) continue;
+    std::vector<int32_t> chain{j};
+    sn_of[j] = static_cast<int32_t>(sn_cols.size());
+    int32_t k = j;
+    while (opt.supernodal && chain.size() < kSnWidthMax) {
+      const int32_t p = P.parent[k];
+      // rows of the trapezoid after adding p: chain + struct(L_p) + rhs row
+      if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
+          chain.size() + 1 + Lcol[p].size() + 1 > kSnRowsMax)
+        break;
+      sn_of[p] = sn_of[j];
+      sn_pos[p] = static_cast<int32_t>(chain.size());
+      chain.push_back(p);
+      k = p;
+    }
+    if (chain.size() > 1 && static_cast<int>(chain.size()) < opt.min_supernode_width) {
+      // not worth a dense pass: back to single columns
+      for (size_t i = 1; i < chain.size(); ++i) {
+        sn_of[chain[i]] = -2;  // claimed by nobody; gets its own (lone) supernode below
+        sn_pos[chain[i]] = 0;
+      }
+      chain.resize(1);
+    }
+    sn_cols.push_back(std::move(chain));
+  }
   for (int j = 0; j < n; ++j)
-    for (int32_t c : children[j])
-      if (task_of[c] == task_of[j]) tlevel[j] = std::max(tlevel[j], tlevel[c] + 1);
+    if (sn_of[j] == -2) {
+      sn_of[j] = static_cast<int32_t>(sn_cols.size());
+      sn_cols.push_back({j});
+    }
+  P.n_supernodes = static_cast<int>(sn_cols.size());
+  for (auto& c : sn_cols) {
+    P.widest_supernode = std::max<int>(P.widest_supernode, static_cast<int>(c.size()));
+    if (P.sn_width_hist.size() <= c.size()) P.sn_width_hist.resize(c.size() + 1, 0);
+    ++P.sn_width_hist[c.size()];
+  }
+  auto sn_width = [&](int32_t j) { return static_cast<int32_t>(sn_cols[sn_of[j]].size()); };
+  // level of a supernode = 1 + the deepest supernode among the other children of its columns
+  // (columns ascending: a child outside the chain ends its own chain, so that one is final)
+  {
+    std::vector<int32_t> snlevel(sn_cols.size(), 0);
+    for (int j = 0; j < n; ++j)
+      for (int32_t c : children[j])
+        if (task_of[c] == task_of[j] && sn_of[c] != sn_of[j])
+          snlevel[sn_of[j]] = std::max(snlevel[sn_of[j]], snlevel[sn_of[c]] + 1);
+    for (int j = 0; j < n; ++j) tlevel[j] = snlevel[sn_of[j]];
+  }
   for (int t = 0; t < ntasks; ++t) {
     auto& cols = tcols[t].cols;
+    // within a level: supernodes by width (the lanes finishing them run width-specific code),
+    // a supernode's columns consecutive and ascending
     std::sort(cols.begin(), cols.end(), [&](int32_t a, int32_t b) {
-      return tlevel[a] != tlevel[b] ? tlevel[a] < tlevel[b] : a < b;
+      if (tlevel[a] != tlevel[b]) return tlevel[a] < tlevel[b];
+      if (sn_of[a] != sn_of[b]) {
+        const int32_t wa = sn_width(a), wb = sn_width(b);
+        return wa != wb ? wa < wb : sn_cols[sn_of[a]][0] < sn_cols[sn_of[b]][0];
+      }
+      return a < b;
     });
     for (size_t i = 0; i < cols.size(); ++i) lcol[cols[i]] = static_cast<int32_t>(i);
   }
@@ -435,7 +495,10 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       const int32_t j = rows[a];  // target column
       const int tj = task_of[j];
       const uint32_t ent_jk = lent[P.Lp[k] + a];
+      // updates between two columns of one supernode are done in registers (ldlt_kernels.h)
+      const bool in_chain = sn_of[k] == sn_of[j];
       auto add_pair = [&](uint32_t target, const LdltPair& pr) {
+        if (in_chain) return;
         if (tk == tj) {
           epairs[tj][target].push_back(pr);
         } else {
@@ -490,7 +553,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       const int tk = task_of[k];
       LdltSolveItem it{lpos, static_cast<uint32_t>(lcol[k])};
       if (tk == tj) {
-        fwd[j].push_back(it);
+        if (sn_of[k] != sn_of[j]) fwd[j].push_back(it);  // the chain's own columns follow below
       } else {
         auto f = sext_map[tk].find(j);
         if (f == sext_map[tk].end()) {
@@ -501,6 +564,15 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
         }
         sexts[tk][f->second].items.push_back(it);
       }
+    }
+    // row j against the earlier columns of its own supernode: the LAST sn_pos[j] items, chain order
+    for (int c = 0; c < sn_pos[j]; ++c) {
+      const int32_t k = sn_cols[sn_of[j]][c];
+      const int32_t* b = P.Li.data() + P.Lp[k];
+      const int32_t* e = P.Li.data() + P.Lp[k + 1];
+      const int32_t* f = std::lower_bound(b, e, j);
+      if (f == e || *f != j) throw std::runtime_error("ldlt: supernode column lacks a chain row");
+      fwd[j].push_back({static_cast<uint32_t>(f - P.Li.data()), static_cast<uint32_t>(lcol[k])});
     }
     for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
       int32_t i = P.Li[p];
@@ -547,6 +619,9 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     }
     pad(P.fwd_items, 2);
     pad(P.bwd_items, 2);
+    pad(P.sn_desc, 4);  // 12-byte records: four of them are three 16-byte groups
+    pad(P.col_sn, 4);
+    pad(P.sn_lvl_ptr, 4);
     LdltTask T{};
     const auto& cols = tcols[t].cols;
     T.round = static_cast<uint32_t>(tcols[t].round);
@@ -569,6 +644,9 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     T.contrib_ptr_off = static_cast<uint32_t>(P.ent_contrib_ptr.size());
     T.colptr_off = static_cast<uint32_t>(P.fwd_ptr.size());
     T.sext_ptr_off = static_cast<uint32_t>(P.sext_ptr.size());
+    T.sn_off = static_cast<uint32_t>(P.sn_desc.size());
+    if (P.col_sn.size() != P.col_perm.size() || P.sn_lvl_ptr.size() != P.lvl_ptr.size())
+      throw std::runtime_error("ldlt: supernode arrays out of step with the column arrays");
 
     int32_t cur_level = -1;
     uint32_t pair_count = 0, contrib_count = 0, fwd_count = 0, bwd_count = 0, sc_count = 0;
@@ -577,9 +655,19 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       if (tlevel[j] != cur_level) {
         P.lvl_ptr.push_back(diag_ent[j]);
         P.col_lvl_ptr.push_back(static_cast<uint32_t>(ci));
+        P.sn_lvl_ptr.push_back(static_cast<uint32_t>(P.sn_desc.size()) - T.sn_off);
         cur_level = tlevel[j];
       }
       P.col_perm.push_back(static_cast<uint32_t>(j));
+      const uint32_t w = static_cast<uint32_t>(sn_width(j)), pos = static_cast<uint32_t>(sn_pos[j]);
+      P.col_sn.push_back(pos | (w << 8));
+      if (w >= 2 && pos == 0) {
+        // rows of the trapezoid: the chain, the common structure below it, the rhs row
+        const uint32_t nr = w + static_cast<uint32_t>(Lcol[sn_cols[sn_of[j]].back()].size()) + 1;
+        if (nr > kSnRowsMax) throw std::runtime_error("ldlt: supernode has more rows than a wave has lanes");
+        P.sn_desc.push_back(LdltSn{diag_ent[j], static_cast<uint16_t>(w), static_cast<uint16_t>(nr),
+                                   static_cast<uint16_t>(ci), 0});
+      }
       auto emit_entry = [&](uint32_t le, int32_t src, uint8_t flags, uint32_t out) {
         P.ent_src.push_back(src);
         P.ent_flags.push_back(flags);
@@ -593,7 +681,10 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
         contrib_count += static_cast<uint32_t>(econtrib[t][le].size());
       };
       const bool gamma_kind = P.perm[j] >= n_dec;
-      emit_entry(diag_ent[j], diag_src[j], static_cast<uint8_t>(1 | (gamma_kind ? 2 : 0)),
+      // bit 3: entry of the diagonal block of a supernode with w >= 2 — finished (and written
+      // out) by the lanes that work on the supernode, not by the generic passes
+      const uint8_t in_block = w >= 2 ? 8 : 0;
+      emit_entry(diag_ent[j], diag_src[j], static_cast<uint8_t>(1 | (gamma_kind ? 2 : 0) | in_block),
                  static_cast<uint32_t>(j));
       // off-diagonal entries: A source by merge with Acol[j]
       size_t ap = 0;
@@ -601,7 +692,9 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
         int32_t src = -1;
         while (ap < Acol[j].size() && Acol[j][ap].first < P.Li[p]) ++ap;
         if (ap < Acol[j].size() && Acol[j][ap].first == P.Li[p]) src = Acol[j][ap].second;
-        emit_entry(lent[p], src, 0, static_cast<uint32_t>(p));
+        // the first w - pos - 1 rows of the column are the later columns of its chain
+        const bool block_row = static_cast<uint32_t>(p - P.Lp[j]) + pos + 1 < w;
+        emit_entry(lent[p], src, block_row ? in_block : 0, static_cast<uint32_t>(p));
       }
       // rhs-row entry: source = rhs[perm[j]], result z_j = U_b(j)/d_j
       emit_entry(bent[j], P.perm[j], 4, static_cast<uint32_t>(j));
@@ -619,6 +712,8 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     P.lvl_ptr.push_back(T.n_ent);
     P.col_lvl_ptr.push_back(T.n_col);
     T.n_lvl = static_cast<uint32_t>(P.lvl_ptr.size() - T.lvl_off - 1);
+    T.n_sn = static_cast<uint32_t>(P.sn_desc.size()) - T.sn_off;
+    P.sn_lvl_ptr.push_back(T.n_sn);
     // pseudo entries continue the pair_ptr array
     for (auto& ex : exts[t]) {
       P.ext_dst.push_back(ex.dst);
@@ -649,10 +744,10 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
     const uint32_t fb = q(pair_count, 2) + q(T.n_ent + T.n_ext + 1, 4) + q(T.n_lvl + 1, 4) +
                         q(T.n_ent, 4) + q(T.n_ent, 8) + q(T.n_ent, 16) + q(T.n_ent, 4) +
-                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32;
+                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32 + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);
     const uint32_t items = std::max(fwd_count, bwd_count);
     const uint32_t sb = q(items, 2) + 2 * q(T.n_col + 1, 4) + q(T.n_lvl + 1, 4) + q(T.n_col, 4) +
-                        8 * items + 8 * (T.n_col + 1) + 32;
+                        8 * items + 8 * (T.n_col + 1) + 32 + q(T.n_col, 4) + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);
     P.factor_lds_bytes = std::max(P.factor_lds_bytes, fb);
     P.solve_lds_bytes = std::max(P.solve_lds_bytes, sb);
     P.tasks.push_back(T);
@@ -681,6 +776,41 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     P.bwd_ptr.push_back(0);
     P.fwd_items.push_back({});
     P.bwd_items.push_back({});
+    P.sn_desc.push_back({});
+    P.col_sn.push_back(0);
+    P.sn_lvl_ptr.push_back(0);
+  }
+  if (std::getenv("SLPX_LDLT_VERBOSE")) {
+    // per round: tasks, levels, supernodes (w >= 2) per level, rows per level
+    for (int r = 0; r < P.n_rounds; ++r) {
+      std::vector<int> hist(9, 0);
+      uint32_t max_sn = 0, max_rows = 0, lvls = 0, ntask = P.round_ptr[r + 1] - P.round_ptr[r];
+      double sum_sn = 0, sum_ent = 0;
+      for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) {
+        const LdltTask& T = P.tasks[ti];
+        for (uint32_t l = 0; l < T.n_lvl; ++l) {
+          const uint32_t ns = P.sn_lvl_ptr[T.lvl_off + l + 1] - P.sn_lvl_ptr[T.lvl_off + l];
+          uint32_t ni = 0;
+          for (uint32_t q = P.sn_lvl_ptr[T.lvl_off + l]; q < P.sn_lvl_ptr[T.lvl_off + l + 1]; ++q) ni += P.sn_desc[T.sn_off + q].nr;
+          const uint32_t ne = P.lvl_ptr[T.lvl_off + l + 1] - P.lvl_ptr[T.lvl_off + l];
+          max_sn = std::max(max_sn, ns);
+          max_rows = std::max(max_rows, ni);
+          sum_sn += ns;
+          sum_ent += ne;
+          ++lvls;
+          ++hist[std::min<uint32_t>(8, (ns + 3) / 4)];
+        }
+      }
+      std::fprintf(stderr, "ldlt round %d: %u tasks, %.1f levels/task, chains(w>=2)/level avg %.1f max %u, chain rows/level max %u, entries/level avg %.0f; chains/level hist (0,1-4,5-8,...,>=29):",
+                   r, ntask, double(lvls) / ntask, sum_sn / lvls, max_sn, max_rows, sum_ent / lvls);
+      for (int h : hist) std::fprintf(stderr, " %d", h);
+      std::fprintf(stderr, "\n");
+    }
+  }
+  for (int r = 0; r < P.n_rounds; ++r) {
+    uint32_t deepest = 0;
+    for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) deepest = std::max(deepest, P.tasks[ti].n_lvl);
+    P.critical_levels += static_cast<int>(deepest);
   }
   if (P.factor_lds_bytes > 160u * 1024u || P.solve_lds_bytes > 160u * 1024u)
     throw std::runtime_error("ldlt: a task's working set exceeds the 160 KB LDS of a CU; lower "

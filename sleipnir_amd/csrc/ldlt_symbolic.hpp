@@ -54,7 +54,29 @@ struct LdltTask {
   uint32_t sext_ptr_off;     // sext_ptr: n_sext + 1 entries
   uint32_t n_pairs;          // update pairs of own + pseudo entries
   uint32_t n_fwd_items, n_bwd_items;
+  // supernodes of two or more columns (see LdltSn): descriptors in level order
+  uint32_t sn_off, n_sn;  // this task's slice of `sn_desc`; `sn_lvl_ptr` shares lvl_off
 };
+
+// A supernode of w >= 2 columns: a chain j_0 < ... < j_{w-1} of the elimination tree inside
+// one task whose columns have the SAME structure below the chain (struct(L_{j_c}) =
+// {j_{c+1}, ..., j_{w-1}} u R) — the separator cliques of a dissected transcription problem,
+// whatever the number of children a column has (relaxed in that sense; no explicit zeros).
+// The chain is ONE level of the task: first every entry of its columns receives the updates
+// of the columns below the chain (the pair lists, which contain no in-chain pair), then the
+// dense (w + |R| + 1) x w trapezoid — diagonal block, rows R, right-hand-side row — is
+// finished in registers by ONE WAVE, a lane per row (ldlt_kernels.h: sn_finish_wave).  Its entries are contiguous in the task's local numbering: row t
+// of column c (t >= c; t = c the diagonal, t = nr - 1 the rhs row) is entry
+// base0 + c nr - c (c - 1) / 2 + (t - c).
+struct LdltSn {
+  uint32_t base0;  // local entry index of the first column's diagonal
+  uint16_t w;      // columns
+  uint16_t nr;     // rows: w + |R| + 1
+  uint16_t col0;   // local column index of j_0 (the chain's columns are consecutive)
+  uint16_t pad;
+};
+constexpr uint32_t kSnWidthMax = 8;  // longer chains are cut (a lane keeps a row of this many doubles in registers)
+constexpr uint32_t kSnRowsMax = 64;   // rows of the trapezoid (w + |R| + 1): one lane each; bigger ones stay single columns
 
 struct LdltSolveItem {
   uint32_t lpos;  // index into Lx
@@ -107,6 +129,16 @@ struct LdltPlan {
   std::vector<LdltSolveItem> bwd_items;
   uint32_t n_scontrib = 0;
 
+  // ---- supernodes (w >= 2 only; none when LdltOptions::supernodal is off) ----
+  std::vector<LdltSn> sn_desc;            // per task, level order
+  std::vector<uint32_t> sn_lvl_ptr;       // per task n_lvl + 1 (relative to sn_off), in step with lvl_ptr
+  // solves: per column (task order) pos-in-chain | w << 8 (a lone column: 0x100)
+  std::vector<uint32_t> col_sn;
+  int n_supernodes = 0;                   // all of them, singletons included
+  int widest_supernode = 1;
+  int critical_levels = 0;                // sum over rounds of the deepest task's level count
+  std::vector<int32_t> sn_width_hist;     // [w] = supernodes of that width
+
   // traffic model: factor = 12k + 16ℓ, solve = 32ℓ + 16 n
   int64_t factor_bytes = 0, solve_bytes = 0;
   int64_t flops = 0;  // 2 * number of pair products
@@ -122,6 +154,14 @@ struct LdltOptions {
   // descriptors; four update pairs ~ one entry).  2048 keeps a task near 64-96 KB.
   uint32_t task_entries = 2048;
   bool defer_constraints = true;
+  // levels are supernodes (chains of equal-structure columns) instead of single columns:
+  // cart-pole N=1000 50 -> 16 levels on the critical path, g-fold N=100 68 -> 16.  The
+  // batch-interleaved kernels (ldlt_il_kernels.h) read the column-level plan: off for them.
+  bool supernodal = true;
+  // shorter chains stay single columns: finishing a chain has a fixed cost of about two column
+  // levels (profiles/microbench/chain.hip), so a pair gains nothing (cart-pole N=1000, steps/s:
+  // 2 -> 11.39 k, 4 -> 11.52 k, off -> 10.42 k; N=5000: 7.66 k, 7.69 k, 7.08 k)
+  int min_supernode_width = 4;
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

@@ -38,6 +38,10 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   // (measured at 512 x N=1000, ms per factorization: 192 -> 0.55 but some problems then need a
   // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+  // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
+  if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
+  if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
+  if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
   if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
   if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
   m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
@@ -120,6 +124,8 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   LdltOptions lopt = opt.ldlt;
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+  if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
+  if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
   m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));

@@ -106,3 +106,24 @@ def max_rel(a, b):
     if a.size == 0:
         return 0.0
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+def sym_from_lower(colptr, rowidx, val):
+    """scipy CSC of the full symmetric matrix given by its lower triangle."""
+    import scipy.sparse as sp
+
+    n = len(colptr) - 1
+    low = sp.csc_matrix((np.asarray(val, dtype=np.float64), np.asarray(rowidx), np.asarray(colptr)), shape=(n, n))
+    return (low + sp.tril(low, -1).T).tocsc()
+
+
+def cond_inf_estimate(colptr, rowidx, val):
+    """kappa_inf(K) = |K|_inf |K^-1|_inf for symmetric K (lower CSC): |K^-1|_1 by Hager/Higham's
+    estimator over a sparse LU of K (scipy) — independent of both implementations under test."""
+    import scipy.sparse.linalg as spla
+
+    K = sym_from_lower(colptr, rowidx, val)
+    lu = spla.splu(K)
+    inv = spla.LinearOperator(K.shape, matvec=lu.solve, rmatvec=lambda b: lu.solve(b, trans="T"), dtype=np.float64)
+    inv_norm = spla.onenormest(inv)  # symmetric: |.|_1 = |.|_inf
+    return float(abs(K).sum(axis=1).max()) * float(inv_norm)

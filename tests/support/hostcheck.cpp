@@ -130,6 +130,8 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (perm && perm_len > 0) up.assign(perm, perm + perm_len);
   LdltOptions lopt;
   if (task_entries > 0) lopt.task_entries = task_entries;
+  if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = env[0] != '0';
+  if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
   h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);
@@ -347,7 +349,24 @@ void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* 
         for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
           uint32_t e = t.ent_off + i;
           U[i] = acc_v[i - lvl[l]];
-          if (L.ent_flags[e] & 1) invd[L.ent_col[e]] = 1.0 / U[i];
+          if ((L.ent_flags[e] & 9) == 1) invd[L.ent_col[e]] = 1.0 / U[i];
+        }
+        // supernodes of two or more columns in this level: the dense trapezoid (LdltSn),
+        // eliminated column by column
+        std::vector<uint32_t> descs;
+        const uint32_t* snl = L.sn_lvl_ptr.data() + t.lvl_off;
+        for (uint32_t q = snl[l]; q < snl[l + 1]; ++q) descs.push_back(q);
+        for (uint32_t d : descs) {
+          const LdltSn& sn = L.sn_desc[t.sn_off + d];
+          auto off = [&](uint32_t c) { return sn.base0 + c * sn.nr - (c * (c - 1)) / 2; };
+          for (uint32_t c = 0; c < sn.w; ++c) {
+            const double inv = 1.0 / U[off(c)];
+            invd[sn.col0 + c] = inv;
+            for (uint32_t r = c + 1; r < sn.nr; ++r) {
+              const double lrc = U[off(c) + (r - c)] * inv;
+              for (uint32_t j = c + 1; j < sn.w && j <= r; ++j) U[off(j) + (r - j)] -= lrc * U[off(c) + (j - c)];
+            }
+          }
         }
       }
       for (uint32_t x = 0; x < t.n_ext; ++x) {
@@ -407,10 +426,17 @@ void hc_solve(hc_handle* h, double* p_out) {
           uint32_t pj = L.col_perm[t.col_off + i];
           double acc = h->rhs[L.perm[pj]];
           for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= h->scontrib[scidx[c]];
-          for (uint32_t q = fptr[i]; q < fptr[i + 1]; ++q) acc -= h->Lx[items[q].lpos] * y[items[q].ref];
+          const uint32_t pos = L.col_sn[t.col_off + i] & 0xffu;  // the last `pos` items: the row's own chain
+          for (uint32_t q = fptr[i]; q < fptr[i + 1] - pos; ++q) acc -= h->Lx[items[q].lpos] * y[items[q].ref];
           acc_v[i - lvl[l]] = acc;
         }
         for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) y[i] = acc_v[i - lvl[l]];
+        const uint32_t* snl = L.sn_lvl_ptr.data() + t.lvl_off;
+        for (uint32_t q = snl[l]; q < snl[l + 1]; ++q) {
+          const uint32_t i0 = L.sn_desc[t.sn_off + q].col0, w = L.sn_desc[t.sn_off + q].w;
+          for (uint32_t c = 1; c < w; ++c)
+            for (uint32_t k = 0; k < c; ++k) y[i0 + c] -= h->Lx[items[fptr[i0 + c + 1] - c + k].lpos] * y[i0 + k];
+        }
       }
       const uint32_t* sptr = L.sext_ptr.data() + t.sext_ptr_off;
       const LdltSolveItem* sitems = L.sext_items.data() + t.sext_item_off;
@@ -441,7 +467,8 @@ static void hc_backward(hc_handle* h, double* p_out) {
         for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) {
           uint32_t pj = L.col_perm[t.col_off + i];
           double acc = h->zv[pj];
-          for (uint32_t q = bptr[i]; q < bptr[i + 1]; ++q) {
+          const uint32_t cs = L.col_sn[t.col_off + i];  // the first w - pos - 1 items: the column's own chain
+          for (uint32_t q = bptr[i] + ((cs >> 8) - (cs & 0xffu) - 1u); q < bptr[i + 1]; ++q) {
             uint32_t ref = items[q].ref;
             double xi = (ref & 0x80000000u) ? h->xg[ref & 0x7fffffffu] : x[ref];
             acc -= h->Lx[items[q].lpos] * xi;
@@ -449,6 +476,12 @@ static void hc_backward(hc_handle* h, double* p_out) {
           acc_v[i - lvl[l]] = acc;
         }
         for (uint32_t i = lvl[l]; i < lvl[l + 1]; ++i) x[i] = acc_v[i - lvl[l]];
+        const uint32_t* snl = L.sn_lvl_ptr.data() + t.lvl_off;
+        for (uint32_t q = snl[l]; q < snl[l + 1]; ++q) {
+          const uint32_t i0 = L.sn_desc[t.sn_off + q].col0, w = L.sn_desc[t.sn_off + q].w;
+          for (int c = static_cast<int>(w) - 2; c >= 0; --c)
+            for (uint32_t k = c + 1; k < w; ++k) x[i0 + c] -= h->Lx[items[bptr[i0 + c] + (k - c - 1)].lpos] * x[i0 + k];
+        }
       }
       for (uint32_t i = 0; i < t.n_col; ++i) {
         uint32_t pj = L.col_perm[t.col_off + i];
@@ -525,4 +558,24 @@ extern "C" void hc_supernodes(hc_handle* h, int64_t* out) {
   out[2] = longest;
   out[3] = in4;
   out[4] = in16;
+}
+
+// Elimination tree and column counts of L (permuted space) for structure studies in tests.
+extern "C" void hc_ldlt_tree(hc_handle* h, int32_t* parent, int32_t* colcount) {
+  const LdltPlan& L = h->l;
+  for (int j = 0; j < L.n; ++j) {
+    parent[j] = L.parent[j];
+    colcount[j] = L.Lp[j + 1] - L.Lp[j];
+  }
+}
+
+// Supernodes of the plan: out[0] = count (singletons included), out[1] = widest, out[2] = levels on
+// the critical path, out[3 + w] = supernodes of width w for w < cap - 3.
+extern "C" void hc_supernode_plan(hc_handle* h, int64_t* out, int32_t cap) {
+  const LdltPlan& L = h->l;
+  for (int i = 0; i < cap; ++i) out[i] = 0;
+  out[0] = L.n_supernodes;
+  out[1] = L.widest_supernode;
+  out[2] = L.critical_levels;
+  for (size_t w = 0; w < L.sn_width_hist.size() && 3 + static_cast<int>(w) < cap; ++w) out[3 + w] = L.sn_width_hist[w];
 }

@@ -54,6 +54,8 @@ def lib():
     sig("hc_destroy", None, vp)
     sig("hc_tape_jit_compiles", i32, vp)
     sig("hc_supernodes", None, vp, vp)
+    sig("hc_ldlt_tree", None, vp, vp, vp)
+    sig("hc_supernode_plan", None, vp, vp, i32)
     sig("hc_info", None, vp, vp)
     sig("hc_pattern", i32, vp, ctypes.c_int, vp, vp)
     sig("hc_perm", None, vp, vp)
@@ -106,6 +108,21 @@ class HostCheck:
         out = np.zeros(5, dtype=np.int64)
         lib().hc_supernodes(self._h, out.ctypes.data)
         return dict(zip(("count", "widest", "longest_column", "cols_in_ge4", "cols_in_ge16"), (int(v) for v in out)))
+
+    def supernode_plan(self):
+        """Supernodes the numeric kernels work on (relaxed: equal structure, any number of children)."""
+        out = np.zeros(3 + 40, dtype=np.int64)
+        lib().hc_supernode_plan(self._h, out.ctypes.data, len(out))
+        return {"count": int(out[0]), "widest": int(out[1]), "critical_levels": int(out[2]),
+                "width_hist": {w: int(c) for w, c in enumerate(out[3:]) if c}}
+
+    def ldlt_tree(self):
+        """(parent, column count) of the elimination tree in the permuted space."""
+        dim = self.n + self.m_e
+        parent = np.zeros(dim, dtype=np.int32)
+        cc = np.zeros(dim, dtype=np.int32)
+        lib().hc_ldlt_tree(self._h, parent.ctypes.data, cc.ctypes.data)
+        return parent, cc
 
     def pattern(self, which):
         nnz = lib().hc_pattern(self._h, which, None, None)

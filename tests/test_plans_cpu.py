@@ -17,6 +17,71 @@ def test_plan_interpreter_matches_oracle(fresh, slpx, orc, hostcheck, kind, N, c
     parity.check_newton_step(hc, op, case)
 
 
+@pytest.mark.parametrize("env", [{"SLPX_SUPERNODAL": "0"}, {"SLPX_SN_MIN_WIDTH": "2"}, {"SLPX_SN_MIN_WIDTH": "3"}])
+@pytest.mark.parametrize("kind,N", [("cart_pole", 37), ("flywheel", 50)])
+def test_plan_interpreter_with_other_supernode_settings(fresh, slpx, orc, hostcheck, monkeypatch, env, kind, N):
+    """Column levels (no supernodes) and chains of every width from 2 / 3 up: the same step."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pp, op = cases.build_pair(kind, N, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    plan = hc.supernode_plan()
+    if env.get("SLPX_SUPERNODAL") == "0":
+        assert plan["widest"] == 1 and plan["count"] == hc.n + hc.m_e
+    else:
+        assert plan["widest"] >= 2 and min(w for w in plan["width_hist"] if w > 1) >= int(env["SLPX_SN_MIN_WIDTH"])
+    parity.check_newton_step(hc, op, "interior")
+
+
+def relaxed_chains(parent, cc):
+    """Maximal chains j -> parent(j) with |struct(L_j)| = |struct(L_parent)| + 1 (equal structure up
+    to the parent itself), any number of other children: what ldlt_symbolic.cpp amalgamates before
+    it cuts chains at kSnWidthMax columns.  Returns the list of (width, rows below the chain)."""
+    n = len(parent)
+    taken = [False] * n
+    out = []
+    for j in range(n):
+        if taken[j]:
+            continue
+        k, w = j, 1
+        taken[j] = True
+        while parent[k] >= 0 and cc[k] == cc[parent[k]] + 1 and not taken[parent[k]]:
+            k = parent[k]
+            taken[k] = True
+            w += 1
+        out.append((w, int(cc[k])))
+    return out
+
+
+def test_supernodal_levels(fresh, slpx, orc, hostcheck):
+    """relaxed supernodes (separator cliques and chains, whatever the number of
+    children) cut the levels on the critical path of the factorization from the etree height to
+    about a third; the width histogram is the measured basis of the MFMA decision:
+    cart-pole chains are at most 13 columns wide (one root chain), g-fold has panels of 16-26
+    columns over 8-20 rows."""
+    from tests.support import gfold, model
+
+    pp, _ = cases.build_pair("cart_pole", 1000, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    plan = hc.supernode_plan()
+    assert hc.info["etree_height"] == 50
+    assert plan["critical_levels"] <= 22
+    assert 4 <= plan["widest"] <= 8          # chains are cut at kSnWidthMax = 8 columns, shorter than 4 stay columns
+    chains = relaxed_chains(*hc.ldlt_tree())
+    widths = sorted(w for w, _ in chains)
+    assert widths[-1] == 13 and sum(1 for w in widths if w >= 12) == 1
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    g = gfold.build(mp, 100)
+    hg = hostcheck.HostCheck(g.p)
+    pg = hg.supernode_plan()
+    assert hg.info["etree_height"] >= 60 and pg["critical_levels"] <= 36
+    gch = relaxed_chains(*hg.ldlt_tree())
+    wide = sorted((w, r) for w, r in gch if w >= 12)
+    assert wide and wide[-1][0] >= 16        # dense panels an MFMA tile could bite on exist here
+    print("cart-pole N=1000 plan:", plan, " g-fold N=100 plan:", pg, " g-fold chains >= 12 columns (w, rows below):", wide)
+
+
 def test_small_tasks_force_many_rounds(fresh, slpx, orc, hostcheck):
     """Tiny LDS budgets: many tape tasks, many LDLᵀ rounds, lots of cross-task
     contribution slots — results must not change."""

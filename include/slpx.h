@@ -114,13 +114,18 @@ typedef struct slpx_report {
  * with CALLBACK_REQUESTED_STOP (exit_status.hpp:17).  The pointers are valid during the call. */
 typedef struct slpx_iteration_info {
   int32_t iteration;
-  int32_t n, m_e, m_i;
+  int32_t n, m_e, m_i; /* sizes of the arrays below */
   const double* x; /* n */
   const double* s; /* m_i */
   const double* y; /* m_e */
   const double* z; /* m_i */
   const double* V;
   int64_t off[8]; /* f, c_e, c_i, g, A_e, A_i, H_f, H_c */
+  /* 1 inside feasibility restoration (feasibility_restoration.hpp:347-628): the arrays are then
+   * the RESTORATION model's — n + 2 m_e + 2 m_i variables [x | p_e | n_e | p_i | n_i] and
+   * m_i + 2 m_e + 2 m_i inequality rows, the user's x and s first — and n, m_e, m_i, off[] and V
+   * describe that model (the reference calls the user's callbacks there too, :852) */
+  int32_t in_restoration;
 } slpx_iteration_info;
 typedef int (*slpx_iteration_callback)(const slpx_iteration_info* info, void* user);
 int slpx_problem_add_callback(slpx_problem* p, slpx_iteration_callback callback, void* user);
@@ -133,6 +138,14 @@ slpx_system* slpx_problem_system(slpx_problem* p);
  * 0 success, 1 callback stop, -1..-10 as in the reference; -100 on library error. */
 int slpx_problem_solve(slpx_problem* p, const slpx_options* opt, slpx_report* report);
 void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double* z);
+/* feasibility_restoration (solver/util/feasibility_restoration.hpp:347-628) on its own: from the
+ * iterate (x[n], s[m_i], y[m_e], z[m_i], mu) — all in/out but mu — build the restoration model,
+ * run `steps` iterations of its interior-point loop, leave it the way the reference does when its
+ * acceptance callback fires (:729-752), and replace y, z by the least-squares multiplier estimate
+ * (lagrange_multiplier_estimate.hpp:56-133).  Scaling as in slpx_problem_solve (at the variables'
+ * current values).  Returns the ExitStatus of that function (0: restored), -100 on library error. */
+int slpx_problem_restoration_steps(slpx_problem* p, const slpx_options* opt, double* x, double* s, double* y,
+                                   double* z, double mu, int32_t steps);
 
 /* The reference's benchmark models, built with the C++ slp:: surface:
  * benchmarks/scalability/cart_pole/sleipnir.cpp:76-129, .../flywheel/sleipnir.cpp:12-42 */

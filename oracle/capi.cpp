@@ -2,7 +2,9 @@
 //
 // C-ABI over the oracle so tests/ (ctypes) and bench.py's cpu_baseline leg can
 // drive it.  Nothing here is part of the product.
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -240,6 +242,70 @@ int orc_problem_solve(int p, double tolerance, int max_iterations, double timeou
     stats_out[7] = st.t_linesearch;
     stats_out[8] = st.t_total;
   }
+  return static_cast<int>(e);
+}
+
+// Problem::solve with a record per iteration (taken where the reference calls the user's
+// iteration callbacks, interior_point.hpp:411-424; inside feasibility restoration the iterate is
+// the restoration model's, its first n / m_i entries the outer x / s):
+// out[r] = {iteration, len(x), |x[0:n]|_2, |s[0:m_i]|_2, |y|_2, |z|_2}
+int orc_problem_solve_trace(int p, double tolerance, int max_iterations, const int* perm, int perm_len,
+                            int max_records, double* out, int* n_records) {
+  Options opt;
+  opt.tolerance = tolerance;
+  opt.max_iterations = max_iterations;
+  std::vector<int> up;
+  if (perm && perm_len > 0) up.assign(perm, perm + perm_len);
+  auto& prob = g_problems[p]->problem;
+  prob.ensure_setup();
+  const int n = prob.evaluators()->callbacks.num_decision_variables;
+  const int m_i = prob.evaluators()->callbacks.num_inequality_constraints;
+  int count = 0;
+  auto norm = [](const Vec& v, size_t len) {
+    double a = 0.0;
+    for (size_t i = 0; i < std::min(len, v.size()); ++i) a += v[i] * v[i];
+    return std::sqrt(a);
+  };
+  prob.add_callback([&](const IterationInfo& it) {
+    if (count < max_records) {
+      double* r = out + 6 * count;
+      r[0] = it.iteration;
+      r[1] = static_cast<double>(it.x.size());
+      r[2] = norm(it.x, n);
+      r[3] = norm(it.s, m_i);
+      r[4] = norm(it.y, it.y.size());
+      r[5] = norm(it.z, it.z.size());
+    }
+    ++count;
+    return false;
+  });
+  SolveStats st;
+  ExitStatus e = prob.solve(opt, &st, up.empty() ? nullptr : &up);
+  prob.clear_callbacks();
+  if (n_records) *n_records = std::min(count, max_records);
+  return static_cast<int>(e);
+}
+
+// feasibility_restoration (feasibility_restoration.hpp:347-628) from a caller-given iterate: `steps`
+// iterations of the restoration problem's interior-point loop, left through the callback exit
+// (:729-752), multipliers re-estimated (lagrange_multiplier_estimate.hpp:56-133).  x, s, y, z in/out.
+int orc_problem_restoration_steps(int p, double tolerance, int max_iterations, double* x, double* s,
+                                  double* y, double* z, double mu, int steps) {
+  auto& prob = g_problems[p]->problem;
+  prob.ensure_setup();
+  auto& cb = prob.evaluators()->callbacks;
+  const int n = cb.num_decision_variables, m_e = cb.num_equality_constraints, m_i = cb.num_inequality_constraints;
+  Options opt;
+  opt.tolerance = tolerance;
+  opt.max_iterations = max_iterations;
+  Vec vx(x, x + n), vs(s, s + m_i), vy(y, y + m_e), vz(z, z + m_i);
+  int iterations = 0;
+  std::vector<IterationCallback> stop{[steps](const IterationInfo& it) { return it.iteration >= steps; }};
+  const ExitStatus e = feasibility_restoration(cb, stop, opt, vx, vs, vy, vz, mu, iterations, nullptr);
+  std::copy(vx.begin(), vx.end(), x);
+  std::copy(vs.begin(), vs.end(), s);
+  std::copy(vy.begin(), vy.end(), y);
+  std::copy(vz.begin(), vz.end(), z);
   return static_cast<int>(e);
 }
 

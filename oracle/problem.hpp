@@ -56,6 +56,7 @@ class Problem {
   }
 
   void add_callback(IterationCallback cb) { m_iteration_callbacks.push_back(std::move(cb)); }
+  void clear_callbacks() { m_iteration_callbacks.clear(); }  // problem.hpp:712
 
   // Everything Problem::solve builds before calling interior_point (problem.hpp:517-660)
   struct Evaluators {

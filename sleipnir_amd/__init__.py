@@ -116,6 +116,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_problem_set_x", None, vp, vp)
     sig("slpx_problem_solve", ctypes.c_int, vp, ctypes.POINTER(Options), ctypes.POINTER(Report))
     sig("slpx_problem_get_duals", None, vp, vp, vp, vp)
+    sig("slpx_problem_restoration_steps", ctypes.c_int, vp, ctypes.POINTER(Options), vp, vp, vp, vp, f64, i32)
     sig("slpx_problem_cart_pole", vp, i32, f64)
     sig("slpx_problem_flywheel", vp, i32, f64)
     sig("slpx_system_create", vp, vp, i32, i32, vp, i32)
@@ -176,7 +177,7 @@ def _check(rc):
 class IterationInfo(ctypes.Structure):
     _fields_ = [("iteration", ctypes.c_int32), ("n", ctypes.c_int32), ("m_e", ctypes.c_int32),
                 ("m_i", ctypes.c_int32)] + [(k, ctypes.POINTER(ctypes.c_double)) for k in "xsyzV"] + [
-                    ("off", ctypes.c_int64 * 8)]
+                    ("off", ctypes.c_int64 * 8), ("in_restoration", ctypes.c_int32)]
 
 
 IterationCallback = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(IterationInfo), ctypes.c_void_p)
@@ -247,6 +248,16 @@ class Problem:
             raise SlpxError(lib().slpx_last_error().decode())
         return status, {f[0]: getattr(rep, f[0]) for f in Report._fields_}
 
+    def restoration_steps(self, x, s, y, z, mu, steps, tolerance=1e-8, max_iterations=5000):
+        """feasibility_restoration from the given iterate, `steps` iterations (slpx_problem_restoration_steps)."""
+        x, s, y, z = (np.array(a, dtype=np.float64, copy=True) for a in (x, s, y, z))
+        opt = Options(tolerance, max_iterations, 0.0, 0, 0)
+        status = lib().slpx_problem_restoration_steps(self._h, ctypes.byref(opt), x.ctypes.data, s.ctypes.data,
+                                                      y.ctypes.data, z.ctypes.data, float(mu), int(steps))
+        if status == -100:
+            raise SlpxError(lib().slpx_last_error().decode())
+        return status, x, s, y, z
+
     def add_callback(self, fn):
         """Problem::add_callback (problem.hpp:690-709): fn(info: dict) -> truthy to stop."""
 
@@ -256,7 +267,7 @@ class Problem:
             off = list(i.off)
             return int(bool(fn({"iteration": i.iteration, "x": view(i.x, i.n), "s": view(i.s, i.m_i),
                                 "y": view(i.y, i.m_e), "z": view(i.z, i.m_i), "f": i.V[off[0]], "off": off,
-                                "V": i.V})))
+                                "V": i.V, "in_restoration": bool(i.in_restoration)})))
 
         cb = IterationCallback(trampoline)
         self._callbacks = getattr(self, "_callbacks", []) + [cb]  # keep the thunks alive

@@ -30,7 +30,7 @@ int guard(F&& f) {
 
 extern "C" {
 
-int slpx_abi_version(void) { return 1; }
+int slpx_abi_version(void) { return 2; }
 const char* slpx_last_error(void) { return g_error.c_str(); }
 int slpx_device_count(void) {
   int count = 0;
@@ -118,12 +118,35 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
   return rc == 0 ? status : rc;
 }
 
+int slpx_problem_restoration_steps(slpx_problem* p, const slpx_options* o, double* x, double* sv, double* y,
+                                   double* z, double mu, int32_t steps) {
+  int status = -100;
+  const int rc = guard([&] {
+    slp::Options opt;
+    if (o) {
+      opt.tolerance = o->tolerance;
+      opt.max_iterations = o->max_iterations;
+      if (o->timeout > 0) opt.timeout = o->timeout;
+    }
+    const size_t n = p->problem.decision_variables().size(), me = p->problem.equality_constraints().size(),
+                 mi = p->problem.inequality_constraints().size();
+    std::vector<double> vx(x, x + n), vs(sv, sv + mi), vy(y, y + me), vz(z, z + mi);
+    status = static_cast<int>(p->problem.restoration_steps(opt, vx, vs, vy, vz, mu, steps));
+    std::copy(vx.begin(), vx.end(), x);
+    std::copy(vs.begin(), vs.end(), sv);
+    std::copy(vy.begin(), vy.end(), y);
+    std::copy(vz.begin(), vz.end(), z);
+  });
+  return rc == 0 ? status : rc;
+}
+
 int slpx_problem_add_callback(slpx_problem* p, slpx_iteration_callback callback, void* user) {
   return guard([&] {
     if (!callback) throw std::runtime_error("slpx_problem_add_callback: null callback");
     p->problem.add_callback([p, callback, user](const slp::IterationInfo& it) -> bool {
-      const auto& st = p->problem.compile().structure();
+      const auto& st = it.structure ? *it.structure : p->problem.compile().structure();
       slpx_iteration_info info{};
+      info.in_restoration = it.in_restoration ? 1 : 0;
       info.iteration = it.iteration;
       info.n = st.n;
       info.m_e = st.m_e;

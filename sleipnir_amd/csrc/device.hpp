@@ -228,6 +228,7 @@ class DeviceNlp {
                          const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
+  void refine_solution(int iters);                  // iterative refinement of the last solve() against the lhs
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
   void backsub_publish();
@@ -307,6 +308,8 @@ class DeviceNlp {
       m_sext_dst, m_bwd_ptr;
   DevBuf<LdltPair> m_pairs;
   DevBuf<LdltSn> m_sn_desc;
+  DevBuf<int32_t> m_lhs_colptr, m_lhs_rowidx;  // refine_solution (uploaded on first use)
+  DevBuf<double> m_rhs0, m_p_acc;
   DevBuf<uint32_t> m_sn_lvl_ptr, m_col_sn, m_lvl_pack, m_col_lvl_pack;
   DevBuf<uint2> m_bwd_range;
   DevBuf<LdltSolveItem> m_fwd_items, m_sext_items, m_bwd_items;

@@ -318,7 +318,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
       return finish(ExitStatus::DIVERGING_ITERATES);
 
     for (const auto& cb : callbacks)
-      if (cb({iterations, x, s, y, z, V})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+      if (cb({iterations, x, s, y, z, V, &st, in_feasibility_restoration})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
 
     // ---- Newton step on the device (:426-482) ----
     auto t0 = clk::now();
@@ -688,7 +688,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       pull_state();
       pull_V();
       for (const auto& cb : callbacks)
-        if (cb({iterations, x, s, y, z, V})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+        if (cb({iterations, x, s, y, z, V, &st, in_feasibility_restoration})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
       push_state();  // a callback may have used this system's device buffers (restoration does)
     }
 
@@ -824,6 +824,10 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         Vec Vt(st.nV);
         dev.download_V(Vt.data());
         push_state();
+        // the device V must describe x again (feasibility_restoration.hpp:393-394 evaluates at
+        // the current iterate): the restoration entry below, and the next step if the fallback
+        // accepts, read it
+        dev.sweep_full();
         VView tv{st, Vt};
         const double next_kkt = kkt_error_impl<ErrType::ONE_NORM>(st, tv.g_dense(), tv.Ae(), tv.c_e(), tv.Ai(),
                                                                   tv.c_i(), trial_s, trial_y, trial_z, mu,
@@ -1025,15 +1029,33 @@ bool lagrange_multiplier_estimate(NewtonSystem& sys, const Vec& V, const Vec& s,
   dev.assemble_lsq();
   SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs.data(), dim * sizeof(double), hipMemcpyHostToDevice,
                                 dev.stream()));
-  // a separate solver object in the reference: keep the outer regularization history
-  const auto saved = sys.regularization_state();
-  sys.reset_regularization();
-  const auto info = sys.compute();
-  rep.factorizations += sys.last_factorizations();
-  sys.set_regularization_state(saved);
-  if (info[0] != FactorInfo::Success) return false;
+  // The reference factors this system without any regularization (a SimplicialLDLT of its own,
+  // :107): the top-left block I + A_i^T S^-2 A_i is positive definite, so delta = gamma = 0 is
+  // tried first whatever the KKT pattern's structural zeros say — starting the usual loop at
+  // delta = 1e-4 instead perturbed the estimate by 1e-4 relative (tests/test_restoration_gpu.py).
+  // Only a rank-deficient A_e falls back to the regularizing loop, with its own history.
+  // Only when that breaks down (a constraint row the elimination order could not pair with a
+  // variable is a zero pivot without gamma; a rank-deficient A_e) the regularizing loop runs,
+  // with its own history — and three steps of iterative refinement against the unregularized
+  // matrix take its delta, gamma out of the answer again.
+  bool regularized = false;
+  if (sys.factor_unregularized()) {
+    ++rep.factorizations;
+  } else {
+    const auto saved = sys.regularization_state();
+    sys.reset_regularization();
+    const auto info = sys.compute();
+    rep.factorizations += 1 + sys.last_factorizations();
+    sys.set_regularization_state(saved);
+    if (info[0] != FactorInfo::Success) return false;
+    regularized = true;
+  }
   dev.solve();
   ++rep.solves;
+  if (regularized) {
+    dev.refine_solution(3);
+    rep.solves += 3;
+  }
   Vec p(dim);
   dev.download(dev.d_p(), p.data(), dim);
   y.assign(m_e, 0.0);
@@ -1133,6 +1155,31 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
 }
 
 }  // namespace
+
+ExitStatus feasibility_restoration_steps(NewtonSystem& sys, const std::vector<double>& scales,
+                                         const Options& options, std::vector<double>& x,
+                                         std::vector<double>& s, std::vector<double>& y,
+                                         std::vector<double>& z, double mu, int steps,
+                                         SolveReport* report) {
+  const NlpStructure& st = sys.structure();
+  SolveReport local;
+  SolveReport& rep = report ? *report : local;
+  rep = SolveReport{};
+  // c_e, c_i at x (the caller of feasibility_restoration holds them, interior_point.hpp:721-727)
+  DeviceNlp& dev = sys.device();
+  Vec V(st.nV);
+  dev.upload_x(x.data());
+  dev.upload_duals(s.data(), y.data(), z.data());
+  dev.sweep_full();
+  dev.download_V(V.data());
+  const Vec c_e(V.begin() + st.off_ce, V.begin() + st.off_ce + st.m_e);
+  const Vec c_i(V.begin() + st.off_ci, V.begin() + st.off_ci + st.m_i);
+  int iterations = 0;
+  const std::vector<IterationCallback> stop{
+      [steps](const IterationInfo& info) { return info.iteration >= steps; }};
+  return feasibility_restoration(sys, scales, stop, options, x, s, y, z, mu, iterations, rep, clk::now(), c_e,
+                                 c_i);
+}
 
 ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
                           const std::vector<IterationCallback>& callbacks, const Options& options,

@@ -16,6 +16,7 @@
 // that ends it is one more factorization on the outer system's KKT pattern.
 #pragma once
 
+
 #include <functional>
 #include <limits>
 #include <vector>
@@ -57,6 +58,11 @@ struct IterationInfo {
   const std::vector<double>& y;
   const std::vector<double>& z;
   const std::vector<double>& V;  // [f | c_e | c_i | g | A_e | A_i | H_f | H_c], see nlp.hpp
+  // The system these arrays belong to: inside feasibility restoration that is the restoration
+  // model (n + 2 m_e + 2 m_i variables, m_i + 2 m_e + 2 m_i inequality rows; the outer
+  // problem's x, s come first), not the user's problem.
+  const NlpStructure* structure = nullptr;
+  bool in_restoration = false;
 };
 using IterationCallback = std::function<bool(const IterationInfo&)>;
 
@@ -79,6 +85,17 @@ struct SolveReport {
 
 // Scaling at x0 (util/problem_scaling.hpp:100-107) from an unscaled V.
 std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::vector<double>& V_raw);
+
+// feasibility_restoration (util/feasibility_restoration.hpp:347-628) on its own, from a given
+// iterate: builds the restoration model around (x, s), runs `steps` iterations of its
+// interior-point loop (a callback then stops it, the reference's own way out, :729-752) and, as
+// after any accepted restoration, replaces y, z by the least-squares multiplier estimate
+// (lagrange_multiplier_estimate.hpp:56-133).  `scales` must be installed on the device.
+ExitStatus feasibility_restoration_steps(NewtonSystem& sys, const std::vector<double>& scales,
+                                         const Options& options, std::vector<double>& x,
+                                         std::vector<double>& s, std::vector<double>& y,
+                                         std::vector<double>& z, double mu, int steps,
+                                         SolveReport* report = nullptr);
 
 // x in/out.  `scales` = [d_f, d_ce.., d_ci..] already installed on the device.
 ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,

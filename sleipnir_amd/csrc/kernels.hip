@@ -303,6 +303,35 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
   }
 }
 
+// Iterative refinement of a solve (used where the regularization would otherwise show in the
+// answer: the least-squares multiplier estimate): r = b - K p for the UNREGULARIZED symmetric K
+// given by its lower CSC values in `lhs`; one thread per column, the mirrored half by fp64
+// atomics (the system has a few thousand columns: latency, not bandwidth).
+__global__ __launch_bounds__(256) void sym_residual_kernel(int dim, const int32_t* __restrict__ colptr,
+                                                           const int32_t* __restrict__ rowidx,
+                                                           const double* __restrict__ lhs,
+                                                           const double* __restrict__ p,
+                                                           double* __restrict__ res) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim; c += gridDim.x * blockDim.x) {
+    const double pc = p[c];
+    double acc = 0.0;
+    for (int q = colptr[c]; q < colptr[c + 1]; ++q) {
+      const int r = rowidx[q];
+      const double v = lhs[q];
+      if (r == c) {
+        acc += v * pc;
+      } else {
+        acc += v * p[r];                   // K(c, r) p_r
+        atomicAdd(&res[r], -(v * pc));     // K(r, c) p_c
+      }
+    }
+    atomicAdd(&res[c], -acc);
+  }
+}
+__global__ __launch_bounds__(256) void axpy_kernel(int count, const double* __restrict__ x, double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) y[i] += x[i];
+}
+
 // Separable sums on their own (tape_reduce_body, tape_kernels.h) — used when the reductions
 // cannot ride along with the interpreted tail of the tape (launch_tape).
 __global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::SumReduce* __restrict__ red,
@@ -1167,6 +1196,32 @@ bool DeviceNlp::interleaved_for(int batch) {
   int min_batch = 192;
   if (const char* env = std::getenv("SLPX_IL_MIN_BATCH")) min_batch = std::atoi(env);
   return batch >= min_batch;
+}
+
+// p <- p + K_reg^-1 (b - K p), `iters` times: b = the right-hand side now in m_rhs, p = the
+// solution of the last solve(), K = the unregularized matrix in m_lhs, K_reg = what was factored.
+// Converges like (regularization / smallest eigenvalue)^iters.  Single problem.
+void DeviceNlp::refine_solution(int iters) {
+  if (m_batch != 1) throw std::runtime_error("slpx: refine_solution handles one problem");
+  const int dim = m_kdev.dim;
+  if (m_lhs_colptr.n == 0) {
+    m_lhs_colptr.upload(m_k_ref.lhs.colptr);
+    m_lhs_rowidx.upload(m_k_ref.lhs.rowidx);
+    m_rhs0.alloc(dim);
+    m_p_acc.alloc(dim);
+  }
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_rhs0.p, m_rhs.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_p_acc.p, m_p.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  for (int it = 0; it < iters; ++it) {
+    SLPX_HIP_CHECK(hipMemcpyAsync(m_rhs.p, m_rhs0.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+    hipLaunchKernelGGL(sym_residual_kernel, dim3(grid_for(dim, 256)), dim3(256), 0, m_stream, dim, m_lhs_colptr.p,
+                       m_lhs_rowidx.p, m_lhs.p, m_p_acc.p, m_rhs.p);
+    solve();  // m_rhs -> m_p
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(dim, 256)), dim3(256), 0, m_stream, dim, m_p.p, m_p_acc.p);
+  }
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_p.p, m_p_acc.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_rhs.p, m_rhs0.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
+  SLPX_HIP_CHECK(hipGetLastError());
 }
 
 void DeviceNlp::backsub() { backsub_and_publish(nullptr); }

@@ -263,6 +263,20 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   return info;
 }
 
+bool NewtonSystem::factor_unregularized() {
+  const int B = m_opt.batch;
+  std::vector<double> zero(B, 0.0);
+  std::vector<uint8_t> active(B, 1);
+  m_dev->factor(zero, zero, active);
+  std::vector<LdltStats> stats;
+  m_dev->read_stats(stats);
+  ++m_last_factorizations;
+  for (int b = 0; b < B; ++b)
+    if (stats[b].n_bad != 0 || stats[b].n_pos != m_s.n || stats[b].n_neg != m_s.m_e || stats[b].n_zero != 0)
+      return false;
+  return true;
+}
+
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
   if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);

@@ -87,6 +87,12 @@ class NewtonSystem {
   // solve_speculatively: also run solve() + backsub() after every attempt (see newton.cpp).
   std::vector<FactorInfo> compute(bool solve_speculatively = false);
   std::vector<FactorInfo> compute_impl(int mode, bool refresh_ad);
+  // One factorization of the lhs in device memory with delta = gamma = 0, accepted whenever it
+  // has no zero / non-finite pivot and the ideal inertia — no |D| threshold, no regularization
+  // memory touched.  For systems that are not KKT systems of the barrier problem: the
+  // least-squares multiplier estimate, which the reference factors unregularized
+  // (lagrange_multiplier_estimate.hpp:107).  Single problem.
+  bool factor_unregularized();
   const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
   const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
   int last_factorizations() const { return m_last_factorizations; }

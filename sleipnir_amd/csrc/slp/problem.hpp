@@ -131,6 +131,29 @@ class Problem {
     return status;
   }
 
+  // feasibility_restoration (util/feasibility_restoration.hpp:347-628) from a caller-given
+  // iterate, `steps` iterations of it, with the scaling solve() would use (at the variables'
+  // current values): the seam the restoration parity tests compare with the oracle at.
+  ExitStatus restoration_steps(const Options& options, std::vector<double>& x, std::vector<double>& s,
+                               std::vector<double>& y, std::vector<double>& z, double mu, int steps) {
+    auto& g = detail::G();
+    compile();
+    std::vector<double> x0(m_decision_variables.size());
+    for (size_t i = 0; i < x0.size(); ++i) x0[i] = g.val[m_decision_variables[i].expr];
+    std::vector<double> V(m_sys->structure().nV);
+    auto& dev = m_sys->device();
+    dev.set_scaling(std::vector<double>(m_sys->structure().n_scales(), 1.0));
+    std::vector<double> zeros_e(std::max<size_t>(1, m_equality_constraints.size()), 0.0);
+    std::vector<double> ones_i(std::max<size_t>(1, m_inequality_constraints.size()), 1.0);
+    dev.upload_x(x0.data());
+    dev.upload_duals(ones_i.data(), zeros_e.data(), ones_i.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+    m_scales = slpx::compute_problem_scaling(m_sys->structure(), V);
+    dev.set_scaling(m_scales);
+    return slpx::feasibility_restoration_steps(*m_sys, m_scales, options, x, s, y, z, mu, steps, &m_report);
+  }
+
   // Compiles (once) the NLP for the device; exposed so harnesses can time setup
   // separately and drive the Newton step directly.
   slpx::NewtonSystem& compile(const slpx::NewtonOptions& opt = {}) {

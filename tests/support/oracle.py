@@ -75,6 +75,8 @@ def lib():
     sig("orc_problem_set_x", None, i, vp)
     sig("orc_problem_get_duals", None, i, vp, vp, vp)
     sig("orc_problem_solve", i, i, d, i, d, vp, i, vp)
+    sig("orc_problem_solve_trace", i, i, d, i, vp, i, i, vp, vp)
+    sig("orc_problem_restoration_steps", i, i, d, i, vp, vp, vp, vp, d, i)
     sig("orc_build_cart_pole", i, i, d)
     sig("orc_build_flywheel", i, i, d)
     sig("orc_problem_scaling", None, i, vp, vp, vp)
@@ -162,6 +164,24 @@ class OracleProblem:
         keys = ["iterations", "factorizations", "solves", "t_ad", "t_build", "t_decomp", "t_solve",
                 "t_linesearch", "t_total"]
         return status, dict(zip(keys, stats))
+
+    def solve_trace(self, tolerance=1e-8, max_iterations=5000, perm=None, max_records=6000):
+        """solve() recording, per iteration, [iteration, len(x), |x|_2, |s|_2, |y|_2, |z|_2] (x, s:
+        the outer problem's part of the iterate, also inside feasibility restoration)."""
+        out = np.zeros((max_records, 6))
+        nrec = ctypes.c_int()
+        p = None if perm is None else _ia(perm)
+        status = lib().orc_problem_solve_trace(self.pid, tolerance, max_iterations,
+                                               None if p is None else p.ctypes.data, 0 if p is None else len(p),
+                                               max_records, out.ctypes.data, ctypes.addressof(nrec))
+        return status, out[:nrec.value]
+
+    def restoration_steps(self, x, s, y, z, mu, steps, tolerance=1e-8, max_iterations=5000):
+        """feasibility_restoration from the given iterate, `steps` iterations (oracle/ipm.hpp)."""
+        x, s, y, z = (np.array(a, dtype=np.float64, copy=True) for a in (x, s, y, z))
+        status = lib().orc_problem_restoration_steps(self.pid, tolerance, max_iterations, x.ctypes.data,
+                                                     s.ctypes.data, y.ctypes.data, z.ctypes.data, float(mu), int(steps))
+        return status, x, s, y, z
 
     def newton_step(self, x, s, y, z, mu, do_solve=True, perm=None, reuse_solver=False):
         x, s, y, z = _fa(x), _fa(s), _fa(y), _fa(z)

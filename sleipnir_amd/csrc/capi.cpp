@@ -62,17 +62,17 @@ slpx_problem* slpx_problem_create(void) { return new slpx_problem(); }
 void slpx_problem_destroy(slpx_problem* p) { delete p; }
 int32_t slpx_problem_decision_variable(slpx_problem* p) { return p->problem.decision_variable().expr; }
 void slpx_problem_adopt_variable(slpx_problem* p, int32_t var) {
-  p->problem.adopt_decision_variable(slp::Variable::wrap(var));
+  p->problem.adopt_decision_variable(slp::Variable<double>::wrap(var));
 }
-void slpx_problem_minimize(slpx_problem* p, int32_t cost) { p->problem.minimize(slp::Variable::wrap(cost)); }
+void slpx_problem_minimize(slpx_problem* p, int32_t cost) { p->problem.minimize(slp::Variable<double>::wrap(cost)); }
 void slpx_problem_maximize(slpx_problem* p, int32_t objective) {
-  p->problem.maximize(slp::Variable::wrap(objective));
+  p->problem.maximize(slp::Variable<double>::wrap(objective));
 }
 void slpx_problem_subject_to_eq(slpx_problem* p, int32_t c) {
-  p->problem.subject_to(slp::EqualityConstraints{std::vector<slp::Variable>{slp::Variable::wrap(c)}});
+  p->problem.subject_to(slp::EqualityConstraints<double>{std::vector<slp::VariableF64>{slp::Variable<double>::wrap(c)}});
 }
 void slpx_problem_subject_to_ineq(slpx_problem* p, int32_t c) {
-  p->problem.subject_to(slp::InequalityConstraints{std::vector<slp::Variable>{slp::Variable::wrap(c)}});
+  p->problem.subject_to(slp::InequalityConstraints<double>{std::vector<slp::VariableF64>{slp::Variable<double>::wrap(c)}});
 }
 int slpx_problem_cost_type(const slpx_problem* p) { return static_cast<int>(p->problem.cost_function_type()); }
 int slpx_problem_eq_type(const slpx_problem* p) { return static_cast<int>(p->problem.equality_constraint_type()); }
@@ -168,6 +168,7 @@ int slpx_problem_clear_callbacks(slpx_problem* p) {
 slpx_system* slpx_problem_system(slpx_problem* p) {
   const int rc = guard([&] {
     if (!p->borrowed) p->borrowed = std::make_unique<slpx_system>();
+    p->borrowed->owner = &p->problem;
     p->borrowed->ref = &p->problem.compile();
   });
   return rc == 0 ? p->borrowed.get() : nullptr;
@@ -200,6 +201,7 @@ slpx_system* slpx_system_create(slpx_problem* p, int32_t batch, int32_t device, 
                                 int32_t perm_len) {
   auto* s = new slpx_system();
   int rc = guard([&] {
+    if (batch < 1) throw std::runtime_error("slpx_system_create: batch must be at least 1");
     slpx::NewtonOptions opt;
     opt.batch = batch;
     opt.device = device;
@@ -517,6 +519,7 @@ slpx_system* slpx_ldlt_create(int32_t n, int32_t m_e, const int32_t* colptr, con
     lower.rows = lower.cols = n + m_e;
     lower.colptr.assign(colptr, colptr + n + m_e + 1);
     lower.rowidx.assign(rowidx, rowidx + colptr[n + m_e]);
+    if (batch < 1) throw std::runtime_error("slpx_ldlt_create: batch must be at least 1");
     slpx::NewtonOptions opt;
     opt.batch = batch;
     opt.device = device;

@@ -3,29 +3,35 @@
 //   benchmarks/scalability/cart_pole/sleipnir.cpp:16-129
 //   benchmarks/scalability/flywheel/sleipnir.cpp:12-42
 //   benchmarks/rk4.hpp:14-23
-// Eigen::Matrix constants become slp::DenseMatrix (Eigen is not in this toolchain).
+// Same spellings as there (slp::Problem<double>, slp::VariableMatrix<double>, rk4<...>); the only
+// substitution is Eigen::Matrix / Eigen::Vector constants -> slp::DenseMatrix (Eigen is not in
+// this toolchain).  tests/test_slp_surface.py compiles the same text as a user program.
 #include "problems.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <numbers>
 
 namespace slpx_models {
 
 using slp::DenseMatrix;
-using slp::VariableMatrix;
 
 // benchmarks/rk4.hpp:14-23
-template <typename F>
-VariableMatrix rk4(F&& f, VariableMatrix x, VariableMatrix u, double h) {
-  VariableMatrix k1 = f(x, u);
-  VariableMatrix k2 = f(x + h * 0.5 * k1, u);
-  VariableMatrix k3 = f(x + h * 0.5 * k2, u);
-  VariableMatrix k4 = f(x + h * k3, u);
+template <typename F, typename T, typename U>
+T rk4(F&& f, T x, U u, std::chrono::duration<double> dt) {
+  const auto h = dt.count();
+
+  T k1 = f(x, u);
+  T k2 = f(x + h * 0.5 * k1, u);
+  T k3 = f(x + h * 0.5 * k2, u);
+  T k4 = f(x + h * k3, u);
+
   return x + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
 }
 
 // cart_pole/sleipnir.cpp:16-74
-VariableMatrix cart_pole_dynamics(const VariableMatrix& x, const VariableMatrix& u) {
+slp::VariableMatrix<double> cart_pole_dynamics(const slp::VariableMatrix<double>& x,
+                                               const slp::VariableMatrix<double>& u) {
   constexpr double m_c = 5.0;  // Cart mass (kg)
   constexpr double m_p = 0.5;  // Pole mass (kg)
   constexpr double l = 0.5;    // Pole length (m)
@@ -36,20 +42,22 @@ VariableMatrix cart_pole_dynamics(const VariableMatrix& x, const VariableMatrix&
   auto theta = q[1];
   auto thetadot = qdot[1];
 
-  VariableMatrix M{{m_c + m_p, m_p * l * cos(theta)}, {m_p * l * cos(theta), m_p * std::pow(l, 2)}};
-  VariableMatrix C{{0, -m_p * l * thetadot * sin(theta)}, {0, 0}};
-  VariableMatrix tau_g{{0}, {-m_p * g * l * sin(theta)}};
+  slp::VariableMatrix<double> M{{m_c + m_p, m_p * l * cos(theta)},
+                                {m_p * l * cos(theta), m_p * std::pow(l, 2)}};
+  slp::VariableMatrix<double> C{{0, -m_p * l * thetadot * sin(theta)}, {0, 0}};
+  slp::VariableMatrix<double> tau_g{{0}, {-m_p * g * l * sin(theta)}};
   DenseMatrix B{{1}, {0}};
 
-  VariableMatrix qddot{4, 1};
+  slp::VariableMatrix<double> qddot{4, 1};
   qddot.segment(0, 2) = qdot;
   qddot.segment(2, 2) = solve(M, tau_g - C * qdot + B * u);
   return qddot;
 }
 
 // cart_pole/sleipnir.cpp:76-129
-void build_cart_pole(slp::Problem& problem, double dt, int N, VariableMatrix* X_out,
-                     VariableMatrix* U_out) {
+void build_cart_pole(slp::Problem<double>& problem, double dt_seconds, int N, slp::VariableMatrix<double>* X_out,
+                     slp::VariableMatrix<double>* U_out) {
+  const std::chrono::duration<double> dt{dt_seconds};
   constexpr double u_max = 20.0;  // N
   constexpr double d_max = 2.0;   // m
   const DenseMatrix x_initial = DenseMatrix::vector({0.0, 0.0, 0.0, 0.0});
@@ -68,7 +76,9 @@ void build_cart_pole(slp::Problem& problem, double dt, int N, VariableMatrix* X_
   problem.subject_to(slp::bounds(-u_max, U, u_max));
 
   for (int k = 0; k < N; ++k) {
-    problem.subject_to(X.col(k + 1) == rk4(cart_pole_dynamics, X.col(k), U.col(k), dt));
+    problem.subject_to(X.col(k + 1) ==
+                       rk4<decltype(cart_pole_dynamics), slp::VariableMatrix<double>, slp::VariableMatrix<double>>(
+                           cart_pole_dynamics, X.col(k), U.col(k), dt));
   }
 
   slp::Variable J = 0.0;
@@ -81,8 +91,8 @@ void build_cart_pole(slp::Problem& problem, double dt, int N, VariableMatrix* X_
 }
 
 // flywheel/sleipnir.cpp:12-42
-void build_flywheel(slp::Problem& problem, double dt, int N, VariableMatrix* X_out,
-                    VariableMatrix* U_out) {
+void build_flywheel(slp::Problem<double>& problem, double dt, int N, slp::VariableMatrix<double>* X_out,
+                    slp::VariableMatrix<double>* U_out) {
   DenseMatrix A{{std::exp(-dt)}};
   DenseMatrix B{{1.0 - std::exp(-dt)}};
 

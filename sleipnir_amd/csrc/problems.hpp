@@ -5,9 +5,9 @@
 
 namespace slpx_models {
 
-void build_cart_pole(slp::Problem& problem, double dt, int N, slp::VariableMatrix* X = nullptr,
-                     slp::VariableMatrix* U = nullptr);
-void build_flywheel(slp::Problem& problem, double dt, int N, slp::VariableMatrix* X = nullptr,
-                    slp::VariableMatrix* U = nullptr);
+void build_cart_pole(slp::Problem<double>& problem, double dt, int N, slp::VariableMatrix<double>* X = nullptr,
+                     slp::VariableMatrix<double>* U = nullptr);
+void build_flywheel(slp::Problem<double>& problem, double dt, int N, slp::VariableMatrix<double>* X = nullptr,
+                    slp::VariableMatrix<double>* U = nullptr);
 
 }  // namespace slpx_models

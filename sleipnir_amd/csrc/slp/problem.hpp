@@ -1,5 +1,6 @@
-// slp::Problem — the user surface of the reference
-// (include/sleipnir/optimization/problem.hpp:67-744) kept for the path's callers:
+// slp::Problem<double> — the user surface of the reference
+// (include/sleipnir/optimization/problem.hpp:67-744) kept for the path's callers
+// (ProblemF64 is the implementation, Problem<Scalar> at the end of this header the spelling):
 // decision_variable(), minimize()/maximize(), subject_to(), solve(), add_callback().
 // solve() compiles the model for the GPU (NewtonSystem) and runs the interior-point
 // iteration around the device Newton step.
@@ -27,18 +28,20 @@ using Options = slpx::Options;
 using IterationInfo = slpx::IterationInfo;
 using SolveReport = slpx::SolveReport;
 
-class Problem {
+class ProblemF64 {
  public:
-  Problem() noexcept = default;
+  ProblemF64() noexcept = default;
 
-  [[nodiscard]] Variable decision_variable() {
+  [[nodiscard]] VariableF64 decision_variable() {
+    invalidate();
     m_decision_variables.emplace_back();
     return m_decision_variables.back();
   }
 
   // problem.hpp:91-104
-  [[nodiscard]] VariableMatrix decision_variable(int rows, int cols = 1) {
-    VariableMatrix vars{detail::empty, rows, cols};
+  [[nodiscard]] VariableMatrixF64 decision_variable(int rows, int cols = 1) {
+    invalidate();
+    VariableMatrixF64 vars{detail::empty, rows, cols};
     for (int row = 0; row < rows; ++row)
       for (int col = 0; col < cols; ++col) {
         m_decision_variables.emplace_back();
@@ -47,13 +50,17 @@ class Problem {
     return vars;
   }
 
-  // FFI helper (no reference counterpart): make an already-created free Variable a
+  // FFI helper (no reference counterpart): make an already-created free VariableF64 a
   // decision variable of this problem.
-  void adopt_decision_variable(const Variable& v) { m_decision_variables.push_back(v); }
+  void adopt_decision_variable(const VariableF64& v) {
+    invalidate();
+    m_decision_variables.push_back(v);
+  }
 
   // problem.hpp:118-140
-  [[nodiscard]] VariableMatrix symmetric_decision_variable(int rows) {
-    VariableMatrix vars{detail::empty, rows, rows};
+  [[nodiscard]] VariableMatrixF64 symmetric_decision_variable(int rows) {
+    invalidate();
+    VariableMatrixF64 vars{detail::empty, rows, rows};
     for (int row = 0; row < rows; ++row)
       for (int col = 0; col <= row; ++col) {
         m_decision_variables.emplace_back();
@@ -63,13 +70,23 @@ class Problem {
     return vars;
   }
 
-  void minimize(const Variable& cost) { m_f = cost; }
-  void maximize(const Variable& objective) { m_f = -objective; }
-  void subject_to(const EqualityConstraints& constraint) {
+  // The compiled system belongs to the model as it was when compile() ran: every change of
+  // the model drops it (the reference rebuilds its evaluators in every solve(), problem.hpp:517-660).
+  void minimize(const VariableF64& cost) {
+    invalidate();
+    m_f = cost;
+  }
+  void maximize(const VariableF64& objective) {
+    invalidate();
+    m_f = -objective;
+  }
+  void subject_to(const EqualityConstraintsF64& constraint) {
+    invalidate();
     m_equality_constraints.insert(m_equality_constraints.end(), constraint.constraints.begin(),
                                   constraint.constraints.end());
   }
-  void subject_to(const InequalityConstraints& constraint) {
+  void subject_to(const InequalityConstraintsF64& constraint) {
+    invalidate();
     m_inequality_constraints.insert(m_inequality_constraints.end(),
                                     constraint.constraints.begin(), constraint.constraints.end());
   }
@@ -157,6 +174,16 @@ class Problem {
   // Compiles (once) the NLP for the device; exposed so harnesses can time setup
   // separately and drive the Newton step directly.
   slpx::NewtonSystem& compile(const slpx::NewtonOptions& opt = {}) {
+    // Values of free Variables that are not decision variables ("parameters") are folded into
+    // the compiled constants and the cached linear rows: a changed one means a new system.
+    if (m_sys) {
+      auto& g = detail::G();
+      for (const auto& [node, value] : m_param_snapshot)
+        if (g.val[node] != value) {
+          invalidate();
+          break;
+        }
+    }
     if (!m_sys) {
       std::vector<NodeId> xs, ce, ci;
       for (auto& v : m_decision_variables) xs.push_back(v.expr);
@@ -164,22 +191,33 @@ class Problem {
       for (auto& v : m_inequality_constraints) ci.push_back(v.expr);
       m_sys = std::make_unique<slpx::NewtonSystem>(detail::G(), xs, m_f ? m_f->expr : slpx::kNull, ce,
                                                    ci, opt);
+      m_param_snapshot.clear();
+      for (const slpx::TapeProgram* prog : {&m_sys->structure().full, &m_sys->structure().values})
+        for (const auto& [node, slot] : prog->params) m_param_snapshot.emplace_back(node, detail::G().val[node]);
     }
     return *m_sys;
   }
+  // true when the next compile() / solve() will build a new system (handles from
+  // slpx_problem_system taken before that are stale)
+  bool needs_compile() const { return !m_sys; }
 
   const SolveReport& report() const { return m_report; }
-  const Variable& cost() const { return *m_f; }
-  const std::vector<Variable>& decision_variables() const { return m_decision_variables; }
-  const std::vector<Variable>& equality_constraints() const { return m_equality_constraints; }
-  const std::vector<Variable>& inequality_constraints() const { return m_inequality_constraints; }
+  const VariableF64& cost() const { return *m_f; }
+  const std::vector<VariableF64>& decision_variables() const { return m_decision_variables; }
+  const std::vector<VariableF64>& equality_constraints() const { return m_equality_constraints; }
+  const std::vector<VariableF64>& inequality_constraints() const { return m_inequality_constraints; }
   const std::vector<double>& scales() const { return m_scales; }
   const std::vector<double>& slack() const { return m_s; }
   const std::vector<double>& equality_duals() const { return m_y; }
   const std::vector<double>& inequality_duals() const { return m_z; }
 
  private:
-  static ExpressionType max_type(const std::vector<Variable>& v) {
+  void invalidate() {
+    m_sys.reset();
+    m_param_snapshot.clear();
+  }
+
+  static ExpressionType max_type(const std::vector<VariableF64>& v) {
     ExpressionType t = ExpressionType::NONE;
     for (auto& e : v) t = std::max(t, e.type());
     return t;
@@ -217,14 +255,25 @@ class Problem {
     return conflict;
   }
 
-  std::vector<Variable> m_decision_variables;
-  std::optional<Variable> m_f;
-  std::vector<Variable> m_equality_constraints;
-  std::vector<Variable> m_inequality_constraints;
+  std::vector<VariableF64> m_decision_variables;
+  std::optional<VariableF64> m_f;
+  std::vector<VariableF64> m_equality_constraints;
+  std::vector<VariableF64> m_inequality_constraints;
   std::vector<slpx::IterationCallback> m_iteration_callbacks;
   std::unique_ptr<slpx::NewtonSystem> m_sys;
+  std::vector<std::pair<NodeId, double>> m_param_snapshot;  // (parameter node, value at compile time)
   std::vector<double> m_scales, m_s, m_y, m_z;
   SolveReport m_report;
+};
+
+
+// slp::Problem<Scalar> (include/sleipnir/optimization/problem.hpp:66-67): only double exists.
+template <typename Scalar>
+class Problem;
+template <>
+class Problem<double> : public ProblemF64 {
+ public:
+  using ProblemF64::ProblemF64;
 };
 
 }  // namespace slp

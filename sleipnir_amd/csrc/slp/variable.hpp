@@ -1,10 +1,10 @@
-// slp::Variable / slp::VariableMatrix / slp::VariableBlock — the modelling surface
+// slp::VariableF64 / slp::VariableMatrixF64 / slp::VariableBlockF64 — the modelling surface
 // of the reference kept source-compatible for the path's callers
 // (include/sleipnir/autodiff/variable.hpp, variable_matrix.hpp, variable_block.hpp),
 // but recording into the flat SoA arena of graph.hpp instead of a pointer graph.
 //
 // Kept semantics (cited where they matter for graph identity):
-//   * default-constructed Variable = decision variable with value 0 (variable.hpp:289-290)
+//   * default-constructed VariableF64 = decision variable with value 0 (variable.hpp:289-290)
 //   * scalar (x) matrix builds `element * scalar` (variable_matrix.hpp:592-640)
 //   * matmul accumulates `sum{0}; sum += a*b` (variable_matrix.hpp:505-557)
 //   * lhs ? rhs builds rows `lhs - rhs`, row-major (variable.hpp:716-778)
@@ -37,23 +37,23 @@ inline constexpr empty_t empty{};
 
 enum class ExpressionType : uint8_t { NONE = 0, CONSTANT, LINEAR, QUADRATIC, NONLINEAR };
 
-class VariableMatrix;
-class VariableBlock;
+class VariableMatrixF64;
+class VariableBlockF64;
 
-class Variable {
+class VariableF64 {
  public:
   using Scalar = double;
 
-  Variable() : expr{detail::G().variable(0.0)} {}
-  explicit constexpr Variable(std::nullptr_t) : expr{slpx::kNull} {}
-  Variable(double value) : expr{detail::G().constant(value)} {}  // NOLINT
-  Variable(std::integral auto value) : expr{detail::G().constant(static_cast<double>(value))} {}  // NOLINT
-  Variable(const VariableMatrix& value);  // NOLINT (1x1 only)
-  Variable(const VariableBlock& value);   // NOLINT (1x1 only)
+  VariableF64() : expr{detail::G().variable(0.0)} {}
+  explicit constexpr VariableF64(std::nullptr_t) : expr{slpx::kNull} {}
+  VariableF64(double value) : expr{detail::G().constant(value)} {}  // NOLINT
+  VariableF64(std::integral auto value) : expr{detail::G().constant(static_cast<double>(value))} {}  // NOLINT
+  VariableF64(const VariableMatrixF64& value);  // NOLINT (1x1 only)
+  VariableF64(const VariableBlockF64& value);   // NOLINT (1x1 only)
   struct from_node_t {};
-  Variable(from_node_t, NodeId n) : expr{n} {}
+  VariableF64(from_node_t, NodeId n) : expr{n} {}
 
-  Variable& operator=(double value) {
+  VariableF64& operator=(double value) {
     expr = detail::G().constant(value);
     return *this;
   }
@@ -64,34 +64,34 @@ class Variable {
   double value() const { return detail::G().value(expr); }
   ExpressionType type() const { return static_cast<ExpressionType>(detail::G().type[expr]); }
 
-  friend Variable operator*(const Variable& l, const Variable& r) { return wrap(detail::G().mul(l.expr, r.expr)); }
-  friend Variable operator/(const Variable& l, const Variable& r) { return wrap(detail::G().div(l.expr, r.expr)); }
-  friend Variable operator+(const Variable& l, const Variable& r) { return wrap(detail::G().add(l.expr, r.expr)); }
-  friend Variable operator-(const Variable& l, const Variable& r) { return wrap(detail::G().sub(l.expr, r.expr)); }
-  friend Variable operator-(const Variable& l) { return wrap(detail::G().neg(l.expr)); }
-  friend Variable operator+(const Variable& l) { return l; }
+  friend VariableF64 operator*(const VariableF64& l, const VariableF64& r) { return wrap(detail::G().mul(l.expr, r.expr)); }
+  friend VariableF64 operator/(const VariableF64& l, const VariableF64& r) { return wrap(detail::G().div(l.expr, r.expr)); }
+  friend VariableF64 operator+(const VariableF64& l, const VariableF64& r) { return wrap(detail::G().add(l.expr, r.expr)); }
+  friend VariableF64 operator-(const VariableF64& l, const VariableF64& r) { return wrap(detail::G().sub(l.expr, r.expr)); }
+  friend VariableF64 operator-(const VariableF64& l) { return wrap(detail::G().neg(l.expr)); }
+  friend VariableF64 operator+(const VariableF64& l) { return l; }
   // arithmetic-with-scalar overloads: exact matches, so `0.5 * x` never competes
-  // with the Variable<->VariableMatrix conversions (variable.hpp:157-167)
-  friend Variable operator*(double l, const Variable& r) { return Variable{l} * r; }
-  friend Variable operator*(const Variable& l, double r) { return l * Variable{r}; }
-  friend Variable operator/(double l, const Variable& r) { return Variable{l} / r; }
-  friend Variable operator/(const Variable& l, double r) { return l / Variable{r}; }
-  friend Variable operator+(double l, const Variable& r) { return Variable{l} + r; }
-  friend Variable operator+(const Variable& l, double r) { return l + Variable{r}; }
-  friend Variable operator-(double l, const Variable& r) { return Variable{l} - r; }
-  friend Variable operator-(const Variable& l, double r) { return l - Variable{r}; }
-  Variable& operator*=(const Variable& r) { return *this = *this * r; }
-  Variable& operator/=(const Variable& r) { return *this = *this / r; }
-  Variable& operator+=(const Variable& r) { return *this = *this + r; }
-  Variable& operator-=(const Variable& r) { return *this = *this - r; }
+  // with the VariableF64<->VariableMatrixF64 conversions (variable.hpp:157-167)
+  friend VariableF64 operator*(double l, const VariableF64& r) { return VariableF64{l} * r; }
+  friend VariableF64 operator*(const VariableF64& l, double r) { return l * VariableF64{r}; }
+  friend VariableF64 operator/(double l, const VariableF64& r) { return VariableF64{l} / r; }
+  friend VariableF64 operator/(const VariableF64& l, double r) { return l / VariableF64{r}; }
+  friend VariableF64 operator+(double l, const VariableF64& r) { return VariableF64{l} + r; }
+  friend VariableF64 operator+(const VariableF64& l, double r) { return l + VariableF64{r}; }
+  friend VariableF64 operator-(double l, const VariableF64& r) { return VariableF64{l} - r; }
+  friend VariableF64 operator-(const VariableF64& l, double r) { return l - VariableF64{r}; }
+  VariableF64& operator*=(const VariableF64& r) { return *this = *this * r; }
+  VariableF64& operator/=(const VariableF64& r) { return *this = *this / r; }
+  VariableF64& operator+=(const VariableF64& r) { return *this = *this + r; }
+  VariableF64& operator-=(const VariableF64& r) { return *this = *this - r; }
 
-  static Variable wrap(NodeId n) { return Variable{from_node_t{}, n}; }
+  static VariableF64 wrap(NodeId n) { return VariableF64{from_node_t{}, n}; }
 
   NodeId expr;
 };
 
 #define SLP_UNARY(name, OP) \
-  inline Variable name(const Variable& x) { return Variable::wrap(detail::G().unary(slpx::OP, x.expr)); }
+  inline VariableF64 name(const VariableF64& x) { return VariableF64::wrap(detail::G().unary(slpx::OP, x.expr)); }
 SLP_UNARY(abs, OP_ABS)
 SLP_UNARY(acos, OP_ACOS)
 SLP_UNARY(asin, OP_ASIN)
@@ -111,8 +111,8 @@ SLP_UNARY(tan, OP_TAN)
 SLP_UNARY(tanh, OP_TANH)
 #undef SLP_UNARY
 #define SLP_BINARY(name, OP)                                     \
-  inline Variable name(const Variable& a, const Variable& b) {   \
-    return Variable::wrap(detail::G().binary(slpx::OP, a.expr, b.expr)); \
+  inline VariableF64 name(const VariableF64& a, const VariableF64& b) {   \
+    return VariableF64::wrap(detail::G().binary(slpx::OP, a.expr, b.expr)); \
   }
 SLP_BINARY(atan2, OP_ATAN2)
 SLP_BINARY(hypot, OP_HYPOT)
@@ -121,7 +121,7 @@ SLP_BINARY(min, OP_MIN)
 SLP_BINARY(pow, OP_POW)
 #undef SLP_BINARY
 // variable.hpp:711-714
-inline Variable hypot(const Variable& x, const Variable& y, const Variable& z) {
+inline VariableF64 hypot(const VariableF64& x, const VariableF64& y, const VariableF64& z) {
   return sqrt(pow(x, 2) + pow(y, 2) + pow(z, 2));
 }
 
@@ -156,19 +156,19 @@ class DenseMatrix {
   std::vector<double> m_d;
 };
 
-class VariableMatrix {
+class VariableMatrixF64 {
  public:
   using Scalar = double;
-  VariableMatrix() = default;
-  explicit VariableMatrix(int rows) : VariableMatrix(rows, 1) {}
+  VariableMatrixF64() = default;
+  explicit VariableMatrixF64(int rows) : VariableMatrixF64(rows, 1) {}
   // variable_matrix.hpp:47-58: filled with default (decision-variable) handles
-  VariableMatrix(int rows, int cols) : m_rows{rows}, m_cols{cols} {
+  VariableMatrixF64(int rows, int cols) : m_rows{rows}, m_cols{cols} {
     m_storage.reserve(static_cast<size_t>(rows) * cols);
     for (int i = 0; i < rows * cols; ++i) m_storage.emplace_back();
   }
-  VariableMatrix(detail::empty_t, int rows, int cols)
-      : m_rows{rows}, m_cols{cols}, m_storage(static_cast<size_t>(rows) * cols, Variable{nullptr}) {}
-  VariableMatrix(std::initializer_list<std::initializer_list<Variable>> list) {
+  VariableMatrixF64(detail::empty_t, int rows, int cols)
+      : m_rows{rows}, m_cols{cols}, m_storage(static_cast<size_t>(rows) * cols, VariableF64{nullptr}) {}
+  VariableMatrixF64(std::initializer_list<std::initializer_list<VariableF64>> list) {
     m_rows = static_cast<int>(list.size());
     m_cols = m_rows ? static_cast<int>(list.begin()->size()) : 0;
     for (auto& row : list) {
@@ -176,40 +176,40 @@ class VariableMatrix {
       for (auto& v : row) m_storage.push_back(v);
     }
   }
-  VariableMatrix(const DenseMatrix& values)  // NOLINT
+  VariableMatrixF64(const DenseMatrix& values)  // NOLINT
       : m_rows{values.rows()}, m_cols{values.cols()} {
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) m_storage.emplace_back(values[r, c]);
   }
-  VariableMatrix(const Variable& v) : m_rows{1}, m_cols{1}, m_storage{v} {}  // NOLINT
-  VariableMatrix(const VariableBlock& b);                                     // NOLINT
-  explicit VariableMatrix(const std::vector<Variable>& values)
+  VariableMatrixF64(const VariableF64& v) : m_rows{1}, m_cols{1}, m_storage{v} {}  // NOLINT
+  VariableMatrixF64(const VariableBlockF64& b);                                     // NOLINT
+  explicit VariableMatrixF64(const std::vector<VariableF64>& values)
       : m_rows{static_cast<int>(values.size())}, m_cols{1}, m_storage{values} {}
 
-  Variable& operator[](int row, int col) {
+  VariableF64& operator[](int row, int col) {
     assert(row >= 0 && row < m_rows && col >= 0 && col < m_cols);
     return m_storage[static_cast<size_t>(row) * m_cols + col];
   }
-  const Variable& operator[](int row, int col) const {
+  const VariableF64& operator[](int row, int col) const {
     assert(row >= 0 && row < m_rows && col >= 0 && col < m_cols);
     return m_storage[static_cast<size_t>(row) * m_cols + col];
   }
-  Variable& operator[](int index) { return m_storage[index]; }
-  const Variable& operator[](int index) const { return m_storage[index]; }
-  Variable& operator()(int row, int col) { return (*this)[row, col]; }
-  const Variable& operator()(int row, int col) const { return (*this)[row, col]; }
+  VariableF64& operator[](int index) { return m_storage[index]; }
+  const VariableF64& operator[](int index) const { return m_storage[index]; }
+  VariableF64& operator()(int row, int col) { return (*this)[row, col]; }
+  const VariableF64& operator()(int row, int col) const { return (*this)[row, col]; }
 
-  VariableBlock block(int row_offset, int col_offset, int block_rows, int block_cols);
-  VariableMatrix block(int row_offset, int col_offset, int block_rows, int block_cols) const;
-  VariableBlock segment(int offset, int length);
-  VariableMatrix segment(int offset, int length) const;
-  VariableBlock row(int row);
-  VariableMatrix row(int row) const;
-  VariableBlock col(int col);
-  VariableMatrix col(int col) const;
+  VariableBlockF64 block(int row_offset, int col_offset, int block_rows, int block_cols);
+  VariableMatrixF64 block(int row_offset, int col_offset, int block_rows, int block_cols) const;
+  VariableBlockF64 segment(int offset, int length);
+  VariableMatrixF64 segment(int offset, int length) const;
+  VariableBlockF64 row(int row);
+  VariableMatrixF64 row(int row) const;
+  VariableBlockF64 col(int col);
+  VariableMatrixF64 col(int col) const;
 
-  VariableMatrix T() const {
-    VariableMatrix result{detail::empty, m_cols, m_rows};
+  VariableMatrixF64 T() const {
+    VariableMatrixF64 result{detail::empty, m_cols, m_rows};
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) result[c, r] = (*this)[r, c];
     return result;
@@ -238,66 +238,66 @@ class VariableMatrix {
   auto begin() const { return m_storage.begin(); }
   auto end() const { return m_storage.end(); }
 
-  VariableMatrix& operator+=(const VariableMatrix& rhs);
-  VariableMatrix& operator-=(const VariableMatrix& rhs);
-  VariableMatrix& operator*=(const Variable& rhs) {
+  VariableMatrixF64& operator+=(const VariableMatrixF64& rhs);
+  VariableMatrixF64& operator-=(const VariableMatrixF64& rhs);
+  VariableMatrixF64& operator*=(const VariableF64& rhs) {
     for (auto& v : m_storage) v *= rhs;
     return *this;
   }
-  VariableMatrix& operator/=(const Variable& rhs) {
+  VariableMatrixF64& operator/=(const VariableF64& rhs) {
     for (auto& v : m_storage) v /= rhs;
     return *this;
   }
 
  private:
   int m_rows = 0, m_cols = 0;
-  std::vector<Variable> m_storage;
+  std::vector<VariableF64> m_storage;
 };
 
-// Mutable view into a VariableMatrix (variable_block.hpp:27).  Assigning a matrix
+// Mutable view into a VariableMatrixF64 (variable_block.hpp:27).  Assigning a matrix
 // re-points the viewed handles, as in the reference.
-class VariableBlock {
+class VariableBlockF64 {
  public:
-  VariableBlock(VariableMatrix& mat, int row_offset, int col_offset, int rows, int cols)
+  VariableBlockF64(VariableMatrixF64& mat, int row_offset, int col_offset, int rows, int cols)
       : m_mat{&mat}, m_r0{row_offset}, m_c0{col_offset}, m_rows{rows}, m_cols{cols} {}
 
-  VariableBlock& operator=(const VariableMatrix& values) {
+  VariableBlockF64& operator=(const VariableMatrixF64& values) {
     assert(values.rows() == m_rows && values.cols() == m_cols);
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) (*this)[r, c] = values[r, c];
     return *this;
   }
-  VariableBlock& operator=(const VariableBlock& values) {
+  VariableBlockF64& operator=(const VariableBlockF64& values) {
     if (this == &values) return *this;
-    return *this = VariableMatrix{values};
+    return *this = VariableMatrixF64{values};
   }
-  VariableBlock(const VariableBlock&) = default;
-  VariableBlock& operator=(const DenseMatrix& values) { return *this = VariableMatrix{values}; }
-  VariableBlock& operator=(double value) {
+  VariableBlockF64(const VariableBlockF64&) = default;
+  VariableBlockF64& operator=(const DenseMatrix& values) { return *this = VariableMatrixF64{values}; }
+  VariableBlockF64& operator=(double value) {
     assert(m_rows == 1 && m_cols == 1);
-    (*this)[0, 0] = Variable{value};
+    (*this)[0, 0] = VariableF64{value};
     return *this;
   }
 
-  Variable& operator[](int row, int col) const { return (*m_mat)[m_r0 + row, m_c0 + col]; }
-  Variable& operator[](int index) const { return (*this)[index / m_cols, index % m_cols]; }
-  Variable& operator()(int row, int col) const { return (*this)[row, col]; }
+  VariableF64& operator[](int row, int col) const { return (*m_mat)[m_r0 + row, m_c0 + col]; }
+  VariableF64& operator[](int index) const { return (*this)[index / m_cols, index % m_cols]; }
+  VariableF64& operator()(int row, int col) const { return (*this)[row, col]; }
   int rows() const { return m_rows; }
   int cols() const { return m_cols; }
 
-  VariableBlock block(int r0, int c0, int rows, int cols) const {
-    return VariableBlock{*m_mat, m_r0 + r0, m_c0 + c0, rows, cols};
+  VariableBlockF64 block(int r0, int c0, int rows, int cols) const {
+    return VariableBlockF64{*m_mat, m_r0 + r0, m_c0 + c0, rows, cols};
   }
-  VariableBlock segment(int offset, int length) const {
+  VariableBlockF64 segment(int offset, int length) const {
     return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
   }
-  VariableBlock row(int r) const { return block(r, 0, 1, m_cols); }
-  VariableBlock col(int c) const { return block(0, c, m_rows, 1); }
-  VariableMatrix T() const { return VariableMatrix{*this}.T(); }
+  VariableBlockF64 row(int r) const { return block(r, 0, 1, m_cols); }
+  VariableBlockF64 col(int c) const { return block(0, c, m_rows, 1); }
+  VariableMatrixF64 T() const { return VariableMatrixF64{*this}.T(); }
 
   double value(int row, int col) const { return (*this)[row, col].value(); }
   double value(int index) const { return (*this)[index].value(); }
-  DenseMatrix value() const { return VariableMatrix{*this}.value(); }
+  DenseMatrix value() const { return VariableMatrixF64{*this}.value(); }
   void set_value(const DenseMatrix& values) {
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) (*this)[r, c].set_value(values[r, c]);
@@ -308,153 +308,153 @@ class VariableBlock {
   }
 
  private:
-  VariableMatrix* m_mat;
+  VariableMatrixF64* m_mat;
   int m_r0, m_c0, m_rows, m_cols;
 };
 
-inline Variable::Variable(const VariableMatrix& value) : expr{value[0, 0].expr} {
+inline VariableF64::VariableF64(const VariableMatrixF64& value) : expr{value[0, 0].expr} {
   assert(value.rows() == 1 && value.cols() == 1);
 }
-inline Variable::Variable(const VariableBlock& value) : expr{value[0, 0].expr} {
+inline VariableF64::VariableF64(const VariableBlockF64& value) : expr{value[0, 0].expr} {
   assert(value.rows() == 1 && value.cols() == 1);
 }
-inline VariableMatrix::VariableMatrix(const VariableBlock& b) : m_rows{b.rows()}, m_cols{b.cols()} {
+inline VariableMatrixF64::VariableMatrixF64(const VariableBlockF64& b) : m_rows{b.rows()}, m_cols{b.cols()} {
   m_storage.reserve(static_cast<size_t>(m_rows) * m_cols);
   for (int r = 0; r < m_rows; ++r)
     for (int c = 0; c < m_cols; ++c) m_storage.push_back(b[r, c]);
 }
-inline VariableBlock VariableMatrix::block(int r0, int c0, int rows, int cols) {
-  return VariableBlock{*this, r0, c0, rows, cols};
+inline VariableBlockF64 VariableMatrixF64::block(int r0, int c0, int rows, int cols) {
+  return VariableBlockF64{*this, r0, c0, rows, cols};
 }
-inline VariableMatrix VariableMatrix::block(int r0, int c0, int rows, int cols) const {
-  VariableMatrix m{detail::empty, rows, cols};
+inline VariableMatrixF64 VariableMatrixF64::block(int r0, int c0, int rows, int cols) const {
+  VariableMatrixF64 m{detail::empty, rows, cols};
   for (int r = 0; r < rows; ++r)
     for (int c = 0; c < cols; ++c) m[r, c] = (*this)[r0 + r, c0 + c];
   return m;
 }
-inline VariableBlock VariableMatrix::segment(int offset, int length) {
+inline VariableBlockF64 VariableMatrixF64::segment(int offset, int length) {
   return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
 }
-inline VariableMatrix VariableMatrix::segment(int offset, int length) const {
+inline VariableMatrixF64 VariableMatrixF64::segment(int offset, int length) const {
   return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
 }
-inline VariableBlock VariableMatrix::row(int r) { return block(r, 0, 1, m_cols); }
-inline VariableMatrix VariableMatrix::row(int r) const { return block(r, 0, 1, m_cols); }
-inline VariableBlock VariableMatrix::col(int c) { return block(0, c, m_rows, 1); }
-inline VariableMatrix VariableMatrix::col(int c) const { return block(0, c, m_rows, 1); }
+inline VariableBlockF64 VariableMatrixF64::row(int r) { return block(r, 0, 1, m_cols); }
+inline VariableMatrixF64 VariableMatrixF64::row(int r) const { return block(r, 0, 1, m_cols); }
+inline VariableBlockF64 VariableMatrixF64::col(int c) { return block(0, c, m_rows, 1); }
+inline VariableMatrixF64 VariableMatrixF64::col(int c) const { return block(0, c, m_rows, 1); }
 
 // ---- matrix arithmetic ---------------------------------------------------------
 namespace detail {
 template <typename L, typename R>
-VariableMatrix matmul(const L& lhs, const R& rhs) {
+VariableMatrixF64 matmul(const L& lhs, const R& rhs) {
   assert(lhs.cols() == rhs.rows());
-  VariableMatrix result{empty, lhs.rows(), rhs.cols()};
+  VariableMatrixF64 result{empty, lhs.rows(), rhs.cols()};
   for (int i = 0; i < lhs.rows(); ++i)
     for (int j = 0; j < rhs.cols(); ++j) {
-      Variable sum{0.0};
-      for (int k = 0; k < lhs.cols(); ++k) sum += Variable{lhs[i, k]} * Variable{rhs[k, j]};
+      VariableF64 sum{0.0};
+      for (int k = 0; k < lhs.cols(); ++k) sum += VariableF64{lhs[i, k]} * VariableF64{rhs[k, j]};
       result[i, j] = sum;
     }
   return result;
 }
 template <typename L, typename R, typename F>
-VariableMatrix cwise(const L& lhs, const R& rhs, F&& f) {
+VariableMatrixF64 cwise(const L& lhs, const R& rhs, F&& f) {
   assert(lhs.rows() == rhs.rows() && lhs.cols() == rhs.cols());
-  VariableMatrix result{empty, lhs.rows(), lhs.cols()};
+  VariableMatrixF64 result{empty, lhs.rows(), lhs.cols()};
   for (int r = 0; r < lhs.rows(); ++r)
-    for (int c = 0; c < lhs.cols(); ++c) result[r, c] = f(Variable{lhs[r, c]}, Variable{rhs[r, c]});
+    for (int c = 0; c < lhs.cols(); ++c) result[r, c] = f(VariableF64{lhs[r, c]}, VariableF64{rhs[r, c]});
   return result;
 }
 template <typename M, typename F>
-VariableMatrix cwise1(const M& m, F&& f) {
-  VariableMatrix result{empty, m.rows(), m.cols()};
+VariableMatrixF64 cwise1(const M& m, F&& f) {
+  VariableMatrixF64 result{empty, m.rows(), m.cols()};
   for (int r = 0; r < m.rows(); ++r)
-    for (int c = 0; c < m.cols(); ++c) result[r, c] = f(Variable{m[r, c]});
+    for (int c = 0; c < m.cols(); ++c) result[r, c] = f(VariableF64{m[r, c]});
   return result;
 }
 }  // namespace detail
 
-inline VariableMatrix operator*(const VariableMatrix& l, const VariableMatrix& r) { return detail::matmul(l, r); }
-inline VariableMatrix operator*(const DenseMatrix& l, const VariableMatrix& r) { return detail::matmul(l, r); }
-inline VariableMatrix operator*(const VariableMatrix& l, const DenseMatrix& r) { return detail::matmul(l, r); }
+inline VariableMatrixF64 operator*(const VariableMatrixF64& l, const VariableMatrixF64& r) { return detail::matmul(l, r); }
+inline VariableMatrixF64 operator*(const DenseMatrix& l, const VariableMatrixF64& r) { return detail::matmul(l, r); }
+inline VariableMatrixF64 operator*(const VariableMatrixF64& l, const DenseMatrix& r) { return detail::matmul(l, r); }
 // matrix (x) scalar: element on the LEFT in both argument orders (variable_matrix.hpp:592-640)
-inline VariableMatrix operator*(const VariableMatrix& l, const Variable& r) {
-  return detail::cwise1(l, [&](const Variable& e) { return e * r; });
+inline VariableMatrixF64 operator*(const VariableMatrixF64& l, const VariableF64& r) {
+  return detail::cwise1(l, [&](const VariableF64& e) { return e * r; });
 }
-inline VariableMatrix operator*(const Variable& l, const VariableMatrix& r) {
-  return detail::cwise1(r, [&](const Variable& e) { return e * l; });
+inline VariableMatrixF64 operator*(const VariableF64& l, const VariableMatrixF64& r) {
+  return detail::cwise1(r, [&](const VariableF64& e) { return e * l; });
 }
-inline VariableMatrix operator*(const VariableMatrix& l, double r) { return l * Variable{r}; }
-inline VariableMatrix operator*(double l, const VariableMatrix& r) { return Variable{l} * r; }
-inline VariableMatrix operator*(const DenseMatrix& l, const Variable& r) {
-  return detail::cwise1(l, [&](const Variable& e) { return e * r; });
+inline VariableMatrixF64 operator*(const VariableMatrixF64& l, double r) { return l * VariableF64{r}; }
+inline VariableMatrixF64 operator*(double l, const VariableMatrixF64& r) { return VariableF64{l} * r; }
+inline VariableMatrixF64 operator*(const DenseMatrix& l, const VariableF64& r) {
+  return detail::cwise1(l, [&](const VariableF64& e) { return e * r; });
 }
-inline VariableMatrix operator*(const Variable& l, const DenseMatrix& r) {
-  return detail::cwise1(r, [&](const Variable& e) { return e * l; });
+inline VariableMatrixF64 operator*(const VariableF64& l, const DenseMatrix& r) {
+  return detail::cwise1(r, [&](const VariableF64& e) { return e * l; });
 }
-inline VariableMatrix operator/(const VariableMatrix& l, const Variable& r) {
-  return detail::cwise1(l, [&](const Variable& e) { return e / r; });
+inline VariableMatrixF64 operator/(const VariableMatrixF64& l, const VariableF64& r) {
+  return detail::cwise1(l, [&](const VariableF64& e) { return e / r; });
 }
-inline VariableMatrix operator/(const VariableMatrix& l, double r) { return l / Variable{r}; }
-inline VariableMatrix operator+(const VariableMatrix& l, const VariableMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a + b; });
+inline VariableMatrixF64 operator/(const VariableMatrixF64& l, double r) { return l / VariableF64{r}; }
+inline VariableMatrixF64 operator+(const VariableMatrixF64& l, const VariableMatrixF64& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a + b; });
 }
-inline VariableMatrix operator+(const DenseMatrix& l, const VariableMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a + b; });
+inline VariableMatrixF64 operator+(const DenseMatrix& l, const VariableMatrixF64& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a + b; });
 }
-inline VariableMatrix operator+(const VariableMatrix& l, const DenseMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a + b; });
+inline VariableMatrixF64 operator+(const VariableMatrixF64& l, const DenseMatrix& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a + b; });
 }
-inline VariableMatrix operator-(const VariableMatrix& l, const VariableMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a - b; });
+inline VariableMatrixF64 operator-(const VariableMatrixF64& l, const VariableMatrixF64& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a - b; });
 }
-inline VariableMatrix operator-(const DenseMatrix& l, const VariableMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a - b; });
+inline VariableMatrixF64 operator-(const DenseMatrix& l, const VariableMatrixF64& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a - b; });
 }
-inline VariableMatrix operator-(const VariableMatrix& l, const DenseMatrix& r) {
-  return detail::cwise(l, r, [](const Variable& a, const Variable& b) { return a - b; });
+inline VariableMatrixF64 operator-(const VariableMatrixF64& l, const DenseMatrix& r) {
+  return detail::cwise(l, r, [](const VariableF64& a, const VariableF64& b) { return a - b; });
 }
-inline VariableMatrix operator-(const VariableMatrix& m) {
-  return detail::cwise1(m, [](const Variable& e) { return -e; });
+inline VariableMatrixF64 operator-(const VariableMatrixF64& m) {
+  return detail::cwise1(m, [](const VariableF64& e) { return -e; });
 }
-inline VariableMatrix& VariableMatrix::operator+=(const VariableMatrix& rhs) {
+inline VariableMatrixF64& VariableMatrixF64::operator+=(const VariableMatrixF64& rhs) {
   assert(m_rows == rhs.rows() && m_cols == rhs.cols());
   for (int i = 0; i < size(); ++i) m_storage[i] += rhs[i];
   return *this;
 }
-inline VariableMatrix& VariableMatrix::operator-=(const VariableMatrix& rhs) {
+inline VariableMatrixF64& VariableMatrixF64::operator-=(const VariableMatrixF64& rhs) {
   assert(m_rows == rhs.rows() && m_cols == rhs.cols());
   for (int i = 0; i < size(); ++i) m_storage[i] -= rhs[i];
   return *this;
 }
-// VariableBlock operands convert to VariableMatrix
-inline VariableMatrix operator*(const VariableBlock& l, const VariableBlock& r) { return VariableMatrix{l} * VariableMatrix{r}; }
-inline VariableMatrix operator*(const VariableMatrix& l, const VariableBlock& r) { return l * VariableMatrix{r}; }
-inline VariableMatrix operator*(const VariableBlock& l, const VariableMatrix& r) { return VariableMatrix{l} * r; }
-inline VariableMatrix operator*(const DenseMatrix& l, const VariableBlock& r) { return l * VariableMatrix{r}; }
-inline VariableMatrix operator*(double l, const VariableBlock& r) { return l * VariableMatrix{r}; }
-inline VariableMatrix operator*(const VariableBlock& l, double r) { return VariableMatrix{l} * r; }
-inline VariableMatrix operator+(const VariableBlock& l, const VariableMatrix& r) { return VariableMatrix{l} + r; }
-inline VariableMatrix operator+(const VariableMatrix& l, const VariableBlock& r) { return l + VariableMatrix{r}; }
-inline VariableMatrix operator+(const VariableBlock& l, const VariableBlock& r) { return VariableMatrix{l} + VariableMatrix{r}; }
-inline VariableMatrix operator-(const VariableBlock& l, const VariableMatrix& r) { return VariableMatrix{l} - r; }
-inline VariableMatrix operator-(const VariableMatrix& l, const VariableBlock& r) { return l - VariableMatrix{r}; }
-inline VariableMatrix operator-(const VariableBlock& l, const VariableBlock& r) { return VariableMatrix{l} - VariableMatrix{r}; }
-inline VariableMatrix operator-(const DenseMatrix& l, const VariableBlock& r) { return l - VariableMatrix{r}; }
-inline VariableMatrix operator-(const VariableBlock& l, const DenseMatrix& r) { return VariableMatrix{l} - r; }
-inline VariableMatrix operator-(const VariableBlock& m) { return -VariableMatrix{m}; }
+// VariableBlockF64 operands convert to VariableMatrixF64
+inline VariableMatrixF64 operator*(const VariableBlockF64& l, const VariableBlockF64& r) { return VariableMatrixF64{l} * VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator*(const VariableMatrixF64& l, const VariableBlockF64& r) { return l * VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator*(const VariableBlockF64& l, const VariableMatrixF64& r) { return VariableMatrixF64{l} * r; }
+inline VariableMatrixF64 operator*(const DenseMatrix& l, const VariableBlockF64& r) { return l * VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator*(double l, const VariableBlockF64& r) { return l * VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator*(const VariableBlockF64& l, double r) { return VariableMatrixF64{l} * r; }
+inline VariableMatrixF64 operator+(const VariableBlockF64& l, const VariableMatrixF64& r) { return VariableMatrixF64{l} + r; }
+inline VariableMatrixF64 operator+(const VariableMatrixF64& l, const VariableBlockF64& r) { return l + VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator+(const VariableBlockF64& l, const VariableBlockF64& r) { return VariableMatrixF64{l} + VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator-(const VariableBlockF64& l, const VariableMatrixF64& r) { return VariableMatrixF64{l} - r; }
+inline VariableMatrixF64 operator-(const VariableMatrixF64& l, const VariableBlockF64& r) { return l - VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator-(const VariableBlockF64& l, const VariableBlockF64& r) { return VariableMatrixF64{l} - VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator-(const DenseMatrix& l, const VariableBlockF64& r) { return l - VariableMatrixF64{r}; }
+inline VariableMatrixF64 operator-(const VariableBlockF64& l, const DenseMatrix& r) { return VariableMatrixF64{l} - r; }
+inline VariableMatrixF64 operator-(const VariableBlockF64& m) { return -VariableMatrixF64{m}; }
 
 // variable_matrix.hpp:1516-1620
-inline VariableMatrix solve(const VariableMatrix& A, const VariableMatrix& B) {
+inline VariableMatrixF64 solve(const VariableMatrixF64& A, const VariableMatrixF64& B) {
   assert(A.rows() == B.rows());
   if (A.rows() == 1 && A.cols() == 1) {
-    return VariableMatrix{B[0, 0] / A[0, 0]};
+    return VariableMatrixF64{B[0, 0] / A[0, 0]};
   } else if (A.rows() == 2 && A.cols() == 2) {
     const auto& a = A[0, 0];
     const auto& b = A[0, 1];
     const auto& c = A[1, 0];
     const auto& d = A[1, 1];
-    VariableMatrix adj_A{{d, -b}, {-c, a}};
+    VariableMatrixF64 adj_A{{d, -b}, {-c, a}};
     auto det_A = a * d - b * c;
     return adj_A / det_A * B;
   } else if (A.rows() == 3 && A.cols() == 3) {
@@ -475,7 +475,7 @@ inline VariableMatrix solve(const VariableMatrix& A, const VariableMatrix& B) {
     auto adj_A00 = ei - fh;
     auto adj_A10 = fg - di;
     auto adj_A20 = dh - eg;
-    VariableMatrix adj_A{{adj_A00, ch - bi, bf - ce}, {adj_A10, ai - cg, cd - af}, {adj_A20, bg - ah, ae - bd}};
+    VariableMatrixF64 adj_A{{adj_A00, ch - bi, bf - ce}, {adj_A10, ai - cg, cd - af}, {adj_A20, bg - ah, ae - bd}};
     auto det_A = a * adj_A00 + b * adj_A10 + c * adj_A20;
     return adj_A / det_A * B;
   }
@@ -485,55 +485,57 @@ inline VariableMatrix solve(const VariableMatrix& A, const VariableMatrix& B) {
 
 // ---- constraints (variable.hpp:716-1013) ------------------------------------------
 namespace detail {
+// (derived_from: the Variable<double> / VariableMatrix<double> spellings are classes derived
+// from the fp64 ones)
 template <typename T>
-concept ScalarOperand = std::is_arithmetic_v<std::decay_t<T>> || std::same_as<std::decay_t<T>, Variable>;
+concept ScalarOperand = std::is_arithmetic_v<std::decay_t<T>> || std::derived_from<std::decay_t<T>, VariableF64>;
 template <typename T>
-concept MatrixOperand = std::same_as<std::decay_t<T>, VariableMatrix> || std::same_as<std::decay_t<T>, VariableBlock> ||
+concept MatrixOperand = std::derived_from<std::decay_t<T>, VariableMatrixF64> || std::derived_from<std::decay_t<T>, VariableBlockF64> ||
                         std::same_as<std::decay_t<T>, DenseMatrix>;
 template <typename T>
-concept SleipnirOperand = std::same_as<std::decay_t<T>, Variable> || std::same_as<std::decay_t<T>, VariableMatrix> ||
-                          std::same_as<std::decay_t<T>, VariableBlock>;
+concept SleipnirOperand = std::derived_from<std::decay_t<T>, VariableF64> || std::derived_from<std::decay_t<T>, VariableMatrixF64> ||
+                          std::derived_from<std::decay_t<T>, VariableBlockF64>;
 
 template <typename L, typename R>
-std::vector<Variable> make_constraints(const L& lhs, const R& rhs) {
-  std::vector<Variable> out;
+std::vector<VariableF64> make_constraints(const L& lhs, const R& rhs) {
+  std::vector<VariableF64> out;
   if constexpr (ScalarOperand<L> && ScalarOperand<R>) {
-    out.push_back(Variable{lhs} - Variable{rhs});
+    out.push_back(VariableF64{lhs} - VariableF64{rhs});
   } else if constexpr (ScalarOperand<L>) {
     for (int r = 0; r < rhs.rows(); ++r)
-      for (int c = 0; c < rhs.cols(); ++c) out.push_back(Variable{lhs} - Variable{rhs[r, c]});
+      for (int c = 0; c < rhs.cols(); ++c) out.push_back(VariableF64{lhs} - VariableF64{rhs[r, c]});
   } else if constexpr (ScalarOperand<R>) {
     for (int r = 0; r < lhs.rows(); ++r)
-      for (int c = 0; c < lhs.cols(); ++c) out.push_back(Variable{lhs[r, c]} - Variable{rhs});
+      for (int c = 0; c < lhs.cols(); ++c) out.push_back(VariableF64{lhs[r, c]} - VariableF64{rhs});
   } else {
     assert(lhs.rows() == rhs.rows() && lhs.cols() == rhs.cols());
     for (int r = 0; r < lhs.rows(); ++r)
-      for (int c = 0; c < lhs.cols(); ++c) out.push_back(Variable{lhs[r, c]} - Variable{rhs[r, c]});
+      for (int c = 0; c < lhs.cols(); ++c) out.push_back(VariableF64{lhs[r, c]} - VariableF64{rhs[r, c]});
   }
   return out;
 }
 }  // namespace detail
 
-struct EqualityConstraints {
-  std::vector<Variable> constraints;
-  EqualityConstraints() = default;
-  EqualityConstraints(std::initializer_list<EqualityConstraints> list) {
+struct EqualityConstraintsF64 {
+  std::vector<VariableF64> constraints;
+  EqualityConstraintsF64() = default;
+  EqualityConstraintsF64(std::initializer_list<EqualityConstraintsF64> list) {
     for (auto& e : list) constraints.insert(constraints.end(), e.constraints.begin(), e.constraints.end());
   }
-  explicit EqualityConstraints(std::vector<Variable> c) : constraints{std::move(c)} {}
+  explicit EqualityConstraintsF64(std::vector<VariableF64> c) : constraints{std::move(c)} {}
   explicit operator bool() const {
     for (auto& c : constraints)
       if (c.value() != 0.0) return false;
     return true;
   }
 };
-struct InequalityConstraints {
-  std::vector<Variable> constraints;
-  InequalityConstraints() = default;
-  InequalityConstraints(std::initializer_list<InequalityConstraints> list) {
+struct InequalityConstraintsF64 {
+  std::vector<VariableF64> constraints;
+  InequalityConstraintsF64() = default;
+  InequalityConstraintsF64(std::initializer_list<InequalityConstraintsF64> list) {
     for (auto& e : list) constraints.insert(constraints.end(), e.constraints.begin(), e.constraints.end());
   }
-  explicit InequalityConstraints(std::vector<Variable> c) : constraints{std::move(c)} {}
+  explicit InequalityConstraintsF64(std::vector<VariableF64> c) : constraints{std::move(c)} {}
   explicit operator bool() const {
     for (auto& c : constraints)
       if (!(c.value() >= 0.0)) return false;
@@ -544,37 +546,94 @@ struct InequalityConstraints {
 template <typename L, typename R>
   requires(detail::ScalarOperand<L> || detail::MatrixOperand<L>) && (detail::ScalarOperand<R> || detail::MatrixOperand<R>) &&
           (detail::SleipnirOperand<L> || detail::SleipnirOperand<R>)
-EqualityConstraints operator==(const L& lhs, const R& rhs) {
-  return EqualityConstraints{detail::make_constraints(lhs, rhs)};
+EqualityConstraintsF64 operator==(const L& lhs, const R& rhs) {
+  return EqualityConstraintsF64{detail::make_constraints(lhs, rhs)};
 }
 template <typename L, typename R>
   requires(detail::ScalarOperand<L> || detail::MatrixOperand<L>) && (detail::ScalarOperand<R> || detail::MatrixOperand<R>) &&
           (detail::SleipnirOperand<L> || detail::SleipnirOperand<R>)
-InequalityConstraints operator>=(const L& lhs, const R& rhs) {
-  return InequalityConstraints{detail::make_constraints(lhs, rhs)};
+InequalityConstraintsF64 operator>=(const L& lhs, const R& rhs) {
+  return InequalityConstraintsF64{detail::make_constraints(lhs, rhs)};
 }
 template <typename L, typename R>
   requires(detail::ScalarOperand<L> || detail::MatrixOperand<L>) && (detail::ScalarOperand<R> || detail::MatrixOperand<R>) &&
           (detail::SleipnirOperand<L> || detail::SleipnirOperand<R>)
-InequalityConstraints operator<=(const L& lhs, const R& rhs) {
+InequalityConstraintsF64 operator<=(const L& lhs, const R& rhs) {
   return rhs >= lhs;
 }
 template <typename L, typename R>
   requires(detail::ScalarOperand<L> || detail::MatrixOperand<L>) && (detail::ScalarOperand<R> || detail::MatrixOperand<R>) &&
           (detail::SleipnirOperand<L> || detail::SleipnirOperand<R>)
-InequalityConstraints operator>(const L& lhs, const R& rhs) {
+InequalityConstraintsF64 operator>(const L& lhs, const R& rhs) {
   return lhs >= rhs;
 }
 template <typename L, typename R>
   requires(detail::ScalarOperand<L> || detail::MatrixOperand<L>) && (detail::ScalarOperand<R> || detail::MatrixOperand<R>) &&
           (detail::SleipnirOperand<L> || detail::SleipnirOperand<R>)
-InequalityConstraints operator<(const L& lhs, const R& rhs) {
+InequalityConstraintsF64 operator<(const L& lhs, const R& rhs) {
   return rhs >= lhs;
 }
 
 template <typename L, typename X, typename U>
-InequalityConstraints bounds(const L& l, const X& x, const U& u) {
-  return InequalityConstraints{l <= x, x <= u};
+InequalityConstraintsF64 bounds(const L& l, const X& x, const U& u) {
+  return InequalityConstraintsF64{l <= x, x <= u};
 }
+
+
+// ---------------------------------------------------------------------------
+// The reference's spellings: slp::Variable<Scalar>, VariableMatrix<Scalar>, VariableBlock<...>,
+// EqualityConstraints<Scalar>, InequalityConstraints<Scalar>
+// (include/sleipnir/autodiff/variable.hpp:52, variable_matrix.hpp:43, variable.hpp:832,877).
+// Only Scalar = double exists: the expression graph, the tapes and every kernel behind it are
+// fp64.  The specializations ARE the fp64 classes above (derived, constructors inherited), so
+// every operator and function of this header serves them, `slp::Variable J = 0.0;` deduces
+// Variable<double> like the reference's deduction guides do (variable.hpp:283-295), and
+// `auto X = problem.decision_variable(4, N + 1)` is assignable to a VariableMatrix<double>.
+// ---------------------------------------------------------------------------
+template <typename Scalar>
+class Variable;
+template <typename Scalar>
+class VariableMatrix;
+template <typename Scalar>
+struct EqualityConstraints;
+template <typename Scalar>
+struct InequalityConstraints;
+
+template <>
+class Variable<double> : public VariableF64 {
+ public:
+  using VariableF64::VariableF64;
+  using VariableF64::operator=;
+  Variable() = default;
+  Variable(const VariableF64& v) : VariableF64{v} {}  // NOLINT
+};
+Variable() -> Variable<double>;
+Variable(double) -> Variable<double>;
+Variable(std::integral auto) -> Variable<double>;
+Variable(const VariableF64&) -> Variable<double>;
+Variable(const VariableMatrixF64&) -> Variable<double>;
+Variable(const VariableBlockF64&) -> Variable<double>;
+
+template <>
+class VariableMatrix<double> : public VariableMatrixF64 {
+ public:
+  using VariableMatrixF64::VariableMatrixF64;
+  using VariableMatrixF64::operator=;
+  VariableMatrix() = default;
+  VariableMatrix(const VariableMatrixF64& m) : VariableMatrixF64{m} {}   // NOLINT
+  VariableMatrix(VariableMatrixF64&& m) : VariableMatrixF64{std::move(m)} {}  // NOLINT
+  VariableMatrix(const VariableBlockF64& b) : VariableMatrixF64{b} {}    // NOLINT
+};
+
+template <>
+struct EqualityConstraints<double> : public EqualityConstraintsF64 {
+  using EqualityConstraintsF64::EqualityConstraintsF64;
+  EqualityConstraints(const EqualityConstraintsF64& c) : EqualityConstraintsF64{c} {}  // NOLINT
+};
+template <>
+struct InequalityConstraints<double> : public InequalityConstraintsF64 {
+  using InequalityConstraintsF64::InequalityConstraintsF64;
+  InequalityConstraints(const InequalityConstraintsF64& c) : InequalityConstraintsF64{c} {}  // NOLINT
+};
 
 }  // namespace slp

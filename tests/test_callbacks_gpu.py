@@ -78,3 +78,27 @@ def test_callback_matrices_follow_the_static_patterns():
     assert np.isfinite(Ae).all() and np.abs(Ae).sum() > 0
     assert np.linalg.matrix_rank(Ae) == m_e
     p.close()
+
+
+def test_model_changes_after_a_solve_are_honoured(fresh, slpx):
+    """compile() used to keep the first compiled system for good, so constraints, costs
+    or variables added after a solve() — and changed values of parameters — were silently ignored.
+    The reference rebuilds its evaluators in every solve() (problem.hpp:517-660)."""
+    from tests.support import model
+
+    m = model.Model(model.ProductBackend("gpu"))
+    m.be.reset()
+    P = model.NlpProblem
+    p = P(m)
+    x, y = p.decision_variable(1.0), p.decision_variable(1.0)
+    a = m.variable(3.0)  # a free Variable that is not a decision variable: a parameter
+    p.minimize(m.pow(x - a, 2) + m.pow(y - 1, 2))
+    assert p.solve() == P.SUCCESS
+    assert abs(x.value() - 3.0) <= 1e-6 and abs(y.value() - 1.0) <= 1e-6
+    a.set_value(-2.0)               # parameter change: folded constants are stale
+    assert p.solve() == P.SUCCESS
+    assert abs(x.value() + 2.0) <= 1e-6
+    p.le(x + y, -4.0)               # new constraint after two solves
+    assert p.solve() == P.SUCCESS
+    assert x.value() + y.value() <= -4.0 + 1e-6
+    assert abs((x.value() + 2.0) - (y.value() - 1.0)) <= 1e-5   # projection onto x + y = -4 from (-2, 1)

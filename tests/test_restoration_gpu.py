@@ -68,3 +68,24 @@ def test_trajectory_tracks_oracle_at_the_start(fresh, slpx, orc, N):
     first_o = next((int(r[0]) for r in to if r[1] != n), None)
     print(f"N={N}: first restoration iteration within the window: product {first_p}, oracle {first_o}")
     pp.close()
+
+
+@pytest.mark.parametrize("N", [50, 300, 500, 1000])
+def test_whole_solve_status_matches_oracle_at_baseline_horizons(fresh, slpx, orc, N):
+    """the swing-up at the BASELINE horizons ends in the same exit status as
+    the oracle (same elimination order).  Iteration counts are recorded, not pinned: the two runs
+    leave each other after ~10 iterations (test above), so they differ by tens of percent either
+    way (N=50: 624 vs 179, N=300: 362 vs 324, N=1000: 2902 vs 1003 when this was written)."""
+    pp, op = cases.build_pair("cart_pole", N, slpx, orc)
+    perm = pp.system().perm()
+    status, rep = pp.solve()
+    so, stats = op.solve(perm=perm)
+    print(f"N={N}: product status {status} in {rep['iterations']} iterations ({rep['restorations']} restorations, "
+          f"{rep['t_total']:.3f} s); oracle status {so} in {int(stats['iterations'])} iterations ({stats['t_total']:.1f} s)")
+    assert status == so
+    if status == 0:
+        # both ended on a KKT point of the same problem: the swing-up is reached (cart_pole_problem_test.cpp:87-124)
+        X, U = cases.cart_pole_unpack(pp.get_x(), N)
+        assert np.max(np.abs(X[:, 0])) <= 1e-6 and np.max(np.abs(X[:, -1] - np.array([1.0, np.pi, 0.0, 0.0]))) <= 1e-6
+        assert np.max(np.abs(U)) <= 20.0 + 1e-6
+    pp.close()

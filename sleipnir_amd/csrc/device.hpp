@@ -81,7 +81,7 @@ struct TapeDevice {
   uint32_t tmpl_blocks[2] = {0, 0};
   uint32_t n_templated_tasks = 0;
   double jit_seconds = 0.0;
-  void upload(const TapeProgram& p, int batch);
+  void upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs);
   TapeDev view() const;
 };
 

@@ -346,11 +346,13 @@ __global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::Sum
 // DeviceNlp
 // ============================================================================
 
-void TapeDevice::upload(const TapeProgram& p, int batch) {
+void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs) {
   tasks.upload(p.tasks);
   // families of structurally identical tasks and the big singles get a body in the
   // generated lane-per-task kernel; everything else is interpreted
-  const TapeJitResult jit = build_tape_templates(p);
+  TapeJitOptions jit_opt;
+  jit_opt.n_unscaled_inputs = n_unscaled_inputs;  // x: set_scaling leaves their factor at 1
+  const TapeJitResult jit = build_tape_templates(p, jit_opt);
   jit_seconds = jit.compile_seconds;
   tmpl_fn = jit.fn;
   tmpl_mod = jit.mod;
@@ -453,8 +455,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     throw std::runtime_error("slpx: no HIP device available (the product path has no CPU fallback)");
   SLPX_HIP_CHECK(hipSetDevice(device));
 
-  m_full.upload(s.full, batch);
-  m_values.upload(s.values, batch);
+  m_full.upload(s.full, batch, static_cast<uint32_t>(s.n));
+  m_values.upload(s.values, batch, static_cast<uint32_t>(s.n));
   m_reduces.upload(s.reduces);
   // allow > 64 KB dynamic LDS
   for (const void* fn : {reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, true>),

@@ -60,6 +60,9 @@ struct TapeJitOptions {
   uint32_t max_bodies = 8;
   bool compile_without_device = false;  // tests: check that the generated source compiles
   uint32_t max_generated_nodes = 4000;  // code-size / compile-time cap over all bodies
+  // inputs [0, n) whose scale factor (in_scale) is identically 1: the decision variables
+  // (DeviceNlp::set_scaling scales only the multiplier inputs); leaves bound to them skip the factor
+  uint32_t n_unscaled_inputs = 0;
 };
 
 // Groups the LDS-class tasks of `prog` by identical structure and output wiring, picks the
@@ -68,8 +71,10 @@ struct TapeJitOptions {
 // reason is put in `log`.
 TapeJitResult build_tape_templates(const TapeProgram& prog, const TapeJitOptions& opt = {});
 
-// The generated source for a set of representative tasks (exposed for tests / inspection).
-std::string generate_templates_source(const TapeProgram& prog, const std::vector<uint32_t>& representatives);
+// The generated source for a set of families (members in instance order; exposed for tests /
+// inspection).  The bindings of each body are specialized for its family, see tape_jit.cpp.
+std::string generate_templates_source(const TapeProgram& prog, const std::vector<std::vector<uint32_t>>& families,
+                                      uint32_t n_unscaled_inputs);
 
 // Number of wave-uniform row groups the adjoint part of a template is split into.
 uint32_t template_row_groups(const TapeProgram& prog, const TapeTask& representative);

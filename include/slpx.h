@@ -147,6 +147,12 @@ void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double*
 int slpx_problem_restoration_steps(slpx_problem* p, const slpx_options* opt, double* x, double* s, double* y,
                                    double* z, double mu, int32_t steps);
 
+/* Build-time helper (no reference counterpart; needs NO device): compiles the model's structure
+ * on the host, generates its tape kernels and cross-compiles them for gfx950 with hipRTC into
+ * `dir` (NULL: <directory of libslpx.so>/jit_cache, where slpx_system_create looks before it
+ * compiles anything).  Returns the number of generated bodies, < 0 on failure. */
+int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir);
+
 /* The reference's benchmark models, built with the C++ slp:: surface:
  * benchmarks/scalability/cart_pole/sleipnir.cpp:76-129, .../flywheel/sleipnir.cpp:12-42 */
 slpx_problem* slpx_problem_cart_pole(int32_t N, double dt);

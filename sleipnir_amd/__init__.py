@@ -59,6 +59,24 @@ class Report(ctypes.Structure):
                 ("t_restoration", ctypes.c_double)]
 
 
+PREBUILT_MODELS = (("cart_pole", 1000), ("cart_pole", 500), ("cart_pole", 5000), ("cart_pole", 100))
+
+
+def prebuild_kernels(models=PREBUILT_MODELS) -> int:
+    """Code objects of the generated tape kernels of the BASELINE models into
+    sleipnir_amd/jit_cache/ (built artefacts like libslpx.so: they travel with the tree, not with
+    the history).  hipRTC cross-compiles for gfx950 without a device; ~1 s per model, skipped for
+    code objects that are already there."""
+    total = 0
+    for kind, N in models:
+        lib().slpx_graph_reset()
+        p = Problem.cart_pole(N, 5.0 / N) if kind == "cart_pole" else Problem.flywheel(N, 5.0 / N)
+        total += p.prebuild_kernels()
+        p.close()
+    lib().slpx_graph_reset()
+    return total
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile libslpx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     cmd = ["make", "-C", str(_PKG / "csrc"), "-j", str(os.cpu_count() or 4)]
@@ -117,6 +135,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_problem_solve", ctypes.c_int, vp, ctypes.POINTER(Options), ctypes.POINTER(Report))
     sig("slpx_problem_get_duals", None, vp, vp, vp, vp)
     sig("slpx_problem_restoration_steps", ctypes.c_int, vp, ctypes.POINTER(Options), vp, vp, vp, vp, f64, i32)
+    sig("slpx_problem_prebuild_kernels", ctypes.c_int, vp, ctypes.c_char_p)
     sig("slpx_problem_cart_pole", vp, i32, f64)
     sig("slpx_problem_flywheel", vp, i32, f64)
     sig("slpx_system_create", vp, vp, i32, i32, vp, i32)
@@ -272,6 +291,14 @@ class Problem:
         cb = IterationCallback(trampoline)
         self._callbacks = getattr(self, "_callbacks", []) + [cb]  # keep the thunks alive
         _check(lib().slpx_problem_add_callback(self._h, ctypes.cast(cb, ctypes.c_void_p), None))
+
+    def prebuild_kernels(self, directory=None) -> int:
+        """Cross-compile this model's generated tape kernels for gfx950 into the library's
+        jit_cache (slpx_problem_prebuild_kernels; needs no device)."""
+        n = lib().slpx_problem_prebuild_kernels(self._h, None if directory is None else str(directory).encode())
+        if n < 0:
+            raise SlpxError(lib().slpx_last_error().decode())
+        return n
 
     def system(self) -> "System":
         """The system solve() runs on (slpx_problem_system); owned by the problem."""

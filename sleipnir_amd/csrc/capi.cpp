@@ -7,7 +7,12 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
+#include <filesystem>
+
 #include "capi_internal.hpp"
+#include "tape_jit.hpp"
 #include "problems.hpp"
 
 namespace {
@@ -178,6 +183,34 @@ void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double*
   if (s) std::copy(p->problem.slack().begin(), p->problem.slack().end(), s);
   if (y) std::copy(p->problem.equality_duals().begin(), p->problem.equality_duals().end(), y);
   if (z) std::copy(p->problem.inequality_duals().begin(), p->problem.inequality_duals().end(), z);
+}
+
+int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
+  int bodies = -1;
+  const int rc = guard([&] {
+    std::vector<slpx::NodeId> xs, ce, ci;
+    for (auto& v : p->problem.decision_variables()) xs.push_back(v.expr);
+    for (auto& v : p->problem.equality_constraints()) ce.push_back(v.expr);
+    for (auto& v : p->problem.inequality_constraints()) ci.push_back(v.expr);
+    const slpx::NodeId f =
+        p->problem.cost_function_type() == slp::ExpressionType::NONE ? slpx::kNull : p->problem.cost().expr;
+    const slpx::NlpStructure st = slpx::build_nlp_structure(slpx::graph(), xs, f, ce, ci, slpx::TapeCompileOptions{});
+    slpx::TapeJitOptions opt;
+    opt.n_unscaled_inputs = static_cast<uint32_t>(st.n);
+    std::string where = dir ? dir : "";
+    if (where.empty()) {
+      Dl_info info{};
+      if (dladdr(reinterpret_cast<const void*>(&slpx_problem_prebuild_kernels), &info) == 0 || !info.dli_fname)
+        throw std::runtime_error("slpx_problem_prebuild_kernels: cannot locate libslpx.so");
+      where = (std::filesystem::path(info.dli_fname).parent_path() / "jit_cache").string();
+    }
+    std::string log;
+    const int a = slpx::prebuild_tape_templates(st.full, opt, where, log);
+    const int b = slpx::prebuild_tape_templates(st.values, opt, where, log);
+    if (a < 0 || b < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
+    bodies = a + b;
+  });
+  return rc == 0 ? bodies : rc;
 }
 
 slpx_problem* slpx_problem_cart_pole(int32_t N, double dt) {

@@ -3,6 +3,7 @@
 #include "setup_timing.hpp"
 
 #include <algorithm>
+#include <future>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,12 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   // graph launches, A/B measurements)
   if (const char* env = std::getenv("SLPX_STEP_GRAPH")) m_opt.use_step_graph = env[0] != '0';
   SetupLap lap;
+  // the HIP runtime comes up (context, first allocation: 50-700 ms in a fresh process) while the
+  // host compiles the model
+  auto device_job = std::async(std::launch::async, [device = opt.device] {
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+    (void)hipGetLastError();
+  });
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
   lap("= AD structure + tape compile");
   m_k = build_kkt_plan(m_s);
@@ -56,6 +63,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
   }
   lap("= LDLT symbolic");
+  device_job.get();
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
   lap("= device upload + tape JIT");
   reset_regularization();

@@ -5,6 +5,7 @@
 #include <unordered_map>
 
 #include <algorithm>
+#include <future>
 #include <functional>
 #include <stdexcept>
 
@@ -328,10 +329,12 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   }
 
   lap("V layout, separable sums");
+  // the two tapes only read the graph: the small one (values only) compiles on a second thread
+  auto values_job = std::async(std::launch::async, [&] { return compile_tape(g, inputs, live_vouts, {}, opt); });
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);
   lap("tape compile (full)");
-  s.values = compile_tape(g, inputs, live_vouts, {}, opt);
-  lap("tape compile (values)");
+  s.values = values_job.get();
+  lap("tape compile (values): the wait");
   s.full.n_inputs = s.values.n_inputs = s.n_inputs();
   s.full.n_outputs = s.values.n_outputs = s.nV;
   return s;

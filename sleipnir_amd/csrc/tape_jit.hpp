@@ -63,6 +63,8 @@ struct TapeJitOptions {
   // inputs [0, n) whose scale factor (in_scale) is identically 1: the decision variables
   // (DeviceNlp::set_scaling scales only the multiplier inputs); leaves bound to them skip the factor
   uint32_t n_unscaled_inputs = 0;
+  // non-empty: generate + compile WITHOUT a device and store the code object there (prebuild_tape_templates)
+  std::string prebuild_dir;
 };
 
 // Groups the LDS-class tasks of `prog` by identical structure and output wiring, picks the
@@ -70,6 +72,12 @@ struct TapeJitOptions {
 // kernel.  Never throws: on any hipRTC problem everything stays on the interpreter and the
 // reason is put in `log`.
 TapeJitResult build_tape_templates(const TapeProgram& prog, const TapeJitOptions& opt = {});
+
+// Generates and compiles the kernel of `prog` for gfx950 without a device and stores the code
+// object under `dir` (file name = hash of the generated source, as in the user cache), where
+// build_tape_templates looks first (<libslpx.so dir>/jit_cache by default).  Returns the number
+// of bodies, 0 if the program has no family worth one, -1 if hipRTC rejected the source.
+int prebuild_tape_templates(const TapeProgram& prog, const TapeJitOptions& opt, const std::string& dir, std::string& log);
 
 // The generated source for a set of families (members in instance order; exposed for tests /
 // inspection).  The bindings of each body are specialized for its family, see tape_jit.cpp.

@@ -685,6 +685,245 @@ inline ExitStatus interior_point(const MatrixCallbacks& matrices,
 }
 
 // ----------------------------------------------------------------------------
+// sqp.hpp:98-604 — problems with equality constraints only (problem.hpp:403).  The
+// MatrixCallbacks of the interior-point method are used with no inequality rows.
+// ----------------------------------------------------------------------------
+inline ExitStatus sqp(const MatrixCallbacks& matrices, std::vector<IterationCallback>& iteration_callbacks,
+                      const Options& options, Vec& x, Vec& y, int& iterations, SolveStats* stats = nullptr,
+                      const std::vector<int>* user_perm = nullptr) {
+  using clock = std::chrono::steady_clock;
+  const auto solve_start_time = clock::now();
+  const int n = matrices.num_decision_variables;
+  const int m_e = matrices.num_equality_constraints;
+  const Vec none;
+  const CSC no_rows(0, n);
+
+  double f = matrices.f(x);
+  Vec g = matrices.g(x);
+  CSC H = matrices.H(x, y, none);
+  Vec c_e = matrices.c_e(x);
+  CSC A_e = matrices.A_e(x);
+  Vec trial_x, trial_y, trial_c_e;
+  double trial_f;
+
+  if (m_e > n) return ExitStatus::TOO_FEW_DOFS;  // :205-210
+  if (!std::isfinite(f) || !all_finite(g) || !all_finite(H) || !all_finite(c_e) || !all_finite(A_e))
+    return ExitStatus::NONFINITE_INITIAL_GUESS;  // :213-216
+
+  Filter filter{norm_1(c_e)};  // :220
+  const int lhs_rows = n + m_e;
+  RegularizedLDLT solver{double(H.nnz() + A_e.nnz()) < 0.25 * double(lhs_rows) * double(lhs_rows), n, m_e};  // :238-240
+  if (user_perm != nullptr && !user_perm->empty()) solver.set_permutation(*user_perm);
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-7;
+  int full_step_rejected_counter = 0;
+  auto error = [&](const Vec& gg, const CSC& Ae, const Vec& ce, const Vec& yy) {  // kkt_error.hpp (SQP overloads)
+    return unscaled_kkt_error<KKTErrorType::INF_NORM_SCALED>(matrices.scaling, gg, Ae, ce, no_rows, none, none, yy,
+                                                             none, 0.0);
+  };
+  double E_0 = error(g, A_e, c_e, y);
+
+  while (E_0 > options.tolerance) {
+    if (is_equality_locally_infeasible(A_e, c_e)) return ExitStatus::LOCALLY_INFEASIBLE;  // :277
+    if (norm_inf(x) > 1e10 || !all_finite(x)) return ExitStatus::DIVERGING_ITERATES;      // :288
+    for (const auto& callback : iteration_callbacks)
+      if (callback({iterations, x, none, y, none, g, H, A_e, no_rows})) return ExitStatus::CALLBACK_REQUESTED_STOP;
+
+    // :305-325  lhs = [H A_e^T; A_e 0] (lower), rhs = -[g - A_e^T y; c_e]
+    CSC lhs = build_kkt_lhs(H, A_e, no_rows, none, none);
+    Vec rhs = build_kkt_rhs(g, A_e, no_rows, c_e, none, none, y, none, 0.0);
+    if (solver.compute(lhs).info() != Success) return ExitStatus::FACTORIZATION_FAILED;  // :336
+    if (stats) stats->factorizations += solver.factorizations();
+    auto compute_step = [&](Vec& px, Vec& py) {
+      Vec p = solver.solve(rhs);
+      if (stats) ++stats->solves;
+      px.assign(p.begin(), p.begin() + n);
+      py.resize(m_e);
+      for (int j = 0; j < m_e; ++j) py[j] = -p[n + j];
+    };
+    Vec p_x, p_y;
+    compute_step(p_x, p_y);
+
+    constexpr double alpha_max = 1.0;
+    double alpha = alpha_max;
+    bool call_feasibility_restoration = false;
+    const FilterEntry current_entry{f, norm_1(c_e)};
+    const double D_phi = dot(g, p_x);  // :360
+
+    while (true) {
+      trial_x = axpy(x, alpha, p_x);
+      trial_y = axpy(y, alpha, p_y);
+      trial_f = matrices.f(trial_x);
+      trial_c_e = matrices.c_e(trial_x);
+      if (!std::isfinite(trial_f) || !all_finite(trial_c_e)) {  // :373-384
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) {
+          call_feasibility_restoration = true;
+          break;
+        }
+        continue;
+      }
+      if (filter.try_add(current_entry, FilterEntry{trial_f, norm_1(trial_c_e)}, D_phi, alpha)) break;
+
+      const double prev_violation = norm_1(c_e);
+      double next_violation = norm_1(trial_c_e);
+      if (alpha == alpha_max && next_violation >= prev_violation) {  // :397-468 second-order corrections
+        Vec soc_px = p_x, soc_py = p_y, c_e_soc = c_e;
+        const double alpha_soc = alpha;
+        double soc_violation = next_violation;
+        bool step_acceptable = false;
+        for (int soc_iteration = 0; soc_iteration < 5 && !step_acceptable; ++soc_iteration) {
+          for (int j = 0; j < m_e; ++j) c_e_soc[j] = alpha_soc * c_e_soc[j] + trial_c_e[j];
+          for (int j = 0; j < m_e; ++j) rhs[n + j] = -c_e_soc[j];
+          compute_step(soc_px, soc_py);
+          trial_x = axpy(x, alpha_soc, soc_px);
+          trial_y = axpy(y, alpha_soc, soc_py);
+          trial_f = matrices.f(trial_x);
+          trial_c_e = matrices.c_e(trial_x);
+          if (filter.try_add(current_entry, FilterEntry{trial_f, norm_1(trial_c_e)}, D_phi, alpha)) {
+            p_x = soc_px;
+            p_y = soc_py;
+            alpha = alpha_soc;
+            step_acceptable = true;
+            break;
+          }
+          constexpr double kappa_soc = 0.99;
+          next_violation = norm_1(trial_c_e);
+          if (next_violation > kappa_soc * soc_violation) break;
+          soc_violation = next_violation;
+        }
+        if (step_acceptable) break;
+      }
+      if (alpha == alpha_max) ++full_step_rejected_counter;
+      if (full_step_rejected_counter >= 4 && filter.max_constraint_violation > current_entry.constraint_violation / 10.0 &&
+          filter.last_rejection_due_to_filter()) {
+        filter.max_constraint_violation *= 0.1;
+        filter.reset();
+        continue;
+      }
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {  // :492-517
+        const double current_kkt = kkt_error<KKTErrorType::ONE_NORM>(g, A_e, c_e, no_rows, none, none, y, none, 0.0);
+        trial_x = axpy(x, alpha_max, p_x);
+        trial_y = axpy(y, alpha_max, p_y);
+        trial_f = matrices.f(trial_x);
+        trial_c_e = matrices.c_e(trial_x);
+        const double next_kkt = kkt_error<KKTErrorType::ONE_NORM>(matrices.g(trial_x), matrices.A_e(trial_x), trial_c_e,
+                                                                  no_rows, none, none, trial_y, none, 0.0);
+        if (next_kkt <= 0.999 * current_kkt) break;
+        call_feasibility_restoration = true;
+        break;
+      }
+    }
+
+    if (call_feasibility_restoration) {  // :521-556
+      const FilterEntry initial_entry{matrices.f(x), norm_1(c_e)};
+      std::vector<IterationCallback> callbacks;
+      for (auto& cb : iteration_callbacks) callbacks.push_back(cb);
+      callbacks.push_back([&](const IterationInfo& info) {
+        Vec tx(info.x.begin(), info.x.begin() + n);
+        const Vec tce = matrices.c_e(tx);
+        const FilterEntry trial_entry{matrices.f(tx), norm_1(tce)};
+        const double D_phi_restoration = dot(g, vsub(tx, x));
+        return trial_entry.constraint_violation < 0.9 * initial_entry.constraint_violation &&
+               filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      });
+      // feasibility_restoration.hpp:103-345: the interior-point variant with no inequality rows of
+      // the original problem and mu = tolerance / 10
+      Vec s_none, z_none;
+      const ExitStatus status = feasibility_restoration(matrices, callbacks, options, x, s_none, y, z_none,
+                                                        options.tolerance / 10.0, iterations, stats);
+      if (status != ExitStatus::SUCCESS) return status;
+      f = matrices.f(x);
+      c_e = matrices.c_e(x);
+    } else {
+      if (alpha == alpha_max) full_step_rejected_counter = 0;
+      x = trial_x;
+      y = trial_y;
+      f = trial_f;
+      c_e = trial_c_e;
+    }
+    A_e = matrices.A_e(x);  // :574-577
+    g = matrices.g(x);
+    H = matrices.H(x, y, none);
+    E_0 = error(g, A_e, c_e, y);
+    ++iterations;
+    if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
+    if (std::chrono::duration<double>(clock::now() - solve_start_time).count() > options.timeout) return ExitStatus::TIMEOUT;
+  }
+  return ExitStatus::SUCCESS;
+}
+
+// ----------------------------------------------------------------------------
+// newton.hpp:51-292 — unconstrained problems (problem.hpp:335)
+// ----------------------------------------------------------------------------
+inline ExitStatus newton(const MatrixCallbacks& matrices, std::vector<IterationCallback>& iteration_callbacks,
+                         const Options& options, Vec& x, int& iterations, SolveStats* stats = nullptr) {
+  using clock = std::chrono::steady_clock;
+  const auto solve_start_time = clock::now();
+  const int n = matrices.num_decision_variables;
+  const Vec none;
+  const CSC no_rows(0, n);
+  double f = matrices.f(x);
+  Vec g = matrices.g(x);
+  CSC H = matrices.H(x, none, none);
+  if (!std::isfinite(f) || !all_finite(g) || !all_finite(H)) return ExitStatus::NONFINITE_INITIAL_GUESS;  // :125
+  Filter filter{0.0};  // :131
+  RegularizedLDLT solver{double(H.nnz()) < 0.25 * double(n) * double(n), n, 0};  // :133-135
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-20;
+  auto error = [&](const Vec& gg) {
+    return unscaled_kkt_error<KKTErrorType::INF_NORM_SCALED>(matrices.scaling, gg, no_rows, none, no_rows, none, none,
+                                                             none, none, 0.0);
+  };
+  double E_0 = error(g);
+  Vec trial_x;
+  double trial_f;
+  while (E_0 > options.tolerance) {
+    if (norm_inf(x) > 1e10 || !all_finite(x)) return ExitStatus::DIVERGING_ITERATES;
+    for (const auto& callback : iteration_callbacks)
+      if (callback({iterations, x, none, none, none, g, H, no_rows, no_rows})) return ExitStatus::CALLBACK_REQUESTED_STOP;
+    if (solver.compute(H).info() != Success) return ExitStatus::FACTORIZATION_FAILED;
+    if (stats) stats->factorizations += solver.factorizations();
+    Vec neg_g(n);
+    for (int i = 0; i < n; ++i) neg_g[i] = -g[i];
+    Vec p_x = solver.solve(neg_g);  // :190
+    if (stats) ++stats->solves;
+    constexpr double alpha_max = 1.0;
+    double alpha = alpha_max;
+    const double D_phi = dot(g, p_x);
+    while (true) {  // :201-243
+      trial_x = axpy(x, alpha, p_x);
+      trial_f = matrices.f(trial_x);
+      if (!std::isfinite(trial_f)) {
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) return ExitStatus::LINE_SEARCH_FAILED;
+        continue;
+      }
+      if (filter.try_add(FilterEntry{f, 0.0}, FilterEntry{trial_f, 0.0}, D_phi, alpha)) break;
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {
+        const double current_kkt = norm_1(g);
+        trial_x = axpy(x, alpha_max, p_x);
+        const double next_kkt = norm_1(matrices.g(trial_x));
+        if (next_kkt <= 0.999 * current_kkt) {
+          trial_f = matrices.f(trial_x);
+          break;
+        }
+        return ExitStatus::LINE_SEARCH_FAILED;
+      }
+    }
+    x = trial_x;
+    f = trial_f;
+    g = matrices.g(x);
+    H = matrices.H(x, none, none);
+    E_0 = error(g);
+    ++iterations;
+    if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
+    if (std::chrono::duration<double>(clock::now() - solve_start_time).count() > options.timeout) return ExitStatus::TIMEOUT;
+  }
+  return ExitStatus::SUCCESS;
+}
+
+// ----------------------------------------------------------------------------
 // lagrange_multiplier_estimate.hpp:56-133
 // ----------------------------------------------------------------------------
 inline std::pair<Vec, Vec> lagrange_multiplier_estimate(const Vec& g, const CSC& A_e,

@@ -125,8 +125,26 @@ class Problem {
 
     std::vector<IterationCallback> callbacks = m_iteration_callbacks;
     auto t0 = std::chrono::steady_clock::now();
-    st = interior_point(m_ev->callbacks, callbacks, options, x, stats, user_perm, &last_s, &last_y,
-                        &last_z);
+    // problem.hpp:335, 403, 512: the solver follows the kinds of constraints present
+    if (m_equality_constraints.empty() && m_inequality_constraints.empty()) {
+      int iterations = 0;
+      st = newton(m_ev->callbacks, callbacks, options, x, iterations, stats);
+      if (stats) stats->iterations = iterations;
+      last_s.clear();
+      last_y.clear();
+      last_z.clear();
+    } else if (m_inequality_constraints.empty()) {
+      int iterations = 0;
+      Vec y(m_equality_constraints.size(), 0.0);  // problem.hpp:503-504
+      st = sqp(m_ev->callbacks, callbacks, options, x, y, iterations, stats, user_perm);
+      if (stats) stats->iterations = iterations;
+      last_s.clear();
+      last_y = y;
+      last_z.clear();
+    } else {
+      st = interior_point(m_ev->callbacks, callbacks, options, x, stats, user_perm, &last_s, &last_y,
+                          &last_z);
+    }
     if (stats)
       stats->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (size_t i = 0; i < x.size(); ++i) m_decision_variables[i].set_value(x[i]);  // :676

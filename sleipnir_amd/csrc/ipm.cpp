@@ -1156,6 +1156,378 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// The reference's other two solvers on the same device Newton step:
+// Problem::solve sends problems without constraints to newton() and problems with equality
+// constraints only to sqp() (problem.hpp:335, 403).  Both are the interior-point iteration
+// with its inequality machinery taken out — but not quite the m_i = 0 special case of it: SQP
+// moves y with the primal step size (the IPM would take alpha_z = 1), Newton's line search
+// goes down to alpha = 1e-20 and ends in LINE_SEARCH_FAILED instead of a restoration phase.
+// Host-resident drivers (one value sweep per trial point crosses PCIe): these are the small
+// problems of the reference's unit tests, not the benchmark path.
+// ---------------------------------------------------------------------------
+namespace {
+
+// sqp.hpp:98-604
+ExitStatus sqp_core(NewtonSystem& sys, const Vec& scales, const std::vector<IterationCallback>& callbacks,
+                    const Options& options, Vec& x, Vec& y, int& iterations, SolveReport& rep,
+                    clk::time_point solve_start) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n, m_e = st.m_e, dim = n + m_e;
+  const Vec none;  // no slacks, no inequality multipliers
+  double mu0 = 0.0;
+
+  sys.reset_regularization();
+  sys.set_gamma_min(1e-10);  // sparse_regularized_ldlt.hpp:197 (the constructor of sqp.hpp:238-240 passes none)
+
+  Vec V(st.nV), Vtrial(st.nV);
+  auto refresh_full = [&](const Vec& xx, const Vec& yy) {
+    dev.upload_x(xx.data());
+    dev.upload_duals(none.data(), yy.data(), none.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+  };
+  auto eval_values = [&](const Vec& xx) {
+    dev.upload_x(xx.data());
+    dev.sweep_values();
+    dev.download(dev.d_V(), Vtrial.data(), static_cast<size_t>(st.off_g));
+    ++rep.value_sweeps;
+  };
+
+  auto t_setup = clk::now();
+  refresh_full(x, y);  // :182-186
+  VView cur{st, V};
+  Vec g = cur.g_dense();
+  if (m_e > n) return ExitStatus::TOO_FEW_DOFS;                                   // :205-210
+  if (!all_finite(V.data(), st.nV)) return ExitStatus::NONFINITE_INITIAL_GUESS;  // :213-216
+
+  double f = cur.f();
+  Vec c_e(cur.c_e(), cur.c_e() + m_e);
+  Filter filter{norm_1(c_e.data(), m_e)};  // :220
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-7;
+  int full_step_rejected_counter = 0;
+  const bool identity = scaling_is_identity(st, scales);
+  auto E0_of = [&](const Vec& gg, const Vec& ce, const Vec& yy) {
+    return kkt_error_impl<ErrType::INF_NORM_SCALED>(st, gg, cur.Ae(), ce.data(), nullptr, nullptr, none, yy, none,
+                                                    0.0, identity ? nullptr : &scales);
+  };
+  double E_0 = E0_of(g, c_e, y);  // :253-254
+  rep.t_setup = since(t_setup);
+
+  Vec p(dim), p_x(n), p_y(m_e), trial_x, trial_y, trial_c_e(m_e);
+  double trial_f = 0.0;
+  auto read_trial = [&] {
+    trial_f = Vtrial[st.off_f];
+    std::copy(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e, trial_c_e.begin());
+  };
+  auto solve_step = [&](Vec& px, Vec& py) {
+    dev.download(dev.d_p(), p.data(), dim);
+    std::copy(p.begin(), p.begin() + n, px.begin());
+    for (int j = 0; j < m_e; ++j) py[j] = -p[n + j];
+  };
+
+  while (E_0 > options.tolerance) {
+    // :277-292 infeasibility / divergence checks
+    if (m_e > 0) {
+      Vec t(n, 0.0);
+      add_At_v(st.Ae, cur.Ae(), nullptr, c_e.data(), 1.0, t);
+      double nt = 0.0, nc = 0.0;
+      for (double v : t) nt += v * v;
+      for (double v : c_e) nc += v * v;
+      if (std::sqrt(nt) < 1e-6 && std::sqrt(nc) > 1e-2) return ExitStatus::LOCALLY_INFEASIBLE;
+    }
+    if (norm_inf(x.data(), n) > 1e10 || !all_finite(x.data(), n)) return ExitStatus::DIVERGING_ITERATES;
+    for (const auto& cb : callbacks)
+      if (cb({iterations, x, none, y, none, V, &st, false})) return ExitStatus::CALLBACK_REQUESTED_STOP;
+
+    // ---- Newton-KKT step on the device: [H A_e^T; A_e 0] [p_x; -p_y] = -[g - A_e^T y; c_e] (:305-346) ----
+    auto t0 = clk::now();
+    dev.upload_x(x.data());
+    dev.upload_duals(none.data(), y.data(), none.data());
+    dev.upload_mu(&mu0);
+    dev.assemble();
+    dev.build_rhs();
+    rep.t_kkt_build += since(t0);
+    t0 = clk::now();
+    auto info = sys.compute(/*solve_speculatively=*/true);
+    rep.factorizations += sys.last_factorizations();
+    rep.t_kkt_decomp += since(t0);
+    if (info[0] != FactorInfo::Success) return ExitStatus::FACTORIZATION_FAILED;  // :336-338
+    rep.delta = sys.hessian_regularization()[0];
+    rep.gamma = sys.constraint_jacobian_regularization()[0];
+    t0 = clk::now();
+    rep.solves += sys.last_factorizations();
+    solve_step(p_x, p_y);
+    rep.t_kkt_solve += since(t0);
+
+    t0 = clk::now();
+    constexpr double alpha_max = 1.0;
+    double alpha = alpha_max;
+    bool call_feasibility_restoration = false;
+    const FilterEntry current_entry{f, norm_1(c_e.data(), m_e)};
+    double D_phi = 0.0;  // :360
+    for (int i = 0; i < n; ++i) D_phi += g[i] * p_x[i];
+
+    while (true) {  // :364
+      trial_x = axpy(x, alpha, p_x);
+      trial_y = axpy(y, alpha, p_y);
+      eval_values(trial_x);
+      read_trial();
+      if (!std::isfinite(trial_f) || !all_finite(trial_c_e.data(), m_e)) {  // :373-384
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) {
+          call_feasibility_restoration = true;
+          break;
+        }
+        continue;
+      }
+      if (filter.try_add(current_entry, FilterEntry{trial_f, norm_1(trial_c_e.data(), m_e)}, D_phi, alpha)) break;
+
+      const double prev_violation = norm_1(c_e.data(), m_e);
+      double next_violation = norm_1(trial_c_e.data(), m_e);
+      // second-order corrections (:397-468): new bottom rows of the rhs, SAME factorization
+      if (alpha == alpha_max && next_violation >= prev_violation) {
+        Vec soc_px = p_x, soc_py = p_y, c_e_soc = c_e;
+        const double alpha_soc = alpha;
+        double soc_violation = next_violation;
+        bool step_acceptable = false;
+        for (int it = 0; it < 5 && !step_acceptable; ++it) {
+          for (int j = 0; j < m_e; ++j) c_e_soc[j] = alpha_soc * c_e_soc[j] + trial_c_e[j];  // :435
+          Vec rhs(dim, 0.0);
+          for (int i = 0; i < n; ++i) rhs[i] = -g[i];
+          add_At_v(st.Ae, cur.Ae(), nullptr, y.data(), 1.0, rhs);
+          for (int j = 0; j < m_e; ++j) rhs[n + j] = -c_e_soc[j];
+          SLPX_HIP_CHECK(hipMemcpyAsync(dev.d_rhs(), rhs.data(), dim * sizeof(double), hipMemcpyHostToDevice,
+                                        dev.stream()));
+          dev.solve();
+          ++rep.solves;
+          solve_step(soc_px, soc_py);
+          trial_x = axpy(x, alpha_soc, soc_px);
+          trial_y = axpy(y, alpha_soc, soc_py);
+          eval_values(trial_x);
+          read_trial();
+          if (filter.try_add(current_entry, FilterEntry{trial_f, norm_1(trial_c_e.data(), m_e)}, D_phi, alpha)) {
+            p_x = soc_px;
+            p_y = soc_py;
+            alpha = alpha_soc;
+            step_acceptable = true;
+            break;
+          }
+          constexpr double kappa_soc = 0.99;
+          next_violation = norm_1(trial_c_e.data(), m_e);
+          if (next_violation > kappa_soc * soc_violation) break;
+          soc_violation = next_violation;
+        }
+        if (step_acceptable) break;
+      }
+      if (alpha == alpha_max) ++full_step_rejected_counter;  // :472-474
+      if (full_step_rejected_counter >= 4 && filter.max_constraint_violation > current_entry.constraint_violation / 10.0 &&
+          filter.last_rejection_due_to_filter()) {  // :478-485
+        filter.max_constraint_violation *= 0.1;
+        filter.reset();
+        continue;
+      }
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {  // :492-517
+        const double current_kkt = kkt_error_impl<ErrType::ONE_NORM>(st, g, cur.Ae(), c_e.data(), nullptr, nullptr, none,
+                                                                     y, none, 0.0, nullptr);
+        trial_x = axpy(x, alpha_max, p_x);
+        trial_y = axpy(y, alpha_max, p_y);
+        Vec Vt(st.nV);
+        dev.upload_x(trial_x.data());
+        dev.upload_duals(none.data(), trial_y.data(), none.data());
+        dev.sweep_full();
+        dev.download_V(Vt.data());
+        VView tv{st, Vt};
+        trial_f = tv.f();
+        std::copy(tv.c_e(), tv.c_e() + m_e, trial_c_e.begin());
+        const double next_kkt = kkt_error_impl<ErrType::ONE_NORM>(st, tv.g_dense(), tv.Ae(), tv.c_e(), nullptr, nullptr,
+                                                                  none, trial_y, none, 0.0, nullptr);
+        if (next_kkt <= 0.999 * current_kkt) break;
+        call_feasibility_restoration = true;
+        break;
+      }
+    }
+    rep.t_line_search += since(t0);
+
+    if (call_feasibility_restoration) {  // :521-556
+      refresh_full(x, y);  // the device V describes x again (the fallback above moved it)
+      const double f_x = cur.f();
+      const FilterEntry initial_entry{f_x, norm_1(c_e.data(), m_e)};
+      std::vector<IterationCallback> fr_callbacks = callbacks;
+      Vec g_here = cur.g_dense();
+      fr_callbacks.emplace_back([&, alpha](const IterationInfo& info) {
+        Vec tx(info.x.begin(), info.x.begin() + n);
+        eval_values(tx);
+        const double tf = Vtrial[st.off_f];
+        const double tviol = norm_1(Vtrial.data() + st.off_ce, m_e);
+        double D_phi_restoration = 0.0;
+        for (int i = 0; i < n; ++i) D_phi_restoration += g_here[i] * (tx[i] - x[i]);
+        return tviol < 0.9 * initial_entry.constraint_violation &&
+               filter.try_add(initial_entry, FilterEntry{tf, tviol}, D_phi_restoration, alpha);
+      });
+      // feasibility_restoration.hpp:103-345: the interior-point variant with no inequality rows
+      // of the original problem and mu = tolerance / 10
+      Vec s_none, z_none;
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s_none, y, z_none,
+                                                           options.tolerance / 10.0, iterations, rep, solve_start, c_e,
+                                                           Vec{});
+      if (fr_status != ExitStatus::SUCCESS) return fr_status;
+      sys.set_gamma_min(1e-10);
+    } else {
+      if (alpha == 1.0) full_step_rejected_counter = 0;
+      x = trial_x;
+      y = trial_y;
+    }
+    auto t1 = clk::now();
+    refresh_full(x, y);  // :574-577
+    rep.t_ad_refresh += since(t1);
+    g = cur.g_dense();
+    f = cur.f();
+    std::copy(cur.c_e(), cur.c_e() + m_e, c_e.begin());
+    E_0 = E0_of(g, c_e, y);
+    rep.final_error = E_0;
+    ++iterations;
+    if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
+    if (since(solve_start) > options.timeout) return ExitStatus::TIMEOUT;
+  }
+  return ExitStatus::SUCCESS;
+}
+
+// newton.hpp:51-292
+ExitStatus newton_core(NewtonSystem& sys, const Vec& scales, const std::vector<IterationCallback>& callbacks,
+                       const Options& options, Vec& x, int& iterations, SolveReport& rep,
+                       clk::time_point solve_start) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n;
+  const Vec none;
+  double mu0 = 0.0;
+  sys.reset_regularization();
+  sys.set_gamma_min(1e-10);  // no equality rows: unused
+
+  Vec V(st.nV), Vtrial(st.nV);
+  auto refresh_full = [&](const Vec& xx) {
+    dev.upload_x(xx.data());
+    dev.sweep_full();
+    dev.download_V(V.data());
+  };
+  auto eval_f = [&](const Vec& xx) {
+    dev.upload_x(xx.data());
+    dev.sweep_values();
+    dev.download(dev.d_V(), Vtrial.data(), static_cast<size_t>(st.off_g));
+    ++rep.value_sweeps;
+    return Vtrial[st.off_f];
+  };
+  refresh_full(x);
+  VView cur{st, V};
+  Vec g = cur.g_dense();
+  if (!all_finite(V.data(), st.nV)) return ExitStatus::NONFINITE_INITIAL_GUESS;  // :125-127
+  double f = cur.f();
+  Filter filter{0.0};  // :131
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-20;  // :138-139
+  const bool identity = scaling_is_identity(st, scales);
+  auto E0_of = [&](const Vec& gg) {
+    return kkt_error_impl<ErrType::INF_NORM_SCALED>(st, gg, nullptr, nullptr, nullptr, nullptr, none, none, none, 0.0,
+                                                    identity ? nullptr : &scales);
+  };
+  double E_0 = E0_of(g);
+  Vec p_x(n), trial_x;
+  double trial_f = 0.0;
+  while (E_0 > options.tolerance) {
+    if (norm_inf(x.data(), n) > 1e10 || !all_finite(x.data(), n)) return ExitStatus::DIVERGING_ITERATES;  // :164
+    for (const auto& cb : callbacks)
+      if (cb({iterations, x, none, none, none, V, &st, false})) return ExitStatus::CALLBACK_REQUESTED_STOP;
+    // H p_x = -g (:182-190)
+    auto t0 = clk::now();
+    dev.upload_x(x.data());
+    dev.upload_mu(&mu0);
+    dev.assemble();
+    dev.build_rhs();
+    auto info = sys.compute(/*solve_speculatively=*/true);
+    rep.factorizations += sys.last_factorizations();
+    rep.solves += sys.last_factorizations();
+    rep.t_kkt_decomp += since(t0);
+    if (info[0] != FactorInfo::Success) return ExitStatus::FACTORIZATION_FAILED;
+    rep.delta = sys.hessian_regularization()[0];
+    dev.download(dev.d_p(), p_x.data(), n);
+
+    t0 = clk::now();
+    constexpr double alpha_max = 1.0;
+    double alpha = alpha_max;
+    double D_phi = 0.0;
+    for (int i = 0; i < n; ++i) D_phi += g[i] * p_x[i];
+    while (true) {  // :201-243
+      trial_x = axpy(x, alpha, p_x);
+      trial_f = eval_f(trial_x);
+      if (!std::isfinite(trial_f)) {
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) return ExitStatus::LINE_SEARCH_FAILED;
+        continue;
+      }
+      if (filter.try_add(FilterEntry{f, 0.0}, FilterEntry{trial_f, 0.0}, D_phi, alpha)) break;
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {
+        const double current_kkt = norm_1(g.data(), n);
+        trial_x = axpy(x, alpha_max, p_x);
+        Vec Vt(st.nV);
+        dev.upload_x(trial_x.data());
+        dev.sweep_full();
+        dev.download_V(Vt.data());
+        VView tv{st, Vt};
+        const Vec tg = tv.g_dense();
+        if (norm_1(tg.data(), n) <= 0.999 * current_kkt) {
+          trial_f = tv.f();
+          break;
+        }
+        return ExitStatus::LINE_SEARCH_FAILED;
+      }
+    }
+    rep.t_line_search += since(t0);
+    x = trial_x;
+    f = trial_f;
+    refresh_full(x);  // :254-255
+    g = cur.g_dense();
+    E_0 = E0_of(g);
+    rep.final_error = E_0;
+    ++iterations;
+    if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
+    if (since(solve_start) > options.timeout) return ExitStatus::TIMEOUT;
+  }
+  return ExitStatus::SUCCESS;
+}
+
+}  // namespace
+
+ExitStatus sqp(NewtonSystem& sys, const std::vector<double>& scales, const std::vector<IterationCallback>& callbacks,
+               const Options& options, std::vector<double>& x, std::vector<double>* y_out, SolveReport* report) {
+  const auto solve_start = clk::now();
+  SolveReport local;
+  SolveReport& rep = report ? *report : local;
+  rep = SolveReport{};
+  Vec y(sys.structure().m_e, 0.0);  // problem.hpp:503-504
+  int iterations = 0;
+  const ExitStatus status = sqp_core(sys, scales, callbacks, options, x, y, iterations, rep, solve_start);
+  if (y_out) *y_out = y;
+  rep.iterations = iterations;
+  rep.t_total = since(solve_start);
+  return status;
+}
+
+ExitStatus newton(NewtonSystem& sys, const std::vector<double>& scales, const std::vector<IterationCallback>& callbacks,
+                  const Options& options, std::vector<double>& x, SolveReport* report) {
+  const auto solve_start = clk::now();
+  SolveReport local;
+  SolveReport& rep = report ? *report : local;
+  rep = SolveReport{};
+  int iterations = 0;
+  const ExitStatus status = newton_core(sys, scales, callbacks, options, x, iterations, rep, solve_start);
+  rep.iterations = iterations;
+  rep.t_total = since(solve_start);
+  return status;
+}
+
 ExitStatus feasibility_restoration_steps(NewtonSystem& sys, const std::vector<double>& scales,
                                          const Options& options, std::vector<double>& x,
                                          std::vector<double>& s, std::vector<double>& y,

@@ -86,6 +86,16 @@ struct SolveReport {
 // Scaling at x0 (util/problem_scaling.hpp:100-107) from an unscaled V.
 std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::vector<double>& V_raw);
 
+// The reference's solvers for problems without inequality constraints, on the same device
+// Newton step: sqp() (solver/sqp.hpp:98-604; equality constraints only, problem.hpp:403) and
+// newton() (solver/newton.hpp:51-292; unconstrained, problem.hpp:335).  x in/out.
+ExitStatus sqp(NewtonSystem& sys, const std::vector<double>& scales, const std::vector<IterationCallback>& callbacks,
+               const Options& options, std::vector<double>& x, std::vector<double>* y_out = nullptr,
+               SolveReport* report = nullptr);
+ExitStatus newton(NewtonSystem& sys, const std::vector<double>& scales,
+                  const std::vector<IterationCallback>& callbacks, const Options& options,
+                  std::vector<double>& x, SolveReport* report = nullptr);
+
 // feasibility_restoration (util/feasibility_restoration.hpp:347-628) on its own, from a given
 // iterate: builds the restoration model around (x, s), runs `steps` iterations of its
 // interior-point loop (a callback then stops it, the reference's own way out, :729-752) and, as

@@ -5,10 +5,9 @@
 // solve() compiles the model for the GPU (NewtonSystem) and runs the interior-point
 // iteration around the device Newton step.
 //
-// Scope of this round: the reference routes
-// unconstrained problems to newton() and equality-only problems to sqp()
-// (problem.hpp:335,403); this build always uses the interior-point path, which
-// contains both as special cases (m_i = 0 and/or m_e = 0).
+// Like the reference, solve() routes unconstrained problems to newton() and equality-only
+// problems to sqp() (problem.hpp:335,403), everything else to interior_point() — all three on
+// the same device Newton step (csrc/ipm.cpp).
 #pragma once
 
 #include <functional>
@@ -141,8 +140,21 @@ class ProblemF64 {
     m_scales = slpx::compute_problem_scaling(m_sys->structure(), V);
     dev.set_scaling(m_scales);
 
-    ExitStatus status = slpx::interior_point(*m_sys, m_scales, m_iteration_callbacks, options, x,
-                                             &m_s, &m_y, &m_z, &m_report);
+    // problem.hpp:335, 403, 512: the solver follows the kinds of constraints present
+    ExitStatus status;
+    if (m_equality_constraints.empty() && m_inequality_constraints.empty()) {
+      m_s.clear();
+      m_y.clear();
+      m_z.clear();
+      status = slpx::newton(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_report);
+    } else if (m_inequality_constraints.empty()) {
+      m_s.clear();
+      m_z.clear();
+      status = slpx::sqp(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_y, &m_report);
+    } else {
+      status = slpx::interior_point(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_s, &m_y, &m_z,
+                                    &m_report);
+    }
     // problem.hpp:676
     for (size_t i = 0; i < x.size(); ++i) g.val[m_decision_variables[i].expr] = x[i];
     return status;

@@ -12,9 +12,9 @@ Sources (problems, initial guesses, expected values and tolerances taken from th
   test/src/optimization/cart_pole_problem_test.cpp:87-124
   test/src/optimization/flywheel_problem_test.cpp:70-122
 
-The reference dispatches problems without inequality constraints to its Newton / SQP
-solvers (problem.hpp:335,403); both implementations here run every problem through
-the interior-point branch (:512), which for m_i = 0 takes the same steps as SQP.
+Like the reference, both implementations send problems without constraints to newton()
+(problem.hpp:335, solver/newton.hpp), problems with equality constraints only to sqp()
+(:403, solver/sqp.hpp) and everything else to interior_point() (:512).
 """
 import math
 
@@ -359,3 +359,46 @@ def test_flywheel_end_state(m):
         x = A * x + B * u
     if N == 1000:
         assert near(X[N], r, 2e-7)  # :121
+
+
+# ---- solver dispatch (problem.hpp:335, 403, 512) --------------------------------------
+
+@pytest.mark.gpu
+def test_newton_and_sqp_iteration_counts_match_the_oracle():
+    """Unconstrained -> newton(), equality-only -> sqp(): on these small, well-conditioned problems
+    the product (device Newton steps) and the oracle take the same number of iterations — one for a
+    quadratic without constraints (a single Newton step), and the same handful for the others."""
+    def build(m):
+        out = []
+        p = P(m)                                      # quadratic_problem_test.cpp:37-80
+        x, y = p.decision_variable(1.0), p.decision_variable(2.0)
+        p.minimize(m.pow(x, 2) + m.pow(y, 2))
+        out.append(("newton quadratic", p))
+        p = P(m)                                      # nonlinear_problem_test.cpp:19-38
+        x = p.decision_variable(20.0)
+        p.minimize(m.pow(x - 1, 4))
+        out.append(("newton quartic", p))
+        p = P(m)                                      # quadratic_problem_test.cpp:82-160
+        x, y = p.decision_variable(1.0), p.decision_variable(2.0)
+        p.minimize(m.pow(x, 2) + m.pow(y, 2))
+        p.eq(x + 3 * y, 36)
+        out.append(("sqp quadratic", p))
+        p = P(m)                                      # a nonlinear equality: needs several SQP steps
+        x, y = p.decision_variable(2.0), p.decision_variable(1.0)
+        p.minimize(m.pow(x - 2, 2) + m.pow(y - 1, 2))
+        p.eq(m.pow(x, 2) + m.pow(y, 2), 2)
+        out.append(("sqp circle", p))
+        return out
+
+    mo = model.Model(model.OracleBackend())
+    mo.be.reset()
+    mp = model.Model(model.ProductBackend("gpu"))
+    mp.be.reset()
+    for (name, po), (_, pp) in zip(build(mo), build(mp)):
+        so, sp = po.solve(), pp.solve()
+        io, ip = int(po.stats["iterations"]), int(pp.stats["iterations"])
+        print(name, "status", so, sp, "iterations oracle", io, "product", ip)
+        assert so == sp == P.SUCCESS
+        assert io == ip, (name, io, ip)
+        if name == "newton quadratic":
+            assert ip == 1

@@ -14,6 +14,9 @@ resident in HBM (the seeded interior state of SURVEY.md §8d).
 launcher the flag must equal WORLD_SIZE.  Workloads:
   single    (default, BASELINE config 2) every rank steps its own replica of ONE N=1000
             problem — the path has no cross-problem exchange ("replicas only")
+  gfold     (BASELINE config 5) the g-fold powered-descent OCP at N=100 (quadratic cone-type
+            inequality rows: the general A_i^T Sigma A_i product, chains of 16-26 columns in L),
+            built through the expression C-ABI by tests/support/gfold.py; replicas like `single`
   batch512  (BASELINE config 4) 512 independent cart-pole N=500 problems, problem b seeded
             with SEED + b, sharded contiguously over the ranks (sleipnir_amd.dist.shard_range:
             64 per GPU at 8 GPUs; multistart.hpp:45-74 hands whole solves to threads the same
@@ -112,13 +115,18 @@ def scaling_at_x0(system, info, x0, me, mi, B):
     return scales
 
 
-def make_system(sa, cases, N, problem_ids, device):
-    """Compiles cart-pole N for `device` with one value set per problem id (seeded interior
-    states) resident in HBM."""
+def make_system(sa, cases, N, problem_ids, device, kind="cart_pole"):
+    """Compiles cart-pole N (or g-fold N) for `device` with one value set per problem id (seeded
+    interior states) resident in HBM."""
     dt = 5.0 / N
     sa.lib().slpx_graph_reset()
     t0 = time.perf_counter()
-    pp = sa.Problem.cart_pole(N, dt)
+    if kind == "gfold":
+        from tests.support import gfold, model
+
+        pp = gfold.build(model.Model(model.ProductBackend("gpu")), N).p
+    else:
+        pp = sa.Problem.cart_pole(N, dt)
     t_model = time.perf_counter() - t0
     B = len(problem_ids)
     t0 = time.perf_counter()
@@ -209,7 +217,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed K-step blocks; the median is reported")
-    ap.add_argument("--workload", choices=["single", "batch512"], default="single")
+    ap.add_argument("--workload", choices=["single", "batch512", "gfold"], default="single")
     ap.add_argument("--N", type=int, default=None, help="horizon (single: 1000, batch512: 500)")
     ap.add_argument("--batch", type=int, default=None,
                     help="single: independent replicas per GPU (1); batch512: total problems (512)")
@@ -253,8 +261,8 @@ def main():
     comm = sa.Comm(backend="nccl")
     rank, local_rank, world = comm.rank, comm.local_rank, comm.world
 
-    if args.workload == "single":
-        N = args.N or 1000
+    if args.workload in ("single", "gfold"):
+        N = args.N or (1000 if args.workload == "single" else 100)
         B = args.batch or 1
         ids = [rank * B + b for b in range(B)]
         total_problems = world * B
@@ -266,7 +274,7 @@ def main():
         B = len(ids)
         scaling = "strong"
     dt = 5.0 / N
-    pp, system, setup_s = make_system(sa, cases, N, ids, local_rank)
+    pp, system, setup_s = make_system(sa, cases, N, ids, local_rank, "gfold" if args.workload == "gfold" else "cart_pole")
     info = system.info
     n, me, mi = info["n"], info["m_e"], info["m_i"]
 
@@ -330,7 +338,7 @@ def main():
                 pres = pre if isinstance(pre, tuple) else (pre,)
                 traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
                                             if kname.startswith(pres) for e in grids.values())
-        single = args.workload == "single" and B == 1
+        single = args.workload in ("single", "gfold") and B == 1
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -349,12 +357,14 @@ def main():
                      "batch variants on 64 x N=500 and 512 x N=1000)") if single else
                     f"{B} problems of N={N} per launch on this rank",
         }
-        workload = ("cart-pole direct transcription N=%d, %d problem(s) per GPU (replicas), seeded interior "
-                    "IPM state, inputs resident in HBM" % (N, B)) if args.workload == "single" else (
+        workload = ("%s N=%d, %d problem(s) per GPU (replicas), seeded interior "
+                    "IPM state, inputs resident in HBM" % ("cart-pole direct transcription" if args.workload == "single"
+                                                           else "g-fold powered-descent OCP", N, B)) if args.workload != "batch512" else (
                     "batch of %d independent cart-pole N=%d problems (seed + b), sharded contiguously: %d on "
                     "rank 0, inputs resident in HBM" % (total_problems, N, B))
         out = {
-            "metric": "Newton steps/sec, cart-pole direct-transcription N=%d" % N,
+            "metric": "Newton steps/sec, %s N=%d" % ("g-fold OCP" if args.workload == "gfold" else
+                                                     "cart-pole direct-transcription", N),
             "value": total_problems * args.steps / elapsed,
             "unit": "Newton steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,7 +380,7 @@ def main():
                        "ldlt_rounds": info["ldlt_rounds"], "ldlt_tasks": info["ldlt_tasks"],
                        "tape_tasks": info["tape_tasks"], "tape_nodes": info["tape_nodes"],
                        "tape_slots": info["tape_slots"],
-                       "multi_gpu": "replicas only" if args.workload == "single" else
+                       "multi_gpu": "replicas only" if args.workload != "batch512" else
                                     "problems sharded, no data-path collective"},
             "ms_per_ldlt_factor": groups["ldlt_factor"][0],
             "ms_per_ldlt_solve": groups["ldlt_solve"][0],
@@ -388,7 +398,7 @@ def main():
     system.close()
     pp.close()
     if rank == 0:
-        if world == 1 and single:
+        if world == 1 and single and args.workload == "single":
             # warm setup: the same model compiled a second time in this process (hipRTC code
             # objects cached, HIP runtime up)
             pp2, sys2, setup2 = make_system(sa, cases, N, [0], local_rank)
@@ -401,7 +411,7 @@ def main():
                                   batched_probe(sa, cases, 1000, 512, local_rank)]
             if not args.no_whole_solve:
                 out["whole_solve"] = whole_solve(sa, N)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload != "gfold":
             out["cpu_baseline"] = cpu_baseline(N, dt)
             out["speedup_vs_cpu_baseline"] = out["value"] / (out["cpu_baseline"]["value"] * 1.0)
         print(json.dumps(out))

@@ -1,30 +1,47 @@
+# The whole evidence sequence of a round, on the GPU box, from the repo root:
+#   bash profiles/collect_all.sh r02
+# Every --pmc pass on its own, never combined with a trace (MI355X_MICROARCH.md).  Leaves the
+# condensed files under gpurun_out/profiles_new/ (gpurun_out/ is what travels back).
 set -x
+TAG=${1:-r02}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 O=$R/gpurun_out
-rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/bprof $O/bpmc_fetch $O/bpmc_write
-# unprofiled reference run
-timeout 600 python bench.py > $O/bench_unprofiled.log 2>&1
-# 1. kernel stats of the exact default command
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py > $O/bench_profiled.log 2>&1
+N=$O/profiles_new
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write $N
+mkdir -p $N
+FAST="--no-cpu-baseline --no-batched --no-whole-solve"
+# 0. unprofiled reference run of the exact default command
+timeout 900 python bench.py > $O/bench_unprofiled.log 2>&1
+tail -1 $O/bench_unprofiled.log > $N/${TAG}_bench_unprofiled.json
+# 1. kernel stats of the default workload (single N=1000 problem; the after-the-region batch
+#    probes and the whole solve are left out so that the averages are per-launch numbers of it)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $FAST > $O/bench_profiled.log 2>&1
+tail -1 $O/bench_profiled.log > $N/${TAG}_bench.json
 # 2. counters, each in its own pass
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-batched-roofline > $O/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-batched-roofline > $O/pmc_write.log 2>&1
-# 3. batch of 512
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bprof -- python bench.py --batched-roofline --no-cpu-baseline > $O/bbench_profiled.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/bpmc_fetch -- python bench.py --batched-roofline --steps 2 --warmup 1 --no-cpu-baseline > $O/bpmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/bpmc_write -- python bench.py --batched-roofline --steps 2 --warmup 1 --no-cpu-baseline > $O/bpmc_write.log 2>&1
-# condense on the box (the raw traces are too big to travel)
-python profiles/collect.py r01 $O/prof $O/pmc_fetch $O/pmc_write > $O/collect.log 2>&1
-python profiles/collect.py r01_batched $O/bprof $O/bpmc_fetch $O/bpmc_write >> $O/collect.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_write.log 2>&1
+python profiles/collect.py $TAG $O/prof $O/pmc_fetch $O/pmc_write > $O/collect.log 2>&1
 KT=$(ls $O/prof/*/*kernel_trace.csv | head -1)
-python profiles/timeline.py $KT > $O/r01_step_timeline.txt 2>> $O/collect.log
-mkdir -p $O/profiles_new && cp profiles/r01_kernel_stats.csv profiles/r01_traffic.json profiles/r01_batched_kernel_stats.csv profiles/r01_batched_traffic.json $O/profiles_new/ 
-tail -1 $O/bench_profiled.log > $O/profiles_new/r01_bench.line
-tail -1 $O/bench_unprofiled.log > $O/profiles_new/r01_bench_unprofiled.line
-tail -1 $O/bbench_profiled.log > $O/profiles_new/r01_batched_bench.line
-cp $O/r01_step_timeline.txt $O/profiles_new/
-# keep the merged-back payload small
-rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/bprof $O/bpmc_fetch $O/bpmc_write
-cat $O/collect.log | tail -5
+python profiles/timeline.py $KT > $N/${TAG}_step_timeline.txt 2>> $O/collect.log
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_traffic.json $N/
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write
+# 3. the other configurations: kernel stats + counters each
+for CFG in "N5000:--N 5000" "gfold:--workload gfold" "b64xN500:--workload batch512 --batch 64" "b512xN1000:--workload batch512 --batch 512 --N 1000"; do
+  NAME=${CFG%%:*}
+  ARGS=${CFG#*:}
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $ARGS --steps 50 --warmup 5 --repeats 3 $FAST > $O/bench_$NAME.log 2>&1
+  tail -1 $O/bench_$NAME.log > $N/${TAG}_${NAME}_bench.json
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_fetch_$NAME.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_write_$NAME.log 2>&1
+  python profiles/collect.py ${TAG}_$NAME $O/prof $O/pmc_fetch $O/pmc_write >> $O/collect.log 2>&1
+  cp profiles/${TAG}_${NAME}_kernel_stats.csv profiles/${TAG}_${NAME}_traffic.json $N/
+  rm -rf $O/prof $O/pmc_fetch $O/pmc_write
+done
+# 4. phase clocks inside the LDLT kernels and the latency microbenchmarks
+PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>&1
+PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
+for B in latency icache chain; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
+PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= " > $N/${TAG}_setup_time.txt
+tail -5 $O/collect.log

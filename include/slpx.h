@@ -35,6 +35,13 @@ int slpx_abi_version(void);
 const char* slpx_last_error(void);
 int slpx_device_count(void);
 
+/* Multi-GPU: a batch of independent problems is sharded over one process per GPU,
+ * contiguous blocks, the first n_items % world ranks one item more — how multistart hands whole
+ * solves to threads (optimization/multistart.hpp:52-62).  *lo, *hi = the half-open range of
+ * `rank`.  No collective is needed inside a Newton step; a host joins the ranks only for
+ * end-of-region reductions (RCCL).  Returns 0, -1 on a bad rank. */
+int slpx_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+
 /* ---- expression graph ------------------------------------------------------
  * Replaces: slp::Variable and the detail:: operator set
  * (include/sleipnir/autodiff/variable.hpp:52-295, expression.hpp:155-2080), i.e.

@@ -13,12 +13,12 @@ rm -rf $O/prof $O/pmc_fetch $O/pmc_write $N
 mkdir -p $N
 FAST="--no-cpu-baseline --no-batched --no-whole-solve"
 # 0. unprofiled reference run of the exact default command
-timeout 900 python bench.py > $O/bench_unprofiled.log 2>&1
-tail -1 $O/bench_unprofiled.log > $N/${TAG}_bench_unprofiled.json
+timeout 900 python bench.py > $O/bench_unprofiled.log 2> $O/bench_unprofiled.err
+grep '^{' $O/bench_unprofiled.log | tail -1 > $N/${TAG}_bench_unprofiled.json
 # 1. kernel stats of the default workload (single N=1000 problem; the after-the-region batch
 #    probes and the whole solve are left out so that the averages are per-launch numbers of it)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $FAST > $O/bench_profiled.log 2>&1
-tail -1 $O/bench_profiled.log > $N/${TAG}_bench.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $FAST > $O/bench_profiled.log 2> $O/bench_profiled.err
+grep '^{' $O/bench_profiled.log | tail -1 > $N/${TAG}_bench.json
 # 2. counters, each in its own pass
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_write.log 2>&1
@@ -31,8 +31,8 @@ rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 for CFG in "N5000:--N 5000" "gfold:--workload gfold" "b64xN500:--workload batch512 --batch 64" "b512xN1000:--workload batch512 --batch 512 --N 1000"; do
   NAME=${CFG%%:*}
   ARGS=${CFG#*:}
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $ARGS --steps 50 --warmup 5 --repeats 3 $FAST > $O/bench_$NAME.log 2>&1
-  tail -1 $O/bench_$NAME.log > $N/${TAG}_${NAME}_bench.json
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $ARGS --steps 50 --warmup 5 --repeats 3 $FAST > $O/bench_$NAME.log 2> $O/bench_$NAME.err
+  grep '^{' $O/bench_$NAME.log | tail -1 > $N/${TAG}_${NAME}_bench.json
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_fetch_$NAME.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_write_$NAME.log 2>&1
   python profiles/collect.py ${TAG}_$NAME $O/prof $O/pmc_fetch $O/pmc_write >> $O/collect.log 2>&1

@@ -109,6 +109,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_abi_version", ctypes.c_int)
     sig("slpx_last_error", ctypes.c_char_p)
     sig("slpx_device_count", ctypes.c_int)
+    sig("slpx_shard_range", ctypes.c_int, i64, i32, i32, c_i64p, c_i64p)
     sig("slpx_graph_reset", None)
     sig("slpx_graph_size", i64)
     sig("slpx_expr_variable", i32, f64)

@@ -43,6 +43,14 @@ int slpx_device_count(void) {
   return count;
 }
 
+int slpx_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+  if (world < 1 || rank < 0 || rank >= world || n_items < 0) return -1;
+  const int64_t base = n_items / world, extra = n_items % world;
+  *lo = rank * base + std::min<int64_t>(rank, extra);
+  *hi = *lo + base + (rank < extra ? 1 : 0);
+  return 0;
+}
+
 void slpx_graph_reset(void) { slpx::graph().clear(); }
 int64_t slpx_graph_size(void) { return static_cast<int64_t>(slpx::graph().size()); }
 int32_t slpx_expr_variable(double value) { return slpx::graph().variable(value); }

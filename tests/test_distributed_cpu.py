@@ -28,6 +28,18 @@ def test_shard_range_partitions():
             sizes = [len(shard_range(n_items, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
     assert len(shard_range(512, 3, 8)) == 64  # config 4: 512 problems over 8 GPUs
+    # the C-ABI's rule (what a C++ host uses, include/slpx.h: slpx_shard_range) is the same one
+    import ctypes
+
+    import sleipnir_amd as sa
+
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for n_items in (0, 5, 512, 513):
+        for world in (1, 3, 8):
+            for r in range(world):
+                assert sa.lib().slpx_shard_range(n_items, r, world, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert range(lo.value, hi.value) == shard_range(n_items, r, world)
+    assert sa.lib().slpx_shard_range(4, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == -1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
 

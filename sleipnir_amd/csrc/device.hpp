@@ -146,6 +146,66 @@ struct KktDev {
   int off_f, off_ce, off_ci, off_g, off_Ae, off_Ai;
 };
 
+// Work that rides in another kernel's launch (one problem, single-launch factorization).  Every
+// kernel boundary of a Newton step costs 1-2 us of idle GPU plus the consumer's start-up, and an
+// assembly pass in front of the factorization is a chain of three dependent trips to memory
+// with the result written out only to be gathered again; so
+//  - KktFuse: the factorization's tasks evaluate the lhs / rhs entries they own straight from
+//    the AD sweep's V (kkt_kernels.h: one more dependent load in their gather, no assembly pass,
+//    no lhs / rhs in memory unless somebody asks: DeviceNlp::materialize_kkt); the tape's
+//    separable sums, which only feed f, ride as n_blocks extra workgroups nobody waits for;
+//  - BacksubFuse: the step's back-substitution (p_s, p_z) runs as the LAST workgroups of the
+//    backward solve's launch, waiting for cnt[0] to reach n_tasks (cnt[1] counts the waiters
+//    that are through; the last one clears both words — the launches are replayed from a
+//    captured graph, so no per-launch target can be passed).  Its first workgroup also hands
+//    the factorization's inertia counters to the host — at the START of the launch: the host
+//    learns the verdict of the attempt while the solve is still running and has the next
+//    launch queued by the time it ends.  p crosses workgroups inside the launch: agent-scope
+//    accesses (coherent.h).
+// One addend of an lhs / rhs entry that is a sum (kkt_kernels.h: kkt_terms_value); twelve bytes,
+// staged into LDS with the task's plan.  kind = b >> 28, row = b & 0x0fffffff:
+//   0  direct += V[a]                 1  g = V[a]                  2  aey += V[a] * y[row]
+//   3  ait += V[a] * (-(z/s)[row] * V[c] + mu / s[row] + z[row])   4  prod += (V[a] * (z/s)[row]) * V[c]
+struct KktTerm {
+  int32_t a, b, c;
+};
+struct KktFuse {
+  int inline_kkt = 0;
+  int n_blocks = 0;  // separable sums riding along
+  const double* V = nullptr;
+  const double* s = nullptr;
+  const double* y = nullptr;
+  const double* z = nullptr;
+  const double* mu = nullptr;
+  // per entry of the factorization plan (same layout as LdltDev::ent_src): the V slot of a plain
+  // copy (bit 30: negated), -1 a structural zero, <= -2 a sum: -(2 + (first term | count << 20)),
+  // first term relative to the task's block
+  const int32_t* ent_vsrc = nullptr;
+  const uint4* terms = nullptr;        // KktTerm[], every task's block padded to 16 bytes
+  const uint2* task_terms = nullptr;   // per task {offset of its block in uint4, its length in uint4}
+  double* Vw = nullptr;
+  double* store_lhs = nullptr;  // SLPX_FUSE_KKT_STORE=1 (tests): also write the evaluated system to memory
+  double* store_rhs = nullptr;
+  const NlpStructure::SumReduce* red = nullptr;
+  const double* scales = nullptr;
+};
+struct BacksubFuse {
+  int n_blocks = 0;  // 0: nothing rides along
+  unsigned int n_tasks = 0;
+  KktDev K{};
+  const double* V = nullptr;
+  const double* s = nullptr;
+  const double* z = nullptr;
+  const double* mu = nullptr;
+  double* ps = nullptr;
+  double* pz = nullptr;
+  const LdltStats* stats_src = nullptr;
+  LdltStats* stats_host = nullptr;
+  unsigned long long* seq_dev = nullptr;
+  volatile unsigned long long* seq_host = nullptr;
+  unsigned int* cnt = nullptr;
+};
+
 // Scalars the interior-point iteration kernels (ipm_kernels.h) hand to the host; the
 // three blocks live side by side in pinned host memory and are written by the kernels.
 struct IpmDirOut {
@@ -204,6 +264,7 @@ class DeviceNlp {
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs
   void build_kkt(bool with_reduce);  // assemble() + build_rhs() [+ reductions] as one launch
+  void build_kkt_for_step(bool with_reduce);  // same, inside the launch of the factor() that must follow
   // Least-squares multiplier estimate system on the same pattern:
   // lhs = [[I + A_i^T S^-2 A_i, A_e^T],[A_e, 0]] (util/lagrange_multiplier_estimate.hpp:56-133
   // with d, t eliminated; see ipm.cpp)
@@ -228,6 +289,7 @@ class DeviceNlp {
                          const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
+  void solve_backsub_publish();                     // solve_after_factor() + backsub_publish(), one launch where possible
   void refine_solution(int iters);                  // iterative refinement of the last solve() against the lhs
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
@@ -264,8 +326,16 @@ class DeviceNlp {
   double* d_y() { return m_y.p; }
   double* d_z() { return m_z.p; }
   double* d_mu() { return m_mu.p; }
-  double* d_lhs() { return m_lhs.p; }
-  double* d_rhs() { return m_rhs.p; }
+  // (a step whose factorization evaluated the system in place left nothing in memory: assembled on demand)
+  double* d_lhs() {
+    materialize_kkt();
+    return m_lhs.p;
+  }
+  double* d_rhs() {
+    materialize_kkt();
+    return m_rhs.p;
+  }
+  void materialize_kkt();
   double* d_p() { return m_p.p; }
   double* d_ps() { return m_ps.p; }
   double* d_pz() { return m_pz.p; }
@@ -308,7 +378,7 @@ class DeviceNlp {
       m_sext_dst, m_bwd_ptr;
   DevBuf<LdltPair> m_pairs;
   DevBuf<LdltSn> m_sn_desc;
-  DevBuf<int32_t> m_lhs_colptr, m_lhs_rowidx;  // refine_solution (uploaded on first use)
+  DevBuf<int32_t> m_lhs_colptr, m_lhs_rowidx, m_lhs_rowptr, m_lhs_rowent, m_lhs_rowcol;  // refine_solution (uploaded on first use)
   DevBuf<double> m_rhs0, m_p_acc;
   DevBuf<uint32_t> m_sn_lvl_ptr, m_col_sn, m_lvl_pack, m_col_lvl_pack;
   DevBuf<uint2> m_bwd_range;
@@ -331,6 +401,19 @@ class DeviceNlp {
   unsigned long long m_seq_expected = 0;  // publishing launches enqueued so far
   unsigned long long m_stats_seq = 0;     // the one that carries the current inertia counters
   bool m_seq_poll = true;
+  bool m_fuse_kkt_store = false;
+  bool m_fuse_kkt = false, m_fuse_backsub = false;  // the two halves of it (SLPX_FUSE_KKT, SLPX_FUSE_BACKSUB)
+  bool m_fuse_launches = false;       // KKT assembly inside the factorization launch, back-substitution inside the solve's
+  bool m_defer_kkt = false;           // build_kkt() only notes the request ...
+  int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
+  DevBuf<unsigned int> m_fuse_cnt;    // BacksubFuse::cnt
+  DevBuf<int32_t> m_ent_vsrc;
+  DevBuf<KktTerm> m_kkt_terms;
+  DevBuf<uint2> m_task_terms;
+  uint32_t m_factor_lds_inline = 0;   // dynamic LDS of the factorization with the terms staged
+  void build_inline_kkt(const NlpStructure& s, const KktPlan& k, const LdltPlan& l);
+  bool m_lhs_stale = false, m_rhs_stale = false;  // memory does not hold the system of the current state
+  void solve_after_factor_impl(const LdltStats* publish);
   bool m_capturing = false;           // a step graph is being captured: launches do not run
   bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
   // all rounds of a factorization / backward solve in one launch (device-side round

@@ -699,7 +699,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       dev.upload_mu(&mu);
       mu_on_device = mu;
     }
-    dev.build_kkt(/*with_reduce=*/false);
+    dev.build_kkt_for_step(/*with_reduce=*/false);
     sys.set_after_attempt([&] {
       dev.ipm_direction(tau);
       dev.sweep_values_trial();

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "device.hpp"
+#include "kkt_kernels.h"
 #include "ldlt_kernels.h"
 #include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
@@ -35,48 +36,6 @@ namespace slpx {
 // consecutive threads write consecutive entries; the sources of consecutive lhs
 // entries are (nearly) consecutive in V because both are CSC-ordered.
 // ============================================================================
-// (`vblock` of `vgrid`: the block's position among the blocks doing this job — the fused
-// kkt_build_kernel gives each job a slice of one launch)
-__device__ __forceinline__ void kkt_assemble_body(const KktDev& K, const double* __restrict__ V,
-                                                  const double* __restrict__ s,
-                                                  const double* __restrict__ z, double* __restrict__ lhs,
-                                                  int vblock, int vgrid) {
-  auto general = [&](int k) {
-    double direct = 0.0;
-    for (int d = K.dptr[k]; d < K.dptr[k + 1]; ++d) direct += V[K.dsrc[d]];
-    double prod = 0.0;
-    for (int p = K.pptr[k]; p < K.pptr[k + 1]; ++p) {
-      const int r = K.pr[p];
-      const double sigma = (1.0 / s[r]) * z[r];  // Σ = S⁻¹Z (interior_point.hpp:426)
-      prod += (V[K.pa[p]] * sigma) * V[K.pb[p]];
-    }
-    return direct + prod;
-  };
-  // Four entries per thread with their gathers in flight together (the kernel is a chain
-  // of dependent loads; HBM bandwidth needs the memory-level parallelism), and a one-index
-  // fast path for the entries that are plain copies of a V value (all of A_e, most of H).
-  const int stride = vgrid * blockDim.x;
-  int k = vblock * blockDim.x + threadIdx.x;
-  for (; k + 3 * stride < K.nnz_lhs; k += 4 * stride) {
-    const int f0 = K.fast_src[k], f1 = K.fast_src[k + stride], f2 = K.fast_src[k + 2 * stride],
-              f3 = K.fast_src[k + 3 * stride];
-    double v0 = f0 >= 0 ? V[f0] : 0.0, v1 = f1 >= 0 ? V[f1] : 0.0, v2 = f2 >= 0 ? V[f2] : 0.0,
-           v3 = f3 >= 0 ? V[f3] : 0.0;
-    if (f0 == -2) v0 = general(k);
-    if (f1 == -2) v1 = general(k + stride);
-    if (f2 == -2) v2 = general(k + 2 * stride);
-    if (f3 == -2) v3 = general(k + 3 * stride);
-    lhs[k] = v0;
-    lhs[k + stride] = v1;
-    lhs[k + 2 * stride] = v2;
-    lhs[k + 3 * stride] = v3;
-  }
-  for (; k < K.nnz_lhs; k += stride) {
-    const int f = K.fast_src[k];
-    lhs[k] = f >= 0 ? V[f] : (f == -2 ? general(k) : 0.0);
-  }
-}
-
 __global__ __launch_bounds__(256) void kkt_assemble_kernel(KktDev K, const double* __restrict__ V,
                                                            int v_stride,
                                                            const double* __restrict__ s,
@@ -131,8 +90,7 @@ __global__ __launch_bounds__(256) void kkt_assemble_batch_kernel(KktDev K, const
         for (int q = 0; q < P; ++q)
           if (q < nb) {
             const double* Vq = V + static_cast<size_t>(q) * v_stride;
-            const double sigma = (1.0 / s[q * K.m_i + r]) * z[q * K.m_i + r];
-            prod[q] += (Vq[a] * sigma) * Vq[bb];
+            prod[q] += kkt_prod_term(Vq[a], s[q * K.m_i + r], z[q * K.m_i + r], Vq[bb]);
           }
       }
 #pragma unroll
@@ -175,33 +133,6 @@ __global__ __launch_bounds__(256) void kkt_add_identity_kernel(KktDev K, const i
   lhs += static_cast<size_t>(blockIdx.y) * K.nnz_lhs;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K.n; j += gridDim.x * blockDim.x)
     lhs[diag_pos[j]] += 1.0;
-}
-
-__device__ __forceinline__ void kkt_rhs_body(const KktDev& K, const double* __restrict__ V,
-                                             const double* __restrict__ s, const double* __restrict__ y,
-                                             const double* __restrict__ z, const double m,
-                                             double* __restrict__ rhs, int vblock, int vgrid) {
-  const double* ce = V + K.off_ce;
-  const double* ci = V + K.off_ci;
-  const double* Ae = V + K.off_Ae;
-  const double* Ai = V + K.off_Ai;
-  for (int j = vblock * blockDim.x + threadIdx.x; j < K.dim; j += vgrid * blockDim.x) {
-    if (j >= K.n) {
-      rhs[j] = -ce[j - K.n];
-      continue;
-    }
-    const int gs = K.g_src[j];
-    double aey = 0.0;
-    for (int p = K.ae_colptr[j]; p < K.ae_colptr[j + 1]; ++p) aey += Ae[p] * y[K.ae_rowidx[p]];
-    double ait = 0.0;
-    for (int p = K.ai_colptr[j]; p < K.ai_colptr[j + 1]; ++p) {
-      const int r = K.ai_rowidx[p];
-      const double sinv = 1.0 / s[r];
-      const double sigma = sinv * z[r];
-      ait += Ai[p] * (-sigma * ci[r] + m * sinv + z[r]);
-    }
-    rhs[j] = -(gs >= 0 ? V[gs] : 0.0) + aey + ait;
-  }
 }
 
 __global__ __launch_bounds__(256) void kkt_rhs_kernel(KktDev K, const double* __restrict__ V,
@@ -291,41 +222,30 @@ __global__ __launch_bounds__(256) void step_backsub_kernel(KktDev K, const doubl
   z += static_cast<size_t>(b) * K.m_i;
   ps += static_cast<size_t>(b) * K.m_i;
   pz += static_cast<size_t>(b) * K.m_i;
-  const double m = mu[b];
-  const double* ci = V + K.off_ci;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < K.m_i; r += gridDim.x * blockDim.x) {
-    double aipx = 0.0;
-    for (int q = K.ai_rowptr[r]; q < K.ai_rowptr[r + 1]; ++q) aipx += V[K.ai_src[q]] * p[K.ai_col[q]];
-    const double sinv = 1.0 / s[r];
-    const double p_s = (ci[r] - s[r]) + aipx;
-    ps[r] = p_s;
-    pz[r] = m * sinv - z[r] - (sinv * z[r]) * p_s;
-  }
+  step_backsub_body(K, V, p, s, z, mu[b], ps, pz, static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x),
+                    static_cast<int>(gridDim.x * blockDim.x));
 }
 
 // Iterative refinement of a solve (used where the regularization would otherwise show in the
 // answer: the least-squares multiplier estimate): r = b - K p for the UNREGULARIZED symmetric K
-// given by its lower CSC values in `lhs`; one thread per column, the mirrored half by fp64
-// atomics (the system has a few thousand columns: latency, not bandwidth).
+// given by its lower CSC values in `lhs`.  One thread per row i: the column i of the lower
+// triangle gives K(r, i), r >= i, and a row index of the same triangle (rowptr / rowent / rowcol)
+// gives K(i, c), c < i — a fixed order of summation, so the same bits on every run (scattering
+// the mirrored half with floating-point atomics made the multiplier estimate, and with it the
+// whole trajectory of a solve, differ from run to run in the last bits).
 __global__ __launch_bounds__(256) void sym_residual_kernel(int dim, const int32_t* __restrict__ colptr,
                                                            const int32_t* __restrict__ rowidx,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ rowent,
+                                                           const int32_t* __restrict__ rowcol,
                                                            const double* __restrict__ lhs,
                                                            const double* __restrict__ p,
                                                            double* __restrict__ res) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dim; c += gridDim.x * blockDim.x) {
-    const double pc = p[c];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) {
     double acc = 0.0;
-    for (int q = colptr[c]; q < colptr[c + 1]; ++q) {
-      const int r = rowidx[q];
-      const double v = lhs[q];
-      if (r == c) {
-        acc += v * pc;
-      } else {
-        acc += v * p[r];                   // K(c, r) p_r
-        atomicAdd(&res[r], -(v * pc));     // K(r, c) p_c
-      }
-    }
-    atomicAdd(&res[c], -acc);
+    for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) acc += lhs[rowent[q]] * p[rowcol[q]];  // K(i, c), c < i
+    for (int q = colptr[i]; q < colptr[i + 1]; ++q) acc += lhs[q] * p[rowidx[q]];          // K(r, i), r >= i
+    res[i] -= acc;
   }
 }
 __global__ __launch_bounds__(256) void axpy_kernel(int count, const double* __restrict__ x, double* __restrict__ y) {
@@ -574,6 +494,15 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
+  // launch fusion (device.hpp: KktFuse / BacksubFuse): one problem, single-launch factorization
+  m_fuse_launches = m_single_launch && batch == 1 && l.factor_lds_bytes >= 64 * sizeof(double);
+  if (const char* env = std::getenv("SLPX_FUSE_LAUNCHES")) m_fuse_launches = m_fuse_launches && env[0] != '0';
+  m_fuse_cnt.upload(std::vector<unsigned int>(2, 0u));
+  m_fuse_kkt = m_fuse_backsub = m_fuse_launches;
+  if (const char* env = std::getenv("SLPX_FUSE_KKT")) m_fuse_kkt = m_fuse_kkt && env[0] != '0';
+  if (const char* env = std::getenv("SLPX_FUSE_BACKSUB")) m_fuse_backsub = m_fuse_backsub && env[0] != '0';
+  if (const char* env = std::getenv("SLPX_FUSE_KKT_STORE")) m_fuse_kkt_store = env[0] != '0';
+  if (m_fuse_kkt) build_inline_kkt(s, k, l);
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -856,7 +785,83 @@ static inline int grid_for(int work, int block, int cap = 2048) {
   return std::max(1, std::min((work + block - 1) / block, cap));
 }
 
+// The static side of KktFuse: for every entry of the factorization plan what it is made of.
+void DeviceNlp::build_inline_kkt(const NlpStructure& s, const KktPlan& k, const LdltPlan& l) {
+  std::vector<int32_t> vsrc(l.ent_src.size(), -1);
+  std::vector<KktTerm> terms;
+  std::vector<uint2> task_terms(l.tasks.size(), uint2{0, 0});
+  auto term = [](int kind, int a, int row, int c) { return KktTerm{a, (kind << 28) | row, c}; };
+  bool ok = s.nV < (1 << 30) && k.m_i < (1 << 28) && k.m_e < (1 << 28);
+  uint32_t widest = 0;
+  for (size_t ti = 0; ti < l.tasks.size() && ok; ++ti) {
+    const LdltTask& t = l.tasks[ti];
+    const size_t block = terms.size();
+    for (uint32_t i = 0; i < t.n_ent; ++i) {
+      const size_t e = t.ent_off + i;
+      const int32_t s0 = l.ent_src[e];
+      if (s0 < 0) continue;
+      const size_t first = terms.size();
+      if (l.ent_flags[e] & 4) {  // rhs entry s0 (kkt_kernels.h: kkt_rhs_entry)
+        const int j = s0;
+        if (j >= k.n) {
+          vsrc[e] = (s.off_ce + j - k.n) | (1 << 30);
+          continue;
+        }
+        if (k.g_src[j] >= 0) terms.push_back(term(1, k.g_src[j], 0, 0));
+        for (int p = s.Ae.colptr[j]; p < s.Ae.colptr[j + 1]; ++p)
+          terms.push_back(term(2, s.off_Ae + p, s.Ae.rowidx[p], 0));
+        for (int p = s.Ai.colptr[j]; p < s.Ai.colptr[j + 1]; ++p)
+          terms.push_back(term(3, s.off_Ai + p, s.Ai.rowidx[p], s.off_ci + s.Ai.rowidx[p]));
+      } else {  // lhs entry s0 (kkt_kernels.h: kkt_assemble_body)
+        const int f = k.fast_src[s0];
+        if (f >= 0) {
+          vsrc[e] = f;
+          continue;
+        }
+        if (f != -2) continue;
+        for (int q = k.dptr[s0]; q < k.dptr[s0 + 1]; ++q) terms.push_back(term(0, k.dsrc[q], 0, 0));
+        for (int q = k.pptr[s0]; q < k.pptr[s0 + 1]; ++q) terms.push_back(term(4, k.pa[q], k.pr[q], k.pb[q]));
+      }
+      const size_t rel = first - block, cnt = terms.size() - first;
+      if (rel >= (1u << 20) || cnt >= (1u << 11)) {
+        ok = false;
+        break;
+      }
+      // (a sum of nothing — an x row with no gradient, no A_e, no A_i entry — is a zero)
+      vsrc[e] = cnt == 0 ? -1 : -static_cast<int32_t>(2 + (rel | (cnt << 20)));
+    }
+    while ((terms.size() - block) % 4 != 0) terms.push_back(KktTerm{0, 0, 0});  // 4 terms = 3 x 16 bytes
+    const uint32_t off16 = static_cast<uint32_t>(block * sizeof(KktTerm) / 16);
+    const uint32_t len16 = static_cast<uint32_t>((terms.size() - block) * sizeof(KktTerm) / 16);
+    task_terms[ti] = uint2{off16, len16};
+    widest = std::max(widest, len16);
+  }
+  // the staged terms and, behind them, one product per term (4 terms = 3 x 16 bytes)
+  m_factor_lds_inline = l.factor_lds_bytes + 16u + 16u * widest + 8u * (widest * 4u / 3u);
+  if (!ok || m_factor_lds_inline > 160u * 1024u) {
+    m_fuse_kkt = false;  // (the stand-alone assembly kernels then)
+    return;
+  }
+  if (terms.empty()) terms.push_back(KktTerm{0, 0, 0});
+  m_ent_vsrc.upload(vsrc);
+  m_kkt_terms.upload(terms);
+  m_task_terms.upload(task_terms);
+}
+
+// lhs / rhs of the CURRENT state into memory, if the last step did without them
+void DeviceNlp::materialize_kkt() {
+  if (m_kkt_pending) {  // the factorization that was to evaluate the system never came
+    const bool with_reduce = m_kkt_pending == 2;
+    m_kkt_pending = 0;
+    build_kkt(with_reduce);
+    return;
+  }
+  if (m_lhs_stale) assemble();
+  if (m_rhs_stale) build_rhs();
+}
+
 void DeviceNlp::assemble() {
+  m_lhs_stale = false;
   if (m_batch >= kBatchPerThread) {
     // measured at 512 x N=1000: 1 problem per thread 0.084 ms, 2: 0.083, 4: 0.079, 8: 0.090
     hipLaunchKernelGGL(kkt_assemble_batch_kernel<kBatchPerThread>,
@@ -881,6 +886,12 @@ void DeviceNlp::build_kkt(bool with_reduce) {
     SLPX_HIP_CHECK(hipGetLastError());
     return;
   }
+  if (m_defer_kkt) {  // evaluated inside the factorization's launch (enqueue_factor)
+    m_kkt_pending = with_reduce ? 2 : 1;
+    m_lhs_stale = m_rhs_stale = true;
+    return;
+  }
+  m_lhs_stale = m_rhs_stale = false;
   const int na = grid_for((m_kdev.nnz_lhs + 3) / 4, 256), nr = grid_for(m_kdev.dim, 256);
   const int nred = with_reduce ? static_cast<int>(m_reduces.n) : 0;
   hipLaunchKernelGGL(kkt_build_kernel, dim3(na + nr + nred, m_batch), dim3(256), 0, m_stream, m_kdev, m_V.p,
@@ -888,7 +899,16 @@ void DeviceNlp::build_kkt(bool with_reduce) {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
+// build_kkt() when a factorization attempt is the next thing enqueued (a Newton step): the
+// assembly then rides in that launch (device.hpp: KktFuse)
+void DeviceNlp::build_kkt_for_step(bool with_reduce) {
+  m_defer_kkt = m_fuse_kkt;
+  build_kkt(with_reduce);
+  m_defer_kkt = false;
+}
+
 void DeviceNlp::assemble_lsq() {
+  m_lhs_stale = false;
   hipLaunchKernelGGL(kkt_assemble_lsq_kernel, dim3(grid_for(m_kdev.nnz_lhs, 256), m_batch), dim3(256),
                      0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_lhs.p);
   hipLaunchKernelGGL(kkt_add_identity_kernel, dim3(grid_for(m_kdev.n, 256), m_batch), dim3(256), 0,
@@ -933,6 +953,7 @@ void DeviceNlp::refresh_params(const Graph& g) {
 }
 
 void DeviceNlp::build_rhs() {
+  m_rhs_stale = false;
   // (a batch variant like kkt_assemble_batch_kernel was measured SLOWER here: 0.102 ms vs
   // 0.070 ms at 512 x N=1000 — the per-column loops are short and the extra registers cost
   // occupancy)
@@ -962,6 +983,7 @@ constexpr int kFactorThreadsSingle = 1024;
 
 void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   const LdltPlan& l = m_l_ref;
+  if (!m_kkt_pending) materialize_kkt();  // e.g. a second attempt after one that evaluated the system in place
   LdltStats* cur = m_stats.p + static_cast<size_t>(parity) * m_batch;
   LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1) * m_batch;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
@@ -991,18 +1013,41 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                        static_cast<int>(l.tasks.size()), reg, cur, m_batch);
     m_il_outputs_stale = true;
   } else if (m_single_launch) {
+    KktFuse f;
+    if (m_kkt_pending) {
+      f.inline_kkt = 1;
+      f.n_blocks = m_kkt_pending == 2 ? static_cast<int>(m_reduces.n) : 0;
+      f.V = m_V.p;
+      f.s = m_s.p;
+      f.y = m_y.p;
+      f.z = m_z.p;
+      f.mu = m_mu.p;
+      f.ent_vsrc = m_ent_vsrc.p;
+      f.terms = reinterpret_cast<const uint4*>(m_kkt_terms.p);
+      f.task_terms = m_task_terms.p;
+      f.Vw = m_V.p;
+      if (m_fuse_kkt_store) {
+        f.store_lhs = m_lhs.p;
+        f.store_rhs = m_rhs.p;
+        m_lhs_stale = m_rhs_stale = false;
+      }
+      f.red = m_reduces.p;
+      f.scales = m_scales.p;
+      m_kkt_pending = 0;
+    }
     // every round in one launch; tasks wait on device-side round counters
-    hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>, dim3(static_cast<uint32_t>(l.tasks.size()), m_batch),
-                       dim3(kFactorThreadsSingle), l.factor_lds_bytes, stream, m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs,
-                       reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next, m_rhs.p, m_zv.p,
-                       m_fround_cnt.p, m_slot_handoff ? 1 : 0);
+    hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>,
+                       dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks), m_batch),
+                       dim3(kFactorThreadsSingle), f.inline_kkt ? m_factor_lds_inline : l.factor_lds_bytes, stream,
+                       m_ldev, 0u, m_lhs.p, m_kdev.nnz_lhs, reg, m_Lx.p, lxs, m_D.p, l.n, m_contrib.p, cs, cur, next,
+                       m_rhs.p, m_zv.p, m_fround_cnt.p, m_slot_handoff ? 1 : 0, f);
   } else {
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_kernel<256>, dim3(nt, m_batch), dim3(256), l.factor_lds_bytes, stream,
                          m_ldev, l.round_ptr[r], m_lhs.p, m_kdev.nnz_lhs, reg, m_Lx.p, lxs, m_D.p,
                          l.n, m_contrib.p, cs, cur, r == 0 ? next : nullptr, m_rhs.p, m_zv.p,
-                         static_cast<unsigned int*>(nullptr), 0);
+                         static_cast<unsigned int*>(nullptr), 0, KktFuse{});
     }
   }
   SLPX_HIP_CHECK(hipGetLastError());
@@ -1098,11 +1143,10 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
       join();
     } else {
       if (refresh_ad) sweep_full(/*with_reduce=*/false);
-      build_kkt(/*with_reduce=*/refresh_ad);
+      build_kkt_for_step(/*with_reduce=*/refresh_ad);
     }
     enqueue_factor(m_stats_cur, cap);
-    solve_after_factor();
-    backsub_and_publish(m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
+    solve_backsub_publish();
     m_stream = saved;
     m_capturing = false;
     hipGraph_t graph = nullptr;
@@ -1118,6 +1162,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
 // Full solve for a right-hand side that arrived AFTER the factorization (second-order
 // corrections, multiplier estimate, slpx_ldlt_solve): forward, then backward.
 void DeviceNlp::solve() {
+  if (m_rhs_stale) build_rhs();
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   const int scs = static_cast<int>(std::max<uint32_t>(1, l.n_scontrib));
@@ -1145,7 +1190,23 @@ void DeviceNlp::solve() {
 
 // The factorization carried the rhs along as an extra row and left z = D⁻¹L⁻¹Pb behind
 // (ldlt_symbolic.cpp), so only the backward substitution remains.
-void DeviceNlp::solve_after_factor() {
+void DeviceNlp::solve_after_factor() { solve_after_factor_impl(nullptr); }
+
+// backward solve, back-substitution and the hand-over of the current attempt's counters to the
+// host: one launch where the back-substitution can ride along (device.hpp: BacksubFuse)
+void DeviceNlp::solve_backsub_publish() {
+  const LdltStats* src = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
+  if (m_fuse_backsub) {
+    solve_after_factor_impl(src);
+    if (m_batch == 1 && !m_capturing) m_stats_seq = ++m_seq_expected;
+  } else {
+    solve_after_factor_impl(nullptr);
+    backsub_and_publish(src);
+  }
+  m_stats_in_host = true;
+}
+
+void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   if (m_il) {
@@ -1160,14 +1221,32 @@ void DeviceNlp::solve_after_factor() {
   }
   if (m_single_launch) {
     const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
-    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
-                       m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p, m_bround_cnt.p);
+    BacksubFuse f;
+    if (publish != nullptr) {
+      f.n_blocks = grid_for(std::max(1, m_kdev.m_i), 256);
+      f.n_tasks = nt;
+      f.K = m_kdev;
+      f.V = m_V.p;
+      f.s = m_s.p;
+      f.z = m_z.p;
+      f.mu = m_mu.p;
+      f.ps = m_ps.p;
+      f.pz = m_pz.p;
+      f.stats_src = publish;
+      f.stats_host = m_h_stats;
+      f.seq_dev = m_seq_dev.p;
+      f.seq_host = m_h_seq;
+      f.cnt = m_fuse_cnt.p;
+    }
+    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt + static_cast<uint32_t>(f.n_blocks), m_batch), dim3(256),
+                       l.solve_lds_bytes, m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p,
+                       m_bround_cnt.p, f);
   } else {
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
                          m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p,
-                         static_cast<unsigned int*>(nullptr));
+                         static_cast<unsigned int*>(nullptr), BacksubFuse{});
     }
   }
   SLPX_HIP_CHECK(hipGetLastError());
@@ -1204,11 +1283,34 @@ bool DeviceNlp::interleaved_for(int batch) {
 // solution of the last solve(), K = the unregularized matrix in m_lhs, K_reg = what was factored.
 // Converges like (regularization / smallest eigenvalue)^iters.  Single problem.
 void DeviceNlp::refine_solution(int iters) {
+  materialize_kkt();
   if (m_batch != 1) throw std::runtime_error("slpx: refine_solution handles one problem");
   const int dim = m_kdev.dim;
   if (m_lhs_colptr.n == 0) {
     m_lhs_colptr.upload(m_k_ref.lhs.colptr);
     m_lhs_rowidx.upload(m_k_ref.lhs.rowidx);
+    {
+      // the strictly lower triangle by rows, entries of a row in column order
+      const CscPattern& lp = m_k_ref.lhs;
+      std::vector<int32_t> rowptr(dim + 1, 0), rowent, rowcol;
+      for (int c = 0; c < dim; ++c)
+        for (int q = lp.colptr[c]; q < lp.colptr[c + 1]; ++q)
+          if (lp.rowidx[q] != c) ++rowptr[lp.rowidx[q] + 1];
+      for (int i = 0; i < dim; ++i) rowptr[i + 1] += rowptr[i];
+      rowent.resize(std::max(1, rowptr[dim]));
+      rowcol.resize(std::max(1, rowptr[dim]));
+      std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+      for (int c = 0; c < dim; ++c)
+        for (int q = lp.colptr[c]; q < lp.colptr[c + 1]; ++q)
+          if (lp.rowidx[q] != c) {
+            const int at = fill[lp.rowidx[q]]++;
+            rowent[at] = q;
+            rowcol[at] = c;
+          }
+      m_lhs_rowptr.upload(rowptr);
+      m_lhs_rowent.upload(rowent);
+      m_lhs_rowcol.upload(rowcol);
+    }
     m_rhs0.alloc(dim);
     m_p_acc.alloc(dim);
   }
@@ -1217,7 +1319,7 @@ void DeviceNlp::refine_solution(int iters) {
   for (int it = 0; it < iters; ++it) {
     SLPX_HIP_CHECK(hipMemcpyAsync(m_rhs.p, m_rhs0.p, dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
     hipLaunchKernelGGL(sym_residual_kernel, dim3(grid_for(dim, 256)), dim3(256), 0, m_stream, dim, m_lhs_colptr.p,
-                       m_lhs_rowidx.p, m_lhs.p, m_p_acc.p, m_rhs.p);
+                       m_lhs_rowidx.p, m_lhs_rowptr.p, m_lhs_rowent.p, m_lhs_rowcol.p, m_lhs.p, m_p_acc.p, m_rhs.p);
     solve();  // m_rhs -> m_p
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(dim, 256)), dim3(256), 0, m_stream, dim, m_p.p, m_p_acc.p);
   }
@@ -1352,6 +1454,7 @@ void DeviceNlp::ipm_soc_accumulate(double alpha, bool first, bool s_from_ci) {
 }
 
 void DeviceNlp::ipm_soc_rhs() {
+  m_rhs_stale = false;
   hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(grid_for(m_kdev.dim, 256)), dim3(256), 0, m_stream, m_kdev, m_V.p,
                      m_s.p, m_y.p, m_z.p, m_mu.p, m_soc_ce.p, m_soc_cims.p, m_rhs.p);
   SLPX_HIP_CHECK(hipGetLastError());

@@ -19,7 +19,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include "coherent.h"
 #include "device.hpp"
+#include "kkt_kernels.h"
 #include "tape_kernels.h"  // stage16, q16
 
 namespace slpx {
@@ -43,21 +45,6 @@ __device__ unsigned int g_ldlt_clock_round;  // which round's launch records
 // expected) time-out marks the factorization bad instead of hanging the GPU.
 // Measured at cart-pole N=1000: factorization 80 -> 66 us, backward solve 36 -> 33 us.
 // ---------------------------------------------------------------------------
-// Values that cross workgroups INSIDE a launch (update blocks, finished x of ancestor tasks)
-// are moved with agent-scope relaxed atomics: they bypass the non-coherent cache levels, so
-// the round hand-over needs no L2 write-back / invalidate (an agent-scope fence does both to
-// the whole XCD L2 and slows every workgroup on it: measured 29 -> 76 us for the backward
-// solve).
-// (`in_launch` false = one launch per round: the kernel boundary orders everything and the
-// plain cached accesses are used.)
-__device__ __forceinline__ double coherent_load(const double* p, bool in_launch) {
-  return in_launch ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-__device__ __forceinline__ void coherent_store(double* p, double v, bool in_launch) {
-  if (in_launch) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
 __device__ __forceinline__ void round_wait(const unsigned int* cnt, unsigned int target,
                                            LdltStats* stats_b) {
   if (threadIdx.x == 0) {
@@ -295,14 +282,31 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
     const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt,
-    int slot_handoff) {
+    int slot_handoff, KktFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const uint32_t task_index = task_base + blockIdx.x;
+  const int tid = threadIdx.x;
+  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+    // a separable sum of the tape rides along (they only feed f, which nothing in this launch reads)
+    double* part = reinterpret_cast<double*>(smem_raw);
+    const NlpStructure::SumReduce r = F.red[blockIdx.x];
+    double acc = 0.0;
+    if (tid < 64) {
+      for (int k = tid; k < r.count; k += 64) acc += F.V[r.src_off + k];
+      part[tid] = acc;
+    }
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) part[tid] += part[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) F.Vw[r.dst] = (r.scale_idx >= 0 ? F.scales[r.scale_idx] : 1.0) * part[0];
+    return;
+  }
+  const uint32_t task_index = task_base + blockIdx.x - static_cast<uint32_t>(F.n_blocks);
   const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
-  const int tid = threadIdx.x;
   // the counters the NEXT factorization attempt accumulates into (nobody touches them now)
-  if (stats_next != nullptr && blockIdx.x == 0 && tid == 0)
+  if (stats_next != nullptr && task_index == task_base && tid == 0)
     stats_next[b] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   const double delta = reg[2 * b], gamma = reg[2 * b + 1];
   if (delta != delta) return;  // NaN: this problem is not part of the attempt
@@ -346,7 +350,17 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   stage16<THREADS>(s_pairs, reinterpret_cast<const uint4*>(L.pairs + t.pair_off), g_pairs, tid);
   stage16<THREADS>(s_pptr, reinterpret_cast<const uint4*>(L.ent_pair_ptr + t.pair_ptr_off), g_pptr, tid);
   stage16<THREADS>(s_lvl, reinterpret_cast<const uint4*>(L.lvl_pack + t.lvl_off), g_lvl, tid);
-  stage16<THREADS>(s_src, reinterpret_cast<const uint4*>(L.ent_src + t.ent_off), g_src, tid);
+  // (inline assembly, device.hpp KktFuse: what every entry is made of instead of where it sits in lhs)
+  stage16<THREADS>(s_src, reinterpret_cast<const uint4*>((F.inline_kkt ? F.ent_vsrc : L.ent_src) + t.ent_off), g_src,
+                   tid);
+  uint4* s_terms = reinterpret_cast<uint4*>(
+      smem_raw + ((static_cast<uint32_t>(reinterpret_cast<unsigned char*>(s_minp + 1) - smem_raw) + 15u) & ~15u));
+  uint32_t n_terms16 = 0;  // the task's term block in 16-byte units
+  if (F.inline_kkt) {
+    const uint2 tt = F.task_terms[task_index];
+    n_terms16 = tt.y;
+    stage16<THREADS>(s_terms, F.terms + tt.x, tt.y, tid);
+  }
   stage16<THREADS>(s_col, reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), g_col, tid);
   stage16<THREADS>(s_flags, reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), g_flags, tid);
   stage16<THREADS>(s_out, reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), g_out, tid);
@@ -361,20 +375,58 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   // ---- matrix values: four independent gathers per lane in flight ----
   {
     // entries of the right-hand-side row (flag bit 2) read rhs instead of lhs
-    auto fetch = [&](uint32_t i) {
-      const int32_t s0 = src[i];
-      const double* base = (flags[i] & 4) ? rhs : lhs;
-      return s0 >= 0 ? base[s0] : 0.0;
-    };
-    uint32_t i = tid;
-    for (; i + 3 * THREADS < t.n_ent; i += 4 * THREADS) {
-      const double a0 = fetch(i), a1 = fetch(i + THREADS), a2 = fetch(i + 2 * THREADS), a3 = fetch(i + 3 * THREADS);
-      U[i] = a0;
-      U[i + THREADS] = a1;
-      U[i + 2 * THREADS] = a2;
-      U[i + 3 * THREADS] = a3;
+    if (!F.inline_kkt) {
+      auto fetch = [&](uint32_t i) {
+        const int32_t s0 = src[i];
+        const double* base = (flags[i] & 4) ? rhs : lhs;
+        return s0 >= 0 ? base[s0] : 0.0;
+      };
+      uint32_t i = tid;
+      for (; i + 3 * THREADS < t.n_ent; i += 4 * THREADS) {
+        const double a0 = fetch(i), a1 = fetch(i + THREADS), a2 = fetch(i + 2 * THREADS), a3 = fetch(i + 3 * THREADS);
+        U[i] = a0;
+        U[i + THREADS] = a1;
+        U[i + 2 * THREADS] = a2;
+        U[i + 3 * THREADS] = a3;
+      }
+      for (; i < t.n_ent; i += THREADS) U[i] = fetch(i);
+    } else {
+      // The system is not in memory: every task evaluates the entries it owns from what the AD
+      // sweep left in V (each lhs / rhs entry feeds exactly one entry of L, so nothing is
+      // computed twice).  What an entry is made of came with the plan, so this is still ONE
+      // trip to memory (two for the rare sum of more than kKktUnroll terms) — instead of a whole
+      // assembly pass and a kernel boundary in front of this launch.
+      // (src[] holds device.hpp's KktFuse::ent_vsrc here)
+      const double m = F.mu[0];
+      const KktTerm* terms = reinterpret_cast<const KktTerm*>(s_terms);
+      double* tprod = reinterpret_cast<double*>(s_terms + n_terms16);
+      const uint32_t n_terms = n_terms16 * 4u / 3u;  // (the padding terms are harmless: V[0])
+      const uint32_t span = n_terms > t.n_ent ? n_terms : t.n_ent;
+      for (uint32_t k = tid; k < span; k += THREADS) {
+        // a plain copy and a term per lane and pass, their loads in flight together
+        const int w = k < t.n_ent ? src[k] : -1;
+        const double v = w >= 0 ? F.V[w & 0x3fffffff] : 0.0;
+        const bool on = k < n_terms;
+        const KktTermLoads tl = kkt_term_fetch(on ? terms[k] : KktTerm{0, 0, 0}, on, F.V, F.s, F.y, F.z);
+        if (k < t.n_ent && w >= -1) U[k] = (w & 0x40000000) && w >= 0 ? -v : v;
+        if (on) tprod[k] = kkt_term_product(tl, m);
+      }
+      __syncthreads();
+      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+        const int w = src[i];
+        if (w < -1) {
+          const uint32_t code = static_cast<uint32_t>(-(w + 2));
+          U[i] = kkt_terms_sum(terms, tprod, code & 0xfffffu, code >> 20, (flags[i] & 4) != 0);
+        }
+      }
+      if (F.store_lhs != nullptr) {  // verification: leave what was evaluated where an assembly pass would have
+        __syncthreads();
+        for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+          const int32_t s0 = L.ent_src[t.ent_off + i];
+          if (s0 >= 0) ((flags[i] & 4) ? F.store_rhs : F.store_lhs)[s0] = U[i];
+        }
+      }
     }
-    for (; i < t.n_ent; i += THREADS) U[i] = fetch(i);
   }
   __syncthreads();
   // everything above only needed static data and the assembled matrix; the update blocks
@@ -645,13 +697,41 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
     const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out,
-    unsigned int* __restrict__ round_cnt) {
+    unsigned int* __restrict__ round_cnt, BacksubFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const bool fused = F.n_blocks != 0;  // the step's back-substitution rides in this launch (device.hpp)
+  if (fused && blockIdx.x >= F.n_tasks) {
+    const int vb = static_cast<int>(blockIdx.x - F.n_tasks);
+    // the verdict of the factorization this solve belongs to: known since the launch began
+    if (vb == 0 && tid == 0 && F.stats_host != nullptr) {
+      F.stats_host[0] = F.stats_src[0];
+      if (F.seq_host != nullptr) {
+        __threadfence_system();
+        const unsigned long long v = *F.seq_dev + 1;
+        *F.seq_dev = v;
+        *F.seq_host = v;
+      }
+    }
+    const int stride = F.n_blocks * 256;
+    int r = vb * 256 + tid;
+    const double m = F.mu[0];
+    BacksubRow row{};
+    if (r < F.K.m_i) row = backsub_prefetch(F.K, F.V, F.s, F.z, r);
+    done_wait(&F.cnt[0], F.n_tasks, nullptr);
+    if (r < F.K.m_i) backsub_finish(F.K, F.V, out, row, m, F.ps, F.pz, r);
+    for (r += stride; r < F.K.m_i; r += stride) {  // (more rows than threads: only beyond 2048 workgroups)
+      row = backsub_prefetch(F.K, F.V, F.s, F.z, r);
+      backsub_finish(F.K, F.V, out, row, m, F.ps, F.pz, r);
+    }
+    __syncthreads();
+    done_consumed(F.cnt, static_cast<unsigned int>(F.n_blocks));
+    return;
+  }
   // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
   const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
-  const int tid = threadIdx.x;
   Lx += static_cast<size_t>(b) * lx_stride;
   zv += static_cast<size_t>(b) * n;
   xg += static_cast<size_t>(b) * n;
@@ -771,11 +851,13 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
     coherent_store(&xg[pj], x[i], round_cnt != nullptr);
-    out[L.perm[pj]] = x[i];
+    coherent_store(&out[L.perm[pj]], x[i], fused);
   }
   if (round_cnt != nullptr)
     round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
                  t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
+  // (round_signal waited for every lane's stores and ended on a barrier)
+  if (fused && tid == 0) __hip_atomic_fetch_add(&F.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   SLPX_LDLT_CLOCK(20);
 }
 

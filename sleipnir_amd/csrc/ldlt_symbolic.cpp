@@ -812,6 +812,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) deepest = std::max(deepest, P.tasks[ti].n_lvl);
     P.critical_levels += static_cast<int>(deepest);
   }
+  if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "ldlt LDS: factor %u bytes, solve %u bytes\n", P.factor_lds_bytes, P.solve_lds_bytes);
   if (P.factor_lds_bytes > 160u * 1024u || P.solve_lds_bytes > 160u * 1024u)
     throw std::runtime_error("ldlt: a task's working set exceeds the 160 KB LDS of a CU; lower "
                              "LdltOptions::task_entries");

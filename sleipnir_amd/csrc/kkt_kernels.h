@@ -233,8 +233,21 @@ __device__ __forceinline__ void kkt_rhs_body(const KktDev& K, const double* __re
 }
 
 
-// p_s = (c_i - s) + A_i p_x, p_z = mu/s - z - Sigma p_s (interior_point.hpp:479-480) for the
-// rows [first, first + count) step `stride`; COHERENT: p was written inside this launch.
+// p_s = (c_i - s) + A_i p_x, p_z = mu/s - z - Sigma p_s (interior_point.hpp:479-480); rounding
+// pinned like the assembly's: the stand-alone kernel and the backward solve's tasks
+// (device.hpp: BacksubFuse) must give the same bits.
+__device__ __forceinline__ double backsub_dot(double acc, double a, double p) { return __builtin_fma(a, p, acc); }
+__device__ __forceinline__ void backsub_row(double ci, double s, double z, double m, double aipx, double* ps,
+                                            double* pz) {
+#pragma clang fp contract(off)
+  const double sinv = 1.0 / s;
+  const double p_s = (ci - s) + aipx;
+  *ps = p_s;
+  const double sz = sinv * z;
+  const double t = sz * p_s;
+  *pz = (m * sinv - z) - t;
+}
+
 template <bool COHERENT = false>
 __device__ __forceinline__ void step_backsub_body(const KktDev& K, const double* __restrict__ V,
                                                   const double* __restrict__ p, const double* __restrict__ s,
@@ -244,54 +257,9 @@ __device__ __forceinline__ void step_backsub_body(const KktDev& K, const double*
   for (int r = first; r < K.m_i; r += stride) {
     double aipx = 0.0;
     for (int q = K.ai_rowptr[r]; q < K.ai_rowptr[r + 1]; ++q)
-      aipx += V[K.ai_src[q]] * coherent_load(&p[K.ai_col[q]], COHERENT);
-    const double sinv = 1.0 / s[r];
-    const double p_s = (ci[r] - s[r]) + aipx;
-    ps[r] = p_s;
-    pz[r] = m * sinv - z[r] - (sinv * z[r]) * p_s;
+      aipx = backsub_dot(aipx, V[K.ai_src[q]], coherent_load(&p[K.ai_col[q]], COHERENT));
+    backsub_row(ci[r], s[r], z[r], m, aipx, &ps[r], &pz[r]);
   }
-}
-
-// The same for the workgroups that ride in the backward solve's launch: everything that does not
-// depend on p (row pointers, A_i values, s, z, c_i: three dependent trips to memory) is fetched
-// BEFORE the wait for the solve, so that afterwards one trip (p itself) remains.  One row per
-// thread and pass; rows with more than kPre entries finish theirs after the wait.
-struct BacksubRow {
-  static constexpr int kPre = 4;
-  double a[kPre];
-  int col[kPre];
-  int q_rest, q_end;
-  double sinv, zr, base;
-};
-__device__ __forceinline__ BacksubRow backsub_prefetch(const KktDev& K, const double* __restrict__ V,
-                                                       const double* __restrict__ s, const double* __restrict__ z,
-                                                       int r) {
-  BacksubRow row;
-  const int qb = K.ai_rowptr[r], qe = K.ai_rowptr[r + 1];
-#pragma unroll
-  for (int k = 0; k < BacksubRow::kPre; ++k) {
-    const bool on = qb + k < qe;
-    row.col[k] = on ? K.ai_col[qb + k] : 0;
-    row.a[k] = on ? V[K.ai_src[qb + k]] : 0.0;
-  }
-  row.q_rest = qb + BacksubRow::kPre;
-  row.q_end = qe;
-  const double sr = s[r];
-  row.sinv = 1.0 / sr;
-  row.zr = z[r];
-  row.base = V[K.off_ci + r] - sr;
-  return row;
-}
-__device__ __forceinline__ void backsub_finish(const KktDev& K, const double* __restrict__ V, const double* p,
-                                               const BacksubRow& row, double m, double* __restrict__ ps,
-                                               double* __restrict__ pz, int r) {
-  double aipx = 0.0;
-#pragma unroll
-  for (int k = 0; k < BacksubRow::kPre; ++k) aipx += row.a[k] * coherent_load(&p[row.col[k]], true);
-  for (int q = row.q_rest; q < row.q_end; ++q) aipx += V[K.ai_src[q]] * coherent_load(&p[K.ai_col[q]], true);
-  const double p_s = row.base + aipx;
-  ps[r] = p_s;
-  pz[r] = m * row.sinv - row.zr - (row.sinv * row.zr) * p_s;
 }
 
 }  // namespace slpx

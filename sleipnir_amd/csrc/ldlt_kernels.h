@@ -700,33 +700,16 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     unsigned int* __restrict__ round_cnt, BacksubFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
-  const bool fused = F.n_blocks != 0;  // the step's back-substitution rides in this launch (device.hpp)
-  if (fused && blockIdx.x >= F.n_tasks) {
-    const int vb = static_cast<int>(blockIdx.x - F.n_tasks);
-    // the verdict of the factorization this solve belongs to: known since the launch began
-    if (vb == 0 && tid == 0 && F.stats_host != nullptr) {
-      F.stats_host[0] = F.stats_src[0];
-      if (F.seq_host != nullptr) {
-        __threadfence_system();
-        const unsigned long long v = *F.seq_dev + 1;
-        *F.seq_dev = v;
-        *F.seq_host = v;
-      }
+  // the verdict of the factorization this solve belongs to: known since the launch began; handed
+  // over by the last workgroup, a leaf task that has to wait for its ancestors anyway
+  if (F.on && blockIdx.x == gridDim.x - 1 && tid == 0 && F.stats_host != nullptr) {
+    F.stats_host[0] = F.stats_src[0];
+    if (F.seq_host != nullptr) {
+      __threadfence_system();
+      const unsigned long long v = *F.seq_dev + 1;
+      *F.seq_dev = v;
+      *F.seq_host = v;
     }
-    const int stride = F.n_blocks * 256;
-    int r = vb * 256 + tid;
-    const double m = F.mu[0];
-    BacksubRow row{};
-    if (r < F.K.m_i) row = backsub_prefetch(F.K, F.V, F.s, F.z, r);
-    done_wait(&F.cnt[0], F.n_tasks, nullptr);
-    if (r < F.K.m_i) backsub_finish(F.K, F.V, out, row, m, F.ps, F.pz, r);
-    for (r += stride; r < F.K.m_i; r += stride) {  // (more rows than threads: only beyond 2048 workgroups)
-      row = backsub_prefetch(F.K, F.V, F.s, F.z, r);
-      backsub_finish(F.K, F.V, out, row, m, F.ps, F.pz, r);
-    }
-    __syncthreads();
-    done_consumed(F.cnt, static_cast<unsigned int>(F.n_blocks));
-    return;
   }
   // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
   const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
@@ -759,6 +742,14 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_pack + t.lvl_off), g_lvl, tid);
   stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
   if (t.n_sn) stage16<256>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
+  // the rows of the back-substitution this task owns (device.hpp: BacksubFuse), behind x[]
+  uint4* s_bs = reinterpret_cast<uint4*>(
+      smem_raw + ((static_cast<uint32_t>(reinterpret_cast<unsigned char*>(x + t.n_col + 1) - smem_raw) + 15u) & ~15u));
+  uint4 bs_task = uint4{0, 0, 0, 0};
+  if (F.on) {
+    bs_task = F.task_plan[task_index];
+    stage16<256>(s_bs, F.plan + bs_task.x, bs_task.y, tid);
+  }
   __syncthreads();
   SLPX_LDLT_CLOCK(17);
   // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
@@ -776,6 +767,34 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[colperm[i]];
     if (tid == 0) x[t.n_col] = 1.0;
   }
+  // this lane's row of the back-substitution: everything but p is known now
+  constexpr int kBsPre = 4;
+  const BsRow* bs_rows = reinterpret_cast<const BsRow*>(s_bs);
+  const BsTerm* bs_terms = reinterpret_cast<const BsTerm*>(s_bs + bs_task.w);
+  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z;
+  BsRow bs_row = BsRow{0, 0};
+  double bs_a[kBsPre], bs_p[kBsPre], bs_s = 1.0, bs_z = 0.0, bs_ci = 0.0;
+  uint32_t bs_ref[kBsPre];
+#pragma unroll
+  for (int k = 0; k < kBsPre; ++k) {
+    bs_a[k] = 0.0;
+    bs_p[k] = 0.0;
+    bs_ref[k] = 0;
+  }
+  if (bs_mine) {
+    bs_row = bs_rows[tid];
+    const uint32_t first = bs_row.terms & 0xfffffu, cnt = bs_row.terms >> 20;
+    bs_s = F.s[bs_row.r];
+    bs_z = F.z[bs_row.r];
+    bs_ci = F.V[F.off_ci + bs_row.r];
+#pragma unroll
+    for (int k = 0; k < kBsPre; ++k)
+      if (static_cast<uint32_t>(k) < cnt) {
+        const BsTerm bt = bs_terms[first + k];
+        bs_a[k] = F.V[bt.a];
+        bs_ref[k] = bt.ref;
+      }
+  }
   // rows owned by ancestor tasks (later rounds) must be final before they are gathered
   if (round_cnt != nullptr && static_cast<int>(t.round) + 1 < L.n_rounds)
     round_wait(&round_cnt[b * L.n_rounds + t.round + 1],
@@ -789,6 +808,11 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
         vals[q] *= coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr);
         items[q].y = t.n_col;
       }
+    }
+    if (bs_mine) {
+#pragma unroll
+      for (int k = 0; k < kBsPre; ++k)
+        if (bs_ref[k] & 0x80000000u) bs_p[k] = coherent_load(&xg[bs_ref[k] & 0x7fffffffu], round_cnt != nullptr);
     }
   }
   __syncthreads();
@@ -851,13 +875,39 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];
     coherent_store(&xg[pj], x[i], round_cnt != nullptr);
-    coherent_store(&out[L.perm[pj]], x[i], fused);
+    out[L.perm[pj]] = x[i];
+  }
+  if (F.on) {
+    const double m = F.mu[0];
+    auto p_of = [&](uint32_t ref) {
+      return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr) : x[ref];
+    };
+    for (uint32_t j = tid; j < bs_task.z; j += 256) {
+      const BsRow row = j == static_cast<uint32_t>(tid) ? bs_row : bs_rows[j];
+      const uint32_t first = row.terms & 0xfffffu, cnt = row.terms >> 20;
+      double aipx = 0.0, s_r = bs_s, z_r = bs_z, ci_r = bs_ci;
+      uint32_t k0 = 0;
+      if (j == static_cast<uint32_t>(tid)) {
+#pragma unroll
+        for (int k = 0; k < kBsPre; ++k)
+          if (static_cast<uint32_t>(k) < cnt)
+            aipx = backsub_dot(aipx, bs_a[k], (bs_ref[k] & 0x80000000u) ? bs_p[k] : x[bs_ref[k]]);
+        k0 = kBsPre;
+      } else {  // (more rows than lanes: nothing was fetched ahead)
+        s_r = F.s[row.r];
+        z_r = F.z[row.r];
+        ci_r = F.V[F.off_ci + row.r];
+      }
+      for (uint32_t k = k0; k < cnt; ++k) {
+        const BsTerm bt = bs_terms[first + k];
+        aipx = backsub_dot(aipx, F.V[bt.a], p_of(bt.ref));
+      }
+      backsub_row(ci_r, s_r, z_r, m, aipx, &F.ps[row.r], &F.pz[row.r]);
+    }
   }
   if (round_cnt != nullptr)
     round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
                  t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
-  // (round_signal waited for every lane's stores and ended on a barrier)
-  if (fused && tid == 0) __hip_atomic_fetch_add(&F.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   SLPX_LDLT_CLOCK(20);
 }
 

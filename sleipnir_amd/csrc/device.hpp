@@ -216,6 +216,16 @@ struct BacksubFuse {
   volatile unsigned long long* seq_host = nullptr;
 };
 
+// ldlt_factor_solve_kernel (ldlt_kernels.h): what the backward solve needs to run on the
+// factorization's LDS instead of on L and z in memory.
+struct SolveInPlace {
+  const LdltSolveItem* bwd_items_u = nullptr;  // bwd_items with lpos replaced by the task-local entry of U
+  const uint32_t* col_zent = nullptr;          // per column: the entry of U that is its right-hand-side row
+  uint32_t bwd_lds_off = 0;                    // where the solve's carve-up starts
+  unsigned int n_tasks = 0;
+  unsigned int* exit_cnt = nullptr;            // workgroups through their exit phase (the last one publishes)
+};
+
 // Scalars the interior-point iteration kernels (ipm_kernels.h) hand to the host; the
 // three blocks live side by side in pinned host memory and are written by the kernels.
 struct IpmDirOut {
@@ -300,6 +310,9 @@ class DeviceNlp {
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   void solve_backsub_publish();                     // solve_after_factor() + backsub_publish(), one launch where possible
+  // factor() + solve_backsub_publish(): ONE launch where every task's workgroup fits on the device at once
+  void factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
+                            const std::vector<uint8_t>& active);
   void refine_solution(int iters);                  // iterative refinement of the last solve() against the lhs
   void backsub();                                   // p -> p_x, p_y, p_s, p_z
   void backsub_and_publish(const LdltStats* stats_src);
@@ -416,6 +429,16 @@ class DeviceNlp {
   bool m_fuse_launches = false;       // KKT assembly inside the factorization launch, back-substitution inside the solve's
   bool m_defer_kkt = false;           // build_kkt() only notes the request ...
   int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
+  bool m_fuse_solve = false;          // ldlt_factor_solve_kernel (SLPX_FUSE_SOLVE)
+  DevBuf<LdltSolveItem> m_bwd_items_u;
+  DevBuf<uint32_t> m_col_zent;
+  DevBuf<unsigned int> m_exit_cnt;
+  SolveInPlace m_sip;
+  void build_solve_in_place(const LdltPlan& l);
+  void enqueue_factor_solve(int parity);
+  KktFuse take_kkt_fuse();
+  BacksubFuse backsub_fuse(const LdltStats* publish);
+  uint32_t m_factor_solve_lds = 0;
   DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
   DevBuf<uint4> m_bs_task_plan;
   uint32_t m_solve_lds_inline = 0;    // dynamic LDS of the backward solve with the rows staged

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 #include "device.hpp"
 #include "kkt_kernels.h"
@@ -503,6 +504,9 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (const char* env = std::getenv("SLPX_FUSE_KKT_STORE")) m_fuse_kkt_store = env[0] != '0';
   if (m_fuse_kkt) build_inline_kkt(s, k, l);
   if (m_fuse_backsub) build_inline_backsub(k, l);
+  m_fuse_solve = m_fuse_launches && m_fuse_backsub;
+  if (const char* env = std::getenv("SLPX_FUSE_SOLVE")) m_fuse_solve = m_fuse_solve && env[0] != '0';
+  if (m_fuse_solve) build_solve_in_place(l);
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -916,6 +920,50 @@ void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
   m_bs_task_plan.upload(task_plan);
 }
 
+// The static side of ldlt_factor_solve_kernel, and whether it can be used at all: its workgroups
+// wait for each other across the whole tree, so every one of them must be resident at once.
+void DeviceNlp::build_solve_in_place(const LdltPlan& l) {
+  std::vector<LdltSolveItem> items(l.bwd_items);
+  std::vector<uint32_t> zent(l.col_perm.size(), 0);
+  uint32_t widest_cols = 0;
+  bool ok = true;
+  for (const LdltTask& t : l.tasks) {
+    std::unordered_map<uint32_t, uint32_t> entry_of;  // position in Lx -> entry of the task
+    for (uint32_t i = 0; i < t.n_ent; ++i) {
+      const uint8_t fl = l.ent_flags[t.ent_off + i];
+      if (fl & 4) zent[t.col_off + l.ent_col[t.ent_off + i]] = i;
+      else if (!(fl & 1)) entry_of[l.ent_out[t.ent_off + i]] = i;
+    }
+    for (uint32_t q = 0; q < t.n_bwd_items; ++q) {
+      auto it = entry_of.find(l.bwd_items[t.bwd_item_off + q].lpos);
+      if (it == entry_of.end()) ok = false;
+      else items[t.bwd_item_off + q].lpos = it->second;
+    }
+    widest_cols = std::max(widest_cols, t.n_col);
+  }
+  const uint32_t factor_part = ((m_fuse_kkt ? m_factor_lds_inline : l.factor_lds_bytes) + 15u) & ~15u;
+  const uint32_t solve_part = m_solve_lds_inline + 16u * ((widest_cols + 3u) / 4u);
+  const uint32_t total = factor_part + solve_part;
+  int per_cu = 0, cus = 0;
+  if (ok && total <= 160u * 1024u) {
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_solve_kernel<1024>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ldlt_factor_solve_kernel<1024>, 1024, total));
+    SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+  }
+  // (the separable sums ride in the same launch, and leave: a few workgroups of slack for them)
+  if (!ok || total > 160u * 1024u || l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus) {
+    m_fuse_solve = false;
+    return;
+  }
+  m_bwd_items_u.upload(items);
+  m_col_zent.upload(zent);
+  m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
+  m_sip = SolveInPlace{m_bwd_items_u.p, m_col_zent.p, factor_part, static_cast<unsigned int>(l.tasks.size()),
+                       m_exit_cnt.p};
+  m_factor_solve_lds = total;
+}
+
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
 void DeviceNlp::materialize_kkt() {
   if (m_kkt_pending) {  // the factorization that was to evaluate the system never came
@@ -1049,6 +1097,52 @@ void DeviceNlp::write_reg(const std::vector<double>& delta, const std::vector<do
 
 constexpr int kFactorThreadsSingle = 1024;
 
+// the system evaluated inside the factorization's launch, if a build_kkt_for_step() asked for it
+KktFuse DeviceNlp::take_kkt_fuse() {
+  KktFuse f;
+  if (m_kkt_pending) {
+    f.inline_kkt = 1;
+    f.n_blocks = m_kkt_pending == 2 ? static_cast<int>(m_reduces.n) : 0;
+    f.V = m_V.p;
+    f.s = m_s.p;
+    f.y = m_y.p;
+    f.z = m_z.p;
+    f.mu = m_mu.p;
+    f.ent_vsrc = m_ent_vsrc.p;
+    f.terms = reinterpret_cast<const uint4*>(m_kkt_terms.p);
+    f.task_terms = m_task_terms.p;
+    f.Vw = m_V.p;
+    if (m_fuse_kkt_store) {
+      f.store_lhs = m_lhs.p;
+      f.store_rhs = m_rhs.p;
+      m_lhs_stale = m_rhs_stale = false;
+    }
+    f.red = m_reduces.p;
+    f.scales = m_scales.p;
+    m_kkt_pending = 0;
+  }
+  return f;
+}
+
+BacksubFuse DeviceNlp::backsub_fuse(const LdltStats* publish) {
+  BacksubFuse f;
+  f.on = 1;
+  f.V = m_V.p;
+  f.s = m_s.p;
+  f.z = m_z.p;
+  f.mu = m_mu.p;
+  f.ps = m_ps.p;
+  f.pz = m_pz.p;
+  f.off_ci = m_kdev.off_ci;
+  f.plan = reinterpret_cast<const uint4*>(m_bs_plan.p);
+  f.task_plan = m_bs_task_plan.p;
+  f.stats_src = publish;
+  f.stats_host = m_h_stats;
+  f.seq_dev = m_seq_dev.p;
+  f.seq_host = m_h_seq;
+  return f;
+}
+
 void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   const LdltPlan& l = m_l_ref;
   if (!m_kkt_pending) materialize_kkt();  // e.g. a second attempt after one that evaluated the system in place
@@ -1081,28 +1175,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                        static_cast<int>(l.tasks.size()), reg, cur, m_batch);
     m_il_outputs_stale = true;
   } else if (m_single_launch) {
-    KktFuse f;
-    if (m_kkt_pending) {
-      f.inline_kkt = 1;
-      f.n_blocks = m_kkt_pending == 2 ? static_cast<int>(m_reduces.n) : 0;
-      f.V = m_V.p;
-      f.s = m_s.p;
-      f.y = m_y.p;
-      f.z = m_z.p;
-      f.mu = m_mu.p;
-      f.ent_vsrc = m_ent_vsrc.p;
-      f.terms = reinterpret_cast<const uint4*>(m_kkt_terms.p);
-      f.task_terms = m_task_terms.p;
-      f.Vw = m_V.p;
-      if (m_fuse_kkt_store) {
-        f.store_lhs = m_lhs.p;
-        f.store_rhs = m_rhs.p;
-        m_lhs_stale = m_rhs_stale = false;
-      }
-      f.red = m_reduces.p;
-      f.scales = m_scales.p;
-      m_kkt_pending = 0;
-    }
+    KktFuse f = take_kkt_fuse();
     // every round in one launch; tasks wait on device-side round counters
     hipLaunchKernelGGL(ldlt_factor_kernel<kFactorThreadsSingle>,
                        dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks), m_batch),
@@ -1127,6 +1200,35 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
   m_stats_cur ^= 1;
   m_stats_in_host = false;
   enqueue_factor(m_stats_cur, m_stream);
+}
+
+void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
+                                     const std::vector<uint8_t>& active) {
+  if (!m_fuse_solve) {
+    factor(delta, gamma, active);
+    solve_backsub_publish();
+    return;
+  }
+  write_reg(delta, gamma, active);
+  m_stats_cur ^= 1;
+  enqueue_factor_solve(m_stats_cur);
+  if (!m_capturing) m_stats_seq = ++m_seq_expected;
+  m_stats_in_host = true;
+}
+
+void DeviceNlp::enqueue_factor_solve(int parity) {
+  const LdltPlan& l = m_l_ref;
+  if (!m_kkt_pending) materialize_kkt();
+  LdltStats* cur = m_stats.p + static_cast<size_t>(parity);
+  LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1);
+  KktFuse f = take_kkt_fuse();
+  BacksubFuse bf = backsub_fuse(cur);
+  hipLaunchKernelGGL(ldlt_factor_solve_kernel<kFactorThreadsSingle>,
+                     dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
+                     dim3(kFactorThreadsSingle), m_factor_solve_lds, m_stream, m_ldev, m_lhs.p, m_h_reg, m_Lx.p, m_D.p,
+                     l.n, m_contrib.p, cur, next, m_rhs.p, m_zv.p, m_fround_cnt.p, m_slot_handoff ? 1 : 0, f, m_xg.p,
+                     m_p.p, m_bround_cnt.p, bf, m_sip);
+  SLPX_HIP_CHECK(hipGetLastError());
 }
 
 void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
@@ -1213,8 +1315,12 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
       if (refresh_ad) sweep_full(/*with_reduce=*/false);
       build_kkt_for_step(/*with_reduce=*/refresh_ad);
     }
-    enqueue_factor(m_stats_cur, cap);
-    solve_backsub_publish();
+    if (m_fuse_solve) {
+      enqueue_factor_solve(m_stats_cur);
+    } else {
+      enqueue_factor(m_stats_cur, cap);
+      solve_backsub_publish();
+    }
     m_stream = saved;
     m_capturing = false;
     hipGraph_t graph = nullptr;
@@ -1289,23 +1395,7 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   }
   if (m_single_launch) {
     const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
-    BacksubFuse f;
-    if (publish != nullptr) {
-      f.on = 1;
-      f.V = m_V.p;
-      f.s = m_s.p;
-      f.z = m_z.p;
-      f.mu = m_mu.p;
-      f.ps = m_ps.p;
-      f.pz = m_pz.p;
-      f.off_ci = m_kdev.off_ci;
-      f.plan = reinterpret_cast<const uint4*>(m_bs_plan.p);
-      f.task_plan = m_bs_task_plan.p;
-      f.stats_src = publish;
-      f.stats_host = m_h_stats;
-      f.seq_dev = m_seq_dev.p;
-      f.seq_host = m_h_seq;
-    }
+    const BacksubFuse f = publish != nullptr ? backsub_fuse(publish) : BacksubFuse{};
     hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), f.on ? m_solve_lds_inline : l.solve_lds_bytes,
                        m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p, m_bround_cnt.p, f);
   } else {

@@ -275,41 +275,82 @@ __device__ __attribute__((noinline)) void chain_solve_wave(double* __restrict__ 
 // columns (in-chain pairs are not in the lists), then — only in levels that hold a chain of two
 // or more columns — a barrier and sn_finish_wave, one wave per chain.
 // ---------------------------------------------------------------------------
+// What the factorization leaves in LDS for whoever runs next in the same workgroup (the exit
+// phase; the backward solve of ldlt_factor_solve_kernel).
+struct FactorKeep {
+  double* U;
+  double* invd;
+  const uint16_t* col;
+  const uint8_t* flags;
+  const uint32_t* out;
+  int* s_cnt;
+  unsigned long long* s_minp;
+};
+
+// results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero)
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
-    LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
+__device__ __forceinline__ void ldlt_factor_exit(const FactorKeep& K, const LdltTask& t, int b,
+                                                 double* __restrict__ Lx, double* __restrict__ D,
+                                                 double* __restrict__ zv, LdltStats* __restrict__ stats) {
+  const int tid = threadIdx.x;
+  for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+    const double u = K.U[i];
+    if (K.flags[i] & 1) {
+      D[K.out[i]] = u;
+      const double eps = 2.220446049250313e-16;
+      if (u > eps) atomicAdd(&K.s_cnt[0], 1);
+      else if (u < -eps) atomicAdd(&K.s_cnt[1], 1);
+      else atomicAdd(&K.s_cnt[2], 1);
+      if (u == 0.0 || !isfinite(u)) atomicAdd(&K.s_cnt[3], 1);
+      else atomicMin(K.s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
+    } else if (K.flags[i] & 4) {
+      zv[K.out[i]] = u * K.invd[K.col[i]];  // z = D⁻¹L⁻¹Pb: the forward solve came for free
+    } else {
+      Lx[K.out[i]] = u * K.invd[K.col[i]];
+    }
+  }
+  __syncthreads();
+  if (tid < 4 && K.s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[b]) + tid, K.s_cnt[tid]);
+  if (tid == 0) atomicMin(&stats[b].min_abs_bits, *K.s_minp);
+}
+
+// a separable sum of the tape riding in the factorization's launch (they only feed f, which
+// nothing in that launch reads)
+__device__ __forceinline__ void ride_along_sum(const KktFuse& F, uint32_t which, unsigned char* smem_raw) {
+  const int tid = threadIdx.x;
+  double* part = reinterpret_cast<double*>(smem_raw);
+  const NlpStructure::SumReduce r = F.red[which];
+  double acc = 0.0;
+  if (tid < 64) {
+    for (int k = tid; k < r.count; k += 64) acc += F.V[r.src_off + k];
+    part[tid] = acc;
+  }
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (tid < w) part[tid] += part[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) F.Vw[r.dst] = (r.scale_idx >= 0 ? F.scales[r.scale_idx] : 1.0) * part[0];
+}
+
+// One task of the factorization.  `defer_exit`: leave L, D, z and the inertia counters to a later
+// ldlt_factor_exit (the caller has something more urgent to do first).  Returns false when the
+// problem is not part of this attempt.
+template <int THREADS>
+__device__ __forceinline__ bool ldlt_factor_body(
+    const LdltDev& L, uint32_t task_index, bool first_task, const LdltTask& t, int b, unsigned char* smem_raw,
+    const double* __restrict__ lhs, int lhs_stride,
     const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
     const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt,
-    int slot_handoff, KktFuse F) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int slot_handoff, const KktFuse& F, bool defer_exit, FactorKeep* keep) {
   const int tid = threadIdx.x;
-  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
-    // a separable sum of the tape rides along (they only feed f, which nothing in this launch reads)
-    double* part = reinterpret_cast<double*>(smem_raw);
-    const NlpStructure::SumReduce r = F.red[blockIdx.x];
-    double acc = 0.0;
-    if (tid < 64) {
-      for (int k = tid; k < r.count; k += 64) acc += F.V[r.src_off + k];
-      part[tid] = acc;
-    }
-    __syncthreads();
-    for (int w = 32; w > 0; w >>= 1) {
-      if (tid < w) part[tid] += part[tid + w];
-      __syncthreads();
-    }
-    if (tid == 0) F.Vw[r.dst] = (r.scale_idx >= 0 ? F.scales[r.scale_idx] : 1.0) * part[0];
-    return;
-  }
-  const uint32_t task_index = task_base + blockIdx.x - static_cast<uint32_t>(F.n_blocks);
-  const LdltTask t = L.tasks[task_index];
-  const int b = blockIdx.y;
   // the counters the NEXT factorization attempt accumulates into (nobody touches them now)
-  if (stats_next != nullptr && task_index == task_base && tid == 0)
+  if (stats_next != nullptr && first_task && tid == 0)
     stats_next[b] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   const double delta = reg[2 * b], gamma = reg[2 * b + 1];
-  if (delta != delta) return;  // NaN: this problem is not part of the attempt
+  if (delta != delta) return false;  // NaN: this problem is not part of the attempt
   lhs += static_cast<size_t>(b) * lhs_stride;
   Lx += static_cast<size_t>(b) * lx_stride;
   D += static_cast<size_t>(b) * n;
@@ -541,27 +582,31 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   }
 
   SLPX_LDLT_CLOCK(4);
-  // ---- results + inertia (inertia.hpp:40-50: |d| <= eps counts as zero) ----
-  for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-    const double u = U[i];
-    if (flags[i] & 1) {
-      D[out[i]] = u;
-      const double eps = 2.220446049250313e-16;
-      if (u > eps) atomicAdd(&s_cnt[0], 1);
-      else if (u < -eps) atomicAdd(&s_cnt[1], 1);
-      else atomicAdd(&s_cnt[2], 1);
-      if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
-      else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
-    } else if (flags[i] & 4) {
-      zv[out[i]] = u * invd[col[i]];  // z = D⁻¹L⁻¹Pb: the forward solve came for free
-    } else {
-      Lx[out[i]] = u * invd[col[i]];
-    }
-  }
-  __syncthreads();
-  if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[b]) + tid, s_cnt[tid]);
-  if (tid == 0) atomicMin(&stats[b].min_abs_bits, *s_minp);
+  *keep = FactorKeep{U, invd, col, flags, out, s_cnt, s_minp};
+  if (!defer_exit) ldlt_factor_exit<THREADS>(*keep, t, b, Lx, D, zv, stats);
   SLPX_LDLT_CLOCK(5);
+  return true;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
+    LdltDev L, uint32_t task_base, const double* __restrict__ lhs, int lhs_stride,
+    const double* __restrict__ reg, double* __restrict__ Lx, long long lx_stride,
+    double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
+    LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
+    const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt,
+    int slot_handoff, KktFuse F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+    ride_along_sum(F, blockIdx.x, smem_raw);
+    return;
+  }
+  const uint32_t task_index = task_base + blockIdx.x - static_cast<uint32_t>(F.n_blocks);
+  const LdltTask t = L.tasks[task_index];
+  FactorKeep keep;
+  ldlt_factor_body<THREADS>(L, task_index, task_index == task_base, t, blockIdx.y, smem_raw, lhs, lhs_stride, reg, Lx,
+                            lx_stride, D, n, contrib, contrib_stride, stats, stats_next, rhs, zv, round_cnt,
+                            slot_handoff, F, false, &keep);
 }
 
 // ---------------------------------------------------------------------------
@@ -694,84 +739,110 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 // A chain's columns share a level: pass A takes the rows below the chain (all but the FIRST
 // w - pos - 1 items of a column), then the chain is finished top-down by chain_solve_wave.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ldlt_bwd_kernel(
-    LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
-    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out,
-    unsigned int* __restrict__ round_cnt, BacksubFuse F) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+struct BwdCarve {
+  uint4 *s_items, *s_rng, *s_lvl, *s_cp, *s_snd, *s_zent, *s_bs;
+  uint32_t g_items, g_rng, g_lvl, g_cp, g_snd, g_zent;
+  double *vals, *x;
+};
+// (WITH_ZENT: one more word per column — where the factorization left that column's z, for the
+// backward solve that runs in the factorization's workgroup)
+template <bool WITH_ZENT>
+__device__ __forceinline__ BwdCarve bwd_carve(unsigned char* smem, const LdltTask& t) {
+  BwdCarve c;
+  c.g_items = q16(t.n_bwd_items, 2);
+  c.g_rng = q16(t.n_col, 2);
+  c.g_lvl = q16(t.n_lvl + 1, 4);
+  c.g_cp = q16(t.n_col, 4);
+  c.g_snd = q16(3 * t.n_sn, 4);
+  c.g_zent = WITH_ZENT ? q16(t.n_col, 4) : 0;
+  c.s_items = reinterpret_cast<uint4*>(smem);
+  c.s_rng = c.s_items + c.g_items;
+  c.s_lvl = c.s_rng + c.g_rng;
+  c.s_cp = c.s_lvl + c.g_lvl;
+  c.s_snd = c.s_cp + c.g_cp;
+  c.s_zent = c.s_snd + c.g_snd;
+  c.vals = reinterpret_cast<double*>(c.s_zent + c.g_zent);
+  c.x = c.vals + t.n_bwd_items;
+  // the rows of the back-substitution this task owns (device.hpp: BacksubFuse), behind x[]
+  c.s_bs = reinterpret_cast<uint4*>(
+      smem + ((static_cast<uint32_t>(reinterpret_cast<unsigned char*>(c.x + t.n_col + 1) - smem) + 15u) & ~15u));
+  return c;
+}
+
+// the static part of a backward-solve task into LDS (no barrier: the caller's)
+template <int THREADS, bool FROM_FACTOR>
+__device__ __forceinline__ uint4 ldlt_bwd_stage(const LdltDev& L, const LdltTask& t, uint32_t task_index,
+                                                const BwdCarve& c, const BacksubFuse& F, const SolveInPlace& M) {
   const int tid = threadIdx.x;
-  // the verdict of the factorization this solve belongs to: known since the launch began; handed
-  // over by the last workgroup, a leaf task that has to wait for its ancestors anyway
-  if (F.on && blockIdx.x == gridDim.x - 1 && tid == 0 && F.stats_host != nullptr) {
-    F.stats_host[0] = F.stats_src[0];
-    if (F.seq_host != nullptr) {
-      __threadfence_system();
-      const unsigned long long v = *F.seq_dev + 1;
-      *F.seq_dev = v;
-      *F.seq_host = v;
-    }
+  stage16<THREADS>(c.s_items, reinterpret_cast<const uint4*>((FROM_FACTOR ? M.bwd_items_u : L.bwd_items) + t.bwd_item_off),
+                   c.g_items, tid);
+  stage16<THREADS>(c.s_rng, reinterpret_cast<const uint4*>(L.bwd_range + t.col_off), c.g_rng, tid);
+  stage16<THREADS>(c.s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_pack + t.lvl_off), c.g_lvl, tid);
+  stage16<THREADS>(c.s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), c.g_cp, tid);
+  if (t.n_sn) stage16<THREADS>(c.s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), c.g_snd, tid);
+  if (FROM_FACTOR) stage16<THREADS>(c.s_zent, reinterpret_cast<const uint4*>(M.col_zent + t.col_off), c.g_zent, tid);
+  uint4 bs_task = uint4{0, 0, 0, 0};
+  if (F.on) {
+    bs_task = F.task_plan[task_index];
+    stage16<THREADS>(c.s_bs, F.plan + bs_task.x, bs_task.y, tid);
   }
-  // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
-  const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
-  const LdltTask t = L.tasks[task_index];
-  const int b = blockIdx.y;
+  return bs_task;
+}
+
+// One task of the backward solve, its plan staged (and a barrier passed).  FROM_FACTOR: L and z
+// are taken from what the factorization of the same task left in this workgroup's LDS.
+template <int THREADS, bool FROM_FACTOR>
+__device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t, uint32_t task_index, int b,
+                                             const BwdCarve& c,
+                                             const uint4 bs_task, int n, const double* __restrict__ Lx,
+                                             long long lx_stride, const double* __restrict__ zv,
+                                             double* __restrict__ xg, double* __restrict__ out,
+                                             unsigned int* __restrict__ round_cnt, const BacksubFuse& F,
+                                             const FactorKeep* keep) {
+  const int tid = threadIdx.x;
   Lx += static_cast<size_t>(b) * lx_stride;
   zv += static_cast<size_t>(b) * n;
   xg += static_cast<size_t>(b) * n;
   out += static_cast<size_t>(b) * n;
-
-  SLPX_LDLT_CLOCK(16);
   const uint32_t n_items = t.n_bwd_items;
-  const uint32_t g_items = q16(n_items, 2), g_rng = q16(t.n_col, 2), g_lvl = q16(t.n_lvl + 1, 4),
-                 g_cp = q16(t.n_col, 4), g_snd = q16(3 * t.n_sn, 4);
-  uint4* s_items = reinterpret_cast<uint4*>(smem_raw);
-  uint4* s_rng = s_items + g_items;
-  uint4* s_lvl = s_rng + g_rng;
-  uint4* s_cp = s_lvl + g_lvl;
-  uint4* s_snd = s_cp + g_cp;
-  double* vals = reinterpret_cast<double*>(s_snd + g_snd);
-  double* x = vals + n_items;
-  const LdltSn* snd = reinterpret_cast<const LdltSn*>(s_snd);
-  uint2* items = reinterpret_cast<uint2*>(s_items);  // x = lpos, y = ref (rewritten in place)
-  const uint2* rng = reinterpret_cast<const uint2*>(s_rng);  // {first item below the column's own chain, end}
-  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(s_lvl);  // column | first chain << 16
-  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(s_cp);
-
-  stage16<256>(s_items, reinterpret_cast<const uint4*>(L.bwd_items + t.bwd_item_off), g_items, tid);
-  stage16<256>(s_rng, reinterpret_cast<const uint4*>(L.bwd_range + t.col_off), g_rng, tid);
-  stage16<256>(s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_pack + t.lvl_off), g_lvl, tid);
-  stage16<256>(s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), g_cp, tid);
-  if (t.n_sn) stage16<256>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
-  // the rows of the back-substitution this task owns (device.hpp: BacksubFuse), behind x[]
-  uint4* s_bs = reinterpret_cast<uint4*>(
-      smem_raw + ((static_cast<uint32_t>(reinterpret_cast<unsigned char*>(x + t.n_col + 1) - smem_raw) + 15u) & ~15u));
-  uint4 bs_task = uint4{0, 0, 0, 0};
-  if (F.on) {
-    bs_task = F.task_plan[task_index];
-    stage16<256>(s_bs, F.plan + bs_task.x, bs_task.y, tid);
-  }
-  __syncthreads();
+  double* vals = c.vals;
+  double* x = c.x;
+  const LdltSn* snd = reinterpret_cast<const LdltSn*>(c.s_snd);
+  uint2* items = reinterpret_cast<uint2*>(c.s_items);  // x = lpos (FROM_FACTOR: entry of U), y = ref (rewritten in place)
+  const uint2* rng = reinterpret_cast<const uint2*>(c.s_rng);  // {first item below the column's own chain, end}
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(c.s_lvl);  // column | first chain << 16
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(c.s_cp);
   SLPX_LDLT_CLOCK(17);
-  // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
-  {
-    uint32_t q = tid;
-    for (; q + 3 * 256 < n_items; q += 4 * 256) {
-      const double v0 = Lx[items[q].x], v1 = Lx[items[q + 256].x], v2 = Lx[items[q + 512].x],
-                   v3 = Lx[items[q + 768].x];
-      vals[q] = v0;
-      vals[q + 256] = v1;
-      vals[q + 512] = v2;
-      vals[q + 768] = v3;
+  if (FROM_FACTOR) {
+    const uint32_t* zent = reinterpret_cast<const uint32_t*>(c.s_zent);
+    for (uint32_t q = tid; q < n_items; q += THREADS) {
+      const uint32_t e = items[q].x;
+      vals[q] = keep->U[e] * keep->invd[keep->col[e]];  // what ldlt_factor_exit writes to Lx
     }
-    for (; q < n_items; q += 256) vals[q] = Lx[items[q].x];
-    for (uint32_t i = tid; i < t.n_col; i += 256) x[i] = zv[colperm[i]];
+    for (uint32_t i = tid; i < t.n_col; i += THREADS) x[i] = keep->U[zent[i]] * keep->invd[i];
+    if (tid == 0) x[t.n_col] = 1.0;
+  } else {
+    // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
+    uint32_t q = tid;
+    for (; q + 3 * THREADS < n_items; q += 4 * THREADS) {
+      const double v0 = Lx[items[q].x], v1 = Lx[items[q + THREADS].x], v2 = Lx[items[q + 2 * THREADS].x],
+                   v3 = Lx[items[q + 3 * THREADS].x];
+      vals[q] = v0;
+      vals[q + THREADS] = v1;
+      vals[q + 2 * THREADS] = v2;
+      vals[q + 3 * THREADS] = v3;
+    }
+    for (; q < n_items; q += THREADS) vals[q] = Lx[items[q].x];
+    for (uint32_t i = tid; i < t.n_col; i += THREADS) x[i] = zv[colperm[i]];
     if (tid == 0) x[t.n_col] = 1.0;
   }
   // this lane's row of the back-substitution: everything but p is known now
   constexpr int kBsPre = 4;
-  const BsRow* bs_rows = reinterpret_cast<const BsRow*>(s_bs);
-  const BsTerm* bs_terms = reinterpret_cast<const BsTerm*>(s_bs + bs_task.w);
-  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z;
+  const BsRow* bs_rows = reinterpret_cast<const BsRow*>(c.s_bs);
+  const BsTerm* bs_terms = reinterpret_cast<const BsTerm*>(c.s_bs + bs_task.w);
+  // (only tasks nobody waits for fetch ahead: the others hand x to their descendants first and do
+  // their rows afterwards, off the critical path — and must not stall here on these loads)
+  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z && t.round == 0;
   BsRow bs_row = BsRow{0, 0};
   double bs_a[kBsPre], bs_p[kBsPre], bs_s = 1.0, bs_z = 0.0, bs_ci = 0.0;
   uint32_t bs_ref[kBsPre];
@@ -802,7 +873,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   {
     // fold the finished x of ancestor rows into the staged values; those items then point at
     // the constant-one slot (each thread touches the items it staged itself: no barrier needed)
-    for (uint32_t q = tid; q < n_items; q += 256) {
+    for (uint32_t q = tid; q < n_items; q += THREADS) {
       const uint32_t ref = items[q].y;
       if (ref & 0x80000000u) {
         vals[q] *= coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr);
@@ -821,10 +892,10 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   // without a chain of two or more columns: ONE wave runs the whole level loop — eight 8-lane
   // groups — with no workgroup barrier between two levels (the wave's own LDS operations are
   // issued in order, only the compiler has to be kept from moving them across the level
-  // boundary).  Tasks with chains: all four waves, thirty-two groups, one barrier after the
-  // gather and one after the chains, which get a wave each (a barrier of four waves is ~40
-  // clocks; solving the chains of a level one after the other in a single wave cost more than
-  // the levels it saved: backward solve at N=5000 39.9 -> 52.5 us).
+  // boundary).  Tasks with chains: every wave, one barrier after the gather and one after the
+  // chains, which get a wave each (a barrier of four waves is ~40 clocks; solving the chains
+  // of a level one after the other in a single wave cost more than the levels it saved:
+  // backward solve at N=5000 39.9 -> 52.5 us).
   if (t.n_sn == 0) {
     if (tid < 64) {
       const int lane8 = tid & 7, grp = tid >> 3;
@@ -851,7 +922,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
       const uint32_t next_pack = lvl[l >= 1 ? l - 1 : 0];
       const uint32_t beg = beg_pack & 0xffffu, end = end_pack & 0xffffu;
-      for (uint32_t i = beg + grp; i < end; i += 32) {
+      for (uint32_t i = beg + grp; i < end; i += THREADS / 8) {
         const uint2 r = rng[i];
         double partial = 0.0;
         for (uint32_t q = r.x + lane8; q < r.y; q += 8) partial += vals[q] * x[items[q].y];
@@ -861,7 +932,7 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
       __syncthreads();
       const uint32_t sb = beg_pack >> 16, se = end_pack >> 16;
       if (se > sb) {  // chains of two or more columns in this level (block-uniform)
-        for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += 4)
+        for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += THREADS / 64)
           chain_solve_wave<false>(x, vals, rng, __builtin_amdgcn_readfirstlane(snd[q].col0),
                                   __builtin_amdgcn_readfirstlane(snd[q].w), tid & 63);
         __syncthreads();
@@ -872,28 +943,30 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(19);
-  for (uint32_t i = tid; i < t.n_col; i += 256) {
-    const uint32_t pj = colperm[i];
-    coherent_store(&xg[pj], x[i], round_cnt != nullptr);
-    out[L.perm[pj]] = x[i];
-  }
+  // the descendants wait for x alone: hand it over before anything else goes out
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], round_cnt != nullptr);
+  if (round_cnt != nullptr)
+    round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
+                 t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
   if (F.on) {
     const double m = F.mu[0];
     auto p_of = [&](uint32_t ref) {
       return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr) : x[ref];
     };
-    for (uint32_t j = tid; j < bs_task.z; j += 256) {
-      const BsRow row = j == static_cast<uint32_t>(tid) ? bs_row : bs_rows[j];
+    for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
+      const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
+      const BsRow row = ahead ? bs_row : bs_rows[j];
       const uint32_t first = row.terms & 0xfffffu, cnt = row.terms >> 20;
       double aipx = 0.0, s_r = bs_s, z_r = bs_z, ci_r = bs_ci;
       uint32_t k0 = 0;
-      if (j == static_cast<uint32_t>(tid)) {
+      if (ahead) {
 #pragma unroll
         for (int k = 0; k < kBsPre; ++k)
           if (static_cast<uint32_t>(k) < cnt)
             aipx = backsub_dot(aipx, bs_a[k], (bs_ref[k] & 0x80000000u) ? bs_p[k] : x[bs_ref[k]]);
         k0 = kBsPre;
-      } else {  // (more rows than lanes: nothing was fetched ahead)
+      } else {  // (nothing was fetched ahead)
         s_r = F.s[row.r];
         z_r = F.z[row.r];
         ci_r = F.V[F.off_ci + row.r];
@@ -905,10 +978,97 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
       backsub_row(ci_r, s_r, z_r, m, aipx, &F.ps[row.r], &F.pz[row.r]);
     }
   }
-  if (round_cnt != nullptr)
-    round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
-                 t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
   SLPX_LDLT_CLOCK(20);
+}
+
+// the factorization's inertia counters to the host (pinned memory) with a sequence number it spins on
+__device__ __forceinline__ void publish_stats(const BacksubFuse& F, bool coherent) {
+  LdltStats st;
+  if (coherent) {
+    const int* src = reinterpret_cast<const int*>(F.stats_src);
+    st.n_pos = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_neg = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_zero = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_bad = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.min_abs_bits = __hip_atomic_load(&F.stats_src->min_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    st = F.stats_src[0];
+  }
+  F.stats_host[0] = st;
+  if (F.seq_host != nullptr) {
+    __threadfence_system();
+    const unsigned long long v = *F.seq_dev + 1;
+    *F.seq_dev = v;
+    *F.seq_host = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ldlt_bwd_kernel(
+    LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
+    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out,
+    unsigned int* __restrict__ round_cnt, BacksubFuse F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // the verdict of the factorization this solve belongs to: known since the launch began; handed
+  // over by the last workgroup, a leaf task that has to wait for its ancestors anyway
+  if (F.on && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && F.stats_host != nullptr) publish_stats(F, false);
+  // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
+  const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
+  SLPX_LDLT_CLOCK(16);
+  const BwdCarve c = bwd_carve<false>(smem_raw, t);
+  const uint4 bs_task = ldlt_bwd_stage<256, false>(L, t, task_index, c, F, SolveInPlace{});
+  __syncthreads();
+  ldlt_bwd_run<256, false>(L, t, task_index, blockIdx.y, c, bs_task, n, Lx, lx_stride, zv, xg, out, round_cnt, F, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// Factorization and backward solve of a Newton step in ONE launch (one problem, every task's
+// workgroup resident at once: DeviceNlp checks the occupancy): each workgroup factors its task
+// and then, when its ancestors' x are final, solves it — from the L and z it still holds in LDS.
+// Against the two launches this drops, on the critical path through the root task, the write of
+// L, the end of one kernel and the start of the next, and the staging and gather of the solve
+// (profiles/: ~8 us of 66).  The root solves first and writes L, D, z and its inertia counters
+// afterwards; the others write them while they wait.  The workgroup that finishes the LAST exit
+// hands the counters to the host.
+// LDS: the factorization's carve-up, then at M.bwd_lds_off the solve's.
+// ---------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_factor_solve_kernel(
+    LdltDev L, const double* __restrict__ lhs, const double* __restrict__ reg, double* __restrict__ Lx,
+    double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
+    LdltStats* __restrict__ stats_next, const double* __restrict__ rhs, double* __restrict__ zv,
+    unsigned int* __restrict__ fround_cnt, int slot_handoff, KktFuse F, double* __restrict__ xg,
+    double* __restrict__ out, unsigned int* __restrict__ bround_cnt, BacksubFuse B, SolveInPlace M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+    ride_along_sum(F, blockIdx.x, smem_raw);
+    return;
+  }
+  const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
+  const LdltTask t = L.tasks[task_index];
+  const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
+  // the solve's plan travels with the factorization's
+  const BwdCarve c = bwd_carve<true>(smem_raw + M.bwd_lds_off, t);
+  const uint4 bs_task = ldlt_bwd_stage<THREADS, true>(L, t, task_index, c, B, M);
+  FactorKeep keep;
+  if (!ldlt_factor_body<THREADS>(L, task_index, task_index == 0, t, 0, smem_raw, lhs, 0, reg, Lx, 0, D, n, contrib, 0,
+                                 stats, stats_next, rhs, zv, fround_cnt, slot_handoff, F, /*defer_exit=*/true, &keep))
+    return;
+  auto exit_and_count = [&] {
+    ldlt_factor_exit<THREADS>(keep, t, 0, Lx, D, zv, stats);
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
+      const unsigned int old = __hip_atomic_fetch_add(M.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == M.n_tasks) {
+        __hip_atomic_store(M.exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (B.stats_host != nullptr) publish_stats(B, true);
+      }
+    }
+  };
+  if (!top) exit_and_count();  // (its store acknowledgements come in while the task waits for its ancestors)
+  __syncthreads();
+  ldlt_bwd_run<THREADS, true>(L, t, task_index, 0, c, bs_task, n, Lx, 0, zv, xg, out, bround_cnt, B, &keep);
+  if (top) exit_and_count();
 }
 
 }  // namespace slpx

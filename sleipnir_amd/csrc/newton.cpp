@@ -171,10 +171,11 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
       m_dev->launch_step_graph(refresh_ad, d, g, a);
       return;
     }
-    m_dev->factor(d, g, a);
     if (solve_speculatively) {
-      m_dev->solve_backsub_publish();
+      m_dev->factor_solve_publish(d, g, a);
       if (m_after_attempt) m_after_attempt();
+    } else {
+      m_dev->factor(d, g, a);
     }
   };
   const int n = m_s.n, m_e = m_s.m_e;

@@ -182,7 +182,7 @@ def batched_probe(sa, cases, N, B, device):
         "hbm_frac": {k: B * v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS for k, v in gb.items()},
         "factorizations_per_step": kb["factorizations"],
     }
-    tfile = ROOT / "profiles" / f"{PROFILE_TAG}_batched_traffic.json"
+    tfile = ROOT / "profiles" / f"{PROFILE_TAG}_b512xN1000_traffic.json"
     if tfile.exists() and N == 1000 and B == 512:
         tj = json.loads(tfile.read_text())
         pre = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
@@ -320,8 +320,23 @@ def main():
             "unregularized_attempt": "not launched: the symbolic phase found a structurally zero pivot"
             if info["struct_singular"] else "launched",
         }
-        dom = max(groups, key=lambda k: groups[k][0] * (nf if k == "ldlt_factor" else 1.0))
-        dom_ms, dom_bytes = groups[dom]
+        # A single problem's step is two launches (the AD sweep; KKT evaluation + factorization +
+        # backward solve + back-substitution in one: csrc/device.hpp KktFuse / BacksubFuse,
+        # ldlt_factor_solve_kernel); the second one's algorithmic bytes are the SURVEY.md §8d
+        # figures of the stages it performs.  `groups` (the stages as kernels of their own)
+        # stays in the line as per_kernel_ms: it is what batches run and what the step falls
+        # back to when the launch cannot be used.
+        fused = system.time_fused_step(iters=max(10, min(100, args.steps))) if B == 1 else None
+        if fused is not None and fused["one_launch"]:
+            stage_keys = ("kkt_assemble", "kkt_rhs", "ldlt_factor", "ldlt_solve")
+            groups_step = {"tape_sweep": (fused["sweep"], groups["tape_sweep"][1]),
+                           "kkt_factor_solve": (fused["kkt_factor_solve"],
+                                                sum(groups[k][1] for k in stage_keys) +
+                                                8 * (n + 4 * mi) + 12 * info["nnz_Ai"])}
+        else:
+            groups_step = groups
+        dom = max(groups_step, key=lambda k: groups_step[k][0] * (nf if k == "ldlt_factor" else 1.0))
+        dom_ms, dom_bytes = groups_step[dom]
         achieved = B * dom_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per step of each kernel group from the committed PMC passes
         # (profiles/collect.py; FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE)
@@ -329,9 +344,10 @@ def main():
         tfile = ROOT / "profiles" / f"{PROFILE_TAG}_traffic.json"
         if tfile.exists() and args.workload == "single" and N == 1000 and B == 1:
             tj = json.loads(tfile.read_text())
-            prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
+            prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates"),
+                      "kkt_factor_solve": "ldlt_factor_solve_kernel",
                       "kkt_assemble": "kkt_assemble_kernel",
-                      "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor",
+                      "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
                       "ldlt_solve": ("ldlt_fwd", "ldlt_bwd")}
             traffic_by_group = {}
             for grp, pre in prefix.items():
@@ -342,9 +358,11 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None if traffic_by_group is None else traffic_by_group[dom],
+            "traffic": None if traffic_by_group is None else traffic_by_group.get(dom),
             "traffic_per_kernel": traffic_by_group,
             "algorithmic_bytes_per_launch": B * dom_bytes, "launch_ms": dom_ms,
+            "step_launches_ms": {k: v[0] for k, v in groups_step.items()},
+            "step_launches_algorithmic_bytes": {k: B * v[1] for k, v in groups_step.items()},
             "per_kernel_ms": {k: v[0] for k, v in groups.items()},
             "per_kernel_GBps": {k: B * v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None
                                 for k, v in groups.items()},

@@ -296,6 +296,13 @@ int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24);
  * backsub, sum, factorizations per step} */
 int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms);
 
+/* The same for the launches a single problem's Newton step actually makes (device.hpp: KktFuse,
+ * BacksubFuse, ldlt_factor_solve_kernel): ms[4] = {AD sweep launch, the launch that evaluates the
+ * KKT system, factorizes, solves and back-substitutes (first attempt of the policy loop's
+ * settled regularization), their sum, 1 if that single launch exists for this system — 0: the
+ * step is made of the kernels slpx_system_time_step times and ms[1] is their sum} */
+int slpx_system_time_fused_step(slpx_system* s, int iters, float* ms);
+
 /* Profiling aid: wall_clock64() ticks (100 MHz) recorded by workgroup 0 of the last tape
  * sweep at {entry, staged, leaves, forward done, values out, adjoints done, exit};
  * out16[0..7] = 64-thread kernel, out16[8..15] = 256-thread kernel. */

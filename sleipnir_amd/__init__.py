@@ -161,6 +161,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_system_time_fused_step", ctypes.c_int, vp, ctypes.c_int, vp)
     sig("slpx_newton_steps", ctypes.c_int, vp, i32, ctypes.c_int, ctypes.c_int, vp)
     sig("slpx_system_regularization", ctypes.c_int, vp, vp)
     sig("slpx_problem_add_callback", ctypes.c_int, vp, vp, vp)
@@ -479,6 +480,13 @@ class System:
     def set_lhs(self, lhs):
         a = _f64(lhs)
         _check(lib().slpx_system_set_lhs(self._h, a.ctypes.data))
+
+    def time_fused_step(self, iters=10):
+        """The launches a single problem's step really makes (slpx_system_time_fused_step)."""
+        ms = np.zeros(4, dtype=np.float32)
+        _check(lib().slpx_system_time_fused_step(self._h, iters, ms.ctypes.data))
+        return {"sweep": float(ms[0]), "kkt_factor_solve": float(ms[1]), "total": float(ms[2]),
+                "one_launch": bool(ms[3])}
 
     def time_step(self, iters=10, refresh_ad=True):
         ms = np.zeros(8, dtype=np.float32)

@@ -12,6 +12,7 @@
 #include <filesystem>
 
 #include "capi_internal.hpp"
+#include "ipm.hpp"
 #include "tape_jit.hpp"
 #include "problems.hpp"
 
@@ -35,7 +36,7 @@ int guard(F&& f) {
 
 extern "C" {
 
-int slpx_abi_version(void) { return 2; }
+int slpx_abi_version(void) { return 3; }
 const char* slpx_last_error(void) { return g_error.c_str(); }
 int slpx_device_count(void) {
   int count = 0;
@@ -217,6 +218,18 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
     const int b = slpx::prebuild_tape_templates(st.values, opt, where, log);
     if (a < 0 || b < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
     bodies = a + b;
+    // the feasibility-restoration system a solve compiles on first use (csrc/ipm.cpp)
+    if (!ce.empty() || !ci.empty()) {
+      const slpx::RestorationModel rm = slpx::build_restoration_model(slpx::graph(), xs, ce, ci);
+      const slpx::NlpStructure rs =
+          slpx::build_nlp_structure(slpx::graph(), rm.vars, rm.cost, rm.c_e, rm.c_i, slpx::TapeCompileOptions{});
+      slpx::TapeJitOptions ropt;
+      ropt.n_unscaled_inputs = static_cast<uint32_t>(rs.n);
+      const int ra = slpx::prebuild_tape_templates(rs.full, ropt, where, log);
+      const int rb = slpx::prebuild_tape_templates(rs.values, ropt, where, log);
+      if (ra < 0 || rb < 0) throw std::runtime_error("slpx_problem_prebuild_kernels (restoration): " + log);
+      bodies += ra + rb;
+    }
   });
   return rc == 0 ? bodies : rc;
 }
@@ -696,6 +709,46 @@ int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms) 
     }
     ms[6] = ms[0] + ms[1] + ms[2] + ms[3] + ms[4] + ms[5];
     ms[7] = static_cast<float>(nfact);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  });
+}
+
+int slpx_system_time_fused_step(slpx_system* s, int iters, float* ms) {
+  return guard([&] {
+    slpx::NewtonSystem& sys = s->get();
+    slpx::DeviceNlp& dev = sys.device();
+    const int B = sys.options().batch;
+    hipStream_t st = dev.stream();
+    hipEvent_t e0, e1;
+    SLPX_HIP_CHECK(hipEventCreate(&e0));
+    SLPX_HIP_CHECK(hipEventCreate(&e1));
+    auto timed = [&](auto&& launch) {
+      launch();
+      SLPX_HIP_CHECK(hipStreamSynchronize(st));
+      SLPX_HIP_CHECK(hipEventRecord(e0, st));
+      for (int it = 0; it < iters; ++it) launch();
+      SLPX_HIP_CHECK(hipEventRecord(e1, st));
+      SLPX_HIP_CHECK(hipEventSynchronize(e1));
+      float t = 0;
+      SLPX_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+      return t / static_cast<float>(iters);
+    };
+    // the regularization the policy loop settles on for this state
+    sys.reset_regularization();
+    dev.sweep_full();
+    dev.assemble();
+    dev.build_rhs();
+    sys.compute();
+    const std::vector<double> delta = sys.hessian_regularization(), gamma = sys.constraint_jacobian_regularization();
+    const std::vector<uint8_t> active(B, 1);
+    ms[0] = timed([&] { dev.sweep_full(/*with_reduce=*/false); });
+    ms[1] = timed([&] {
+      dev.build_kkt_for_step(/*with_reduce=*/true);
+      dev.factor_solve_publish(delta, gamma, active);
+    });
+    ms[2] = ms[0] + ms[1];
+    ms[3] = dev.step_is_one_launch() ? 1.0f : 0.0f;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   });

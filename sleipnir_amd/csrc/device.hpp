@@ -309,6 +309,7 @@ class DeviceNlp {
                          const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
+  bool step_is_one_launch() const { return m_fuse_solve && m_fuse_kkt; }
   void solve_backsub_publish();                     // solve_after_factor() + backsub_publish(), one launch where possible
   // factor() + solve_backsub_publish(): ONE launch where every task's workgroup fits on the device at once
   void factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,

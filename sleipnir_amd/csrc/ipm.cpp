@@ -949,13 +949,11 @@ void compute_p_n(const Vec& c, double rho, double mu, Vec& p, Vec& n) {
 //
 // x_R, w and the outer problem's row scalings d_ce, d_ci are tape PARAMETERS (free
 // Variables), so one compiled system serves every restoration call of every solve.
-NewtonSystem& restoration_system(NewtonSystem& outer) {
-  auto& R = outer.restoration();
-  if (R.sys) return *R.sys;
-  Graph& g = outer.graph();
-  const auto& xs = outer.x_nodes();
-  const auto& ces = outer.c_e_nodes();
-  const auto& cis = outer.c_i_nodes();
+}  // namespace
+
+RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs, const std::vector<NodeId>& ces,
+                                         const std::vector<NodeId>& cis) {
+  RestorationModel R;
   const size_t n = xs.size(), m_e = ces.size(), m_i = cis.size();
   constexpr double rho = 1e3;
 
@@ -985,23 +983,36 @@ NewtonSystem& restoration_system(NewtonSystem& outer) {
   // components with tens of thousands of nodes — one 1024-thread workgroup walking them in
   // HBM scratch, measured 0.68 ms per sweep, 57 % of the GPU time of a cart-pole N=750 solve.
   const NodeId half = g.constant(0.5), rho_c = g.constant(rho);
-  NodeId cost = kNull;
+  R.cost = kNull;
   for (size_t k = 0; k < n; ++k) {
     const NodeId d = g.sub(xs[k], R.x_ref[k]);
-    cost = g.add(cost, g.mul(g.mul(half, R.weight[k]), g.mul(d, d)));
+    R.cost = g.add(R.cost, g.mul(g.mul(half, R.weight[k]), g.mul(d, d)));
   }
-  for (size_t k = n; k < R.vars.size(); ++k) cost = g.add(cost, g.mul(rho_c, R.vars[k]));
+  for (size_t k = n; k < R.vars.size(); ++k) R.cost = g.add(R.cost, g.mul(rho_c, R.vars[k]));
 
-  std::vector<NodeId> c_e(m_e), c_i;
+  R.c_e.resize(m_e);
   for (size_t j = 0; j < m_e; ++j)
-    c_e[j] = g.add(g.sub(g.mul(R.d_ce[j], ces[j]), p_e[j]), n_e[j]);
+    R.c_e[j] = g.add(g.sub(g.mul(R.d_ce[j], ces[j]), p_e[j]), n_e[j]);
   for (size_t j = 0; j < m_i; ++j)
-    c_i.push_back(g.add(g.sub(g.mul(R.d_ci[j], cis[j]), p_i[j]), n_i[j]));
-  for (size_t k = n; k < R.vars.size(); ++k) c_i.push_back(R.vars[k]);
+    R.c_i.push_back(g.add(g.sub(g.mul(R.d_ci[j], cis[j]), p_i[j]), n_i[j]));
+  for (size_t k = n; k < R.vars.size(); ++k) R.c_i.push_back(R.vars[k]);
+  return R;
+}
 
+namespace {
+
+NewtonSystem& restoration_system(NewtonSystem& outer) {
+  auto& R = outer.restoration();
+  if (R.sys) return *R.sys;
+  RestorationModel M = build_restoration_model(outer.graph(), outer.x_nodes(), outer.c_e_nodes(), outer.c_i_nodes());
+  R.vars = std::move(M.vars);
+  R.x_ref = std::move(M.x_ref);
+  R.weight = std::move(M.weight);
+  R.d_ce = std::move(M.d_ce);
+  R.d_ci = std::move(M.d_ci);
   NewtonOptions opt = outer.options();
   opt.batch = 1;
-  R.sys = std::make_unique<NewtonSystem>(g, R.vars, cost, c_e, c_i, opt);
+  R.sys = std::make_unique<NewtonSystem>(outer.graph(), R.vars, M.cost, M.c_e, M.c_i, opt);
   return *R.sys;
 }
 

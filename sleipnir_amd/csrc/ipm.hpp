@@ -114,4 +114,14 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
                           std::vector<double>* y_out = nullptr, std::vector<double>* z_out = nullptr,
                           SolveReport* report = nullptr);
 
+// The restoration model (feasibility_restoration.hpp:347-628) as graph nodes: what
+// feasibility_restoration() compiles on first use, and what slpx_problem_prebuild_kernels
+// compiles ahead of time.
+struct RestorationModel {
+  std::vector<NodeId> vars, x_ref, weight, d_ce, d_ci, c_e, c_i;
+  NodeId cost = kNull;
+};
+RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs, const std::vector<NodeId>& ces,
+                                         const std::vector<NodeId>& cis);
+
 }  // namespace slpx

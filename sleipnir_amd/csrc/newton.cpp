@@ -26,43 +26,44 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
     (void)hipGetLastError();
   });
-  m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape);
-  lap("= AD structure + tape compile");
-  m_k = build_kkt_plan(m_s);
-  lap("= KKT plan");
-  // which diagonal entries of the unregularized lhs have any source at all
-  std::vector<uint8_t> diag_has_source(m_k.dim, 0);
-  for (int c = 0; c < m_k.dim; ++c)
-    for (int p = m_k.lhs.colptr[c]; p < m_k.lhs.colptr[c + 1]; ++p)
-      if (m_k.lhs.rowidx[p] == c)
-        diag_has_source[c] = (m_k.dptr[p + 1] > m_k.dptr[p]) || (m_k.pptr[p + 1] > m_k.pptr[p]);
-  // One problem: big tasks = few rounds and levels (latency).  A batch is throughput bound
-  // by how many tasks fit a CU's LDS at once: half-size tasks (~30 KB instead of ~60 KB)
-  // put five instead of two workgroups on a CU and have fewer levels each.
-  LdltOptions lopt = opt.ldlt;
-  if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
-  // one lane per problem (ldlt_il_kernels.h): a task's values x 64 problems must fit LDS
-  // (measured at 512 x N=1000, ms per factorization: 192 -> 0.55 but some problems then need a
-  // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
-  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
-  // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
-  if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
-  if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
-  if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
-  if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
-  if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
-  m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
-  // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
-  // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
-  // and usually has a round more than necessary; twice the task size fixes both (cart-pole
-  // N=5000: 547 tasks / 4 rounds -> 265 / 3, factorization 73 -> 62 us, backward solve 42 -> 38;
-  // at N=1000 the 137 tasks of the default are the better choice: 39 vs 45 us).
-  if (opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
-      std::getenv("SLPX_TASK_ENTRIES") == nullptr) {
-    lopt.task_entries *= 2;
-    m_l = build_ldlt_plan(m_k.lhs, m_s.n, lopt, user_perm, &diag_has_source);
-  }
-  lap("= LDLT symbolic");
+  // the KKT plan and the symbolic factorization (25 ms at N=1000) alongside the tape compiler
+  auto plan_linear_algebra = [&](const NlpStructure& st) {
+    m_k = build_kkt_plan(st);
+    // which diagonal entries of the unregularized lhs have any source at all
+    std::vector<uint8_t> diag_has_source(m_k.dim, 0);
+    for (int c = 0; c < m_k.dim; ++c)
+      for (int p = m_k.lhs.colptr[c]; p < m_k.lhs.colptr[c + 1]; ++p)
+        if (m_k.lhs.rowidx[p] == c)
+          diag_has_source[c] = (m_k.dptr[p + 1] > m_k.dptr[p]) || (m_k.pptr[p + 1] > m_k.pptr[p]);
+    // One problem: big tasks = few rounds and levels (latency).  A batch is throughput bound
+    // by how many tasks fit a CU's LDS at once: half-size tasks (~30 KB instead of ~60 KB)
+    // put five instead of two workgroups on a CU and have fewer levels each.
+    LdltOptions lopt = opt.ldlt;
+    if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
+    // one lane per problem (ldlt_il_kernels.h): a task's values x 64 problems must fit LDS
+    // (measured at 512 x N=1000, ms per factorization: 192 -> 0.55 but some problems then need a
+    // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
+    if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+    // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
+    if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
+    if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
+    if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
+    if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
+    if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
+    m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
+    // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
+    // and usually has a round more than necessary; twice the task size fixes both (cart-pole
+    // N=5000: 547 tasks / 4 rounds -> 265 / 3, factorization 73 -> 62 us, backward solve 42 -> 38;
+    // at N=1000 the 137 tasks of the default are the better choice: 39 vs 45 us).
+    if (opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
+        std::getenv("SLPX_TASK_ENTRIES") == nullptr) {
+      lopt.task_entries *= 2;
+      m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    }
+  };
+  m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
+  lap("= AD structure + tape compile, KKT plan, LDLT symbolic");
   device_job.get();
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
   lap("= device upload + tape JIT");

@@ -109,7 +109,8 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
 
 NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId f_in,
                                  const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
-                                 const TapeCompileOptions& opt) {
+                                 const TapeCompileOptions& opt,
+                                 const std::function<void(const NlpStructure&)>& on_patterns) {
   NlpStructure s;
   SetupLap lap;
   s.graph_nodes_before = g.size();
@@ -331,9 +332,12 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   lap("V layout, separable sums");
   // the two tapes only read the graph: the small one (values only) compiles on a second thread
   auto values_job = std::async(std::launch::async, [&] { return compile_tape(g, inputs, live_vouts, {}, opt); });
+  std::future<void> patterns_job;
+  if (on_patterns) patterns_job = std::async(std::launch::async, [&] { on_patterns(s); });
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);
   lap("tape compile (full)");
   s.values = values_job.get();
+  if (patterns_job.valid()) patterns_job.get();
   lap("tape compile (values): the wait");
   s.full.n_inputs = s.values.n_inputs = s.n_inputs();
   s.full.n_outputs = s.values.n_outputs = s.nV;

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "graph.hpp"
@@ -59,6 +60,10 @@ struct NlpStructure {
 // the constraint roots already in `lhs - rhs` form (variable.hpp:716-778).
 NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId f,
                                  const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
-                                 const TapeCompileOptions& opt = {});
+                                 const TapeCompileOptions& opt = {},
+                                 const std::function<void(const NlpStructure&)>& on_patterns = {});
+// (`on_patterns` runs on a thread of its own as soon as everything but the two tape programs is
+// in place — sizes, V layout, sparsity patterns — and is joined before the function returns: the
+// KKT plan and the symbolic factorization only need those, and the tape compiler is the long pole)
 
 }  // namespace slpx

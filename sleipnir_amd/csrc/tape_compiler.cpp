@@ -101,7 +101,12 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
           stack.push_back(a);
         }
     }
-    std::sort(reach.begin(), reach.end());
+    // ascending ids (children first): read off the marks instead of sorting the visit order
+    const size_t count = reach.size();
+    reach.clear();
+    reach.reserve(count);
+    for (size_t n = 0; n < seen.size(); ++n)
+      if (seen[n]) reach.push_back(static_cast<NodeId>(n));
   }
   // graph node -> working-copy node (-1: not reachable); a flat table, the lookups are hot
   struct NodeTable {
@@ -120,9 +125,36 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     // propagated separately through the duplicates is now summed first.
     bool cse = opt.cse;
     if (const char* env = std::getenv("SLPX_TAPE_CSE")) cse = env[0] != '0';
-    std::unordered_map<uint64_t, int32_t> seen;
-    std::unordered_map<uint64_t, int32_t> seen_const;
-    if (cse) seen.reserve(reach.size());
+    // open addressing, keys are never 0 (the opcode byte of an interior node is not): a node-based
+    // map was a third of the whole tape compilation
+    struct FlatMap {
+      std::vector<uint64_t> keys;
+      std::vector<int32_t> vals;
+      uint64_t mask;
+      explicit FlatMap(size_t n) {
+        size_t cap = 16;
+        while (cap < 2 * n) cap <<= 1;
+        keys.assign(cap, 0);
+        vals.assign(cap, 0);
+        mask = cap - 1;
+      }
+      // the slot of `key` (fresh: it was not there and has been claimed)
+      int32_t* find_or_claim(uint64_t key, bool& fresh) {
+        uint64_t h = key * 0x9e3779b97f4a7c15ull;
+        h ^= h >> 29;
+        for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+          if (keys[i] == key) {
+            fresh = false;
+            return &vals[i];
+          }
+          if (keys[i] == 0) {
+            keys[i] = key;
+            fresh = true;
+            return &vals[i];
+          }
+        }
+      }
+    } seen(cse ? reach.size() : 0);
     for (NodeId n : reach) {
       int32_t l = g.a0[n] == kNull ? -1 : to_cg.at(g.a0[n]);
       int32_t r = g.a1[n] == kNull ? -1 : to_cg.at(g.a1[n]);
@@ -132,12 +164,13 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         if ((g.op[n] == OP_ADD || g.op[n] == OP_MUL) && kr >= 0 && kr < kl) std::swap(kl, kr);
         const uint64_t key = (static_cast<uint64_t>(g.op[n]) << 56) | (static_cast<uint64_t>(kl) << 28) |
                              static_cast<uint64_t>(kr + 1);
-        auto [it, fresh] = seen.try_emplace(key, 0);
+        bool fresh = false;
+        int32_t* slot = seen.find_or_claim(key | (1ull << 63), fresh);
         if (!fresh) {
-          to_cg[n] = it->second;
+          to_cg[n] = *slot;
           continue;
         }
-        it->second = to_cg[n] = cg.add(g.op[n], l, r, n);
+        *slot = to_cg[n] = cg.add(g.op[n], l, r, n);
         continue;
       }
       to_cg[n] = cg.add(g.op[n], l, r, n);

@@ -44,4 +44,8 @@ PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>
 PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
 for B in latency icache chain; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
 PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= " > $N/${TAG}_setup_time.txt
+# 5. whole solves over the BASELINE horizons; the launch-fusion switches one by one
+PYTHONPATH=$R timeout 600 python profiles/horizon_sweep.py > $N/${TAG}_horizon_sweep.txt 2>&1
+bash profiles/ab_fuse.sh > $N/${TAG}_fusion_ab.txt 2>&1
+for v in all nosolve none; do cp $O/timeline_$v.txt $N/${TAG}_step_timeline_fuse_$v.txt; done
 tail -5 $O/collect.log

@@ -395,7 +395,7 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     std::vector<int32_t> chain{j};
     sn_of[j] = static_cast<int32_t>(sn_cols.size());
     int32_t k = j;
-    while (opt.supernodal && chain.size() < kSnWidthMax) {
+    while (opt.supernodal && chain.size() < opt.max_supernode_width) {
       const int32_t p = P.parent[k];
       // rows of the trapezoid after adding p: chain + struct(L_p) + rhs row
       if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||

@@ -162,6 +162,9 @@ struct LdltOptions {
   // levels (profiles/microbench/chain.hip), so a pair gains nothing (cart-pole N=1000, steps/s:
   // 2 -> 11.39 k, 4 -> 11.52 k, off -> 10.42 k; N=5000: 7.66 k, 7.69 k, 7.08 k)
   int min_supernode_width = 4;
+  // chains are cut at this many columns; the device kernels hold a row of kSnWidthMax doubles in
+  // registers, wider plans are for the host interpreter's what-if statistics only
+  uint32_t max_supernode_width = kSnWidthMax;
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

@@ -132,6 +132,7 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (task_entries > 0) lopt.task_entries = task_entries;
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
+  if (const char* env = std::getenv("SLPX_HOSTCHECK_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
   h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);

@@ -82,6 +82,25 @@ def test_supernodal_levels(fresh, slpx, orc, hostcheck):
     print("cart-pole N=1000 plan:", plan, " g-fold N=100 plan:", pg, " g-fold chains >= 12 columns (w, rows below):", wide)
 
 
+@pytest.mark.parametrize("width,levels_cp,levels_gf", [(16, 18, 29), (32, 18, 24)])
+def test_wider_supernodes_what_if(fresh, slpx, orc, hostcheck, monkeypatch, width, levels_cp, levels_gf):
+    """DESIGN.md §4 (MFMA panels: measured, not built): what cutting chains at 16 / 32 columns
+    instead of the kernels' 8 would do to the critical path — the plans are valid (the host
+    interpreter reproduces the oracle's step with them), the device kernels do not take them."""
+    from tests.support import gfold, model
+
+    monkeypatch.setenv("SLPX_HOSTCHECK_SN_MAX_WIDTH", str(width))
+    pp, op = cases.build_pair("cart_pole", 1000, slpx, orc)
+    plan = hostcheck.HostCheck(pp).supernode_plan()
+    assert plan["critical_levels"] == levels_cp and plan["widest"] == 13
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    pg = hostcheck.HostCheck(gfold.build(mp, 100).p).supernode_plan()
+    assert pg["critical_levels"] == levels_gf and pg["widest"] == min(width, 20)
+    pq, oq = cases.build_pair("cart_pole", 37, slpx, orc)
+    parity.check_newton_step(hostcheck.HostCheck(pq), oq, "interior")
+
+
 def test_small_tasks_force_many_rounds(fresh, slpx, orc, hostcheck):
     """Tiny LDS budgets: many tape tasks, many LDLᵀ rounds, lots of cross-task
     contribution slots — results must not change."""

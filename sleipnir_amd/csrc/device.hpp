@@ -431,6 +431,19 @@ class DeviceNlp {
   bool m_defer_kkt = false;           // build_kkt() only notes the request ...
   int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
   bool m_fuse_solve = false;          // ldlt_factor_solve_kernel (SLPX_FUSE_SOLVE)
+  // backward solve: x of finished columns handed to the descendants through the values (two
+  // buffers, the solves alternate; a captured graph has its pointers baked in: counters there)
+  bool m_xg_by_data = false;
+  int m_xg_parity = 0;
+  DevBuf<double> m_xg2;
+  double* xg_now() { return (m_xg_by_data && !m_capturing && m_xg_parity) ? m_xg2.p : m_xg.p; }
+  double* xg_other() {
+    if (!m_xg_by_data || m_capturing) return nullptr;
+    return m_xg_parity ? m_xg.p : m_xg2.p;
+  }
+  void xg_flip() {
+    if (m_xg_by_data && !m_capturing) m_xg_parity ^= 1;
+  }
   DevBuf<LdltSolveItem> m_bwd_items_u;
   DevBuf<uint32_t> m_col_zent;
   DevBuf<unsigned int> m_exit_cnt;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <bit>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -543,6 +544,15 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_scontrib.alloc(B * std::max<uint32_t>(1, l.n_scontrib));
   m_zv.alloc(B * l.n);
   m_xg.alloc(B * l.n);
+  // the backward solve's hand-over through the data (ldlt_kernels.h: slot_read): two buffers of
+  // x, both armed; SLPX_XG_HANDOFF=0: round counters
+  m_xg_by_data = m_single_launch;
+  if (const char* env = std::getenv("SLPX_XG_HANDOFF")) m_xg_by_data = m_xg_by_data && env[0] != '0';
+  if (m_xg_by_data) {
+    const std::vector<double> armed(static_cast<size_t>(B) * l.n, std::bit_cast<double>(kSlotEmpty));
+    m_xg.upload(armed);
+    m_xg2.upload(armed);
+  }
   {
     // two inertia-counter buffers (see factor()), both cleared once here
     std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
@@ -1226,8 +1236,9 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
   hipLaunchKernelGGL(ldlt_factor_solve_kernel<kFactorThreadsSingle>,
                      dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
                      dim3(kFactorThreadsSingle), m_factor_solve_lds, m_stream, m_ldev, m_lhs.p, m_h_reg, m_Lx.p, m_D.p,
-                     l.n, m_contrib.p, cur, next, m_rhs.p, m_zv.p, m_fround_cnt.p, m_slot_handoff ? 1 : 0, f, m_xg.p,
-                     m_p.p, m_bround_cnt.p, bf, m_sip);
+                     l.n, m_contrib.p, cur, next, m_rhs.p, m_zv.p, m_fround_cnt.p, m_slot_handoff ? 1 : 0, f, xg_now(),
+                     xg_other(), m_p.p, m_bround_cnt.p, bf, m_sip);
+  xg_flip();
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -1270,6 +1281,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
                                   const std::vector<uint8_t>& active) {
   write_reg(delta, gamma, active);
   m_stats_cur ^= 1;
+  m_xg_by_data = false;  // a graph's pointers are baked in: round counters from here on (they do not care what x holds)
   hipGraphExec_t& exec = m_step_graph[m_stats_cur][refresh_ad ? 1 : 0];
   if (exec == nullptr) {
     if (m_aux_stream == nullptr) {
@@ -1397,12 +1409,13 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
     const uint32_t nt = static_cast<uint32_t>(l.tasks.size());
     const BacksubFuse f = publish != nullptr ? backsub_fuse(publish) : BacksubFuse{};
     hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), f.on ? m_solve_lds_inline : l.solve_lds_bytes,
-                       m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p, m_bround_cnt.p, f);
+                       m_stream, m_ldev, nt - 1, l.n, m_Lx.p, lxs, m_zv.p, xg_now(), xg_other(), m_p.p, m_bround_cnt.p, f);
+    xg_flip();
   } else {
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_bwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
-                         m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, m_p.p,
+                         m_ldev, l.round_ptr[r], l.n, m_Lx.p, lxs, m_zv.p, m_xg.p, static_cast<double*>(nullptr), m_p.p,
                          static_cast<unsigned int*>(nullptr), BacksubFuse{});
     }
   }

@@ -104,6 +104,20 @@ __device__ __forceinline__ double slot_take(double* p, LdltStats* stats_b) {
   }
 }
 
+// The backward solve's version of the same idea: x of a finished column has MANY readers (every
+// descendant task that has an entry in that row), so a reader cannot re-arm the slot.  Instead the
+// solves alternate between two x buffers, and a task re-arms its own columns in the OTHER buffer
+// — the one the next solve will hand over through — after it has published them in this one.
+__device__ __forceinline__ double slot_read(const double* p) {
+  unsigned int spins = 0;
+  for (;;) {
+    const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<unsigned long long>(__double_as_longlong(v)) != kSlotEmpty) return v;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 22)) return v;  // never expected: the reserved NaN poisons the step instead of hanging
+  }
+}
+
 // 1/d on the critical path of every level: hardware estimate + two Newton steps (full
 // double precision for normal inputs; 0 -> inf and inf -> 0 like the division) instead of
 // the ~15-instruction IEEE division sequence with its scale/fixup steps.
@@ -796,13 +810,18 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
                                              const BwdCarve& c,
                                              const uint4 bs_task, int n, const double* __restrict__ Lx,
                                              long long lx_stride, const double* __restrict__ zv,
-                                             double* __restrict__ xg, double* __restrict__ out,
+                                             double* __restrict__ xg, double* __restrict__ xg_next,
+                                             double* __restrict__ out,
                                              unsigned int* __restrict__ round_cnt, const BacksubFuse& F,
                                              const FactorKeep* keep) {
   const int tid = threadIdx.x;
+  // xg_next != nullptr (every round in this launch): the ancestors' x is handed over through
+  // the values themselves (slot_read) instead of round counters
+  const bool by_data = xg_next != nullptr;
   Lx += static_cast<size_t>(b) * lx_stride;
   zv += static_cast<size_t>(b) * n;
   xg += static_cast<size_t>(b) * n;
+  if (by_data) xg_next += static_cast<size_t>(b) * n;
   out += static_cast<size_t>(b) * n;
   const uint32_t n_items = t.n_bwd_items;
   double* vals = c.vals;
@@ -867,7 +886,7 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
       }
   }
   // rows owned by ancestor tasks (later rounds) must be final before they are gathered
-  if (round_cnt != nullptr && static_cast<int>(t.round) + 1 < L.n_rounds)
+  if (!by_data && round_cnt != nullptr && static_cast<int>(t.round) + 1 < L.n_rounds)
     round_wait(&round_cnt[b * L.n_rounds + t.round + 1],
                L.round_ptr[t.round + 2] - L.round_ptr[t.round + 1], nullptr);
   {
@@ -876,14 +895,18 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
     for (uint32_t q = tid; q < n_items; q += THREADS) {
       const uint32_t ref = items[q].y;
       if (ref & 0x80000000u) {
-        vals[q] *= coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr);
+        const double* src = &xg[ref & 0x7fffffffu];
+        vals[q] *= by_data ? slot_read(src) : coherent_load(src, round_cnt != nullptr);
         items[q].y = t.n_col;
       }
     }
     if (bs_mine) {
 #pragma unroll
       for (int k = 0; k < kBsPre; ++k)
-        if (bs_ref[k] & 0x80000000u) bs_p[k] = coherent_load(&xg[bs_ref[k] & 0x7fffffffu], round_cnt != nullptr);
+        if (bs_ref[k] & 0x80000000u) {
+          const double* src = &xg[bs_ref[k] & 0x7fffffffu];
+          bs_p[k] = by_data ? slot_read(src) : coherent_load(src, round_cnt != nullptr);
+        }
     }
   }
   __syncthreads();
@@ -944,15 +967,20 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
   __syncthreads();
   SLPX_LDLT_CLOCK(19);
   // the descendants wait for x alone: hand it over before anything else goes out
-  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], round_cnt != nullptr);
-  if (round_cnt != nullptr)
+  for (uint32_t i = tid; i < t.n_col; i += THREADS)
+    coherent_store(&xg[colperm[i]], x[i], round_cnt != nullptr || by_data);
+  if (by_data) {
+    for (uint32_t i = tid; i < t.n_col; i += THREADS)
+      coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
+  } else if (round_cnt != nullptr) {
     round_signal(&round_cnt[b * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
                  t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
+  }
   for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
   if (F.on) {
     const double m = F.mu[0];
     auto p_of = [&](uint32_t ref) {
-      return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr) : x[ref];
+      return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], round_cnt != nullptr || by_data) : x[ref];
     };
     for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
       const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
@@ -1005,20 +1033,22 @@ __device__ __forceinline__ void publish_stats(const BacksubFuse& F, bool coheren
 
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
-    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ out,
-    unsigned int* __restrict__ round_cnt, BacksubFuse F) {
+    const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ xg_next,
+    double* __restrict__ out, unsigned int* __restrict__ round_cnt, BacksubFuse F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // the verdict of the factorization this solve belongs to: known since the launch began; handed
   // over by the last workgroup, a leaf task that has to wait for its ancestors anyway
   if (F.on && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && F.stats_host != nullptr) publish_stats(F, false);
   // single-launch mode (round_cnt != nullptr): every task of every round, LAST round first
-  const uint32_t task_index = round_cnt != nullptr ? task_base - blockIdx.x : task_base + blockIdx.x;
+  const uint32_t task_index =
+      (round_cnt != nullptr || xg_next != nullptr) ? task_base - blockIdx.x : task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   SLPX_LDLT_CLOCK(16);
   const BwdCarve c = bwd_carve<false>(smem_raw, t);
   const uint4 bs_task = ldlt_bwd_stage<256, false>(L, t, task_index, c, F, SolveInPlace{});
   __syncthreads();
-  ldlt_bwd_run<256, false>(L, t, task_index, blockIdx.y, c, bs_task, n, Lx, lx_stride, zv, xg, out, round_cnt, F, nullptr);
+  ldlt_bwd_run<256, false>(L, t, task_index, blockIdx.y, c, bs_task, n, Lx, lx_stride, zv, xg, xg_next, out, round_cnt, F,
+                           nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -1038,7 +1068,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_solve_kernel(
     double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, const double* __restrict__ rhs, double* __restrict__ zv,
     unsigned int* __restrict__ fround_cnt, int slot_handoff, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ out, unsigned int* __restrict__ bround_cnt, BacksubFuse B, SolveInPlace M) {
+    double* __restrict__ xg_next, double* __restrict__ out, unsigned int* __restrict__ bround_cnt, BacksubFuse B,
+    SolveInPlace M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (static_cast<int>(blockIdx.x) < F.n_blocks) {
     ride_along_sum(F, blockIdx.x, smem_raw);
@@ -1067,7 +1098,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_solve_kernel(
   };
   if (!top) exit_and_count();  // (its store acknowledgements come in while the task waits for its ancestors)
   __syncthreads();
-  ldlt_bwd_run<THREADS, true>(L, t, task_index, 0, c, bs_task, n, Lx, 0, zv, xg, out, bround_cnt, B, &keep);
+  ldlt_bwd_run<THREADS, true>(L, t, task_index, 0, c, bs_task, n, Lx, 0, zv, xg, xg_next, out, bround_cnt, B, &keep);
   if (top) exit_and_count();
 }
 

@@ -529,7 +529,9 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     // slot hand-over (ldlt_kernels.h: slot_take) needs every slot to have exactly one reader
     std::vector<uint8_t> readers(std::max<uint32_t>(1, l.n_contrib), 0);
     bool single_reader = true;
-    for (uint32_t idx : l.contrib_idx) single_reader = single_reader && ++readers[idx] == 1;
+    for (const LdltTask& t : l.tasks)  // (each task's slice is padded to a multiple of four)
+      for (uint32_t c = 0; c < t.n_contrib_idx; ++c)
+        single_reader = single_reader && ++readers[l.contrib_idx[t.contrib_off + c]] == 1;
     m_slot_handoff = m_single_launch && single_reader;
     if (const char* env = std::getenv("SLPX_SLOT_HANDOFF")) m_slot_handoff = m_slot_handoff && env[0] != '0';
     if (m_slot_handoff) {

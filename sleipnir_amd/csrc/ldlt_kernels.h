@@ -87,6 +87,9 @@ __device__ __forceinline__ void round_signal(unsigned int* cnt_base, int round, 
 // counter moved.  A computed NaN never carries this payload (the hardware produces the
 // canonical quiet NaN), so a numerical breakdown cannot be mistaken for "not yet written".
 constexpr unsigned long long kSlotEmpty = 0x7ff8dead0badbeefull;
+__device__ __forceinline__ bool slot_is_empty(double v) {
+  return static_cast<unsigned long long>(__double_as_longlong(v)) == kSlotEmpty;
+}
 __device__ __forceinline__ double slot_take(double* p, LdltStats* stats_b) {
   unsigned int spins = 0;
   for (;;) {
@@ -377,7 +380,8 @@ __device__ __forceinline__ bool ldlt_factor_body(
   const uint32_t np = t.n_pairs;
   const uint32_t g_pairs = q16(np, 2), g_pptr = q16(n_pp, 4), g_lvl = q16(t.n_lvl + 1, 4),
                  g_src = q16(t.n_ent, 4), g_col = q16(t.n_ent, 8), g_flags = q16(t.n_ent, 16),
-                 g_out = q16(t.n_ent, 4), g_cptr = q16(t.n_ent + 1, 4), g_snd = q16(3 * t.n_sn, 4);
+                 g_out = q16(t.n_ent, 4), g_cptr = q16(t.n_ent + 1, 4), g_snd = q16(3 * t.n_sn, 4),
+                 g_cidx = q16(t.n_contrib_idx, 4);
   uint4* s_pairs = reinterpret_cast<uint4*>(smem_raw);
   uint4* s_pptr = s_pairs + g_pairs;
   uint4* s_lvl = s_pptr + g_pptr;
@@ -387,7 +391,8 @@ __device__ __forceinline__ bool ldlt_factor_body(
   uint4* s_out = s_flags + g_flags;
   uint4* s_cptr = s_out + g_out;
   uint4* s_snd = s_cptr + g_cptr;
-  double* U = reinterpret_cast<double*>(s_snd + g_snd);
+  uint4* s_cidx = s_snd + g_snd;
+  double* U = reinterpret_cast<double*>(s_cidx + g_cidx);
   double* invd = U + t.n_ent;
   int* s_cnt = reinterpret_cast<int*>(invd + t.n_col);
   unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
@@ -422,6 +427,7 @@ __device__ __forceinline__ bool ldlt_factor_body(
   stage16<THREADS>(s_cptr, reinterpret_cast<const uint4*>(L.ent_contrib_ptr + t.contrib_ptr_off), g_cptr,
                tid);
   if (t.n_sn) stage16<THREADS>(s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), g_snd, tid);
+  stage16<THREADS>(s_cidx, reinterpret_cast<const uint4*>(L.contrib_idx + t.contrib_off), g_cidx, tid);
   if (tid < 4) s_cnt[tid] = 0;
   if (tid == 0) *s_minp = 0x7ff0000000000000ull;  // +inf
   __syncthreads();
@@ -491,7 +497,8 @@ __device__ __forceinline__ bool ldlt_factor_body(
                L.round_ptr[t.round] - L.round_ptr[t.round - 1], &stats[b]);
   // regularization + update blocks of child tasks (few entries have any)
   {
-    const uint32_t* cidx = L.contrib_idx + t.contrib_off;
+    // (the slot indices came with the plan: the trip to the slot is the only one on this path)
+    const uint32_t* cidx = reinterpret_cast<const uint32_t*>(s_cidx);
     for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
       const uint8_t fl = flags[i];
       const uint32_t cb = cptr[i], ce = cptr[i + 1];
@@ -499,7 +506,45 @@ __device__ __forceinline__ bool ldlt_factor_body(
       double acc = U[i];
       if (fl & 1) acc += (fl & 2) ? -gamma : delta;
       if (slot_handoff) {
-        for (uint32_t c = cb; c < ce; ++c) acc -= slot_take(&contrib[cidx[c]], &stats[b]);
+        // Four slots in flight per look, ONE loop for every lane (slots past the entry's last are
+        // predicated off): an entry of a task with many children would otherwise pay a trip to
+        // memory per child even when all of them have long delivered.  Summed in list order.
+        for (uint32_t c = cb; c < ce; c += 4) {
+          double* p0 = &contrib[cidx[c]];
+          double* p1 = &contrib[cidx[c + 1 < ce ? c + 1 : c]];
+          double* p2 = &contrib[cidx[c + 2 < ce ? c + 2 : c]];
+          double* p3 = &contrib[cidx[c + 3 < ce ? c + 3 : c]];
+          double v0, v1, v2, v3;
+          unsigned int spins = 0;
+          for (;;) {
+            v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v3 = __hip_atomic_load(p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool all_in = !slot_is_empty(v0) && !slot_is_empty(v1) && !slot_is_empty(v2) && !slot_is_empty(v3);
+            if (all_in) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
+              atomicAdd(&stats[b].n_bad, 1 << 20);
+              break;
+            }
+          }
+          const double armed = __longlong_as_double(static_cast<long long>(kSlotEmpty));
+          __hip_atomic_store(p0, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc -= v0;
+          if (c + 1 < ce) {
+            __hip_atomic_store(p1, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc -= v1;
+          }
+          if (c + 2 < ce) {
+            __hip_atomic_store(p2, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc -= v2;
+          }
+          if (c + 3 < ce) {
+            __hip_atomic_store(p3, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc -= v3;
+          }
+        }
       } else {
         for (uint32_t c = cb; c < ce; ++c) acc -= coherent_load(&contrib[cidx[c]], round_cnt != nullptr);
       }

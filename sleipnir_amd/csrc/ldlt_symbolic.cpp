@@ -727,6 +727,8 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     T.n_fwd_items = fwd_count;
     T.n_bwd_items = bwd_count;
     P.ent_contrib_ptr.push_back(contrib_count);
+    T.n_contrib_idx = contrib_count;
+    while (P.contrib_idx.size() % 4 != 0) P.contrib_idx.push_back(0);  // 16-byte slices: staged into LDS
     P.fwd_ptr.push_back(fwd_count);
     P.fwd_contrib_ptr.push_back(sc_count);
     P.bwd_ptr.push_back(bwd_count);
@@ -744,7 +746,8 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
     auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
     const uint32_t fb = q(pair_count, 2) + q(T.n_ent + T.n_ext + 1, 4) + q(T.n_lvl + 1, 4) +
                         q(T.n_ent, 4) + q(T.n_ent, 8) + q(T.n_ent, 16) + q(T.n_ent, 4) +
-                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32 + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);
+                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32 + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4) +
+                        q(T.n_contrib_idx, 4);
     const uint32_t items = std::max(fwd_count, bwd_count);
     const uint32_t sb = q(items, 2) + 2 * q(T.n_col + 1, 4) + q(T.n_lvl + 1, 4) + q(T.n_col, 4) +
                         8 * items + 8 * (T.n_col + 1) + 32 + q(T.n_col, 4) + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);

@@ -56,6 +56,7 @@ struct LdltTask {
   uint32_t n_fwd_items, n_bwd_items;
   // supernodes of two or more columns (see LdltSn): descriptors in level order
   uint32_t sn_off, n_sn;  // this task's slice of `sn_desc`; `sn_lvl_ptr` shares lvl_off
+  uint32_t n_contrib_idx;  // length of this task's slice of contrib_idx (padded to 4 in the array)
 };
 
 // A supernode of w >= 2 columns: a chain j_0 < ... < j_{w-1} of the elimination tree inside

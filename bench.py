@@ -428,7 +428,13 @@ def main():
                 out["batched"] = [batched_probe(sa, cases, 500, 64, local_rank),
                                   batched_probe(sa, cases, 1000, 512, local_rank)]
             if not args.no_whole_solve:
+                # Problem::solve() at the BASELINE horizon and at three shorter ones.  Whether this
+                # IPM gets through the swing-up on a given grid depends on the last bits of the
+                # arithmetic — in the reference algorithm itself (DESIGN.md §2,
+                # profiles/r02_oracle_sensitivity.txt: the CPU restatement ends LOCALLY_INFEASIBLE
+                # at N=1000 as well) — so the line shows more than one horizon.
                 out["whole_solve"] = whole_solve(sa, N)
+                out["whole_solves"] = [whole_solve(sa, n_) for n_ in (100, 300, 500)] + [out["whole_solve"]]
         if not args.no_cpu_baseline and world == 1 and args.workload != "gfold":
             out["cpu_baseline"] = cpu_baseline(N, dt)
             out["speedup_vs_cpu_baseline"] = out["value"] / (out["cpu_baseline"]["value"] * 1.0)

@@ -41,3 +41,47 @@ def test_reference_benchmark_program_solves_on_the_gpu(slpx):
     build_user_program(slpx) if not BIN.exists() else None
     res = subprocess.run([str(BIN), "100"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+OCP_SRC = ROOT / "tests" / "support" / "user_program" / "flywheel_ocp_user.cpp"
+OCP_BIN = ROOT / "build" / "flywheel_ocp_user"
+
+
+def build_ocp_program(slpx):
+    OCP_BIN.parent.mkdir(parents=True, exist_ok=True)
+    lib_dir = slpx.LIB_PATH.parent
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(OCP_SRC), "-o",
+           str(OCP_BIN), "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_ocp_helper_builds_the_models_of_the_reference_test(slpx):
+    """slp::OCP (ocp.hpp:49-400) under the reference's include paths: the flywheel OCP of
+    test/src/optimization/flywheel_ocp_test.cpp with every transcription method and both kinds
+    of dynamics has a QUADRATIC cost, LINEAR equalities (none at all for single shooting) and
+    LINEAR inequalities (:83-85)."""
+    build_ocp_program(slpx)
+    for method in (0, 1, 2):
+        for kind in (0, 1):
+            if method == 1 and kind == 1:
+                continue  # direct collocation needs an explicit ODE (ocp.hpp:323)
+            res = subprocess.run([str(OCP_BIN), str(method), str(kind), "50", "model-only"], capture_output=True,
+                                 text=True, timeout=300)
+            assert res.returncode == 0, res.stdout + res.stderr
+            assert res.stdout.splitlines()[0] == "cost=3 eq=2 ineq=2", (method, kind, res.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,kind,steps", [(0, 0, 1000), (0, 1, 1000), (1, 0, 1000), (2, 0, 50), (2, 1, 50)])
+def test_ocp_helper_flywheel_known_answer_on_the_gpu(slpx, method, kind, steps):
+    """flywheel_ocp_test.cpp:87-140: bang-then-hold input, states within 1e-2 of the discrete
+    model's, final state r = 10 within 2e-6 — direct transcription and collocation at the
+    reference's own size (1000 steps of 5 ms).  Single shooting makes the Hessian dense in the
+    inputs; the reference then takes its DENSE LDLT branch (interior_point.hpp:340-349), which is
+    outside SURVEY.md §8 — the sparse factorization here holds a column in LDS and says so when
+    one does not fit (1000 steps), so that method is exercised at 50 steps."""
+    build_ocp_program(slpx) if not OCP_BIN.exists() else None
+    res = subprocess.run([str(OCP_BIN), str(method), str(kind), str(steps)], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <future>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -288,9 +290,30 @@ bool NewtonSystem::factor_unregularized() {
 
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
+  // SLPX_HOST_TIMING=1: where the host's time per step goes (printed every 1000 steps)
+  static const bool timing = std::getenv("SLPX_HOST_TIMING") != nullptr;
+  if (!timing) {
+    if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
+    m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
+    return compute(/*solve_speculatively=*/true);
+  }
+  using clk = std::chrono::steady_clock;
+  static double t_sweep = 0, t_rest = 0;
+  static long n = 0;
+  const auto t0 = clk::now();
   if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
+  const auto t1 = clk::now();
   m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
-  return compute(/*solve_speculatively=*/true);
+  auto res = compute(/*solve_speculatively=*/true);
+  const auto t2 = clk::now();
+  t_sweep += std::chrono::duration<double, std::micro>(t1 - t0).count();
+  t_rest += std::chrono::duration<double, std::micro>(t2 - t1).count();
+  if (++n % 1000 == 0) {
+    std::fprintf(stderr, "slpx host timing: sweep launch %.2f us, launch + wait for the verdict %.2f us per step\n",
+                 t_sweep / 1000, t_rest / 1000);
+    t_sweep = t_rest = 0;
+  }
+  return res;
 }
 
 }  // namespace slpx

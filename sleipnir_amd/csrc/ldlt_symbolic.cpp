@@ -804,6 +804,33 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
           ++hist[std::min<uint32_t>(8, (ns + 3) / 4)];
         }
       }
+      {
+        // update blocks for the parents: how many entries per task, how long their pair lists,
+        // and how many update slots an entry of this round's tasks takes from its children
+        double ext = 0, ext_pairs = 0, own_pairs = 0, own_ent = 0, takes = 0, takers = 0;
+        uint32_t ext_max = 0, take_max = 0;
+        for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) {
+          const LdltTask& T = P.tasks[ti];
+          ext += T.n_ext;
+          ext_max = std::max(ext_max, T.n_ext);
+          const uint32_t* pp = P.ent_pair_ptr.data() + T.pair_ptr_off;
+          ext_pairs += pp[T.n_ent + T.n_ext] - pp[T.n_ent];
+          own_pairs += pp[T.n_ent];
+          own_ent += T.n_ent;
+          const uint32_t* cp = P.ent_contrib_ptr.data() + T.contrib_ptr_off;
+          for (uint32_t i = 0; i < T.n_ent; ++i)
+            if (cp[i + 1] > cp[i]) {
+              takes += cp[i + 1] - cp[i];
+              takers += 1;
+              take_max = std::max(take_max, cp[i + 1] - cp[i]);
+            }
+        }
+        std::fprintf(stderr,
+                     "ldlt round %d: update entries/task avg %.0f max %u, pairs per update entry %.1f, pairs per own entry "
+                     "%.1f; entries taking update slots/task %.0f, slots per such entry avg %.1f max %u\n",
+                     r, ext / ntask, ext_max, ext > 0 ? ext_pairs / ext : 0.0, own_pairs / std::max(1.0, own_ent),
+                     takers / ntask, takers > 0 ? takes / takers : 0.0, take_max);
+      }
       std::fprintf(stderr, "ldlt round %d: %u tasks, %.1f levels/task, chains(w>=2)/level avg %.1f max %u, chain rows/level max %u, entries/level avg %.0f; chains/level hist (0,1-4,5-8,...,>=29):",
                    r, ntask, double(lvls) / ntask, sum_sn / lvls, max_sn, max_rows, sum_ent / lvls);
       for (int h : hist) std::fprintf(stderr, " %d", h);

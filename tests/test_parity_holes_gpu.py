@@ -124,6 +124,8 @@ def test_supernode_settings(fresh, slpx, orc, monkeypatch, env, kind, N):
     (factorization, the solve that rides in it, the re-solve with a new right-hand side)."""
     from tests.support import gfold, model
 
+    for k in ("SLPX_SUPERNODAL", "SLPX_SN_MIN_WIDTH"):  # (the suite may itself run under one of them: profiles/switch_matrix.sh)
+        monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     if kind == "gfold":

@@ -332,7 +332,7 @@ class DeviceNlp {
   void sweep_values_trial();                  // f, c_e, c_i at the trial x -> trial V
   void ipm_trial_metrics(double alpha, bool s_from_ci);  // alpha < 0: the device's alpha_max
   void ipm_commit(double alpha, double alpha_z, bool s_from_ci);
-  void ipm_errors(bool check_all_V);
+  void ipm_errors(bool check_all_V, bool sums_ride = false);  // -> IpmHost::err (one launch; the last workgroup folds)
   void ipm_soc_accumulate(double alpha, bool first, bool s_from_ci);
   void ipm_soc_rhs();                         // -> rhs
   void ipm_soc_backsub();                     // p -> p_s, p_z with the corrected c_i - s
@@ -453,6 +453,7 @@ class DeviceNlp {
   KktFuse take_kkt_fuse();
   BacksubFuse backsub_fuse(const LdltStats* publish);
   uint32_t m_factor_solve_lds = 0;
+  DevBuf<unsigned int> m_ipm_err_done;
   DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
   DevBuf<uint4> m_bs_task_plan;
   uint32_t m_solve_lds_inline = 0;    // dynamic LDS of the backward solve with the rows staged

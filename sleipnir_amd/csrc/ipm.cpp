@@ -631,8 +631,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   push_state();
   dev.upload_mu(&mu);
   double mu_on_device = mu;
-  dev.sweep_full();  // :245-251
-  dev.ipm_errors(/*check_all_V=*/true);
+  dev.sweep_full(/*with_reduce=*/false);  // :245-251 (the separable sums ride in the error launch)
+  dev.ipm_errors(/*check_all_V=*/true, /*sums_ride=*/true);
   dev.wait_published();
   IpmErrOut cur = H.err;  // scalars of the current iterate
 
@@ -885,8 +885,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     }
 
     // AD refresh (:809-812) and every norm the next decisions need
-    dev.sweep_full();
-    dev.ipm_errors(false);
+    dev.sweep_full(/*with_reduce=*/false);
+    dev.ipm_errors(false, /*sums_ride=*/true);
     dev.wait_published();
     cur = H.err;
     rep.t_ad_refresh += since(t0);

@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "coherent.h"
 #include "device.hpp"
 
 namespace slpx {
@@ -316,19 +317,119 @@ enum {
    IPM_MIN}
 }  // namespace ipm_err
 
+struct IpmErrFinish {
+  int n_err_blocks = 0;   // 0: two launches (partials, then ipm_error_final_kernel)
+  int n_total_blocks = 0; // error workgroups + one per separable sum
+  const NlpStructure::SumReduce* red = nullptr;
+  const double* tape_scales = nullptr;
+  double* Vw = nullptr;
+  unsigned int* done = nullptr;  // workgroups through (the last one clears it)
+  IpmErrOut* out = nullptr;
+  unsigned long long* seq_dev = nullptr;
+  volatile unsigned long long* seq_host = nullptr;
+};
+
+// folds the per-workgroup partials in workgroup order and hands the result to the host;
+// `in_launch`: the partials and f were written by other workgroups of this launch
+__device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __restrict__ V,
+                                               const double* __restrict__ partial, int n_blocks, bool in_launch,
+                                               IpmErrOut* __restrict__ out, unsigned long long* __restrict__ seq_dev,
+                                               volatile unsigned long long* seq_host, double* tot) {
+  using namespace ipm_err;
+  constexpr int NQ = kIpmErrQ;
+  const int ops[NQ] = SLPX_IPM_ERR_OPS;
+  const int q = threadIdx.x;
+  if (q < NQ) {
+    int op = ops[0];
+#pragma unroll
+    for (int k = 1; k < NQ; ++k)
+      if (q == k) op = ops[k];
+    double v = coherent_load(&partial[q], in_launch);
+    for (int b = 1; b < n_blocks; ++b) v = ipm_combine(op, v, coherent_load(&partial[b * NQ + q], in_launch));
+    tot[q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out->dual_inf_u = tot[DUAL_U];
+    out->sz_max_u = tot[SZ_MAX_U];
+    out->ce_inf_u = tot[CE_U];
+    out->cis_inf_u = tot[CIS_U];
+    out->y1_u = tot[Y1_U];
+    out->z1_u = tot[Z1_U];
+    out->dual_inf = tot[DUAL];
+    out->sz_min = K.m_i ? tot[SZ_MIN] : 0.0;
+    out->sz_max = tot[SZ_MAX];
+    out->ce_inf = tot[CE];
+    out->cis_inf = tot[CIS];
+    out->y1 = tot[Y1];
+    out->z1 = tot[Z1];
+    const double f = coherent_load(&V[K.off_f], in_launch);
+    out->f = f;
+    out->viol = tot[VIOL];
+    out->logsum = tot[LOGSUM];
+    out->aetce_sq = tot[AETCE];
+    out->ce_sq = tot[CESQ];
+    out->aitcp_sq = tot[AITCP];
+    out->cp_sq = tot[CPSQ];
+    out->x_inf = tot[XINF];
+    out->s_inf = tot[SINF];
+    out->finite = (tot[FINITE] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
+    out->ci_all_pos = tot[CIPOS];
+    ipm_publish(seq_dev, seq_host);
+  }
+}
+
+// end of a workgroup of the one-launch error computation: count it in; the last one folds
+__device__ __forceinline__ void ipm_error_finish(const KktDev& K, const double* __restrict__ V,
+                                                 const double* __restrict__ partial, const IpmErrFinish& fin) {
+  __shared__ double tot[kIpmErrQ];
+  __shared__ int last;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this workgroup's coherent stores are in
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(fin.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = old + 1 == static_cast<unsigned int>(fin.n_total_blocks);
+    if (last) __hip_atomic_store(fin.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) return;
+  ipm_error_fold(K, V, partial, fin.n_err_blocks, true, fin.out, fin.seq_dev, fin.seq_host, tot);
+}
+
 __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
     KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
     const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
-    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial) {
+    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial, IpmErrFinish fin) {
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
+  // fin.n_err_blocks != 0: ONE launch — the tape's separable sums (which make f) ride as extra
+  // workgroups, and whichever workgroup finishes last folds the partials and publishes
+  // (ipm_error_finish); 0: the partials only, ipm_error_final_kernel follows.
+  if (fin.n_err_blocks != 0 && static_cast<int>(blockIdx.x) >= fin.n_err_blocks) {
+    const NlpStructure::SumReduce r = fin.red[blockIdx.x - fin.n_err_blocks];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    if (tid < 64)
+      for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
+    if (tid < 64) scratch[tid] = acc;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) scratch[tid] += scratch[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0)
+      coherent_store(&fin.Vw[r.dst], (r.scale_idx >= 0 ? fin.tape_scales[r.scale_idx] : 1.0) * scratch[0], true);
+    ipm_error_finish(K, V, partial, fin);
+    return;
+  }
+  const int n_blocks = fin.n_err_blocks != 0 ? fin.n_err_blocks : static_cast<int>(gridDim.x);
   double acc[NQ];
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = ops[q] == IPM_MIN ? 1.0 : 0.0;
   acc[SZ_MIN] = 1e300;
-  const int t0 = blockIdx.x * kIpmErrThreads + threadIdx.x, stride = gridDim.x * kIpmErrThreads;
+  const int t0 = blockIdx.x * kIpmErrThreads + threadIdx.x, stride = n_blocks * kIpmErrThreads;
   const double inv_f = 1.0 / scales[0];
   const double* d_ce = scales + 1;
   const double* d_ci = scales + 1 + K.m_e;
@@ -402,8 +503,9 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   block_reduce<NQ, kIpmErrThreads>(acc, ops, scratch);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) partial[blockIdx.x * NQ + q] = acc[q];
+    for (int q = 0; q < NQ; ++q) coherent_store(&partial[blockIdx.x * NQ + q], acc[q], fin.n_err_blocks != 0);
   }
+  if (fin.n_err_blocks != 0) ipm_error_finish(K, V, partial, fin);
 }
 
 __global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,
@@ -411,49 +513,8 @@ __global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const dou
                                                              IpmErrOut* __restrict__ out,
                                                              unsigned long long* __restrict__ seq_dev,
                                                              volatile unsigned long long* seq_host) {
-  using namespace ipm_err;
-  constexpr int NQ = kIpmErrQ;
-  __shared__ double tot[NQ];
-  const int ops[NQ] = SLPX_IPM_ERR_OPS;
-  const int q = threadIdx.x;
-  if (q < NQ) {
-    int op = ops[0];
-#pragma unroll
-    for (int k = 1; k < NQ; ++k)
-      if (q == k) op = ops[k];
-    double v = partial[q];
-    for (int b = 1; b < n_blocks; ++b) v = ipm_combine(op, v, partial[b * NQ + q]);
-    tot[q] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out->dual_inf_u = tot[DUAL_U];
-    out->sz_max_u = tot[SZ_MAX_U];
-    out->ce_inf_u = tot[CE_U];
-    out->cis_inf_u = tot[CIS_U];
-    out->y1_u = tot[Y1_U];
-    out->z1_u = tot[Z1_U];
-    out->dual_inf = tot[DUAL];
-    out->sz_min = K.m_i ? tot[SZ_MIN] : 0.0;
-    out->sz_max = tot[SZ_MAX];
-    out->ce_inf = tot[CE];
-    out->cis_inf = tot[CIS];
-    out->y1 = tot[Y1];
-    out->z1 = tot[Z1];
-    const double f = V[K.off_f];
-    out->f = f;
-    out->viol = tot[VIOL];
-    out->logsum = tot[LOGSUM];
-    out->aetce_sq = tot[AETCE];
-    out->ce_sq = tot[CESQ];
-    out->aitcp_sq = tot[AITCP];
-    out->cp_sq = tot[CPSQ];
-    out->x_inf = tot[XINF];
-    out->s_inf = tot[SINF];
-    out->finite = (tot[FINITE] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
-    out->ci_all_pos = tot[CIPOS];
-    ipm_publish(seq_dev, seq_host);
-  }
+  __shared__ double tot[kIpmErrQ];
+  ipm_error_fold(K, V, partial, n_blocks, false, out, seq_dev, seq_host, tot);
 }
 
 }  // namespace slpx

@@ -1604,15 +1604,27 @@ void DeviceNlp::ipm_commit(double alpha, double alpha_z, bool s_from_ci) {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
-void DeviceNlp::ipm_errors(bool check_all_V) {
+// `sums_ride`: the sweep before this call left the tape's separable sums out
+// (sweep_full(false)); they ride in this launch
+void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride) {
   const int work = std::max({m_kdev.n, m_kdev.m_e, m_kdev.m_i, 1});
   const int blocks = grid_for(work, kIpmErrThreads, 256);
   if (m_ipm_partial.n < static_cast<size_t>(blocks) * kIpmErrQ) m_ipm_partial.alloc(static_cast<size_t>(256) * kIpmErrQ);
-  hipLaunchKernelGGL(ipm_error_partial_kernel, dim3(blocks), dim3(kIpmErrThreads), 0, m_stream, m_kdev, m_V.p,
+  if (m_ipm_err_done.n == 0) m_ipm_err_done.upload(std::vector<unsigned int>(1, 0u));
+  const int n_sums = sums_ride ? static_cast<int>(m_reduces.n) : 0;
+  IpmErrFinish fin;
+  fin.n_err_blocks = blocks;
+  fin.n_total_blocks = blocks + n_sums;
+  fin.red = m_reduces.p;
+  fin.tape_scales = m_scales.p;
+  fin.Vw = m_V.p;
+  fin.done = m_ipm_err_done.p;
+  fin.out = &m_ipm_host->err;
+  fin.seq_dev = m_seq_dev.p;
+  fin.seq_host = m_h_seq;
+  hipLaunchKernelGGL(ipm_error_partial_kernel, dim3(blocks + n_sums), dim3(kIpmErrThreads), 0, m_stream, m_kdev, m_V.p,
                      m_s_ref.nV, m_in.p, m_s.p, m_y.p, m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0,
-                     m_ipm_partial.p);
-  hipLaunchKernelGGL(ipm_error_final_kernel, dim3(1), dim3(64), 0, m_stream, m_kdev, m_V.p, m_ipm_partial.p,
-                     blocks, &m_ipm_host->err, m_seq_dev.p, m_h_seq);
+                     m_ipm_partial.p, fin);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }

@@ -50,6 +50,15 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
+    // One problem (or a handful: the same plan, so that a small batch and single problems agree to
+    // the bit), smaller than the BASELINE horizon: smaller tasks (less plan to stage per
+    // task, shorter level passes, more of the chip in the leaf round) — task size with the square
+    // root of the system's order.  Measured (fused kernel, us): cart-pole N=300 1024 entries 47.9
+    // vs 2048 54.6; N=500 1536 52.3 vs 2048 53.8; N=1000 2048 56.2 vs 1792 59.4.
+    if (opt.batch < 16 && lopt.task_entries == LdltOptions{}.task_entries && m_k.dim < 9000) {
+      const double scaled = 2048.0 * std::sqrt(static_cast<double>(m_k.dim) / 9000.0);
+      lopt.task_entries = std::clamp<uint32_t>(256u * static_cast<uint32_t>(std::lround(scaled / 256.0)), 1024u, 2048u);
+    }
     if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
     m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);

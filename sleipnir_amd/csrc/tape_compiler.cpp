@@ -505,7 +505,9 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
         packs.push_back(std::move(big));
         continue;
       }
-      if (family[signature[c]] >= 16 && comp_nodes[c].size() >= 16) {
+      // (8: the term groups of a separable cost over 300-500 steps are 9-15 of a kind; packed into
+      // one interpreted task they took 11-20 us against 7 us for the whole generated kernel)
+      if (family[signature[c]] >= kTapeFamilyMin && comp_nodes[c].size() >= 16) {
         Pack own;
         own.comps.push_back(c);
         own.cost = cost;

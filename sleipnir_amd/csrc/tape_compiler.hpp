@@ -88,6 +88,10 @@ struct TapeProgram {
   uint32_t max_levels = 0, max_slot_levels = 0;
 };
 
+// Structurally identical components from this many up are a FAMILY: each keeps a task of its own
+// (tape_compiler.cpp) and they run as instances of one generated body, a lane each (tape_jit.cpp).
+constexpr uint32_t kTapeFamilyMin = 8;
+
 struct TapeCompileOptions {
   bool cse = true;                        // merge structurally identical interior nodes (SLPX_TAPE_CSE=0: off)
   uint32_t small_lds_bytes = 40 * 1024;   // 64-thread workgroups, four per CU

@@ -53,7 +53,7 @@ struct TapeJitOptions {
   // A family needs this many members to get a body: one LANE runs the whole task, so a
   // lone task is far slower generated (one lane, serial: measured 229 us for ten packed
   // 320-node linear-row tasks) than interpreted by a workgroup (level-parallel, ~10 us).
-  uint32_t min_instances = 16;
+  uint32_t min_instances = kTapeFamilyMin;
   // ... and so is a wide, shallow task (measured at N=5000: a family of packed linear-row
   // tasks, 640 loads + 320 stores per lane, turned a 45 us launch into 300 us)
   uint32_t max_width = 32;

@@ -119,6 +119,7 @@ struct LdltDev {
   const uint32_t* lvl_pack;      // lvl_ptr | sn_lvl_ptr << 16
   const uint32_t* col_lvl_pack;  // col_lvl_ptr | sn_lvl_ptr << 16
   const uint2* bwd_range;        // per column {first item below its own chain, end}; shares col_off
+  uint32_t clock_task;           // the task whose phase clocks are recorded (slpx_debug_ldlt_clocks); 0xffffffff: none
 };
 
 struct LdltStats {   // one per batch item, written by the factor kernels

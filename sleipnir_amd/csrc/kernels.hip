@@ -455,6 +455,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                    l.n_rounds};
   m_round_ptr.upload(l.round_ptr);
   m_ldev.round_ptr = m_round_ptr.p;
+  m_ldev.clock_task = 0xffffffffu;
   m_sn_desc.upload(l.sn_desc);
   m_sn_lvl_ptr.upload(l.sn_lvl_ptr);
   m_col_sn.upload(l.col_sn);
@@ -1065,7 +1066,7 @@ void DeviceNlp::debug_tape_clocks(unsigned long long* out16) {
 void DeviceNlp::debug_ldlt_clocks(unsigned int next_round, unsigned long long* out24) {
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
   SLPX_HIP_CHECK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_ldlt_clocks), 24 * sizeof(unsigned long long)));
-  SLPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ldlt_clock_round), &next_round, sizeof(unsigned int)));
+  m_ldev.clock_task = next_round < static_cast<unsigned int>(m_l_ref.n_rounds) ? m_l_ref.round_ptr[next_round] : 0xffffffffu;
 }
 
 void DeviceNlp::refresh_params(const Graph& g) {

@@ -35,7 +35,7 @@ namespace slpx {
 // phase clocks of the first task of the selected round, first problem group (slots [8,16) of
 // g_ldlt_clocks, which the per-task forward kernel does not use inside a Newton step)
 #define SLPX_IL_CLOCK(k)                                                                      \
-  if (task_index == L.round_ptr[g_ldlt_clock_round] && blockIdx.y == 0 && threadIdx.x == 0) \
+  if (task_index == L.clock_task && blockIdx.y == 0 && threadIdx.x == 0) \
   g_ldlt_clocks[8 + (k)] = wall_clock64()
 
 constexpr int kIlLanes = 64;  // lanes of a wave

@@ -30,9 +30,12 @@ namespace slpx {
 // launch of each kernel: [0,8) factor, [8,16) fwd, [16,24) bwd (debug aid,
 // slpx_debug_ldlt_clocks).
 __device__ unsigned long long g_ldlt_clocks[24];
-__device__ unsigned int g_ldlt_clock_round;  // which round's launch records
-#define SLPX_LDLT_CLOCK(k)                                                                   \
-  if (task_index == L.round_ptr[g_ldlt_clock_round] && blockIdx.y == 0 && threadIdx.x == 0) \
+// Which task records: LdltDev::clock_task, a kernel ARGUMENT (0xffffffff = nobody, the default).
+// It used to be looked up in memory at every clock point (a global holding the round, then
+// round_ptr[round]): two dependent trips to memory and a wait for everything outstanding, ten
+// times per task — several microseconds of instrumentation on every step's critical path.
+#define SLPX_LDLT_CLOCK(k)                                                          \
+  if (task_index == L.clock_task && blockIdx.y == 0 && threadIdx.x == 0) \
   g_ldlt_clocks[k] = wall_clock64()
 
 // ---------------------------------------------------------------------------
@@ -614,7 +617,7 @@ __device__ __forceinline__ bool ldlt_factor_body(
       end = end_pack & 0xffffu;
     }
 #ifdef SLPX_LDLT_LEVEL_CLOCKS
-    if (task_index == L.round_ptr[g_ldlt_clock_round] && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (task_index == L.clock_task && blockIdx.y == 0 && threadIdx.x == 0) {
       g_ldlt_clocks[6] = static_cast<unsigned long long>(clk_a);
       g_ldlt_clocks[7] = static_cast<unsigned long long>(clk_b);
     }

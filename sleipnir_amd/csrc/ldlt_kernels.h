@@ -199,16 +199,38 @@ __device__ __forceinline__ double chain_reciprocal(double d) {
 // straight-line code per w, reached by one scalar jump, out of line so that its registers do
 // not weigh on the level loop.
 // ---------------------------------------------------------------------------
+// The chain code works on LDS through pointers that SAY so (address space 3): handed a plain
+// `double*` an out-of-line function gets a generic pointer and every access becomes a flat
+// load / store (slower, and counted on both wait counters); and it takes its wave-uniform
+// arguments through readfirstlane ITSELF, because the calling convention passes them in vector
+// registers — the width switch was a cascade of exec-mask branches, the address arithmetic
+// vector work.  Loads are unconditional (a clamped index, then a select): a guarded load is a
+// compare, an exec save, a branch and a restore around it.
+using LdsF64 = __attribute__((address_space(3))) double;
+using LdsU32 = __attribute__((address_space(3))) uint32_t;
+using LdsU2 = __attribute__((address_space(3))) uint2;
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* lds_cast(T* p) {
+  return (__attribute__((address_space(3))) T*)p;
+}
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) const T* lds_cast(const T* p) {
+  return (__attribute__((address_space(3))) const T*)p;
+}
+
 template <int W>
-__device__ __forceinline__ void sn_finish_wave_exact(double* __restrict__ U, double* __restrict__ invd, uint32_t base0,
+__device__ __forceinline__ void sn_finish_wave_exact(LdsF64* __restrict__ U, LdsF64* __restrict__ invd, uint32_t base0,
                                                      uint32_t nr, uint32_t col0, uint32_t lane) {
-  const uint32_t t = lane;
-  const bool live = t < nr;
+  const uint32_t t = lane < nr ? lane : nr - 1u;  // (idle lanes shadow the last row; they store nothing)
+  const bool live = lane < nr;
   double a[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) {
+    // column c holds rows c .. nr-1; rows above the diagonal (t < c) read the diagonal and drop it
     const uint32_t offc = base0 + c * nr - (c * (c - 1)) / 2;
-    a[c] = (live && static_cast<uint32_t>(c) <= t) ? U[offc + (t - c)] : 0.0;
+    const uint32_t row = t >= static_cast<uint32_t>(c) ? t - c : 0u;
+    const double v = U[offc + row];
+    a[c] = t >= static_cast<uint32_t>(c) ? v : 0.0;
   }
 #pragma unroll
   for (int c = 0; c < W; ++c) {
@@ -220,14 +242,17 @@ __device__ __forceinline__ void sn_finish_wave_exact(double* __restrict__ U, dou
   }
 #pragma unroll
   for (int c = 0; c < W; ++c)
-    if (live && static_cast<uint32_t>(c) <= t) U[base0 + c * nr - (c * (c - 1)) / 2 + (t - c)] = a[c];
+    if (live && static_cast<uint32_t>(c) <= lane) U[base0 + c * nr - (c * (c - 1)) / 2 + (lane - c)] = a[c];
 }
 
-// (all arguments but `lane` are wave-uniform: the caller passes them through readfirstlane so
-// that the switch is a scalar jump)
-__device__ __attribute__((noinline)) void sn_finish_wave(double* __restrict__ U, double* __restrict__ invd,
+// (every argument but `lane` is wave-uniform)
+__device__ __attribute__((noinline)) void sn_finish_wave(LdsF64* __restrict__ U, LdsF64* __restrict__ invd,
                                                          uint32_t base0, uint32_t w, uint32_t nr, uint32_t col0,
                                                          uint32_t lane) {
+  base0 = __builtin_amdgcn_readfirstlane(base0);
+  w = __builtin_amdgcn_readfirstlane(w);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  col0 = __builtin_amdgcn_readfirstlane(col0);
   switch (w) {
 #define SLPX_SN_CASE(W) case W: sn_finish_wave_exact<W>(U, invd, base0, nr, col0, lane); break;
     SLPX_SN_CASE(2) SLPX_SN_CASE(3) SLPX_SN_CASE(4) SLPX_SN_CASE(5) SLPX_SN_CASE(6) SLPX_SN_CASE(7) SLPX_SN_CASE(8)
@@ -244,7 +269,7 @@ __device__ __attribute__((noinline)) void sn_finish_wave(double* __restrict__ U,
 // L(j_c, j_0..j_{c-1}).  Backward: `ptr` is the column range table (uint2): the W - c - 1 items
 // before .x are L(j_{c+1}..j_{W-1}, j_c).
 template <int W, bool FORWARD, typename Ptr>
-__device__ __forceinline__ void chain_solve_wave_w(double* __restrict__ v, const double* __restrict__ vals,
+__device__ __forceinline__ void chain_solve_wave_w(LdsF64* __restrict__ v, const LdsF64* __restrict__ vals,
                                                    const Ptr* __restrict__ ptr, uint32_t i0, uint32_t lane) {
   const bool mine = lane < static_cast<uint32_t>(W);
   const uint32_t c = mine ? lane : 0u;
@@ -255,10 +280,14 @@ __device__ __forceinline__ void chain_solve_wave_w(double* __restrict__ v, const
 #pragma unroll
   for (int k = 0; k < W; ++k) {
     const uint32_t kk = static_cast<uint32_t>(k);
-    const bool use = mine && (FORWARD ? kk < c : kk > c);
-    cf[k] = use ? vals[FORWARD ? first + kk : first + (kk - c - 1)] : 0.0;
+    const bool use = FORWARD ? kk < c : kk > c;
+    // (clamped: lanes without such a coupling read their first one and drop it)
+    const uint32_t at = use ? (FORWARD ? first + kk : first + (kk - c - 1u)) : first;
+    const double x = vals[at];
+    cf[k] = (use && mine) ? x : 0.0;
   }
-  double p = mine ? v[i0 + c] : 0.0;
+  double p = v[i0 + c];
+  p = mine ? p : 0.0;
   if (FORWARD) {
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) p = __builtin_fma(-cf[k], readlane_f64(p, k), p);
@@ -269,9 +298,11 @@ __device__ __forceinline__ void chain_solve_wave_w(double* __restrict__ v, const
   if (mine) v[i0 + c] = p;
 }
 template <bool FORWARD, typename Ptr>
-__device__ __attribute__((noinline)) void chain_solve_wave(double* __restrict__ v, const double* __restrict__ vals,
+__device__ __attribute__((noinline)) void chain_solve_wave(LdsF64* __restrict__ v, const LdsF64* __restrict__ vals,
                                                            const Ptr* __restrict__ ptr, uint32_t i0, uint32_t w,
                                                            uint32_t lane) {
+  i0 = __builtin_amdgcn_readfirstlane(i0);
+  w = __builtin_amdgcn_readfirstlane(w);
   switch (w) {
 #define SLPX_SN_CASE(W) case W: chain_solve_wave_w<W, FORWARD>(v, vals, ptr, i0, lane); break;
     SLPX_SN_CASE(2) SLPX_SN_CASE(3) SLPX_SN_CASE(4) SLPX_SN_CASE(5) SLPX_SN_CASE(6) SLPX_SN_CASE(7) SLPX_SN_CASE(8)
@@ -598,8 +629,7 @@ __device__ __forceinline__ bool ldlt_factor_body(
           // everything about the chain is wave-uniform: scalar registers, scalar jump
           for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += THREADS / 64) {
             const LdltSn sn = snd[q];
-            sn_finish_wave(U, invd, __builtin_amdgcn_readfirstlane(sn.base0), __builtin_amdgcn_readfirstlane(sn.w),
-                                  __builtin_amdgcn_readfirstlane(sn.nr), __builtin_amdgcn_readfirstlane(sn.col0), tid & 63);
+            sn_finish_wave(lds_cast(U), lds_cast(invd), sn.base0, sn.w, sn.nr, sn.col0, tid & 63);
           }
           __syncthreads();
         }
@@ -766,8 +796,8 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
       const uint32_t sb = snl[l], se = snl[l + 1];
       if (se > sb) {  // chains of two or more columns in this level (block-uniform)
         for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += 4)
-          chain_solve_wave<true>(y, vals, ptr, __builtin_amdgcn_readfirstlane(snd[q].col0),
-                                 __builtin_amdgcn_readfirstlane(snd[q].w), tid & 63);
+          chain_solve_wave<true>(lds_cast(y), lds_cast(static_cast<const double*>(vals)), lds_cast(ptr), snd[q].col0,
+                                 snd[q].w, tid & 63);
         __syncthreads();
       }
       beg = end;
@@ -1004,8 +1034,8 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
       const uint32_t sb = beg_pack >> 16, se = end_pack >> 16;
       if (se > sb) {  // chains of two or more columns in this level (block-uniform)
         for (uint32_t q = sb + __builtin_amdgcn_readfirstlane(tid >> 6); q < se; q += THREADS / 64)
-          chain_solve_wave<false>(x, vals, rng, __builtin_amdgcn_readfirstlane(snd[q].col0),
-                                  __builtin_amdgcn_readfirstlane(snd[q].w), tid & 63);
+          chain_solve_wave<false>(lds_cast(x), lds_cast(static_cast<const double*>(vals)), lds_cast(rng), snd[q].col0,
+                                  snd[q].w, tid & 63);
         __syncthreads();
       }
       end_pack = beg_pack;

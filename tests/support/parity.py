@@ -146,7 +146,20 @@ def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=
     # (p90 1.3e-6 at N=1000: delta = 1e-4 against O(1e4) update terms loses ten digits in every
     # separator pivot; quantiles are recorded, the median and the signs are asserted)
     assert errs["D_rel_median"] <= 1e-11, (errs["D_rel_median"], errs["D_rel_p90"], errs["D_rel"])
-    assert np.array_equal(np.sign(D), np.sign(Do))
+    # Signs: equal entry by entry — except where a noise-level pivot decides.  With gamma = 1e-10
+    # some pivots are differences of O(1) terms, |d| ~ 1e-10; whether such a pivot comes out
+    # +1e-10 or -1e-10 is rounding (it changed with the host: the oracle's libm picks CPU-specific
+    # sin / cos; and with the summation order of the device's dot products), and the next pivot
+    # of its 2 x 2 block, x - y^2 / d, is then huge with the opposite sign: flips come in such
+    # pairs, the inertia counts (asserted above) stay equal, and the backward-error checks below
+    # bound what the step sees of it.
+    flipped = np.nonzero(np.sign(D) != np.sign(Do))[0]
+    errs["D_sign_flips"] = int(flipped.size)
+    if flipped.size:
+        bulk = float(np.median(np.abs(Do)))
+        size = np.minimum(np.abs(D[flipped]), np.abs(Do[flipped]))
+        assert flipped.size <= 4 and flipped.size % 2 == 0 and float(size.min()) <= 1e-6 * bulk, (
+            flipped.tolist(), D[flipped].tolist(), Do[flipped].tolist(), bulk)
     p = backend.solve()
     # residual of the regularized system actually factored
     Kreg = cases.regularized(lcp, lri, lhs, n, delta, gamma)

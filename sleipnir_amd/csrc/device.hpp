@@ -480,7 +480,6 @@ class DeviceNlp {
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
-  int m_bround_cur = 0;
   hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
   hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
   hipEvent_t m_fork = nullptr, m_join = nullptr;

@@ -224,9 +224,9 @@ struct Orderer {
 
 }  // namespace
 
-LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt,
-                         const std::vector<int32_t>* user_perm,
-                         const std::vector<uint8_t>* diag_has_source) {
+static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const LdltOptions& opt,
+                                     const std::vector<int32_t>* user_perm,
+                                     const std::vector<uint8_t>* diag_has_source) {
   LdltPlan P;
   const int n = lower.cols;
   P.n = n;
@@ -254,9 +254,21 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
       a.erase(std::unique(a.begin(), a.end()), a.end());
     }
     Orderer ord(adj, has_diag, opt);
-    std::vector<int32_t> all(n);
-    std::iota(all.begin(), all.end(), 0);
-    ord.dissect(std::move(all));
+    // Hubs (LdltOptions::hub_factor) defeat level-set dissection — everything is two steps from
+    // everything — so they are taken out of the graph that is dissected and eliminated last.
+    std::vector<int32_t> rest, hubs;
+    {
+      std::vector<size_t> degs(n);
+      for (int v = 0; v < n; ++v) degs[v] = adj[v].size();
+      std::vector<size_t> sorted = degs;
+      std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+      const size_t median = n ? sorted[n / 2] : 0;
+      const size_t hub_degree =
+          std::max<size_t>(opt.hub_floor, static_cast<size_t>(opt.hub_factor * static_cast<double>(median)));
+      for (int v = 0; v < n; ++v) (degs[v] > hub_degree ? hubs : rest).push_back(v);
+    }
+    ord.dissect(std::move(rest));
+    if (!hubs.empty()) ord.order_separator(std::move(hubs));
     P.perm = std::move(ord.order);
     ordering_forced = ord.forced;
   }
@@ -850,6 +862,24 @@ LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& 
   P.factor_bytes = 12LL * lower.nnz() + 16LL * (P.nnzL + n);
   P.solve_bytes = 32LL * P.nnzL + 16LL * n;
   return P;
+}
+
+LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt,
+                         const std::vector<int32_t>* user_perm,
+                         const std::vector<uint8_t>* diag_has_source) {
+  try {
+    return build_ldlt_plan_once(lower, n_dec, opt, user_perm, diag_has_source);
+  } catch (const std::runtime_error& e) {
+    // a column that does not fit a task is usually the work of a few well-connected nodes the
+    // default rule did not take for hubs: once more with a sharper one, and bigger tasks
+    if (user_perm != nullptr && !user_perm->empty()) throw;
+    if (std::string(e.what()).find("exceeds the LDS task budget") == std::string::npos) throw;
+    LdltOptions sharper = opt;
+    sharper.hub_factor = 2.0;
+    sharper.hub_floor = 12;
+    sharper.task_entries = std::max<uint32_t>(opt.task_entries, LdltOptions{}.task_entries);
+    return build_ldlt_plan_once(lower, n_dec, sharper, user_perm, diag_has_source);
+  }
 }
 
 }  // namespace slpx

@@ -166,6 +166,12 @@ struct LdltOptions {
   // chains are cut at this many columns; the device kernels hold a row of kSnWidthMax doubles in
   // registers, wider plans are for the host interpreter's what-if statistics only
   uint32_t max_supernode_width = kSnWidthMax;
+  // Hubs (nodes adjacent to a large part of the graph: a timestep shared by every stage, the
+  // dense border of an arrow matrix) are set aside and eliminated last, like the "dense rows" of
+  // the sparse orderings: degree > max(hub_floor, hub_factor x median degree).  build_ldlt_plan
+  // retries with a sharper rule before it gives up on a column that does not fit a task.
+  double hub_factor = 3.0;
+  uint32_t hub_floor = 24;
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

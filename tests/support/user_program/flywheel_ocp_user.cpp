@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <string>
 
 #include <sleipnir/autodiff/variable_matrix.hpp>
 #include <sleipnir/optimization/ocp.hpp>
@@ -32,6 +33,30 @@ int main(int argc, char** argv) {
                              : method == 1 ? slp::TranscriptionMethod::DIRECT_COLLOCATION
                                            : slp::TranscriptionMethod::SINGLE_SHOOTING;
   try {
+    if (argc > 4 && std::string(argv[4]) == "shared-dt") {
+      // TimestepMethod::VARIABLE_SINGLE (ocp.hpp:127-136): ONE timestep decision variable shared
+      // by every step — a node of the KKT graph adjacent to all dynamics rows, which the
+      // factorization's ordering has to set aside as a hub.  Time-stamped ODE signature.
+      slp::OCP<double> problem(
+          1, 1, dt, N,
+          [=](const slp::Variable<double>&, const slp::VariableMatrix<double>& x, const slp::VariableMatrix<double>& u,
+              const slp::Variable<double>&) { return A * x + B * u; },
+          slp::DynamicsType::EXPLICIT_ODE, slp::TimestepMethod::VARIABLE_SINGLE, transcription);
+      problem.constrain_initial_state(0.0);
+      problem.set_upper_input_bound(12.0);
+      problem.set_lower_input_bound(-12.0);
+      problem.set_min_timestep(std::chrono::duration<double>{0.8 * dt.count()});
+      problem.set_max_timestep(std::chrono::duration<double>{1.2 * dt.count()});
+      slp::DenseMatrix r_mat{1, N + 1};
+      for (int k = 0; k < N + 1; ++k) r_mat[0, k] = r;
+      problem.minimize((r_mat - problem.X()) * (r_mat - problem.X()).T());
+      const auto status = problem.solve();
+      const double h = problem.dt().value(0, 0);
+      const bool ok = static_cast<int>(status) == 0 && h >= 0.8 * dt.count() - 1e-9 && h <= 1.2 * dt.count() + 1e-9 &&
+                      std::abs(problem.X().value(0, N) - r) < 1e-3;
+      std::printf("status=%d shared dt=%.6f final=%.9f\n", static_cast<int>(status), h, problem.X().value(0, N));
+      return ok ? 0 : 1;
+    }
     auto f_ode = [=](const slp::VariableMatrix<double>& x, const slp::VariableMatrix<double>& u) {
       return A * x + B * u;
     };

@@ -137,3 +137,79 @@ def test_batch_of_matrices_with_one_pattern(batch):
 def test_pattern_must_be_a_lower_triangle():
     with pytest.raises(sa.SlpxError):
         sa.System.linear_solver(2, 0, [0, 1, 3], [0, 0, 1])
+
+
+def _structured_kkt(rng, kind, n, m_e):
+    """Quasi-definite test matrices with the structures that make supernodes: banded (chains of
+    equal structure), block-arrow (a dense border: wide trapezoids), random sparse."""
+    dim = n + m_e
+    H = np.zeros((n, n))
+    if kind == "banded":
+        bw = int(rng.integers(2, 9))
+        for d in range(1, bw + 1):
+            v = rng.standard_normal(n - d) * 0.3
+            H += np.diag(v, -d) + np.diag(v, d)
+    elif kind == "arrow":
+        blk = int(rng.integers(3, 9))
+        for b0 in range(0, n - blk, blk):
+            B = rng.standard_normal((blk, blk)) * 0.3
+            H[b0:b0 + blk, b0:b0 + blk] += B + B.T
+        border = int(rng.integers(2, 12))
+        W = rng.standard_normal((border, n)) * (rng.random((border, n)) < 0.3) * 0.3
+        H[n - border:, :] += W
+        H[:, n - border:] += W.T
+    else:
+        M = rng.standard_normal((n, n)) * (rng.random((n, n)) < 1.5 / n) * 0.3
+        H = M + M.T
+    H += np.diag(np.abs(H).sum(axis=1) + 1.0)  # strictly diagonally dominant: positive definite
+    # constraint rows couple a few NEIGHBOURING variables, like the rows of a transcription (a
+    # dense A makes L dense, which is the reference's dense-LDLT territory, DESIGN.md §6)
+    A = np.zeros((m_e, n))
+    centres = np.sort(rng.integers(0, n, size=m_e))
+    for r, c0 in enumerate(centres):
+        cols = np.unique(np.clip(c0 + rng.integers(-4, 5, size=3), 0, n - 1))
+        A[r, cols] = rng.standard_normal(len(cols))
+    # full row rank without long-range couplings: every row gets a pivot column of its own nearby
+    free = np.ones(n, dtype=bool)
+    for r, c0 in enumerate(centres):
+        c = next(int(k) for k in sorted(range(n), key=lambda k: abs(k - int(c0))) if free[k])
+        free[c] = False
+        A[r, c] += 2.0 + abs(A[r]).sum()
+    K = np.block([[H, A.T], [A, -1e-2 * np.eye(m_e)]])
+    colptr, rowidx, vals = [0], [], []
+    for c in range(dim):
+        for r in range(c, dim):
+            if K[r, c] != 0.0:
+                rowidx.append(r)
+                vals.append(K[r, c])
+        colptr.append(len(rowidx))
+    return K, np.array(colptr, np.int32), np.array(rowidx, np.int32), np.array(vals)
+
+
+@pytest.mark.parametrize("kind", ["banded", "arrow", "random"])
+def test_irregular_patterns_against_dense_solves(kind):
+    """Twelve seeded matrices per structure, 40 to 600 unknowns: supernode chains of every width,
+    trapezoids up to a wave of rows, one to several rounds of tasks, hand-overs both ways — the
+    factorization with the right-hand side riding in it (compute + solve after a step-like
+    sequence) and the forward / backward pair for a new right-hand side, each against numpy."""
+    rng = np.random.default_rng({"banded": 11, "arrow": 12, "random": 13}[kind])
+    seen_chain = False
+    for trial in range(12):
+        # (a random sparse graph is an expander: its factor fills in almost completely whatever the
+        # ordering, so those stay small enough for a column to fit a task — DESIGN.md §6)
+        n = int(rng.integers(30, 110 if kind == "random" else 450))
+        m_e = int(rng.integers(5, max(6, n // 3)))
+        K, colptr, rowidx, vals = _structured_kkt(rng, kind, n, m_e)
+        ls = sa.System.linear_solver(n, m_e, colptr, rowidx)
+        seen_chain = seen_chain or ls.info["ldlt_widest_supernode"] >= 2
+        ls.reset_regularization(1e-10)
+        ls.set_matrix(vals)
+        info, reg, nfact = ls.compute()
+        assert info[0] == 0 and nfact == 1 and reg[0, 0] == 0.0, (kind, trial, n, m_e, info, reg)
+        for _ in range(2):
+            rhs = rng.standard_normal(n + m_e)
+            ls.set_rhs(rhs)
+            ls.solve()
+            _check_solution(K, n, reg[0], rhs, ls.get("p")[0])
+        ls.close()
+    assert seen_chain or kind == "random"

@@ -85,3 +85,14 @@ def test_ocp_helper_flywheel_known_answer_on_the_gpu(slpx, method, kind, steps):
     res = subprocess.run([str(OCP_BIN), str(method), str(kind), str(steps)], capture_output=True, text=True,
                          timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_ocp_helper_shared_timestep_is_a_hub_the_ordering_sets_aside(slpx):
+    """TimestepMethod::VARIABLE_SINGLE: one decision variable in every dynamics row.  Level-set
+    nested dissection cannot separate anything while it is in the graph (ldlt_symbolic.cpp: hubs
+    are eliminated last); the larger timestep wins (the cost is a tracking error)."""
+    rm = OCP_BIN.exists() and OCP_BIN.stat().st_mtime < OCP_SRC.stat().st_mtime
+    build_ocp_program(slpx) if (rm or not OCP_BIN.exists()) else None
+    res = subprocess.run([str(OCP_BIN), "0", "0", "200", "shared-dt"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

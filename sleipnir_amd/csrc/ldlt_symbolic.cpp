@@ -867,19 +867,35 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
 LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt,
                          const std::vector<int32_t>* user_perm,
                          const std::vector<uint8_t>* diag_has_source) {
+  auto too_big = [](const std::runtime_error& e) {
+    const std::string what = e.what();
+    return what.find("exceeds the LDS task budget") != std::string::npos ||
+           what.find("exceeds the 160 KB LDS") != std::string::npos;
+  };
   try {
     return build_ldlt_plan_once(lower, n_dec, opt, user_perm, diag_has_source);
   } catch (const std::runtime_error& e) {
-    // a column that does not fit a task is usually the work of a few well-connected nodes the
-    // default rule did not take for hubs: once more with a sharper one, and bigger tasks
-    if (user_perm != nullptr && !user_perm->empty()) throw;
-    if (std::string(e.what()).find("exceeds the LDS task budget") == std::string::npos) throw;
-    LdltOptions sharper = opt;
+    if (!too_big(e)) throw;
+  }
+  // A column that does not fit a task is usually the work of a few well-connected nodes the
+  // default rule did not take for hubs: once more with a sharper rule; then with bigger tasks
+  // (a column of c entries needs about c^2 / 8 entry-equivalents: 2048 hold c = 124, 5120 c = 198;
+  // beyond that the factor is dense enough for the reference's dense branch).
+  LdltOptions sharper = opt;
+  if (user_perm == nullptr || user_perm->empty()) {
     sharper.hub_factor = 2.0;
     sharper.hub_floor = 12;
-    sharper.task_entries = std::max<uint32_t>(opt.task_entries, LdltOptions{}.task_entries);
-    return build_ldlt_plan_once(lower, n_dec, sharper, user_perm, diag_has_source);
   }
+  for (uint32_t entries : {std::max<uint32_t>(opt.task_entries, LdltOptions{}.task_entries), 4096u, 5120u}) {
+    if (entries < opt.task_entries) continue;
+    sharper.task_entries = entries;
+    try {
+      return build_ldlt_plan_once(lower, n_dec, sharper, user_perm, diag_has_source);
+    } catch (const std::runtime_error& e) {
+      if (!too_big(e) || entries == 5120u) throw;
+    }
+  }
+  throw std::runtime_error("ldlt: no plan");  // not reached
 }
 
 }  // namespace slpx

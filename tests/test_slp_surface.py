@@ -96,3 +96,33 @@ def test_ocp_helper_shared_timestep_is_a_hub_the_ordering_sets_aside(slpx):
     build_ocp_program(slpx) if (rm or not OCP_BIN.exists()) else None
     res = subprocess.run([str(OCP_BIN), "0", "0", "200", "shared-dt"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+DD_SRC = ROOT / "tests" / "support" / "user_program" / "differential_drive_ocp_user.cpp"
+DD_BIN = ROOT / "build" / "differential_drive_ocp_user"
+
+
+def build_dd_program(slpx):
+    DD_BIN.parent.mkdir(parents=True, exist_ok=True)
+    lib_dir = slpx.LIB_PATH.parent
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(DD_SRC), "-o",
+           str(DD_BIN), "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_differential_drive_ocp_model_of_the_reference_test(slpx):
+    """differential_drive_ocp_test.cpp:61-63: LINEAR cost (the sum of the timesteps), NONLINEAR
+    equality constraints, LINEAR inequalities."""
+    build_dd_program(slpx)
+    res = subprocess.run([str(DD_BIN), "model-only"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.splitlines()[0] == "cost=2 eq=4 ineq=2", res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_differential_drive_minimum_time_ocp_on_the_gpu(slpx):
+    """differential_drive_ocp_test.cpp:65-107: SUCCESS, initial and final state to 1e-8 — a
+    nonlinear minimum-time problem whose single timestep variable sits in every dynamics row."""
+    build_dd_program(slpx) if not DD_BIN.exists() else None
+    res = subprocess.run([str(DD_BIN)], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

@@ -126,3 +126,32 @@ def test_differential_drive_minimum_time_ocp_on_the_gpu(slpx):
     build_dd_program(slpx) if not DD_BIN.exists() else None
     res = subprocess.run([str(DD_BIN)], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+CPO_SRC = ROOT / "tests" / "support" / "user_program" / "cart_pole_ocp_user.cpp"
+CPO_BIN = ROOT / "build" / "cart_pole_ocp_user"
+
+
+def build_cart_pole_ocp_program(slpx):
+    CPO_BIN.parent.mkdir(parents=True, exist_ok=True)
+    lib_dir = slpx.LIB_PATH.parent
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(CPO_SRC), "-o",
+           str(CPO_BIN), "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_cart_pole_ocp_model_of_the_reference_test(slpx):
+    """cart_pole_ocp_test.cpp:87-89: QUADRATIC cost, NONLINEAR equalities, LINEAR inequalities
+    (direct collocation, shared timestep variable, position bounds through for_each_step)."""
+    build_cart_pole_ocp_program(slpx)
+    res = subprocess.run([str(CPO_BIN), "model-only"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.splitlines()[0] == "cost=3 eq=4 ineq=2", res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_cart_pole_collocation_ocp_on_the_gpu(slpx):
+    """cart_pole_ocp_test.cpp:91-131: SUCCESS, initial and final state to 1e-8."""
+    build_cart_pole_ocp_program(slpx) if not CPO_BIN.exists() else None
+    res = subprocess.run([str(CPO_BIN)], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

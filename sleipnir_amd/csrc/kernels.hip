@@ -964,6 +964,9 @@ void DeviceNlp::build_solve_in_place(const LdltPlan& l) {
     SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ldlt_factor_solve_kernel<1024>, 1024, total));
     SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
   }
+  if (std::getenv("SLPX_LDLT_VERBOSE"))
+    std::fprintf(stderr, "ldlt one-launch step: %zu tasks, LDS %u + %u bytes, %d workgroup(s) per CU x %d CUs\n",
+                 l.tasks.size(), factor_part, solve_part, per_cu, cus);
   // (the separable sums ride in the same launch, and leave: a few workgroups of slack for them)
   if (!ok || total > 160u * 1024u || l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus) {
     m_fuse_solve = false;

@@ -13,5 +13,7 @@ for N in Ns:
     t0 = time.perf_counter()
     st, rep = pp.solve()
     print(f"N {N:5d} status {st:3d} iterations {rep['iterations']:5d} restorations {rep['restorations']:3d} "
-          f"t_total {rep['t_total']:.3f} s (wall {time.perf_counter() - t0:.3f}) error {rep['final_error']:.2e}", flush=True)
+          f"t_total {rep['t_total']:.3f} s (wall {time.perf_counter() - t0:.3f}) error {rep['final_error']:.2e} | "
+          f"restoration: {rep['restoration_iterations']} iterations, setup {rep['t_restoration_setup']:.3f} s, "
+          f"steps {rep['t_restoration']:.3f} s", flush=True)
     pp.close()

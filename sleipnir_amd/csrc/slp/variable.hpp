@@ -17,6 +17,7 @@
 #include <cassert>
 #include <cmath>
 #include <concepts>
+#include <functional>
 #include <initializer_list>
 #include <type_traits>
 #include <utility>
@@ -150,6 +151,9 @@ class DenseMatrix {
   double operator[](int i) const { return m_d[i]; }
   double& operator()(int r, int c) { return (*this)[r, c]; }
   double operator()(int r, int c) const { return (*this)[r, c]; }
+  friend bool operator==(const DenseMatrix& a, const DenseMatrix& b) {
+    return a.m_rows == b.m_rows && a.m_cols == b.m_cols && a.m_d == b.m_d;
+  }
 
  private:
   int m_rows = 0, m_cols = 0;
@@ -212,6 +216,14 @@ class VariableMatrixF64 {
     VariableMatrixF64 result{detail::empty, m_cols, m_rows};
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) result[c, r] = (*this)[r, c];
+    return result;
+  }
+
+  // variable_matrix.hpp:1027-1039
+  VariableMatrixF64 cwise_transform(const std::function<VariableF64(const VariableF64&)>& unary_op) const {
+    VariableMatrixF64 result{detail::empty, m_rows, m_cols};
+    for (int r = 0; r < m_rows; ++r)
+      for (int c = 0; c < m_cols; ++c) result[r, c] = unary_op((*this)[r, c]);
     return result;
   }
 
@@ -289,11 +301,13 @@ class VariableBlockF64 {
     return VariableBlockF64{*m_mat, m_r0 + r0, m_c0 + c0, rows, cols};
   }
   VariableBlockF64 segment(int offset, int length) const {
-    return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
+    return (m_rows == 1 && m_cols != 1) ? block(0, offset, 1, length) : block(offset, 0, length, 1);
   }
   VariableBlockF64 row(int r) const { return block(r, 0, 1, m_cols); }
   VariableBlockF64 col(int c) const { return block(0, c, m_rows, 1); }
   VariableMatrixF64 T() const { return VariableMatrixF64{*this}.T(); }
+  // variable_block.hpp: cwise_transform
+  VariableMatrixF64 cwise_transform(const std::function<VariableF64(const VariableF64&)>& unary_op) const;
 
   double value(int row, int col) const { return (*this)[row, col].value(); }
   double value(int index) const { return (*this)[index].value(); }
@@ -323,6 +337,19 @@ inline VariableMatrixF64::VariableMatrixF64(const VariableBlockF64& b) : m_rows{
   for (int r = 0; r < m_rows; ++r)
     for (int c = 0; c < m_cols; ++c) m_storage.push_back(b[r, c]);
 }
+inline VariableMatrixF64 VariableBlockF64::cwise_transform(
+    const std::function<VariableF64(const VariableF64&)>& unary_op) const {
+  return VariableMatrixF64{*this}.cwise_transform(unary_op);
+}
+// variable_matrix.hpp:1378-1395
+inline VariableMatrixF64 cwise_reduce(const VariableMatrixF64& lhs, const VariableMatrixF64& rhs,
+                                      const std::function<VariableF64(const VariableF64&, const VariableF64&)>& binary_op) {
+  assert(lhs.rows() == rhs.rows() && lhs.cols() == rhs.cols());
+  VariableMatrixF64 result{detail::empty, lhs.rows(), lhs.cols()};
+  for (int r = 0; r < lhs.rows(); ++r)
+    for (int c = 0; c < lhs.cols(); ++c) result[r, c] = binary_op(lhs[r, c], rhs[r, c]);
+  return result;
+}
 inline VariableBlockF64 VariableMatrixF64::block(int r0, int c0, int rows, int cols) {
   return VariableBlockF64{*this, r0, c0, rows, cols};
 }
@@ -333,10 +360,10 @@ inline VariableMatrixF64 VariableMatrixF64::block(int r0, int c0, int rows, int 
   return m;
 }
 inline VariableBlockF64 VariableMatrixF64::segment(int offset, int length) {
-  return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
+  return (m_rows == 1 && m_cols != 1) ? block(0, offset, 1, length) : block(offset, 0, length, 1);
 }
 inline VariableMatrixF64 VariableMatrixF64::segment(int offset, int length) const {
-  return m_cols == 1 ? block(offset, 0, length, 1) : block(0, offset, 1, length);
+  return (m_rows == 1 && m_cols != 1) ? block(0, offset, 1, length) : block(offset, 0, length, 1);
 }
 inline VariableBlockF64 VariableMatrixF64::row(int r) { return block(r, 0, 1, m_cols); }
 inline VariableMatrixF64 VariableMatrixF64::row(int r) const { return block(r, 0, 1, m_cols); }
@@ -625,6 +652,42 @@ class VariableMatrix<double> : public VariableMatrixF64 {
   VariableMatrix(const VariableBlockF64& b) : VariableMatrixF64{b} {}    // NOLINT
 };
 
+// slp::sin<Scalar> and friends, as template-ids (`arm.row(0).cwise_transform(slp::sin<T>)`,
+// arm_on_elevator_problem_test.cpp:97; variable.hpp:340-830 declares every function as a template
+// over Scalar).  Plain calls keep resolving to the fp64 functions above.
+#define SLP_UNARY_T(name) \
+  template <typename Scalar>                                                              \
+  Variable<Scalar> name(const Variable<Scalar>& x) { return name(static_cast<const VariableF64&>(x)); }
+SLP_UNARY_T(abs)
+SLP_UNARY_T(acos)
+SLP_UNARY_T(asin)
+SLP_UNARY_T(atan)
+SLP_UNARY_T(cbrt)
+SLP_UNARY_T(cos)
+SLP_UNARY_T(cosh)
+SLP_UNARY_T(erf)
+SLP_UNARY_T(exp)
+SLP_UNARY_T(log)
+SLP_UNARY_T(log10)
+SLP_UNARY_T(sign)
+SLP_UNARY_T(sin)
+SLP_UNARY_T(sinh)
+SLP_UNARY_T(sqrt)
+SLP_UNARY_T(tan)
+SLP_UNARY_T(tanh)
+#undef SLP_UNARY_T
+#define SLP_BINARY_T(name) \
+  template <typename Scalar>                                                              \
+  Variable<Scalar> name(const Variable<Scalar>& a, const Variable<Scalar>& b) {           \
+    return name(static_cast<const VariableF64&>(a), static_cast<const VariableF64&>(b));  \
+  }
+SLP_BINARY_T(atan2)
+SLP_BINARY_T(hypot)
+SLP_BINARY_T(max)
+SLP_BINARY_T(min)
+SLP_BINARY_T(pow)
+#undef SLP_BINARY_T
+
 template <>
 struct EqualityConstraints<double> : public EqualityConstraintsF64 {
   using EqualityConstraintsF64::EqualityConstraintsF64;
@@ -635,5 +698,10 @@ struct InequalityConstraints<double> : public InequalityConstraintsF64 {
   using InequalityConstraintsF64::InequalityConstraintsF64;
   InequalityConstraints(const InequalityConstraintsF64& c) : InequalityConstraintsF64{c} {}  // NOLINT
 };
+// `EqualityConstraints eq = x == y;`, `EqualityConstraints eqs{eq1, eq2};` (constraints_test.cpp:247-276)
+EqualityConstraints(const EqualityConstraintsF64&) -> EqualityConstraints<double>;
+EqualityConstraints(std::initializer_list<EqualityConstraintsF64>) -> EqualityConstraints<double>;
+InequalityConstraints(const InequalityConstraintsF64&) -> InequalityConstraints<double>;
+InequalityConstraints(std::initializer_list<InequalityConstraintsF64>) -> InequalityConstraints<double>;
 
 }  // namespace slp

@@ -155,3 +155,57 @@ def test_cart_pole_collocation_ocp_on_the_gpu(slpx):
     build_cart_pole_ocp_program(slpx) if not CPO_BIN.exists() else None
     res = subprocess.run([str(CPO_BIN)], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+# ---- the other problem tests of the reference (test/src/optimization/*_problem_test.cpp) ----
+USER_DIR = ROOT / "tests" / "support" / "user_program"
+
+
+def build_named_program(slpx, name):
+    src, out = USER_DIR / f"{name}.cpp", ROOT / "build" / name
+    if out.exists() and out.stat().st_mtime > src.stat().st_mtime:
+        return out
+    out.parent.mkdir(parents=True, exist_ok=True)
+    lib_dir = slpx.LIB_PATH.parent
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(src), "-o", str(out),
+           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return out
+
+
+def test_host_side_tests_of_the_reference_surface(slpx):
+    """trivial_problem_test.cpp, decision_variable_test.cpp and constraints_test.cpp: 279 checks that
+    need no device (an empty or cost-free problem is SUCCESS before anything is compiled,
+    problem.hpp:304-313)."""
+    exe = build_named_program(slpx, "small_surface_user")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "failed=0" in res.stdout, res.stdout + res.stderr
+
+
+# (program, arguments for the model only, expected types): cost / equality / inequality ExpressionType
+PROBLEM_PROGRAMS = [
+    ("arm_on_elevator_user", ["800", "model-only"], "cost=3 eq=2 ineq=4"),  # arm_on_elevator_problem_test.cpp:109-111
+    ("double_integrator_user", ["model-only"], "cost=3 eq=2 ineq=2"),        # double_integrator_problem_test.cpp:80-82
+    ("differential_drive_user", ["model-only"], "cost=3 eq=4 ineq=2"),       # differential_drive_problem_test.cpp:83-85
+]
+
+
+@pytest.mark.parametrize("name,args,types", PROBLEM_PROGRAMS, ids=[p[0] for p in PROBLEM_PROGRAMS])
+def test_problem_models_of_the_reference_tests(slpx, name, args, types):
+    exe = build_named_program(slpx, name)
+    res = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.splitlines()[0] == types, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args", [("arm_on_elevator_user", ["800"]), ("double_integrator_user", []),
+                                       ("differential_drive_user", [])], ids=lambda v: v if isinstance(v, str) else "")
+def test_problem_tests_of_the_reference_on_the_gpu(slpx, name, args):
+    """SUCCESS and the known answers of the reference's own tests: arm on elevator N = 800
+    (arm_on_elevator_problem_test.cpp:113), the double integrator's bang-coast-bang profile
+    (double_integrator_problem_test.cpp:84-131), the differential drive's states against the RK4
+    model to 1e-8 (differential_drive_problem_test.cpp:87-119)."""
+    exe = build_named_program(slpx, name)
+    res = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr

@@ -277,6 +277,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   const TapeJitResult jit = build_tape_templates(p, jit_opt);
   jit_seconds = jit.compile_seconds;
   tmpl_fn = jit.fn;
+  tmpl_params = jit.params;
   tmpl_mod = jit.mod;
   n_bodies = static_cast<uint32_t>(jit.groups.size());
   n_templated_tasks = 0;
@@ -332,6 +333,9 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   small_list.upload(small_rest);
   large_list.upload(large_rest);
   global_list.upload(p.global_tasks);
+  if (std::getenv("SLPX_TAPE_JIT_VERBOSE") && jit.fn)
+    std::fprintf(stderr, "slpx tape kernel: %zu bodies, %s code object (%zu bytes of arguments), %.3f s\n",
+                 jit.groups.size(), jit.specialized ? "specialized" : "generic", jit.params.size(), jit.compile_seconds);
   if (std::getenv("SLPX_TAPE_JIT_VERBOSE"))
     for (uint32_t ti : p.global_tasks)
       std::fprintf(stderr, "slpx tape GLOBAL task: leaf %u node %u slot %u vout %u jout %u levels %u+%u\n", p.tasks[ti].n_leaf,
@@ -757,7 +761,8 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     int do_reverse = reverse ? 1 : 0;
     void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
-                    &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse};
+                    &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
+                    const_cast<unsigned char*>(t.tmpl_params.data())};
     const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
     SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, 64, 1, 1, small_rides ? t.small_lds : 0u,
                                          small_stream, args, nullptr));

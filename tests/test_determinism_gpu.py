@@ -60,3 +60,29 @@ def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch,
         assert len(seen) == 1, sorted(seen.values(), reverse=True)
     finally:
         system.close()
+
+
+def test_generic_and_specialized_tape_kernels_give_the_same_bits(fresh, slpx, monkeypatch):
+    """tape_jit.cpp: the generic code object (the model's numbers as kernel arguments; what a
+    horizon without a prebuilt kernel runs) and the specialized one (literals; shipped for the
+    BASELINE horizons) are the same arithmetic in the same order."""
+    N = 100  # a prebuilt horizon: both kinds are in sleipnir_amd/jit_cache
+    out = {}
+    for kind, env in (("specialized", "1"), ("generic", "0")):
+        monkeypatch.setenv("SLPX_TAPE_SPECIALIZE", env)
+        slpx.lib().slpx_graph_reset()
+        pp = slpx.Problem.cart_pole(N, 5.0 / N)
+        n, me, mi = pp.dims
+        x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)
+        system = slpx.System(pp, batch=1, device=0)
+        try:
+            system.set_state(x, s, y, z, np.array([mu]))
+            system.sweep(True)
+            V = system.get("V")[0].copy()
+            info = system.newton_step(True)
+            assert info[0] == 0
+            out[kind] = (V.tobytes(), system.get("p").tobytes())
+        finally:
+            system.close()
+            pp.close()
+    assert out["generic"] == out["specialized"]

@@ -160,3 +160,21 @@ def test_no_supernode_reaches_an_mfma_tile(fresh, slpx, orc, hostcheck):
     sg = hostcheck.HostCheck(g.p).supernodes()
     assert sg["widest"] < 16 and sg["cols_in_ge16"] == 0
     print("supernodes cart-pole N=1000:", sn, " g-fold N=100:", sg)
+
+
+def test_generated_kernel_of_a_family_serves_every_horizon(fresh, slpx, tmp_path):
+    """tape_jit.cpp (ParamSink): in the GENERIC source the numbers that follow the horizon — base
+    indices, constants derived from the timestep — are members of a by-value kernel argument, so
+    two horizons of one model generate the same text (one code object, no hipRTC wait for a new
+    N); the SPECIALIZED source has them as literals and differs.  hipRTC cross-compiles both."""
+    names = {}
+    for N in (16, 24):
+        slpx.lib().slpx_graph_reset()
+        pp = slpx.Problem.cart_pole(N, 5.0 / N)
+        assert pp.prebuild_kernels(tmp_path / f"N{N}") >= 1
+        pp.close()
+        names[N] = {f.name for f in (tmp_path / f"N{N}").iterdir()}
+    shared = names[16] & names[24]
+    assert shared, "no code object in common: the generic source depends on the horizon"
+    assert names[16] - shared and names[24] - shared  # the specialized ones
+    assert len(shared) == len(names[16]) - len(shared)  # one generic beside every specialized

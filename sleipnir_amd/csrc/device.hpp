@@ -74,7 +74,8 @@ struct TapeDevice {
   // (mode 0 = values only, 1 = with adjoints) holds (first block, instances, instance
   // offset, row-group mode) per body, `tmpl_blocks[mode]` the grid size.
   hipFunction_t tmpl_fn = nullptr;
-  std::vector<unsigned char> tmpl_params;  // its last argument, by value (TemplateParams::blob)
+  std::vector<unsigned char> tmpl_params;  // the model's numbers a generic code object reads (TemplateParams::blob)
+  DevBuf<uint64_t> tmpl_params_dev;        // ... on the device: the kernel's last argument points here
   hipModule_t tmpl_mod = nullptr;
   uint32_t n_bodies = 0;
   DevBuf<uint32_t> tmpl_inst;  // per body: leaf bindings + output destinations, transposed (kernels.hip)

@@ -278,6 +278,11 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   jit_seconds = jit.compile_seconds;
   tmpl_fn = jit.fn;
   tmpl_params = jit.params;
+  {
+    std::vector<uint64_t> words((tmpl_params.size() + 7) / 8, 0);
+    std::memcpy(words.data(), tmpl_params.data(), tmpl_params.size());
+    tmpl_params_dev.upload(words);
+  }
   tmpl_mod = jit.mod;
   n_bodies = static_cast<uint32_t>(jit.groups.size());
   n_templated_tasks = 0;
@@ -334,7 +339,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   large_list.upload(large_rest);
   global_list.upload(p.global_tasks);
   if (std::getenv("SLPX_TAPE_JIT_VERBOSE") && jit.fn)
-    std::fprintf(stderr, "slpx tape kernel: %zu bodies, %s code object (%zu bytes of arguments), %.3f s\n",
+    std::fprintf(stderr, "slpx tape kernel: %zu bodies, %s code object (%zu bytes of model numbers), %.3f s\n",
                  jit.groups.size(), jit.specialized ? "specialized" : "generic", jit.params.size(), jit.compile_seconds);
   if (std::getenv("SLPX_TAPE_JIT_VERBOSE"))
     for (uint32_t ti : p.global_tasks)
@@ -759,10 +764,11 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     const unsigned* task_list = t.small_list.p;
     int n_template_blocks = static_cast<int>(t.tmpl_blocks[mode]);
     int do_reverse = reverse ? 1 : 0;
+    const uint64_t* params_dev = t.tmpl_params_dev.p;
     void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
                     &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
-                    const_cast<unsigned char*>(t.tmpl_params.data())};
+                    &params_dev};
     const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
     SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, 64, 1, 1, small_rides ? t.small_lds : 0u,
                                          small_stream, args, nullptr));

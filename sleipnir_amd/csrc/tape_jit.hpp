@@ -42,7 +42,7 @@ struct TapeJitResult {
   hipFunction_t fn = nullptr;              // extern "C" slpx_tape_templates(...), null = no templates
   std::vector<TapeTemplateGroup> groups;   // body k of the kernel serves groups[k]
   std::vector<uint8_t> task_is_templated;  // per task of the program
-  std::vector<unsigned char> params;       // the kernel's last argument (TemplateParams::blob)
+  std::vector<unsigned char> params;       // the table behind the kernel's last argument (TemplateParams::blob)
   bool specialized = false;                // the code object has this model's numbers as literals
   double compile_seconds = 0.0;
   // TapeJitOptions::compile_without_device on a machine without a GPU: bodies that were
@@ -83,18 +83,18 @@ int prebuild_tape_templates(const TapeProgram& prog, const TapeJitOptions& opt, 
 
 // The generated source for a set of families (members in instance order; exposed for tests /
 // inspection).  The bindings of each body are specialized for its family, see tape_jit.cpp.
-// `params` (optional): the model's numbers — base indices, constants — become members of the
-// kernel's last argument (struct SlpxParams { double c[]; unsigned w[]; }, by value) instead of
-// literals, and their values come back here: the source is then the same for every horizon and
-// parameter value of a model family.  Without it, or when they exceed kTemplateParamBytesMax,
-// they are literals and SlpxParams has one unused element of each kind.
+// `params` (optional): the model's numbers — base indices, constants — become members of a table
+// in device memory the kernel's last argument points to (struct SlpxParams { double c[];
+// unsigned w[]; }) instead of literals, and their values come back here: the source is then the
+// same for every horizon and parameter value of a model family.  Without it, or when they exceed
+// kTemplateParamBytesMax, they are literals and SlpxParams has one unused element of each kind.
 struct TemplateParams {
   std::vector<uint32_t> w;
   std::vector<double> c;
-  // the argument as the kernel expects it: c[max(1, |c|)] then w[max(1, |w|)], padded to 8 bytes
+  // the table as the kernel expects it: c[max(1, |c|)] then w[max(1, |w|)], padded to 8 bytes
   std::vector<unsigned char> blob() const;
 };
-constexpr size_t kTemplateParamBytesMax = 3072;  // of the 4 KB kernarg segment
+constexpr size_t kTemplateParamBytesMax = 16384;  // beyond this the numbers stay literals
 std::string generate_templates_source(const TapeProgram& prog, const std::vector<std::vector<uint32_t>>& families,
                                       uint32_t n_unscaled_inputs, TemplateParams* params = nullptr);
 

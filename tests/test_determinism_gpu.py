@@ -63,7 +63,7 @@ def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch,
 
 
 def test_generic_and_specialized_tape_kernels_give_the_same_bits(fresh, slpx, monkeypatch):
-    """tape_jit.cpp: the generic code object (the model's numbers as kernel arguments; what a
+    """tape_jit.cpp: the generic code object (the model's numbers in a device table; what a
     horizon without a prebuilt kernel runs) and the specialized one (literals; shipped for the
     BASELINE horizons) are the same arithmetic in the same order."""
     N = 100  # a prebuilt horizon: both kinds are in sleipnir_amd/jit_cache

@@ -164,7 +164,7 @@ def test_no_supernode_reaches_an_mfma_tile(fresh, slpx, orc, hostcheck):
 
 def test_generated_kernel_of_a_family_serves_every_horizon(fresh, slpx, tmp_path):
     """tape_jit.cpp (ParamSink): in the GENERIC source the numbers that follow the horizon — base
-    indices, constants derived from the timestep — are members of a by-value kernel argument, so
+    indices, constants derived from the timestep — are members of a table in device memory, so
     two horizons of one model generate the same text (one code object, no hipRTC wait for a new
     N); the SPECIALIZED source has them as literals and differs.  hipRTC cross-compiles both."""
     names = {}

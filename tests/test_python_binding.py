@@ -528,3 +528,76 @@ def test_flywheel_ocp_through_the_python_interface(kind, method, steps):
             assert near(u, U[k], 2.0 if method == TranscriptionMethod.DIRECT_COLLOCATION else 2e-4), k
         x = Ad * x + Bd * u
     assert near(r, X[steps], 2e-6)
+
+
+@pytest.mark.gpu
+def test_arm_on_elevator_through_the_python_interface():
+    """arm_on_elevator_problem_test.py: N = 800, one nonlinear inequality per sample (the end
+    effector's height, through cwise_map(autodiff.sin)); SUCCESS."""
+    N, T = 800, 4.0
+    dt = T / N
+    problem = Problem()
+    elevator, elevator_accel = problem.decision_variable(2, N + 1), problem.decision_variable(1, N)
+    arm, arm_accel = problem.decision_variable(2, N + 1), problem.decision_variable(1, N)
+    for k in range(N):
+        problem.subject_to(elevator[0, k + 1] == elevator[0, k] + elevator[1, k] * dt + 0.5 * elevator_accel[0, k] * dt ** 2)
+        problem.subject_to(elevator[1, k + 1] == elevator[1, k] + elevator_accel[0, k] * dt)
+        problem.subject_to(arm[0, k + 1] == arm[0, k] + arm[1, k] * dt + 0.5 * arm_accel[0, k] * dt ** 2)
+        problem.subject_to(arm[1, k + 1] == arm[1, k] + arm_accel[0, k] * dt)
+    problem.subject_to(elevator[:, :1] == np.array([[1.0], [0.0]]))
+    problem.subject_to(elevator[:, N:N + 1] == np.array([[1.25], [0.0]]))
+    problem.subject_to(arm[:, :1] == np.array([[0.0], [0.0]]))
+    problem.subject_to(arm[:, N:N + 1] == np.array([[math.pi], [0.0]]))
+    problem.subject_to(bounds(-1.0, elevator[1:2, :], 1.0))
+    problem.subject_to(bounds(-2.0, elevator_accel, 2.0))
+    problem.subject_to(bounds(-2.0 * math.pi, arm[1:2, :], 2.0 * math.pi))
+    problem.subject_to(bounds(-4.0 * math.pi, arm_accel, 4.0 * math.pi))
+    heights = elevator[:1, :] + 1.0 * arm[:1, :].cwise_map(autodiff.sin)
+    problem.subject_to(heights <= 1.8)
+    problem.minimize(sum((1.25 - elevator[0, k]) ** 2 + (math.pi - arm[0, k]) ** 2 for k in range(N + 1)))
+    assert problem.cost_function_type() == ExpressionType.QUADRATIC
+    assert problem.equality_constraint_type() == ExpressionType.LINEAR
+    assert problem.inequality_constraint_type() == ExpressionType.NONLINEAR
+    assert problem.solve() == ExitStatus.SUCCESS
+    assert (elevator.value()[0] + np.sin(arm.value()[0])).max() <= 1.8 + 1e-6
+
+
+def _differential_drive(x, u):
+    """test/include/differential_drive_util.hpp"""
+    trackwidth, Kv_l, Ka_l, Kv_a, Ka_a = 0.699, 3.02, 0.642, 1.382, 0.08495
+    A1, A2 = -(Kv_l / Ka_l + Kv_a / Ka_a) / 2.0, -(Kv_l / Ka_l - Kv_a / Ka_a) / 2.0
+    B1, B2 = 0.5 / Ka_l + 0.5 / Ka_a, 0.5 / Ka_l - 0.5 / Ka_a
+    v = (x[3, 0] + x[4, 0]) / 2.0
+    xdot = VariableMatrix(5)
+    xdot[0] = v * autodiff.cos(x[2, 0])
+    xdot[1] = v * autodiff.sin(x[2, 0])
+    xdot[2] = (x[4, 0] - x[3, 0]) / trackwidth
+    xdot[3:5, :] = np.array([[A1, A2], [A2, A1]]) @ x[3:5, :] + np.array([[B1, B2], [B2, B1]]) @ u
+    return xdot
+
+
+@pytest.mark.gpu
+def test_minimum_time_differential_drive_ocp_through_the_python_interface():
+    """differential_drive_ocp_test.py: 50 steps, ONE shared timestep variable, minimum total
+    time from the origin to (1, 1) at rest within +-12 V; SUCCESS, end points to 1e-8."""
+    N, min_dt = 50, 0.05
+    problem = OCP(5, 2, min_dt, N, _differential_drive, DynamicsType.EXPLICIT_ODE, TimestepMethod.VARIABLE_SINGLE,
+                  TranscriptionMethod.DIRECT_TRANSCRIPTION)
+    for i in range(N + 1):
+        problem.X()[0, i].set_value(i / (N + 1))
+        problem.X()[1, i].set_value(i / (N + 1))
+    x_final = np.array([[1.0], [1.0], [0.0], [0.0], [0.0]])
+    problem.constrain_initial_state(np.zeros((5, 1)))
+    problem.constrain_final_state(x_final)
+    problem.set_lower_input_bound(np.array([[-12.0], [-12.0]]))
+    problem.set_upper_input_bound(np.array([[12.0], [12.0]]))
+    problem.set_min_timestep(min_dt)
+    problem.set_max_timestep(3.0)
+    problem.minimize(problem.dt() @ np.ones((N + 1, 1)))
+    assert problem.cost_function_type() == ExpressionType.LINEAR
+    assert problem.equality_constraint_type() == ExpressionType.NONLINEAR
+    assert problem.inequality_constraint_type() == ExpressionType.LINEAR
+    assert problem.solve() == ExitStatus.SUCCESS
+    X = problem.X().value()
+    assert np.abs(X[:, 0]).max() < 1e-8 and np.abs(X[:, N:N + 1] - x_final).max() < 1e-8
+    assert min_dt - 1e-9 <= problem.dt().value(0, 0) <= 3.0

@@ -7,7 +7,7 @@
 // 128-byte line: problem b lives in element b % 16 of row [b / 16][i][0..15] of the
 // interleaved arrays  lhs_il, rhs_il, Lx_il, D_il, contrib_il, scontrib_il, zv_il, xg_il.
 //
-//  * factorization: a workgroup = one task x 16 problems x SIXTEEN entries of a level at a
+//  * factorization: a workgroup = one task x 16 problems x THIRTY-TWO entries of a level at a
 //    time (thread = entry slot * 16 + problem).  The task's U values and 1/d of its columns sit in
 //    LDS as rows of 16 — a quarter of what 64 problems per wave would need, so a dozen
 //    waves share a CU and hide each other's LDS latency (measured with 64 problems per wave
@@ -42,7 +42,10 @@ constexpr int kIlLanes = 64;  // lanes of a wave
 constexpr int kIlWShift = 4;  // (measured: 8-wide rows 0.74 ms per factorization of 512 x N=1000, 16-wide 0.67)
 constexpr int kIlW = 1 << kIlWShift;  // problems per interleaved row
 constexpr int kIlRowsPerChunk = 64 / kIlW;  // rows groups covering a 64-problem chunk
-constexpr int kIlFactorThreads = 256;
+// a level has ~65-120 entries: with 32 of them in flight a task's level loop takes half the passes
+// of 16, and the same LDS per workgroup holds twice the waves to hide its latency (measured, ms per
+// factorization of 512 x N=1000: 256 threads 0.629, 512 threads 0.589, 1024 threads 0.809)
+constexpr int kIlFactorThreads = 512;
 constexpr int kIlSlots = kIlFactorThreads / kIlW;  // entries of a level a factorization workgroup works on at a time
 
 // number of 16-problem rows groups a batch occupies (padded to whole waves of 64 problems)
@@ -94,7 +97,7 @@ __device__ __forceinline__ double il_reciprocal(double d) {
 }
 
 // One workgroup = one task x 16 problems; thread = slot * 16 + problem, the kIlSlots slots work
-// on that many entries of a level at a time (four waves per workgroup: twelve or more waves
+// on that many entries of a level at a time (eight waves per workgroup: sixteen or more waves
 // share a CU's LDS and hide each other's latency).
 // LDS: U[n_ent][16] | invd[n_col][16] | the task's plan slices (pairs, pointers, sources, ...).
 __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(

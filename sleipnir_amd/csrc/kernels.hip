@@ -588,7 +588,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     // per task: the plan slices the factor kernel keeps in LDS, packed back to back
     // [n_cref, n_words | pairs (2 words each) | pair ptr | src | out |
     //  flags + column | ext dst | level ptr | per-slot update-block refs]
-    uint32_t fbytes = 0, col = 0;
+    uint32_t fbytes = 0, col = 0, solve_bytes = 0;
     std::vector<uint32_t> meta, meta_off;
     for (const LdltTask& t : l.tasks) {
       const uint32_t n_cref = l.ent_contrib_ptr[t.contrib_ptr_off + t.n_ent];
@@ -629,11 +629,12 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       meta[head + 1] = n_words;
       fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * kIlW * 8u, 3u * kIlSlots * kIlW * 8u) + 4u * n_words + 16u);
       col = std::max(col, t.n_col + 1);
+      solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (2u * t.n_col + 2u) + 8u * t.n_bwd_items + 16u);
     }
     m_il_meta.upload(meta);
     m_il_meta_off.upload(meta_off);
     m_il_factor_lds = fbytes;
-    m_il_solve_lds = col * 64u * 8u;
+    m_il_solve_lds = std::max(col * 64u * 8u, solve_bytes);  // fwd: y rows; bwd: x rows + its plan slices
     if (m_il_factor_lds > 160u * 1024u)
       throw std::runtime_error("slpx: an LDLT task does not fit the interleaved kernel's LDS (LdltOptions::task_entries)");
     SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_il_kernel),

@@ -42,8 +42,9 @@ done
 # 4. phase clocks inside the LDLT kernels and the latency microbenchmarks
 PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>&1
 PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
+PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
 for B in latency icache chain; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
-PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= " > $N/${TAG}_setup_time.txt
+PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= \|tape kernel" > $N/${TAG}_setup_time.txt
 # 5. whole solves over the BASELINE horizons; the launch-fusion switches one by one
 PYTHONPATH=$R timeout 600 python profiles/horizon_sweep.py > $N/${TAG}_horizon_sweep.txt 2>&1
 bash profiles/ab_fuse.sh > $N/${TAG}_fusion_ab.txt 2>&1

@@ -117,7 +117,12 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
       opt.diagnostics = o->diagnostics != 0;
     }
     auto t0 = std::chrono::steady_clock::now();
-    p->problem.compile();
+    // problem.hpp:304-313: a problem without cost and constraints is SUCCESS before anything is
+    // built — nothing to compile, no device needed
+    const bool nothing_to_do = p->problem.cost_function_type() <= slp::ExpressionType::CONSTANT &&
+                               p->problem.equality_constraint_type() <= slp::ExpressionType::CONSTANT &&
+                               p->problem.inequality_constraint_type() <= slp::ExpressionType::CONSTANT;
+    if (!nothing_to_do) p->problem.compile();
     p->t_compile = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     status = static_cast<int>(p->problem.solve(opt));
     if (report) {

@@ -212,6 +212,13 @@ def test_trivial_problems_need_no_device():  # trivial_problem_test.py
     assert (X.value() == 1.0).all()
     with pytest.raises(KeyError):
         problem.solve(tolerence=1e-3)  # misspelt keyword: bind_problem.cpp:108-111
+    # the C entry point itself (slpx_problem_solve) takes the same early exit
+    import sleipnir_amd
+
+    low = sleipnir_amd.Problem()
+    low.decision_variable()
+    assert low.solve()[0] == 0
+    low.close()
 
 
 @pytest.mark.parametrize("lhs,rhs", [(1.0, 1.0), (1.0, 2.0), (2.0, 1.0)])

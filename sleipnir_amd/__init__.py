@@ -59,7 +59,7 @@ class Report(ctypes.Structure):
                 ("t_restoration", ctypes.c_double)]
 
 
-PREBUILT_MODELS = (("cart_pole", 1000), ("cart_pole", 500), ("cart_pole", 5000), ("cart_pole", 100))
+PREBUILT_MODELS = (("cart_pole", 1000), ("cart_pole", 500), ("cart_pole", 5000), ("cart_pole", 100), ("cart_pole", 50))
 
 
 def prebuild_kernels(models=PREBUILT_MODELS) -> int:

@@ -556,6 +556,15 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_scontrib.alloc(B * std::max<uint32_t>(1, l.n_scontrib));
   m_zv.alloc(B * l.n);
   m_xg.alloc(B * l.n);
+  // Every value buffer starts at zero, not at whatever the allocator hands back: the right-hand
+  // side rides in the factorization as an extra row, and compute() may come before any rhs was
+  // set (RegularizedLDLT::compute(lhs), regularized_ldlt.hpp:72) — recycled memory of an earlier
+  // system can hold the hand-over sentinel (a NaN pattern: the armed slots below), a NaN keeps
+  // its payload through arithmetic, and an update block that IS the sentinel is never taken
+  // (seen with SLPX_FUSE_SOLVE=0: the fourth solver of a process spinning to its time-out).
+  for (DevBuf<double>* buf : {&m_V, &m_s, &m_y, &m_z, &m_mu, &m_lhs, &m_rhs, &m_p, &m_ps, &m_pz, &m_D, &m_Lx, &m_scontrib, &m_zv})
+    buf->zero();
+  SLPX_HIP_CHECK(hipDeviceSynchronize());  // (the memsets ran on the null stream, the kernels will not)
   // the backward solve's hand-over through the data (ldlt_kernels.h: slot_read): two buffers of
   // x, both armed; SLPX_XG_HANDOFF=0: round counters
   m_xg_by_data = m_single_launch;

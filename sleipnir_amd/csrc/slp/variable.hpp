@@ -14,11 +14,14 @@
 // Eigen::Matrix<double,...> constants that appear in problem definitions.
 #pragma once
 
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <concepts>
 #include <functional>
 #include <initializer_list>
+#include <iterator>
+#include <limits>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -126,6 +129,64 @@ inline VariableF64 hypot(const VariableF64& x, const VariableF64& y, const Varia
   return sqrt(pow(x, 2) + pow(y, 2) + pow(z, 2));
 }
 
+// slice.hpp:14-160: Python's slice — start, stop, step, any of them `_` (slicing::none_t) —
+// with adjust(length) doing what slice.indices() does and returning the number of elements.
+namespace slicing {
+struct none_t {};
+inline constexpr none_t _;
+}  // namespace slicing
+
+class Slice {
+ public:
+  int start = 0, stop = 0, step = 1;
+
+  constexpr Slice() = default;
+  constexpr Slice(slicing::none_t) : start{0}, stop{kMax}, step{1} {}  // NOLINT: everything
+  // one element; -1 is the last one, whose successor is not 0 but the end
+  constexpr Slice(int index) : start{index}, stop{index == -1 ? kMax : index + 1}, step{1} {}  // NOLINT
+
+  template <typename Start, typename Stop>
+    requires(std::same_as<Start, slicing::none_t> || std::convertible_to<Start, int>) &&
+            (std::same_as<Stop, slicing::none_t> || std::convertible_to<Stop, int>)
+  constexpr Slice(Start from, Stop to) : Slice(from, to, 1) {}
+
+  template <typename Start, typename Stop, typename Step>
+    requires(std::same_as<Start, slicing::none_t> || std::convertible_to<Start, int>) &&
+            (std::same_as<Stop, slicing::none_t> || std::convertible_to<Stop, int>) &&
+            (std::same_as<Step, slicing::none_t> || std::convertible_to<Step, int>)
+  constexpr Slice(Start from, Stop to, Step by) {
+    if constexpr (!std::same_as<Step, slicing::none_t>) {
+      assert(by != 0);
+      step = by == std::numeric_limits<int>::min() ? -kMax : static_cast<int>(by);  // -step must exist
+    }
+    // an open end is "as far as it goes" in the direction of travel
+    if constexpr (std::same_as<Start, slicing::none_t>) start = step < 0 ? kMax : 0;
+    else start = from;
+    if constexpr (std::same_as<Stop, slicing::none_t>) stop = step < 0 ? std::numeric_limits<int>::min() : kMax;
+    else stop = to;
+  }
+
+  // clamp to a sequence of `length` elements (negative indices count from the end); returns how
+  // many elements the slice selects
+  constexpr int adjust(int length) {
+    assert(step != 0);
+    auto clamp = [&](int i) {
+      if (i < 0) {
+        i += length;
+        return i < 0 ? (step < 0 ? -1 : 0) : i;
+      }
+      return i >= length ? (step < 0 ? length - 1 : length) : i;
+    };
+    start = clamp(start);
+    stop = clamp(stop);
+    if (step < 0) return stop < start ? (start - stop - 1) / -step + 1 : 0;
+    return start < stop ? (stop - start - 1) / step + 1 : 0;
+  }
+
+ private:
+  static constexpr int kMax = std::numeric_limits<int>::max();
+};
+
 // Dense constant matrix (row-major), stand-in for Eigen::Matrix in model code
 class DenseMatrix {
  public:
@@ -202,6 +263,9 @@ class VariableMatrixF64 {
   const VariableF64& operator[](int index) const { return m_storage[index]; }
   VariableF64& operator()(int row, int col) { return (*this)[row, col]; }
   const VariableF64& operator()(int row, int col) const { return (*this)[row, col]; }
+  // variable_matrix.hpp:330-400: a strided view / copy
+  VariableBlockF64 operator[](Slice row_slice, Slice col_slice);
+  VariableMatrixF64 operator[](Slice row_slice, Slice col_slice) const;
 
   VariableBlockF64 block(int row_offset, int col_offset, int block_rows, int block_cols);
   VariableMatrixF64 block(int row_offset, int col_offset, int block_rows, int block_cols) const;
@@ -249,9 +313,41 @@ class VariableMatrixF64 {
   auto end() { return m_storage.end(); }
   auto begin() const { return m_storage.begin(); }
   auto end() const { return m_storage.end(); }
+  auto cbegin() const { return m_storage.cbegin(); }
+  auto cend() const { return m_storage.cend(); }
+  auto rbegin() { return m_storage.rbegin(); }
+  auto rend() { return m_storage.rend(); }
+  auto rbegin() const { return m_storage.rbegin(); }
+  auto rend() const { return m_storage.rend(); }
+  auto crbegin() const { return m_storage.crbegin(); }
+  auto crend() const { return m_storage.crend(); }
+
+  // variable_matrix.hpp:1100-1160
+  static VariableMatrixF64 constant(int rows, int cols, double value) {
+    VariableMatrixF64 m{detail::empty, rows, cols};
+    for (auto& e : m.m_storage) e = VariableF64{value};
+    return m;
+  }
+  static VariableMatrixF64 zero(int rows, int cols) { return constant(rows, cols, 0.0); }
+  static VariableMatrixF64 one(int rows, int cols) { return constant(rows, cols, 1.0); }
+  static VariableMatrixF64 identity(int rows) {
+    VariableMatrixF64 m{detail::empty, rows, rows};
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < rows; ++c) m[r, c] = VariableF64{r == c ? 1.0 : 0.0};
+    return m;
+  }
 
   VariableMatrixF64& operator+=(const VariableMatrixF64& rhs);
   VariableMatrixF64& operator-=(const VariableMatrixF64& rhs);
+  VariableMatrixF64& operator*=(const VariableMatrixF64& rhs);  // matrix product (variable_matrix.hpp:700-720)
+  VariableMatrixF64& operator+=(const VariableF64& rhs) {
+    for (auto& v : m_storage) v += rhs;
+    return *this;
+  }
+  VariableMatrixF64& operator-=(const VariableF64& rhs) {
+    for (auto& v : m_storage) v -= rhs;
+    return *this;
+  }
   VariableMatrixF64& operator*=(const VariableF64& rhs) {
     for (auto& v : m_storage) v *= rhs;
     return *this;
@@ -270,8 +366,9 @@ class VariableMatrixF64 {
 // re-points the viewed handles, as in the reference.
 class VariableBlockF64 {
  public:
-  VariableBlockF64(VariableMatrixF64& mat, int row_offset, int col_offset, int rows, int cols)
-      : m_mat{&mat}, m_r0{row_offset}, m_c0{col_offset}, m_rows{rows}, m_cols{cols} {}
+  VariableBlockF64(VariableMatrixF64& mat, int row_offset, int col_offset, int rows, int cols, int row_step = 1,
+                   int col_step = 1)
+      : m_mat{&mat}, m_r0{row_offset}, m_c0{col_offset}, m_rows{rows}, m_cols{cols}, m_rstep{row_step}, m_cstep{col_step} {}
 
   VariableBlockF64& operator=(const VariableMatrixF64& values) {
     assert(values.rows() == m_rows && values.cols() == m_cols);
@@ -291,14 +388,20 @@ class VariableBlockF64 {
     return *this;
   }
 
-  VariableF64& operator[](int row, int col) const { return (*m_mat)[m_r0 + row, m_c0 + col]; }
+  VariableF64& operator[](int row, int col) const { return (*m_mat)[m_r0 + row * m_rstep, m_c0 + col * m_cstep]; }
   VariableF64& operator[](int index) const { return (*this)[index / m_cols, index % m_cols]; }
+  // a slice of a slice: offsets add, steps multiply (variable_block.hpp)
+  VariableBlockF64 operator[](Slice row_slice, Slice col_slice) const {
+    const int rows = row_slice.adjust(m_rows), cols = col_slice.adjust(m_cols);
+    return VariableBlockF64{*m_mat, m_r0 + row_slice.start * m_rstep, m_c0 + col_slice.start * m_cstep, rows, cols,
+                            m_rstep * row_slice.step, m_cstep * col_slice.step};
+  }
   VariableF64& operator()(int row, int col) const { return (*this)[row, col]; }
   int rows() const { return m_rows; }
   int cols() const { return m_cols; }
 
   VariableBlockF64 block(int r0, int c0, int rows, int cols) const {
-    return VariableBlockF64{*m_mat, m_r0 + r0, m_c0 + c0, rows, cols};
+    return VariableBlockF64{*m_mat, m_r0 + r0 * m_rstep, m_c0 + c0 * m_cstep, rows, cols, m_rstep, m_cstep};
   }
   VariableBlockF64 segment(int offset, int length) const {
     return (m_rows == 1 && m_cols != 1) ? block(0, offset, 1, length) : block(offset, 0, length, 1);
@@ -316,6 +419,54 @@ class VariableBlockF64 {
     for (int r = 0; r < m_rows; ++r)
       for (int c = 0; c < m_cols; ++c) (*this)[r, c].set_value(values[r, c]);
   }
+
+  // variable_block.hpp: compound assignment writes through to the viewed matrix
+  VariableBlockF64& operator+=(const VariableMatrixF64& rhs);
+  VariableBlockF64& operator-=(const VariableMatrixF64& rhs);
+  VariableBlockF64& operator*=(const VariableMatrixF64& rhs);  // matrix product
+  VariableBlockF64& operator+=(const VariableF64& rhs);        // 1x1 blocks
+  VariableBlockF64& operator-=(const VariableF64& rhs);
+  VariableBlockF64& operator*=(const VariableF64& rhs) {
+    for (int r = 0; r < m_rows; ++r)
+      for (int c = 0; c < m_cols; ++c) (*this)[r, c] *= rhs;
+    return *this;
+  }
+  VariableBlockF64& operator/=(const VariableF64& rhs) {
+    for (int r = 0; r < m_rows; ++r)
+      for (int c = 0; c < m_cols; ++c) (*this)[r, c] /= rhs;
+    return *this;
+  }
+
+  // elements in row-major order of the view
+  class iterator {
+   public:
+    using iterator_category = std::bidirectional_iterator_tag;
+    using value_type = VariableF64;
+    using difference_type = std::ptrdiff_t;
+    using pointer = VariableF64*;
+    using reference = VariableF64&;
+    iterator() = default;
+    iterator(const VariableBlockF64* block, int index) : m_block{block}, m_index{index} {}
+    reference operator*() const { return (*m_block)[m_index]; }
+    pointer operator->() const { return &(*m_block)[m_index]; }
+    iterator& operator++() { ++m_index; return *this; }
+    iterator operator++(int) { iterator old = *this; ++m_index; return old; }
+    iterator& operator--() { --m_index; return *this; }
+    iterator operator--(int) { iterator old = *this; --m_index; return old; }
+    friend bool operator==(const iterator& a, const iterator& b) { return a.m_index == b.m_index; }
+
+   private:
+    const VariableBlockF64* m_block = nullptr;
+    int m_index = 0;
+  };
+  iterator begin() const { return iterator{this, 0}; }
+  iterator end() const { return iterator{this, m_rows * m_cols}; }
+  iterator cbegin() const { return begin(); }
+  iterator cend() const { return end(); }
+  std::reverse_iterator<iterator> rbegin() const { return std::reverse_iterator<iterator>{end()}; }
+  std::reverse_iterator<iterator> rend() const { return std::reverse_iterator<iterator>{begin()}; }
+  std::reverse_iterator<iterator> crbegin() const { return rbegin(); }
+  std::reverse_iterator<iterator> crend() const { return rend(); }
   void set_value(double value) {
     assert(m_rows == 1 && m_cols == 1);
     (*this)[0, 0].set_value(value);
@@ -323,7 +474,7 @@ class VariableBlockF64 {
 
  private:
   VariableMatrixF64* m_mat;
-  int m_r0, m_c0, m_rows, m_cols;
+  int m_r0, m_c0, m_rows, m_cols, m_rstep = 1, m_cstep = 1;
 };
 
 inline VariableF64::VariableF64(const VariableMatrixF64& value) : expr{value[0, 0].expr} {
@@ -349,6 +500,17 @@ inline VariableMatrixF64 cwise_reduce(const VariableMatrixF64& lhs, const Variab
   for (int r = 0; r < lhs.rows(); ++r)
     for (int c = 0; c < lhs.cols(); ++c) result[r, c] = binary_op(lhs[r, c], rhs[r, c]);
   return result;
+}
+inline VariableBlockF64 VariableMatrixF64::operator[](Slice row_slice, Slice col_slice) {
+  const int rows = row_slice.adjust(m_rows), cols = col_slice.adjust(m_cols);
+  return VariableBlockF64{*this, row_slice.start, col_slice.start, rows, cols, row_slice.step, col_slice.step};
+}
+inline VariableMatrixF64 VariableMatrixF64::operator[](Slice row_slice, Slice col_slice) const {
+  const int rows = row_slice.adjust(m_rows), cols = col_slice.adjust(m_cols);
+  VariableMatrixF64 m{detail::empty, rows, cols};
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) m[r, c] = (*this)[row_slice.start + r * row_slice.step, col_slice.start + c * col_slice.step];
+  return m;
 }
 inline VariableBlockF64 VariableMatrixF64::block(int r0, int c0, int rows, int cols) {
   return VariableBlockF64{*this, r0, c0, rows, cols};
@@ -454,6 +616,62 @@ inline VariableMatrixF64& VariableMatrixF64::operator-=(const VariableMatrixF64&
   for (int i = 0; i < size(); ++i) m_storage[i] -= rhs[i];
   return *this;
 }
+inline VariableMatrixF64& VariableMatrixF64::operator*=(const VariableMatrixF64& rhs) {
+  return *this = detail::matmul(*this, rhs);
+}
+inline VariableBlockF64& VariableBlockF64::operator+=(const VariableMatrixF64& rhs) {
+  assert(m_rows == rhs.rows() && m_cols == rhs.cols());
+  for (int r = 0; r < m_rows; ++r)
+    for (int c = 0; c < m_cols; ++c) (*this)[r, c] += rhs[r, c];
+  return *this;
+}
+inline VariableBlockF64& VariableBlockF64::operator-=(const VariableMatrixF64& rhs) {
+  assert(m_rows == rhs.rows() && m_cols == rhs.cols());
+  for (int r = 0; r < m_rows; ++r)
+    for (int c = 0; c < m_cols; ++c) (*this)[r, c] -= rhs[r, c];
+  return *this;
+}
+inline VariableBlockF64& VariableBlockF64::operator*=(const VariableMatrixF64& rhs) {
+  return *this = detail::matmul(VariableMatrixF64{*this}, rhs);
+}
+inline VariableBlockF64& VariableBlockF64::operator+=(const VariableF64& rhs) {
+  for (int r = 0; r < m_rows; ++r)
+    for (int c = 0; c < m_cols; ++c) (*this)[r, c] += rhs;
+  return *this;
+}
+inline VariableBlockF64& VariableBlockF64::operator-=(const VariableF64& rhs) {
+  for (int r = 0; r < m_rows; ++r)
+    for (int c = 0; c < m_cols; ++c) (*this)[r, c] -= rhs;
+  return *this;
+}
+// variable_matrix.hpp:1397-1470: [[A, B], [C]] -> one matrix
+inline VariableMatrixF64 block(std::initializer_list<std::initializer_list<VariableMatrixF64>> list) {
+  int rows = 0, cols = -1;
+  for (const auto& row : list) {
+    int h = -1, w = 0;
+    for (const auto& m : row) {
+      assert(h < 0 || h == m.rows());  // blocks of one row: same height
+      h = m.rows();
+      w += m.cols();
+    }
+    assert(cols < 0 || cols == w);  // block rows: same width
+    cols = w;
+    rows += std::max(h, 0);
+  }
+  VariableMatrixF64 result{detail::empty, rows, std::max(cols, 0)};
+  int r0 = 0;
+  for (const auto& row : list) {
+    int c0 = 0, h = 0;
+    for (const auto& m : row) {
+      for (int r = 0; r < m.rows(); ++r)
+        for (int c = 0; c < m.cols(); ++c) result[r0 + r, c0 + c] = m[r, c];
+      c0 += m.cols();
+      h = m.rows();
+    }
+    r0 += h;
+  }
+  return result;
+}
 // VariableBlockF64 operands convert to VariableMatrixF64
 inline VariableMatrixF64 operator*(const VariableBlockF64& l, const VariableBlockF64& r) { return VariableMatrixF64{l} * VariableMatrixF64{r}; }
 inline VariableMatrixF64 operator*(const VariableMatrixF64& l, const VariableBlockF64& r) { return l * VariableMatrixF64{r}; }
@@ -506,8 +724,34 @@ inline VariableMatrixF64 solve(const VariableMatrixF64& A, const VariableMatrixF
     auto det_A = a * adj_A00 + b * adj_A10 + c * adj_A20;
     return adj_A / det_A * B;
   }
-  assert(false && "solve(): only 1x1, 2x2 and 3x3 systems are built in this round");
-  return {};
+  // beyond 3x3: Gaussian elimination on the expressions, rows pivoted by the CURRENT values (the
+  // reference goes through Eigen's decompositions of Variables there, variable_matrix.hpp:1588-1620)
+  const int n = A.rows(), k = B.cols();
+  assert(A.cols() == n);
+  VariableMatrixF64 M{detail::empty, n, n + k};
+  for (int r = 0; r < n; ++r) {
+    for (int c = 0; c < n; ++c) M[r, c] = A[r, c];
+    for (int c = 0; c < k; ++c) M[r, n + c] = B[r, c];
+  }
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < n; ++r)
+      if (std::fabs(M[r, col].value()) > std::fabs(M[piv, col].value())) piv = r;
+    if (piv != col)
+      for (int c = col; c < n + k; ++c) std::swap(M[piv, c], M[col, c]);
+    for (int r = col + 1; r < n; ++r) {
+      const VariableF64 f = M[r, col] / M[col, col];
+      for (int c = col + 1; c < n + k; ++c) M[r, c] = M[r, c] - f * M[col, c];
+    }
+  }
+  VariableMatrixF64 X{detail::empty, n, k};
+  for (int c = 0; c < k; ++c)
+    for (int r = n - 1; r >= 0; --r) {
+      VariableF64 acc = M[r, n + c];
+      for (int j = r + 1; j < n; ++j) acc = acc - M[r, j] * X[j, c];
+      X[r, c] = acc / M[r, r];
+    }
+  return X;
 }
 
 // ---- constraints (variable.hpp:716-1013) ------------------------------------------
@@ -698,6 +942,16 @@ struct InequalityConstraints<double> : public InequalityConstraintsF64 {
   using InequalityConstraintsF64::InequalityConstraintsF64;
   InequalityConstraints(const InequalityConstraintsF64& c) : InequalityConstraintsF64{c} {}  // NOLINT
 };
+// slp::cwise_reduce<T>(A, B, std::multiplies<>{}) (variable_matrix_test.cpp:522-532)
+template <typename Scalar, typename F>
+VariableMatrix<Scalar> cwise_reduce(const VariableMatrix<Scalar>& lhs, const VariableMatrix<Scalar>& rhs, F&& binary_op) {
+  return cwise_reduce(static_cast<const VariableMatrixF64&>(lhs), static_cast<const VariableMatrixF64&>(rhs),
+                      [&](const VariableF64& x, const VariableF64& y) -> VariableF64 { return binary_op(x, y); });
+}
+VariableMatrix(const VariableMatrixF64&) -> VariableMatrix<double>;
+VariableMatrix(const VariableBlockF64&) -> VariableMatrix<double>;
+VariableMatrix(std::initializer_list<std::initializer_list<VariableF64>>) -> VariableMatrix<double>;
+
 // `EqualityConstraints eq = x == y;`, `EqualityConstraints eqs{eq1, eq2};` (constraints_test.cpp:247-276)
 EqualityConstraints(const EqualityConstraintsF64&) -> EqualityConstraints<double>;
 EqualityConstraints(std::initializer_list<EqualityConstraintsF64>) -> EqualityConstraints<double>;

@@ -168,7 +168,7 @@ def build_named_program(slpx, name):
     out.parent.mkdir(parents=True, exist_ok=True)
     lib_dir = slpx.LIB_PATH.parent
     cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++23", "--offload-arch=gfx950", "-x", "hip", str(src), "-o", str(out),
-           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir)]
+           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-Wl,-rpath," + str(lib_dir), "-pthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return out
@@ -209,3 +209,30 @@ def test_problem_tests_of_the_reference_on_the_gpu(slpx, name, args):
     exe = build_named_program(slpx, name)
     res = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
+
+
+def test_matrix_surface_of_the_reference_unit_tests(slpx):
+    """variable_matrix_test.cpp / slice_test.cpp with their own spellings: slp::Slice and `_`,
+    strided views written through, compound assignment on views, iterators of views, the static
+    constructors, cwise_reduce<T>, the free block() and solve() up to 5x5 — 143 checks, no device."""
+    exe = build_named_program(slpx, "variable_matrix_user")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "failed=0" in res.stdout, res.stdout + res.stderr
+
+
+def test_multistart_program_builds_and_refuses_without_a_device(slpx):
+    """slp::multistart (multistart.hpp:17-79) under the reference's include path; without a HIP
+    device the solves say so (the exception crosses the std::async boundary), nothing falls back."""
+    exe = build_named_program(slpx, "multistart_user")
+    if slpx.lib().slpx_device_count() == 0:
+        res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 3 and "no HIP device" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_multistart_of_the_reference_test_on_the_gpu(slpx):
+    """multistart_test.cpp:16-53: Mishra's bird function from two starts on two threads; the better
+    optimum (-3.13024680, -1.58214218) to 1e-8."""
+    exe = build_named_program(slpx, "multistart_user")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "status=0" in res.stdout and "failed_checks=0" in res.stdout, res.stdout + res.stderr

@@ -236,3 +236,25 @@ def test_multistart_of_the_reference_test_on_the_gpu(slpx):
     exe = build_named_program(slpx, "multistart_user")
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "status=0" in res.stdout and "failed_checks=0" in res.stdout, res.stdout + res.stderr
+
+
+def test_derivative_classes_symbolic_side(slpx):
+    """slp::Gradient / Jacobian / Hessian (gradient.hpp, jacobian.hpp, hessian.hpp) under the
+    reference's include paths: get() is the gradient tree — known answers of the reference's unit
+    tests, no device.  value() refuses without one."""
+    exe = build_named_program(slpx, "derivatives_user")
+    res = subprocess.run([str(exe), "symbolic"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "failed=0" in res.stdout, res.stdout + res.stderr
+    if slpx.lib().slpx_device_count() == 0:
+        res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 3 and "no HIP device" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_derivative_classes_values_from_the_device(slpx):
+    """value(): the compiled tape on the GPU — jacobian_test.cpp (y = x, products, re-evaluation at
+    new values), hessian_test.cpp (quadratic, sum of squares, product of sines; lower triangle
+    only), gradient_test.cpp."""
+    exe = build_named_program(slpx, "derivatives_user")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "failed=0" in res.stdout, res.stdout + res.stderr

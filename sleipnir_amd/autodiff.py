@@ -312,6 +312,23 @@ class VariableMatrix:
 
     cwise_transform = cwise_map
 
+    def exp(self):
+        """variable_matrix.hpp:1044-1098: the matrix exponential, q(A)^-1 p(A) with p the degree-13
+        diagonal Pade numerator and q(A) = p(-A); c_k = c_{k-1} (m - k + 1) / (k (2m - k + 1))."""
+        n = self.rows()
+        if n != self.cols():
+            raise ValueError("exp() needs a square matrix")
+        m = 13
+        c = [1.0]
+        for k in range(1, m + 1):
+            c.append(c[-1] * (m - k + 1) / (k * (2 * m - k + 1)))
+        I = np.eye(n)
+        P, Q = VariableMatrix(I * c[m]), VariableMatrix(I * -c[m])
+        for k in range(m - 1, -1, -1):
+            P = P @ self + I * c[k]
+            Q = Q @ self + I * (-c[k] if k & 1 else c[k])
+        return solve(Q, P)
+
     # ---- arithmetic (variable_matrix.hpp:587-1020) ----
     @staticmethod
     def _matmul(a: np.ndarray, b: np.ndarray) -> "VariableMatrix":

@@ -283,6 +283,9 @@ class VariableMatrixF64 {
     return result;
   }
 
+  // variable_matrix.hpp:1044-1098: the matrix exponential, (13, 13) Padé approximant
+  VariableMatrixF64 exp() const;
+
   // variable_matrix.hpp:1027-1039
   VariableMatrixF64 cwise_transform(const std::function<VariableF64(const VariableF64&)>& unary_op) const {
     VariableMatrixF64 result{detail::empty, m_rows, m_cols};
@@ -409,8 +412,9 @@ class VariableBlockF64 {
   VariableBlockF64 row(int r) const { return block(r, 0, 1, m_cols); }
   VariableBlockF64 col(int c) const { return block(0, c, m_rows, 1); }
   VariableMatrixF64 T() const { return VariableMatrixF64{*this}.T(); }
-  // variable_block.hpp: cwise_transform
+  // variable_block.hpp: cwise_transform, exp
   VariableMatrixF64 cwise_transform(const std::function<VariableF64(const VariableF64&)>& unary_op) const;
+  VariableMatrixF64 exp() const;
 
   double value(int row, int col) const { return (*this)[row, col].value(); }
   double value(int index) const { return (*this)[index].value(); }
@@ -753,6 +757,24 @@ inline VariableMatrixF64 solve(const VariableMatrixF64& A, const VariableMatrixF
     }
   return X;
 }
+
+// exp(A) ~ q(A)^-1 p(A) with p the degree-13 diagonal Padé numerator, q(A) = p(-A); the
+// coefficients follow c_0 = 1, c_k = c_{k-1} (m - k + 1) / (k (2m - k + 1)), m = 13.  Horner in A.
+inline VariableMatrixF64 VariableMatrixF64::exp() const {
+  assert(m_rows == m_cols);
+  constexpr int m = 13;
+  double c[m + 1];
+  c[0] = 1.0;
+  for (int k = 1; k <= m; ++k) c[k] = c[k - 1] * static_cast<double>(m - k + 1) / static_cast<double>(k * (2 * m - k + 1));
+  const VariableMatrixF64 I = identity(m_rows);
+  VariableMatrixF64 P = I * c[m], Q = I * -c[m];  // (-1)^13 = -1
+  for (int k = m - 1; k >= 0; --k) {
+    P = P * *this + I * c[k];
+    Q = Q * *this + I * ((k & 1) ? -c[k] : c[k]);
+  }
+  return solve(Q, P);
+}
+inline VariableMatrixF64 VariableBlockF64::exp() const { return VariableMatrixF64{*this}.exp(); }
 
 // ---- constraints (variable.hpp:716-1013) ------------------------------------------
 namespace detail {

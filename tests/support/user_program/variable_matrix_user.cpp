@@ -217,6 +217,42 @@ void element_functions_and_statics() {
   CHECK((result.value() == M{{16, 27, 40}, {55, 72, 91}}));
 }
 
+bool within(const M& a, const M& b, double tol) {
+  if (a.rows() != b.rows() || a.cols() != b.cols()) return false;
+  for (int r = 0; r < a.rows(); ++r)
+    for (int c = 0; c < a.cols(); ++c)
+      if (!(std::abs(a[r, c] - b[r, c]) <= tol)) return false;
+  return true;
+}
+M product(const M& a, const M& b) {
+  M p{a.rows(), b.cols()};
+  for (int r = 0; r < a.rows(); ++r)
+    for (int c = 0; c < b.cols(); ++c)
+      for (int k = 0; k < a.cols(); ++k) p[r, c] += a[r, k] * b[k, c];
+  return p;
+}
+
+void matrix_exponential() {  // variable_matrix_test.cpp:534-595
+  auto A1 = slp::VariableMatrix<T>{{T(4)}};
+  CHECK(within(A1.exp().value(), M{{std::exp(4.0)}}, 1e-13));
+  CHECK(within(A1[_, _].exp().value(), M{{std::exp(4.0)}}, 1e-13));
+  const M eye{{1, 0}, {0, 1}};
+  for (auto A : {slp::VariableMatrix<T>{{T(0), T(1)}, {T(0), T(-0.5)}}, slp::VariableMatrix<T>{{T(0), T(1)}, {T(0), T(10)}},
+                 slp::VariableMatrix<T>{{T(1), T(10)}, {T(0), T(0)}}, slp::VariableMatrix<T>{{T(2), T(3)}, {T(4), T(5)}}}) {
+    CHECK(within(product(A.exp().value(), (-A).exp().value()), eye, 1e-12));
+    CHECK(within(product(A[_, _].exp().value(), (-A[_, _]).exp().value()), eye, 1e-12));
+  }
+  // exp of the subdiagonal 1..6 is Pascal's triangle
+  auto pascal = slp::VariableMatrix<T>::zero(7, 7);
+  for (int col = 0; col < 6; ++col) pascal[col + 1, col] = T(col + 1);
+  M expected{7, 7};
+  for (int r = 0; r < 7; ++r) expected[r, 0] = 1;
+  for (int col = 1; col < 7; ++col)
+    for (int row = col; row < 7; ++row) expected[row, col] = expected[row - 1, col - 1] + expected[row - 1, col];
+  CHECK(within(pascal.exp().value(), expected, 1e-13));
+  CHECK(within(pascal[_, _].exp().value(), expected, 1e-13));
+}
+
 void block_free_function() {
   slp::VariableMatrix<T> A{{T(1), T(2), T(3)}, {T(4), T(5), T(6)}};
   slp::VariableMatrix<T> B{{T(7)}, {T(8)}};
@@ -265,6 +301,7 @@ int main() {
   compound_assignment();
   iterators_and_values();
   element_functions_and_statics();
+  matrix_exponential();
   block_free_function();
   solve_free_function();
   std::printf("checks=%d failed=%d\n", checked, failed);

@@ -163,6 +163,19 @@ def test_matrix_arithmetic_with_numpy_on_either_side():
     assert J.shape == (1, 1) and J.value(0, 0) == 30.0 and Variable(J).type() == ExpressionType.QUADRATIC
 
 
+def test_matrix_exponential():  # variable_matrix_test.py: exp()
+    assert VariableMatrix([[4.0]]).exp().value() == pytest.approx(np.array([[math.exp(4.0)]]), abs=1e-13)
+    for a in ([[0.0, 1.0], [0.0, -0.5]], [[0.0, 1.0], [0.0, 10.0]], [[1.0, 10.0], [0.0, 0.0]], [[2.0, 3.0], [4.0, 5.0]]):
+        A = VariableMatrix(a)
+        assert np.allclose(A.exp().value() @ (-A).exp().value(), np.eye(2), atol=1e-12)
+        assert np.allclose(A[:, :].exp().value() @ (-A[:, :]).exp().value(), np.eye(2), atol=1e-12)
+    pascal = VariableMatrix.zero(7, 7)
+    for col in range(6):
+        pascal[col + 1, col] = col + 1
+    expected = np.array([[math.comb(r, c) for c in range(7)] for r in range(7)], dtype=float)
+    assert np.allclose(pascal.exp().value(), expected, atol=1e-13)
+
+
 def test_block_and_solve_free_functions():  # variable_matrix_test.py: block(), solve()
     A = VariableMatrix([[1.0, 2.0], [3.0, 4.0]])
     B = VariableMatrix([[5.0], [6.0]])

@@ -98,6 +98,8 @@ typedef struct slpx_options {
   double timeout;      /* seconds; <= 0 means infinity */
   int32_t feasible_ipm;
   int32_t diagnostics;
+  int32_t spy; /* Problem::solve(options, spy) (problem.hpp:281): write H.spy, A_e.spy, A_i.spy (util/spy.hpp) into the
+                  working directory, one record per iteration; since ABI version 4 */
 } slpx_options;
 
 /* Per-solve counters and wall-clock phases (names of interior_point.hpp:155-174) */

@@ -43,7 +43,7 @@ OPS = {name: i for i, name in enumerate([
 class Options(ctypes.Structure):
     _fields_ = [("tolerance", ctypes.c_double), ("max_iterations", ctypes.c_int32),
                 ("timeout", ctypes.c_double), ("feasible_ipm", ctypes.c_int32),
-                ("diagnostics", ctypes.c_int32)]
+                ("diagnostics", ctypes.c_int32), ("spy", ctypes.c_int32)]
 
 
 class Report(ctypes.Structure):
@@ -261,8 +261,8 @@ class Problem:
         lib().slpx_problem_set_x(self._h, x.ctypes.data)
 
     def solve(self, tolerance=1e-8, max_iterations=5000, timeout=0.0, feasible_ipm=False,
-              diagnostics=False):
-        opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), int(diagnostics))
+              diagnostics=False, spy=False):
+        opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), int(diagnostics), int(spy))
         rep = Report()
         status = lib().slpx_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(rep))
         if status == -100:
@@ -272,7 +272,7 @@ class Problem:
     def restoration_steps(self, x, s, y, z, mu, steps, tolerance=1e-8, max_iterations=5000):
         """feasibility_restoration from the given iterate, `steps` iterations (slpx_problem_restoration_steps)."""
         x, s, y, z = (np.array(a, dtype=np.float64, copy=True) for a in (x, s, y, z))
-        opt = Options(tolerance, max_iterations, 0.0, 0, 0)
+        opt = Options(tolerance, max_iterations, 0.0, 0, 0, 0)
         status = lib().slpx_problem_restoration_steps(self._h, ctypes.byref(opt), x.ctypes.data, s.ctypes.data,
                                                       y.ctypes.data, z.ctypes.data, float(mu), int(steps))
         if status == -100:

@@ -36,7 +36,7 @@ int guard(F&& f) {
 
 extern "C" {
 
-int slpx_abi_version(void) { return 3; }
+int slpx_abi_version(void) { return 4; }
 const char* slpx_last_error(void) { return g_error.c_str(); }
 int slpx_device_count(void) {
   int count = 0;
@@ -124,7 +124,7 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
                                p->problem.inequality_constraint_type() <= slp::ExpressionType::CONSTANT;
     if (!nothing_to_do) p->problem.compile();
     p->t_compile = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    status = static_cast<int>(p->problem.solve(opt));
+    status = static_cast<int>(p->problem.solve(opt, o && o->spy != 0));
     if (report) {
       const auto& r = p->problem.report();
       *report = slpx_report{r.iterations,    r.factorizations, r.solves,       r.value_sweeps,
@@ -162,7 +162,7 @@ int slpx_problem_restoration_steps(slpx_problem* p, const slpx_options* o, doubl
 int slpx_problem_add_callback(slpx_problem* p, slpx_iteration_callback callback, void* user) {
   return guard([&] {
     if (!callback) throw std::runtime_error("slpx_problem_add_callback: null callback");
-    p->problem.add_callback([p, callback, user](const slp::IterationInfo& it) -> bool {
+    p->problem.add_callback([p, callback, user](const slpx::IterationInfo& it) -> bool {
       const auto& st = it.structure ? *it.structure : p->problem.compile().structure();
       slpx_iteration_info info{};
       info.in_restoration = it.in_restoration ? 1 : 0;

@@ -10,9 +10,14 @@
 // the same device Newton step (csrc/ipm.cpp).
 #pragma once
 
+#include <algorithm>
+#include <cstdint>
+#include <fstream>
 #include <functional>
+#include <map>
 #include <memory>
 #include <optional>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -24,8 +29,55 @@ namespace slp {
 
 using ExitStatus = slpx::ExitStatus;
 using Options = slpx::Options;
+// slp::IterationInfo<Scalar> (solver/iteration_info.hpp:13): only fp64 exists
+template <typename Scalar = double>
 using IterationInfo = slpx::IterationInfo;
 using SolveReport = slpx::SolveReport;
+
+// util/spy.hpp:20-80: the file tools/spy.py plots — title, row label, column label (each a
+// 32-bit little-endian length and the bytes), rows, columns, then per iteration the number of
+// coordinates and (row, column, '+' | '-' | '0') for every stored entry, column by column.
+class Spy {
+ public:
+  Spy(const std::string& filename, const std::string& title, const std::string& row_label,
+      const std::string& col_label, int rows, int cols)
+      : m_file{filename, std::ios::binary} {
+    for (const std::string* text : {&title, &row_label, &col_label}) {
+      write32le(static_cast<int32_t>(text->size()));
+      m_file.write(text->data(), static_cast<std::streamsize>(text->size()));
+    }
+    write32le(rows);
+    write32le(cols);
+  }
+  // the entries of `patterns` (same shape; values at V + offset, summed where two patterns meet)
+  void add(std::initializer_list<std::pair<const slpx::CscPattern*, const double*>> patterns, int cols) {
+    std::vector<std::map<int, double>> columns(static_cast<size_t>(cols));
+    int32_t count = 0;
+    for (const auto& [pat, values] : patterns)
+      for (int c = 0; c < cols && c + 1 < static_cast<int>(pat->colptr.size()); ++c)
+        for (int q = pat->colptr[c]; q < pat->colptr[c + 1]; ++q) {
+          auto [it, fresh] = columns[c].try_emplace(pat->rowidx[q], 0.0);
+          it->second += values[q];
+          count += fresh;
+        }
+    write32le(count);
+    for (int c = 0; c < cols; ++c)
+      for (const auto& [row, value] : columns[c]) {
+        write32le(row);
+        write32le(c);
+        m_file << (value > 0.0 ? '+' : value < 0.0 ? '-' : '0');
+      }
+    m_file.flush();
+  }
+
+ private:
+  std::ofstream m_file;
+  void write32le(int32_t num) {
+    const unsigned char b[4] = {static_cast<unsigned char>(num), static_cast<unsigned char>(num >> 8),
+                                static_cast<unsigned char>(num >> 16), static_cast<unsigned char>(num >> 24)};
+    m_file.write(reinterpret_cast<const char*>(b), 4);
+  }
+};
 
 class ProblemF64 {
  public:
@@ -95,22 +147,22 @@ class ProblemF64 {
   ExpressionType inequality_constraint_type() const { return max_type(m_inequality_constraints); }
 
   template <typename F>
-    requires requires(F cb, const IterationInfo& info) { { cb(info) } -> std::same_as<void>; }
+    requires requires(F cb, const slpx::IterationInfo& info) { { cb(info) } -> std::same_as<void>; }
   void add_callback(F&& callback) {
-    m_iteration_callbacks.emplace_back([cb = std::forward<F>(callback)](const IterationInfo& info) {
+    m_iteration_callbacks.emplace_back([cb = std::forward<F>(callback)](const slpx::IterationInfo& info) {
       cb(info);
       return false;
     });
   }
   template <typename F>
-    requires requires(F cb, const IterationInfo& info) { { cb(info) } -> std::same_as<bool>; }
+    requires requires(F cb, const slpx::IterationInfo& info) { { cb(info) } -> std::same_as<bool>; }
   void add_callback(F&& callback) {
     m_iteration_callbacks.emplace_back(std::forward<F>(callback));
   }
   void clear_callbacks() { m_iteration_callbacks.clear(); }
 
   // problem.hpp:281-679
-  ExitStatus solve(const Options& options = Options{}, [[maybe_unused]] bool spy = false) {
+  ExitStatus solve(const Options& options = Options{}, bool spy = false) {
     auto& g = detail::G();
     std::vector<double> x(m_decision_variables.size());
     for (size_t i = 0; i < x.size(); ++i) x[i] = m_decision_variables[i].value();
@@ -140,19 +192,39 @@ class ProblemF64 {
     m_scales = slpx::compute_problem_scaling(m_sys->structure(), V);
     dev.set_scaling(m_scales);
 
+    // problem.hpp:365-375, 453-470, 571-596: sparsity files of H (lower triangle of the Lagrangian's
+    // Hessian), A_e, A_i — one record per iteration, written from a callback like the reference's
+    std::vector<slpx::IterationCallback> callbacks = m_iteration_callbacks;
+    std::unique_ptr<Spy> H_spy, A_e_spy, A_i_spy;
+    if (spy) {
+      const int n = static_cast<int>(x.size()), m_e = static_cast<int>(m_equality_constraints.size()),
+                m_i = static_cast<int>(m_inequality_constraints.size());
+      H_spy = std::make_unique<Spy>("H.spy", "Hessian", "Decision variables", "Decision variables", n, n);
+      if (m_e || m_i) A_e_spy = std::make_unique<Spy>("A_e.spy", "Equality constraint Jacobian", "Constraints", "Decision variables", m_e, n);
+      if (m_i) A_i_spy = std::make_unique<Spy>("A_i.spy", "Inequality constraint Jacobian", "Constraints", "Decision variables", m_i, n);
+      callbacks.emplace_back([&](const slpx::IterationInfo& info) {
+        const slpx::NlpStructure& st = info.structure ? *info.structure : m_sys->structure();
+        const double* V = info.V.data();
+        H_spy->add({{&st.Hf, V + st.off_Hf}, {&st.Hc, V + st.off_Hc}}, st.n);
+        if (A_e_spy) A_e_spy->add({{&st.Ae, V + st.off_Ae}}, st.n);
+        if (A_i_spy) A_i_spy->add({{&st.Ai, V + st.off_Ai}}, st.n);
+        return false;
+      });
+    }
+
     // problem.hpp:335, 403, 512: the solver follows the kinds of constraints present
     ExitStatus status;
     if (m_equality_constraints.empty() && m_inequality_constraints.empty()) {
       m_s.clear();
       m_y.clear();
       m_z.clear();
-      status = slpx::newton(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_report);
+      status = slpx::newton(*m_sys, m_scales, callbacks, options, x, &m_report);
     } else if (m_inequality_constraints.empty()) {
       m_s.clear();
       m_z.clear();
-      status = slpx::sqp(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_y, &m_report);
+      status = slpx::sqp(*m_sys, m_scales, callbacks, options, x, &m_y, &m_report);
     } else {
-      status = slpx::interior_point(*m_sys, m_scales, m_iteration_callbacks, options, x, &m_s, &m_y, &m_z,
+      status = slpx::interior_point(*m_sys, m_scales, callbacks, options, x, &m_s, &m_y, &m_z,
                                     &m_report);
     }
     // problem.hpp:676

@@ -158,8 +158,6 @@ class Problem:
         for k in kwargs:
             if k not in allowed:
                 raise KeyError(f"Invalid keyword argument: {k}")
-        if kwargs.pop("spy", False):
-            raise NotImplementedError("spy files are not written by this build")
         timeout = kwargs.pop("timeout", 0.0)
         if timeout is None or math.isinf(timeout):
             timeout = 0.0

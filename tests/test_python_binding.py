@@ -393,6 +393,58 @@ def test_callbacks_see_the_iterates_and_can_stop_the_solve():  # nonlinear_probl
 
 
 @pytest.mark.gpu
+def test_spy_files(tmp_path, monkeypatch):
+    """problem_spy_test.py: solve(spy=True) writes H.spy, A_e.spy, A_i.spy (util/spy.hpp: labels,
+    shape, then per iteration the coordinates with the signs of the entries)."""
+    import struct
+
+    monkeypatch.chdir(tmp_path)
+    problem = Problem()
+    x, y = problem.decision_variable(), problem.decision_variable()
+    x.set_value(20.0)
+    y.set_value(20.0)
+    problem.minimize(x ** 4 + y ** 4)
+    problem.subject_to(x >= 1)
+    problem.subject_to(x <= 10)
+    problem.subject_to(y == 2)
+    iterations = []
+    problem.add_callback(lambda info: iterations.append(info.iteration))
+    assert problem.solve(spy=True) == ExitStatus.SUCCESS
+    assert x.value() == pytest.approx(1.0, abs=1e-8) and y.value() == pytest.approx(2.0, abs=1e-8)
+
+    def records(name, title, rows, cols):
+        data = (tmp_path / name).read_bytes()
+        pos = 0
+
+        def i32():
+            nonlocal pos
+            pos += 4
+            return struct.unpack_from("<i", data, pos - 4)[0]
+
+        def text():
+            nonlocal pos
+            n = i32()
+            pos += n
+            return data[pos - n:pos].decode()
+
+        assert (text(), text(), text()) == (title, "Constraints" if name != "H.spy" else "Decision variables", "Decision variables")
+        assert (i32(), i32()) == (rows, cols)
+        out = []
+        while pos < len(data):
+            rec = []
+            for _ in range(i32()):
+                r, c = i32(), i32()
+                rec.append((r, c, chr(data[pos])))
+                pos += 1
+            out.append(rec)
+        return out
+
+    assert records("H.spy", "Hessian", 2, 2) == [[(0, 0, "+"), (1, 1, "+")]] * len(iterations)
+    assert records("A_e.spy", "Equality constraint Jacobian", 1, 2) == [[(0, 1, "+")]] * len(iterations)
+    assert records("A_i.spy", "Inequality constraint Jacobian", 2, 2) == [[(0, 0, "+"), (1, 0, "-")]] * len(iterations)
+
+
+@pytest.mark.gpu
 def test_double_integrator_through_the_python_interface():
     """double_integrator_problem_test.py: the bang-coast-bang profile (1e-4 away from switches),
     end points to 1e-8."""

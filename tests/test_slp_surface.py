@@ -258,3 +258,13 @@ def test_derivative_classes_values_from_the_device(slpx):
     exe = build_named_program(slpx, "derivatives_user")
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "failed=0" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_spy_files_of_the_reference_test_on_the_gpu(slpx, tmp_path):
+    """problem_spy_test.cpp:54-148: solve(options, spy = true) leaves H.spy, A_e.spy, A_i.spy — one
+    record per iteration, coordinates with the signs of the entries — read back like the test does."""
+    exe = build_named_program(slpx, "problem_spy_user")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert res.returncode == 0 and "failed_checks=0" in res.stdout, res.stdout + res.stderr
+    assert {"H.spy", "A_e.spy", "A_i.spy"} <= {f.name for f in tmp_path.iterdir()}

@@ -2,9 +2,9 @@
 slp:: surface with its own include lines and spellings and links libslpx.so.
 
 VERDICT r01: "`slp::Problem` is a plain class, so the reference benchmark does not compile against
-it; no test compiles a C++ user program".  tests/support/user_program/cart_pole_user.cpp is
-benchmarks/scalability/cart_pole/sleipnir.cpp:16-129 + rk4.hpp with only its Eigen constants
-swapped for slp::DenseMatrix."""
+it; no test compiles a C++ user program".  tests/support/user_program/cart_pole_user.cpp builds the
+model of benchmarks/scalability/cart_pole/sleipnir.cpp:16-129 + rk4.hpp with every API spelling
+that program uses, Eigen constants as slp::DenseMatrix."""
 import subprocess
 from pathlib import Path
 

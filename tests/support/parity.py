@@ -238,3 +238,87 @@ def check_policy_loop(system, op_lhs, n, m_e, gamma_min=1e-10, start=None):
     skipped = 1 if system.info["struct_singular"] and float(dg[0]) != 0.0 else 0
     assert onf == nf + skipped, (onf, nf, skipped)
     return float(dg[0]), float(dg[1]), nf, onf
+
+
+def check_timed_step(system, op, state, b=0, tol_kkt=1e-10, tol_resid=1e-10, tol_step=1e-8, verbose=False,
+                     label=""):
+    """The step AS THE BENCH TIMES IT — `system.newton_step(True)` has just run on `state` =
+    (x, s, y, z, mu) (item `b` of a batch) from a reset regularization: whichever of the fused
+    one-launch kernel, the two-launch path or the batch-interleaved kernels the system picked —
+    against the oracle's whole step `op.newton_step` (interior_point.hpp:426-482 with the
+    delta / gamma loop of sparse_regularized_ldlt.hpp:64-152) on the product's permutation:
+    the (delta, gamma) the loop settled on, the inertia of D, then p, p_s, p_z with the same
+    conditioning-aware bounds as check_newton_step."""
+    x, s, y, z, mu = state
+    n, me, mi = system.info["n"], system.info["m_e"], system.info["m_i"]
+    perm = system.perm()
+    info, _ = op.newton_step(x, s, y, z, mu, True, perm)
+    assert info == 0
+    delta, gamma, nfact, _ = op.reg()
+    reg = system.regularization()[b]
+    errs = {"delta": float(reg[0]), "gamma": float(reg[1])}
+    assert (float(reg[0]), float(reg[1])) == (float(delta), float(gamma)), (label, reg, (delta, gamma))
+    p = system.get("p")[b]
+    ps = system.get("p_s")[b]
+    pz = system.get("p_z")[b]
+    D = system.get("D")[b]
+    Do = op.vec("D")
+    eps = np.finfo(float).eps
+    inertia = lambda d: (int(np.sum(d > eps)), int(np.sum(d < -eps)), int(np.sum(np.abs(d) <= eps)))
+    assert inertia(D) == inertia(Do) == (n, me, 0), (label, inertia(D), inertia(Do))
+    drel = np.abs(D - Do) / np.maximum(np.abs(Do), 1e-300)
+    errs["D_rel_median"] = float(np.median(drel))
+    errs["D_rel_p90"] = float(np.quantile(drel, 0.90))
+    errs["D_rel"] = float(np.max(drel))
+    assert errs["D_rel_median"] <= 1e-11, (label, errs)
+    # the system the step was computed from (written on demand after a fused step)
+    lhs = system.get("lhs")[b]
+    rhs = system.get("rhs")[b]
+    lcp, lri = system.pattern(5)
+    ocp, ori, ov = op.csc("lhs")
+    Lo = cases.csc_to_dict(ocp, ori, ov)
+    Lp = cases.csc_to_dict(lcp, lri, lhs)
+    lmax = max([1.0] + [abs(v) for v in Lo.values()])
+    errs["lhs"] = max(abs(Lp[k] - Lo[k]) for k in Lo) / lmax
+    errs["rhs"] = cases.max_rel(rhs, op.vec("rhs"))
+    assert errs["lhs"] <= tol_kkt and errs["rhs"] <= tol_kkt, (label, errs)
+    Kreg = cases.regularized(lcp, lri, lhs, n, delta, gamma)
+    po = op.vec("p")
+    k_inf = float(np.max(cases.lower_csc_matvec(lcp, lri, np.abs(Kreg), np.ones_like(rhs))))
+    scale = max(1.0, float(np.max(np.abs(rhs))), k_inf * float(np.max(np.abs(po))))
+    errs["resid"] = float(np.max(np.abs(cases.lower_csc_matvec(lcp, lri, Kreg, p) - rhs))) / scale
+    errs["resid_oracle"] = float(np.max(np.abs(cases.lower_csc_matvec(lcp, lri, Kreg, po) - rhs))) / scale
+    assert errs["resid"] <= max(tol_resid, 10.0 * errs["resid_oracle"]), (label, errs)
+    errs["p"] = cases.max_rel(p, po)
+    errs["p_s"] = cases.max_rel(ps, op.vec("p_s"))
+    errs["p_z"] = cases.max_rel(pz, op.vec("p_z"))
+    kappa = cases.cond_inf_estimate(lcp, lri, Kreg)
+    errs["kappa"] = kappa
+    tol_p = max(tol_step, 2.0 * kappa * (errs["resid"] + errs["resid_oracle"] + eps))
+    errs["tol_p"] = tol_p
+    assert errs["p"] <= tol_p, (label, errs)
+    p_true = cases.refined_solution(lcp, lri, Kreg, rhs)
+    errs["p_vs_true"] = cases.max_rel(p, p_true)
+    errs["po_vs_true"] = cases.max_rel(po, p_true)
+    assert errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"]), (label, errs)
+    # p_s, p_z (interior_point.hpp:479-480): the error of p carried through |A_i| and Sigma
+    V = system.get("V")[b]
+    I = system.info
+    acp, ari = system.pattern(2)
+    ai_inf = 1.0
+    if len(ari):
+        rown = np.zeros(mi)
+        np.add.at(rown, ari, np.abs(V[I["off_Ai"]:I["off_Ai"] + len(ari)]))
+        ai_inf = max(1.0, float(rown.max()))
+    pmax = max(1.0, float(np.max(np.abs(po))))
+    ps_ref = max(1.0, float(np.max(np.abs(op.vec("p_s"))))) if mi else 1.0
+    pz_ref = max(1.0, float(np.max(np.abs(op.vec("p_z"))))) if mi else 1.0
+    sigma_inf = max(1.0, float(np.max(z / s))) if mi else 1.0
+    tol_ps = max(tol_step, 2.0 * max(tol_step, 10.0 * errs["po_vs_true"]) * pmax * ai_inf / ps_ref)
+    errs["tol_ps"] = tol_ps
+    assert errs["p_s"] <= tol_ps, (label, errs)
+    assert errs["p_z"] <= max(tol_step, 2.0 * tol_ps * ps_ref * sigma_inf / pz_ref), (label, errs)
+    if verbose:
+        print(label, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in errs.items()},
+              "oracle factorizations", nfact)
+    return errs

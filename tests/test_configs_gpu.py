@@ -196,9 +196,6 @@ def test_batch_interleaved_ldlt(fresh, slpx, orc, monkeypatch):
     for b in range(190, 200):
         for key in ("p", "p_s", "p_z", "D"):
             assert np.array_equal(il[key][b], il[key][b - 190])
-    # the two paths sum in different orders: same inertia decisions, and the same step up to
-    # (condition number) x (backward error) — both are backward stable to 1e-10, the systems
-    # have condition numbers around 1e5 after regularization
+    # the two paths sum in different orders: same inertia decisions; the step itself is compared
+    # with the ORACLE, item by item, in tests/test_timed_path_parity_gpu.py (same N, B)
     assert np.array_equal(il["reg"], ref["reg"])
-    scale = np.abs(ref["p"]).max(axis=1, keepdims=True)
-    assert np.max(np.abs(il["p"] - ref["p"]) / scale) <= 1e-5

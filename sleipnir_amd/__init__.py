@@ -486,7 +486,7 @@ class System:
         ms = np.zeros(4, dtype=np.float32)
         _check(lib().slpx_system_time_fused_step(self._h, iters, ms.ctypes.data))
         return {"sweep": float(ms[0]), "kkt_factor_solve": float(ms[1]), "total": float(ms[2]),
-                "one_launch": bool(ms[3])}
+                "one_launch": bool(ms[3]), "multifrontal": ms[3] == 2.0}
 
     def time_step(self, iters=10, refresh_ad=True):
         ms = np.zeros(8, dtype=np.float32)

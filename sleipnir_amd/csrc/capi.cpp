@@ -753,7 +753,7 @@ int slpx_system_time_fused_step(slpx_system* s, int iters, float* ms) {
       dev.factor_solve_publish(delta, gamma, active);
     });
     ms[2] = ms[0] + ms[1];
-    ms[3] = dev.step_is_one_launch() ? 1.0f : 0.0f;
+    ms[3] = dev.step_is_one_launch() ? (dev.step_is_multifrontal() ? 2.0f : 1.0f) : 0.0f;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   });

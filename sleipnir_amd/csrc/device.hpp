@@ -313,6 +313,7 @@ class DeviceNlp {
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   bool step_is_one_launch() const { return m_fuse_solve && m_fuse_kkt; }
+  bool step_is_multifrontal() const { return m_mf; }
   void solve_backsub_publish();                     // solve_after_factor() + backsub_publish(), one launch where possible
   // factor() + solve_backsub_publish(): ONE launch where every task's workgroup fits on the device at once
   void factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
@@ -456,6 +457,16 @@ class DeviceNlp {
   KktFuse take_kkt_fuse();
   BacksubFuse backsub_fuse(const LdltStats* publish);
   uint32_t m_factor_solve_lds = 0;
+  // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
+  bool m_mf = false;
+  uint32_t m_mf_lds = 0;
+  std::vector<uint32_t> m_task_terms16, m_task_bs16;  // per task: 16-byte groups of its KKT terms / back-substitution rows
+  DevBuf<LdltMfTask> m_mf_tasks;
+  DevBuf<LdltFront> m_mf_fronts;
+  DevBuf<uint32_t> m_mf_lvl_ptr, m_mf_ext, m_mf_contrib_ptr, m_mf_contrib_idx, m_mf_anc;
+  DevBuf<uint16_t> m_mf_tab;
+  DevBuf<double> m_mf_contrib;
+  void build_mf(const LdltPlan& l);
   DevBuf<unsigned int> m_ipm_err_done;
   DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
   DevBuf<uint4> m_bs_task_plan;

@@ -23,6 +23,7 @@
 #include "device.hpp"
 #include "kkt_kernels.h"
 #include "ldlt_kernels.h"
+#include "ldlt_mf_kernels.h"
 #include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
@@ -518,6 +519,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_fuse_solve = m_fuse_launches && m_fuse_backsub;
   if (const char* env = std::getenv("SLPX_FUSE_SOLVE")) m_fuse_solve = m_fuse_solve && env[0] != '0';
   if (m_fuse_solve) build_solve_in_place(l);
+  if (m_fuse_solve && m_fuse_kkt && l.mf) build_mf(l);
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -872,6 +874,7 @@ void DeviceNlp::build_inline_kkt(const NlpStructure& s, const KktPlan& k, const 
     const uint32_t off16 = static_cast<uint32_t>(block * sizeof(KktTerm) / 16);
     const uint32_t len16 = static_cast<uint32_t>((terms.size() - block) * sizeof(KktTerm) / 16);
     task_terms[ti] = uint2{off16, len16};
+    m_task_terms16.push_back(len16);
     widest = std::max(widest, len16);
   }
   // the staged terms and, behind them, one product per term (4 terms = 3 x 16 bytes)
@@ -942,6 +945,7 @@ void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
     const uint32_t len16 = static_cast<uint32_t>((plan.size() - block) / 2);
     task_plan[ti] = uint4{static_cast<uint32_t>(block / 2), len16, static_cast<uint32_t>(n_rows),
                           static_cast<uint32_t>(rows_padded / 2)};
+    m_task_bs16.push_back(len16);
     widest = std::max(widest, len16);
   }
   m_solve_lds_inline = l.solve_lds_bytes + 16u + 16u * widest;
@@ -999,6 +1003,50 @@ void DeviceNlp::build_solve_in_place(const LdltPlan& l) {
   m_sip = SolveInPlace{m_bwd_items_u.p, m_col_zent.p, factor_part, static_cast<unsigned int>(l.tasks.size()),
                        m_exit_cnt.p};
   m_factor_solve_lds = total;
+}
+
+constexpr int kFactorThreadsSingle = 1024;
+// The multifrontal step (ldlt_mf_kernels.h): plan upload, LDS footprint, co-residency of every task's workgroup.
+void DeviceNlp::build_mf(const LdltPlan& l) {
+  if (const char* env = std::getenv("SLPX_LDLT_MF"))
+    if (env[0] == '0') return;
+  if (m_task_terms16.size() != l.tasks.size() || m_task_bs16.size() != l.tasks.size()) return;
+  uint32_t lds = 0;
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
+    const MfCarve cv = mf_carve(l.tasks[ti], l.mf_tasks[ti]);
+    const uint32_t n_terms = m_task_terms16[ti] * 4u / 3u;
+    lds = std::max(lds, mf_align16(cv.o_terms + 16u * m_task_terms16[ti] + 8u * n_terms) + 16u * m_task_bs16[ti]);
+  }
+  lds = mf_align16(lds) + 16u;
+  int per_cu = 0, cus = 0;
+  hipFuncAttributes attr{};
+  if (lds <= 160u * 1024u) {
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_mf_step_kernel<kFactorThreadsSingle>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ldlt_mf_step_kernel<kFactorThreadsSingle>)));
+    SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ldlt_mf_step_kernel<kFactorThreadsSingle>,
+                                                                kFactorThreadsSingle, lds));
+    SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+  }
+  if (std::getenv("SLPX_LDLT_VERBOSE"))
+    std::fprintf(stderr, "ldlt multifrontal step: %zu tasks, LDS %u bytes (static %zu), %d workgroup(s) per CU x %d CUs\n",
+                 l.tasks.size(), lds, attr.sharedSizeBytes, per_cu, cus);
+  // (the tables hold LDS byte addresses from 0: no static LDS in front of the dynamic block)
+  if (lds > 160u * 1024u || attr.sharedSizeBytes != 0 ||
+      l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus)
+    return;
+  m_mf_tasks.upload(l.mf_tasks);
+  m_mf_fronts.upload(l.mf_fronts);
+  m_mf_lvl_ptr.upload(l.mf_lvl_ptr);
+  m_mf_tab.upload(l.mf_tab);
+  m_mf_ext.upload(l.mf_ext);
+  m_mf_contrib_ptr.upload(l.mf_contrib_ptr);
+  m_mf_contrib_idx.upload(l.mf_contrib_idx);
+  m_mf_anc.upload(l.mf_anc);
+  m_mf_contrib.upload(std::vector<double>(std::max<uint32_t>(1, l.mf_n_contrib), std::bit_cast<double>(kSlotEmpty)));
+  if (m_exit_cnt.n == 0) m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
+  m_mf_lds = lds;
+  m_mf = true;
 }
 
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
@@ -1132,7 +1180,6 @@ void DeviceNlp::write_reg(const std::vector<double>& delta, const std::vector<do
   }
 }
 
-constexpr int kFactorThreadsSingle = 1024;
 
 // the system evaluated inside the factorization's launch, if a build_kkt_for_step() asked for it
 KktFuse DeviceNlp::take_kkt_fuse() {
@@ -1260,6 +1307,26 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
   LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1);
   KktFuse f = take_kkt_fuse();
   BacksubFuse bf = backsub_fuse(cur);
+  if (m_mf && f.inline_kkt && xg_other() != nullptr) {
+    MfDev md;
+    md.tasks = m_mf_tasks.p;
+    md.fronts = m_mf_fronts.p;
+    md.lvl_ptr = m_mf_lvl_ptr.p;
+    md.tab = m_mf_tab.p;
+    md.ext = m_mf_ext.p;
+    md.contrib_ptr = m_mf_contrib_ptr.p;
+    md.contrib_idx = m_mf_contrib_idx.p;
+    md.anc = m_mf_anc.p;
+    md.n_tasks = static_cast<unsigned int>(l.tasks.size());
+    md.exit_cnt = m_exit_cnt.p;
+    hipLaunchKernelGGL(ldlt_mf_step_kernel<kFactorThreadsSingle>,
+                       dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
+                       dim3(kFactorThreadsSingle), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
+                       l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
+    xg_flip();
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(ldlt_factor_solve_kernel<kFactorThreadsSingle>,
                      dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
                      dim3(kFactorThreadsSingle), m_factor_solve_lds, m_stream, m_ldev, m_lhs.p, m_h_reg, m_Lx.p, m_D.p,

@@ -1,0 +1,525 @@
+// Multifrontal numeric phase of the task-parallel LDLᵀ (ldlt_kernels.h): the per-level work of a
+// task as DENSE FRONTS, one wave per front, everything a lane touches found through precomputed
+// 16-bit LDS byte offsets (ldlt_symbolic.hpp: LdltFront) — and the Newton step built on it:
+// KKT evaluation, factorization, backward solve and back-substitution in ONE launch
+// (ldlt_mf_step_kernel; the pair-list version is ldlt_factor_solve_kernel).
+//
+// Why fronts.  A lone wave issues a dependent instruction every 6-9 clocks whatever it is
+// (profiles/microbench), so a level costs what it EXECUTES, not what it waits for.  The left-looking
+// pair lists executed, per level, a pointer trip, a pair trip, three value loads and two multiplies
+// per pair (~10 pairs per entry, LDS-throughput bound in the upper rounds) + an 8-lane DPP reduction
+// + a barrier + the chain pass + a second barrier.  A front J (w pivot columns, structure R below
+// them, r = |R|, rows = [columns | R | right-hand-side row], nr = w + r + 1):
+//   1. its first w columns (the LdltSn trapezoid in the task's entry array U) = A + the entries of
+//      the child fronts' update blocks that fall into them: at most `nch` values per entry, their
+//      addresses read from the front's pivot table;
+//   2. w pivots in registers, a lane per row (v_readlane broadcasts, as sn_finish_wave);
+//   3. its update block S_J(a, b) = Σ_children S_K(..) − Σ_c L(R_a, c) U(R_b, c), a in R + rhs, b in R,
+//      b <= a — a lane per entry, addresses from the front's update table — stored for the parent
+//      front, or, when the parent column lies in another task, sent straight to that task's
+//      update slots;
+// one barrier per level.  The backward solve walks the same fronts top-down on the U and 1/d the
+// factorization left in LDS: eight lanes per pivot column over the rows of R, a DPP reduction,
+// the chain's own couplings by v_readlane.
+//
+// Fronts wide enough for the matrix cores (w >= 4 pivots under more than 16 rows: the g-fold
+// problem's separator chains) take step 3 as v_mfma_f64_16x16x4_f64 tiles (mf_update_mfma).
+//
+// Replaces Eigen::SimplicialLDLT::factorize / solve as used by
+// util/sparse_regularized_ldlt.hpp:74,105,159-161 and Inertia (inertia.hpp:40-50).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ldlt_kernels.h"
+
+namespace slpx {
+
+using LdsU16 = __attribute__((address_space(3))) uint16_t;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+struct MfDev {
+  const LdltMfTask* tasks = nullptr;
+  const LdltFront* fronts = nullptr;
+  const uint32_t* lvl_ptr = nullptr;
+  const uint16_t* tab = nullptr;
+  const uint32_t* ext = nullptr;
+  const uint32_t* contrib_ptr = nullptr;
+  const uint32_t* contrib_idx = nullptr;
+  const uint32_t* anc = nullptr;
+  unsigned int n_tasks = 0;
+  unsigned int* exit_cnt = nullptr;  // workgroups through their exit phase (the last one publishes)
+};
+
+// LDS by byte address (what the tables hold)
+__device__ __forceinline__ double lds_ld(uint32_t addr) { return *reinterpret_cast<const LdsF64*>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ void lds_st(uint32_t addr, double v) { *reinterpret_cast<LdsF64*>(static_cast<uintptr_t>(addr)) = v; }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t addr) { return *reinterpret_cast<const LdsU16*>(static_cast<uintptr_t>(addr)); }
+
+// column c against column 0 of a trapezoid, same row, in bytes
+__device__ __forceinline__ uint32_t mf_coff(uint32_t c, uint32_t nr) { return 8u * (c * nr - (c * (c - 1u)) / 2u - c); }
+
+// ---------------------------------------------------------------------------
+// One front, one wave.  `tab`: LDS byte address of the front's tables.  Wave-uniform: everything
+// but `lane`.
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, bool root,
+                                           uint32_t invd_addr, const uint32_t* __restrict__ ext,
+                                           double* __restrict__ contrib, uint32_t lane) {
+  // ---- pivot columns ----
+  const uint32_t row = lane < nr ? lane : nr - 1u;  // (idle lanes shadow the last row: same loads, same stores)
+  const uint32_t stride = 2u * W * (1u + nch);
+  uint32_t pr = tab + row * stride;
+  uint32_t ua[W];
+  double a[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) ua[c] = lds_ld16(pr + 2u * c);
+#pragma unroll
+  for (int c = 0; c < W; ++c) a[c] = lds_ld(ua[c]);
+  for (uint32_t k = 0; k < nch; ++k) {
+    pr += 2u * W;
+    uint32_t sa[W];
+    double sv[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) sa[c] = lds_ld16(pr + 2u * c);
+#pragma unroll
+    for (int c = 0; c < W; ++c) sv[c] = lds_ld(sa[c]);
+#pragma unroll
+    for (int c = 0; c < W; ++c) a[c] += sv[c];
+  }
+  double inv[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    inv[c] = chain_reciprocal(readlane_f64(a[c], c));
+    const double lc = a[c] * inv[c];
+#pragma unroll
+    for (int j = c + 1; j < W; ++j) a[j] = __builtin_fma(-lc, readlane_f64(a[c], j), a[j]);
+  }
+#pragma unroll
+  for (int c = 0; c < W; ++c) lds_st(ua[c], a[c]);  // (rows above the diagonal: the scratch double)
+#pragma unroll
+  for (int c = 0; c < W; ++c) lds_st(invd_addr + 8u * c, inv[c]);  // (every lane the same value)
+  // ---- update block, a lane per entry ----
+  const uint32_t upd = tab + nr * stride;
+  const uint32_t ustride = 2u * (3u + nch);
+  for (uint32_t e0 = 0; e0 < n_s; e0 += 64u) {
+    const uint32_t e = e0 + lane < n_s ? e0 + lane : n_s - 1u;
+    const uint32_t ur = upd + e * ustride;
+    const uint32_t o = lds_ld16(ur), pa = lds_ld16(ur + 2u), pb = lds_ld16(ur + 4u);
+    double ra[W], rb[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const uint32_t coff = mf_coff(c, nr);
+      ra[c] = lds_ld(pa + coff);
+      rb[c] = lds_ld(pb + coff);
+    }
+    double v = 0.0;
+    for (uint32_t k = 0; k < nch; ++k) v += lds_ld(lds_ld16(ur + 6u + 2u * k));
+#pragma unroll
+    for (int c = 0; c < W; ++c) v = __builtin_fma(-(ra[c] * inv[c]), rb[c], v);
+    if (root) {
+      // (the receiving entry subtracts; and only ONE store per slot: its reader re-arms it)
+      if (e0 + lane < n_s) coherent_store(&contrib[ext[o]], -v, true);
+    } else {
+      lds_st(o, v);
+    }
+  }
+}
+
+__device__ __attribute__((noinline)) void mf_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t n_s,
+                                                   uint32_t root, uint32_t invd_addr, const uint32_t* __restrict__ ext,
+                                                   double* __restrict__ contrib, uint32_t lane) {
+  tab = __builtin_amdgcn_readfirstlane(tab);
+  w = __builtin_amdgcn_readfirstlane(w);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  nch = __builtin_amdgcn_readfirstlane(nch);
+  n_s = __builtin_amdgcn_readfirstlane(n_s);
+  root = __builtin_amdgcn_readfirstlane(root);
+  invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
+  switch (w) {
+#define SLPX_MF_CASE(W) case W: mf_front_w<W>(tab, nr, nch, n_s, root != 0, invd_addr, ext, contrib, lane); break;
+    SLPX_MF_CASE(1) SLPX_MF_CASE(2) SLPX_MF_CASE(3) SLPX_MF_CASE(4) SLPX_MF_CASE(5) SLPX_MF_CASE(6) SLPX_MF_CASE(7)
+    SLPX_MF_CASE(8)
+#undef SLPX_MF_CASE
+    default: break;
+  }
+  static_assert(kSnWidthMax == 8, "one case per front width");
+}
+
+// ---------------------------------------------------------------------------
+// Backward solve of one front, one wave: x_c = (U(rhs, c) − Σ_{t in R} U(t, c) x_t − Σ_{c' > c} U(c', c) x_c') / d_c.
+// Eight lanes per pivot column over the rows of R (their x through the front's solve table), DPP
+// sum, then the chain top-down with v_readlane.  `xr`: LDS byte address of the solve table,
+// `u0`: of the front's first entry, `x_addr`: of x[col0], `invd_addr`: of 1/d[col0].
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void mf_solve_w(uint32_t xr, uint32_t u0, uint32_t nr, uint32_t invd_addr, uint32_t x_addr,
+                                           uint32_t lane) {
+  const uint32_t r = nr - W - 1u;
+  const uint32_t c = lane >> 3, g = lane & 7u;
+  const bool mine = c < static_cast<uint32_t>(W);
+  const uint32_t cc = mine ? c : 0u;
+  const uint32_t colc = u0 + 8u * (cc * nr - (cc * (cc - 1u)) / 2u);  // diagonal of column cc
+  double dot = 0.0;
+  for (uint32_t a = g; a < r; a += 8u) dot = __builtin_fma(lds_ld(colc + 8u * (W - cc + a)), lds_ld(lds_ld16(xr + 2u * a)), dot);
+  dot = group8_sum(dot);
+  // the chain's own couplings U(k, cc), k > cc, and the right-hand-side row
+  double cf[W];
+#pragma unroll
+  for (int k = 1; k < W; ++k) {
+    const bool use = static_cast<uint32_t>(k) > cc;
+    const double v = lds_ld(colc + 8u * (use ? k - cc : 0u));
+    cf[k] = (use && mine) ? v : 0.0;
+  }
+  const double inv = lds_ld(invd_addr + 8u * cc);
+  double p = lds_ld(colc + 8u * (nr - 1u - cc)) - dot;  // (lane 8 c holds column c)
+#pragma unroll
+  for (int k = W - 1; k >= 0; --k) {
+    // column k is final once the columns above it are in: scale it, then hand it to the columns below
+    const double xk = readlane_f64(p, 8 * k) * readlane_f64(inv, 8 * k);
+    if (k > 0) p = __builtin_fma(-cf[k], xk, p);
+    if (lane == 0) lds_st(x_addr + 8u * k, xk);
+  }
+}
+
+__device__ __attribute__((noinline)) void mf_solve_front(uint32_t xr, uint32_t u0, uint32_t w, uint32_t nr,
+                                                         uint32_t invd_addr, uint32_t x_addr, uint32_t lane) {
+  xr = __builtin_amdgcn_readfirstlane(xr);
+  u0 = __builtin_amdgcn_readfirstlane(u0);
+  w = __builtin_amdgcn_readfirstlane(w);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
+  x_addr = __builtin_amdgcn_readfirstlane(x_addr);
+  switch (w) {
+#define SLPX_MF_CASE(W) case W: mf_solve_w<W>(xr, u0, nr, invd_addr, x_addr, lane); break;
+    SLPX_MF_CASE(1) SLPX_MF_CASE(2) SLPX_MF_CASE(3) SLPX_MF_CASE(4) SLPX_MF_CASE(5) SLPX_MF_CASE(6) SLPX_MF_CASE(7)
+    SLPX_MF_CASE(8)
+#undef SLPX_MF_CASE
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The step: one workgroup per task, every round in the launch (tasks wait for each other through the
+// update slots and, in the solve, through x itself: every workgroup must be resident).
+// LDS (bytes; the first four regions are what the tables address, so they start at 0):
+//   U[n_ent] f64 | arena f64 | 1/d[n_col] f64 | x[n_col + n_anc + 1] f64 |
+//   tables u16 | fronts 16 B | levels u32 | ext u32 | src i32 | col u16 | flags u8 | out u32 | cptr u32 | cidx u32 |
+//   colperm u32 | anc u32 | counters 32 B | KKT terms + products | back-substitution rows
+// ---------------------------------------------------------------------------
+struct MfCarve {
+  uint32_t o_arena, o_invd, o_x, o_tab, o_fr, o_lvl, o_ext, o_src, o_col, o_flags, o_out, o_cptr, o_cidx, o_cp, o_anc,
+      o_cnt, o_terms;
+};
+__host__ __device__ inline uint32_t mf_align16(uint32_t v) { return (v + 15u) & ~15u; }
+__host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask& m) {
+  MfCarve c;
+  auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1u) / per16); };
+  c.o_arena = 8u * t.n_ent;
+  c.o_invd = c.o_arena + 8u * m.arena;
+  c.o_x = c.o_invd + 8u * t.n_col;
+  c.o_tab = mf_align16(c.o_x + 8u * (t.n_col + m.n_anc + 1u));
+  c.o_fr = c.o_tab + q(m.n_tab, 8);
+  c.o_lvl = c.o_fr + 16u * m.n_front;
+  c.o_ext = c.o_lvl + q(t.n_lvl + 1u, 4);
+  c.o_src = c.o_ext + q(m.n_ext, 4);
+  c.o_col = c.o_src + q(t.n_ent, 4);
+  c.o_flags = c.o_col + q(t.n_ent, 8);
+  c.o_out = c.o_flags + q(t.n_ent, 16);
+  c.o_cptr = c.o_out + q(t.n_ent, 4);
+  c.o_cidx = c.o_cptr + q(t.n_ent + 1u, 4);
+  c.o_cp = c.o_cidx + q(m.n_contrib_idx, 4);
+  c.o_anc = c.o_cp + q(t.n_col, 4);
+  c.o_cnt = c.o_anc + q(m.n_anc, 4);
+  c.o_terms = c.o_cnt + 32u;
+  return c;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
+    LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
+    double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
+    LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+    ride_along_sum(F, blockIdx.x, smem_raw);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
+  const LdltTask t = L.tasks[task_index];
+  const LdltMfTask m = Mf.tasks[task_index];
+  const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
+  if (stats_next != nullptr && task_index == 0 && tid == 0) stats_next[0] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
+  const double delta = reg[0], gamma = reg[1];
+  SLPX_LDLT_CLOCK(0);
+  const MfCarve cv = mf_carve(t, m);
+  double* U = reinterpret_cast<double*>(smem_raw);
+  double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
+  double* invd = reinterpret_cast<double*>(smem_raw + cv.o_invd);
+  double* x = reinterpret_cast<double*>(smem_raw + cv.o_x);
+  const LdltFront* fronts = reinterpret_cast<const LdltFront*>(smem_raw + cv.o_fr);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
+  const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
+  const int32_t* src = reinterpret_cast<const int32_t*>(smem_raw + cv.o_src);
+  const uint16_t* col = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_col);
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(smem_raw + cv.o_flags);
+  const uint32_t* eout = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_out);
+  const uint32_t* cptr = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cptr);
+  const uint32_t* cidx = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cidx);
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cp);
+  const uint32_t* anc = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_anc);
+  int* s_cnt = reinterpret_cast<int*>(smem_raw + cv.o_cnt);
+  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
+  uint4* s_terms = reinterpret_cast<uint4*>(smem_raw + cv.o_terms);
+  auto g16 = [&](uint32_t o) { return reinterpret_cast<uint4*>(smem_raw + o); };
+
+  // ---- stage the plan ----
+  stage16<THREADS>(g16(cv.o_tab), reinterpret_cast<const uint4*>(Mf.tab + m.tab_off), q16(m.n_tab, 8), tid);
+  stage16<THREADS>(g16(cv.o_fr), reinterpret_cast<const uint4*>(Mf.fronts + m.front_off), m.n_front, tid);
+  stage16<THREADS>(g16(cv.o_lvl), reinterpret_cast<const uint4*>(Mf.lvl_ptr + t.lvl_off), q16(t.n_lvl + 1, 4), tid);
+  stage16<THREADS>(g16(cv.o_ext), reinterpret_cast<const uint4*>(Mf.ext + m.ext_off), q16(m.n_ext, 4), tid);
+  stage16<THREADS>(g16(cv.o_src), reinterpret_cast<const uint4*>((F.inline_kkt ? F.ent_vsrc : L.ent_src) + t.ent_off),
+                   q16(t.n_ent, 4), tid);
+  uint32_t n_terms16 = 0;
+  if (F.inline_kkt) {
+    const uint2 tt = F.task_terms[task_index];
+    n_terms16 = tt.y;
+    stage16<THREADS>(s_terms, F.terms + tt.x, tt.y, tid);
+  }
+  stage16<THREADS>(g16(cv.o_col), reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), q16(t.n_ent, 8), tid);
+  stage16<THREADS>(g16(cv.o_flags), reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), q16(t.n_ent, 16), tid);
+  stage16<THREADS>(g16(cv.o_out), reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), q16(t.n_ent, 4), tid);
+  stage16<THREADS>(g16(cv.o_cptr), reinterpret_cast<const uint4*>(Mf.contrib_ptr + m.contrib_ptr_off), q16(t.n_ent + 1, 4), tid);
+  stage16<THREADS>(g16(cv.o_cidx), reinterpret_cast<const uint4*>(Mf.contrib_idx + m.contrib_off), q16(m.n_contrib_idx, 4), tid);
+  stage16<THREADS>(g16(cv.o_cp), reinterpret_cast<const uint4*>(L.col_perm + t.col_off), q16(t.n_col, 4), tid);
+  stage16<THREADS>(g16(cv.o_anc), reinterpret_cast<const uint4*>(Mf.anc + m.anc_off), q16(m.n_anc, 4), tid);
+  // the back-substitution rows this task owns (BacksubFuse), behind the KKT terms and their products
+  const uint32_t n_terms = n_terms16 * 4u / 3u;
+  double* tprod = reinterpret_cast<double*>(s_terms + n_terms16);
+  uint4* s_bs = reinterpret_cast<uint4*>(smem_raw + mf_align16(cv.o_terms + 16u * n_terms16 + 8u * n_terms));
+  uint4 bs_task = uint4{0, 0, 0, 0};
+  if (B.on) {
+    bs_task = B.task_plan[task_index];
+    stage16<THREADS>(s_bs, B.plan + bs_task.x, bs_task.y, tid);
+  }
+  if (tid < 4) s_cnt[tid] = 0;
+  if (tid == 0) {
+    *s_minp = 0x7ff0000000000000ull;  // +inf
+    arena[0] = 0.0;
+    arena[1] = 0.0;
+    x[t.n_col + m.n_anc] = 1.0;
+  }
+  __syncthreads();
+  SLPX_LDLT_CLOCK(1);
+
+  // ---- matrix values (ldlt_factor_body) ----
+  if (!F.inline_kkt) {
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const int32_t s0 = src[i];
+      const double* base = (flags[i] & 4) ? rhs : lhs;
+      U[i] = s0 >= 0 ? base[s0] : 0.0;
+    }
+  } else {
+    const double mu = F.mu[0];
+    const KktTerm* terms = reinterpret_cast<const KktTerm*>(s_terms);
+    const uint32_t span = n_terms > t.n_ent ? n_terms : t.n_ent;
+    for (uint32_t k = tid; k < span; k += THREADS) {
+      const int w = k < t.n_ent ? src[k] : -1;
+      const double v = w >= 0 ? F.V[w & 0x3fffffff] : 0.0;
+      const bool on = k < n_terms;
+      const KktTermLoads tl = kkt_term_fetch(on ? terms[k] : KktTerm{0, 0, 0}, on, F.V, F.s, F.y, F.z);
+      if (k < t.n_ent && w >= -1) U[k] = (w & 0x40000000) && w >= 0 ? -v : v;
+      if (on) tprod[k] = kkt_term_product(tl, mu);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const int w = src[i];
+      if (w < -1) {
+        const uint32_t code = static_cast<uint32_t>(-(w + 2));
+        U[i] = kkt_terms_sum(terms, tprod, code & 0xfffffu, code >> 20, (flags[i] & 4) != 0);
+      }
+    }
+    if (F.store_lhs != nullptr) {
+      __syncthreads();
+      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+        const int32_t s0 = L.ent_src[t.ent_off + i];
+        if (s0 >= 0) ((flags[i] & 4) ? F.store_rhs : F.store_lhs)[s0] = U[i];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- regularization + update blocks of child tasks (slots: ldlt_factor_body) ----
+  for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+    const uint8_t fl = flags[i];
+    const uint32_t cb = cptr[i], ce = cptr[i + 1];
+    if (!(fl & 1) && cb == ce) continue;
+    double acc = U[i];
+    if (fl & 1) acc += (fl & 2) ? -gamma : delta;
+    for (uint32_t c = cb; c < ce; c += 4) {
+      double* p0 = &contrib[cidx[c]];
+      double* p1 = &contrib[cidx[c + 1 < ce ? c + 1 : c]];
+      double* p2 = &contrib[cidx[c + 2 < ce ? c + 2 : c]];
+      double* p3 = &contrib[cidx[c + 3 < ce ? c + 3 : c]];
+      double v0, v1, v2, v3;
+      unsigned int spins = 0;
+      for (;;) {
+        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v3 = __hip_atomic_load(p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!slot_is_empty(v0) && !slot_is_empty(v1) && !slot_is_empty(v2) && !slot_is_empty(v3)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
+          atomicAdd(&stats[0].n_bad, 1 << 20);
+          break;
+        }
+      }
+      const double armed = __longlong_as_double(static_cast<long long>(kSlotEmpty));
+      __hip_atomic_store(p0, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc -= v0;
+      if (c + 1 < ce) {
+        __hip_atomic_store(p1, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc -= v1;
+      }
+      if (c + 2 < ce) {
+        __hip_atomic_store(p2, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc -= v2;
+      }
+      if (c + 3 < ce) {
+        __hip_atomic_store(p3, armed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc -= v3;
+      }
+    }
+    U[i] = acc;
+  }
+  __syncthreads();
+  SLPX_LDLT_CLOCK(2);
+
+  // ---- levels: a wave per front ----
+  {
+    uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
+    for (uint32_t l = 0; l < t.n_lvl; ++l) {
+      const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];
+      for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+        const LdltFront f = fronts[q];
+        mf_front(cv.o_tab + 2u * f.tab, f.w, f.nr, f.nch, f.n_s, f.flags & 1u, cv.o_invd + 8u * f.col0, ext + f.ext, contrib,
+                 lane);
+      }
+      __syncthreads();
+      beg = end;
+      end = next_end;
+    }
+  }
+  SLPX_LDLT_CLOCK(3);
+  SLPX_LDLT_CLOCK(4);
+  FactorKeep keep{U, invd, col, flags, eout, s_cnt, s_minp};
+  auto exit_and_count = [&] {
+    ldlt_factor_exit<THREADS>(keep, t, 0, Lx, D, zv, stats);
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
+      const unsigned int old = __hip_atomic_fetch_add(Mf.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == Mf.n_tasks) {
+        __hip_atomic_store(Mf.exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (B.stats_host != nullptr) publish_stats(B, true);
+      }
+    }
+  };
+  if (!top) exit_and_count();  // (its store acknowledgements come in while the task waits for its ancestors)
+  SLPX_LDLT_CLOCK(5);
+
+  // ---- backward solve on what the factorization left in LDS ----
+  // this lane's row of the back-substitution (ldlt_bwd_run): everything but p is known now
+  constexpr int kBsPre = 4;
+  const BsRow* bs_rows = reinterpret_cast<const BsRow*>(s_bs);
+  const BsTerm* bs_terms = reinterpret_cast<const BsTerm*>(s_bs + bs_task.w);
+  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z && t.round == 0;
+  BsRow bs_row = BsRow{0, 0};
+  double bs_a[kBsPre], bs_p[kBsPre], bs_s = 1.0, bs_z = 0.0, bs_ci = 0.0;
+  uint32_t bs_ref[kBsPre];
+#pragma unroll
+  for (int k = 0; k < kBsPre; ++k) {
+    bs_a[k] = 0.0;
+    bs_p[k] = 0.0;
+    bs_ref[k] = 0;
+  }
+  if (bs_mine) {
+    bs_row = bs_rows[tid];
+    const uint32_t first = bs_row.terms & 0xfffffu, cnt = bs_row.terms >> 20;
+    bs_s = B.s[bs_row.r];
+    bs_z = B.z[bs_row.r];
+    bs_ci = B.V[B.off_ci + bs_row.r];
+#pragma unroll
+    for (int k = 0; k < kBsPre; ++k)
+      if (static_cast<uint32_t>(k) < cnt) {
+        const BsTerm bt = bs_terms[first + k];
+        bs_a[k] = B.V[bt.a];
+        bs_ref[k] = bt.ref;
+      }
+  }
+  SLPX_LDLT_CLOCK(17);
+  // x of the ancestor tasks' rows the fronts reach: handed over through the values themselves
+  for (uint32_t a = tid; a < m.n_anc; a += THREADS) x[t.n_col + a] = slot_read(&xg[anc[a]]);
+  if (bs_mine) {
+#pragma unroll
+    for (int k = 0; k < kBsPre; ++k)
+      if (bs_ref[k] & 0x80000000u) bs_p[k] = slot_read(&xg[bs_ref[k] & 0x7fffffffu]);
+  }
+  __syncthreads();
+  SLPX_LDLT_CLOCK(18);
+  {
+    uint32_t end = lvl[t.n_lvl], beg = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
+    for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+      const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0];
+      for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+        const LdltFront f = fronts[q];
+        const uint32_t stride = 2u * f.w * (1u + f.nch);
+        const uint32_t xr = cv.o_tab + 2u * f.tab + f.nr * stride + static_cast<uint32_t>(f.n_s) * 2u * (3u + f.nch);
+        mf_solve_front(xr, 8u * f.base0, f.w, f.nr, cv.o_invd + 8u * f.col0, cv.o_x + 8u * f.col0, lane);
+      }
+      __syncthreads();
+      end = beg;
+      beg = next_beg;
+    }
+  }
+  SLPX_LDLT_CLOCK(19);
+  // the descendants wait for x alone: hand it over before anything else goes out
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS)
+    coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
+  if (B.on) {
+    const double mu = B.mu[0];
+    auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
+    for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
+      const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
+      const BsRow row = ahead ? bs_row : bs_rows[j];
+      const uint32_t first = row.terms & 0xfffffu, cnt = row.terms >> 20;
+      double aipx = 0.0, s_r = bs_s, z_r = bs_z, ci_r = bs_ci;
+      uint32_t k0 = 0;
+      if (ahead) {
+#pragma unroll
+        for (int k = 0; k < kBsPre; ++k)
+          if (static_cast<uint32_t>(k) < cnt)
+            aipx = backsub_dot(aipx, bs_a[k], (bs_ref[k] & 0x80000000u) ? bs_p[k] : x[bs_ref[k]]);
+        k0 = kBsPre;
+      } else {  // (nothing was fetched ahead)
+        s_r = B.s[row.r];
+        z_r = B.z[row.r];
+        ci_r = B.V[B.off_ci + row.r];
+      }
+      for (uint32_t k = k0; k < cnt; ++k) {
+        const BsTerm bt = bs_terms[first + k];
+        aipx = backsub_dot(aipx, B.V[bt.a], p_of(bt.ref));
+      }
+      backsub_row(ci_r, s_r, z_r, mu, aipx, &B.ps[row.r], &B.pz[row.r]);
+    }
+  }
+  SLPX_LDLT_CLOCK(20);
+  if (top) exit_and_count();
+}
+
+}  // namespace slpx

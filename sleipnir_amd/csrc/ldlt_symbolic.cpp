@@ -768,6 +768,254 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     P.tasks.push_back(T);
   }
 
+  // ---- multifrontal plan (LdltFront, ldlt_symbolic.hpp) -------------------------------------------
+  if (opt.multifrontal) {
+    struct Front {
+      std::vector<int32_t> cols, R;  // permuted indices, ascending
+      int task = 0, level = 0, parent = -1;
+      uint32_t nr = 0, n_s = 0, s_base = 0;  // s_base: doubles into the arena
+      std::vector<int> kids;
+    };
+    std::vector<Front> fronts;
+    std::vector<int32_t> front_of(n, -1);
+    std::vector<std::vector<int>> task_fronts(ntasks);  // level order
+    bool ok = true;
+    for (int t = 0; t < ntasks && ok; ++t)
+      for (int32_t j : tcols[t].cols) {
+        if (sn_pos[j] != 0) continue;
+        Front f;
+        f.cols = sn_cols[sn_of[j]];
+        f.R = Lcol[f.cols.back()];
+        f.task = t;
+        f.level = tlevel[j];
+        f.nr = static_cast<uint32_t>(f.cols.size() + f.R.size() + 1);
+        const uint32_t r = static_cast<uint32_t>(f.R.size());
+        f.n_s = r * (r + 1) / 2 + r;
+        if (f.nr > kSnRowsMax || f.cols.size() > kSnWidthMax || f.n_s > 0xffffu) ok = false;
+        for (int32_t c : f.cols) front_of[c] = static_cast<int>(fronts.size());
+        task_fronts[t].push_back(static_cast<int>(fronts.size()));
+        fronts.push_back(std::move(f));
+      }
+    for (size_t fi = 0; fi < fronts.size() && ok; ++fi) {
+      Front& f = fronts[fi];
+      const int32_t pc = P.parent[f.cols.back()];
+      if (pc >= 0 && task_of[pc] == f.task && !f.R.empty()) {
+        f.parent = front_of[pc];
+        fronts[f.parent].kids.push_back(static_cast<int>(fi));
+      }
+    }
+    // update slots between tasks: one per entry of a root front's block
+    std::vector<std::vector<std::vector<uint32_t>>> mcontrib(ntasks);
+    for (int t = 0; t < ntasks; ++t) mcontrib[t].resize(task_nent[t]);
+    auto entry_of = [&](int32_t row, int32_t col) -> uint32_t {  // row = -1: the right-hand-side row
+      if (row == col) return diag_ent[col];
+      if (row < 0) return bent[col];
+      const int32_t* b = P.Li.data() + P.Lp[col];
+      const int32_t* e = P.Li.data() + P.Lp[col + 1];
+      const int32_t* f = std::lower_bound(b, e, row);
+      if (f == e || *f != row) throw std::runtime_error("ldlt: a front's update block has an entry outside the pattern of L");
+      return lent[f - P.Li.data()];
+    };
+    P.mf_tasks.assign(ntasks, LdltMfTask{});
+    for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
+      const int t = torder[ti];
+      const LdltTask& T = P.tasks[ti];
+      LdltMfTask& M = P.mf_tasks[ti];
+      const auto& fl = task_fronts[t];
+      // ---- S blocks: a block lives from its front's level to its parent's; first fit over the free gaps
+      uint32_t arena = 2;  // [0] = 0.0, [1] = scratch
+      {
+        struct Blk { uint32_t off, len; int until; };
+        std::vector<Blk> live;
+        for (int fi : fl) {
+          Front& f = fronts[fi];
+          if (f.parent < 0 || f.n_s == 0) continue;  // root fronts write to the update slots
+          const int lvl = f.level, until = fronts[f.parent].level;
+          live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < lvl; }), live.end());
+          std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+          uint32_t at = 2;
+          for (const Blk& b : live) {
+            if (at + f.n_s <= b.off) break;
+            at = std::max(at, b.off + b.len);
+          }
+          f.s_base = at;
+          live.push_back({at, f.n_s, until});
+          arena = std::max(arena, at + f.n_s);
+        }
+      }
+      M.arena = arena;
+      // ---- rows of ancestor tasks the solve reaches
+      std::vector<int32_t> anc;
+      for (int fi : fl)
+        for (int32_t i : fronts[fi].R)
+          if (task_of[i] != t) anc.push_back(i);
+      std::sort(anc.begin(), anc.end());
+      anc.erase(std::unique(anc.begin(), anc.end()), anc.end());
+      M.anc_off = static_cast<uint32_t>(P.mf_anc.size());
+      M.n_anc = static_cast<uint32_t>(anc.size());
+      for (int32_t i : anc) P.mf_anc.push_back(static_cast<uint32_t>(i));
+      while (P.mf_anc.size() % 4) P.mf_anc.push_back(0);
+      // ---- the 64 KB every table offset must reach
+      const uint32_t off_arena = 8u * T.n_ent, off_invd = off_arena + 8u * arena, off_x = off_invd + 8u * T.n_col;
+      const uint32_t reach = off_x + 8u * (T.n_col + M.n_anc + 1u);
+      if (reach > 0x10000u) {
+        ok = false;
+        break;
+      }
+      const uint16_t kZero = static_cast<uint16_t>(off_arena), kScratch = static_cast<uint16_t>(off_arena + 8u);
+      auto s_addr = [&](const Front& f, uint32_t e) { return static_cast<uint16_t>(off_arena + 8u * (f.s_base + e)); };
+      auto u_addr = [&](uint32_t ent) { return static_cast<uint16_t>(8u * ent); };
+      // ---- fronts and their tables
+      M.front_off = static_cast<uint32_t>(P.mf_fronts.size());
+      M.n_front = static_cast<uint32_t>(fl.size());
+      M.tab_off = static_cast<uint32_t>(P.mf_tab.size());
+      M.ext_off = static_cast<uint32_t>(P.mf_ext.size());
+      while (P.mf_lvl_ptr.size() < T.lvl_off) P.mf_lvl_ptr.push_back(0);
+      int cur_level = -1;
+      uint32_t n_ext = 0;
+      for (size_t q = 0; q < fl.size(); ++q) {
+        const Front& f = fronts[fl[q]];
+        if (f.level != cur_level) {
+          P.mf_lvl_ptr.push_back(static_cast<uint32_t>(q));
+          cur_level = f.level;
+        }
+        const uint32_t w = static_cast<uint32_t>(f.cols.size()), r = static_cast<uint32_t>(f.R.size()), nr = f.nr;
+        const uint32_t base0 = diag_ent[f.cols[0]];
+        auto tr = [&](uint32_t c, uint32_t row) { return base0 + c * nr - (c * (c - 1)) / 2 + (row - c); };
+        // where the rows of each child land in this front
+        std::vector<std::vector<uint16_t>> piv(static_cast<size_t>(nr) * w), upd(f.n_s);
+        for (int ki : f.kids) {
+          const Front& k = fronts[ki];
+          const uint32_t rk = static_cast<uint32_t>(k.R.size());
+          std::vector<uint32_t> to(rk + 1);
+          for (uint32_t a = 0; a < rk; ++a) {
+            const int32_t i = k.R[a];
+            auto ic = std::lower_bound(f.cols.begin(), f.cols.end(), i);
+            if (ic != f.cols.end() && *ic == i) {
+              to[a] = static_cast<uint32_t>(ic - f.cols.begin());
+            } else {
+              auto ir = std::lower_bound(f.R.begin(), f.R.end(), i);
+              if (ir == f.R.end() || *ir != i) throw std::runtime_error("ldlt: a child front's row is not in its parent front");
+              to[a] = w + static_cast<uint32_t>(ir - f.R.begin());
+            }
+          }
+          to[rk] = nr - 1;
+          for (uint32_t a = 0; a <= rk; ++a)
+            for (uint32_t b = 0; b < rk && b <= a; ++b) {
+              const uint32_t ta = to[a], tb = to[b];
+              const uint16_t src = s_addr(k, a * (a + 1) / 2 + b);
+              if (tb < w) piv[static_cast<size_t>(ta) * w + tb].push_back(src);
+              else upd[(ta - w) * (ta - w + 1) / 2 + (tb - w)].push_back(src);
+            }
+        }
+        uint32_t nch = 0;
+        for (auto& v : piv) nch = std::max<uint32_t>(nch, static_cast<uint32_t>(v.size()));
+        for (auto& v : upd) nch = std::max<uint32_t>(nch, static_cast<uint32_t>(v.size()));
+        if (nch > 255u) {
+          ok = false;
+          break;
+        }
+        LdltFront F{};
+        F.tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
+        F.base0 = static_cast<uint16_t>(base0);
+        F.col0 = static_cast<uint16_t>(lcol[f.cols[0]]);
+        F.w = static_cast<uint8_t>(w);
+        F.nr = static_cast<uint8_t>(nr);
+        F.nch = static_cast<uint8_t>(nch);
+        F.n_s = static_cast<uint16_t>(f.n_s);
+        const bool root = f.parent < 0;
+        F.flags = root ? 1 : 0;
+        F.ext = static_cast<uint16_t>(n_ext);
+        if (root && n_ext + f.n_s > 0xffffu) {
+          ok = false;
+          break;
+        }
+        // pivot table: rows x [k][c]
+        for (uint32_t row = 0; row < nr; ++row)
+          for (uint32_t k = 0; k <= nch; ++k)
+            for (uint32_t c = 0; c < w; ++c) {
+              uint16_t v;
+              if (k == 0) v = row >= c ? u_addr(tr(c, row)) : kScratch;
+              else v = (row >= c && k - 1 < piv[static_cast<size_t>(row) * w + c].size()) ? piv[static_cast<size_t>(row) * w + c][k - 1] : kZero;
+              P.mf_tab.push_back(v);
+            }
+        // update table: out, U(a, 0), U(b, 0), children
+        for (uint32_t a = 0; a <= r; ++a)
+          for (uint32_t b = 0; b < r && b <= a; ++b) {
+            const uint32_t e = a * (a + 1) / 2 + b;
+            P.mf_tab.push_back(root ? static_cast<uint16_t>(e) : s_addr(f, e));
+            P.mf_tab.push_back(u_addr(tr(0, w + a)));
+            P.mf_tab.push_back(u_addr(tr(0, w + b)));
+            for (uint32_t k = 0; k < nch; ++k) P.mf_tab.push_back(k < upd[e].size() ? upd[e][k] : kZero);
+            if (root) {
+              const int32_t gb = f.R[b], ga = a < r ? f.R[a] : -1;
+              const int tj = task_of[gb];
+              const uint32_t slot = P.mf_n_contrib++;
+              mcontrib[tj][entry_of(ga, gb)].push_back(slot);
+              P.mf_ext.push_back(slot);
+              ++n_ext;
+            }
+          }
+        // solve table: x of the rows of R
+        for (uint32_t a = 0; a < r; ++a) {
+          const int32_t i = f.R[a];
+          uint32_t xi;
+          if (task_of[i] == t) xi = static_cast<uint32_t>(lcol[i]);
+          else xi = T.n_col + static_cast<uint32_t>(std::lower_bound(anc.begin(), anc.end(), i) - anc.begin());
+          P.mf_tab.push_back(static_cast<uint16_t>(off_x + 8u * xi));
+        }
+        P.mf_fronts.push_back(F);
+        P.mf_max_nch = std::max(P.mf_max_nch, nch);
+        P.mf_max_front_rows = std::max(P.mf_max_front_rows, nr);
+      }
+      if (!ok) break;
+      P.mf_lvl_ptr.push_back(static_cast<uint32_t>(fl.size()));
+      if (P.mf_lvl_ptr.size() != T.lvl_off + T.n_lvl + 1)
+        throw std::runtime_error("ldlt: front levels out of step with the column levels");
+      M.n_ext = n_ext;
+      M.n_tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
+      while (P.mf_tab.size() % 8) P.mf_tab.push_back(0);
+      while (P.mf_ext.size() % 4) P.mf_ext.push_back(0);
+      while (P.mf_fronts.size() % 1) P.mf_fronts.push_back(LdltFront{});
+    }
+    // update slots per receiving entry (the tasks' entries are numbered in emission order)
+    for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
+      const int t = torder[ti];
+      LdltMfTask& M = P.mf_tasks[ti];
+      while (P.mf_contrib_ptr.size() % 4) P.mf_contrib_ptr.push_back(0);
+      M.contrib_ptr_off = static_cast<uint32_t>(P.mf_contrib_ptr.size());
+      M.contrib_off = static_cast<uint32_t>(P.mf_contrib_idx.size());
+      uint32_t count = 0;
+      for (uint32_t e = 0; e < task_nent[t]; ++e) {
+        P.mf_contrib_ptr.push_back(count);
+        for (uint32_t s : mcontrib[t][e]) P.mf_contrib_idx.push_back(s);
+        count += static_cast<uint32_t>(mcontrib[t][e].size());
+      }
+      P.mf_contrib_ptr.push_back(count);
+      M.n_contrib_idx = count;
+      while (P.mf_contrib_idx.size() % 4) P.mf_contrib_idx.push_back(0);
+    }
+    P.mf = ok;
+    for (int k = 0; k < 16; ++k) {
+      P.mf_tab.push_back(0);
+      P.mf_ext.push_back(0);
+      P.mf_contrib_ptr.push_back(0);
+      P.mf_contrib_idx.push_back(0);
+      P.mf_anc.push_back(0);
+      P.mf_lvl_ptr.push_back(0);
+      P.mf_fronts.push_back(LdltFront{});
+    }
+    if (std::getenv("SLPX_LDLT_VERBOSE")) {
+      size_t tab = 0, arena = 0;
+      for (auto& M : P.mf_tasks) {
+        tab = std::max<size_t>(tab, M.n_tab);
+        arena = std::max<size_t>(arena, M.arena);
+      }
+      std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u)\n",
+                   ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib);
+    }
+  }
+
   // structural zero pivots of the unregularized matrix: a diagonal of the (2,2)
   // block (no lhs source other than the forced 0) that no earlier column updates
   for (int j = 0; j < n; ++j)

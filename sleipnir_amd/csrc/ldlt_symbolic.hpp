@@ -79,6 +79,41 @@ struct LdltSn {
 constexpr uint32_t kSnWidthMax = 8;  // longer chains are cut (a lane keeps a row of this many doubles in registers)
 constexpr uint32_t kSnRowsMax = 64;   // rows of the trapezoid (w + |R| + 1): one lane each; bigger ones stay single columns
 
+// ---------------------------------------------------------------------------------------------
+// Multifrontal plan (ldlt_mf_kernels.h): every supernode of a task — lone columns included — is a
+// dense FRONT: rows = [its w columns | the common structure R below them | the right-hand-side
+// row], nr = w + r + 1; its first w columns are the LdltSn trapezoid in the task's entry array.
+// What the pair lists did entry by entry (left-looking), fronts do block by block: a front's update
+// block S (rows R + rhs, columns R; packed, entry (a, b) at a (a + 1) / 2 + b) is handed to its
+// parent front inside the task, whose entries take at most `nch` such values each, or — a front
+// whose parent column lies in another task — straight to that task's update slots.  Everything a
+// lane needs is a precomputed 16-bit BYTE offset into the first 64 KB of the task's LDS:
+//   [ U: n_ent doubles | arena: 0.0, a scratch double, the S blocks | 1/d: n_col | x: n_col + n_anc + 1 ]
+// Tables of a front in mf_tab (16-bit words), at LdltFront::tab:
+//   pivot table   nr rows x (1 + nch) x w : [k][c], k = 0 the entry of U itself (rows above the diagonal:
+//                 the scratch double), k >= 1 the k-th child value (none: the 0.0)
+//   update table  n_s entries x (3 + nch) : out (the S slot), U(row a, column 0), U(row b, column 0), children
+//   solve table   r words                 : where x of row t of R lives (own column, or an ancestor task's row)
+// ---------------------------------------------------------------------------------------------
+struct LdltFront {
+  uint32_t tab;      // first word of its tables in the task's slice of mf_tab
+  uint16_t base0;    // local entry of the first column's diagonal
+  uint16_t col0;     // local column of the first column
+  uint8_t w, nr, nch, flags;  // flags bit 0: its update block leaves the task (mf_ext); bit 1: matrix-core path
+  uint16_t n_s;      // entries of its update block: r (r + 1) / 2 + r
+  uint16_t ext;      // first slot of its block in the task's slice of mf_ext (flags bit 0)
+};
+static_assert(sizeof(LdltFront) == 16, "staged into LDS as one 16-byte group");
+struct LdltMfTask {
+  uint32_t front_off, n_front;   // slice of mf_fronts (level order; mf_lvl_ptr shares LdltTask::lvl_off)
+  uint32_t tab_off, n_tab;       // slice of mf_tab, 16-bit words (padded to 8)
+  uint32_t ext_off, n_ext;       // slice of mf_ext (padded to 4)
+  uint32_t contrib_ptr_off;      // mf_contrib_ptr: n_ent + 1 entries
+  uint32_t contrib_off, n_contrib_idx;  // slice of mf_contrib_idx (padded to 4)
+  uint32_t anc_off, n_anc;       // slice of mf_anc: rows of ancestor tasks its fronts reach (permuted indices)
+  uint32_t arena;                // doubles: 0.0, scratch, update blocks
+};
+
 struct LdltSolveItem {
   uint32_t lpos;  // index into Lx
   uint32_t ref;   // fwd: local column of y_k; bwd: local column (bit31 clear) or global permuted row (bit31 set)
@@ -140,6 +175,18 @@ struct LdltPlan {
   int critical_levels = 0;                // sum over rounds of the deepest task's level count
   std::vector<int32_t> sn_width_hist;     // [w] = supernodes of that width
 
+  // ---- multifrontal plan (LdltFront above); mf == false: not built, or a task does not fit its addressing ----
+  bool mf = false;
+  std::vector<LdltMfTask> mf_tasks;       // in step with `tasks`
+  std::vector<LdltFront> mf_fronts;
+  std::vector<uint32_t> mf_lvl_ptr;       // per task n_lvl + 1 first fronts (relative), in step with lvl_ptr
+  std::vector<uint16_t> mf_tab;
+  std::vector<uint32_t> mf_ext;
+  std::vector<uint32_t> mf_contrib_ptr, mf_contrib_idx;
+  std::vector<uint32_t> mf_anc;
+  uint32_t mf_n_contrib = 0;
+  uint32_t mf_max_nch = 0, mf_max_front_rows = 0;
+
   // traffic model: factor = 12k + 16ℓ, solve = 32ℓ + 16 n
   int64_t factor_bytes = 0, solve_bytes = 0;
   int64_t flops = 0;  // 2 * number of pair products
@@ -172,6 +219,8 @@ struct LdltOptions {
   // retries with a sharper rule before it gives up on a column that does not fit a task.
   double hub_factor = 3.0;
   uint32_t hub_floor = 24;
+  // also build the multifrontal plan (LdltFront) next to the pair lists
+  bool multifrontal = false;
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

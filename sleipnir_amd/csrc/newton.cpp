@@ -49,6 +49,15 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
+    // one problem: the multifrontal step (ldlt_mf_kernels.h) — every supernode a dense front, so a chain
+    // of two columns already saves a level (the pair-list kernels' chain pass only paid from four)
+    if (opt.batch == 1 && lopt.supernodal) {
+      const char* env = std::getenv("SLPX_LDLT_MF");
+      if (env == nullptr || env[0] != '0') {
+        lopt.multifrontal = true;
+        lopt.min_supernode_width = 2;
+      }
+    }
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
     // One problem (or a handful: the same plan, so that a small batch and single problems agree to
     // the bit), smaller than the BASELINE horizon: smaller tasks (less plan to stage per

@@ -30,6 +30,10 @@ struct hc_handle {
   LdltPlan l;
   std::vector<double> scales, in_scale, V, lhs, rhs, Lx, D, contrib, scontrib, zv, xg, p, ps, pz;
   std::vector<double> z_factor;  // z left behind by the factorization (rhs carried as a row)
+  // multifrontal plan (SLPX_LDLT_MF=1): the update slots between tasks, and every task's first
+  // 64 KB of LDS as the factorization leaves it (the in-place backward solve reads U and 1/d there)
+  std::vector<double> mf_contrib;
+  std::vector<std::vector<double>> mf_lds;
   int stats[4] = {0, 0, 0, 0};
   double min_abs = 0.0;
 };
@@ -133,6 +137,11 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
   if (const char* env = std::getenv("SLPX_HOSTCHECK_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
+  if (const char* env = std::getenv("SLPX_LDLT_MF"))
+    if (env[0] != '0') {
+      lopt.multifrontal = true;
+      if (std::getenv("SLPX_SN_MIN_WIDTH") == nullptr) lopt.min_supernode_width = 2;
+    }
   h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);
@@ -142,6 +151,8 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   h->Lx.assign(std::max<int64_t>(1, h->l.nnzL), 0.0);
   h->D.assign(h->l.n, 0.0);
   h->contrib.assign(std::max<uint32_t>(1, h->l.n_contrib), 0.0);
+  h->mf_contrib.assign(std::max<uint32_t>(1, h->l.mf_n_contrib), 0.0);
+  h->mf_lds.assign(h->l.mf ? h->l.tasks.size() : 0, {});
   h->scontrib.assign(std::max<uint32_t>(1, h->l.n_scontrib), 0.0);
   h->zv.assign(h->l.n, 0.0);
   h->z_factor.assign(h->l.n, 0.0);
@@ -321,10 +332,137 @@ void hc_rhs(hc_handle* h, const double* s, const double* y, const double* z, dou
 void hc_set_rhs(hc_handle* h, const double* rhs) { std::copy(rhs, rhs + h->k.dim, h->rhs.begin()); }
 
 // stats_out: n_pos, n_neg, n_zero, n_bad, min|D|
+// The multifrontal plan (ldlt_symbolic.hpp: LdltFront) interpreted the way ldlt_mf_kernels.h runs
+// it: every table word is a byte offset into the task's first 64 KB of LDS.
+static void hc_factor_mf(hc_handle* h, double delta, double gamma) {
+  const LdltPlan& L = h->l;
+  for (int r = 0; r < L.n_rounds; ++r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      const LdltMfTask& M = L.mf_tasks[ti];
+      const uint32_t off_arena = t.n_ent, off_invd = off_arena + M.arena, off_x = off_invd + t.n_col;
+      std::vector<double>& lds = h->mf_lds[ti];
+      lds.assign(off_x + t.n_col + M.n_anc + 1, 0.0);
+      auto at = [&](uint16_t byte_off) -> double& { return lds[byte_off / 8u]; };
+      const uint32_t* cptr = L.mf_contrib_ptr.data() + M.contrib_ptr_off;
+      const uint32_t* cidx = L.mf_contrib_idx.data() + M.contrib_off;
+      for (uint32_t i = 0; i < t.n_ent; ++i) {
+        const uint32_t e = t.ent_off + i;
+        const int32_t src = L.ent_src[e];
+        const uint8_t fl = L.ent_flags[e];
+        double acc = src >= 0 ? ((fl & 4) ? h->rhs[src] : h->lhs[src]) : 0.0;
+        if (fl & 1) acc += (fl & 2) ? -gamma : delta;
+        for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= h->mf_contrib[cidx[c]];
+        lds[i] = acc;
+      }
+      const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
+      const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
+      const uint32_t* ext = L.mf_ext.data() + M.ext_off;
+      for (uint32_t l = 0; l < t.n_lvl; ++l) {
+        // the fronts of a level run concurrently on the device: they may only read what earlier levels wrote
+        for (uint32_t q = lvl[l]; q < lvl[l + 1]; ++q) {
+          const LdltFront& F = L.mf_fronts[M.front_off + q];
+          const uint32_t w = F.w, nr = F.nr, nch = F.nch, rr = nr - w - 1;
+          const uint16_t* piv = tab0 + F.tab;
+          const uint16_t* upd = piv + static_cast<size_t>(nr) * (1 + nch) * w;
+          std::vector<double> a(static_cast<size_t>(nr) * w, 0.0), inv(w);
+          for (uint32_t row = 0; row < nr; ++row)
+            for (uint32_t c = 0; c < w && c <= row; ++c) {
+              double v = 0.0;
+              for (uint32_t k = 0; k <= nch; ++k) v += at(piv[(static_cast<size_t>(row) * (1 + nch) + k) * w + c]);
+              a[static_cast<size_t>(row) * w + c] = v;
+            }
+          for (uint32_t c = 0; c < w; ++c) {
+            inv[c] = 1.0 / a[static_cast<size_t>(c) * w + c];
+            for (uint32_t row = c + 1; row < nr; ++row) {
+              const double lc = a[static_cast<size_t>(row) * w + c] * inv[c];
+              for (uint32_t j = c + 1; j < w && j <= row; ++j) a[static_cast<size_t>(row) * w + j] -= lc * a[static_cast<size_t>(j) * w + c];
+            }
+          }
+          for (uint32_t row = 0; row < nr; ++row)
+            for (uint32_t c = 0; c < w && c <= row; ++c) at(piv[(static_cast<size_t>(row) * (1 + nch)) * w + c]) = a[static_cast<size_t>(row) * w + c];
+          for (uint32_t c = 0; c < w; ++c) lds[off_invd + F.col0 + c] = inv[c];
+          for (uint32_t e = 0; e < F.n_s; ++e) {
+            const uint16_t* row = upd + static_cast<size_t>(e) * (3 + nch);
+            double v = 0.0;
+            for (uint32_t k = 0; k < nch; ++k) v += at(row[3 + k]);
+            for (uint32_t c = 0; c < w; ++c) {
+              const uint32_t coff = c * nr - (c * (c - 1)) / 2 - c;  // column c against column 0, same row
+              v -= (lds[row[1] / 8u + coff] * inv[c]) * lds[row[2] / 8u + coff];
+            }
+            if (F.flags & 1) h->mf_contrib[ext[F.ext + row[0]]] = -v;
+            else at(row[0]) = v;
+          }
+          (void)rr;
+        }
+      }
+      for (uint32_t i = 0; i < t.n_ent; ++i) {
+        const uint32_t e = t.ent_off + i;
+        const double u = lds[i];
+        if (L.ent_flags[e] & 1) {
+          h->D[L.ent_out[e]] = u;
+          const double eps = 2.220446049250313e-16;
+          if (u > eps) ++h->stats[0];
+          else if (u < -eps) ++h->stats[1];
+          else ++h->stats[2];
+          if (u == 0.0 || !std::isfinite(u)) ++h->stats[3];
+          else h->min_abs = std::min(h->min_abs, std::fabs(u));
+        } else if (L.ent_flags[e] & 4) {
+          h->z_factor[L.ent_out[e]] = u * lds[off_invd + L.ent_col[e]];
+        } else {
+          h->Lx[L.ent_out[e]] = u * lds[off_invd + L.ent_col[e]];
+        }
+      }
+    }
+}
+
+// backward substitution on what hc_factor_mf left in every task's LDS image (the fused step's solve)
+static void hc_backward_mf(hc_handle* h, double* p_out) {
+  const LdltPlan& L = h->l;
+  for (int r = L.n_rounds - 1; r >= 0; --r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      const LdltMfTask& M = L.mf_tasks[ti];
+      const uint32_t off_invd = t.n_ent + M.arena, off_x = off_invd + t.n_col;
+      std::vector<double>& lds = h->mf_lds[ti];
+      for (uint32_t a = 0; a < M.n_anc; ++a) lds[off_x + t.n_col + a] = h->xg[L.mf_anc[M.anc_off + a]];
+      const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
+      const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
+      for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l)
+        for (uint32_t q = lvl[l]; q < lvl[l + 1]; ++q) {
+          const LdltFront& F = L.mf_fronts[M.front_off + q];
+          const uint32_t w = F.w, nr = F.nr, nch = F.nch, rr = nr - w - 1;
+          const uint16_t* xr = tab0 + F.tab + static_cast<size_t>(nr) * (1 + nch) * w + static_cast<size_t>(F.n_s) * (3 + nch);
+          auto U = [&](uint32_t row, uint32_t c) { return lds[F.base0 + c * nr - (c * (c - 1)) / 2 + (row - c)]; };
+          for (int c = static_cast<int>(w) - 1; c >= 0; --c) {
+            double dot = 0.0;
+            for (uint32_t a = 0; a < rr; ++a) dot += U(w + a, c) * lds[xr[a] / 8u];
+            for (uint32_t k = c + 1; k < w; ++k) dot += U(k, c) * lds[off_x + F.col0 + k];
+            lds[off_x + F.col0 + c] = (U(nr - 1, c) - dot) * lds[off_invd + F.col0 + c];
+          }
+        }
+      for (uint32_t i = 0; i < t.n_col; ++i) {
+        const uint32_t pj = L.col_perm[t.col_off + i];
+        h->xg[pj] = lds[off_x + i];
+        h->p[L.perm[pj]] = lds[off_x + i];
+      }
+    }
+  if (p_out) std::copy(h->p.begin(), h->p.end(), p_out);
+}
+
 void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* stats_out) {
   const LdltPlan& L = h->l;
   std::memset(h->stats, 0, sizeof(h->stats));
   h->min_abs = INFINITY;
+  if (L.mf) {
+    hc_factor_mf(h, delta, gamma);
+    if (D_out) std::copy(h->D.begin(), h->D.end(), D_out);
+    if (stats_out) {
+      for (int i = 0; i < 4; ++i) stats_out[i] = h->stats[i];
+      stats_out[4] = h->min_abs;
+    }
+    return;
+  }
   for (int r = 0; r < L.n_rounds; ++r)
     for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
       const LdltTask& t = L.tasks[ti];
@@ -406,6 +544,10 @@ static void hc_backward(hc_handle* h, double* p_out);
 // backward substitution only, on the z the factorization left behind (the path the
 // Newton step takes on the device)
 void hc_solve_after_factor(hc_handle* h, double* p_out) {
+  if (h->l.mf) {
+    hc_backward_mf(h, p_out);
+    return;
+  }
   h->zv = h->z_factor;
   hc_backward(h, p_out);
 }

@@ -199,7 +199,10 @@ def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=
     errs["po_vs_true"] = cases.max_rel(po, p_true)
     if verbose:
         print(case, "distance to the refined solution: product %.2e  oracle %.2e" % (errs["p_vs_true"], errs["po_vs_true"]))
-    assert errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"]), (errs["p_vs_true"], errs["po_vs_true"])
+    # (or, where the oracle's rounding happens to land unusually close: three orders of magnitude
+    # inside the forward-error bound kappa x backward error of the product's own residual)
+    assert errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"], 1e-3 * kappa * errs["resid"]), (
+        errs["p_vs_true"], errs["po_vs_true"], kappa, errs["resid"])
     # p_s = (c_i - s) + A_i p_x, p_z = mu/s - z - Sigma p_s (interior_point.hpp:479-480):
     # errors of p carried through |A_i|_inf and |Sigma|_inf
     pmax = max(1.0, float(np.max(np.abs(po))))
@@ -300,7 +303,10 @@ def check_timed_step(system, op, state, b=0, tol_kkt=1e-10, tol_resid=1e-10, tol
     p_true = cases.refined_solution(lcp, lri, Kreg, rhs)
     errs["p_vs_true"] = cases.max_rel(p, p_true)
     errs["po_vs_true"] = cases.max_rel(po, p_true)
-    assert errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"]), (label, errs)
+    # as close to the refined solution as the oracle is, up to a factor — or, where the oracle's
+    # rounding happens to land unusually close, three orders of magnitude inside the forward-error
+    # bound kappa x backward error (both residuals are equal to a factor ~1)
+    assert errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"], 1e-3 * kappa * errs["resid"]), (label, errs)
     # p_s, p_z (interior_point.hpp:479-480): the error of p carried through |A_i| and Sigma
     V = system.get("V")[b]
     I = system.info
@@ -314,7 +320,7 @@ def check_timed_step(system, op, state, b=0, tol_kkt=1e-10, tol_resid=1e-10, tol
     ps_ref = max(1.0, float(np.max(np.abs(op.vec("p_s"))))) if mi else 1.0
     pz_ref = max(1.0, float(np.max(np.abs(op.vec("p_z"))))) if mi else 1.0
     sigma_inf = max(1.0, float(np.max(z / s))) if mi else 1.0
-    tol_ps = max(tol_step, 2.0 * max(tol_step, 10.0 * errs["po_vs_true"]) * pmax * ai_inf / ps_ref)
+    tol_ps = max(tol_step, 2.0 * max(tol_step, 10.0 * errs["po_vs_true"], 1e-3 * kappa * errs["resid"]) * pmax * ai_inf / ps_ref)
     errs["tol_ps"] = tol_ps
     assert errs["p_s"] <= tol_ps, (label, errs)
     assert errs["p_z"] <= max(tol_step, 2.0 * tol_ps * ps_ref * sigma_inf / pz_ref), (label, errs)

@@ -17,7 +17,8 @@ import numpy as np
 
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
-LIB_PATH = _PKG / "libslpx.so"
+# (SLPX_LIB: another build of the library, e.g. for an A/B on one box)
+LIB_PATH = Path(os.environ["SLPX_LIB"]).resolve() if os.environ.get("SLPX_LIB") else _PKG / "libslpx.so"
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

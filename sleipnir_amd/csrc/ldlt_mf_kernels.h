@@ -56,38 +56,107 @@ __device__ __forceinline__ double lds_ld(uint32_t addr) { return *reinterpret_ca
 __device__ __forceinline__ void lds_st(uint32_t addr, double v) { *reinterpret_cast<LdsF64*>(static_cast<uintptr_t>(addr)) = v; }
 __device__ __forceinline__ uint32_t lds_ld16(uint32_t addr) { return *reinterpret_cast<const LdsU16*>(static_cast<uintptr_t>(addr)); }
 
+// A front's descriptor (16 bytes, wave-uniform) through the SCALAR cache into scalar registers: a vector
+// load would hold four vector registers across the front's whole body (the kernel sits at the 128 the
+// 1024-thread workgroup allows: measured, a descriptor prefetched into vector registers was spilled to
+// scratch and reloaded every level).  Load and wait are ONE asm statement: the compiler does not know
+// that the registers are written asynchronously, and a copy or spill of them between a separate load
+// and its wait would take the stale contents (seen: a memory fault).  A wave asks for the descriptor
+// of its front in the NEXT level at the end of this level's work, in front of the barrier.
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ __forceinline__ u32x4 s_load_desc(const LdltFront* p) {
+  u32x4 r;
+#ifdef MF_DESC_VECTOR
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  r[0] = __builtin_amdgcn_readfirstlane(v.x);
+  r[1] = __builtin_amdgcn_readfirstlane(v.y);
+  r[2] = __builtin_amdgcn_readfirstlane(v.z);
+  r[3] = __builtin_amdgcn_readfirstlane(v.w);
+  return r;
+#endif
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+  const uint64_t u = (static_cast<uint64_t>(hi) << 32) | lo;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(u) : "memory");
+  return r;
+}
+
 // column c against column 0 of a trapezoid, same row, in bytes
 __device__ __forceinline__ uint32_t mf_coff(uint32_t c, uint32_t nr) { return 8u * (c * nr - (c * (c - 1u)) / 2u - c); }
 
 // ---------------------------------------------------------------------------
 // One front, one wave.  `tab`: LDS byte address of the front's tables.  Wave-uniform: everything
-// but `lane`.
+// but `lane`.  What bounds a front is the number of instructions its wave executes and the number
+// of DEPENDENT trips to LDS, so the code is laid out in three trips: (1) every table word the lane
+// will need, (2) every value that does not depend on this front's elimination — its own entries,
+// the children's values for the pivot columns AND for the update block —, then the pivots in
+// registers, and (3) the finished columns for the update block.  NCH = children values per entry
+// as a compile-time constant (0, 1, 2) or kMfNchAny: a run-time loop.
 // ---------------------------------------------------------------------------
-template <int W>
+constexpr int kMfNchAny = 3;
+
+template <int W, int NCH>
 __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, bool root,
                                            uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                            double* __restrict__ contrib, uint32_t lane) {
-  // ---- pivot columns ----
+  constexpr bool kAny = NCH == kMfNchAny;
+  constexpr int kN = kAny ? 0 : NCH;  // children handled in registers; the rest (kAny) by loops
   const uint32_t row = lane < nr ? lane : nr - 1u;  // (idle lanes shadow the last row: same loads, same stores)
   const uint32_t stride = 2u * W * (1u + nch);
-  uint32_t pr = tab + row * stride;
-  uint32_t ua[W];
-  double a[W];
+  const uint32_t pr = tab + __umul24(row, stride);
+  const uint32_t upd = tab + nr * stride;
+  const uint32_t ustride = 2u * (3u + nch);
+  const uint32_t e = lane < n_s ? lane : (n_s ? n_s - 1u : 0u);
+  const uint32_t ur = upd + __umul24(e, ustride);
+  // ---- trip 1: table words ----
+  uint32_t ua[W], sa[kN ? kN : 1][W], o = 0, pa = 0, pb = 0, ss[kN ? kN : 1];
 #pragma unroll
   for (int c = 0; c < W; ++c) ua[c] = lds_ld16(pr + 2u * c);
 #pragma unroll
-  for (int c = 0; c < W; ++c) a[c] = lds_ld(ua[c]);
-  for (uint32_t k = 0; k < nch; ++k) {
-    pr += 2u * W;
-    uint32_t sa[W];
-    double sv[W];
+  for (int k = 0; k < kN; ++k)
 #pragma unroll
-    for (int c = 0; c < W; ++c) sa[c] = lds_ld16(pr + 2u * c);
+    for (int c = 0; c < W; ++c) sa[k][c] = lds_ld16(pr + 2u * (W * (k + 1) + c));
+  if (n_s) {
+    o = lds_ld16(ur);
+    pa = lds_ld16(ur + 2u);
+    pb = lds_ld16(ur + 4u);
 #pragma unroll
-    for (int c = 0; c < W; ++c) sv[c] = lds_ld(sa[c]);
-#pragma unroll
-    for (int c = 0; c < W; ++c) a[c] += sv[c];
+    for (int k = 0; k < kN; ++k) ss[k] = lds_ld16(ur + 6u + 2u * k);
   }
+  // ---- trip 2: values ----
+  double a[W], sv[kN ? kN : 1][W], cv[kN ? kN : 1];
+#pragma unroll
+  for (int c = 0; c < W; ++c) a[c] = lds_ld(ua[c]);
+#pragma unroll
+  for (int k = 0; k < kN; ++k)
+#pragma unroll
+    for (int c = 0; c < W; ++c) sv[k][c] = lds_ld(sa[k][c]);
+  double v = 0.0;
+  if (n_s) {
+#pragma unroll
+    for (int k = 0; k < kN; ++k) cv[k] = lds_ld(ss[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kN; ++k)
+#pragma unroll
+    for (int c = 0; c < W; ++c) a[c] += sv[k][c];
+  if (n_s) {
+#pragma unroll
+    for (int k = 0; k < kN; ++k) v = k == 0 ? cv[0] : v + cv[k];
+  }
+  if (kAny) {
+    for (uint32_t k = 0; k < nch; ++k) {
+      uint32_t xa[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) xa[c] = lds_ld16(pr + 2u * (W * (k + 1u) + c));
+      const uint32_t xs = n_s ? lds_ld16(ur + 6u + 2u * k) : 0u;
+#pragma unroll
+      for (int c = 0; c < W; ++c) a[c] += lds_ld(xa[c]);
+      if (n_s) v += lds_ld(xs);
+    }
+  }
+  // ---- pivots ----
   double inv[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) {
@@ -100,13 +169,9 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
   for (int c = 0; c < W; ++c) lds_st(ua[c], a[c]);  // (rows above the diagonal: the scratch double)
 #pragma unroll
   for (int c = 0; c < W; ++c) lds_st(invd_addr + 8u * c, inv[c]);  // (every lane the same value)
-  // ---- update block, a lane per entry ----
-  const uint32_t upd = tab + nr * stride;
-  const uint32_t ustride = 2u * (3u + nch);
-  for (uint32_t e0 = 0; e0 < n_s; e0 += 64u) {
-    const uint32_t e = e0 + lane < n_s ? e0 + lane : n_s - 1u;
-    const uint32_t ur = upd + e * ustride;
-    const uint32_t o = lds_ld16(ur), pa = lds_ld16(ur + 2u), pb = lds_ld16(ur + 4u);
+  if (n_s == 0) return;
+  // ---- trip 3: the update block, a lane per entry ----
+  {
     double ra[W], rb[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) {
@@ -114,22 +179,62 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
       ra[c] = lds_ld(pa + coff);
       rb[c] = lds_ld(pb + coff);
     }
-    double v = 0.0;
-    for (uint32_t k = 0; k < nch; ++k) v += lds_ld(lds_ld16(ur + 6u + 2u * k));
 #pragma unroll
     for (int c = 0; c < W; ++c) v = __builtin_fma(-(ra[c] * inv[c]), rb[c], v);
     if (root) {
       // (the receiving entry subtracts; and only ONE store per slot: its reader re-arms it)
-      if (e0 + lane < n_s) coherent_store(&contrib[ext[o]], -v, true);
+      if (lane < n_s) coherent_store(&contrib[ext[o]], -v, true);
     } else {
       lds_st(o, v);
     }
   }
+  for (uint32_t e0 = 64u; e0 < n_s; e0 += 64u) {  // blocks of more than 64 entries (r >= 11)
+    const uint32_t e2 = e0 + lane < n_s ? e0 + lane : n_s - 1u;
+    const uint32_t ur2 = upd + __umul24(e2, ustride);
+    const uint32_t o2 = lds_ld16(ur2), pa2 = lds_ld16(ur2 + 2u), pb2 = lds_ld16(ur2 + 4u);
+    double ra[W], rb[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const uint32_t coff = mf_coff(c, nr);
+      ra[c] = lds_ld(pa2 + coff);
+      rb[c] = lds_ld(pb2 + coff);
+    }
+    double v2 = 0.0;
+    for (uint32_t k = 0; k < nch; ++k) v2 += lds_ld(lds_ld16(ur2 + 6u + 2u * k));
+#pragma unroll
+    for (int c = 0; c < W; ++c) v2 = __builtin_fma(-(ra[c] * inv[c]), rb[c], v2);
+    if (root) {
+      if (e0 + lane < n_s) coherent_store(&contrib[ext[o2]], -v2, true);
+    } else {
+      lds_st(o2, v2);
+    }
+  }
 }
 
-__device__ __attribute__((noinline)) void mf_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t n_s,
-                                                   uint32_t root, uint32_t invd_addr, const uint32_t* __restrict__ ext,
-                                                   double* __restrict__ contrib, uint32_t lane) {
+template <int W>
+__device__ __forceinline__ void mf_front_nch(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, bool root,
+                                             uint32_t invd_addr, const uint32_t* __restrict__ ext,
+                                             double* __restrict__ contrib, uint32_t lane) {
+  // (code size and register pressure: the in-register children only where they are common)
+  if constexpr (W <= 2) {
+    switch (nch) {
+      case 0: mf_front_w<W, 0>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      case 1: mf_front_w<W, 1>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      case 2: mf_front_w<W, 2>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      default: mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+    }
+  } else if constexpr (W <= 5) {
+    if (nch == 2) mf_front_w<W, 2>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+    else mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+  } else {
+    mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+  }
+}
+
+// (every argument but `lane` wave-uniform: scalar registers, scalar jumps)
+__device__ __forceinline__ void mf_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t n_s,
+                                         uint32_t root, uint32_t invd_addr, const uint32_t* __restrict__ ext,
+                                         double* __restrict__ contrib, uint32_t lane) {
   tab = __builtin_amdgcn_readfirstlane(tab);
   w = __builtin_amdgcn_readfirstlane(w);
   nr = __builtin_amdgcn_readfirstlane(nr);
@@ -138,7 +243,7 @@ __device__ __attribute__((noinline)) void mf_front(uint32_t tab, uint32_t w, uin
   root = __builtin_amdgcn_readfirstlane(root);
   invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
   switch (w) {
-#define SLPX_MF_CASE(W) case W: mf_front_w<W>(tab, nr, nch, n_s, root != 0, invd_addr, ext, contrib, lane); break;
+#define SLPX_MF_CASE(W) case W: mf_front_nch<W>(tab, nr, nch, n_s, root != 0, invd_addr, ext, contrib, lane); break;
     SLPX_MF_CASE(1) SLPX_MF_CASE(2) SLPX_MF_CASE(3) SLPX_MF_CASE(4) SLPX_MF_CASE(5) SLPX_MF_CASE(6) SLPX_MF_CASE(7)
     SLPX_MF_CASE(8)
 #undef SLPX_MF_CASE
@@ -152,19 +257,21 @@ __device__ __attribute__((noinline)) void mf_front(uint32_t tab, uint32_t w, uin
 // Eight lanes per pivot column over the rows of R (their x through the front's solve table), DPP
 // sum, then the chain top-down with v_readlane.  `xr`: LDS byte address of the solve table,
 // `u0`: of the front's first entry, `x_addr`: of x[col0], `invd_addr`: of 1/d[col0].
+// Everything that does not depend on x is requested first: one dependent trip for the rows of R.
 // ---------------------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ void mf_solve_w(uint32_t xr, uint32_t u0, uint32_t nr, uint32_t invd_addr, uint32_t x_addr,
                                            uint32_t lane) {
   const uint32_t r = nr - W - 1u;
-  const uint32_t c = lane >> 3, g = lane & 7u;
-  const bool mine = c < static_cast<uint32_t>(W);
+  const uint32_t c = W > 1 ? lane >> 3 : 0u, g = lane & 7u;
+  const bool mine = W == 8 || c < static_cast<uint32_t>(W);
   const uint32_t cc = mine ? c : 0u;
   const uint32_t colc = u0 + 8u * (cc * nr - (cc * (cc - 1u)) / 2u);  // diagonal of column cc
-  double dot = 0.0;
-  for (uint32_t a = g; a < r; a += 8u) dot = __builtin_fma(lds_ld(colc + 8u * (W - cc + a)), lds_ld(lds_ld16(xr + 2u * a)), dot);
-  dot = group8_sum(dot);
-  // the chain's own couplings U(k, cc), k > cc, and the right-hand-side row
+  // two rows of R per lane cover r <= 16 (a clamped index and a select instead of a guarded load)
+  const uint32_t a0 = g < r ? g : 0u, a1 = g + 8u < r ? g + 8u : 0u;
+  const uint32_t x0a = lds_ld16(xr + 2u * a0), x1a = lds_ld16(xr + 2u * a1);
+  const double u0v = lds_ld(colc + 8u * (W - cc + a0)), u1v = lds_ld(colc + 8u * (W - cc + a1));
+  // the chain's own couplings U(k, cc), k > cc, 1/d and the right-hand-side row
   double cf[W];
 #pragma unroll
   for (int k = 1; k < W; ++k) {
@@ -173,18 +280,24 @@ __device__ __forceinline__ void mf_solve_w(uint32_t xr, uint32_t u0, uint32_t nr
     cf[k] = (use && mine) ? v : 0.0;
   }
   const double inv = lds_ld(invd_addr + 8u * cc);
-  double p = lds_ld(colc + 8u * (nr - 1u - cc)) - dot;  // (lane 8 c holds column c)
+  const double b = lds_ld(colc + 8u * (nr - 1u - cc));
+  const double x0 = lds_ld(x0a), x1 = lds_ld(x1a);
+  double dot = (g < r ? u0v : 0.0) * x0;
+  dot = __builtin_fma(g + 8u < r ? u1v : 0.0, x1, dot);
+  for (uint32_t a = g + 16u; a < r; a += 8u) dot = __builtin_fma(lds_ld(colc + 8u * (W - cc + a)), lds_ld(lds_ld16(xr + 2u * a)), dot);
+  dot = group8_sum(dot);
+  double p = b - dot;  // (lane 8 c holds column c)
 #pragma unroll
   for (int k = W - 1; k >= 0; --k) {
     // column k is final once the columns above it are in: scale it, then hand it to the columns below
-    const double xk = readlane_f64(p, 8 * k) * readlane_f64(inv, 8 * k);
+    const double xk = readlane_f64(p, W > 1 ? 8 * k : 0) * readlane_f64(inv, W > 1 ? 8 * k : 0);
     if (k > 0) p = __builtin_fma(-cf[k], xk, p);
-    if (lane == 0) lds_st(x_addr + 8u * k, xk);
+    lds_st(x_addr + 8u * k, xk);  // (every lane the same value)
   }
 }
 
-__device__ __attribute__((noinline)) void mf_solve_front(uint32_t xr, uint32_t u0, uint32_t w, uint32_t nr,
-                                                         uint32_t invd_addr, uint32_t x_addr, uint32_t lane) {
+__device__ __forceinline__ void mf_solve_front(uint32_t xr, uint32_t u0, uint32_t w, uint32_t nr, uint32_t invd_addr,
+                                               uint32_t x_addr, uint32_t lane) {
   xr = __builtin_amdgcn_readfirstlane(xr);
   u0 = __builtin_amdgcn_readfirstlane(u0);
   w = __builtin_amdgcn_readfirstlane(w);
@@ -261,8 +374,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
   double* invd = reinterpret_cast<double*>(smem_raw + cv.o_invd);
   double* x = reinterpret_cast<double*>(smem_raw + cv.o_x);
-  const LdltFront* fronts = reinterpret_cast<const LdltFront*>(smem_raw + cv.o_fr);
-  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
+    const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
   const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
   const int32_t* src = reinterpret_cast<const int32_t*>(smem_raw + cv.o_src);
   const uint16_t* col = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_col);
@@ -279,7 +391,6 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
 
   // ---- stage the plan ----
   stage16<THREADS>(g16(cv.o_tab), reinterpret_cast<const uint4*>(Mf.tab + m.tab_off), q16(m.n_tab, 8), tid);
-  stage16<THREADS>(g16(cv.o_fr), reinterpret_cast<const uint4*>(Mf.fronts + m.front_off), m.n_front, tid);
   stage16<THREADS>(g16(cv.o_lvl), reinterpret_cast<const uint4*>(Mf.lvl_ptr + t.lvl_off), q16(t.n_lvl + 1, 4), tid);
   stage16<THREADS>(g16(cv.o_ext), reinterpret_cast<const uint4*>(Mf.ext + m.ext_off), q16(m.n_ext, 4), tid);
   stage16<THREADS>(g16(cv.o_src), reinterpret_cast<const uint4*>((F.inline_kkt ? F.ent_vsrc : L.ent_src) + t.ent_off),
@@ -400,15 +511,21 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   SLPX_LDLT_CLOCK(2);
 
   // ---- levels: a wave per front ----
+  // (the descriptor of the wave's front in the NEXT level is requested before this level's work)
+  const LdltFront* gfr = Mf.fronts + m.front_off;
+  const uint32_t last_front = m.n_front ? m.n_front - 1u : 0u;
   {
-    uint32_t beg = lvl[0], end = t.n_lvl ? lvl[1] : 0;
+    uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[0]), end = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[1] : 0);
+    u32x4 d = s_load_desc(gfr + (beg + wave < last_front ? beg + wave : last_front));
     for (uint32_t l = 0; l < t.n_lvl; ++l) {
-      const uint32_t next_end = lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl];
+      const uint32_t next_end = __builtin_amdgcn_readfirstlane(lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl]);
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-        const LdltFront f = fronts[q];
-        mf_front(cv.o_tab + 2u * f.tab, f.w, f.nr, f.nch, f.n_s, f.flags & 1u, cv.o_invd + 8u * f.col0, ext + f.ext, contrib,
-                 lane);
+        if (q != beg + wave) d = s_load_desc(gfr + q);
+        const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 1u;
+        mf_front(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
+                 contrib, lane);
       }
+      d = s_load_desc(gfr + (end + wave < last_front ? end + wave : last_front));
       __syncthreads();
       beg = end;
       end = next_end;
@@ -433,10 +550,17 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
 
   // ---- backward solve on what the factorization left in LDS ----
   // this lane's row of the back-substitution (ldlt_bwd_run): everything but p is known now
+  // (fetched now, while the task waits for its ancestors; parked in LDS — where the KKT terms were —
+  // during the level loop: held in registers they pushed the kernel over the 128 a 1024-thread
+  // workgroup allows, and the compiler's spill of one of them sat in a block that runs with a
+  // partial exec mask: most lanes got zeros back)
   constexpr int kBsPre = 4;
+  constexpr uint32_t kBsStash = 5u + 2u * kBsPre;  // doubles per row: s, z, c_i, a[], p[], refs (two per double)
   const BsRow* bs_rows = reinterpret_cast<const BsRow*>(s_bs);
   const BsTerm* bs_terms = reinterpret_cast<const BsTerm*>(s_bs + bs_task.w);
-  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z && t.round == 0;
+  double* stash = reinterpret_cast<double*>(s_terms);
+  const bool stash_fits = 8u * kBsStash * bs_task.z <= 16u * n_terms16 + 8u * n_terms;
+  const bool bs_mine = static_cast<uint32_t>(tid) < bs_task.z && t.round == 0 && stash_fits;
   BsRow bs_row = BsRow{0, 0};
   double bs_a[kBsPre], bs_p[kBsPre], bs_s = 1.0, bs_z = 0.0, bs_ci = 0.0;
   uint32_t bs_ref[kBsPre];
@@ -467,19 +591,31 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
 #pragma unroll
     for (int k = 0; k < kBsPre; ++k)
       if (bs_ref[k] & 0x80000000u) bs_p[k] = slot_read(&xg[bs_ref[k] & 0x7fffffffu]);
+    double* st = stash + kBsStash * static_cast<uint32_t>(tid);
+    st[0] = bs_s;
+    st[1] = bs_z;
+    st[2] = bs_ci;
+#pragma unroll
+    for (int k = 0; k < kBsPre; ++k) {
+      st[3 + k] = bs_a[k];
+      st[3 + kBsPre + k] = bs_p[k];
+      reinterpret_cast<uint32_t*>(st + 3 + 2 * kBsPre)[k] = bs_ref[k];
+    }
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(18);
   {
-    uint32_t end = lvl[t.n_lvl], beg = t.n_lvl ? lvl[t.n_lvl - 1] : 0;
+    uint32_t end = __builtin_amdgcn_readfirstlane(lvl[t.n_lvl]), beg = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[t.n_lvl - 1] : 0);
+    u32x4 d = s_load_desc(gfr + (beg + wave < last_front ? beg + wave : last_front));
     for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
-      const uint32_t next_beg = lvl[l >= 1 ? l - 1 : 0];
+      const uint32_t next_beg = __builtin_amdgcn_readfirstlane(lvl[l >= 1 ? l - 1 : 0]);
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-        const LdltFront f = fronts[q];
-        const uint32_t stride = 2u * f.w * (1u + f.nch);
-        const uint32_t xr = cv.o_tab + 2u * f.tab + f.nr * stride + static_cast<uint32_t>(f.n_s) * 2u * (3u + f.nch);
-        mf_solve_front(xr, 8u * f.base0, f.w, f.nr, cv.o_invd + 8u * f.col0, cv.o_x + 8u * f.col0, lane);
+        if (q != beg + wave) d = s_load_desc(gfr + q);
+        const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
+        const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
+        mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);
       }
+      d = s_load_desc(gfr + (next_beg + wave < last_front ? next_beg + wave : last_front));
       __syncthreads();
       end = beg;
       beg = next_beg;
@@ -496,15 +632,21 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
     for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
       const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
-      const BsRow row = ahead ? bs_row : bs_rows[j];
+      const BsRow row = bs_rows[j];
       const uint32_t first = row.terms & 0xfffffu, cnt = row.terms >> 20;
-      double aipx = 0.0, s_r = bs_s, z_r = bs_z, ci_r = bs_ci;
+      double aipx = 0.0, s_r = 1.0, z_r = 0.0, ci_r = 0.0;
       uint32_t k0 = 0;
       if (ahead) {
+        const double* st = stash + kBsStash * static_cast<uint32_t>(tid);
+        s_r = st[0];
+        z_r = st[1];
+        ci_r = st[2];
 #pragma unroll
         for (int k = 0; k < kBsPre; ++k)
-          if (static_cast<uint32_t>(k) < cnt)
-            aipx = backsub_dot(aipx, bs_a[k], (bs_ref[k] & 0x80000000u) ? bs_p[k] : x[bs_ref[k]]);
+          if (static_cast<uint32_t>(k) < cnt) {
+            const uint32_t ref = reinterpret_cast<const uint32_t*>(st + 3 + 2 * kBsPre)[k];
+            aipx = backsub_dot(aipx, st[3 + k], (ref & 0x80000000u) ? st[3 + kBsPre + k] : x[ref]);
+          }
         k0 = kBsPre;
       } else {  // (nothing was fetched ahead)
         s_r = B.s[row.r];

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 #include <unordered_map>
@@ -1010,6 +1011,19 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       for (auto& M : P.mf_tasks) {
         tab = std::max<size_t>(tab, M.n_tab);
         arena = std::max<size_t>(arena, M.arena);
+      }
+      {
+        std::map<std::pair<int, int>, int> hist;
+        std::map<int, int> rows;
+        for (size_t i = 0; i + 16 < P.mf_fronts.size(); ++i) {
+          ++hist[{P.mf_fronts[i].w, P.mf_fronts[i].nch}];
+          ++rows[P.mf_fronts[i].nr - P.mf_fronts[i].w - 1];
+        }
+        std::fprintf(stderr, "ldlt fronts (w, children values per entry): count —");
+        for (auto& [k, v] : hist) std::fprintf(stderr, " (%d,%d):%d", k.first, k.second, v);
+        std::fprintf(stderr, "\nldlt fronts rows below the pivots: count —");
+        for (auto& [k, v] : rows) std::fprintf(stderr, " %d:%d", k, v);
+        std::fprintf(stderr, "\n");
       }
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u)\n",
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib);

@@ -460,11 +460,16 @@ class DeviceNlp {
   // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
   bool m_mf = false;
   uint32_t m_mf_lds = 0;
-  std::vector<uint32_t> m_task_terms16, m_task_bs16;  // per task: 16-byte groups of its KKT terms / back-substitution rows
+  // host copies of the inline KKT / back-substitution plans (build_mf packs them into the task images)
+  std::vector<int32_t> m_h_vsrc;
+  std::vector<KktTerm> m_h_terms;
+  std::vector<uint2> m_h_task_terms;
+  std::vector<BsRow> m_h_bs_plan;
+  std::vector<uint4> m_h_bs_task_plan;
   DevBuf<LdltMfTask> m_mf_tasks;
   DevBuf<LdltFront> m_mf_fronts;
-  DevBuf<uint32_t> m_mf_lvl_ptr, m_mf_ext, m_mf_contrib_ptr, m_mf_contrib_idx, m_mf_anc;
-  DevBuf<uint16_t> m_mf_tab;
+  DevBuf<uint4> m_mf_image;        // per task: everything static it keeps in LDS, in LDS order (one copy loop)
+  DevBuf<uint4> m_mf_image_desc;   // per task {first 16-byte group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   DevBuf<double> m_mf_contrib;
   void build_mf(const LdltPlan& l);
   DevBuf<unsigned int> m_ipm_err_done;

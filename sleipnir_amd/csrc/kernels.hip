@@ -874,7 +874,6 @@ void DeviceNlp::build_inline_kkt(const NlpStructure& s, const KktPlan& k, const 
     const uint32_t off16 = static_cast<uint32_t>(block * sizeof(KktTerm) / 16);
     const uint32_t len16 = static_cast<uint32_t>((terms.size() - block) * sizeof(KktTerm) / 16);
     task_terms[ti] = uint2{off16, len16};
-    m_task_terms16.push_back(len16);
     widest = std::max(widest, len16);
   }
   // the staged terms and, behind them, one product per term (4 terms = 3 x 16 bytes)
@@ -887,6 +886,9 @@ void DeviceNlp::build_inline_kkt(const NlpStructure& s, const KktPlan& k, const 
   m_ent_vsrc.upload(vsrc);
   m_kkt_terms.upload(terms);
   m_task_terms.upload(task_terms);
+  m_h_vsrc = std::move(vsrc);
+  m_h_terms = std::move(terms);
+  m_h_task_terms = std::move(task_terms);
 }
 
 // The static side of BacksubFuse: every row of A_i goes to the task that owns the deepest of
@@ -945,7 +947,6 @@ void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
     const uint32_t len16 = static_cast<uint32_t>((plan.size() - block) / 2);
     task_plan[ti] = uint4{static_cast<uint32_t>(block / 2), len16, static_cast<uint32_t>(n_rows),
                           static_cast<uint32_t>(rows_padded / 2)};
-    m_task_bs16.push_back(len16);
     widest = std::max(widest, len16);
   }
   m_solve_lds_inline = l.solve_lds_bytes + 16u + 16u * widest;
@@ -956,6 +957,8 @@ void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
   if (plan.empty()) plan.push_back(BsRow{0, 0});
   m_bs_plan.upload(plan);
   m_bs_task_plan.upload(task_plan);
+  m_h_bs_plan = std::move(plan);
+  m_h_bs_task_plan = std::move(task_plan);
 }
 
 // The static side of ldlt_factor_solve_kernel, and whether it can be used at all: its workgroups
@@ -1010,12 +1013,49 @@ constexpr int kFactorThreadsSingle = 1024;
 void DeviceNlp::build_mf(const LdltPlan& l) {
   if (const char* env = std::getenv("SLPX_LDLT_MF"))
     if (env[0] == '0') return;
-  if (m_task_terms16.size() != l.tasks.size() || m_task_bs16.size() != l.tasks.size()) return;
+  if (m_h_task_terms.size() != l.tasks.size() || m_h_bs_task_plan.size() != l.tasks.size()) return;
+  // Every task's static LDS content as ONE image in LDS order (mf_carve: from the tables to the KKT
+  // terms, then — behind the terms' products, which are not staged — its back-substitution rows):
+  // thirteen arrays staged one after the other were thirteen dependent waits on memory (4.5 us);
+  // one copy loop with every load in flight is a single trip.
   uint32_t lds = 0;
+  std::vector<uint4> image, desc(l.tasks.size());
   for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const MfCarve cv = mf_carve(l.tasks[ti], l.mf_tasks[ti]);
-    const uint32_t n_terms = m_task_terms16[ti] * 4u / 3u;
-    lds = std::max(lds, mf_align16(cv.o_terms + 16u * m_task_terms16[ti] + 8u * n_terms) + 16u * m_task_bs16[ti]);
+    const LdltTask& t = l.tasks[ti];
+    const LdltMfTask& m = l.mf_tasks[ti];
+    const MfCarve cv = mf_carve(t, m);
+    const uint32_t terms16 = m_h_task_terms[ti].y, bs16 = m_h_bs_task_plan[ti].y;
+    const uint32_t n_terms = terms16 * 4u / 3u;
+    const uint32_t end_terms = cv.o_terms + 16u * terms16;
+    lds = std::max(lds, mf_align16(end_terms + 8u * n_terms) + 16u * bs16);
+    std::vector<unsigned char> blob(end_terms - cv.o_tab + 16u * bs16, 0);
+    auto put = [&](uint32_t at, const void* src, size_t bytes) {
+      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
+    };
+    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
+    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
+    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
+    put(cv.o_src, m_h_vsrc.data() + t.ent_off, 4u * t.n_ent);
+    put(cv.o_col, l.ent_col.data() + t.ent_off, 2u * t.n_ent);
+    put(cv.o_flags, l.ent_flags.data() + t.ent_off, t.n_ent);
+    put(cv.o_out, l.ent_out.data() + t.ent_off, 4u * t.n_ent);
+    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (t.n_ent + 1));
+    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
+    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
+    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
+    {
+      // the inertia counters start at zero, the smallest |d| at +inf
+      const unsigned long long inf = 0x7ff0000000000000ull;
+      put(cv.o_cnt + 16u, &inf, 8);
+    }
+    put(cv.o_terms, reinterpret_cast<const unsigned char*>(m_h_terms.data()) + 16u * static_cast<size_t>(m_h_task_terms[ti].x),
+        16u * terms16);
+    put(end_terms, reinterpret_cast<const unsigned char*>(m_h_bs_plan.data()) + 16u * static_cast<size_t>(m_h_bs_task_plan[ti].x),
+        16u * bs16);
+    desc[ti] = uint4{static_cast<uint32_t>(image.size()), (end_terms - cv.o_tab) / 16u, bs16, terms16};
+    const size_t at = image.size();
+    image.resize(at + blob.size() / 16u);
+    std::memcpy(image.data() + at, blob.data(), blob.size());
   }
   lds = mf_align16(lds) + 16u;
   int per_cu = 0, cus = 0;
@@ -1029,20 +1069,16 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
     SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
   }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt multifrontal step: %zu tasks, LDS %u bytes (static %zu), %d workgroup(s) per CU x %d CUs\n",
-                 l.tasks.size(), lds, attr.sharedSizeBytes, per_cu, cus);
+    std::fprintf(stderr, "ldlt multifrontal step: %zu tasks, LDS %u bytes (static %zu), images %zu bytes, %d workgroup(s) per CU x %d CUs\n",
+                 l.tasks.size(), lds, attr.sharedSizeBytes, 16 * image.size(), per_cu, cus);
   // (the tables hold LDS byte addresses from 0: no static LDS in front of the dynamic block)
   if (lds > 160u * 1024u || attr.sharedSizeBytes != 0 ||
       l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus)
     return;
   m_mf_tasks.upload(l.mf_tasks);
   m_mf_fronts.upload(l.mf_fronts);
-  m_mf_lvl_ptr.upload(l.mf_lvl_ptr);
-  m_mf_tab.upload(l.mf_tab);
-  m_mf_ext.upload(l.mf_ext);
-  m_mf_contrib_ptr.upload(l.mf_contrib_ptr);
-  m_mf_contrib_idx.upload(l.mf_contrib_idx);
-  m_mf_anc.upload(l.mf_anc);
+  m_mf_image.upload(image);
+  m_mf_image_desc.upload(desc);
   m_mf_contrib.upload(std::vector<double>(std::max<uint32_t>(1, l.mf_n_contrib), std::bit_cast<double>(kSlotEmpty)));
   if (m_exit_cnt.n == 0) m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
   m_mf_lds = lds;
@@ -1311,12 +1347,8 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
     MfDev md;
     md.tasks = m_mf_tasks.p;
     md.fronts = m_mf_fronts.p;
-    md.lvl_ptr = m_mf_lvl_ptr.p;
-    md.tab = m_mf_tab.p;
-    md.ext = m_mf_ext.p;
-    md.contrib_ptr = m_mf_contrib_ptr.p;
-    md.contrib_idx = m_mf_contrib_idx.p;
-    md.anc = m_mf_anc.p;
+    md.image = m_mf_image.p;
+    md.image_desc = m_mf_image_desc.p;
     md.n_tasks = static_cast<unsigned int>(l.tasks.size());
     md.exit_cnt = m_exit_cnt.p;
     hipLaunchKernelGGL(ldlt_mf_step_kernel<kFactorThreadsSingle>,

@@ -41,12 +41,8 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 struct MfDev {
   const LdltMfTask* tasks = nullptr;
   const LdltFront* fronts = nullptr;
-  const uint32_t* lvl_ptr = nullptr;
-  const uint16_t* tab = nullptr;
-  const uint32_t* ext = nullptr;
-  const uint32_t* contrib_ptr = nullptr;
-  const uint32_t* contrib_idx = nullptr;
-  const uint32_t* anc = nullptr;
+  const uint4* image = nullptr;       // per task: its static LDS content in LDS order (DeviceNlp::build_mf)
+  const uint4* image_desc = nullptr;  // per task {first group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   unsigned int n_tasks = 0;
   unsigned int* exit_cnt = nullptr;  // workgroups through their exit phase (the last one publishes)
 };
@@ -318,11 +314,11 @@ __device__ __forceinline__ void mf_solve_front(uint32_t xr, uint32_t u0, uint32_
 // update slots and, in the solve, through x itself: every workgroup must be resident).
 // LDS (bytes; the first four regions are what the tables address, so they start at 0):
 //   U[n_ent] f64 | arena f64 | 1/d[n_col] f64 | x[n_col + n_anc + 1] f64 |
-//   tables u16 | fronts 16 B | levels u32 | ext u32 | src i32 | col u16 | flags u8 | out u32 | cptr u32 | cidx u32 |
+//   tables u16 | levels u32 | ext u32 | src i32 | col u16 | flags u8 | out u32 | cptr u32 | cidx u32 |
 //   colperm u32 | anc u32 | counters 32 B | KKT terms + products | back-substitution rows
 // ---------------------------------------------------------------------------
 struct MfCarve {
-  uint32_t o_arena, o_invd, o_x, o_tab, o_fr, o_lvl, o_ext, o_src, o_col, o_flags, o_out, o_cptr, o_cidx, o_cp, o_anc,
+  uint32_t o_arena, o_invd, o_x, o_tab, o_lvl, o_ext, o_src, o_col, o_flags, o_out, o_cptr, o_cidx, o_cp, o_anc,
       o_cnt, o_terms;
 };
 __host__ __device__ inline uint32_t mf_align16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -333,8 +329,7 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
   c.o_invd = c.o_arena + 8u * m.arena;
   c.o_x = c.o_invd + 8u * t.n_col;
   c.o_tab = mf_align16(c.o_x + 8u * (t.n_col + m.n_anc + 1u));
-  c.o_fr = c.o_tab + q(m.n_tab, 8);
-  c.o_lvl = c.o_fr + 16u * m.n_front;
+  c.o_lvl = c.o_tab + q(m.n_tab, 8);
   c.o_ext = c.o_lvl + q(t.n_lvl + 1u, 4);
   c.o_src = c.o_ext + q(m.n_ext, 4);
   c.o_col = c.o_src + q(t.n_ent, 4);
@@ -389,37 +384,33 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   uint4* s_terms = reinterpret_cast<uint4*>(smem_raw + cv.o_terms);
   auto g16 = [&](uint32_t o) { return reinterpret_cast<uint4*>(smem_raw + o); };
 
-  // ---- stage the plan ----
-  stage16<THREADS>(g16(cv.o_tab), reinterpret_cast<const uint4*>(Mf.tab + m.tab_off), q16(m.n_tab, 8), tid);
-  stage16<THREADS>(g16(cv.o_lvl), reinterpret_cast<const uint4*>(Mf.lvl_ptr + t.lvl_off), q16(t.n_lvl + 1, 4), tid);
-  stage16<THREADS>(g16(cv.o_ext), reinterpret_cast<const uint4*>(Mf.ext + m.ext_off), q16(m.n_ext, 4), tid);
-  stage16<THREADS>(g16(cv.o_src), reinterpret_cast<const uint4*>((F.inline_kkt ? F.ent_vsrc : L.ent_src) + t.ent_off),
-                   q16(t.n_ent, 4), tid);
-  uint32_t n_terms16 = 0;
-  if (F.inline_kkt) {
-    const uint2 tt = F.task_terms[task_index];
-    n_terms16 = tt.y;
-    stage16<THREADS>(s_terms, F.terms + tt.x, tt.y, tid);
-  }
-  stage16<THREADS>(g16(cv.o_col), reinterpret_cast<const uint4*>(L.ent_col + t.ent_off), q16(t.n_ent, 8), tid);
-  stage16<THREADS>(g16(cv.o_flags), reinterpret_cast<const uint4*>(L.ent_flags + t.ent_off), q16(t.n_ent, 16), tid);
-  stage16<THREADS>(g16(cv.o_out), reinterpret_cast<const uint4*>(L.ent_out + t.ent_off), q16(t.n_ent, 4), tid);
-  stage16<THREADS>(g16(cv.o_cptr), reinterpret_cast<const uint4*>(Mf.contrib_ptr + m.contrib_ptr_off), q16(t.n_ent + 1, 4), tid);
-  stage16<THREADS>(g16(cv.o_cidx), reinterpret_cast<const uint4*>(Mf.contrib_idx + m.contrib_off), q16(m.n_contrib_idx, 4), tid);
-  stage16<THREADS>(g16(cv.o_cp), reinterpret_cast<const uint4*>(L.col_perm + t.col_off), q16(t.n_col, 4), tid);
-  stage16<THREADS>(g16(cv.o_anc), reinterpret_cast<const uint4*>(Mf.anc + m.anc_off), q16(m.n_anc, 4), tid);
-  // the back-substitution rows this task owns (BacksubFuse), behind the KKT terms and their products
-  const uint32_t n_terms = n_terms16 * 4u / 3u;
+  // ---- stage the plan: one image, one copy loop, every load in flight ----
+  const uint4 img = Mf.image_desc[task_index];
+  const uint32_t n_terms16 = img.w, n_terms = n_terms16 * 4u / 3u;
   double* tprod = reinterpret_cast<double*>(s_terms + n_terms16);
   uint4* s_bs = reinterpret_cast<uint4*>(smem_raw + mf_align16(cv.o_terms + 16u * n_terms16 + 8u * n_terms));
-  uint4 bs_task = uint4{0, 0, 0, 0};
-  if (B.on) {
-    bs_task = B.task_plan[task_index];
-    stage16<THREADS>(s_bs, B.plan + bs_task.x, bs_task.y, tid);
+  uint4 bs_task = B.task_plan[task_index];
+  {
+    const uint4* src16 = Mf.image + img.x;
+    uint4* dst_a = g16(cv.o_tab);
+    const uint32_t n_a = img.y, n_all = img.y + img.z;
+    constexpr int kInFlight = 6;
+    for (uint32_t i0 = tid; i0 < n_all; i0 += kInFlight * THREADS) {
+      uint4 v[kInFlight];
+#pragma unroll
+      for (int k = 0; k < kInFlight; ++k) {
+        const uint32_t i = i0 + k * THREADS;
+        v[k] = src16[i < n_all ? i : n_all - 1u];
+      }
+#pragma unroll
+      for (int k = 0; k < kInFlight; ++k) {
+        const uint32_t i = i0 + k * THREADS;
+        if (i < n_a) dst_a[i] = v[k];
+        else if (i < n_all) s_bs[i - n_a] = v[k];
+      }
+    }
   }
-  if (tid < 4) s_cnt[tid] = 0;
   if (tid == 0) {
-    *s_minp = 0x7ff0000000000000ull;  // +inf
     arena[0] = 0.0;
     arena[1] = 0.0;
     x[t.n_col + m.n_anc] = 1.0;

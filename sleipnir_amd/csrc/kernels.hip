@@ -1030,6 +1030,7 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
     lds = std::max(lds, mf_align16(end_terms + 8u * n_terms) + 16u * bs16);
     std::vector<unsigned char> blob(end_terms - cv.o_tab + 16u * bs16, 0);
     auto put = [&](uint32_t at, const void* src, size_t bytes) {
+      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
       if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
     };
     put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);

@@ -20,7 +20,7 @@ BIN = ROOT / "build" / "multi_gpu_batch_host"
 
 
 def build(slpx):
-    if BIN.exists() and BIN.stat().st_mtime > SRC.stat().st_mtime:
+    if BIN.exists() and BIN.stat().st_mtime > max(SRC.stat().st_mtime, slpx.LIB_PATH.stat().st_mtime):
         return
     BIN.parent.mkdir(parents=True, exist_ok=True)
     lib_dir = slpx.LIB_PATH.parent

@@ -154,18 +154,22 @@ def test_supernode_settings(fresh, slpx, orc, monkeypatch, env, kind, N):
         system.close()
 
 
+@pytest.mark.parametrize("mf", ["1", "0"])
 @pytest.mark.parametrize("kind,N", [("cart_pole", 37), ("cart_pole", 300), ("flywheel", 50)])
-def test_system_evaluated_inside_the_factorization_equals_the_assembled_one(fresh, slpx, orc, monkeypatch, kind, N):
+def test_system_evaluated_inside_the_factorization_equals_the_assembled_one(fresh, slpx, orc, monkeypatch, kind, N, mf):
     """r02: a single problem's Newton step no longer assembles lhs / rhs in memory — the
     factorization's tasks evaluate the entries they own from the AD sweep's V (device.hpp:
     KktFuse; kkt_kernels.h).  SLPX_FUSE_KKT_STORE=1 makes them also write what they evaluated
     where the assembly kernels would have: the two must agree to the bit (and both are what the
-    oracle comparison of tests/support/parity.py sees), and so must the steps."""
+    oracle comparison of tests/support/parity.py sees).  The steps: to the bit with the pair-list
+    kernels on both sides (SLPX_LDLT_MF=0); the multifrontal step (r03, the default) sums the
+    updates front by front instead of pair by pair: same inertia, pivots and step to rounding."""
     pp, op = cases.build_pair(kind, N, slpx, orc)
     n, me, mi = pp.dims
     scales = op.scaling()
     x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
     got = {}
+    monkeypatch.setenv("SLPX_LDLT_MF", mf)
     for mode, env in (("inline", {"SLPX_FUSE_KKT_STORE": "1"}), ("assembled", {"SLPX_FUSE_KKT": "0"})):
         for k in ("SLPX_FUSE_KKT_STORE", "SLPX_FUSE_KKT"):
             monkeypatch.delenv(k, raising=False)
@@ -176,9 +180,20 @@ def test_system_evaluated_inside_the_factorization_equals_the_assembled_one(fres
         system.set_state(x, s, y, z, np.array([mu]))
         assert system.newton_step(True)[0] == 0
         got[mode] = {k: system.get(k)[0].copy() for k in ("lhs", "rhs", "p", "p_s", "p_z", "D")}
+        got[mode]["mf"] = system.time_fused_step(1)["multifrontal"]
         system.close()
-    for k in ("lhs", "rhs", "D", "p"):
+    assert bool(got["inline"]["mf"]) == (mf == "1") and not got["assembled"]["mf"]
+    for k in ("lhs", "rhs"):
         assert np.array_equal(got["inline"][k], got["assembled"][k]), k
-    # (p_s, p_z: the back-substitution riding in the solve's launch sums A_i p in the same order)
-    for k in ("p_s", "p_z"):
-        assert cases.max_rel(got["inline"][k], got["assembled"][k]) <= 1e-14, k
+    if mf == "0":
+        for k in ("D", "p"):
+            assert np.array_equal(got["inline"][k], got["assembled"][k]), k
+        # (p_s, p_z: the back-substitution riding in the solve's launch sums A_i p in the same order)
+        for k in ("p_s", "p_z"):
+            assert cases.max_rel(got["inline"][k], got["assembled"][k]) <= 1e-14, k
+    else:
+        Di, Da = got["inline"]["D"], got["assembled"]["D"]
+        assert np.array_equal(np.sign(Di), np.sign(Da))
+        assert np.median(np.abs(Di - Da) / np.abs(Da)) <= 1e-13
+        for k in ("p", "p_s", "p_z"):
+            assert cases.max_rel(got["inline"][k], got["assembled"][k]) <= 1e-6, k

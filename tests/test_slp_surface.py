@@ -15,6 +15,13 @@ SRC = ROOT / "tests" / "support" / "user_program" / "cart_pole_user.cpp"
 BIN = ROOT / "build" / "cart_pole_user"
 
 
+def _fresh(out, src, slpx):
+    """A user program built AFTER its source and after the library it links: the header-only slp::
+    surface compiles library structs into the program, so a binary older than libslpx.so may not
+    match it (seen: heap corruption after LdltOptions gained a member)."""
+    return out.exists() and out.stat().st_mtime > max(src.stat().st_mtime, slpx.LIB_PATH.stat().st_mtime)
+
+
 def build_user_program(slpx):
     BIN.parent.mkdir(parents=True, exist_ok=True)
     lib_dir = slpx.LIB_PATH.parent
@@ -38,7 +45,7 @@ def test_reference_benchmark_program_compiles_and_builds_the_model(slpx):
 
 @pytest.mark.gpu
 def test_reference_benchmark_program_solves_on_the_gpu(slpx):
-    build_user_program(slpx) if not BIN.exists() else None
+    build_user_program(slpx) if not _fresh(BIN, SRC, slpx) else None
     res = subprocess.run([str(BIN), "100"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
 
@@ -81,7 +88,7 @@ def test_ocp_helper_flywheel_known_answer_on_the_gpu(slpx, method, kind, steps):
     inputs; the reference then takes its DENSE LDLT branch (interior_point.hpp:340-349), which is
     outside SURVEY.md §8 — the sparse factorization here holds a column in LDS and says so when
     one does not fit (1000 steps), so that method is exercised at 50 steps."""
-    build_ocp_program(slpx) if not OCP_BIN.exists() else None
+    build_ocp_program(slpx) if not _fresh(OCP_BIN, OCP_SRC, slpx) else None
     res = subprocess.run([str(OCP_BIN), str(method), str(kind), str(steps)], capture_output=True, text=True,
                          timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
@@ -92,8 +99,7 @@ def test_ocp_helper_shared_timestep_is_a_hub_the_ordering_sets_aside(slpx):
     """TimestepMethod::VARIABLE_SINGLE: one decision variable in every dynamics row.  Level-set
     nested dissection cannot separate anything while it is in the graph (ldlt_symbolic.cpp: hubs
     are eliminated last); the larger timestep wins (the cost is a tracking error)."""
-    rm = OCP_BIN.exists() and OCP_BIN.stat().st_mtime < OCP_SRC.stat().st_mtime
-    build_ocp_program(slpx) if (rm or not OCP_BIN.exists()) else None
+    build_ocp_program(slpx) if not _fresh(OCP_BIN, OCP_SRC, slpx) else None
     res = subprocess.run([str(OCP_BIN), "0", "0", "200", "shared-dt"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
 
@@ -123,7 +129,7 @@ def test_differential_drive_ocp_model_of_the_reference_test(slpx):
 def test_differential_drive_minimum_time_ocp_on_the_gpu(slpx):
     """differential_drive_ocp_test.cpp:65-107: SUCCESS, initial and final state to 1e-8 — a
     nonlinear minimum-time problem whose single timestep variable sits in every dynamics row."""
-    build_dd_program(slpx) if not DD_BIN.exists() else None
+    build_dd_program(slpx) if not _fresh(DD_BIN, DD_SRC, slpx) else None
     res = subprocess.run([str(DD_BIN)], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
 
@@ -152,7 +158,7 @@ def test_cart_pole_ocp_model_of_the_reference_test(slpx):
 @pytest.mark.gpu
 def test_cart_pole_collocation_ocp_on_the_gpu(slpx):
     """cart_pole_ocp_test.cpp:91-131: SUCCESS, initial and final state to 1e-8."""
-    build_cart_pole_ocp_program(slpx) if not CPO_BIN.exists() else None
+    build_cart_pole_ocp_program(slpx) if not _fresh(CPO_BIN, CPO_SRC, slpx) else None
     res = subprocess.run([str(CPO_BIN)], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "status=0" in res.stdout, res.stdout + res.stderr
 
@@ -163,7 +169,7 @@ USER_DIR = ROOT / "tests" / "support" / "user_program"
 
 def build_named_program(slpx, name):
     src, out = USER_DIR / f"{name}.cpp", ROOT / "build" / name
-    if out.exists() and out.stat().st_mtime > src.stat().st_mtime:
+    if _fresh(out, src, slpx):
         return out
     out.parent.mkdir(parents=True, exist_ok=True)
     lib_dir = slpx.LIB_PATH.parent

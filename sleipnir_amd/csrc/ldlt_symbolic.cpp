@@ -313,6 +313,71 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       }
     }
   }
+  // ---- relaxed supernodes (LdltOptions::relax_zeros) -------------------------------------------------
+  int relaxed_merges = 0;
+  int64_t relaxed_zeros = 0;
+  if (opt.supernodal && opt.relax_zeros > 0) {
+    for (int round = 0; round < 8; ++round) {
+      // the chains as they stand (exact structure), their levels
+      std::vector<int32_t> sn(n, -1);
+      std::vector<std::vector<int32_t>> cols;
+      for (int j = 0; j < n; ++j) {
+        if (sn[j] >= 0) continue;
+        sn[j] = static_cast<int32_t>(cols.size());
+        std::vector<int32_t> chain{j};
+        int32_t k = j;
+        while (chain.size() < opt.max_supernode_width) {
+          const int32_t p = P.parent[k];
+          if (p < 0 || sn[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
+              chain.size() + 1 + Lcol[p].size() + 1 > kSnRowsMax)
+            break;
+          sn[p] = sn[j];
+          chain.push_back(p);
+          k = p;
+        }
+        cols.push_back(std::move(chain));
+      }
+      std::vector<int32_t> lvl(cols.size(), 0);
+      for (int j = 0; j < n; ++j)
+        for (int32_t c : children[j])
+          if (sn[c] != sn[j]) lvl[sn[j]] = std::max(lvl[sn[j]], lvl[sn[c]] + 1);
+      std::vector<int32_t> by_level(cols.size());
+      std::iota(by_level.begin(), by_level.end(), 0);
+      std::stable_sort(by_level.begin(), by_level.end(), [&](int32_t a, int32_t b) { return lvl[a] < lvl[b]; });
+      std::vector<uint8_t> used(cols.size(), 0);
+      int merged = 0;
+      for (int32_t s : by_level) {
+        if (used[s]) continue;
+        const auto& ch = cols[s];
+        const int32_t p = P.parent[ch.back()];
+        if (p < 0) continue;
+        const int32_t J = sn[p];
+        if (used[J] || cols[J][0] != p || lvl[s] + 1 < lvl[J]) continue;  // joins at the head, deepest child only
+        const auto& cj = cols[J];
+        const size_t below = cj.size() + Lcol[cj.back()].size();  // rows under the joining columns
+        if (ch.size() + cj.size() > opt.max_supernode_width || ch.size() + below + 1 > kSnRowsMax) continue;
+        int64_t zeros = 0;
+        for (size_t i = 0; i < ch.size(); ++i)
+          zeros += static_cast<int64_t>(ch.size() - 1 - i + below) - static_cast<int64_t>(Lcol[ch[i]].size());
+        if (zeros > opt.relax_zeros) continue;
+        std::vector<int32_t> tail(cj.begin(), cj.end());
+        tail.insert(tail.end(), Lcol[cj.back()].begin(), Lcol[cj.back()].end());
+        for (size_t i = 0; i < ch.size(); ++i) {
+          std::vector<int32_t> rows(ch.begin() + i + 1, ch.end());
+          rows.insert(rows.end(), tail.begin(), tail.end());
+          Lcol[ch[i]] = std::move(rows);
+        }
+        used[s] = used[J] = 1;
+        ++merged;
+        relaxed_zeros += zeros;
+      }
+      relaxed_merges += merged;
+      if (merged == 0) break;
+    }
+  }
+  if (std::getenv("SLPX_LDLT_VERBOSE") && opt.relax_zeros > 0)
+    std::fprintf(stderr, "ldlt relaxed supernodes: %d merges, %lld explicit zeros\n", relaxed_merges,
+                 static_cast<long long>(relaxed_zeros));
   P.Lp.assign(n + 1, 0);
   for (int j = 0; j < n; ++j) P.Lp[j + 1] = P.Lp[j] + static_cast<int32_t>(Lcol[j].size());
   P.nnzL = P.Lp[n];
@@ -1024,6 +1089,21 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         std::fprintf(stderr, "\nldlt fronts rows below the pivots: count —");
         for (auto& [k, v] : rows) std::fprintf(stderr, " %d:%d", k, v);
         std::fprintf(stderr, "\n");
+      }
+      for (int r = 0; r < P.n_rounds && ok; ++r) {
+        uint32_t most = 0, over = 0, lv = 0, deepest = 0;
+        for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) {
+          const LdltTask& T = P.tasks[ti];
+          deepest = std::max(deepest, T.n_lvl);
+          for (uint32_t l = 0; l < T.n_lvl; ++l) {
+            const uint32_t nf = P.mf_lvl_ptr[T.lvl_off + l + 1] - P.mf_lvl_ptr[T.lvl_off + l];
+            most = std::max(most, nf);
+            over += nf > 16;
+            ++lv;
+          }
+        }
+        std::fprintf(stderr, "ldlt fronts round %d: deepest task %u levels, most fronts in a level %u, levels with more than 16 fronts %u of %u\n",
+                     r, deepest, most, over, lv);
       }
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u)\n",
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib);

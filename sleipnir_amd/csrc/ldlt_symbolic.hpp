@@ -221,6 +221,12 @@ struct LdltOptions {
   uint32_t hub_floor = 24;
   // also build the multifrontal plan (LdltFront) next to the pair lists
   bool multifrontal = false;
+  // Relaxed supernodes: a supernode whose parent column heads another one may join it at the price of
+  // explicit zeros in L (its columns take the structure of the other's) — at most this many per
+  // merge, only for the child on the deepest path below its parent, within the width and row
+  // limits.  A dense front three columns wider costs a fraction of the levels it replaces
+  // (profiles/microbench/front.hip); 0 = exact structures only.
+  int relax_zeros = 0;
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

@@ -56,8 +56,10 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
       if (env == nullptr || env[0] != '0') {
         lopt.multifrontal = true;
         lopt.min_supernode_width = 2;
+        lopt.relax_zeros = 8;
       }
     }
+    if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
     // One problem (or a handful: the same plan, so that a small batch and single problems agree to
     // the bit), smaller than the BASELINE horizon: smaller tasks (less plan to stage per

@@ -141,7 +141,9 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
     if (env[0] != '0') {
       lopt.multifrontal = true;
       if (std::getenv("SLPX_SN_MIN_WIDTH") == nullptr) lopt.min_supernode_width = 2;
+      lopt.relax_zeros = 8;
     }
+  if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
   h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);

@@ -459,6 +459,8 @@ class DeviceNlp {
   uint32_t m_factor_solve_lds = 0;
   // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
   bool m_mf = false;
+  int m_mf_threads = 1024;            // 512 where the 1024-thread workgroups of every task are not resident at once
+  bool m_sip_ok = false;              // the pair-list one-launch kernel is usable too (build_solve_in_place)
   uint32_t m_mf_lds = 0;
   // host copies of the inline KKT / back-substitution plans (build_mf packs them into the task images)
   std::vector<int32_t> m_h_vsrc;

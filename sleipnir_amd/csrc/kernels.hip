@@ -518,8 +518,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (m_fuse_backsub) build_inline_backsub(k, l);
   m_fuse_solve = m_fuse_launches && m_fuse_backsub;
   if (const char* env = std::getenv("SLPX_FUSE_SOLVE")) m_fuse_solve = m_fuse_solve && env[0] != '0';
+  const bool want_one_launch = m_fuse_solve;
   if (m_fuse_solve) build_solve_in_place(l);
-  if (m_fuse_solve && m_fuse_kkt && l.mf) build_mf(l);
+  m_sip_ok = m_fuse_solve;
+  if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
+  if (m_mf) m_fuse_solve = true;
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -1037,10 +1040,14 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
     put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
     put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
     put(cv.o_src, m_h_vsrc.data() + t.ent_off, 4u * t.n_ent);
-    put(cv.o_col, l.ent_col.data() + t.ent_off, 2u * t.n_ent);
-    put(cv.o_flags, l.ent_flags.data() + t.ent_off, t.n_ent);
-    put(cv.o_out, l.ent_out.data() + t.ent_off, 4u * t.n_ent);
-    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (t.n_ent + 1));
+    {
+      // (bit 5: the entry takes update slots)
+      std::vector<uint8_t> fl(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
+      for (uint32_t j = 0; j < m.n_cent; ++j) fl[l.mf_cent[m.cent_off + j]] |= 0x20;
+      put(cv.o_flags, fl.data(), t.n_ent);
+    }
+    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
+    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
     put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
     put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
     put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
@@ -1061,21 +1068,28 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   lds = mf_align16(lds) + 16u;
   int per_cu = 0, cus = 0;
   hipFuncAttributes attr{};
+  bool fits = false;
   if (lds <= 160u * 1024u) {
-    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_mf_step_kernel<kFactorThreadsSingle>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ldlt_mf_step_kernel<kFactorThreadsSingle>)));
-    SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ldlt_mf_step_kernel<kFactorThreadsSingle>,
-                                                                kFactorThreadsSingle, lds));
     SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+    auto resident = [&](auto kernel, int threads) {
+      SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)));
+      SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+      // (the tables hold LDS byte addresses from 0: no static LDS in front of the dynamic block)
+      return attr.sharedSizeBytes == 0 && l.tasks.size() + m_reduces.n <= static_cast<size_t>(per_cu) * cus;
+    };
+    m_mf_threads = 1024;
+    fits = resident(&ldlt_mf_step_kernel<1024>, 1024);
+    if (const char* env = std::getenv("SLPX_MF_THREADS")) fits = fits && std::atoi(env) == 1024;
+    if (!fits) {
+      m_mf_threads = 512;
+      fits = resident(&ldlt_mf_step_kernel<512>, 512);
+    }
   }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt multifrontal step: %zu tasks, LDS %u bytes (static %zu), images %zu bytes, %d workgroup(s) per CU x %d CUs\n",
-                 l.tasks.size(), lds, attr.sharedSizeBytes, 16 * image.size(), per_cu, cus);
-  // (the tables hold LDS byte addresses from 0: no static LDS in front of the dynamic block)
-  if (lds > 160u * 1024u || attr.sharedSizeBytes != 0 ||
-      l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus)
-    return;
+    std::fprintf(stderr, "ldlt multifrontal step: %zu tasks, LDS %u bytes (static %zu), images %zu bytes, %d workgroup(s) of %d threads per CU x %d CUs%s\n",
+                 l.tasks.size(), lds, attr.sharedSizeBytes, 16 * image.size(), per_cu, m_mf_threads, cus, fits ? "" : ": NOT resident at once");
+  if (!fits) return;
   m_mf_tasks.upload(l.mf_tasks);
   m_mf_fronts.upload(l.mf_fronts);
   m_mf_image.upload(image);
@@ -1325,7 +1339,10 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
 
 void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
                                      const std::vector<uint8_t>& active) {
-  if (!m_fuse_solve) {
+  // (the multifrontal step hands x over through the two x buffers: not inside a captured graph; the
+  // pair-list one-launch kernel needs every task's 1024-thread workgroup resident at once)
+  const bool mf_now = m_mf && xg_other() != nullptr;
+  if (!m_fuse_solve || (!mf_now && !m_sip_ok)) {
     factor(delta, gamma, active);
     solve_backsub_publish();
     return;
@@ -1344,7 +1361,7 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
   LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1);
   KktFuse f = take_kkt_fuse();
   BacksubFuse bf = backsub_fuse(cur);
-  if (m_mf && f.inline_kkt && xg_other() != nullptr) {
+  if (m_mf && xg_other() != nullptr) {
     MfDev md;
     md.tasks = m_mf_tasks.p;
     md.fronts = m_mf_fronts.p;
@@ -1352,10 +1369,13 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
     md.image_desc = m_mf_image_desc.p;
     md.n_tasks = static_cast<unsigned int>(l.tasks.size());
     md.exit_cnt = m_exit_cnt.p;
-    hipLaunchKernelGGL(ldlt_mf_step_kernel<kFactorThreadsSingle>,
-                       dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
-                       dim3(kFactorThreadsSingle), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
-                       l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
+    const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
+    if (m_mf_threads == 1024)
+      hipLaunchKernelGGL(ldlt_mf_step_kernel<1024>, grid, dim3(1024), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg,
+                         m_Lx.p, m_D.p, l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
+    else
+      hipLaunchKernelGGL(ldlt_mf_step_kernel<512>, grid, dim3(512), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg,
+                         m_Lx.p, m_D.p, l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
     xg_flip();
     SLPX_HIP_CHECK(hipGetLastError());
     return;
@@ -1454,7 +1474,7 @@ void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& de
       if (refresh_ad) sweep_full(/*with_reduce=*/false);
       build_kkt_for_step(/*with_reduce=*/refresh_ad);
     }
-    if (m_fuse_solve) {
+    if (m_fuse_solve && m_sip_ok) {
       enqueue_factor_solve(m_stats_cur);
     } else {
       enqueue_factor(m_stats_cur, cap);

@@ -314,11 +314,11 @@ __device__ __forceinline__ void mf_solve_front(uint32_t xr, uint32_t u0, uint32_
 // update slots and, in the solve, through x itself: every workgroup must be resident).
 // LDS (bytes; the first four regions are what the tables address, so they start at 0):
 //   U[n_ent] f64 | arena f64 | 1/d[n_col] f64 | x[n_col + n_anc + 1] f64 |
-//   tables u16 | levels u32 | ext u32 | src i32 | col u16 | flags u8 | out u32 | cptr u32 | cidx u32 |
+//   tables u16 | levels u32 | ext u32 | src i32 | flags u8 | entries with update slots u16 | their slot ranges u32 | slots u32 |
 //   colperm u32 | anc u32 | counters 32 B | KKT terms + products | back-substitution rows
 // ---------------------------------------------------------------------------
 struct MfCarve {
-  uint32_t o_arena, o_invd, o_x, o_tab, o_lvl, o_ext, o_src, o_col, o_flags, o_out, o_cptr, o_cidx, o_cp, o_anc,
+  uint32_t o_arena, o_invd, o_x, o_tab, o_lvl, o_ext, o_src, o_flags, o_cent, o_cptr, o_cidx, o_cp, o_anc,
       o_cnt, o_terms;
 };
 __host__ __device__ inline uint32_t mf_align16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -332,11 +332,10 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
   c.o_lvl = c.o_tab + q(m.n_tab, 8);
   c.o_ext = c.o_lvl + q(t.n_lvl + 1u, 4);
   c.o_src = c.o_ext + q(m.n_ext, 4);
-  c.o_col = c.o_src + q(t.n_ent, 4);
-  c.o_flags = c.o_col + q(t.n_ent, 8);
-  c.o_out = c.o_flags + q(t.n_ent, 16);
-  c.o_cptr = c.o_out + q(t.n_ent, 4);
-  c.o_cidx = c.o_cptr + q(t.n_ent + 1u, 4);
+  c.o_flags = c.o_src + q(t.n_ent, 4);
+  c.o_cent = c.o_flags + q(t.n_ent, 16);
+  c.o_cptr = c.o_cent + q(m.n_cent, 8);
+  c.o_cidx = c.o_cptr + q(m.n_cent + 1u, 4);
   c.o_cp = c.o_cidx + q(m.n_contrib_idx, 4);
   c.o_anc = c.o_cp + q(t.n_col, 4);
   c.o_cnt = c.o_anc + q(m.n_anc, 4);
@@ -372,9 +371,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
   const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
   const int32_t* src = reinterpret_cast<const int32_t*>(smem_raw + cv.o_src);
-  const uint16_t* col = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_col);
   const uint8_t* flags = reinterpret_cast<const uint8_t*>(smem_raw + cv.o_flags);
-  const uint32_t* eout = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_out);
+  const uint16_t* cent = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_cent);
   const uint32_t* cptr = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cptr);
   const uint32_t* cidx = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cidx);
   const uint32_t* colperm = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cp);
@@ -420,8 +418,10 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
 
   // ---- matrix values (ldlt_factor_body) ----
   if (!F.inline_kkt) {
+    // (a re-attempt of the policy loop on the system already in memory: the image holds what every
+    // entry is MADE of, where it sits in lhs / rhs comes from the plan in memory)
     for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-      const int32_t s0 = src[i];
+      const int32_t s0 = L.ent_src[t.ent_off + i];
       const double* base = (flags[i] & 4) ? rhs : lhs;
       U[i] = s0 >= 0 ? base[s0] : 0.0;
     }
@@ -455,10 +455,15 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   __syncthreads();
   // ---- regularization + update blocks of child tasks (slots: ldlt_factor_body) ----
+  // (flag bit 5, set in the task's image only: the entry takes update slots and is handled below)
   for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
     const uint8_t fl = flags[i];
-    const uint32_t cb = cptr[i], ce = cptr[i + 1];
-    if (!(fl & 1) && cb == ce) continue;
+    if ((fl & 0x21) == 1) U[i] += (fl & 2) ? -gamma : delta;
+  }
+  for (uint32_t j = tid; j < m.n_cent; j += THREADS) {
+    const uint32_t i = cent[j];
+    const uint8_t fl = flags[i];
+    const uint32_t cb = cptr[j], ce = cptr[j + 1];
     double acc = U[i];
     if (fl & 1) acc += (fl & 2) ? -gamma : delta;
     for (uint32_t c = cb; c < ce; c += 4) {
@@ -524,9 +529,32 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   SLPX_LDLT_CLOCK(3);
   SLPX_LDLT_CLOCK(4);
-  FactorKeep keep{U, invd, col, flags, eout, s_cnt, s_minp};
+  // results + inertia (ldlt_factor_exit; where an entry goes and whose 1/d scales it: streamed from the
+  // plan in memory — off the critical path, and 6 bytes per entry that need not sit in LDS)
   auto exit_and_count = [&] {
-    ldlt_factor_exit<THREADS>(keep, t, 0, Lx, D, zv, stats);
+    const uint32_t* g_out = L.ent_out + t.ent_off;
+    const uint16_t* g_col = L.ent_col + t.ent_off;
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const double u = U[i];
+      const uint8_t fl = flags[i];
+      const uint32_t o = g_out[i];
+      if (fl & 1) {
+        D[o] = u;
+        const double eps = 2.220446049250313e-16;
+        if (u > eps) atomicAdd(&s_cnt[0], 1);
+        else if (u < -eps) atomicAdd(&s_cnt[1], 1);
+        else atomicAdd(&s_cnt[2], 1);
+        if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
+        else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
+      } else if (fl & 4) {
+        zv[o] = u * invd[g_col[i]];  // z = D⁻¹L⁻¹Pb: the forward solve came for free
+      } else {
+        Lx[o] = u * invd[g_col[i]];
+      }
+    }
+    __syncthreads();
+    if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[0]) + tid, s_cnt[tid]);
+    if (tid == 0) atomicMin(&stats[0].min_abs_bits, *s_minp);
     if (threadIdx.x == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
       const unsigned int old = __hip_atomic_fetch_add(Mf.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

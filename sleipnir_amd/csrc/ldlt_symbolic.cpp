@@ -1049,15 +1049,21 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       const int t = torder[ti];
       LdltMfTask& M = P.mf_tasks[ti];
       while (P.mf_contrib_ptr.size() % 4) P.mf_contrib_ptr.push_back(0);
+      while (P.mf_cent.size() % 8) P.mf_cent.push_back(0);
       M.contrib_ptr_off = static_cast<uint32_t>(P.mf_contrib_ptr.size());
       M.contrib_off = static_cast<uint32_t>(P.mf_contrib_idx.size());
-      uint32_t count = 0;
+      M.cent_off = static_cast<uint32_t>(P.mf_cent.size());
+      uint32_t count = 0, n_cent = 0;
       for (uint32_t e = 0; e < task_nent[t]; ++e) {
+        if (mcontrib[t][e].empty()) continue;
+        P.mf_cent.push_back(static_cast<uint16_t>(e));
         P.mf_contrib_ptr.push_back(count);
         for (uint32_t s : mcontrib[t][e]) P.mf_contrib_idx.push_back(s);
         count += static_cast<uint32_t>(mcontrib[t][e].size());
+        ++n_cent;
       }
       P.mf_contrib_ptr.push_back(count);
+      M.n_cent = n_cent;
       M.n_contrib_idx = count;
       while (P.mf_contrib_idx.size() % 4) P.mf_contrib_idx.push_back(0);
     }
@@ -1067,6 +1073,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       P.mf_ext.push_back(0);
       P.mf_contrib_ptr.push_back(0);
       P.mf_contrib_idx.push_back(0);
+      P.mf_cent.push_back(0);
       P.mf_anc.push_back(0);
       P.mf_lvl_ptr.push_back(0);
       P.mf_fronts.push_back(LdltFront{});

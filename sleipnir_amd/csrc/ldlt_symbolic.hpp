@@ -108,7 +108,10 @@ struct LdltMfTask {
   uint32_t front_off, n_front;   // slice of mf_fronts (level order; mf_lvl_ptr shares LdltTask::lvl_off)
   uint32_t tab_off, n_tab;       // slice of mf_tab, 16-bit words (padded to 8)
   uint32_t ext_off, n_ext;       // slice of mf_ext (padded to 4)
-  uint32_t contrib_ptr_off;      // mf_contrib_ptr: n_ent + 1 entries
+  // update slots from child tasks: only the entries that take any (n_cent of them, mf_cent: local entry
+  // indices, padded to 8; mf_contrib_ptr: n_cent + 1, padded to 4), their slots in mf_contrib_idx
+  uint32_t cent_off, n_cent;
+  uint32_t contrib_ptr_off;
   uint32_t contrib_off, n_contrib_idx;  // slice of mf_contrib_idx (padded to 4)
   uint32_t anc_off, n_anc;       // slice of mf_anc: rows of ancestor tasks its fronts reach (permuted indices)
   uint32_t arena;                // doubles: 0.0, scratch, update blocks
@@ -183,6 +186,7 @@ struct LdltPlan {
   std::vector<uint16_t> mf_tab;
   std::vector<uint32_t> mf_ext;
   std::vector<uint32_t> mf_contrib_ptr, mf_contrib_idx;
+  std::vector<uint16_t> mf_cent;
   std::vector<uint32_t> mf_anc;
   uint32_t mf_n_contrib = 0;
   uint32_t mf_max_nch = 0, mf_max_front_rows = 0;

@@ -348,15 +348,17 @@ static void hc_factor_mf(hc_handle* h, double delta, double gamma) {
       auto at = [&](uint16_t byte_off) -> double& { return lds[byte_off / 8u]; };
       const uint32_t* cptr = L.mf_contrib_ptr.data() + M.contrib_ptr_off;
       const uint32_t* cidx = L.mf_contrib_idx.data() + M.contrib_off;
+      const uint16_t* cent = L.mf_cent.data() + M.cent_off;
       for (uint32_t i = 0; i < t.n_ent; ++i) {
         const uint32_t e = t.ent_off + i;
         const int32_t src = L.ent_src[e];
         const uint8_t fl = L.ent_flags[e];
         double acc = src >= 0 ? ((fl & 4) ? h->rhs[src] : h->lhs[src]) : 0.0;
         if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-        for (uint32_t c = cptr[i]; c < cptr[i + 1]; ++c) acc -= h->mf_contrib[cidx[c]];
         lds[i] = acc;
       }
+      for (uint32_t j = 0; j < M.n_cent; ++j)
+        for (uint32_t c = cptr[j]; c < cptr[j + 1]; ++c) lds[cent[j]] -= h->mf_contrib[cidx[c]];
       const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
       const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
       const uint32_t* ext = L.mf_ext.data() + M.ext_off;

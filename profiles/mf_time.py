@@ -2,7 +2,7 @@
 """Back-to-back launches of a single problem's step (slpx_system_time_fused_step): tape sweep and
 the factor + solve launch, for A/B runs on ONE box (SLPX_LIB=<other build>, SLPX_LDLT_MF=0, ...).
 
-    PYTHONPATH=$PWD python profiles/mf_time.py [N ...]
+    PYTHONPATH=$PWD python profiles/mf_time.py [N ... | gfold]
 """
 import sys
 
@@ -11,9 +11,16 @@ import numpy as np
 import sleipnir_amd as sa
 from tests.support import cases
 
-for N in [int(a) for a in sys.argv[1:]] or [1000]:
+for arg in sys.argv[1:] or ["1000"]:
     sa.lib().slpx_graph_reset()
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    if arg == "gfold":
+        from tests.support import gfold, model
+
+        N = "g-fold N=100"
+        pp = gfold.build(model.Model(model.ProductBackend("gpu")), 100).p
+    else:
+        N = int(arg)
+        pp = sa.Problem.cart_pole(N, 5.0 / N)
     sy = sa.System(pp, batch=1, device=0)
     n, me, mi = sy.info["n"], sy.info["m_e"], sy.info["m_i"]
     x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)

@@ -92,10 +92,92 @@ __device__ __forceinline__ uint32_t mf_coff(uint32_t c, uint32_t nr) { return 8u
 // ---------------------------------------------------------------------------
 constexpr int kMfNchAny = 3;
 
+// ---------------------------------------------------------------------------
+// The update block on the MATRIX CORES (fronts flagged by the plan: at least four pivot columns under
+// more rows than two lane-per-entry passes cover — the separator chains of the g-fold problem).
+// S(a, b) for a in R + rhs, b in R, b <= a, in 16 x 16 tiles of v_mfma_f64_16x16x4_f64:
+//   A operand (lane i + 16 k) = −L(R_{16 I + i}, 4 kb + k) = −U / d,   B operand (lane j + 16 k) = U(R_{16 J + j}, 4 kb + k),
+//   C / D: column = lane & 15, row = (lane >> 4) + 4 q, q = 0..3 — C preloaded with the children's values
+// (same update table as the lane-per-entry path: entry e = a (a + 1) / 2 + b).  One row of tiles at a
+// time keeps the accumulators at four tiles (32 registers).  `u0`: LDS byte address of the front's
+// first entry; the finished columns and 1/d are read back from LDS, where the pivots left them.
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void mf_update_mfma(uint32_t u0, uint32_t nr, uint32_t nch, bool root, uint32_t upd,
+                                               uint32_t ustride, uint32_t invd_addr, const uint32_t* __restrict__ ext,
+                                               double* __restrict__ contrib, uint32_t lane) {
+  const uint32_t r = nr - W - 1u;
+  const uint32_t li = lane & 15u, lk = lane >> 4;
+  const uint32_t nb = (r + 1u + 15u) / 16u;  // row blocks over R + rhs (<= 4)
+  constexpr int KB = (W + 3) / 4;
+  // the B operands of every column block and pivot block (U of rows 16 J + li, column 4 kb + lk)
+  double pB[4][KB], invc[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const uint32_t c = 4u * kb + lk;
+    const bool cok = c < static_cast<uint32_t>(W);
+    const uint32_t cc = cok ? c : W - 1u;
+    const uint32_t diag = u0 + 8u * (cc * nr - (cc * (cc - 1u)) / 2u);
+    invc[kb] = lds_ld(invd_addr + 8u * cc);
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      const uint32_t t = W + 16u * J + li;
+      const bool ok = cok && t < nr;
+      const double u = lds_ld(diag + 8u * ((ok ? t : static_cast<uint32_t>(W)) - cc));
+      pB[J][kb] = ok ? u : 0.0;
+    }
+  }
+  for (uint32_t I = 0; I < nb; ++I) {
+    f64x4 acc[4];
+    uint32_t ent[4][4];
+    // children's values -> C
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      acc[J] = f64x4{0.0, 0.0, 0.0, 0.0};
+      if (static_cast<uint32_t>(J) > I) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a = 16u * I + lk + 4u * q, b = 16u * J + li;
+        const bool ok = b < r && b <= a && a <= r;
+        ent[J][q] = ok ? upd + __umul24((a * (a + 1u)) / 2u + b, ustride) : 0xffffffffu;
+        double v = 0.0;
+        for (uint32_t k = 0; k < nch; ++k) v += lds_ld(lds_ld16((ok ? ent[J][q] : upd) + 6u + 2u * k));
+        acc[J][q] = ok ? v : 0.0;
+      }
+    }
+    // rank-W update of this row of tiles
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      // A operand of row block I: the same entries as the B operand of column block I, scaled
+      double pa = 0.0;
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+        if (static_cast<uint32_t>(J) == I) pa = pB[J][kb];
+      const double ma = -(pa * invc[kb]);
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+        if (static_cast<uint32_t>(J) <= I) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, pB[J][kb], acc[J], 0, 0, 0);
+    }
+    // out
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      if (static_cast<uint32_t>(J) > I) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ent[J][q] != 0xffffffffu) {
+          const uint32_t o = lds_ld16(ent[J][q]);
+          if (root) coherent_store(&contrib[ext[o]], -acc[J][q], true);
+          else lds_st(o, acc[J][q]);
+        }
+    }
+  }
+}
+
 template <int W, int NCH>
-__device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, bool root,
+__device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, uint32_t fl,
                                            uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                            double* __restrict__ contrib, uint32_t lane) {
+  const bool root = (fl & 1u) != 0;
   constexpr bool kAny = NCH == kMfNchAny;
   constexpr int kN = kAny ? 0 : NCH;  // children handled in registers; the rest (kAny) by loops
   const uint32_t row = lane < nr ? lane : nr - 1u;  // (idle lanes shadow the last row: same loads, same stores)
@@ -166,6 +248,13 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
 #pragma unroll
   for (int c = 0; c < W; ++c) lds_st(invd_addr + 8u * c, inv[c]);  // (every lane the same value)
   if (n_s == 0) return;
+  if constexpr (W >= 4) {
+    if (fl & 2u) {  // (wave-uniform)
+      const uint32_t u0 = __builtin_amdgcn_readfirstlane(ua[0]);  // lane 0 holds row 0
+      mf_update_mfma<W>(u0, nr, nch, root, upd, ustride, invd_addr, ext, contrib, lane);
+      return;
+    }
+  }
   // ---- trip 3: the update block, a lane per entry ----
   {
     double ra[W], rb[W];
@@ -208,7 +297,7 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
 }
 
 template <int W>
-__device__ __forceinline__ void mf_front_nch(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, bool root,
+__device__ __forceinline__ void mf_front_nch(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, uint32_t root,
                                              uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                              double* __restrict__ contrib, uint32_t lane) {
   // (code size and register pressure: the in-register children only where they are common)
@@ -239,7 +328,7 @@ __device__ __forceinline__ void mf_front(uint32_t tab, uint32_t w, uint32_t nr, 
   root = __builtin_amdgcn_readfirstlane(root);
   invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
   switch (w) {
-#define SLPX_MF_CASE(W) case W: mf_front_nch<W>(tab, nr, nch, n_s, root != 0, invd_addr, ext, contrib, lane); break;
+#define SLPX_MF_CASE(W) case W: mf_front_nch<W>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
     SLPX_MF_CASE(1) SLPX_MF_CASE(2) SLPX_MF_CASE(3) SLPX_MF_CASE(4) SLPX_MF_CASE(5) SLPX_MF_CASE(6) SLPX_MF_CASE(7)
     SLPX_MF_CASE(8)
 #undef SLPX_MF_CASE
@@ -517,7 +606,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
       const uint32_t next_end = __builtin_amdgcn_readfirstlane(lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl]);
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
         if (q != beg + wave) d = s_load_desc(gfr + q);
-        const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 1u;
+        const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
         mf_front(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
                  contrib, lane);
       }

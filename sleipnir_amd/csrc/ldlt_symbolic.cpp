@@ -990,7 +990,11 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         F.nch = static_cast<uint8_t>(nch);
         F.n_s = static_cast<uint16_t>(f.n_s);
         const bool root = f.parent < 0;
-        F.flags = root ? 1 : 0;
+        // the update block on the matrix cores: four pivot columns or more under more entries than two
+        // lane-per-entry passes cover (ldlt_mf_kernels.h: mf_update_mfma)
+        const bool mfma = w >= 4 && f.n_s > opt.mfma_min_entries;
+        F.flags = static_cast<uint8_t>((root ? 1 : 0) | (mfma ? 2 : 0));
+        P.mf_n_mfma += mfma;
         F.ext = static_cast<uint16_t>(n_ext);
         if (root && n_ext + f.n_s > 0xffffu) {
           ok = false;
@@ -1112,8 +1116,8 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         std::fprintf(stderr, "ldlt fronts round %d: deepest task %u levels, most fronts in a level %u, levels with more than 16 fronts %u of %u\n",
                      r, deepest, most, over, lv);
       }
-      std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u)\n",
-                   ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib);
+      std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u), fronts on the matrix cores %u\n",
+                   ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib, P.mf_n_mfma);
     }
   }
 

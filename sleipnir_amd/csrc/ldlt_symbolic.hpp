@@ -189,7 +189,7 @@ struct LdltPlan {
   std::vector<uint16_t> mf_cent;
   std::vector<uint32_t> mf_anc;
   uint32_t mf_n_contrib = 0;
-  uint32_t mf_max_nch = 0, mf_max_front_rows = 0;
+  uint32_t mf_max_nch = 0, mf_max_front_rows = 0, mf_n_mfma = 0;
 
   // traffic model: factor = 12k + 16ℓ, solve = 32ℓ + 16 n
   int64_t factor_bytes = 0, solve_bytes = 0;
@@ -231,6 +231,8 @@ struct LdltOptions {
   // limits.  A dense front three columns wider costs a fraction of the levels it replaces
   // (profiles/microbench/front.hip); 0 = exact structures only.
   int relax_zeros = 0;
+  // a front's update block goes to the matrix cores from this many entries (and four pivot columns) up
+  uint32_t mfma_min_entries = 400;  // (measured on g-fold N=100: 128 -> 78.8 us, 300 -> 68.4, 400 -> 67.3, never -> 67.7)
 };
 
 // `lower` = lower-triangular CSC pattern with a full diagonal (KktPlan::lhs).

@@ -60,6 +60,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
       }
     }
     if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
+    if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
     // One problem (or a handful: the same plan, so that a small batch and single problems agree to
     // the bit), smaller than the BASELINE horizon: smaller tasks (less plan to stage per

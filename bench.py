@@ -152,9 +152,11 @@ def kernel_groups(system, iters):
     kt = system.time_step(iters=iters, refresh_ad=True)
     nf = max(1.0, kt["factorizations"])
     return kt, nf, {
-        # the tape program (static, read once per sweep) belongs to the sweep's bytes just
-        # like the index maps belong to kkt_assemble's
-        "tape_sweep": (kt["sweep"], info["sweep_bytes"] + info["tape_program_bytes"]),
+        # SURVEY.md §8d's AD-refresh figure: read 8 (n + m_e + m_i), write 8 x (nnz of the outputs),
+        # per problem.  (r02 added the interpreted tape program's bytes here and multiplied them by
+        # the batch: the generated kernel has the program compiled in, and a batch shares whatever
+        # is left of it — VERDICT r02 item 9.)
+        "tape_sweep": (kt["sweep"], info["sweep_bytes"]),
         "kkt_assemble": (kt["assemble"], info["assemble_bytes"]),
         "kkt_rhs": (kt["rhs"], info["rhs_bytes"]),
         "ldlt_factor": (kt["factor"] / nf, info["factor_bytes"]),
@@ -194,6 +196,9 @@ def batched_probe(sa, cases, N, B, device):
                                    if kname.startswith(pres) for grid, e in grids.items()
                                    if not (kname.startswith(("slpx_tape_templates", "tape_")) and int(grid) < 100000))
                           for grp, pres in pre.items()}
+        # the same fractions on the bytes the PMC counters saw (committed pass, this run's times)
+        out["hbm_frac_pmc"] = {k: out["traffic"][k] / (gb[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                               for k in gb if out["traffic"].get(k)}
     sysb.close()
     pp.close()
     return out
@@ -322,6 +327,7 @@ def main():
         }
         # A single problem's step is two launches (the AD sweep; KKT evaluation + factorization +
         # backward solve + back-substitution in one: csrc/device.hpp KktFuse / BacksubFuse,
+        # ldlt_mf_step_kernel — the multifrontal step — or, SLPX_LDLT_MF=0, the pair-list
         # ldlt_factor_solve_kernel); the second one's algorithmic bytes are the SURVEY.md §8d
         # figures of the stages it performs.  `groups` (the stages as kernels of their own)
         # stays in the line as per_kernel_ms: it is what batches run and what the step falls
@@ -347,7 +353,7 @@ def main():
         if tfile.exists() and args.workload == "single" and N == 1000 and B == 1:
             tj = json.loads(tfile.read_text())
             prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates"),
-                      "kkt_factor_solve": "ldlt_factor_solve_kernel",
+                      "kkt_factor_solve": ("ldlt_mf_step_kernel", "ldlt_factor_solve_kernel"),
                       "kkt_assemble": "kkt_assemble_kernel",
                       "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
                       "ldlt_solve": ("ldlt_fwd", "ldlt_bwd")}
@@ -358,7 +364,10 @@ def main():
                                             if kname.startswith(pres) for e in grids.values())
         single = args.workload in ("single", "gfold") and B == 1
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": dom,
+            "kernel_symbol": (("ldlt_mf_step_kernel" if fused.get("multifrontal") else "ldlt_factor_solve_kernel")
+                              if fused is not None and dom.startswith("kkt_factor") and fused["one_launch"] else None),
+            "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None if traffic_by_group is None else traffic_by_group.get(dom),
             "traffic_per_kernel": traffic_by_group,

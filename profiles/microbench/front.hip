@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512) void k_front(long long* clk, const double* img
     const long long t0 = clock64();
     if (wave < static_cast<uint32_t>(waves) && sh.w != 0) {
       const uint32_t tb = oTab + 2u * wave * words;
-      if (mode & 1) mf_front(tb, sh.w, sh.nr, sh.nch, sh.n_s, 0u, oInvd + 64u * wave, nullptr, nullptr, lane);
+      if (mode & 1) mf_front<false>(tb, sh.w, sh.nr, sh.nch, sh.n_s, 0u, oInvd + 64u * wave, nullptr, nullptr, lane);
       if (mode & 2)
         mf_solve_front(tb + 2u * (sh.nr * (1 + sh.nch) * sh.w + sh.n_s * (3 + sh.nch)), 8u * kU * wave, sh.w, sh.nr,
                        oInvd + 64u * wave, oX + 8u * kX * wave, lane);

@@ -459,6 +459,7 @@ class DeviceNlp {
   uint32_t m_factor_solve_lds = 0;
   // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
   bool m_mf = false;
+  bool m_mf_mfma = false;             // the plan has fronts on the matrix cores: the kernel variant with that path
   int m_mf_threads = 1024;            // 512 where the 1024-thread workgroups of every task are not resident at once
   bool m_sip_ok = false;              // the pair-list one-launch kernel is usable too (build_solve_in_place)
   uint32_t m_mf_lds = 0;
@@ -470,6 +471,7 @@ class DeviceNlp {
   std::vector<uint4> m_h_bs_task_plan;
   DevBuf<LdltMfTask> m_mf_tasks;
   DevBuf<LdltFront> m_mf_fronts;
+  uint32_t m_mf_image_stride16 = 0;
   DevBuf<uint4> m_mf_image;        // per task: everything static it keeps in LDS, in LDS order (one copy loop)
   DevBuf<uint4> m_mf_image_desc;   // per task {first 16-byte group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   DevBuf<double> m_mf_contrib;

@@ -1023,6 +1023,7 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   // one copy loop with every load in flight is a single trip.
   uint32_t lds = 0;
   std::vector<uint4> image, desc(l.tasks.size());
+  std::vector<std::vector<unsigned char>> blobs;
   for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
     const LdltTask& t = l.tasks[ti];
     const LdltMfTask& m = l.mf_tasks[ti];
@@ -1060,11 +1061,15 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
         16u * terms16);
     put(end_terms, reinterpret_cast<const unsigned char*>(m_h_bs_plan.data()) + 16u * static_cast<size_t>(m_h_bs_task_plan[ti].x),
         16u * bs16);
-    desc[ti] = uint4{static_cast<uint32_t>(image.size()), (end_terms - cv.o_tab) / 16u, bs16, terms16};
-    const size_t at = image.size();
-    image.resize(at + blob.size() / 16u);
-    std::memcpy(image.data() + at, blob.data(), blob.size());
+    desc[ti] = uint4{0u, (end_terms - cv.o_tab) / 16u, bs16, terms16};
+    blobs.push_back(std::move(blob));
   }
+  // fixed-size slots (the kernel requests a task's image before it knows its length) + one round of padding
+  size_t stride16 = 1;
+  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
+  if (stride16 > kMfImageGroups) return;  // (a task image beyond what the staging loop requests)
+  image.assign(stride16 * blobs.size() + kMfImageGroups, uint4{0, 0, 0, 0});
+  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
   lds = mf_align16(lds) + 16u;
   int per_cu = 0, cus = 0;
   hipFuncAttributes attr{};
@@ -1078,12 +1083,13 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
       // (the tables hold LDS byte addresses from 0: no static LDS in front of the dynamic block)
       return attr.sharedSizeBytes == 0 && l.tasks.size() + m_reduces.n <= static_cast<size_t>(per_cu) * cus;
     };
+    m_mf_mfma = l.mf_n_mfma > 0;
     m_mf_threads = 1024;
-    fits = resident(&ldlt_mf_step_kernel<1024>, 1024);
+    fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<1024, true>, 1024) : resident(&ldlt_mf_step_kernel<1024, false>, 1024);
     if (const char* env = std::getenv("SLPX_MF_THREADS")) fits = fits && std::atoi(env) == 1024;
     if (!fits) {
       m_mf_threads = 512;
-      fits = resident(&ldlt_mf_step_kernel<512>, 512);
+      fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<512, true>, 512) : resident(&ldlt_mf_step_kernel<512, false>, 512);
     }
   }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
@@ -1093,6 +1099,7 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   m_mf_tasks.upload(l.mf_tasks);
   m_mf_fronts.upload(l.mf_fronts);
   m_mf_image.upload(image);
+  m_mf_image_stride16 = static_cast<uint32_t>(stride16);
   m_mf_image_desc.upload(desc);
   m_mf_contrib.upload(std::vector<double>(std::max<uint32_t>(1, l.mf_n_contrib), std::bit_cast<double>(kSlotEmpty)));
   if (m_exit_cnt.n == 0) m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
@@ -1366,16 +1373,17 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
     md.tasks = m_mf_tasks.p;
     md.fronts = m_mf_fronts.p;
     md.image = m_mf_image.p;
+    md.image_stride16 = m_mf_image_stride16;
     md.image_desc = m_mf_image_desc.p;
     md.n_tasks = static_cast<unsigned int>(l.tasks.size());
     md.exit_cnt = m_exit_cnt.p;
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
-    if (m_mf_threads == 1024)
-      hipLaunchKernelGGL(ldlt_mf_step_kernel<1024>, grid, dim3(1024), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg,
-                         m_Lx.p, m_D.p, l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
-    else
-      hipLaunchKernelGGL(ldlt_mf_step_kernel<512>, grid, dim3(512), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg,
-                         m_Lx.p, m_D.p, l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
+    auto launch = [&](auto kernel, int threads) {
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
+                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
+    };
+    if (m_mf_threads == 1024) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false>, 1024);
+    else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true>, 512) : launch(&ldlt_mf_step_kernel<512, false>, 512);
     xg_flip();
     SLPX_HIP_CHECK(hipGetLastError());
     return;

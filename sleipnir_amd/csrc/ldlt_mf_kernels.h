@@ -41,7 +41,8 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 struct MfDev {
   const LdltMfTask* tasks = nullptr;
   const LdltFront* fronts = nullptr;
-  const uint4* image = nullptr;       // per task: its static LDS content in LDS order (DeviceNlp::build_mf)
+  const uint4* image = nullptr;       // per task: its static LDS content in LDS order (DeviceNlp::build_mf), one fixed-size slot each
+  uint32_t image_stride16 = 0;        // slot size in 16-byte groups
   const uint4* image_desc = nullptr;  // per task {first group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   unsigned int n_tasks = 0;
   unsigned int* exit_cnt = nullptr;  // workgroups through their exit phase (the last one publishes)
@@ -91,6 +92,7 @@ __device__ __forceinline__ uint32_t mf_coff(uint32_t c, uint32_t nr) { return 8u
 // as a compile-time constant (0, 1, 2) or kMfNchAny: a run-time loop.
 // ---------------------------------------------------------------------------
 constexpr int kMfNchAny = 3;
+constexpr uint32_t kMfImageGroups = 6144;  // 16-byte groups of a task's image the staging loop requests: 96 KB
 
 // ---------------------------------------------------------------------------
 // The update block on the MATRIX CORES (fronts flagged by the plan: at least four pivot columns under
@@ -102,10 +104,19 @@ constexpr int kMfNchAny = 3;
 // time keeps the accumulators at four tiles (32 registers).  `u0`: LDS byte address of the front's
 // first entry; the finished columns and 1/d are read back from LDS, where the pivots left them.
 // ---------------------------------------------------------------------------
+// (out of line: its accumulators and operands must not weigh on the register allocation of the level
+// loop — inlined, the 1024-thread kernel went from 101 registers and no scratch to 128 and 288 bytes of it)
 template <int W>
-__device__ __forceinline__ void mf_update_mfma(uint32_t u0, uint32_t nr, uint32_t nch, bool root, uint32_t upd,
-                                               uint32_t ustride, uint32_t invd_addr, const uint32_t* __restrict__ ext,
-                                               double* __restrict__ contrib, uint32_t lane) {
+__device__ __attribute__((noinline)) void mf_update_mfma(uint32_t u0, uint32_t nr, uint32_t nch, bool root, uint32_t upd,
+                                                         uint32_t ustride, uint32_t invd_addr,
+                                                         const uint32_t* __restrict__ ext, double* __restrict__ contrib,
+                                                         uint32_t lane) {
+  u0 = __builtin_amdgcn_readfirstlane(u0);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  nch = __builtin_amdgcn_readfirstlane(nch);
+  upd = __builtin_amdgcn_readfirstlane(upd);
+  ustride = __builtin_amdgcn_readfirstlane(ustride);
+  invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
   const uint32_t r = nr - W - 1u;
   const uint32_t li = lane & 15u, lk = lane >> 4;
   const uint32_t nb = (r + 1u + 15u) / 16u;  // row blocks over R + rhs (<= 4)
@@ -173,7 +184,7 @@ __device__ __forceinline__ void mf_update_mfma(uint32_t u0, uint32_t nr, uint32_
   }
 }
 
-template <int W, int NCH>
+template <int W, int NCH, bool MFMA>
 __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, uint32_t fl,
                                            uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                            double* __restrict__ contrib, uint32_t lane) {
@@ -248,7 +259,7 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
 #pragma unroll
   for (int c = 0; c < W; ++c) lds_st(invd_addr + 8u * c, inv[c]);  // (every lane the same value)
   if (n_s == 0) return;
-  if constexpr (W >= 4) {
+  if constexpr (MFMA && W >= 4) {
     if (fl & 2u) {  // (wave-uniform)
       const uint32_t u0 = __builtin_amdgcn_readfirstlane(ua[0]);  // lane 0 holds row 0
       mf_update_mfma<W>(u0, nr, nch, root, upd, ustride, invd_addr, ext, contrib, lane);
@@ -296,27 +307,30 @@ __device__ __forceinline__ void mf_front_w(uint32_t tab, uint32_t nr, uint32_t n
   }
 }
 
-template <int W>
+template <int W, bool MFMA>
 __device__ __forceinline__ void mf_front_nch(uint32_t tab, uint32_t nr, uint32_t nch, uint32_t n_s, uint32_t root,
                                              uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                              double* __restrict__ contrib, uint32_t lane) {
   // (code size and register pressure: the in-register children only where they are common)
   if constexpr (W <= 2) {
     switch (nch) {
-      case 0: mf_front_w<W, 0>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
-      case 1: mf_front_w<W, 1>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
-      case 2: mf_front_w<W, 2>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
-      default: mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      case 0: mf_front_w<W, 0, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      case 1: mf_front_w<W, 1, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      case 2: mf_front_w<W, 2, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+      default: mf_front_w<W, kMfNchAny, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
     }
   } else if constexpr (W <= 5) {
-    if (nch == 2) mf_front_w<W, 2>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
-    else mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+    if (nch == 2) mf_front_w<W, 2, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+    else mf_front_w<W, kMfNchAny, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
   } else {
-    mf_front_w<W, kMfNchAny>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
+    mf_front_w<W, kMfNchAny, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane);
   }
 }
 
-// (every argument but `lane` wave-uniform: scalar registers, scalar jumps)
+// (every argument but `lane` wave-uniform: scalar registers, scalar jumps.  MFMA: the kernel variant
+// for plans with fronts on the matrix cores — the mere presence of that path, even out of line, cost
+// the other fronts' code 2 us per step in registers: plans without such fronts run the variant without it)
+template <bool MFMA>
 __device__ __forceinline__ void mf_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t n_s,
                                          uint32_t root, uint32_t invd_addr, const uint32_t* __restrict__ ext,
                                          double* __restrict__ contrib, uint32_t lane) {
@@ -328,7 +342,7 @@ __device__ __forceinline__ void mf_front(uint32_t tab, uint32_t w, uint32_t nr, 
   root = __builtin_amdgcn_readfirstlane(root);
   invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
   switch (w) {
-#define SLPX_MF_CASE(W) case W: mf_front_nch<W>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
+#define SLPX_MF_CASE(W) case W: mf_front_nch<W, MFMA>(tab, nr, nch, n_s, root, invd_addr, ext, contrib, lane); break;
     SLPX_MF_CASE(1) SLPX_MF_CASE(2) SLPX_MF_CASE(3) SLPX_MF_CASE(4) SLPX_MF_CASE(5) SLPX_MF_CASE(6) SLPX_MF_CASE(7)
     SLPX_MF_CASE(8)
 #undef SLPX_MF_CASE
@@ -432,7 +446,7 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
   return c;
 }
 
-template <int THREADS>
+template <int THREADS, bool MFMA>
 __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
@@ -472,29 +486,26 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   auto g16 = [&](uint32_t o) { return reinterpret_cast<uint4*>(smem_raw + o); };
 
   // ---- stage the plan: one image, one copy loop, every load in flight ----
+  // (the image sits in a slot of fixed size, so its loads are requested before the task's own
+  // descriptors — which say how much of the slot is image — have arrived: one trip to memory, not two)
+  constexpr int kInFlight = kMfImageGroups / THREADS;  // (DeviceNlp::build_mf: no image is longer than kMfImageGroups)
+  uint4 stage_v[kInFlight];
+  const uint4* src16 = Mf.image + static_cast<size_t>(task_index) * Mf.image_stride16;
+#pragma unroll
+  for (int k = 0; k < kInFlight; ++k) stage_v[k] = src16[tid + k * THREADS];  // (the buffer is padded by a full round)
   const uint4 img = Mf.image_desc[task_index];
   const uint32_t n_terms16 = img.w, n_terms = n_terms16 * 4u / 3u;
   double* tprod = reinterpret_cast<double*>(s_terms + n_terms16);
   uint4* s_bs = reinterpret_cast<uint4*>(smem_raw + mf_align16(cv.o_terms + 16u * n_terms16 + 8u * n_terms));
   uint4 bs_task = B.task_plan[task_index];
   {
-    const uint4* src16 = Mf.image + img.x;
     uint4* dst_a = g16(cv.o_tab);
     const uint32_t n_a = img.y, n_all = img.y + img.z;
-    constexpr int kInFlight = 6;
-    for (uint32_t i0 = tid; i0 < n_all; i0 += kInFlight * THREADS) {
-      uint4 v[kInFlight];
 #pragma unroll
-      for (int k = 0; k < kInFlight; ++k) {
-        const uint32_t i = i0 + k * THREADS;
-        v[k] = src16[i < n_all ? i : n_all - 1u];
-      }
-#pragma unroll
-      for (int k = 0; k < kInFlight; ++k) {
-        const uint32_t i = i0 + k * THREADS;
-        if (i < n_a) dst_a[i] = v[k];
-        else if (i < n_all) s_bs[i - n_a] = v[k];
-      }
+    for (int k = 0; k < kInFlight; ++k) {
+      const uint32_t i = tid + k * THREADS;
+      if (i < n_a) dst_a[i] = stage_v[k];
+      else if (i < n_all) s_bs[i - n_a] = stage_v[k];
     }
   }
   if (tid == 0) {
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
         if (q != beg + wave) d = s_load_desc(gfr + q);
         const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
-        mf_front(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
+        mf_front<MFMA>(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
                  contrib, lane);
       }
       d = s_load_desc(gfr + (end + wave < last_front ? end + wave : last_front));

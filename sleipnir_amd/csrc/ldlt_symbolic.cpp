@@ -1102,10 +1102,14 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         std::fprintf(stderr, "\n");
       }
       for (int r = 0; r < P.n_rounds && ok; ++r) {
-        uint32_t most = 0, over = 0, lv = 0, deepest = 0;
+        uint32_t most = 0, over = 0, lv = 0, deepest = 0, most_passes = 0, least_passes = 1u << 30;
         for (uint32_t ti = P.round_ptr[r]; ti < P.round_ptr[r + 1]; ++ti) {
           const LdltTask& T = P.tasks[ti];
           deepest = std::max(deepest, T.n_lvl);
+          uint32_t passes = 0;
+          for (uint32_t l = 0; l < T.n_lvl; ++l) passes += (P.mf_lvl_ptr[T.lvl_off + l + 1] - P.mf_lvl_ptr[T.lvl_off + l] + 15u) / 16u;
+          most_passes = std::max(most_passes, passes);
+          least_passes = std::min(least_passes, passes);
           for (uint32_t l = 0; l < T.n_lvl; ++l) {
             const uint32_t nf = P.mf_lvl_ptr[T.lvl_off + l + 1] - P.mf_lvl_ptr[T.lvl_off + l];
             most = std::max(most, nf);
@@ -1113,8 +1117,8 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
             ++lv;
           }
         }
-        std::fprintf(stderr, "ldlt fronts round %d: deepest task %u levels, most fronts in a level %u, levels with more than 16 fronts %u of %u\n",
-                     r, deepest, most, over, lv);
+        std::fprintf(stderr, "ldlt fronts round %d: deepest task %u levels, most fronts in a level %u, levels with more than 16 fronts %u of %u; passes of 16 waves per task %u..%u\n",
+                     r, deepest, most, over, lv, least_passes, most_passes);
       }
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u), fronts on the matrix cores %u\n",
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib, P.mf_n_mfma);

@@ -99,7 +99,9 @@ typedef struct slpx_options {
   int32_t feasible_ipm;
   int32_t diagnostics;
   int32_t spy; /* Problem::solve(options, spy) (problem.hpp:281): write H.spy, A_e.spy, A_i.spy (util/spy.hpp) into the
-                  working directory, one record per iteration; since ABI version 4 */
+                  working directory, one record per iteration; since ABI version 4.  Read ONLY through
+                  slpx_problem_solve_sized: slpx_problem_solve takes the struct as it was up to ABI version 3
+                  (a caller built against an older header passes a shorter one) */
 } slpx_options;
 
 /* Per-solve counters and wall-clock phases (names of interior_point.hpp:155-174) */
@@ -146,6 +148,9 @@ slpx_system* slpx_problem_system(slpx_problem* p);
 /* Problem::solve.  Returns slp::ExitStatus (solver/exit_status.hpp:13-43):
  * 0 success, 1 callback stop, -1..-10 as in the reference; -100 on library error. */
 int slpx_problem_solve(slpx_problem* p, const slpx_options* opt, slpx_report* report);
+/* The same with the caller's sizeof(slpx_options): members beyond `options_bytes` keep their defaults
+ * (spy, ABI version 4, is read only when the caller's struct holds it). */
+int slpx_problem_solve_sized(slpx_problem* p, const slpx_options* opt, uint32_t options_bytes, slpx_report* report);
 void slpx_problem_get_duals(const slpx_problem* p, double* s, double* y, double* z);
 /* feasibility_restoration (solver/util/feasibility_restoration.hpp:347-628) on its own: from the
  * iterate (x[n], s[m_i], y[m_e], z[m_i], mu) — all in/out but mu — build the restoration model,

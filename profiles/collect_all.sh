@@ -1,9 +1,9 @@
 # The whole evidence sequence of a round, on the GPU box, from the repo root:
-#   bash profiles/collect_all.sh r02
+#   bash profiles/collect_all.sh r03
 # Every --pmc pass on its own, never combined with a trace (MI355X_MICROARCH.md).  Leaves the
 # condensed files under gpurun_out/profiles_new/ (gpurun_out/ is what travels back).
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
@@ -43,10 +43,27 @@ done
 PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>&1
 PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
 PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
-for B in latency icache chain; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
+for B in latency icache chain front; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
 PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= \|tape kernel" > $N/${TAG}_setup_time.txt
 # 5. whole solves over the BASELINE horizons; the launch-fusion switches one by one
 PYTHONPATH=$R timeout 600 python profiles/horizon_sweep.py > $N/${TAG}_horizon_sweep.txt 2>&1
 bash profiles/ab_fuse.sh > $N/${TAG}_fusion_ab.txt 2>&1
 for v in all nosolve none; do cp $O/timeline_$v.txt $N/${TAG}_step_timeline_fuse_$v.txt; done
+# 6. the multifrontal step against the pair-list kernels it replaces, and the matrix-core path (g-fold)
+{
+  for W in "1000" "5000" "500" "gfold"; do
+    echo "== $W: multifrontal (default)"; PYTHONPATH=$R python profiles/mf_time.py $W
+    echo "== $W: pair lists (SLPX_LDLT_MF=0)"; SLPX_LDLT_MF=0 PYTHONPATH=$R python profiles/mf_time.py $W
+  done
+  echo "== gfold: update blocks on the matrix cores from 128 entries (SLPX_MFMA_MIN_ENTRIES=128)"
+  SLPX_MFMA_MIN_ENTRIES=128 PYTHONPATH=$R python profiles/mf_time.py gfold
+  echo "== gfold: never on the matrix cores (SLPX_MFMA_MIN_ENTRIES=1000000)"
+  SLPX_MFMA_MIN_ENTRIES=1000000 PYTHONPATH=$R python profiles/mf_time.py gfold
+  echo "== 1000: exact supernodes only (SLPX_RELAX_ZEROS=0)"; SLPX_RELAX_ZEROS=0 PYTHONPATH=$R python profiles/mf_time.py 1000
+} > $N/${TAG}_mf_ab.txt 2>&1
+# MFMA counters of the g-fold step with the matrix-core path on for every front of >= 128 entries: own pass, no trace
+rm -rf $O/pmc_mfma
+SLPX_MFMA_MIN_ENTRIES=128 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_mfma -- python bench.py --workload gfold --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_mfma.log 2>&1
+python profiles/mfma_counters.py $O/pmc_mfma > $N/${TAG}_gfold_mfma.json 2>> $O/collect.log
+rm -rf $O/pmc_mfma
 tail -5 $O/collect.log

@@ -135,6 +135,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_problem_get_x", None, vp, vp)
     sig("slpx_problem_set_x", None, vp, vp)
     sig("slpx_problem_solve", ctypes.c_int, vp, ctypes.POINTER(Options), ctypes.POINTER(Report))
+    sig("slpx_problem_solve_sized", ctypes.c_int, vp, ctypes.POINTER(Options), ctypes.c_uint32, ctypes.POINTER(Report))
     sig("slpx_problem_get_duals", None, vp, vp, vp, vp)
     sig("slpx_problem_restoration_steps", ctypes.c_int, vp, ctypes.POINTER(Options), vp, vp, vp, vp, f64, i32)
     sig("slpx_problem_prebuild_kernels", ctypes.c_int, vp, ctypes.c_char_p)
@@ -265,7 +266,7 @@ class Problem:
               diagnostics=False, spy=False):
         opt = Options(tolerance, max_iterations, timeout, int(feasible_ipm), int(diagnostics), int(spy))
         rep = Report()
-        status = lib().slpx_problem_solve(self._h, ctypes.byref(opt), ctypes.byref(rep))
+        status = lib().slpx_problem_solve_sized(self._h, ctypes.byref(opt), ctypes.sizeof(Options), ctypes.byref(rep))
         if status == -100:
             raise SlpxError(lib().slpx_last_error().decode())
         return status, {f[0]: getattr(rep, f[0]) for f in Report._fields_}

@@ -280,7 +280,7 @@ class VariableMatrix:
         return self.block(offset, 0, length, 1)
 
     @property
-    def T(self): return VariableMatrix._of(self._a.T)
+    def T(self): return VariableMatrix._of(self._a.T.copy())  # (a new matrix, variable_matrix.hpp:955-965: not a view)
 
     # ---- values ----
     def value(self, *idx):

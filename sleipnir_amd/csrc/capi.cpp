@@ -2,6 +2,7 @@
 #include "../../include/slpx.h"
 
 #include <chrono>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -106,6 +107,12 @@ void slpx_problem_set_x(slpx_problem* p, const double* x) {
 }
 
 int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* report) {
+  // (the struct as it was before `spy` was appended: an older caller's is that short)
+  return slpx_problem_solve_sized(p, o, static_cast<uint32_t>(offsetof(slpx_options, spy)), report);
+}
+
+int slpx_problem_solve_sized(slpx_problem* p, const slpx_options* o, uint32_t options_bytes, slpx_report* report) {
+  const bool spy = o != nullptr && options_bytes >= offsetof(slpx_options, spy) + sizeof(int32_t) && o->spy != 0;
   int status = -100;
   int rc = guard([&] {
     slp::Options opt;
@@ -124,7 +131,7 @@ int slpx_problem_solve(slpx_problem* p, const slpx_options* o, slpx_report* repo
                                p->problem.inequality_constraint_type() <= slp::ExpressionType::CONSTANT;
     if (!nothing_to_do) p->problem.compile();
     p->t_compile = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    status = static_cast<int>(p->problem.solve(opt, o && o->spy != 0));
+    status = static_cast<int>(p->problem.solve(opt, spy));
     if (report) {
       const auto& r = p->problem.report();
       *report = slpx_report{r.iterations,    r.factorizations, r.solves,       r.value_sweeps,

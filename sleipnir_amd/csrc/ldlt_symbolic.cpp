@@ -870,6 +870,48 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         fronts[f.parent].kids.push_back(static_cast<int>(fi));
       }
     }
+    // ---- levels of the fronts inside their task: 0 .. n_lvl - 1 in step with the column levels, then
+    // balanced — a level is worked off sixteen fronts at a time (one wave each), and a front whose parent
+    // sits more than one level up may as well run a level later: fronts with that slack leave levels of
+    // more than sixteen (cart-pole N=1000: the leaf tasks' passes of sixteen 4..6 -> 4..5) — and inside a
+    // level the wide fronts first, so that a second pass holds the cheap ones.
+    for (int t = 0; t < ntasks && ok; ++t) {
+      auto& fl = task_fronts[t];
+      std::vector<int> distinct;
+      for (int fi : fl) distinct.push_back(fronts[fi].level);
+      std::sort(distinct.begin(), distinct.end());
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      const int n_lvl = static_cast<int>(distinct.size());
+      for (int fi : fl)
+        fronts[fi].level = static_cast<int>(std::lower_bound(distinct.begin(), distinct.end(), fronts[fi].level) - distinct.begin());
+      std::vector<int> count(n_lvl, 0);
+      for (int fi : fl) ++count[fronts[fi].level];
+      for (int l = 0; l + 1 < n_lvl; ++l) {
+        if (count[l] <= 16) continue;
+        // candidates: cheapest first (they add least to the level they join)
+        std::vector<int> cand;
+        for (int fi : fl) {
+          const Front& f = fronts[fi];
+          if (f.level != l) continue;
+          const int limit = f.parent >= 0 ? fronts[f.parent].level : n_lvl;  // must stay below
+          if (l + 1 < limit) cand.push_back(fi);
+        }
+        std::sort(cand.begin(), cand.end(), [&](int a, int b) {
+          return fronts[a].cols.size() * 64 + fronts[a].R.size() < fronts[b].cols.size() * 64 + fronts[b].R.size();
+        });
+        for (int fi : cand) {
+          if (count[l] <= 16 || count[l + 1] >= 16) break;
+          ++fronts[fi].level;
+          --count[l];
+          ++count[l + 1];
+        }
+      }
+      std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) {
+        const Front &fa = fronts[a], &fb = fronts[b];
+        if (fa.level != fb.level) return fa.level < fb.level;
+        return fa.cols.size() * 64 + fa.R.size() > fb.cols.size() * 64 + fb.R.size();
+      });
+    }
     // update slots between tasks: one per entry of a root front's block
     std::vector<std::vector<std::vector<uint32_t>>> mcontrib(ntasks);
     for (int t = 0; t < ntasks; ++t) mcontrib[t].resize(task_nent[t]);

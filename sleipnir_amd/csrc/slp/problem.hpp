@@ -160,6 +160,20 @@ class ProblemF64 {
     m_iteration_callbacks.emplace_back(std::forward<F>(callback));
   }
   void clear_callbacks() { m_iteration_callbacks.clear(); }
+  // problem.hpp:714-735: callbacks that survive clear_callbacks() and run after the others
+  template <typename F>
+    requires requires(F cb, const slpx::IterationInfo& info) { { cb(info) } -> std::same_as<void>; }
+  void add_persistent_callback(F&& callback) {
+    m_persistent_iteration_callbacks.emplace_back([cb = std::forward<F>(callback)](const slpx::IterationInfo& info) {
+      cb(info);
+      return false;
+    });
+  }
+  template <typename F>
+    requires requires(F cb, const slpx::IterationInfo& info) { { cb(info) } -> std::same_as<bool>; }
+  void add_persistent_callback(F&& callback) {
+    m_persistent_iteration_callbacks.emplace_back(std::forward<F>(callback));
+  }
 
   // problem.hpp:281-679
   ExitStatus solve(const Options& options = Options{}, bool spy = false) {
@@ -195,6 +209,7 @@ class ProblemF64 {
     // problem.hpp:365-375, 453-470, 571-596: sparsity files of H (lower triangle of the Lagrangian's
     // Hessian), A_e, A_i — one record per iteration, written from a callback like the reference's
     std::vector<slpx::IterationCallback> callbacks = m_iteration_callbacks;
+    callbacks.insert(callbacks.end(), m_persistent_iteration_callbacks.begin(), m_persistent_iteration_callbacks.end());
     std::unique_ptr<Spy> H_spy, A_e_spy, A_i_spy;
     if (spy) {
       const int n = static_cast<int>(x.size()), m_e = static_cast<int>(m_equality_constraints.size()),
@@ -343,7 +358,7 @@ class ProblemF64 {
   std::optional<VariableF64> m_f;
   std::vector<VariableF64> m_equality_constraints;
   std::vector<VariableF64> m_inequality_constraints;
-  std::vector<slpx::IterationCallback> m_iteration_callbacks;
+  std::vector<slpx::IterationCallback> m_iteration_callbacks, m_persistent_iteration_callbacks;
   std::unique_ptr<slpx::NewtonSystem> m_sys;
   std::vector<std::pair<NodeId, double>> m_param_snapshot;  // (parameter node, value at compile time)
   std::vector<double> m_scales, m_s, m_y, m_z;

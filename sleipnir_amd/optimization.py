@@ -99,6 +99,7 @@ class Problem:
         self._p = _sa.Problem()
         self._decision_variables: list[Variable] = []
         self._pattern_cache = None
+        self.report = None  # counters and phase times of the last solve() that ran an iteration
 
     # ---- model ----
     def decision_variable(self, rows=None, cols=1):
@@ -163,6 +164,7 @@ class Problem:
             timeout = 0.0
         # problem.hpp:304-313: nothing to do for a problem without cost and constraints
         if all(t <= ExpressionType.CONSTANT for t in self._p.types()):
+            self.report = None
             return ExitStatus.SUCCESS
         status, self.report = self._p.solve(timeout=timeout, **kwargs)
         return ExitStatus(status)

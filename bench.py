@@ -44,7 +44,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r02"    # profiles/<tag>_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r03"    # profiles/<tag>_traffic.json feeds roofline.traffic
 
 
 def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):

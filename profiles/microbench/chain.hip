@@ -58,7 +58,7 @@ __global__ void k_chain(long long* clk, uint32_t w, uint32_t nr, int reps, int t
   for (int r = 0; r < reps; ++r) {
     if ((threadIdx.x >> 6) < threads_active) {
       if (VARIANT == 0) sn_finish_rolled_any(U, invd, 0u, ws, nrs, 0u, threadIdx.x & 63);
-      else sn_finish_wave(U, invd, 0u, ws, nrs, 0u, threadIdx.x & 63);
+      else sn_finish_wave(lds_cast(U), lds_cast(invd), 0u, ws, nrs, 0u, threadIdx.x & 63);
     }
     __syncthreads();
   }

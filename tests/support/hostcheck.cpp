@@ -144,6 +144,7 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
       lopt.relax_zeros = 8;
     }
   if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
+  if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
   h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);
@@ -718,6 +719,34 @@ extern "C" void hc_ldlt_tree(hc_handle* h, int32_t* parent, int32_t* colcount) {
 
 // Supernodes of the plan: out[0] = count (singletons included), out[1] = widest, out[2] = levels on
 // the critical path, out[3 + w] = supernodes of width w for w < cap - 3.
+// the multifrontal plan (ldlt_symbolic.hpp: LdltFront): {built, fronts, fronts on the matrix cores, most children
+// values per entry, widest front, most rows, explicit zeros of the relaxed supernodes (nnz(L) - exact),
+// largest table bytes, largest arena doubles, update slots}
+extern "C" void hc_mf_plan(hc_handle* h, int64_t* out) {
+  const LdltPlan& L = h->l;
+  for (int i = 0; i < 10; ++i) out[i] = 0;
+  out[0] = L.mf ? 1 : 0;
+  if (!L.mf) return;
+  size_t fronts = 0, tab = 0, arena = 0;
+  int widest = 0;
+  for (size_t ti = 0; ti < L.tasks.size(); ++ti) {
+    const LdltMfTask& M = L.mf_tasks[ti];
+    fronts += M.n_front;
+    tab = std::max<size_t>(tab, 2 * M.n_tab);
+    arena = std::max<size_t>(arena, M.arena);
+    for (uint32_t q = 0; q < M.n_front; ++q) widest = std::max<int>(widest, L.mf_fronts[M.front_off + q].w);
+  }
+  out[1] = static_cast<int64_t>(fronts);
+  out[2] = L.mf_n_mfma;
+  out[3] = L.mf_max_nch;
+  out[4] = widest;
+  out[5] = L.mf_max_front_rows;
+  out[6] = L.nnzL;
+  out[7] = static_cast<int64_t>(tab);
+  out[8] = static_cast<int64_t>(arena);
+  out[9] = L.mf_n_contrib;
+}
+
 extern "C" void hc_supernode_plan(hc_handle* h, int64_t* out, int32_t cap) {
   const LdltPlan& L = h->l;
   for (int i = 0; i < cap; ++i) out[i] = 0;

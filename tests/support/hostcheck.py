@@ -56,6 +56,7 @@ def lib():
     sig("hc_supernodes", None, vp, vp)
     sig("hc_ldlt_tree", None, vp, vp, vp)
     sig("hc_supernode_plan", None, vp, vp, i32)
+    sig("hc_mf_plan", None, vp, vp)
     sig("hc_info", None, vp, vp)
     sig("hc_pattern", i32, vp, ctypes.c_int, vp, vp)
     sig("hc_perm", None, vp, vp)
@@ -115,6 +116,16 @@ class HostCheck:
         lib().hc_supernode_plan(self._h, out.ctypes.data, len(out))
         return {"count": int(out[0]), "widest": int(out[1]), "critical_levels": int(out[2]),
                 "width_hist": {w: int(c) for w, c in enumerate(out[3:]) if c}}
+
+    def mf_plan(self):
+        """The multifrontal plan (SLPX_LDLT_MF=1 when the handle was made), or {"built": False}."""
+        out = np.zeros(10, dtype=np.int64)
+        lib().hc_mf_plan(self._h, out.ctypes.data)
+        keys = ("built", "fronts", "mfma_fronts", "max_children_values", "widest", "most_rows", "nnz_L",
+                "table_bytes", "arena_doubles", "update_slots")
+        d = dict(zip(keys, (int(v) for v in out)))
+        d["built"] = bool(d["built"])
+        return d
 
     def ldlt_tree(self):
         """(parent, column count) of the elimination tree in the permuted space."""

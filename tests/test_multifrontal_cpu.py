@@ -1,0 +1,103 @@
+"""CPU tier: the multifrontal plan (csrc/ldlt_symbolic.hpp: LdltFront — dense fronts, update blocks
+handed from child to parent front, relaxed supernodes, table-driven LDS addressing) interpreted
+on the host exactly as csrc/ldlt_mf_kernels.h runs it (tests/support/hostcheck.cpp: hc_factor_mf,
+hc_backward_mf: every table word a byte offset into the task's first 64 KB of LDS) must reproduce
+the oracle's Newton step (interior_point.hpp:426-482, sparse_regularized_ldlt.hpp:64-161) — the
+same check the pair-list plans get in test_plans_cpu.py."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.support import cases, parity
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture()
+def mf(monkeypatch):
+    monkeypatch.setenv("SLPX_LDLT_MF", "1")
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 4), ("cart_pole", 37), ("cart_pole", 120), ("flywheel", 50)])
+@pytest.mark.parametrize("case", ["step0", "interior"])
+def test_multifrontal_plan_matches_oracle(fresh, slpx, orc, hostcheck, mf, kind, N, case):
+    pp, op = cases.build_pair(kind, N, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    plan = hc.mf_plan()
+    assert plan["built"] and plan["fronts"] > 0 and plan["most_rows"] <= 64 and plan["widest"] <= 8
+    parity.check_newton_step(hc, op, case)
+
+
+@pytest.mark.parametrize("zeros", ["0", "4", "32"])
+def test_relaxed_supernodes_trade_explicit_zeros_for_levels(fresh, slpx, orc, hostcheck, mf, monkeypatch, zeros):
+    """LdltOptions::relax_zeros: a supernode joins the one its parent column heads at the price of
+    explicit zeros — fewer, wider fronts and fewer levels on the critical path, the same step."""
+    monkeypatch.setenv("SLPX_RELAX_ZEROS", zeros)
+    pp, op = cases.build_pair("cart_pole", 60, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    parity.check_newton_step(hc, op, "interior")
+    plan, levels = hc.mf_plan(), hc.supernode_plan()["critical_levels"]
+    monkeypatch.setenv("SLPX_RELAX_ZEROS", "0")
+    slpx.lib().slpx_graph_reset()
+    orc.lib().orc_reset()
+    pq, _ = cases.build_pair("cart_pole", 60, slpx, orc)
+    exact = hostcheck.HostCheck(pq)
+    plan0, levels0 = exact.mf_plan(), exact.supernode_plan()["critical_levels"]
+    if zeros == "0":
+        assert plan["nnz_L"] == plan0["nnz_L"] and plan["fronts"] == plan0["fronts"]
+    else:
+        assert plan["nnz_L"] > plan0["nnz_L"] and plan["fronts"] < plan0["fronts"] and levels <= levels0
+
+
+def test_multifrontal_backward_solve_runs_on_what_the_factorization_left(fresh, slpx, orc, hostcheck, mf):
+    """The fused step's solve reads U and 1/d in place (hc_backward_mf) — it must agree with the full
+    forward + backward substitution from L in memory (the pair-list solve kernels)."""
+    pp, op = cases.build_pair("cart_pole", 37, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    n, me, mi = hc.n, hc.m_e, hc.m_i
+    scales = op.scaling()
+    hc.set_scaling(scales)
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+    hc.sweep(x, y, z, True)
+    hc.assemble(s, z)
+    hc.rhs(s, y, z, mu)
+    hc.factor(1e-4, 1e-10)
+    p_full = hc.solve()
+    p_fused = hc.solve_after_factor()
+    assert cases.max_rel(p_fused, p_full) <= 1e-9
+    hc.close()
+
+
+def test_multifrontal_plan_on_the_indefinite_fixture(fresh, slpx, orc, hostcheck, mf):
+    """cart_pole_N8_indefinite.npz: the inertia along the (delta, gamma) ladder from the fronts equals
+    the fixture's (numpy eigvalsh on the dense KKT matrix, tests/golden/make_fixtures.py)."""
+    fx = dict(np.load(GOLDEN / "cart_pole_N8_indefinite.npz"))
+    pp, op = cases.build_pair("cart_pole", int(fx["N"]), slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    n, me = hc.n, hc.m_e
+    scales = op.scaling()
+    hc.set_scaling(scales)
+    hc.sweep(fx["x"], fx["y"], fx["z"], True)
+    hc.assemble(fx["s"], fx["z"])
+    hc.rhs(fx["s"], fx["y"], fx["z"], float(fx["mu"]))
+    for (delta, gamma), inertia in zip(fx["ladder"], fx["ladder_inertia"]):
+        _, stats = hc.factor(float(delta), float(gamma))
+        if delta == 0.0 and stats[2] + stats[3] > 0:
+            continue  # (an exactly zero pivot at delta = gamma = 0: the reference's NumericalIssue branch)
+        assert tuple(int(v) for v in stats[:3]) == tuple(int(v) for v in inertia), (delta, gamma, stats, inertia)
+    hc.close()
+
+
+def test_gfold_fronts_reach_the_matrix_cores(fresh, hostcheck, mf, monkeypatch):
+    """BASELINE config 5: the g-fold problem's separator chains give fronts of four and more pivot
+    columns over hundreds of update entries — the ones ldlt_mf_kernels.h: mf_update_mfma takes as
+    v_mfma_f64_16x16x4_f64 tiles (from LdltOptions::mfma_min_entries up); cart-pole has none."""
+    from tests.support import gfold, model
+
+    monkeypatch.setenv("SLPX_MFMA_MIN_ENTRIES", "128")
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    g = gfold.build(mp, 40)
+    plan = hostcheck.HostCheck(g.p).mf_plan()
+    assert plan["built"] and plan["mfma_fronts"] > 0 and plan["widest"] >= 4

@@ -143,11 +143,13 @@ def test_generated_tape_kernel_compiles_for_gfx950(fresh, slpx, orc, hostcheck):
 
 
 def test_no_supernode_reaches_an_mfma_tile(fresh, slpx, orc, hostcheck):
-    """north_star: "MFMA only on dense supernode panels".  v_mfma_f64_16x16x4_f64 wants panels
-    at least 16 columns wide; with the depth-first ordering used here (nested dissection,
-    8-node leaves) the factors of the transcription problems have no such supernode at all —
-    the measured reason the panel path is not built.  Recorded for cart-pole
-    N=1000 (the BASELINE horizon) and for g-fold, whose inequality rows give dense blocks."""
+    """north_star: "MFMA only on dense supernode panels".  A 16-column panel for
+    v_mfma_f64_16x16x4_f64 does not occur: with the depth-first ordering used here (nested
+    dissection, 8-node leaves) the factors of the transcription problems have no supernode that
+    wide.  Recorded for cart-pole N=1000 (the BASELINE horizon) and for g-fold, whose inequality
+    rows give dense blocks.  (r03: where the matrix cores do get work is the UPDATE BLOCK of a
+    front — rows x rows below the pivots, four pivot columns per instruction — see
+    tests/test_multifrontal_cpu.py::test_gfold_fronts_reach_the_matrix_cores and DESIGN.md §4.)"""
     from tests.support import gfold, model
 
     pp, _ = cases.build_pair("cart_pole", 1000, slpx, orc)

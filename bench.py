@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--N", type=int, default=None, help="horizon (single: 1000, batch512: 500)")
     ap.add_argument("--batch", type=int, default=None,
                     help="single: independent replicas per GPU (1); batch512: total problems (512)")
+    ap.add_argument("--per-gpu", action="store_true",
+                    help="batch512: --batch problems on EVERY rank (weak scaling) instead of --batch problems "
+                         "sharded over the ranks (strong scaling, BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", "--no-batched-roofline", dest="no_batched", action="store_true",
                     help="skip the after-the-timed-region batch probes (64 x N=500, 512 x N=1000) that "
@@ -274,10 +277,17 @@ def main():
         scaling = "weak"
     else:
         N = args.N or 500
-        total_problems = args.batch or 512
-        ids = list(sa.shard_range(total_problems, rank, world))
-        B = len(ids)
-        scaling = "strong"
+        if args.per_gpu:
+            # weak scaling: every rank steps its own `--batch` problems (ids continue across ranks: seed + id)
+            B = args.batch or 512
+            total_problems = world * B
+            ids = [rank * B + b for b in range(B)]
+            scaling = "weak"
+        else:
+            total_problems = args.batch or 512
+            ids = list(sa.shard_range(total_problems, rank, world))
+            B = len(ids)
+            scaling = "strong"
     dt = 5.0 / N
     pp, system, setup_s = make_system(sa, cases, N, ids, local_rank, "gfold" if args.workload == "gfold" else "cart_pole")
     info = system.info
@@ -410,7 +420,8 @@ def main():
                        "tape_tasks": info["tape_tasks"], "tape_nodes": info["tape_nodes"],
                        "tape_slots": info["tape_slots"],
                        "multi_gpu": "replicas only" if args.workload != "batch512" else
-                                    "problems sharded, no data-path collective"},
+                                    ("%d problems on every rank, no data-path collective" % B if args.per_gpu else
+                                     "problems sharded, no data-path collective")},
             "ms_per_ldlt_factor": groups["ldlt_factor"][0],
             "ms_per_ldlt_solve": groups["ldlt_solve"][0],
             "setup_s": setup_s,

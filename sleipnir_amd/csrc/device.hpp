@@ -259,6 +259,33 @@ struct StepTimings {
   float sweep = 0, assemble = 0, rhs = 0, factor = 0, solve = 0, backsub = 0, total = 0;
 };
 
+// The stream of a DeviceNlp, remembering whether anything was handed it since the last chained Newton
+// step (DeviceNlp::sweep_full_for_step): every use as a hipStream_t marks it.
+struct TrackedStream {
+  hipStream_t s = nullptr;
+  mutable bool touched = true;
+  // a chained sweep is in flight on `tape` and the step kernel that waits for it has not been launched:
+  // whatever else is handed this stream first has to come after the sweep
+  hipStream_t tape = nullptr;
+  hipEvent_t ev = nullptr;
+  mutable bool tape_pending = false;
+  operator hipStream_t() const {
+    touched = true;
+    if (tape_pending) {
+      tape_pending = false;
+      (void)hipEventRecord(ev, tape);
+      (void)hipStreamWaitEvent(s, ev, 0);
+    }
+    return s;
+  }
+  TrackedStream& operator=(hipStream_t v) {
+    s = v;
+    touched = true;
+    return *this;
+  }
+  hipStream_t raw() const { return s; }
+};
+
 class DeviceNlp {
  public:
   DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l, int batch, int device);
@@ -284,6 +311,12 @@ class DeviceNlp {
   // f, c_e, c_i, g, A_e, A_i, H_f, H_c -> V.  with_reduce = false leaves the separable-sum
   // reductions (they only feed f) to the build_kkt(true) that must follow.
   void sweep_full(bool with_reduce = true);
+  // The sweep of a Newton step whose factor_solve_publish() follows at once (no reductions: they ride in
+  // that launch).  Where the step is the one-launch multifrontal kernel, the sweep goes to a stream of its
+  // own and the two kernels order themselves through a word in memory (StepChain below): the step kernel
+  // is dispatched and stages its plan WHILE the sweep runs, and the sweep of the next step starts the
+  // moment this step's kernel is through — no launch boundary on either side.
+  void sweep_full_for_step();
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs
   void build_kkt(bool with_reduce);  // assemble() + build_rhs() [+ reductions] as one launch
@@ -388,7 +421,7 @@ class DeviceNlp {
   const LdltPlan& m_l_ref;
   int m_batch;
   int m_device;
-  hipStream_t m_stream = nullptr;
+  TrackedStream m_stream;
 
   TapeDevice m_full, m_values;
   DevBuf<NlpStructure::SumReduce> m_reduces;
@@ -476,6 +509,14 @@ class DeviceNlp {
   DevBuf<uint4> m_mf_image_desc;   // per task {first 16-byte group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   DevBuf<double> m_mf_contrib;
   void build_mf(const LdltPlan& l);
+  // the same fronts for a batch: one launch per round (ldlt_mf_batch_kernel)
+  bool m_mfb = false;
+  bool m_mfb_rhs_in_fronts = false;  // the last factorization carried the right-hand side now in m_rhs
+  int m_mfb_threads = 256, m_mfb_ppw = 0, m_mfb_wg_per_cu = 4, m_cus = 256;
+  DevBuf<double> m_mfb_ust, m_mfb_invd;
+  void build_mf_batch(const LdltPlan& l);
+  void launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
+                       hipStream_t stream);
   DevBuf<unsigned int> m_ipm_err_done;
   DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
   DevBuf<uint4> m_bs_task_plan;
@@ -511,6 +552,19 @@ class DeviceNlp {
   DevBuf<double> m_trial_in, m_V_trial, m_soc_ce, m_soc_cims, m_p_keep, m_ps_keep, m_pz_keep, m_ipm_alpha, m_ipm_scales, m_ipm_partial;
   IpmHost* m_ipm_host = nullptr;   // pinned
   bool m_tape_reduce = true;       // launch_tape runs the separable-sum reductions itself
+  // chained steps (sweep_full_for_step): words 0 / 16 / 32 / 48 of m_chain = workgroups of the sweep
+  // through, last step whose sweep is complete, workgroups of the step kernel through, last step whose
+  // kernel is complete
+  bool m_chain_on = false;
+  hipStream_t m_tape_stream = nullptr;
+  hipEvent_t m_chain_ev = nullptr;
+  DevBuf<unsigned int> m_chain;
+  unsigned int m_chain_seq = 0;       // steps chained so far
+  struct ChainArgs {
+    unsigned int* chain = nullptr;
+    unsigned int wait_step = 0, this_step = 0;
+  };
+  ChainArgs m_chain_args;             // what launch_tape hands the generated kernel (null: an ordinary launch)
   const double* m_in_override = nullptr;  // launch_tape reads / writes these when set
   double* m_V_override = nullptr;
 };

@@ -523,6 +523,13 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_sip_ok = m_fuse_solve;
   if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
   if (m_mf) m_fuse_solve = true;
+  if (batch > 1 && !m_il && !m_single_launch && l.mf) build_mf_batch(l);
+  // chained steps (sweep_full_for_step): off unless SLPX_CHAIN_TAPE=1 — measured on cart-pole, steps/s chained
+  // vs not: N=100 +8 %, N=300 +3 %, N=1000 -1 % (the sweep shares the chip with the step kernel's 137
+  // workgroups and takes 10 us instead of 7), N=5000 -25 % (265 workgroups leave the sweep no CU):
+  // profiles/r03_chain_ab.txt
+  m_chain_on = false;
+  if (const char* env = std::getenv("SLPX_CHAIN_TAPE")) m_chain_on = m_mf && batch == 1 && env[0] == '1';
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -681,6 +688,12 @@ DeviceNlp::~DeviceNlp() {
   if (m_join) (void)hipEventDestroy(m_join);
   if (m_aux_stream) (void)hipStreamDestroy(m_aux_stream);
   if (m_capture_stream) (void)hipStreamDestroy(m_capture_stream);
+  if (m_tape_stream) {
+    (void)hipStreamSynchronize(m_tape_stream);
+    (void)hipStreamDestroy(m_tape_stream);
+  }
+  if (m_chain_ev) (void)hipEventDestroy(m_chain_ev);
+  if (m_stream.ev) (void)hipEventDestroy(m_stream.ev);
 }
 
 void DeviceNlp::set_scaling(const std::vector<double>& scales) {
@@ -780,11 +793,14 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     int n_template_blocks = static_cast<int>(t.tmpl_blocks[mode]);
     int do_reverse = reverse ? 1 : 0;
     const uint64_t* params_dev = t.tmpl_params_dev.p;
+    unsigned int* chain = m_chain_args.chain;
+    unsigned int wait_step = m_chain_args.wait_step, this_step = m_chain_args.this_step;
+    const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
+    unsigned int n_workgroups = grid * static_cast<unsigned>(m_batch);
     void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
                     &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
-                    &params_dev};
-    const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
+                    &params_dev, &chain, &wait_step, &this_step, &n_workgroups};
     SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, 64, 1, 1, small_rides ? t.small_lds : 0u,
                                          small_stream, args, nullptr));
   }
@@ -812,6 +828,53 @@ void DeviceNlp::sweep_full(bool with_reduce) {
   m_tape_reduce = with_reduce;
   launch_tape(m_full, true);
   m_tape_reduce = true;
+}
+void DeviceNlp::sweep_full_for_step() {
+  const TapeDevice& t = m_full;
+  // one generated kernel is the whole sweep (nothing interpreted beside it), the step is the one-launch
+  // multifrontal kernel, and no graph is being captured
+  const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0;
+  if (!m_chain_on || !one_kernel || !m_mf || m_batch != 1 || m_capturing || xg_other() == nullptr || !m_fuse_solve) {
+    sweep_full(/*with_reduce=*/false);
+    return;
+  }
+  if (m_tape_stream == nullptr) {
+    SLPX_HIP_CHECK(hipStreamCreateWithFlags(&m_tape_stream, hipStreamNonBlocking));
+    SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_chain_ev, hipEventDisableTiming));
+    SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_stream.ev, hipEventDisableTiming));
+    m_stream.tape = m_tape_stream;
+    m_chain.upload(std::vector<unsigned int>(128, 0u));
+  }
+  if (m_stream.touched) {
+    // something else went to the main stream since the last chained step (an upload, another kernel that
+    // reads V): the sweep's stream catches up with all of it
+    SLPX_HIP_CHECK(hipEventRecord(m_chain_ev, m_stream.raw()));
+    SLPX_HIP_CHECK(hipStreamWaitEvent(m_tape_stream, m_chain_ev, 0));
+    m_stream.touched = false;
+  }
+  static const bool chain_debug = std::getenv("SLPX_CHAIN_DEBUG") != nullptr;
+  if (chain_debug && m_chain_seq % 500 == 499) {
+    // the wall clocks (100 MHz) the last two chained steps left: sweep first workgroup in / through its wait /
+    // last workgroup out, step kernel last workgroup in / staged / through its wait / last workgroup out
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+    std::vector<unsigned int> w(128);
+    SLPX_HIP_CHECK(hipMemcpy(w.data(), m_chain.p, w.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    const unsigned long long* st = reinterpret_cast<const unsigned long long*>(w.data() + 64);
+    static unsigned long long prev_done = 0;
+    auto us = [&](unsigned long long v) { return (static_cast<double>(static_cast<long long>(v - st[0]))) / 100.0; };
+    std::fprintf(stderr, "chain step %u: sweep in 0.0, waited %.2f, out %.2f | step kernel in %.2f, staged %.2f, waited %.2f, out %.2f us (previous debug point's out %.2f)\n",
+                 m_chain_seq, us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]), us(st[6]), us(prev_done));
+    prev_done = st[6];
+  }
+  const unsigned int prev = m_chain_seq;
+  ++m_chain_seq;
+  m_chain_args = ChainArgs{m_chain.p, prev, m_chain_seq};
+  m_tape_reduce = false;
+  launch_tape(m_full, true, m_tape_stream, m_tape_stream);
+  m_tape_reduce = true;
+  m_chain_args = ChainArgs{};
+  m_stream.tape_pending = true;  // until the step kernel that waits for this sweep is launched
 }
 void DeviceNlp::sweep_values() { launch_tape(m_values, false); }
 void DeviceNlp::sweep_values_trial() {
@@ -1107,6 +1170,132 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   m_mf = true;
 }
 
+// The fronts for a batch (ldlt_mf_batch_kernel): a task's tables as one image, U and 1/d of every
+// (problem, task) in memory between the factorization and the solve launches.
+void DeviceNlp::build_mf_batch(const LdltPlan& l) {
+  const char* on = std::getenv("SLPX_MF_BATCH");
+  if (on == nullptr || on[0] != '1') return;
+  uint32_t lds = 0;
+  std::vector<uint4> desc(l.tasks.size());
+  std::vector<std::vector<unsigned char>> blobs;
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
+    const LdltTask& t = l.tasks[ti];
+    const LdltMfTask& m = l.mf_tasks[ti];
+    const MfCarve cv = mf_carve(t, m);
+    lds = std::max(lds, cv.o_terms);
+    std::vector<unsigned char> blob(cv.o_cnt - cv.o_tab, 0);
+    auto put = [&](uint32_t at, const void* src, size_t bytes) {
+      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
+      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
+    };
+    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
+    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
+    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
+    put(cv.o_src, l.ent_src.data() + t.ent_off, 4u * t.n_ent);
+    {
+      std::vector<uint8_t> fl(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
+      for (uint32_t j = 0; j < m.n_cent; ++j) fl[l.mf_cent[m.cent_off + j]] |= 0x20;  // takes update slots
+      put(cv.o_flags, fl.data(), t.n_ent);
+    }
+    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
+    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
+    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
+    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
+    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
+    desc[ti] = uint4{0u, static_cast<uint32_t>(blob.size() / 16u), 0u, 0u};
+    blobs.push_back(std::move(blob));
+  }
+  size_t stride16 = 1;
+  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
+  std::vector<uint4> image(stride16 * blobs.size() + 4, uint4{0, 0, 0, 0});
+  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
+  lds = mf_align16(lds) + 16u;
+  if (lds > 160u * 1024u) return;
+  m_mf_mfma = l.mf_n_mfma > 0;
+  m_mfb_threads = 256;
+  SLPX_HIP_CHECK(hipDeviceGetAttribute(&m_cus, hipDeviceAttributeMultiprocessorCount, m_device));
+  if (const char* env = std::getenv("SLPX_MFB_THREADS")) m_mfb_threads = std::atoi(env);
+  if (const char* env = std::getenv("SLPX_MFB_PPW")) m_mfb_ppw = std::atoi(env);
+  if (const char* env = std::getenv("SLPX_MFB_WG_PER_CU")) m_mfb_wg_per_cu = std::max(1, std::atoi(env));
+  if (m_mfb_threads != 256 && m_mfb_threads != 512 && m_mfb_threads != 1024) m_mfb_threads = 256;
+  hipFuncAttributes attr{};
+  auto prepare = [&](auto kernel) {
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)));
+    return attr.sharedSizeBytes == 0;  // (the tables hold LDS byte addresses from 0)
+  };
+  bool ok;
+  if (m_mfb_threads == 256) ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<256, true>) : prepare(&ldlt_mf_batch_kernel<256, false>);
+  else if (m_mfb_threads == 512) ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<512, true>) : prepare(&ldlt_mf_batch_kernel<512, false>);
+  else ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<1024, true>) : prepare(&ldlt_mf_batch_kernel<1024, false>);
+  if (!ok) return;
+  if (std::getenv("SLPX_LDLT_VERBOSE"))
+    std::fprintf(stderr, "ldlt multifrontal batch: %zu tasks, LDS %u bytes, images %zu bytes, %d threads per workgroup\n", l.tasks.size(), lds,
+                 16 * image.size(), m_mfb_threads);
+  m_mf_tasks.upload(l.mf_tasks);
+  m_mf_fronts.upload(l.mf_fronts);
+  m_mf_image.upload(image);
+  m_mf_image_stride16 = static_cast<uint32_t>(stride16);
+  m_mf_image_desc.upload(desc);
+  const size_t B = static_cast<size_t>(m_batch);
+  m_mf_contrib.alloc(B * std::max<uint32_t>(1, l.mf_n_contrib));
+  m_mf_contrib.zero();
+  m_mfb_ust.alloc(B * std::max<size_t>(1, l.ent_src.size()));
+  m_mfb_ust.zero();
+  m_mfb_invd.alloc(B * std::max<size_t>(1, l.col_perm.size()));
+  m_mfb_invd.zero();
+  m_mf_lds = lds;
+  m_mfb = true;
+}
+
+void DeviceNlp::launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
+                                hipStream_t stream) {
+  const LdltPlan& l = m_l_ref;
+  MfDev md;
+  md.tasks = m_mf_tasks.p;
+  md.fronts = m_mf_fronts.p;
+  md.image = m_mf_image.p;
+  md.image_stride16 = m_mf_image_stride16;
+  md.image_desc = m_mf_image_desc.p;
+  md.n_tasks = static_cast<unsigned int>(l.tasks.size());
+  MfBatch bt;
+  bt.lhs = m_lhs.p;
+  bt.rhs = m_rhs.p;
+  bt.reg = reg;
+  bt.Lx = m_Lx.p;
+  bt.D = m_D.p;
+  bt.zv = m_zv.p;
+  bt.contrib = m_mf_contrib.p;
+  bt.ust = m_mfb_ust.p;
+  bt.invd = m_mfb_invd.p;
+  bt.xg = m_xg.p;
+  bt.out = m_p.p;
+  bt.stats = cur;
+  bt.stats_next = next;
+  bt.nnz_lhs = m_kdev.nnz_lhs;
+  bt.nnzL = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
+  bt.n_contrib = static_cast<long long>(std::max<uint32_t>(1, l.mf_n_contrib));
+  bt.n_ent = static_cast<long long>(std::max<size_t>(1, l.ent_src.size()));
+  bt.n_colp = static_cast<long long>(std::max<size_t>(1, l.col_perm.size()));
+  bt.n = l.n;
+  bt.batch = m_batch;
+  // problems per workgroup: as many as still leave every CU a few workgroups of this round
+  {
+    const long long pairs = static_cast<long long>(n_tasks) * m_batch;
+    long long ppw = pairs / (static_cast<long long>(m_cus) * m_mfb_wg_per_cu);
+    ppw = std::clamp<long long>(ppw, 1, 16);
+    if (m_mfb_ppw > 0) ppw = m_mfb_ppw;
+    bt.ppw = static_cast<int>(std::min<long long>(ppw, m_batch));
+  }
+  const dim3 grid(n_tasks, (m_batch + bt.ppw - 1) / bt.ppw);
+  auto launch = [&](auto kernel, int threads) {
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, stream, m_ldev, md, task_base, solve_phase ? 1 : 0, bt);
+  };
+  if (m_mfb_threads == 256) m_mf_mfma ? launch(&ldlt_mf_batch_kernel<256, true>, 256) : launch(&ldlt_mf_batch_kernel<256, false>, 256);
+  else if (m_mfb_threads == 512) m_mf_mfma ? launch(&ldlt_mf_batch_kernel<512, true>, 512) : launch(&ldlt_mf_batch_kernel<512, false>, 512);
+  else m_mf_mfma ? launch(&ldlt_mf_batch_kernel<1024, true>, 1024) : launch(&ldlt_mf_batch_kernel<1024, false>, 1024);
+}
+
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
 void DeviceNlp::materialize_kkt() {
   if (m_kkt_pending) {  // the factorization that was to evaluate the system never came
@@ -1316,6 +1505,10 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
     hipLaunchKernelGGL(ldlt_stats_il_kernel, dim3(m_batch), dim3(64), 0, stream, m_stats_part.p,
                        static_cast<int>(l.tasks.size()), reg, cur, m_batch);
     m_il_outputs_stale = true;
+  } else if (m_mfb) {
+    for (int r = 0; r < l.n_rounds; ++r)
+      launch_mf_batch(l.round_ptr[r], l.round_ptr[r + 1] - l.round_ptr[r], false, reg, cur, r == 0 ? next : nullptr, stream);
+    m_mfb_rhs_in_fronts = true;
   } else if (m_single_launch) {
     KktFuse f = take_kkt_fuse();
     // every round in one launch; tasks wait on device-side round counters
@@ -1378,8 +1571,18 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
     md.n_tasks = static_cast<unsigned int>(l.tasks.size());
     md.exit_cnt = m_exit_cnt.p;
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
+    // a chained step (sweep_full_for_step): the kernel waits for its sweep itself, and the main stream
+    // stays "untouched" — the next step's sweep needs no event to come after this launch, it waits for
+    // this kernel's last workgroup
+    const bool chained = m_stream.tape_pending;
+    md.chain = m_chain.p;
+    md.wait_step = chained ? m_chain_seq : 0u;
+    md.this_step = m_chain_seq;
+    md.n_workgroups = grid.x;
+    m_stream.tape_pending = false;
+    if (!chained) m_stream.touched = true;
     auto launch = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream, m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
                          l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
     };
     if (m_mf_threads == 1024) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false>, 1024);
@@ -1410,7 +1613,7 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
     unsigned spins = 0;
     while (*m_h_seq < m_stats_seq) {
       if ((++spins & 0xfffu) == 0) {
-        const hipError_t st = hipStreamQuery(m_stream);
+        const hipError_t st = hipStreamQuery(m_stream.raw());
         if (st != hipErrorNotReady) {
           SLPX_HIP_CHECK(st);
           if (*m_h_seq < m_stats_seq) throw std::runtime_error("slpx: step finished without publishing its counters");
@@ -1419,7 +1622,7 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
     }
   } else {
     hipError_t st;
-    while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+    while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
     }
     SLPX_HIP_CHECK(st);
   }
@@ -1526,6 +1729,7 @@ void DeviceNlp::solve() {
                        m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs,
                        m_zv.p);
   }
+  m_mfb_rhs_in_fronts = false;  // z of THIS right-hand side is in zv: the pair-list backward solve from L
   solve_after_factor();
 }
 
@@ -1557,6 +1761,12 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
       hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes), m_il_solve_lds, m_stream, m_ldev,
                          l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch);
     }
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (m_mfb && m_mfb_rhs_in_fronts) {
+    for (int r = l.n_rounds - 1; r >= 0; --r)
+      launch_mf_batch(l.round_ptr[r], l.round_ptr[r + 1] - l.round_ptr[r], true, nullptr, nullptr, nullptr, m_stream);
     SLPX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1713,7 +1923,7 @@ void DeviceNlp::wait_published() {
   unsigned spins = 0;
   while (*m_h_seq < m_seq_expected) {
     if ((++spins & 0xfffu) == 0) {
-      const hipError_t st = hipStreamQuery(m_stream);
+      const hipError_t st = hipStreamQuery(m_stream.raw());
       if (st != hipErrorNotReady) {
         SLPX_HIP_CHECK(st);
         if (*m_h_seq < m_seq_expected) throw std::runtime_error("slpx: chain finished without publishing");
@@ -1724,7 +1934,7 @@ void DeviceNlp::wait_published() {
 
 void DeviceNlp::wait() {
   hipError_t st;
-  while ((st = hipStreamQuery(m_stream)) == hipErrorNotReady) {
+  while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
   }
   SLPX_HIP_CHECK(st);
 }

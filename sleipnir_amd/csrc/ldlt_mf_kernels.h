@@ -46,7 +46,55 @@ struct MfDev {
   const uint4* image_desc = nullptr;  // per task {first group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   unsigned int n_tasks = 0;
   unsigned int* exit_cnt = nullptr;  // workgroups through their exit phase (the last one publishes)
+  // chained steps (DeviceNlp::sweep_full_for_step): the AD sweep of this step runs on another stream; the
+  // kernel stages its plan, then waits for chain[16] >= wait_step (0: the sweep came before in this
+  // stream), and its last workgroup leaves this_step in chain[48] for the next step's sweep
+  unsigned int* chain = nullptr;
+  unsigned int wait_step = 0, this_step = 0, n_workgroups = 0;
 };
+
+// (-DSLPX_CHAIN_STAMPS: wall clocks of the last chained step for SLPX_CHAIN_DEBUG, words 64.. of the chain buffer)
+#ifdef SLPX_CHAIN_STAMPS
+#define SLPX_CHAIN_STAMP(k) \
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[k] = wall_clock64()
+#else
+#define SLPX_CHAIN_STAMP(k)
+#endif
+// the sweep this step reads is complete (one lane asks; the workgroup's other waves come through the barrier)
+__device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* stats) {
+  if (Mf.wait_step != 0u) {
+    SLPX_CHAIN_STAMP(4);  // (the last workgroup dispatched: staged)
+    if (threadIdx.x == 0) {
+      unsigned int spins = 0;
+      while (static_cast<int>(__hip_atomic_load(Mf.chain + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - Mf.wait_step) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
+          atomicAdd(&stats[0].n_bad, 1 << 20);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // V as the sweep's workgroups left it, not as this XCD's L2 remembers it
+    }
+    __syncthreads();
+    SLPX_CHAIN_STAMP(5);
+  }
+}
+// this workgroup has read everything it will of V, s, z: the next step's sweep may overwrite V
+__device__ __forceinline__ void mf_signal_done(const MfDev& Mf) {
+  if (Mf.chain != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int old = __hip_atomic_fetch_add(Mf.chain + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == Mf.n_workgroups) {
+#ifdef SLPX_CHAIN_STAMPS
+        reinterpret_cast<unsigned long long*>(Mf.chain + 64)[6] = wall_clock64();
+#endif
+        __hip_atomic_store(Mf.chain + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(Mf.chain + 48, Mf.this_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
 
 // LDS by byte address (what the tables hold)
 __device__ __forceinline__ double lds_ld(uint32_t addr) { return *reinterpret_cast<const LdsF64*>(static_cast<uintptr_t>(addr)); }
@@ -454,12 +502,17 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+    mf_wait_for_sweep(Mf, stats);
     ride_along_sum(F, blockIdx.x, smem_raw);
+    mf_signal_done(Mf);
     return;
   }
   const int tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
+#ifdef SLPX_CHAIN_STAMPS
+  if (Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
+#endif
   const LdltTask t = L.tasks[task_index];
   const LdltMfTask m = Mf.tasks[task_index];
   const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
@@ -515,6 +568,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(1);
+  mf_wait_for_sweep(Mf, stats);
 
   // ---- matrix values (ldlt_factor_body) ----
   if (!F.inline_kkt) {
@@ -781,6 +835,207 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   SLPX_LDLT_CLOCK(20);
   if (top) exit_and_count();
+  mf_signal_done(Mf);
+}
+
+// ---------------------------------------------------------------------------
+// The same fronts for a BATCH of problems that share the plan (multistart.hpp:45-74: the same
+// model from many starting points).  Throughput, not latency: one launch per round (no workgroup
+// waits for another — the rounds of thousands of (task, problem) pairs are not resident at once),
+// a workgroup stages its task's tables ONCE and then takes `ppw` problems through them one after
+// the other; between the factorization launches (rounds up) and the solve launches (rounds down)
+// a task's U and 1/d wait in memory in the layout they have in LDS.
+// LDS: the step kernel's carve-up up to the counters (mf_carve), `src` = where an entry comes from in
+// lhs / rhs (L.ent_src) instead of the KKT sources.
+// ---------------------------------------------------------------------------
+struct MfBatch {
+  const double* lhs = nullptr;   // [b][nnz_lhs]
+  const double* rhs = nullptr;   // [b][n]
+  const double* reg = nullptr;   // [b]{delta, gamma}; delta = NaN: not part of this attempt
+  double* Lx = nullptr;          // [b][nnzL]
+  double* D = nullptr;           // [b][n]
+  double* zv = nullptr;          // [b][n]
+  double* contrib = nullptr;     // [b][n_contrib]: update slots between tasks
+  double* ust = nullptr;         // [b][n_ent_total]: U of every task as it sits in LDS
+  double* invd = nullptr;        // [b][n_colp]: 1/d by (task, local column) — the tasks' column slices are padded
+  double* xg = nullptr;          // [b][n]: x by permuted row
+  double* out = nullptr;         // [b][n]: x by row
+  LdltStats* stats = nullptr;    // [b]
+  LdltStats* stats_next = nullptr;
+  long long nnz_lhs = 0, nnzL = 0, n_contrib = 0, n_ent = 0, n_colp = 0;
+  int n = 0, batch = 0, ppw = 1;
+};
+
+template <int THREADS, bool MFMA>
+__global__ __launch_bounds__(THREADS) void ldlt_mf_batch_kernel(LdltDev L, MfDev Mf, uint32_t task_base, int solve_phase, MfBatch Bt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t task_index = task_base + blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
+  const LdltMfTask m = Mf.tasks[task_index];
+  const MfCarve cv = mf_carve(t, m);
+  double* U = reinterpret_cast<double*>(smem_raw);
+  double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
+  double* invd = reinterpret_cast<double*>(smem_raw + cv.o_invd);
+  double* x = reinterpret_cast<double*>(smem_raw + cv.o_x);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
+  const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
+  const int32_t* src = reinterpret_cast<const int32_t*>(smem_raw + cv.o_src);
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(smem_raw + cv.o_flags);
+  const uint16_t* cent = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_cent);
+  const uint32_t* cptr = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cptr);
+  const uint32_t* cidx = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cidx);
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cp);
+  const uint32_t* anc = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_anc);
+  int* s_cnt = reinterpret_cast<int*>(smem_raw + cv.o_cnt);
+  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
+  {
+    const uint4* src16 = Mf.image + static_cast<size_t>(task_index) * Mf.image_stride16;
+    uint4* dst16 = reinterpret_cast<uint4*>(smem_raw + cv.o_tab);
+    const uint32_t n16 = Mf.image_desc[task_index].y;
+    uint32_t i = tid;
+    for (; i + 3 * THREADS < n16; i += 4 * THREADS) {
+      const uint4 a = src16[i], b = src16[i + THREADS], c = src16[i + 2 * THREADS], d = src16[i + 3 * THREADS];
+      dst16[i] = a;
+      dst16[i + THREADS] = b;
+      dst16[i + 2 * THREADS] = c;
+      dst16[i + 3 * THREADS] = d;
+    }
+    for (; i < n16; i += THREADS) dst16[i] = src16[i];
+  }
+  if (tid == 0) {
+    arena[0] = 0.0;
+    arena[1] = 0.0;
+    x[t.n_col + m.n_anc] = 1.0;
+  }
+  __syncthreads();
+  const LdltFront* gfr = Mf.fronts + m.front_off;
+  const uint32_t last_front = m.n_front ? m.n_front - 1u : 0u;
+  const uint32_t* g_out = L.ent_out + t.ent_off;
+  const uint16_t* g_col = L.ent_col + t.ent_off;
+  const int b_end = min(Bt.batch, static_cast<int>(blockIdx.y + 1) * Bt.ppw);
+  for (int b = static_cast<int>(blockIdx.y) * Bt.ppw; b < b_end; ++b) {
+    const size_t sb = static_cast<size_t>(b);
+    double* ust = Bt.ust + sb * Bt.n_ent + t.ent_off;
+    double* invd_g = Bt.invd + sb * Bt.n_colp + t.col_off;
+    if (!solve_phase) {
+      if (Bt.stats_next != nullptr && task_index == 0 && tid == 0) Bt.stats_next[b] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
+      const double delta = Bt.reg[2 * b], gamma = Bt.reg[2 * b + 1];
+      if (delta != delta) continue;  // (the whole workgroup: the problem is not part of this attempt)
+      const double* lhs = Bt.lhs + sb * Bt.nnz_lhs;
+      const double* rhs = Bt.rhs + sb * Bt.n;
+      double* contrib = Bt.contrib + sb * Bt.n_contrib;
+      // ---- matrix values + regularization; entries with update slots: below ----
+      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+        const uint8_t fl = flags[i];
+        if (fl & 0x20) continue;
+        const int32_t s0 = src[i];
+        const double* base = (fl & 4) ? rhs : lhs;
+        double v = s0 >= 0 ? base[s0] : 0.0;
+        if (fl & 1) v += (fl & 2) ? -gamma : delta;
+        U[i] = v;
+      }
+      for (uint32_t j = tid; j < m.n_cent; j += THREADS) {
+        const uint32_t i = cent[j];
+        const uint8_t fl = flags[i];
+        const int32_t s0 = src[i];
+        const double* base = (fl & 4) ? rhs : lhs;
+        double acc = s0 >= 0 ? base[s0] : 0.0;
+        if (fl & 1) acc += (fl & 2) ? -gamma : delta;
+        const uint32_t cb = cptr[j], ce = cptr[j + 1];
+        for (uint32_t c = cb; c < ce; c += 4) {  // (four in flight, subtracted in list order)
+          const double v0 = contrib[cidx[c]];
+          const double v1 = contrib[cidx[c + 1 < ce ? c + 1 : c]];
+          const double v2 = contrib[cidx[c + 2 < ce ? c + 2 : c]];
+          const double v3 = contrib[cidx[c + 3 < ce ? c + 3 : c]];
+          acc -= v0;
+          if (c + 1 < ce) acc -= v1;
+          if (c + 2 < ce) acc -= v2;
+          if (c + 3 < ce) acc -= v3;
+        }
+        U[i] = acc;
+      }
+      if (tid < 4) s_cnt[tid] = 0;
+      if (tid == 4) *s_minp = 0x7ff0000000000000ull;
+      __syncthreads();
+      // ---- levels: a wave per front ----
+      {
+        uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[0]), end = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[1] : 0);
+        for (uint32_t l = 0; l < t.n_lvl; ++l) {
+          const uint32_t next_end = __builtin_amdgcn_readfirstlane(lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl]);
+          for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+            const u32x4 d = s_load_desc(gfr + q);
+            const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
+            mf_front<MFMA>(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
+                           contrib, lane);
+          }
+          __syncthreads();
+          beg = end;
+          end = next_end;
+        }
+      }
+      // ---- results: U and 1/d for the solve launches, L, D, z in their public layout, inertia ----
+      double* Lx = Bt.Lx + sb * Bt.nnzL;
+      double* D = Bt.D + sb * Bt.n;
+      double* zv = Bt.zv + sb * Bt.n;
+      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+        const double u = U[i];
+        const uint8_t fl = flags[i];
+        const uint32_t o = g_out[i];
+        ust[i] = u;
+        if (fl & 1) {
+          D[o] = u;
+          const double eps = 2.220446049250313e-16;
+          if (u > eps) atomicAdd(&s_cnt[0], 1);
+          else if (u < -eps) atomicAdd(&s_cnt[1], 1);
+          else atomicAdd(&s_cnt[2], 1);
+          if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
+          else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
+        } else if (fl & 4) {
+          zv[o] = u * invd[g_col[i]];
+        } else {
+          Lx[o] = u * invd[g_col[i]];
+        }
+      }
+      for (uint32_t i = tid; i < t.n_col; i += THREADS) invd_g[i] = invd[i];
+      __syncthreads();
+      if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&Bt.stats[b]) + tid, s_cnt[tid]);
+      if (tid == 0) atomicMin(&Bt.stats[b].min_abs_bits, *s_minp);
+      __syncthreads();  // (the counters and U are the next problem's from here on)
+    } else {
+      // ---- backward solve on what the factorization left: U, 1/d back into LDS, x of the ancestors' rows ----
+      const double* xg_r = Bt.xg + sb * Bt.n;
+      for (uint32_t i = tid; i < t.n_ent; i += THREADS) U[i] = ust[i];
+      for (uint32_t i = tid; i < t.n_col; i += THREADS) invd[i] = invd_g[i];
+      for (uint32_t a = tid; a < m.n_anc; a += THREADS) x[t.n_col + a] = xg_r[anc[a]];
+      __syncthreads();
+      {
+        uint32_t end = __builtin_amdgcn_readfirstlane(lvl[t.n_lvl]), beg = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[t.n_lvl - 1] : 0);
+        for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+          const uint32_t next_beg = __builtin_amdgcn_readfirstlane(lvl[l >= 1 ? l - 1 : 0]);
+          for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+            const u32x4 d = s_load_desc(gfr + q);
+            const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
+            const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
+            mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);
+          }
+          __syncthreads();
+          end = beg;
+          beg = next_beg;
+        }
+      }
+      double* xg_w = Bt.xg + sb * Bt.n;
+      double* out = Bt.out + sb * Bt.n;
+      for (uint32_t i = tid; i < t.n_col; i += THREADS) {
+        const uint32_t pj = colperm[i];
+        const double v = x[i];
+        xg_w[pj] = v;
+        out[L.perm[pj]] = v;
+      }
+      __syncthreads();
+    }
+  }
 }
 
 }  // namespace slpx

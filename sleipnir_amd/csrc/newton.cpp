@@ -51,7 +51,12 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
     // one problem: the multifrontal step (ldlt_mf_kernels.h) — every supernode a dense front, so a chain
     // of two columns already saves a level (the pair-list kernels' chain pass only paid from four)
-    if (opt.batch == 1 && lopt.supernodal) {
+    // a batch below the lane-per-problem threshold: the same fronts, a launch per round (ldlt_mf_batch_kernel)
+    // (off unless SLPX_MF_BATCH=1 — measured, 64 x N=500: 180 k steps/s against the pair-list per-task
+    // kernels' 224 k; profiles/r03_mfb_probe.txt)
+    bool mf_batch = false;
+    if (const char* env = std::getenv("SLPX_MF_BATCH")) mf_batch = opt.batch > 1 && !DeviceNlp::interleaved_for(opt.batch) && env[0] == '1';
+    if ((opt.batch == 1 || mf_batch) && lopt.supernodal) {
       const char* env = std::getenv("SLPX_LDLT_MF");
       if (env == nullptr || env[0] != '0') {
         lopt.multifrontal = true;
@@ -314,7 +319,7 @@ std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   // SLPX_HOST_TIMING=1: where the host's time per step goes (printed every 1000 steps)
   static const bool timing = std::getenv("SLPX_HOST_TIMING") != nullptr;
   if (!timing) {
-    if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
+    if (refresh_ad) m_dev->sweep_full_for_step();
     m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
     return compute(/*solve_speculatively=*/true);
   }
@@ -322,7 +327,7 @@ std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   static double t_sweep = 0, t_rest = 0;
   static long n = 0;
   const auto t0 = clk::now();
-  if (refresh_ad) m_dev->sweep_full(/*with_reduce=*/false);
+  if (refresh_ad) m_dev->sweep_full_for_step();
   const auto t1 = clk::now();
   m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
   auto res = compute(/*solve_speculatively=*/true);

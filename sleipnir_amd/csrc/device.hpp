@@ -390,13 +390,16 @@ class DeviceNlp {
   // (a step whose factorization evaluated the system in place left nothing in memory: assembled on demand)
   double* d_lhs() {
     materialize_kkt();
+    materialize_batch_major();
     return m_lhs.p;
   }
   double* d_rhs() {
     materialize_kkt();
+    materialize_batch_major();
     return m_rhs.p;
   }
   void materialize_kkt();
+  void materialize_batch_major();
   double* d_p() { return m_p.p; }
   double* d_ps() { return m_ps.p; }
   double* d_pz() { return m_pz.p; }
@@ -536,6 +539,9 @@ class DeviceNlp {
   bool m_single_launch = true;
   // batch-interleaved LDLT (ldlt_il_kernels.h)
   bool m_il = false, m_il_outputs_stale = false;
+  // the assembly kernels write the interleaved lhs / rhs themselves (SLPX_IL_DIRECT=0: batch-major + transposes);
+  // *_in_il: the current system is in the interleaved arrays only
+  bool m_il_direct = true, m_lhs_in_il = false, m_rhs_in_il = false;
   DevBuf<double> m_lhs_il, m_rhs_il, m_Lx_il, m_D_il, m_contrib_il, m_scontrib_il, m_zv_il, m_xg_il;
   DevBuf<LdltStats> m_stats_part;  // [task][problem]
   DevBuf<uint32_t> m_il_meta, m_il_meta_off;  // per task: the plan slices the factor kernel stages

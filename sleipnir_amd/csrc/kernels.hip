@@ -105,6 +105,91 @@ __global__ __launch_bounds__(256) void kkt_assemble_batch_kernel(KktDev K, const
   }
 }
 
+// The batch-interleaved factorization's inputs written WHERE IT READS THEM (ldlt_il_kernels.h:
+// [b / 16][entry][16]) — the batch-major lhs / rhs and the two transposing launches between the
+// assembly and the factorization (il_gather_kernel: 0.084 ms of a 1.15 ms step at 512 x N=1000) are
+// only made when somebody asks for them (DeviceNlp::d_lhs / d_rhs).
+// lhs: a thread = one entry of FOUR consecutive problems, four adjacent lanes = the 16 problems of
+// the entry's row: every 128-byte row is written whole by one quad, and a wave's loads of one
+// problem's V are sixteen consecutive entries' sources.
+__global__ __launch_bounds__(256) void kkt_assemble_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
+                                                              const double* __restrict__ s, const double* __restrict__ z,
+                                                              double* __restrict__ lhs_il, int batch) {
+  constexpr int P = 4;
+  const int g = blockIdx.y, sub = threadIdx.x & 3;
+  const int b0 = g * kIlW + sub * P;
+  const int nb = max(0, min(P, batch - b0));
+  const size_t bb0 = static_cast<size_t>(nb > 0 ? b0 : 0);  // (no problem of this quad exists: nothing is dereferenced)
+  V += bb0 * v_stride;
+  s += bb0 * K.m_i;
+  z += bb0 * K.m_i;
+  double* out = lhs_il + static_cast<size_t>(g) * K.nnz_lhs * kIlW + sub * P;
+  for (int k = blockIdx.x * 64 + (threadIdx.x >> 2); k < K.nnz_lhs; k += gridDim.x * 64) {
+    const int f = K.fast_src[k];
+    double v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = 0.0;
+    if (f >= 0) {
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        if (q < nb) v[q] = V[static_cast<size_t>(q) * v_stride + f];
+    } else if (f == -2) {
+      double prod[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) prod[q] = 0.0;
+      for (int d = K.dptr[k]; d < K.dptr[k + 1]; ++d) {
+        const int src = K.dsrc[d];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          if (q < nb) v[q] += V[static_cast<size_t>(q) * v_stride + src];
+      }
+      for (int p = K.pptr[k]; p < K.pptr[k + 1]; ++p) {
+        const int r = K.pr[p], a = K.pa[p], c = K.pb[p];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          if (q < nb) {
+            const double* Vq = V + static_cast<size_t>(q) * v_stride;
+            prod[q] += kkt_prod_term(Vq[a], s[q * K.m_i + r], z[q * K.m_i + r], Vq[c]);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < P; ++q) v[q] += prod[q];
+    }
+    double2* o = reinterpret_cast<double2*>(out + static_cast<size_t>(k) * kIlW);
+    o[0] = double2{v[0], v[1]};
+    o[1] = double2{v[2], v[3]};
+  }
+}
+
+// rhs: 64 rows x 16 problems per workgroup through LDS — a row is computed by one lane per problem
+// group of four (consecutive lanes = consecutive rows: the row's sources in V are nearly consecutive),
+// written as whole 128-byte rows.
+__global__ __launch_bounds__(256) void kkt_rhs_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
+                                                         const double* __restrict__ s, const double* __restrict__ y,
+                                                         const double* __restrict__ z, const double* __restrict__ mu,
+                                                         double* __restrict__ rhs_il, int batch) {
+  __shared__ double tile[kIlW][65];
+  const int g = blockIdx.y, i0 = blockIdx.x * 64;
+  const int il = threadIdx.x & 63, bq = threadIdx.x >> 6;
+  const int j = i0 + il;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pl = bq * 4 + q, b = g * kIlW + pl;
+    double val = 0.0;
+    if (b < batch && j < K.dim) {
+      const size_t sb = static_cast<size_t>(b);
+      val = kkt_rhs_entry(K, V + sb * v_stride, s + sb * K.m_i, y + sb * K.m_e, z + sb * K.m_i, mu[b], j);
+    }
+    tile[pl][il] = val;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int idx = threadIdx.x + 256 * jj, pl = idx & (kIlW - 1), r = idx >> kIlWShift;
+    if (i0 + r < K.dim) rhs_il[(static_cast<size_t>(g) * K.dim + i0 + r) * kIlW + pl] = tile[pl][r];
+  }
+}
+
 // Least-squares multiplier estimate (util/lagrange_multiplier_estimate.hpp:56-133) on the
 // KKT pattern: the top-left block is I + A_i^T S^-2 A_i (H sources skipped, identity added
 // by kkt_add_identity_kernel), the A_e block is unchanged.
@@ -504,6 +589,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
   m_il = interleaved_for(batch);
+  if (const char* env = std::getenv("SLPX_IL_DIRECT")) m_il_direct = env[0] != '0';
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
@@ -1308,9 +1394,35 @@ void DeviceNlp::materialize_kkt() {
   if (m_rhs_stale) build_rhs();
 }
 
+// batch-major lhs / rhs for whoever asks (slpx_system_get, a caller that writes its own system):
+// out of the interleaved arrays the assembly kernels filled; what the caller does with the pointer
+// is not known, so the next factorization transposes again
+void DeviceNlp::materialize_batch_major() {
+  if (!m_il) return;
+  const int C = (m_batch + 63) / 64;
+  if (m_lhs_in_il) {
+    const int nnz = m_kdev.nnz_lhs;
+    hipLaunchKernelGGL(il_scatter_kernel, dim3((nnz + 63) / 64, C), dim3(256), 0, m_stream, m_lhs_il.p, nnz, m_lhs.p,
+                       static_cast<long long>(nnz), m_batch);
+    m_lhs_in_il = false;
+  }
+  if (m_rhs_in_il) {
+    const int n = m_kdev.dim;
+    hipLaunchKernelGGL(il_scatter_kernel, dim3((n + 63) / 64, C), dim3(256), 0, m_stream, m_rhs_il.p, n, m_rhs.p,
+                       static_cast<long long>(n), m_batch);
+    m_rhs_in_il = false;
+  }
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
 void DeviceNlp::assemble() {
   m_lhs_stale = false;
-  if (m_batch >= kBatchPerThread) {
+  m_lhs_in_il = false;
+  if (m_il && m_il_direct) {
+    hipLaunchKernelGGL(kkt_assemble_il_kernel, dim3(grid_for(m_kdev.nnz_lhs, 64), il_groups(m_batch)), dim3(256), 0, m_stream,
+                       m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs_il.p, m_batch);
+    m_lhs_in_il = true;
+  } else if (m_batch >= kBatchPerThread) {
     // measured at 512 x N=1000: 1 problem per thread 0.084 ms, 2: 0.083, 4: 0.079, 8: 0.090
     hipLaunchKernelGGL(kkt_assemble_batch_kernel<kBatchPerThread>,
                        dim3(grid_for(m_kdev.nnz_lhs, 256), (m_batch + kBatchPerThread - 1) / kBatchPerThread),
@@ -1340,6 +1452,7 @@ void DeviceNlp::build_kkt(bool with_reduce) {
     return;
   }
   m_lhs_stale = m_rhs_stale = false;
+  m_lhs_in_il = m_rhs_in_il = false;
   const int na = grid_for((m_kdev.nnz_lhs + 3) / 4, 256), nr = grid_for(m_kdev.dim, 256);
   const int nred = with_reduce ? static_cast<int>(m_reduces.n) : 0;
   hipLaunchKernelGGL(kkt_build_kernel, dim3(na + nr + nred, m_batch), dim3(256), 0, m_stream, m_kdev, m_V.p,
@@ -1357,6 +1470,7 @@ void DeviceNlp::build_kkt_for_step(bool with_reduce) {
 
 void DeviceNlp::assemble_lsq() {
   m_lhs_stale = false;
+  m_lhs_in_il = false;
   hipLaunchKernelGGL(kkt_assemble_lsq_kernel, dim3(grid_for(m_kdev.nnz_lhs, 256), m_batch), dim3(256),
                      0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_lhs.p);
   hipLaunchKernelGGL(kkt_add_identity_kernel, dim3(grid_for(m_kdev.n, 256), m_batch), dim3(256), 0,
@@ -1402,6 +1516,14 @@ void DeviceNlp::refresh_params(const Graph& g) {
 
 void DeviceNlp::build_rhs() {
   m_rhs_stale = false;
+  m_rhs_in_il = false;
+  if (m_il && m_il_direct) {
+    hipLaunchKernelGGL(kkt_rhs_il_kernel, dim3((m_kdev.dim + 63) / 64, il_groups(m_batch)), dim3(256), 0, m_stream, m_kdev,
+                       m_V.p, m_s_ref.nV, m_s.p, m_y.p, m_z.p, m_mu.p, m_rhs_il.p, m_batch);
+    m_rhs_in_il = true;
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   // (a batch variant like kkt_assemble_batch_kernel was measured SLOWER here: 0.102 ms vs
   // 0.070 ms at 512 x N=1000 — the per-column loops are short and the extra registers cost
   // occupancy)
@@ -1492,10 +1614,13 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   if (m_il) {
     const int C = (m_batch + 63) / 64;
     const int nnz = m_kdev.nnz_lhs;
-    hipLaunchKernelGGL(il_gather_kernel, dim3((nnz + 63) / 64, C), dim3(256), 0, stream, m_lhs.p,
-                       static_cast<long long>(nnz), nnz, m_lhs_il.p, m_batch);
-    hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, stream, m_rhs.p,
-                       static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
+    // (the assembly kernels wrote the interleaved arrays themselves unless somebody else made lhs / rhs)
+    if (!m_lhs_in_il)
+      hipLaunchKernelGGL(il_gather_kernel, dim3((nnz + 63) / 64, C), dim3(256), 0, stream, m_lhs.p,
+                         static_cast<long long>(nnz), nnz, m_lhs_il.p, m_batch);
+    if (!m_rhs_in_il)
+      hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, stream, m_rhs.p,
+                         static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
@@ -1712,8 +1837,9 @@ void DeviceNlp::solve() {
   const int scs = static_cast<int>(std::max<uint32_t>(1, l.n_scontrib));
   if (m_il) {
     const int C = (m_batch + 63) / 64;
-    hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, m_stream, m_rhs.p,
-                       static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
+    if (!m_rhs_in_il)
+      hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, m_stream, m_rhs.p,
+                         static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
     for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_fwd_il_kernel, dim3(nt, C), dim3(kIlLanes), m_il_solve_lds, m_stream, m_ldev,
@@ -2002,6 +2128,7 @@ void DeviceNlp::ipm_soc_accumulate(double alpha, bool first, bool s_from_ci) {
 
 void DeviceNlp::ipm_soc_rhs() {
   m_rhs_stale = false;
+  m_rhs_in_il = false;
   hipLaunchKernelGGL(ipm_soc_rhs_kernel, dim3(grid_for(m_kdev.dim, 256)), dim3(256), 0, m_stream, m_kdev, m_V.p,
                      m_s.p, m_y.p, m_z.p, m_mu.p, m_soc_ce.p, m_soc_cims.p, m_rhs.p);
   SLPX_HIP_CHECK(hipGetLastError());

@@ -74,6 +74,7 @@ struct TapeDevice {
   // (mode 0 = values only, 1 = with adjoints) holds (first block, instances, instance
   // offset, row-group mode) per body, `tmpl_blocks[mode]` the grid size.
   hipFunction_t tmpl_fn = nullptr;
+  uint32_t tmpl_threads = 64;  // threads of a workgroup of tmpl_fn (TapeJitResult::block_threads)
   std::vector<unsigned char> tmpl_params;  // the model's numbers a generic code object reads (TemplateParams::blob)
   DevBuf<uint64_t> tmpl_params_dev;        // ... on the device: the kernel's last argument points here
   hipModule_t tmpl_mod = nullptr;

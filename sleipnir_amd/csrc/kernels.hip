@@ -370,6 +370,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
     tmpl_params_dev.upload(words);
   }
   tmpl_mod = jit.mod;
+  tmpl_threads = jit.block_threads;
   n_bodies = static_cast<uint32_t>(jit.groups.size());
   n_templated_tasks = 0;
   tmpl_blocks[0] = tmpl_blocks[1] = 0;
@@ -399,8 +400,8 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
       // Adjoint rows are split into wave-uniform groups while the launch would otherwise
       // leave most SIMDs idle; with enough instances x batch items every lane runs all
       // groups (-1) and the forward part is not recomputed per group.
-      const uint32_t waves = (n_inst + 63) / 64;
-      const bool split = waves * static_cast<uint32_t>(batch) < 512 && g.n_groups > 1;
+      const uint32_t waves = (n_inst + tmpl_threads - 1) / tmpl_threads;  // workgroups of one row group
+      const bool split = ((n_inst + 63) / 64) * static_cast<uint32_t>(batch) < 512 && g.n_groups > 1;
       const int mode[2] = {0, split ? static_cast<int>(g.n_groups) : -1};
       for (int m = 0; m < 2; ++m) {
         table[m].push_back(tmpl_blocks[m]);
@@ -420,7 +421,14 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
       if (!jit.task_is_templated[ti]) out.push_back(ti);
     return out;
   };
-  const std::vector<uint32_t> small_rest = interpreted(p.small_tasks), large_rest = interpreted(p.large_tasks);
+  std::vector<uint32_t> small_rest = interpreted(p.small_tasks), large_rest = interpreted(p.large_tasks);
+  uint32_t ride_lds = p.small_lds_bytes;
+  if (n_bodies && tmpl_threads == 256) {
+    // (tape_jit.cpp: the generated kernel's workgroups are 256 threads: every interpreted task rides in its launch)
+    small_rest.insert(small_rest.end(), large_rest.begin(), large_rest.end());
+    large_rest.clear();
+    ride_lds = std::max(p.small_lds_bytes, p.large_lds_bytes);
+  }
   small_list.upload(small_rest);
   large_list.upload(large_rest);
   global_list.upload(p.global_tasks);
@@ -451,7 +459,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   n_small = static_cast<uint32_t>(small_rest.size());
   n_large = static_cast<uint32_t>(large_rest.size());
   n_global = static_cast<uint32_t>(p.global_tasks.size());
-  small_lds = p.small_lds_bytes;
+  small_lds = ride_lds;
   large_lds = p.large_lds_bytes;
   scratch_doubles = p.global_scratch_doubles;
   basic_ops = p.basic_ops;
@@ -887,7 +895,7 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
                     &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
                     &params_dev, &chain, &wait_step, &this_step, &n_workgroups};
-    SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, 64, 1, 1, small_rides ? t.small_lds : 0u,
+    SLPX_HIP_CHECK(hipModuleLaunchKernel(t.tmpl_fn, grid, m_batch, 1, t.tmpl_threads, 1, 1, small_rides ? t.small_lds : 0u,
                                          small_stream, args, nullptr));
   }
   auto small_fn = t.basic_ops ? tape_sweep_lds_kernel<64, false> : tape_sweep_lds_kernel<64, true>;

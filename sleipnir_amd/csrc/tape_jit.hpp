@@ -44,6 +44,7 @@ struct TapeJitResult {
   std::vector<uint8_t> task_is_templated;  // per task of the program
   std::vector<unsigned char> params;       // the table behind the kernel's last argument (TemplateParams::blob)
   bool specialized = false;                // the code object has this model's numbers as literals
+  uint32_t block_threads = 64;             // threads of a workgroup of the kernel (256: the 256-thread interpreted tasks ride in it)
   double compile_seconds = 0.0;
   // TapeJitOptions::compile_without_device on a machine without a GPU: bodies that were
   // generated and compiled for gfx950 (>= 0), or -1 if hipRTC rejected the source
@@ -96,7 +97,7 @@ struct TemplateParams {
 };
 constexpr size_t kTemplateParamBytesMax = 16384;  // beyond this the numbers stay literals
 std::string generate_templates_source(const TapeProgram& prog, const std::vector<std::vector<uint32_t>>& families,
-                                      uint32_t n_unscaled_inputs, TemplateParams* params = nullptr);
+                                      uint32_t n_unscaled_inputs, TemplateParams* params = nullptr, uint32_t block_threads = 64);
 
 // Number of wave-uniform row groups the adjoint part of a template is split into.
 uint32_t template_row_groups(const TapeProgram& prog, const TapeTask& representative);

@@ -179,4 +179,8 @@ def test_generated_kernel_of_a_family_serves_every_horizon(fresh, slpx, tmp_path
     shared = names[16] & names[24]
     assert shared, "no code object in common: the generic source depends on the horizon"
     assert names[16] - shared and names[24] - shared  # the specialized ones
-    assert len(shared) == len(names[16]) - len(shared)  # one generic beside every specialized
+    # one generic beside every specialized — but for a tape whose 256-thread interpreted tasks exist at one
+    # horizon and not at the other: its generic kernel has workgroups of 256 there (those tasks ride in
+    # its launch, tape_jit.cpp: block_threads) and of 64 here, two code objects for the family
+    n_programs = len(names[16]) // 2
+    assert len(names[16]) == 2 * n_programs and n_programs - 1 <= len(shared) <= n_programs

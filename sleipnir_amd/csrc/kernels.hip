@@ -744,7 +744,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       meta[head + 1] = n_words;
       fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * kIlW * 8u, 3u * kIlSlots * kIlW * 8u) + 4u * n_words + 16u);
       col = std::max(col, t.n_col + 1);
-      solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (2u * t.n_col + 2u) + 8u * t.n_bwd_items + 16u);
+      solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (2u * t.n_col + t.n_lvl + 4u) + 8u * t.n_bwd_items + 16u);
     }
     m_il_meta.upload(meta);
     m_il_meta_off.upload(meta_off);
@@ -1892,7 +1892,7 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
     const int C = (m_batch + 63) / 64;
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-      hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes), m_il_solve_lds, m_stream, m_ldev,
+      hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes * kIlBwdWaves), m_il_solve_lds, m_stream, m_ldev,
                          l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch);
     }
     SLPX_HIP_CHECK(hipGetLastError());
@@ -1936,14 +1936,15 @@ void DeviceNlp::materialize_factor() {
   m_il_outputs_stale = false;
 }
 
-// Lane-per-problem pays once there are several 64-problem chunks per task to fill the chip
-// with (measured at N=500: batch 128 a tie with the per-task kernels, 256: 408 k vs 312 k
-// steps/s; at 512 x N=1000: 331 k vs 171 k).  SLPX_LDLT_IL=0 turns it off,
+// Lane-per-problem pays from one 64-problem chunk per task on (r02: from ~200 problems — the backward
+// solve was one wave per task and chunk, a chain of columns; with the columns of a level dealt to four
+// waves, 64 x N=500: 251 k steps/s against 224-238 k for the per-task kernels,
+// profiles/r03_b64_probe.txt; 512 x N=1000: 508 k vs 171 k).  SLPX_LDLT_IL=0 turns it off,
 // SLPX_IL_MIN_BATCH moves the threshold.
 bool DeviceNlp::interleaved_for(int batch) {
   if (const char* env = std::getenv("SLPX_LDLT_IL"))
     if (env[0] == '0') return false;
-  int min_batch = 192;
+  int min_batch = 64;
   if (const char* env = std::getenv("SLPX_IL_MIN_BATCH")) min_batch = std::atoi(env);
   return batch >= min_batch;
 }

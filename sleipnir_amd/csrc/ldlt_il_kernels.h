@@ -370,19 +370,19 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_fwd_il_kernel(
 
 // Backward substitution Lᵀ x = z; x of the task's columns goes to xg_il (for descendants,
 // later launches) and un-permuted to the batch-major solution.
-// LDS: x[n_col][64] | bwd_ptr[n_col + 1] | col_perm[n_col] | bwd_items[n_bwd_items].
-// The chain runs through x from column to column; everything that does not depend on x is kept
-// off it: the plan slices are copied to LDS up front (a global read of a column's item records
-// was a memory round trip per column before the L values could even be asked for), and the first
-// eight L values of the NEXT column are requested before the current column is reduced
-// (measured: backward solve of 512 x N=500 0.183 -> 0.171 ms, of 512 x N=1000 0.263 -> 0.257 ms;
-// what remains is the top rounds: a handful of tasks per launch, each a chain of columns).
-__global__ __launch_bounds__(kIlLanes) void ldlt_bwd_il_kernel(
+// A workgroup = one task x 64 problems x kIlBwdWaves waves: a lane is a problem, and the COLUMNS OF A
+// LEVEL — independent of each other: a column's items reference later levels of the task or rows
+// of ancestor tasks — are dealt to the waves, a barrier per level.  (r02: one wave per task walked the
+// columns one after the other — one wave per CU in the upper rounds, a chain of ~100 columns with a
+// trip to memory for each column's L values; 512 x N=1000: 0.25 ms, 64 x N=500: 0.13 ms.)
+// LDS: x[n_col][64] | bwd_ptr[n_col + 1] | col_perm[n_col] | column levels[n_lvl + 1] | bwd_items[n_bwd_items].
+constexpr int kIlBwdWaves = 4;
+__global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx_il, long long nnzL,
     const double* __restrict__ zv_il, double* __restrict__ xg_il, double* __restrict__ out, int batch) {
   extern __shared__ __attribute__((aligned(16))) double il_smem[];
   const LdltTask t = L.tasks[task_base + blockIdx.x];
-  const int c = blockIdx.y, lane = threadIdx.x;
+  const int c = blockIdx.y, tid = threadIdx.x, lane = tid & (kIlLanes - 1), wave = tid >> 6;
   const int b = c * kIlLanes + lane;
   const size_t g = static_cast<size_t>(c) * kIlRowsPerChunk + (lane >> kIlWShift);
   const int pl = lane & (kIlW - 1);
@@ -392,19 +392,23 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_bwd_il_kernel(
   double* x = il_smem + lane;
   uint32_t* s_ptr = reinterpret_cast<uint32_t*>(il_smem + static_cast<size_t>(t.n_col) * kIlLanes);
   uint32_t* s_colperm = s_ptr + t.n_col + 1;
-  // (8-byte aligned: the x rows are a multiple of 512 bytes, the two word arrays together 2 n_col + 1 words)
-  LdltSolveItem* s_items = reinterpret_cast<LdltSolveItem*>(s_colperm + t.n_col + ((2 * t.n_col + 1) & 1u));
+  uint32_t* s_lvl = s_colperm + t.n_col;
+  // (8-byte aligned: the x rows are a multiple of 512 bytes; the three word arrays together 2 n_col + n_lvl + 2 words)
+  LdltSolveItem* s_items = reinterpret_cast<LdltSolveItem*>(s_lvl + t.n_lvl + 1 + ((2 * t.n_col + t.n_lvl + 2) & 1u));
   {
     const uint32_t* g_ptr = L.bwd_ptr + t.colptr_off;
     const uint32_t* g_colperm = L.col_perm + t.col_off;
+    const uint32_t* g_lvl = L.col_lvl_ptr + t.lvl_off;
     const LdltSolveItem* g_items = L.bwd_items + t.bwd_item_off;
-    for (uint32_t k = lane; k <= t.n_col; k += kIlLanes) s_ptr[k] = g_ptr[k];
-    for (uint32_t k = lane; k < t.n_col; k += kIlLanes) s_colperm[k] = g_colperm[k];
-    for (uint32_t k = lane; k < t.n_bwd_items; k += kIlLanes) s_items[k] = g_items[k];
+    constexpr int kThreads = kIlLanes * kIlBwdWaves;
+    for (uint32_t k = tid; k <= t.n_col; k += kThreads) s_ptr[k] = g_ptr[k];
+    for (uint32_t k = tid; k < t.n_col; k += kThreads) s_colperm[k] = g_colperm[k];
+    for (uint32_t k = tid; k <= t.n_lvl; k += kThreads) s_lvl[k] = g_lvl[k];
+    for (uint32_t k = tid; k < t.n_bwd_items; k += kThreads) s_items[k] = g_items[k];
   }
   __syncthreads();
-  // columns from the last level down: a column's items reference later local columns or
-  // rows of ancestor tasks (bit 31: global permuted row, final since an earlier launch)
+  // a column's items reference later levels' columns or rows of ancestor tasks (bit 31: global permuted
+  // row, final since an earlier launch)
   auto operand = [&](const LdltSolveItem it) {
     return (it.ref & 0x80000000u) ? xg[static_cast<size_t>(it.ref & 0x7fffffffu) * kIlW] : x[it.ref * kIlLanes];
   };
@@ -417,36 +421,33 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_bwd_il_kernel(
       lv[j] = live ? Lx[static_cast<size_t>(its[j].lpos) * kIlW] : 0.0;
     }
   };
-  double lv[8], nlv[8];
-  LdltSolveItem its[8], nits[8];
-  if (t.n_col) request(s_ptr[t.n_col - 1], s_ptr[t.n_col], lv, its);
-  for (int i = static_cast<int>(t.n_col) - 1; i >= 0; --i) {
-    double acc = zv[static_cast<size_t>(s_colperm[i]) * kIlW];
-    uint32_t q = s_ptr[i];
-    const uint32_t qe = s_ptr[i + 1];
-    if (i > 0) request(s_ptr[i - 1], s_ptr[i], nlv, nits);  // not on the chain: in flight during the reduction below
-    // eight at a time, two partial sums each (the order the sums have always had)
-    for (bool first = true; q < qe; q += 8, first = false) {
-      if (!first) request(q, qe, lv, its);
-      double xv[8];
+  for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+    const int lo = static_cast<int>(s_lvl[l]);
+    for (int i = static_cast<int>(s_lvl[l + 1]) - 1 - wave; i >= lo; i -= kIlBwdWaves) {
+      double acc = zv[static_cast<size_t>(s_colperm[i]) * kIlW];
+      uint32_t q = s_ptr[i];
+      const uint32_t qe = s_ptr[i + 1];
+      // eight at a time, two partial sums each (the order the sums have always had)
+      for (; q < qe; q += 8) {
+        double lv[8];
+        LdltSolveItem its[8];
+        request(q, qe, lv, its);
+        double xv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xv[j] = q + j < qe ? operand(its[j]) : 0.0;
-      double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < 8; ++j) xv[j] = q + j < qe ? operand(its[j]) : 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        s0 += lv[j] * xv[j];
-        s1 += lv[j + 1] * xv[j + 1];
+        for (int j = 0; j < 8; j += 2) {
+          s0 += lv[j] * xv[j];
+          s1 += lv[j + 1] * xv[j + 1];
+        }
+        acc -= s0 + s1;
       }
-      acc -= s0 + s1;
+      x[i * kIlLanes] = acc;
     }
-    x[i * kIlLanes] = acc;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      lv[j] = nlv[j];
-      its[j] = nits[j];
-    }
+    __syncthreads();
   }
-  for (uint32_t i = 0; i < t.n_col; ++i) {
+  for (uint32_t i = wave; i < t.n_col; i += kIlBwdWaves) {
     const uint32_t pj = s_colperm[i];
     const double v = x[i * kIlLanes];
     xg[static_cast<size_t>(pj) * kIlW] = v;

@@ -45,7 +45,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // one lane per problem (ldlt_il_kernels.h): a task's values x 64 problems must fit LDS
     // (measured at 512 x N=1000, ms per factorization: 192 -> 0.55 but some problems then need a
     // second attempt, 384 -> 0.67, 768 -> 0.79, 1024 -> 1.25)
-    if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+    // (below ~200 problems the rounds, not the chip, bound a factorization: fewer, bigger tasks — 64 x N=500:
+    // 384 entries 242 k steps/s, 512: 251 k, 768: 247 k)
+    if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
     // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
@@ -160,7 +162,7 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   m_k.ae_rowptr.assign(m_e + 1, 0);
   LdltOptions lopt = opt.ldlt;
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
-  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = 384;
+  if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
   m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);

@@ -133,26 +133,29 @@ def test_config4_batch_of_n500(fresh, slpx, orc):
     for b in (61, 62, 63):  # equal inputs -> bit-identical outputs, wherever they sit in the batch
         for key in ("p", "p_s", "p_z"):
             assert np.array_equal(full[key][b], full[key][b - 61])
-    # sharding (sleipnir_amd.dist.shard_range) does not change any item: bit-identical while
-    # the shards stay in the same plan class (batches >= 16 use half-size LDLT tasks,
-    # newton.cpp), otherwise each item still solves its own system to the same accuracy
+    # sharding (sleipnir_amd.dist.shard_range) does not change any item: bit-identical while the shards
+    # stay in the same plan class (newton.cpp: 64-191 problems run the lane-per-problem kernels on
+    # 512-entry tasks — this batch is one block of a 128-problem batch split in two —, 16-63 the per-task
+    # kernels on half-size tasks, fewer the single problem's plan), otherwise each item still solves its
+    # own system to the same accuracy
     from sleipnir_amd.dist import shard_range
 
-    shard = list(shard_range(B, 1, 2))
-    part = run(shard)
-    for j, b in enumerate(shard):
+    twice = list(range(B)) + list(range(B))
+    assert list(shard_range(2 * B, 1, 2)) == list(range(B, 2 * B))
+    whole = run(twice)
+    for b in range(B):
         for key in ("p", "p_s", "p_z"):
-            assert np.array_equal(part[key][j], full[key][b])
-    shard = list(shard_range(B, 3, 8))
-    part = run(shard)
-    for j, b in enumerate(shard):
-        delta, gamma = part["reg"][j]
-        assert (delta, gamma) == tuple(full["reg"][b])
-        assert backward_error(cp, ri, part["lhs"][j], n, delta, gamma, part["p"][j], part["rhs"][j]) <= 1e-10
+            assert np.array_equal(whole[key][b], full[key][b]) and np.array_equal(whole[key][B + b], full[key][b])
+    for shard in (list(shard_range(B, 1, 2)), list(shard_range(B, 3, 8))):
+        part = run(shard)
+        for j, b in enumerate(shard):
+            delta, gamma = part["reg"][j]
+            assert (delta, gamma) == tuple(full["reg"][b])
+            assert backward_error(cp, ri, part["lhs"][j], n, delta, gamma, part["p"][j], part["rhs"][j]) <= 1e-10
 
 
 def test_batch_interleaved_ldlt(fresh, slpx, orc, monkeypatch):
-    """Batches of ~200 problems and more factor and solve with one LANE per problem
+    """Batches of 64 problems and more factor and solve with one LANE per problem
     (sleipnir_amd/csrc/ldlt_il_kernels.h: 16-wide interleaved value arrays, small tasks).
     Every item must solve ITS system (normwise backward error, as for the per-task kernels),
     equal inputs must give bit-identical outputs wherever they sit in the batch — including

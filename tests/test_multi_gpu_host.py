@@ -55,13 +55,15 @@ def test_cxx_host_one_rank_through_rccl(slpx, tmp_path):
 @pytest.mark.gpu
 def test_cxx_host_blocks_of_a_split_give_the_steps_of_the_whole(slpx):
     build(slpx)
-    whole = run([64, 200, 3, "--no-comm"], RANK=0, WORLD_SIZE=1)
+    # (128 problems: the whole and its two blocks of 64 are in the same plan class — lane-per-problem
+    # kernels, 512-entry tasks, newton.cpp — so that the comparison can be to the bit)
+    whole = run([128, 200, 3, "--no-comm"], RANK=0, WORLD_SIZE=1)
     assert whole.returncode == 0, whole.stdout + whole.stderr
     rows = [l for l in whole.stdout.splitlines() if l.startswith("row ")]
-    assert len(rows) == 64 and all(" info 0 " in r for r in rows)
+    assert len(rows) == 128 and all(" info 0 " in r for r in rows)
     split = []
     for rank in (0, 1):
-        part = run([64, 200, 3, "--no-comm"], RANK=rank, WORLD_SIZE=2)
+        part = run([128, 200, 3, "--no-comm"], RANK=rank, WORLD_SIZE=2)
         assert part.returncode == 0, part.stdout + part.stderr
         split += [l for l in part.stdout.splitlines() if l.startswith("row ")]
     assert split == rows  # same problems, same order, same bits of (delta, gamma) and of the step

@@ -376,6 +376,9 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_fwd_il_kernel(
 // columns one after the other — one wave per CU in the upper rounds, a chain of ~100 columns with a
 // trip to memory for each column's L values; 512 x N=1000: 0.25 ms, 64 x N=500: 0.13 ms.)
 // LDS: x[n_col][64] | bwd_ptr[n_col + 1] | col_perm[n_col] | column levels[n_lvl + 1] | bwd_items[n_bwd_items].
+// (measured on one box, ms per backward solve at 64 x N=500 / 512 x N=1000: 2 waves 0.101 / 0.229, 4 waves
+// 0.090 / 0.218, 8 waves 0.088 / 0.226; the next column's L values requested one column — and one barrier —
+// ahead, as the one-wave kernel did: 0.109 / 0.244, the registers cost more than the trip)
 constexpr int kIlBwdWaves = 4;
 __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx_il, long long nnzL,

@@ -66,4 +66,8 @@ rm -rf $O/pmc_mfma
 SLPX_MFMA_MIN_ENTRIES=128 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_mfma -- python bench.py --workload gfold --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_mfma.log 2>&1
 python profiles/mfma_counters.py $O/pmc_mfma > $N/${TAG}_gfold_mfma.json 2>> $O/collect.log
 rm -rf $O/pmc_mfma
+# 7. the round's measured experiments that stayed behind switches, and the small-batch probe
+bash profiles/chain_ab.sh > $N/${TAG}_chain_ab.txt 2>&1
+[ -x profiles/microbench/anyorder_bin ] && ./profiles/microbench/anyorder_bin > $N/${TAG}_microbench_anyorder.txt 2>&1
+bash profiles/b64_probe.sh > $N/${TAG}_b64_probe.txt 2>&1
 tail -5 $O/collect.log

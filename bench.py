@@ -188,7 +188,7 @@ def batched_probe(sa, cases, N, B, device):
     if tfile.exists() and N == 1000 and B == 512:
         tj = json.loads(tfile.read_text())
         pre = {"tape_sweep": ("tape_sweep", "slpx_tape_templates", "tape_reduce_kernel"),
-               "kkt_assemble": ("kkt_assemble",), "kkt_rhs": ("kkt_rhs_kernel",),
+               "kkt_assemble": ("kkt_assemble",), "kkt_rhs": ("kkt_rhs_kernel", "kkt_rhs_il_kernel"),
                "ldlt_factor": ("ldlt_factor_il_kernel", "il_gather_kernel", "ldlt_stats_il_kernel"),
                "ldlt_solve": ("ldlt_bwd_il_kernel",)}
         # grids with fewer than 100000 threads are the single-problem launches of the same run
@@ -370,12 +370,16 @@ def main():
             traffic_by_group = {}
             for grp, pre in prefix.items():
                 pres = pre if isinstance(pre, tuple) else (pre,)
-                traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for kname, grids in tj.items()
-                                            if kname.startswith(pres) for e in grids.values())
+                names = [k for k in tj if k.startswith(pres)]
+                # (the step kernel has two variants in the same run: the one of a chained step — last template
+                # argument true, waits for its sweep — and the one the launch-duration probe times: that one)
+                if sum(k.startswith("ldlt_mf_step_kernel") for k in names) > 1:
+                    names = [k for k in names if not k.startswith("ldlt_mf_step_kernel") or k.endswith("false>")]
+                traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for k in names for e in tj[k].values())
         single = args.workload in ("single", "gfold") and B == 1
         roofline = {
             "bound": "hbm", "kernel": dom,
-            "kernel_symbol": (("ldlt_mf_step_kernel" if fused.get("multifrontal") else "ldlt_factor_solve_kernel")
+            "kernel_symbol": (("ldlt_mf_step_kernel<.., false>" if fused.get("multifrontal") else "ldlt_factor_solve_kernel")
                               if fused is not None and dom.startswith("kkt_factor") and fused["one_launch"] else None),
             "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

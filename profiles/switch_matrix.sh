@@ -3,7 +3,7 @@
 for v in "SLPX_FUSE_LAUNCHES=0" "SLPX_FUSE_KKT=0" "SLPX_FUSE_BACKSUB=0" "SLPX_FUSE_SOLVE=0" "SLPX_XG_HANDOFF=0" \
          "SLPX_STEP_GRAPH=1" "SLPX_SUPERNODAL=0" "SLPX_SLOT_HANDOFF=0" "SLPX_SINGLE_LAUNCH=0" "SLPX_SEQ_POLL=0" \
          "SLPX_TAPE_JIT=0" "SLPX_TAPE_SPECIALIZE=0" "SLPX_IPM_RESIDENT=0" "SLPX_LDLT_IL=0" "SLPX_TAPE_CSE=0" \
-         "SLPX_LDLT_MF=0" "SLPX_RELAX_ZEROS=0" "SLPX_RELAX_ZEROS=32" "SLPX_MFMA_MIN_ENTRIES=0" "SLPX_MF_THREADS=512" "SLPX_CHAIN_TAPE=1" "SLPX_CHAIN_TAPE=1 SLPX_CHAIN_STORE=wt" "SLPX_MF_BATCH=1" "SLPX_IL_DIRECT=0"; do
+         "SLPX_LDLT_MF=0" "SLPX_RELAX_ZEROS=0" "SLPX_RELAX_ZEROS=32" "SLPX_MFMA_MIN_ENTRIES=0" "SLPX_MF_THREADS=512" "SLPX_CHAIN_TAPE=0" "SLPX_CHAIN_STORE=fence" "SLPX_MF_BATCH=1" "SLPX_IL_DIRECT=0"; do
   echo -n "$v: "
   env $v timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -1
 done

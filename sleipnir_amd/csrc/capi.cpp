@@ -228,7 +228,12 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
     std::string log;
     const int a = slpx::prebuild_tape_templates(st.full, opt, where, log);
     const int b = slpx::prebuild_tape_templates(st.values, opt, where, log);
-    if (a < 0 || b < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
+    // (and the full sweep's kernel as a chained step launches it: DeviceNlp picks that variant for one
+    // problem whose step kernel leaves the sweep room on the chip)
+    slpx::TapeJitOptions copt = opt;
+    copt.chain_mode = 2;
+    const int c = slpx::prebuild_tape_templates(st.full, copt, where, log);
+    if (a < 0 || b < 0 || c < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
     bodies = a + b;
     // the feasibility-restoration system a solve compiles on first use (csrc/ipm.cpp)
     if (!ce.empty() || !ci.empty()) {

@@ -84,7 +84,7 @@ struct TapeDevice {
   uint32_t tmpl_blocks[2] = {0, 0};
   uint32_t n_templated_tasks = 0;
   double jit_seconds = 0.0;
-  void upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs);
+  void upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs, int chain_mode = 0);
   TapeDev view() const;
 };
 
@@ -563,6 +563,8 @@ class DeviceNlp {
   // through, last step whose sweep is complete, workgroups of the step kernel through, last step whose
   // kernel is complete
   bool m_chain_on = false;
+  int m_chain_mode = 0;               // TapeJitOptions::chain_mode the full tape's kernel was generated with
+  bool m_last_step_chained = false;   // the last multifrontal step kernel launched signals its end through the chain words
   hipStream_t m_tape_stream = nullptr;
   hipEvent_t m_chain_ev = nullptr;
   DevBuf<unsigned int> m_chain;

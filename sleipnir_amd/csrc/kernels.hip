@@ -354,12 +354,13 @@ __global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::Sum
 // DeviceNlp
 // ============================================================================
 
-void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs) {
+void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs, int chain_mode) {
   tasks.upload(p.tasks);
   // families of structurally identical tasks and the big singles get a body in the
   // generated lane-per-task kernel; everything else is interpreted
   TapeJitOptions jit_opt;
   jit_opt.n_unscaled_inputs = n_unscaled_inputs;  // x: set_scaling leaves their factor at 1
+  jit_opt.chain_mode = chain_mode;
   const TapeJitResult jit = build_tape_templates(p, jit_opt);
   jit_seconds = jit.compile_seconds;
   tmpl_fn = jit.fn;
@@ -480,7 +481,20 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     throw std::runtime_error("slpx: no HIP device available (the product path has no CPU fallback)");
   SLPX_HIP_CHECK(hipSetDevice(device));
 
-  m_full.upload(s.full, batch, static_cast<uint32_t>(s.n));
+  // Chained steps (sweep_full_for_step): for one problem whose multifrontal step kernel leaves the sweep
+  // room on the chip (at most CUs - 64 workgroups: cart-pole N=5000's 265 do not, and there chaining costs
+  // 25 %, profiles/r03_chain_ab.txt).  SLPX_CHAIN_TAPE=0: off; SLPX_CHAIN_STORE=fence: ordinary stores to V
+  // and a release fence per workgroup of the sweep instead of stores written through.
+  {
+    int cus = 0;
+    SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+    if (batch == 1 && l.mf && static_cast<int>(l.tasks.size() + s.reduces.size()) + 64 <= cus) m_chain_mode = 2;
+    if (const char* env = std::getenv("SLPX_CHAIN_STORE"))
+      if (m_chain_mode && std::string(env) == "fence") m_chain_mode = 1;
+    if (const char* env = std::getenv("SLPX_CHAIN_TAPE"))
+      if (env[0] == '0') m_chain_mode = 0;
+  }
+  m_full.upload(s.full, batch, static_cast<uint32_t>(s.n), m_chain_mode);
   m_values.upload(s.values, batch, static_cast<uint32_t>(s.n));
   m_reduces.upload(s.reduces);
   // allow > 64 KB dynamic LDS
@@ -618,12 +632,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
   if (m_mf) m_fuse_solve = true;
   if (batch > 1 && !m_il && !m_single_launch && l.mf) build_mf_batch(l);
-  // chained steps (sweep_full_for_step): off unless SLPX_CHAIN_TAPE=1 — measured on cart-pole, steps/s chained
-  // vs not: N=100 +8 %, N=300 +3 %, N=1000 -1 % (the sweep shares the chip with the step kernel's 137
-  // workgroups and takes 10 us instead of 7), N=5000 -25 % (265 workgroups leave the sweep no CU):
-  // profiles/r03_chain_ab.txt
-  m_chain_on = false;
-  if (const char* env = std::getenv("SLPX_CHAIN_TAPE")) m_chain_on = m_mf && batch == 1 && env[0] == '1';
+  m_chain_on = m_mf && m_chain_mode != 0;
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -927,7 +936,9 @@ void DeviceNlp::sweep_full_for_step() {
   const TapeDevice& t = m_full;
   // one generated kernel is the whole sweep (nothing interpreted beside it), the step is the one-launch
   // multifrontal kernel, and no graph is being captured
-  const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0;
+  // (and its workgroups are single waves: g-fold's sweep, 256-thread workgroups interpreting its packs of
+  // rows, shares the chip badly with the step kernel — 13.3 k steps/s chained against 13.6 k)
+  const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0 && t.tmpl_threads == 64;
   if (!m_chain_on || !one_kernel || !m_mf || m_batch != 1 || m_capturing || xg_other() == nullptr || !m_fuse_solve) {
     sweep_full(/*with_reduce=*/false);
     return;
@@ -939,32 +950,40 @@ void DeviceNlp::sweep_full_for_step() {
     m_stream.tape = m_tape_stream;
     m_chain.upload(std::vector<unsigned int>(128, 0u));
   }
+  m_tape_reduce = false;
   if (m_stream.touched) {
-    // something else went to the main stream since the last chained step (an upload, another kernel that
-    // reads V): the sweep's stream catches up with all of it
-    SLPX_HIP_CHECK(hipEventRecord(m_chain_ev, m_stream.raw()));
-    SLPX_HIP_CHECK(hipStreamWaitEvent(m_tape_stream, m_chain_ev, 0));
+    // Something else went to the main stream since the last step (an upload of the state, a download of
+    // the result, another kernel): this step's sweep goes there too, behind all of it — the pattern of a
+    // caller that looks at every step costs nothing extra.  Only steps that FOLLOW a step directly chain.
     m_stream.touched = false;
+    launch_tape(m_full, true, m_stream.raw(), m_stream.raw());
+    m_tape_reduce = true;
+    return;
   }
   static const bool chain_debug = std::getenv("SLPX_CHAIN_DEBUG") != nullptr;
   if (chain_debug && m_chain_seq % 500 == 499) {
-    // the wall clocks (100 MHz) the last two chained steps left: sweep first workgroup in / through its wait /
-    // last workgroup out, step kernel last workgroup in / staged / through its wait / last workgroup out
+    // the wall clocks (100 MHz) the last chained step left (builds with -DSLPX_CHAIN_STAMPS): sweep first
+    // workgroup in / through its wait / last workgroup out, step kernel last workgroup in / staged / through
+    // its wait / last workgroup out
     SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
     SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
     std::vector<unsigned int> w(128);
     SLPX_HIP_CHECK(hipMemcpy(w.data(), m_chain.p, w.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
     const unsigned long long* st = reinterpret_cast<const unsigned long long*>(w.data() + 64);
-    static unsigned long long prev_done = 0;
     auto us = [&](unsigned long long v) { return (static_cast<double>(static_cast<long long>(v - st[0]))) / 100.0; };
-    std::fprintf(stderr, "chain step %u: sweep in 0.0, waited %.2f, out %.2f | step kernel in %.2f, staged %.2f, waited %.2f, out %.2f us (previous debug point's out %.2f)\n",
-                 m_chain_seq, us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]), us(st[6]), us(prev_done));
-    prev_done = st[6];
+    std::fprintf(stderr, "chain step %u: sweep in 0.0, waited %.2f, out %.2f | step kernel in %.2f, staged %.2f, waited %.2f, out %.2f us\n",
+                 m_chain_seq, us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]), us(st[6]));
   }
-  const unsigned int prev = m_chain_seq;
+  // the step kernel before this sweep: a chained one tells the sweep itself when its last workgroup is
+  // through; any other (the first step of a run, a re-attempt of the policy loop) through an event, once
+  unsigned int wait_step = m_chain_seq;
+  if (!m_last_step_chained) {
+    SLPX_HIP_CHECK(hipEventRecord(m_chain_ev, m_stream.raw()));
+    SLPX_HIP_CHECK(hipStreamWaitEvent(m_tape_stream, m_chain_ev, 0));
+    wait_step = 0;
+  }
   ++m_chain_seq;
-  m_chain_args = ChainArgs{m_chain.p, prev, m_chain_seq};
-  m_tape_reduce = false;
+  m_chain_args = ChainArgs{m_chain.p, wait_step, m_chain_seq};
   launch_tape(m_full, true, m_tape_stream, m_tape_stream);
   m_tape_reduce = true;
   m_chain_args = ChainArgs{};
@@ -1242,11 +1261,13 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
     };
     m_mf_mfma = l.mf_n_mfma > 0;
     m_mf_threads = 1024;
-    fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<1024, true>, 1024) : resident(&ldlt_mf_step_kernel<1024, false>, 1024);
+    fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<1024, true, true>, 1024) && resident(&ldlt_mf_step_kernel<1024, true, false>, 1024)
+                     : resident(&ldlt_mf_step_kernel<1024, false, true>, 1024) && resident(&ldlt_mf_step_kernel<1024, false, false>, 1024);
     if (const char* env = std::getenv("SLPX_MF_THREADS")) fits = fits && std::atoi(env) == 1024;
     if (!fits) {
       m_mf_threads = 512;
-      fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<512, true>, 512) : resident(&ldlt_mf_step_kernel<512, false>, 512);
+      fits = m_mf_mfma ? resident(&ldlt_mf_step_kernel<512, true, true>, 512) && resident(&ldlt_mf_step_kernel<512, true, false>, 512)
+                       : resident(&ldlt_mf_step_kernel<512, false, true>, 512) && resident(&ldlt_mf_step_kernel<512, false, false>, 512);
     }
   }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
@@ -1704,22 +1725,26 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
     md.n_tasks = static_cast<unsigned int>(l.tasks.size());
     md.exit_cnt = m_exit_cnt.p;
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
-    // a chained step (sweep_full_for_step): the kernel waits for its sweep itself, and the main stream
-    // stays "untouched" — the next step's sweep needs no event to come after this launch, it waits for
-    // this kernel's last workgroup
+    // a chained step (sweep_full_for_step): the kernel variant that waits for its sweep itself and whose last
+    // workgroup tells the next step's sweep; the main stream stays "untouched" by a step's own launches
     const bool chained = m_stream.tape_pending;
-    md.chain = m_chain.p;
+    md.chain = chained ? m_chain.p : nullptr;
     md.wait_step = chained ? m_chain_seq : 0u;
     md.this_step = m_chain_seq;
     md.n_workgroups = grid.x;
     m_stream.tape_pending = false;
-    if (!chained) m_stream.touched = true;
+    m_last_step_chained = chained;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
                          l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
     };
-    if (m_mf_threads == 1024) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false>, 1024);
-    else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true>, 512) : launch(&ldlt_mf_step_kernel<512, false>, 512);
+    if (m_mf_threads == 1024) {
+      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, true>, 1024);
+      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, false>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, false>, 1024);
+    } else {
+      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, true>, 512) : launch(&ldlt_mf_step_kernel<512, false, true>, 512);
+      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, false>, 512) : launch(&ldlt_mf_step_kernel<512, false, false>, 512);
+    }
     xg_flip();
     SLPX_HIP_CHECK(hipGetLastError());
     return;

@@ -494,7 +494,9 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
   return c;
 }
 
-template <int THREADS, bool MFMA>
+// CHAINED: the variant of a chained step (DeviceNlp::sweep_full_for_step) — it waits for its sweep after
+// staging and counts its workgroups out; the other variant has none of that code.
+template <int THREADS, bool MFMA, bool CHAINED>
 __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
@@ -502,16 +504,16 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (static_cast<int>(blockIdx.x) < F.n_blocks) {
-    mf_wait_for_sweep(Mf, stats);
+    if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
     ride_along_sum(F, blockIdx.x, smem_raw);
-    mf_signal_done(Mf);
+    if constexpr (CHAINED) mf_signal_done(Mf);
     return;
   }
   const int tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
 #ifdef SLPX_CHAIN_STAMPS
-  if (Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
+  if (CHAINED && Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
 #endif
   const LdltTask t = L.tasks[task_index];
   const LdltMfTask m = Mf.tasks[task_index];
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(1);
-  mf_wait_for_sweep(Mf, stats);
+  if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
 
   // ---- matrix values (ldlt_factor_body) ----
   if (!F.inline_kkt) {
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   }
   SLPX_LDLT_CLOCK(20);
   if (top) exit_and_count();
-  mf_signal_done(Mf);
+  if constexpr (CHAINED) mf_signal_done(Mf);
 }
 
 // ---------------------------------------------------------------------------

@@ -397,7 +397,10 @@ def main():
             "regularization": regularization,
             "note": (f"single N={N} problem: every kernel is dependency-latency bound (SURVEY.md §7 hard "
                      "part 1); the HBM fractions that mean something are in `batched` (same kernels' "
-                     "batch variants on 64 x N=500 and 512 x N=1000)") if single else
+                     "batch variants on 64 x N=500 and 512 x N=1000).  launch_ms: back-to-back launches of "
+                     "the step kernel on its own (variant <.., false>: profiles/*_kernel_stats.csv has it "
+                     "as a row of its own); in the timed loop consecutive steps are chained — the variant "
+                     "<.., true> is dispatched beside the sweep, and its row's span includes waiting for it") if single else
                     f"{B} problems of N={N} per launch on this rank",
         }
         workload = ("%s N=%d, %d problem(s) per GPU (replicas), seeded interior "

@@ -350,6 +350,21 @@ __global__ __launch_bounds__(64) void tape_reduce_kernel(const NlpStructure::Sum
   tape_reduce_body(red[blockIdx.x], scales, V, part, threadIdx.x);
 }
 
+// Can two kernels of this process run at once?  Chained steps (DeviceNlp::sweep_full_for_step) need the
+// sweep and the step kernel resident together; a profiler collecting hardware counters (rocprofv3 --pmc)
+// or AMD_SERIALIZE_KERNEL runs one kernel at a time, and a step kernel waiting for a sweep that cannot
+// start would sit out its spin bound (seen: 247 ms per step under --pmc).  So, once per system: a kernel
+// on the sweep's stream waits — a few milliseconds at most — for a word a kernel on the main stream sets.
+__global__ void chain_probe_wait_kernel(unsigned int* w) {
+  unsigned int seen = 0;
+  for (int k = 0; k < 3000 && !seen; ++k) {
+    seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(32);
+  }
+  w[1] = seen ? 1u : 2u;
+}
+__global__ void chain_probe_set_kernel(unsigned int* w) { __hip_atomic_store(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ============================================================================
 // DeviceNlp
 // ============================================================================
@@ -949,6 +964,19 @@ void DeviceNlp::sweep_full_for_step() {
     SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_stream.ev, hipEventDisableTiming));
     m_stream.tape = m_tape_stream;
     m_chain.upload(std::vector<unsigned int>(128, 0u));
+    // (words 96, 97: the concurrency probe, see chain_probe_wait_kernel)
+    hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(1), 0, m_tape_stream, m_chain.p + 96);
+    hipLaunchKernelGGL(chain_probe_set_kernel, dim3(1), dim3(1), 0, m_stream.raw(), m_chain.p + 96);
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+    unsigned int verdict = 0;
+    SLPX_HIP_CHECK(hipMemcpy(&verdict, m_chain.p + 97, sizeof(verdict), hipMemcpyDeviceToHost));
+    if (verdict != 1u) {
+      m_chain_on = false;  // kernels run one at a time here: the sweep stays in the main stream
+      if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "slpx: kernels of two streams do not run at once here: steps are not chained\n");
+      sweep_full(/*with_reduce=*/false);
+      return;
+    }
   }
   m_tape_reduce = false;
   if (m_stream.touched) {

@@ -375,7 +375,10 @@ def main():
                 # argument true, waits for its sweep — and the one the launch-duration probe times: that one)
                 if sum(k.startswith("ldlt_mf_step_kernel") for k in names) > 1:
                     names = [k for k in names if not k.startswith("ldlt_mf_step_kernel") or k.endswith("false>")]
-                traffic_by_group[grp] = sum(e["hbm_bytes_per_launch"] for k in names for e in tj[k].values())
+                # (a kernel launched with two grid sizes in the profiled run — the step kernel with and without a
+                # workgroup for the sweep's separable sums — counts once: the grid launched most often)
+                traffic_by_group[grp] = sum(max(tj[k].values(), key=lambda e: e.get("launches_sampled", 0))["hbm_bytes_per_launch"]
+                                            for k in names)
         single = args.workload in ("single", "gfold") and B == 1
         roofline = {
             "bound": "hbm", "kernel": dom,

@@ -48,3 +48,34 @@ def test_chained_steps_give_the_bits_of_the_unchained_ones(fresh, slpx, orc, mon
             assert np.array_equal(u, v)
     # (and the states do differ: the comparison is not of one repeated step)
     assert not np.array_equal(plain[0][0], plain[2][0])
+
+
+def test_no_chaining_where_kernels_run_one_at_a_time(tmp_path):
+    """A profiler collecting hardware counters (rocprofv3 --pmc) or AMD_SERIALIZE_KERNEL runs one kernel at a
+    time: a step kernel dispatched beside its sweep would wait for a sweep that cannot start.  The one-time
+    probe (chain_probe_wait_kernel) sees that and keeps the sweep in the main stream: steps succeed, at
+    their ordinary pace."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import time, numpy as np, sleipnir_amd as sa\n"
+        "from tests.support import cases\n"
+        "pp = sa.Problem.cart_pole(100, 0.05)\n"
+        "n, me, mi = pp.dims\n"
+        "sy = sa.System(pp, batch=1, device=0)\n"
+        "x, s, y, z, mu = cases.newton_state('interior', pp.get_x(), n, me, mi, 1.0)\n"
+        "sy.set_state(x, s, y, z, np.array([mu]))\n"
+        "assert np.all(sy.newton_steps(20) == 0)\n"
+        "t0 = time.time(); info = sy.newton_steps(200); dt = time.time() - t0\n"
+        "assert np.all(info == 0), info\n"
+        "print('per step us', 1e6 * dt / 200)\n"
+        "assert dt / 200 < 5e-3\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3", SLPX_LDLT_VERBOSE="1", PYTHONPATH=root)
+    env.pop("SLPX_CHAIN_TAPE", None)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "steps are not chained" in res.stderr, res.stderr[-2000:]

@@ -1,12 +1,11 @@
 set -x
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out; N=$O/profiles_new; TAG=r03
-rm -rf $O/prof $O/pmc_fetch $O/pmc_write $N; mkdir -p $N
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write; mkdir -p $N
 FAST="--no-cpu-baseline --no-batched --no-whole-solve"
-python bench.py --steps 2000 --warmup 200 $FAST 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'): d=json.loads(l); print('plain', d['value'], d['ms_per_step'])"
+# the default workload's evidence alone (collect_all.sh steps 0-2): unprofiled default command, kernel trace, counters
+timeout 900 python bench.py > $O/bench_unprofiled.log 2> $O/bench_unprofiled.err
+grep '^{' $O/bench_unprofiled.log | tail -1 > $N/${TAG}_bench_unprofiled.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $FAST > $O/bench_profiled.log 2> $O/bench_profiled.err
 grep '^{' $O/bench_profiled.log | tail -1 > $N/${TAG}_bench.json
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_fetch.log 2>&1

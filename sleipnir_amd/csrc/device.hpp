@@ -313,10 +313,11 @@ class DeviceNlp {
   // reductions (they only feed f) to the build_kkt(true) that must follow.
   void sweep_full(bool with_reduce = true);
   // The sweep of a Newton step whose factor_solve_publish() follows at once (no reductions: they ride in
-  // that launch).  Where the step is the one-launch multifrontal kernel, the sweep goes to a stream of its
-  // own and the two kernels order themselves through a word in memory (StepChain below): the step kernel
-  // is dispatched and stages its plan WHILE the sweep runs, and the sweep of the next step starts the
-  // moment this step's kernel is through — no launch boundary on either side.
+  // that launch).  Where the step is the one-launch multifrontal kernel and this step follows another
+  // directly (nothing else was handed the main stream in between), the sweep goes to a stream of its own
+  // and the two kernels order themselves through words in memory (m_chain below): the step kernel is
+  // dispatched and stages its plan WHILE the sweep runs, and the sweep of the next step starts the moment
+  // this step's kernel is through — no launch boundary on either side.  DESIGN.md §4, "chained steps".
   void sweep_full_for_step();
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs

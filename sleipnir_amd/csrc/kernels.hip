@@ -112,9 +112,9 @@ __global__ __launch_bounds__(256) void kkt_assemble_batch_kernel(KktDev K, const
 // lhs: a thread = one entry of FOUR consecutive problems, four adjacent lanes = the 16 problems of
 // the entry's row: every 128-byte row is written whole by one quad, and a wave's loads of one
 // problem's V are sixteen consecutive entries' sources.
-__global__ __launch_bounds__(256) void kkt_assemble_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
-                                                              const double* __restrict__ s, const double* __restrict__ z,
-                                                              double* __restrict__ lhs_il, int batch) {
+__device__ __forceinline__ void kkt_assemble_il_body(const KktDev& K, const double* __restrict__ V, int v_stride,
+                                                     const double* __restrict__ s, const double* __restrict__ z,
+                                                     double* __restrict__ lhs_il, int batch, int vblock, int vgrid) {
   constexpr int P = 4;
   const int g = blockIdx.y, sub = threadIdx.x & 3;
   const int b0 = g * kIlW + sub * P;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void kkt_assemble_il_kernel(KktDev K, const do
   s += bb0 * K.m_i;
   z += bb0 * K.m_i;
   double* out = lhs_il + static_cast<size_t>(g) * K.nnz_lhs * kIlW + sub * P;
-  for (int k = blockIdx.x * 64 + (threadIdx.x >> 2); k < K.nnz_lhs; k += gridDim.x * 64) {
+  for (int k = vblock * 64 + (threadIdx.x >> 2); k < K.nnz_lhs; k += vgrid * 64) {
     const int f = K.fast_src[k];
     double v[P];
 #pragma unroll
@@ -161,15 +161,21 @@ __global__ __launch_bounds__(256) void kkt_assemble_il_kernel(KktDev K, const do
   }
 }
 
+__global__ __launch_bounds__(256) void kkt_assemble_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
+                                                              const double* __restrict__ s, const double* __restrict__ z,
+                                                              double* __restrict__ lhs_il, int batch) {
+  kkt_assemble_il_body(K, V, v_stride, s, z, lhs_il, batch, blockIdx.x, gridDim.x);
+}
+
 // rhs: 64 rows x 16 problems per workgroup through LDS — a row is computed by one lane per problem
 // group of four (consecutive lanes = consecutive rows: the row's sources in V are nearly consecutive),
 // written as whole 128-byte rows.
-__global__ __launch_bounds__(256) void kkt_rhs_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
-                                                         const double* __restrict__ s, const double* __restrict__ y,
-                                                         const double* __restrict__ z, const double* __restrict__ mu,
-                                                         double* __restrict__ rhs_il, int batch) {
+__device__ __forceinline__ void kkt_rhs_il_body(const KktDev& K, const double* __restrict__ V, int v_stride,
+                                                const double* __restrict__ s, const double* __restrict__ y,
+                                                const double* __restrict__ z, const double* __restrict__ mu,
+                                                double* __restrict__ rhs_il, int batch, int vblock) {
   __shared__ double tile[kIlW][65];
-  const int g = blockIdx.y, i0 = blockIdx.x * 64;
+  const int g = blockIdx.y, i0 = vblock * 64;
   const int il = threadIdx.x & 63, bq = threadIdx.x >> 6;
   const int j = i0 + il;
 #pragma unroll
@@ -188,6 +194,23 @@ __global__ __launch_bounds__(256) void kkt_rhs_il_kernel(KktDev K, const double*
     const int idx = threadIdx.x + 256 * jj, pl = idx & (kIlW - 1), r = idx >> kIlWShift;
     if (i0 + r < K.dim) rhs_il[(static_cast<size_t>(g) * K.dim + i0 + r) * kIlW + pl] = tile[pl][r];
   }
+}
+__global__ __launch_bounds__(256) void kkt_rhs_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
+                                                         const double* __restrict__ s, const double* __restrict__ y,
+                                                         const double* __restrict__ z, const double* __restrict__ mu,
+                                                         double* __restrict__ rhs_il, int batch) {
+  kkt_rhs_il_body(K, V, v_stride, s, y, z, mu, rhs_il, batch, blockIdx.x);
+}
+// lhs and rhs in ONE launch (a Newton step builds both: neither reads the other's output) — workgroups
+// [0, na) assemble, the rest take 64 rows of the right-hand side each.  A small batch's two launches are
+// latency each (64 x N=500: 15 + 16 us); side by side they cost the longer one.
+__global__ __launch_bounds__(256) void kkt_build_il_kernel(KktDev K, const double* __restrict__ V, int v_stride,
+                                                           const double* __restrict__ s, const double* __restrict__ y,
+                                                           const double* __restrict__ z, const double* __restrict__ mu,
+                                                           double* __restrict__ lhs_il, double* __restrict__ rhs_il, int batch,
+                                                           int na) {
+  if (static_cast<int>(blockIdx.x) < na) kkt_assemble_il_body(K, V, v_stride, s, z, lhs_il, batch, blockIdx.x, na);
+  else kkt_rhs_il_body(K, V, v_stride, s, y, z, mu, rhs_il, batch, static_cast<int>(blockIdx.x) - na);
 }
 
 // Least-squares multiplier estimate (util/lagrange_multiplier_estimate.hpp:56-133) on the
@@ -1495,8 +1518,17 @@ void DeviceNlp::assemble() {
 // lhs + rhs (+ the separable-sum reductions a sweep_full(false) left out) in one launch
 void DeviceNlp::build_kkt(bool with_reduce) {
   if (m_batch >= kBatchPerThread) {  // throughput regime: the batch kernels, separately
-    assemble();
-    build_rhs();
+    if (m_il && m_il_direct) {
+      // (interleaved lhs and rhs: one launch, kkt_build_il_kernel)
+      const int na = grid_for(m_kdev.nnz_lhs, 64), nr = (m_kdev.dim + 63) / 64;
+      hipLaunchKernelGGL(kkt_build_il_kernel, dim3(na + nr, il_groups(m_batch)), dim3(256), 0, m_stream, m_kdev, m_V.p,
+                         m_s_ref.nV, m_s.p, m_y.p, m_z.p, m_mu.p, m_lhs_il.p, m_rhs_il.p, m_batch, na);
+      m_lhs_stale = m_rhs_stale = false;
+      m_lhs_in_il = m_rhs_in_il = true;
+    } else {
+      assemble();
+      build_rhs();
+    }
     if (with_reduce && m_reduces.n)
       hipLaunchKernelGGL(tape_reduce_kernel, dim3(static_cast<uint32_t>(m_reduces.n), m_batch), dim3(64), 0,
                          m_stream, m_reduces.p, m_scales.p, m_V.p, m_s_ref.nV);

@@ -42,6 +42,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+from tests.support import models
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROFILE_TAG = "r03"    # profiles/<tag>_traffic.json feeds roofline.traffic
@@ -126,7 +127,7 @@ def make_system(sa, cases, N, problem_ids, device, kind="cart_pole"):
 
         pp = gfold.build(model.Model(model.ProductBackend("gpu")), N).p
     else:
-        pp = sa.Problem.cart_pole(N, dt)
+        pp = models.cart_pole(N, dt)
     t_model = time.perf_counter() - t0
     B = len(problem_ids)
     t0 = time.perf_counter()
@@ -208,7 +209,7 @@ def whole_solve(sa, N):
     """Problem::solve() at the BASELINE horizon (status, iterations, wall time) — outside the
     timed region; the iteration path is the product's resident IPM (csrc/ipm.cpp)."""
     sa.lib().slpx_graph_reset()
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     status, rep = pp.solve()
     pp.close()
     return {"N": N, "status": int(status), "iterations": int(rep["iterations"]),

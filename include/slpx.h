@@ -31,6 +31,13 @@ typedef struct slpx_problem slpx_problem;
 typedef struct slpx_system slpx_system;
 
 /* ---- library ------------------------------------------------------------ */
+/* ABI history.  4: slpx_options.spy appended.  5: slpx_problem_solve() reads the options struct as it
+ * was up to version 3 and therefore IGNORES `spy` — a caller that sets it must call
+ * slpx_problem_solve_sized(p, &opt, sizeof opt, &report) (present since version 5: check
+ * slpx_abi_version() >= 5 before binding it); the two benchmark-model constructors of versions <= 4
+ * (slpx_problem_cart_pole / _flywheel) are gone: a model is the CALLER's program, built through the
+ * slp:: surface or slpx_expr_* / slpx_problem_* (tests/support/models/ holds the benchmarks' as fixtures). */
+#define SLPX_ABI_VERSION 5
 int slpx_abi_version(void);
 const char* slpx_last_error(void);
 int slpx_device_count(void);
@@ -166,11 +173,6 @@ int slpx_problem_restoration_steps(slpx_problem* p, const slpx_options* opt, dou
  * `dir` (NULL: <directory of libslpx.so>/jit_cache, where slpx_system_create looks before it
  * compiles anything).  Returns the number of generated bodies, < 0 on failure. */
 int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir);
-
-/* The reference's benchmark models, built with the C++ slp:: surface:
- * benchmarks/scalability/cart_pole/sleipnir.cpp:76-129, .../flywheel/sleipnir.cpp:12-42 */
-slpx_problem* slpx_problem_cart_pole(int32_t N, double dt);
-slpx_problem* slpx_problem_flywheel(int32_t N, double dt);
 
 /* ---- compiled Newton system ------------------------------------------------------
  * One problem structure compiled for one GPU, `batch` independent value sets.

@@ -2,10 +2,11 @@ import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 case = sys.argv[2] if len(sys.argv) > 2 else "step0"
 sa.lib().slpx_graph_reset()
-pp = sa.Problem.cart_pole(N, 5.0 / N)
+pp = models.cart_pole(N, 5.0 / N)
 sy = sa.System(pp, batch=1, device=0)
 n, me, mi = sy.info["n"], sy.info["m_e"], sy.info["m_i"]
 x, s, y, z, mu = cases.newton_state(case, pp.get_x(), n, me, mi, 1.0)

@@ -5,11 +5,12 @@ import sys
 import time
 
 import sleipnir_amd as sa
+from tests.support import models
 
 Ns = [int(a) for a in sys.argv[1:]] or [50, 100, 150, 200, 300, 400, 500, 600, 700, 800, 900, 1000]
 for N in Ns:
     sa.lib().slpx_graph_reset()
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     t0 = time.perf_counter()
     st, rep = pp.solve()
     print(f"N {N:5d} status {st:3d} iterations {rep['iterations']:5d} restorations {rep['restorations']:3d} "

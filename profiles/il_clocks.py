@@ -13,13 +13,14 @@ import numpy as np
 
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 L = sa.lib()
 L.slpx_debug_ldlt_clocks.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
 L.slpx_graph_reset()
-pp = sa.Problem.cart_pole(N, 5.0 / N)
+pp = models.cart_pole(N, 5.0 / N)
 sy = sa.System(pp, batch=B, device=0)
 info = sy.info
 n, me, mi = info["n"], info["m_e"], info["m_i"]

@@ -12,12 +12,13 @@ import numpy as np
 
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 L = sa.lib()
 L.slpx_debug_ldlt_clocks.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
 L.slpx_graph_reset()
-pp = sa.Problem.cart_pole(N, 5.0 / N)
+pp = models.cart_pole(N, 5.0 / N)
 sy = sa.System(pp, batch=1, device=0)
 info = sy.info
 n, me, mi = info["n"], info["m_e"], info["m_i"]

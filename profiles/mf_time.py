@@ -10,6 +10,7 @@ import numpy as np
 
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 
 for arg in sys.argv[1:] or ["1000"]:
     sa.lib().slpx_graph_reset()
@@ -20,7 +21,7 @@ for arg in sys.argv[1:] or ["1000"]:
         pp = gfold.build(model.Model(model.ProductBackend("gpu")), 100).p
     else:
         N = int(arg)
-        pp = sa.Problem.cart_pole(N, 5.0 / N)
+        pp = models.cart_pole(N, 5.0 / N)
     sy = sa.System(pp, batch=1, device=0)
     n, me, mi = sy.info["n"], sy.info["m_e"], sy.info["m_i"]
     x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)

@@ -7,11 +7,12 @@ import sys
 import numpy as np
 
 import sleipnir_amd as sa
+from tests.support import models
 
 for N in [int(a) for a in sys.argv[1:]] or [500, 1000]:
     for k in range(6):
         sa.lib().slpx_graph_reset()
-        pp = sa.Problem.cart_pole(N, 5.0 / N)
+        pp = models.cart_pole(N, 5.0 / N)
         x = pp.get_x()
         rng = np.random.default_rng(k)
         if k:

@@ -10,10 +10,11 @@ sys.path.insert(0, '/root/repo')
 os.environ["SLPX_SETUP_TIMING"] = "1"
 os.environ["SLPX_TAPE_JIT_VERBOSE"] = "1"
 import sleipnir_amd as sa  # noqa: E402
+from tests.support import models
 
 for N in (1000, 700):
     sa.lib().slpx_graph_reset()
-    t = time.time(); pp = sa.Problem.cart_pole(N, 5.0 / N); print(f"model N={N}", time.time() - t)
+    t = time.time(); pp = models.cart_pole(N, 5.0 / N); print(f"model N={N}", time.time() - t)
     t = time.time(); s = sa.System(pp, 1, 0); print(f"system N={N}", time.time() - t)
     s.close()
     t = time.time(); s = sa.System(pp, 1, 0); print(f"system again N={N}", time.time() - t)

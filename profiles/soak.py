@@ -12,11 +12,12 @@ import numpy as np
 
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 
 
 def soak(N, B, steps):
     sa.lib().slpx_graph_reset()
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     n, me, mi = pp.dims
     st = [cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0, seed=cases.SEED + b) for b in range(B)]
     sy = sa.System(pp, batch=B, device=0)

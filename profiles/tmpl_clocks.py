@@ -3,8 +3,9 @@ os.environ["SLPX_TAPE_JIT_CLOCKS"] = "1"
 os.environ["SLPX_TAPE_JIT_VERBOSE"] = "1"
 import numpy as np
 import sleipnir_amd as sa
+from tests.support import models
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-pp = sa.Problem.cart_pole(N, 5.0 / N)
+pp = models.cart_pole(N, 5.0 / N)
 system = sa.System(pp)
 L = sa.lib()
 L.slpx_debug_tmpl_clocks.restype = ctypes.c_int

@@ -20,6 +20,8 @@ _ROOT = _PKG.parent
 # (SLPX_LIB: another build of the library, e.g. for an A/B on one box)
 LIB_PATH = Path(os.environ["SLPX_LIB"]).resolve() if os.environ.get("SLPX_LIB") else _PKG / "libslpx.so"
 
+ABI_VERSION = 5  # include/slpx.h: SLPX_ABI_VERSION (struct layouts and entry points below)
+
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_f64p = ctypes.POINTER(ctypes.c_double)
@@ -60,24 +62,6 @@ class Report(ctypes.Structure):
                 ("t_restoration", ctypes.c_double)]
 
 
-PREBUILT_MODELS = (("cart_pole", 1000), ("cart_pole", 500), ("cart_pole", 5000), ("cart_pole", 100), ("cart_pole", 50))
-
-
-def prebuild_kernels(models=PREBUILT_MODELS) -> int:
-    """Code objects of the generated tape kernels of the BASELINE models into
-    sleipnir_amd/jit_cache/ (built artefacts like libslpx.so: they travel with the tree, not with
-    the history).  hipRTC cross-compiles for gfx950 without a device; ~1 s per model, skipped for
-    code objects that are already there."""
-    total = 0
-    for kind, N in models:
-        lib().slpx_graph_reset()
-        p = Problem.cart_pole(N, 5.0 / N) if kind == "cart_pole" else Problem.flywheel(N, 5.0 / N)
-        total += p.prebuild_kernels()
-        p.close()
-    lib().slpx_graph_reset()
-    return total
-
-
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile libslpx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     cmd = ["make", "-C", str(_PKG / "csrc"), "-j", str(os.cpu_count() or 4)]
@@ -108,6 +92,8 @@ def lib() -> ctypes.CDLL:
         fn.argtypes = list(argtypes)
 
     sig("slpx_abi_version", ctypes.c_int)
+    if L.slpx_abi_version() != ABI_VERSION:
+        raise SlpxError(f"{LIB_PATH} has ABI version {L.slpx_abi_version()}, this binding was written for {ABI_VERSION}")
     sig("slpx_last_error", ctypes.c_char_p)
     sig("slpx_device_count", ctypes.c_int)
     sig("slpx_shard_range", ctypes.c_int, i64, i32, i32, c_i64p, c_i64p)
@@ -139,8 +125,6 @@ def lib() -> ctypes.CDLL:
     sig("slpx_problem_get_duals", None, vp, vp, vp, vp)
     sig("slpx_problem_restoration_steps", ctypes.c_int, vp, ctypes.POINTER(Options), vp, vp, vp, vp, f64, i32)
     sig("slpx_problem_prebuild_kernels", ctypes.c_int, vp, ctypes.c_char_p)
-    sig("slpx_problem_cart_pole", vp, i32, f64)
-    sig("slpx_problem_flywheel", vp, i32, f64)
     sig("slpx_system_create", vp, vp, i32, i32, vp, i32)
     sig("slpx_system_destroy", None, vp)
     sig("slpx_system_set_stream", ctypes.c_int, vp, vp)
@@ -213,14 +197,6 @@ class Problem:
         self._h = handle if handle is not None else lib().slpx_problem_create()
         if not self._h:
             raise SlpxError(lib().slpx_last_error().decode())
-
-    @classmethod
-    def cart_pole(cls, N: int, dt: float) -> "Problem":
-        return cls(lib().slpx_problem_cart_pole(N, dt))
-
-    @classmethod
-    def flywheel(cls, N: int, dt: float) -> "Problem":
-        return cls(lib().slpx_problem_flywheel(N, dt))
 
     def close(self):
         if self._h:

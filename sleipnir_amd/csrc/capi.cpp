@@ -15,7 +15,6 @@
 #include "capi_internal.hpp"
 #include "ipm.hpp"
 #include "tape_jit.hpp"
-#include "problems.hpp"
 
 namespace {
 thread_local std::string g_error;
@@ -37,7 +36,7 @@ int guard(F&& f) {
 
 extern "C" {
 
-int slpx_abi_version(void) { return 4; }
+int slpx_abi_version(void) { return SLPX_ABI_VERSION; }
 const char* slpx_last_error(void) { return g_error.c_str(); }
 int slpx_device_count(void) {
   int count = 0;
@@ -249,23 +248,6 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
     }
   });
   return rc == 0 ? bodies : rc;
-}
-
-slpx_problem* slpx_problem_cart_pole(int32_t N, double dt) {
-  auto* p = new slpx_problem();
-  if (guard([&] { slpx_models::build_cart_pole(p->problem, dt, N); }) != 0) {
-    delete p;
-    return nullptr;
-  }
-  return p;
-}
-slpx_problem* slpx_problem_flywheel(int32_t N, double dt) {
-  auto* p = new slpx_problem();
-  if (guard([&] { slpx_models::build_flywheel(p->problem, dt, N); }) != 0) {
-    delete p;
-    return nullptr;
-  }
-  return p;
 }
 
 slpx_system* slpx_system_create(slpx_problem* p, int32_t batch, int32_t device, const int32_t* perm,

@@ -3,6 +3,7 @@ comparison helpers used by both the CPU (host-check) and GPU parity tests."""
 from __future__ import annotations
 
 import numpy as np
+from tests.support import models
 
 SEED = 20260928
 
@@ -11,9 +12,9 @@ def build_pair(kind: str, N: int, sa, oracle):
     """Builds the same benchmark problem in the product and in the oracle."""
     dt = 5.0 / N
     if kind == "cart_pole":
-        return sa.Problem.cart_pole(N, dt), oracle.OracleProblem.cart_pole(N, dt)
+        return models.cart_pole(N, dt), oracle.OracleProblem.cart_pole(N, dt)
     if kind == "flywheel":
-        return sa.Problem.flywheel(N, dt), oracle.OracleProblem.flywheel(N, dt)
+        return models.flywheel(N, dt), oracle.OracleProblem.flywheel(N, dt)
     raise ValueError(kind)
 
 

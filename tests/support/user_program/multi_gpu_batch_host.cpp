@@ -12,7 +12,7 @@
 // --no-comm skips RCCL and prints this rank's rows only: with RANK / WORLD_SIZE set by hand it
 // shows on ONE device that a problem's step does not depend on the shard it is in.
 //
-//   hipcc -O2 -std=c++17 multi_gpu_batch_host.cpp -I include -L sleipnir_amd -lslpx -lrccl
+//   hipcc -O2 -std=c++17 multi_gpu_batch_host.cpp -I include -L sleipnir_amd -lslpx -L tests/support -lslpx_models -lrccl
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <slpx.h>
@@ -26,6 +26,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+// the model is the host's own program: here the benchmark fixture (tests/support/models/bench_models.cpp)
+extern "C" slpx_problem* bench_models_cart_pole(int32_t N, double dt);
 
 namespace {
 #define CHECK_HIP(x)                                                                     \
@@ -115,7 +118,7 @@ int main(int argc, char** argv) {
   int64_t lo = 0, hi = 0;
   slpx_shard_range(total, rank, world, &lo, &hi);
   const int mine = static_cast<int>(hi - lo);
-  slpx_problem* xp = slpx_problem_cart_pole(N, 5.0 / N);  // the same structure on every rank
+  slpx_problem* xp = bench_models_cart_pole(N, 5.0 / N);  // the same structure on every rank
   int32_t n = 0, m_e = 0, m_i = 0;
   slpx_problem_dims(xp, &n, &m_e, &m_i);
   std::vector<double> x0(n);

@@ -6,6 +6,7 @@ import subprocess
 from pathlib import Path
 
 import pytest
+from tests.support import models
 
 ROOT = Path(__file__).resolve().parents[1]
 HEADER = ROOT / "include" / "slpx.h"
@@ -22,7 +23,7 @@ def test_library_exports_every_declared_symbol(slpx):
     assert len(names) >= 45, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.slpx_abi_version() == 4  # (the header the Python binding's struct layouts were written against)
+    assert lib.slpx_abi_version() == slpx.ABI_VERSION == 5  # (the header the Python binding's struct layouts were written against)
 
 
 def test_header_cites_the_reference_interfaces():
@@ -51,12 +52,23 @@ def test_product_does_not_reference_oracle():
     assert "torch" not in out  # C-ABI: no torch types, no torch linkage
 
 
+def test_product_library_holds_no_benchmark_model(slpx):
+    """the reference's benchmark programs are fixtures (tests/support/models/),
+    not product source — libslpx.so exports nothing named after them and its sources do not hold them."""
+    pkg = Path(slpx.__file__).resolve().parent
+    out = subprocess.run(["nm", "-D", "--defined-only", str(pkg / "libslpx.so")], capture_output=True, text=True).stdout
+    assert out and not re.search(r"cart_pole|flywheel", out)
+    for src in (pkg / "csrc").rglob("*"):
+        if src.is_file() and src.suffix in (".cpp", ".hpp", ".h", ".hip"):
+            assert not re.search(r"cart_pole_dynamics|build_cart_pole|build_flywheel", src.read_text()), src
+
+
 def test_no_cpu_fallback(slpx, fresh):
     """Without a HIP device the compiled Newton system cannot be created and solve()
     reports a library error; nothing is computed on the CPU instead."""
     if slpx.lib().slpx_device_count() > 0:
         pytest.skip("HIP device present")
-    p = slpx.Problem.flywheel(5, 1.0)
+    p = models.flywheel(5, 1.0)
     with pytest.raises(slpx.SlpxError):
         slpx.System(p)
     with pytest.raises(slpx.SlpxError):

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import sleipnir_amd as sa
+from tests.support import models
 
 pytestmark = pytest.mark.gpu
 
@@ -14,7 +15,7 @@ CALLBACK_REQUESTED_STOP = 1  # exit_status.hpp:17
 
 
 def test_callback_runs_once_per_iteration_and_sees_the_iterate():
-    p = sa.Problem.flywheel(50, 0.005)
+    p = models.flywheel(50, 0.005)
     n, m_e, m_i = p.dims
     seen = []
 
@@ -30,7 +31,7 @@ def test_callback_runs_once_per_iteration_and_sees_the_iterate():
     assert status == 0
     assert seen == list(range(rep["iterations"]))
     # the solve is the same one with and without a (passive) callback
-    q = sa.Problem.flywheel(50, 0.005)
+    q = models.flywheel(50, 0.005)
     status_q, rep_q = q.solve()
     assert status_q == 0 and rep_q["iterations"] == rep["iterations"]
     np.testing.assert_allclose(p.get_x(), q.get_x(), rtol=1e-9, atol=1e-12)
@@ -39,7 +40,7 @@ def test_callback_runs_once_per_iteration_and_sees_the_iterate():
 
 
 def test_callback_can_stop_the_solve_and_can_be_cleared():
-    p = sa.Problem.cart_pole(100, 5.0 / 100)  # (N = 50 is one of the fragile horizons)
+    p = models.cart_pole(100, 5.0 / 100)  # (N = 50 is one of the fragile horizons)
     x0 = p.get_x()
     p.add_callback(lambda info: info["iteration"] == 3)
     status, rep = p.solve()
@@ -52,7 +53,7 @@ def test_callback_can_stop_the_solve_and_can_be_cleared():
 
 
 def test_callback_matrices_follow_the_static_patterns():
-    p = sa.Problem.flywheel(20, 0.005)
+    p = models.flywheel(20, 0.005)
     sysh = p.system()  # borrowed: same system solve() runs on
     n, m_e, m_i = p.dims
     assert (sysh.info["n"], sysh.info["m_e"], sysh.info["m_i"]) == (n, m_e, m_i)

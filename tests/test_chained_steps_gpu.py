@@ -61,8 +61,8 @@ def test_no_chaining_where_kernels_run_one_at_a_time(tmp_path):
 
     code = (
         "import time, numpy as np, sleipnir_amd as sa\n"
-        "from tests.support import cases\n"
-        "pp = sa.Problem.cart_pole(100, 0.05)\n"
+        "from tests.support import cases, models\n"
+        "pp = models.cart_pole(100, 0.05)\n"
         "n, me, mi = pp.dims\n"
         "sy = sa.System(pp, batch=1, device=0)\n"
         "x, s, y, z, mu = cases.newton_state('interior', pp.get_x(), n, me, mi, 1.0)\n"

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from tests.support import cases
+from tests.support import models
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def test_batched_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_graph):
     monkeypatch.setenv("SLPX_STEP_GRAPH", step_graph)
     N, B, iters = 500, 64, 400
-    pp = slpx.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     n, me, mi = pp.dims
     x0 = pp.get_x()
     st = [cases.newton_state("interior", x0, n, me, mi, 1.0, seed=cases.SEED + b) for b in range(B)]
@@ -45,7 +46,7 @@ def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch,
     in pinned memory.  A lost ordering anywhere in there is a rare wrong step."""
     monkeypatch.setenv("SLPX_STEP_GRAPH", step_graph)
     N, iters = 300, 1500
-    pp = slpx.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     n, me, mi = pp.dims
     x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)
     system = slpx.System(pp, batch=1, device=0)
@@ -71,7 +72,7 @@ def test_generic_and_specialized_tape_kernels_give_the_same_bits(fresh, slpx, mo
     for kind, env in (("specialized", "1"), ("generic", "0")):
         monkeypatch.setenv("SLPX_TAPE_SPECIALIZE", env)
         slpx.lib().slpx_graph_reset()
-        pp = slpx.Problem.cart_pole(N, 5.0 / N)
+        pp = models.cart_pole(N, 5.0 / N)
         n, me, mi = pp.dims
         x, s, y, z, mu = cases.newton_state("interior", pp.get_x(), n, me, mi, 1.0)
         system = slpx.System(pp, batch=1, device=0)

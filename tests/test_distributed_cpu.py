@@ -12,6 +12,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+from tests.support import models
 
 ROOT = Path(__file__).resolve().parents[1]
 
@@ -51,7 +52,7 @@ def _step_rows(problem_ids, N):
     from tests.support import cases, hostcheck
 
     sa.lib().slpx_graph_reset()
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     hc = hostcheck.HostCheck(pp)
     n, me, mi = hc.n, hc.m_e, hc.m_i
     x0 = pp.get_x()

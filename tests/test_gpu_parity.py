@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from tests.support import cases, parity
+from tests.support import models
 
 pytestmark = pytest.mark.gpu
 
@@ -156,7 +157,7 @@ def test_generated_tape_kernel_matches_the_interpreter_bit_for_bit(fresh, slpx, 
     def sweep(jit):
         monkeypatch.setenv("SLPX_TAPE_JIT", jit)
         slpx.lib().slpx_graph_reset()
-        pp = slpx.Problem.cart_pole(120, 5.0 / 120)
+        pp = models.cart_pole(120, 5.0 / 120)
         n, me, mi = pp.dims
         system = slpx.System(pp, batch=1, device=0)
         try:

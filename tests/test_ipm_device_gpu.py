@@ -15,6 +15,7 @@ import pytest
 
 import sleipnir_amd as sa
 from tests.support import cases
+from tests.support import models
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +37,7 @@ def ftb(x, p, tau):
 @pytest.fixture(scope="module")
 def stepped():
     N = 40
-    pp = sa.Problem.cart_pole(N, 5.0 / N)
+    pp = models.cart_pole(N, 5.0 / N)
     system = sa.System(pp)
     info = dict(system.info)
     n, me, mi = info["n"], info["m_e"], info["m_i"]
@@ -201,10 +202,10 @@ def _solve(make, resident):
     # with the pair lists, N=300 the other way round under some switches of
     # profiles/switch_matrix.sh) — so the horizon is the first of a short list on which the host
     # driver converges; the resident driver must then converge on it too.
-    ("cart_pole", [lambda: sa.Problem.cart_pole(300, 5.0 / 300), lambda: sa.Problem.cart_pole(150, 5.0 / 150),
-                   lambda: sa.Problem.cart_pole(500, 5.0 / 500), lambda: sa.Problem.cart_pole(400, 5.0 / 400)]),
-    ("cart_pole_100", [lambda: sa.Problem.cart_pole(100, 0.05)]),   # restoration on the way
-    ("flywheel_50", [lambda: sa.Problem.flywheel(50, 0.005)]),
+    ("cart_pole", [lambda: models.cart_pole(300, 5.0 / 300), lambda: models.cart_pole(150, 5.0 / 150),
+                   lambda: models.cart_pole(500, 5.0 / 500), lambda: models.cart_pole(400, 5.0 / 400)]),
+    ("cart_pole_100", [lambda: models.cart_pole(100, 0.05)]),   # restoration on the way
+    ("flywheel_50", [lambda: models.flywheel(50, 0.005)]),
 ])
 def test_resident_solve_matches_host_driver(name, makes):
     tried = []
@@ -242,7 +243,7 @@ def test_a_solve_is_reproducible_bit_for_bit(resident):
     refinement of the multiplier estimate used them at first, and the trajectory of a swing-up —
     chaotic in the last bits, profiles/r02_oracle_sensitivity.txt — then differed from run to
     run): two solves of the same model give the same iterates, to the bit."""
-    runs = [_solve(lambda: sa.Problem.cart_pole(100, 0.05), resident) for _ in range(3)]
+    runs = [_solve(lambda: models.cart_pole(100, 0.05), resident) for _ in range(3)]
     st0, rep0, x0, duals0 = runs[0]
     assert st0 == 0
     for st, rep, x, duals in runs[1:]:

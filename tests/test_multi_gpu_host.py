@@ -20,12 +20,17 @@ BIN = ROOT / "build" / "multi_gpu_batch_host"
 
 
 def build(slpx):
-    if BIN.exists() and BIN.stat().st_mtime > max(SRC.stat().st_mtime, slpx.LIB_PATH.stat().st_mtime):
+    from tests.support import models
+
+    models.lib()  # (the cart-pole model the host steps: a fixture library, not part of libslpx.so)
+    if BIN.exists() and BIN.stat().st_mtime > max(SRC.stat().st_mtime, slpx.LIB_PATH.stat().st_mtime,
+                                                    models.LIB_PATH.stat().st_mtime):
         return
     BIN.parent.mkdir(parents=True, exist_ok=True)
     lib_dir = slpx.LIB_PATH.parent
     cmd = ["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", str(SRC), "-o", str(BIN),
-           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-lrccl", "-Wl,-rpath," + str(lib_dir)]
+           "-I" + str(ROOT / "include"), "-L" + str(lib_dir), "-lslpx", "-L" + str(models.LIB_PATH.parent),
+           "-lslpx_models", "-lrccl", "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath," + str(models.LIB_PATH.parent)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
 

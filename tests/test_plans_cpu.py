@@ -5,6 +5,7 @@ nlp.cpp, kkt_plan.cpp and ldlt_symbolic.cpp without a GPU."""
 import pytest
 
 from tests.support import cases, parity
+from tests.support import models
 
 
 @pytest.mark.parametrize("kind,N", [("cart_pole", 4), ("cart_pole", 37), ("flywheel", 50)])
@@ -172,7 +173,7 @@ def test_generated_kernel_of_a_family_serves_every_horizon(fresh, slpx, tmp_path
     names = {}
     for N in (16, 24):
         slpx.lib().slpx_graph_reset()
-        pp = slpx.Problem.cart_pole(N, 5.0 / N)
+        pp = models.cart_pole(N, 5.0 / N)
         assert pp.prebuild_kernels(tmp_path / f"N{N}") >= 1
         pp.close()
         names[N] = {f.name for f in (tmp_path / f"N{N}").iterdir()}

@@ -22,6 +22,7 @@ import numpy as np
 import pytest
 
 from tests.support import cases, model
+from tests.support import models
 
 NONE, CONSTANT, LINEAR, QUADRATIC, NONLINEAR = 0, 1, 2, 3, 4  # expression_type.hpp:17-28
 P = model.NlpProblem
@@ -306,14 +307,14 @@ def _cart_pole_problem(m, N, dt):
     if m.is_oracle:
         from tests.support import oracle
         return oracle.OracleProblem.cart_pole(N, dt)
-    return m.be.sa.Problem.cart_pole(N, dt)
+    return models.cart_pole(N, dt)
 
 
 def _flywheel_problem(m, N, dt):
     if m.is_oracle:
         from tests.support import oracle
         return oracle.OracleProblem.flywheel(N, dt)
-    return m.be.sa.Problem.flywheel(N, dt)
+    return models.flywheel(N, dt)
 
 
 def test_cart_pole_n100_end_state(m):

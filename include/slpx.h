@@ -203,6 +203,9 @@ enum {
   /* supernodal LDLT: levels on the critical path (sum over rounds of the deepest task),
    * supernodes (singletons included), widest supernode in columns */
   SLPX_INFO_LDLT_LEVELS, SLPX_INFO_LDLT_SUPERNODES, SLPX_INFO_LDLT_WIDEST,
+  /* since ABI version 5: the multifrontal plan — 1 if the single-problem step runs on fronts, their
+   * number, and how many of them send their update block through the matrix cores */
+  SLPX_INFO_LDLT_MULTIFRONTAL, SLPX_INFO_LDLT_FRONTS, SLPX_INFO_LDLT_MFMA_FRONTS,
   SLPX_INFO_COUNT
 };
 int slpx_system_info(const slpx_system* s, int64_t* out /* SLPX_INFO_COUNT */);
@@ -325,6 +328,12 @@ int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24)
  * exit, body entered, leaves loaded, forward part done, -, -, -} per workgroup.
  * Returns the number of workgroups that run generated bodies (the rest interpret), or -1. */
 int slpx_debug_tmpl_clocks(slpx_system* s, uint64_t* out, int32_t blocks);
+/* Test hook for chained steps (consecutive slpx_newton_step calls of one problem: the AD sweep and the
+ * step kernel side by side, ordered through words in memory with BOUNDED spins).  action 1: the next
+ * chained sweep is told to wait for a step kernel that does not exist — it gives up after its bound,
+ * the step reports the failure instead of computing on a torn V, and the library redoes that step
+ * unchained.  Returns the number of chain failures recovered from so far (action 0: just that). */
+int slpx_debug_chain(slpx_system* s, int action);
 
 #ifdef __cplusplus
 }

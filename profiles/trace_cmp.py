@@ -1,10 +1,10 @@
 import sys, numpy as np
 sys.path.insert(0,'/root/repo')
 import sleipnir_amd as sa
-from tests.support import oracle
+from tests.support import models, oracle
 N=int(sys.argv[1]) if len(sys.argv)>1 else 100
 sa.lib().slpx_graph_reset(); oracle.lib().orc_reset()
-pp=sa.Problem.cart_pole(N,5.0/N); op=oracle.OracleProblem.cart_pole(N,5.0/N)
+pp=models.cart_pole(N,5.0/N); op=oracle.OracleProblem.cart_pole(N,5.0/N)
 rows=[]
 def cb(info):
     n=pp.dims[0]; mi=pp.dims[2]

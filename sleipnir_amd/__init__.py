@@ -34,6 +34,7 @@ INFO_KEYS = [
     "factor_bytes", "solve_bytes", "sweep_bytes", "struct_singular", "off_g", "off_Ae", "off_Ai",
     "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks", "tape_shared_tasks",
     "tape_program_bytes", "ldlt_levels", "ldlt_supernodes", "ldlt_widest_supernode",
+    "ldlt_multifrontal", "ldlt_fronts", "ldlt_mfma_fronts",
 ]
 
 # slpx_op
@@ -147,6 +148,7 @@ def lib() -> ctypes.CDLL:
     sig("slpx_system_set_rhs", ctypes.c_int, vp, vp)
     sig("slpx_system_set_lhs", ctypes.c_int, vp, vp)
     sig("slpx_system_time_step", ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp)
+    sig("slpx_debug_chain", ctypes.c_int, vp, ctypes.c_int)
     sig("slpx_system_time_fused_step", ctypes.c_int, vp, ctypes.c_int, vp)
     sig("slpx_newton_steps", ctypes.c_int, vp, i32, ctypes.c_int, ctypes.c_int, vp)
     sig("slpx_system_regularization", ctypes.c_int, vp, vp)
@@ -458,6 +460,10 @@ class System:
     def set_lhs(self, lhs):
         a = _f64(lhs)
         _check(lib().slpx_system_set_lhs(self._h, a.ctypes.data))
+
+    def debug_chain(self, action=0) -> int:
+        """Chain failures recovered from so far; action 1 breaks the next chained sweep's hand-over (slpx_debug_chain)."""
+        return _check(lib().slpx_debug_chain(self._h, action))
 
     def time_fused_step(self, iters=10):
         """The launches a single problem's step really makes (slpx_system_time_fused_step)."""

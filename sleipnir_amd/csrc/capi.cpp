@@ -342,6 +342,9 @@ int slpx_system_info(const slpx_system* sc, int64_t* out) {
     out[SLPX_INFO_LDLT_LEVELS] = l.critical_levels;
     out[SLPX_INFO_LDLT_SUPERNODES] = l.n_supernodes;
     out[SLPX_INFO_LDLT_WIDEST] = l.widest_supernode;
+    out[SLPX_INFO_LDLT_MULTIFRONTAL] = l.mf ? 1 : 0;
+    out[SLPX_INFO_LDLT_FRONTS] = l.mf ? static_cast<int64_t>(l.mf_fronts.size()) - 16 : 0;  // (16 padding records)
+    out[SLPX_INFO_LDLT_MFMA_FRONTS] = l.mf ? l.mf_n_mfma : 0;
   });
 }
 
@@ -621,6 +624,16 @@ int slpx_debug_ldlt_clocks(slpx_system* s, uint32_t next_round, uint64_t* out24)
     s->get().device().debug_ldlt_clocks(next_round, t);
     for (int i = 0; i < 24; ++i) out24[i] = t[i];
   });
+}
+
+int slpx_debug_chain(slpx_system* s, int action) {
+  int n = -1;
+  const int rc = guard([&] {
+    auto& dev = s->get().device();
+    if (action == 1) dev.debug_break_next_chain();
+    n = dev.chain_failures();
+  });
+  return rc == 0 ? n : rc;
 }
 
 int slpx_system_set_lhs(slpx_system* s, const double* lhs) {

@@ -125,8 +125,11 @@ struct LdltDev {
   uint32_t clock_task;           // the task whose phase clocks are recorded (slpx_debug_ldlt_clocks); 0xffffffff: none
 };
 
+// n_bad bit of a chained step whose sweep / step kernel gave up waiting for the other (bounded spins)
+constexpr int32_t kLdltChainFailure = 1 << 30;
+
 struct LdltStats {   // one per batch item, written by the factor kernels
-  int32_t n_pos, n_neg, n_zero, n_bad;  // n_bad: exactly-zero or non-finite pivots
+  int32_t n_pos, n_neg, n_zero, n_bad;  // n_bad: exactly-zero or non-finite pivots (+ 2^20 per hand-over that timed out; bit 30: kLdltChainFailure)
   unsigned long long min_abs_bits;      // bit pattern of min |D| (non-negative doubles order like integers)
 };
 
@@ -319,6 +322,10 @@ class DeviceNlp {
   // dispatched and stages its plan WHILE the sweep runs, and the sweep of the next step starts the moment
   // this step's kernel is through — no launch boundary on either side.  DESIGN.md §4, "chained steps".
   void sweep_full_for_step();
+  void recover_from_chain_failure();  // after a step whose counters carry kLdltChainFailure
+  int chain_failures() const { return m_chain_failures; }
+  // test hook: the next chained sweep is launched as if the step kernel before it never signalled
+  void debug_break_next_chain() { m_debug_break_chain = true; }
   void sweep_values();  // f, c_e, c_i only                   -> V
   void assemble();      // V, s, z -> lhs
   void build_kkt(bool with_reduce);  // assemble() + build_rhs() [+ reductions] as one launch
@@ -569,7 +576,9 @@ class DeviceNlp {
   hipStream_t m_tape_stream = nullptr;
   hipEvent_t m_chain_ev = nullptr;
   DevBuf<unsigned int> m_chain;
-  unsigned int m_chain_seq = 0;       // steps chained so far
+  int m_chain_failures = 0;
+  bool m_debug_break_chain = false;
+  unsigned int m_chain_seq = 0;       // number of the last chained step, in [1, 2^30): 0 is the kernels' "no wait", bit 31 their failure flag
   struct ChainArgs {
     unsigned int* chain = nullptr;
     unsigned int wait_step = 0, this_step = 0;

@@ -1002,6 +1002,23 @@ void DeviceNlp::sweep_full_for_step() {
     }
   }
   m_tape_reduce = false;
+  if (m_stream.tape_pending) {
+    // The last chained sweep was never consumed (its step threw before the step kernel was launched, or
+    // the caller swept twice): no step kernel will signal the word a chained sweep would wait for.  Order
+    // the streams by an event and start over.
+    (void)static_cast<hipStream_t>(m_stream);  // waits for that sweep, marks the stream touched
+    m_last_step_chained = false;
+  }
+  if (m_chain_seq >= (1u << 30) - 1u) {
+    // step numbers stay in [1, 2^30) (the kernels compare them as signed differences, use 0 for "no wait"
+    // and bit 31 for failure): every ~14 hours of chained steps, one unchained step and a fresh count
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+    SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
+    m_chain_seq = 0;
+    m_last_step_chained = false;
+    m_stream.touched = true;
+  }
   if (m_stream.touched) {
     // Something else went to the main stream since the last step (an upload of the state, a download of
     // the result, another kernel): this step's sweep goes there too, behind all of it — the pattern of a
@@ -1033,12 +1050,31 @@ void DeviceNlp::sweep_full_for_step() {
     SLPX_HIP_CHECK(hipStreamWaitEvent(m_tape_stream, m_chain_ev, 0));
     wait_step = 0;
   }
+  if (m_debug_break_chain && wait_step != 0u) {
+    m_debug_break_chain = false;
+    wait_step += 7u;  // (slpx_debug_chain) a step kernel nobody launched
+  }
   ++m_chain_seq;
   m_chain_args = ChainArgs{m_chain.p, wait_step, m_chain_seq};
   launch_tape(m_full, true, m_tape_stream, m_tape_stream);
   m_tape_reduce = true;
   m_chain_args = ChainArgs{};
   m_stream.tape_pending = true;  // until the step kernel that waits for this sweep is launched
+}
+// A chained step reported kLdltChainFailure: one of the two kernels gave up waiting for the other (never
+// expected — a shared / preempted / serialized GPU).  Drain both streams, clear the words, keep this
+// system's steps unchained from now on and leave V as a fresh sweep of the current state writes it.
+void DeviceNlp::recover_from_chain_failure() {
+  if (m_tape_stream != nullptr) SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+  if (m_chain.p != nullptr) SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
+  m_chain_on = false;
+  m_last_step_chained = false;
+  m_stream.tape_pending = false;
+  m_stream.touched = true;
+  ++m_chain_failures;
+  if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "slpx: a chained step lost its hand-over: the step is redone, steps are unchained from here on\n");
+  sweep_full(/*with_reduce=*/false);
 }
 void DeviceNlp::sweep_values() { launch_tape(m_values, false); }
 void DeviceNlp::sweep_values_trial() {

@@ -65,14 +65,19 @@ __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* st
   if (Mf.wait_step != 0u) {
     SLPX_CHAIN_STAMP(4);  // (the last workgroup dispatched: staged)
     if (threadIdx.x == 0) {
-      unsigned int spins = 0;
-      while (static_cast<int>(__hip_atomic_load(Mf.chain + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - Mf.wait_step) < 0) {
+      unsigned int spins = 0, seen;
+      // (bit 31 of the word: a workgroup of that sweep gave up waiting for the step kernel before it — V may
+      // have been overwritten under that kernel; step numbers stay below 2^30)
+      while (static_cast<int>(((seen = __hip_atomic_load(Mf.chain + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x7fffffffu) - Mf.wait_step) < 0) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
-          atomicAdd(&stats[0].n_bad, 1 << 20);
+          seen = 0x80000000u;
           break;
         }
       }
+      // kLdltChainFailure (device.hpp) in n_bad — bit 30, above anything the counts can reach: the host
+      // (NewtonSystem::compute_impl) redoes the step with the chain off
+      if (seen & 0x80000000u) atomicOr(&stats[0].n_bad, kLdltChainFailure);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // V as the sweep's workgroups left it, not as this XCD's L2 remembers it
     }
     __syncthreads();

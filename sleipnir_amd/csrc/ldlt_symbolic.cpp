@@ -313,6 +313,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       }
     }
   }
+  // Which diagonal entries receive an update in the EXACT structure of L (before supernodes are relaxed
+  // below: an explicit zero L(j, k) = 0 "updates" d_j by nothing).  A (2,2)-block diagonal without a
+  // source and without such an update is a structurally zero pivot of the unregularized matrix.
+  std::vector<uint8_t> diag_updated_exact(n, 0);
+  for (int k = 0; k < n; ++k)
+    for (int32_t r : Lcol[k]) diag_updated_exact[r] = 1;
   // ---- relaxed supernodes (LdltOptions::relax_zeros) -------------------------------------------------
   int relaxed_merges = 0;
   int64_t relaxed_zeros = 0;
@@ -563,7 +569,6 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   std::vector<std::unordered_map<uint64_t, uint32_t>> ext_map(ntasks);
   std::vector<std::vector<std::vector<uint32_t>>> econtrib(ntasks);
   for (int t = 0; t < ntasks; ++t) econtrib[t].resize(task_nent[t]);
-  std::vector<uint8_t> diag_updated_perm(n, 0);
 
   for (int k = 0; k < n; ++k) {
     const int tk = task_of[k];
@@ -600,7 +605,6 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         uint32_t target;
         if (b == a) {
           target = diag_ent[j];
-          diag_updated_perm[j] = 1;
         } else {
           while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
           if (q >= P.Lp[j + 1]) throw std::runtime_error("ldlt: fill pattern inconsistency");
@@ -835,7 +839,13 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   }
 
   // ---- multifrontal plan (LdltFront, ldlt_symbolic.hpp) -------------------------------------------
-  if (opt.multifrontal) {
+  // The fronts are an optional accelerator: whatever keeps them from being built — a limit (16-bit reach,
+  // children per entry) or a structural corner case its consistency checks trip over (MfRefused) — leaves
+  // P.mf = false and the pair-list plan above, which every system has, in charge.
+  struct MfRefused {
+    const char* why;
+  };
+  if (opt.multifrontal) try {
     struct Front {
       std::vector<int32_t> cols, R;  // permuted indices, ascending
       int task = 0, level = 0, parent = -1;
@@ -921,7 +931,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       const int32_t* b = P.Li.data() + P.Lp[col];
       const int32_t* e = P.Li.data() + P.Lp[col + 1];
       const int32_t* f = std::lower_bound(b, e, row);
-      if (f == e || *f != row) throw std::runtime_error("ldlt: a front's update block has an entry outside the pattern of L");
+      if (f == e || *f != row) throw MfRefused{"a front's update block has an entry outside the pattern of L"};
       return lent[f - P.Li.data()];
     };
     P.mf_tasks.assign(ntasks, LdltMfTask{});
@@ -1003,7 +1013,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
               to[a] = static_cast<uint32_t>(ic - f.cols.begin());
             } else {
               auto ir = std::lower_bound(f.R.begin(), f.R.end(), i);
-              if (ir == f.R.end() || *ir != i) throw std::runtime_error("ldlt: a child front's row is not in its parent front");
+              if (ir == f.R.end() || *ir != i) throw MfRefused{"a child front's row is not in its parent front"};
               to[a] = w + static_cast<uint32_t>(ir - f.R.begin());
             }
           }
@@ -1083,7 +1093,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       if (!ok) break;
       P.mf_lvl_ptr.push_back(static_cast<uint32_t>(fl.size()));
       if (P.mf_lvl_ptr.size() != T.lvl_off + T.n_lvl + 1)
-        throw std::runtime_error("ldlt: front levels out of step with the column levels");
+        throw MfRefused{"front levels out of step with the column levels"};
       M.n_ext = n_ext;
       M.n_tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
       while (P.mf_tab.size() % 8) P.mf_tab.push_back(0);
@@ -1165,12 +1175,26 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u), fronts on the matrix cores %u\n",
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib, P.mf_n_mfma);
     }
+  } catch (const MfRefused& refused) {
+    if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "ldlt multifrontal plan: NOT built (%s)\n", refused.why);
+    P.mf = false;
+    P.mf_tasks.assign(ntasks, LdltMfTask{});
+    P.mf_n_contrib = P.mf_max_nch = P.mf_max_front_rows = P.mf_n_mfma = 0;
+    // (the tail padding the staged kernels' 16-byte reads expect, as above)
+    P.mf_tab.assign(16, 0);
+    P.mf_ext.assign(16, 0);
+    P.mf_contrib_ptr.assign(16, 0);
+    P.mf_contrib_idx.assign(16, 0);
+    P.mf_cent.assign(16, 0);
+    P.mf_anc.assign(16, 0);
+    P.mf_lvl_ptr.assign(16, 0);
+    P.mf_fronts.assign(16, LdltFront{});
   }
 
   // structural zero pivots of the unregularized matrix: a diagonal of the (2,2)
   // block (no lhs source other than the forced 0) that no earlier column updates
   for (int j = 0; j < n; ++j)
-    if (!has_diag[P.perm[j]] && !diag_updated_perm[j]) P.structurally_singular_unregularized = true;
+    if (!has_diag[P.perm[j]] && !diag_updated_exact[j]) P.structurally_singular_unregularized = true;
   if (ordering_forced) P.structurally_singular_unregularized = true;
 
   // tail padding: the staged kernels read whole 16-byte groups

@@ -195,8 +195,8 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   // counters: the device never idles through the host round trip, and in the usual case
   // (first attempt accepted) the step is complete when the counters arrive.  A rejected
   // attempt just has its solve overwritten by the next one.
-  auto factor = [&](const std::vector<double>& d, const std::vector<double>& g,
-                    const std::vector<uint8_t>& a) {
+  auto factor_once = [&](const std::vector<double>& d, const std::vector<double>& g,
+                         const std::vector<uint8_t>& a) {
     if (graph_pending) {
       graph_pending = false;
       m_dev->launch_step_graph(refresh_ad, d, g, a);
@@ -209,11 +209,24 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
       m_dev->factor(d, g, a);
     }
   };
+  std::vector<LdltStats> stats;
+  // one attempt and its counters.  A chained step (DeviceNlp::sweep_full_for_step) whose sweep or step
+  // kernel gave up waiting for the other reports kLdltChainFailure instead of a silent wrong step: the
+  // attempt is redone — V swept again from the unchanged state, the system rebuilt — with the chain off.
+  auto factor = [&](const std::vector<double>& d, const std::vector<double>& g, const std::vector<uint8_t>& a) {
+    factor_once(d, g, a);
+    m_dev->read_stats(stats);
+    if (B == 1 && (stats[0].n_bad & kLdltChainFailure) != 0) {
+      m_dev->recover_from_chain_failure();
+      m_dev->build_kkt_for_step(/*with_reduce=*/true);
+      factor_once(d, g, a);
+      m_dev->read_stats(stats);
+    }
+  };
   const int n = m_s.n, m_e = m_s.m_e;
   std::vector<FactorInfo> info(B, FactorInfo::Success);
   std::vector<double> delta(B, 0.0), gamma(B, 0.0);
   std::vector<uint8_t> active(B, 1);
-  std::vector<LdltStats> stats;
   m_last_factorizations = 0;
   const double eps = std::numeric_limits<double>::epsilon();
 
@@ -234,7 +247,6 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
                           m_l.structurally_singular_unregularized;
   if (!skip_first) {
     factor(delta, gamma, active);
-    m_dev->read_stats(stats);
     ++m_last_factorizations;
     for (int b = 0; b < B; ++b) {
       const bool success = stats[b].n_bad == 0;
@@ -261,7 +273,6 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   }
   while (any) {
     factor(delta, gamma, active);
-    m_dev->read_stats(stats);
     ++m_last_factorizations;
     any = false;
     for (int b = 0; b < B; ++b) {

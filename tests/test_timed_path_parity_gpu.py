@@ -90,7 +90,63 @@ def test_batch_timed_step_items_against_oracle(fresh, slpx, orc, N, B, items):
         system.set_state(*(np.stack([s[k] for s in st]) for k in range(4)), np.array([s[4] for s in st]))
         system.reset_regularization()
         assert np.all(system.newton_step(True) == 0)
+        snap = parity.snapshot_step(system)
         for b in items:
-            parity.check_timed_step(system, op, st[b], b=b, verbose=True, label=f"{B} x N={N} item {b}")
+            parity.check_timed_step(system, op, st[b], b=b, verbose=True, label=f"{B} x N={N} item {b}", snap=snap)
+    finally:
+        system.close()
+
+
+# ---- the alternative paths, in the suite the driver runs -----------------
+# The switches are read when a system is made (DESIGN.md §4 "Switches"): set for ONE system here,
+# each against the oracle's whole step like the default path above — so that the kernels the
+# default path does not reach (matrix-core update blocks, the pair-list one-launch step, the
+# unchained launch order, the exact-structure fronts, 512-thread tasks) are under the oracle in
+# GPUTEST, not only in the builder's profiles/switch_matrix.sh.
+
+@pytest.mark.parametrize("env,expect", [
+    ({"SLPX_LDLT_MF": "0"}, {"ldlt_multifrontal": 0}),                 # r02's pair-list step kernel
+    ({"SLPX_CHAIN_TAPE": "0"}, {"ldlt_multifrontal": 1}),              # sweep and step kernel in one stream
+    ({"SLPX_RELAX_ZEROS": "0"}, {"ldlt_multifrontal": 1}),             # exact structure of L: 20 levels of fronts
+    ({"SLPX_MF_THREADS": "512"}, {"ldlt_multifrontal": 1}),            # the variant N=5000 runs
+    ({"SLPX_FUSE_LAUNCHES": "0"}, {}),                                 # stand-alone assembly / factorization / solve
+], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) and any(k.startswith("SLPX") for k in v) else "")
+def test_config2_alternative_paths_against_oracle(fresh, slpx, orc, monkeypatch, env, expect):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pp, op = cases.build_pair("cart_pole", 1000, slpx, orc)
+    system = slpx.System(pp, batch=1, device=0)
+    try:
+        for k, v in expect.items():
+            assert system.info[k] == v, (k, system.info[k])
+        # several consecutive steps first: chained / unchained launch order is a property of a SEQUENCE
+        n, me, mi = system.info["n"], system.info["m_e"], system.info["m_i"]
+        scales = op.scaling()
+        system.set_scaling(scales)
+        x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+        system.set_state(x, s, y, z, np.array([mu]))
+        assert np.all(system.newton_steps(3) == 0)
+        errs = _step_and_check(system, op, "interior", f"N=1000 interior {env}")
+        assert errs["resid"] <= 1e-10
+    finally:
+        system.close()
+
+
+def test_config5_gfold_matrix_core_fronts_against_oracle(fresh, slpx, monkeypatch):
+    """Row X1: every eligible front's update block through v_mfma_f64_16x16x4_f64
+    (SLPX_MFMA_MIN_ENTRIES=0; the default threshold keeps only the large blocks there) — the plan must
+    say that fronts are on the matrix cores, and the step must be the oracle's."""
+    monkeypatch.setenv("SLPX_MFMA_MIN_ENTRIES", "0")
+    mo = model.Model(model.OracleBackend())
+    mo.be.reset()
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    po, pp = gfold.build(mo, 100), gfold.build(mp, 100)
+    system = slpx.System(pp.p, batch=1, device=0)
+    try:
+        assert system.info["ldlt_multifrontal"] == 1 and system.info["ldlt_mfma_fronts"] >= 50, system.info
+        for case in ("step0", "interior"):
+            _step_and_check(system, po.p, case, f"g-fold N=100 {case}, all eligible fronts on the matrix cores "
+                                                f"({system.info['ldlt_mfma_fronts']} of {system.info['ldlt_fronts']})")
     finally:
         system.close()

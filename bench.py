@@ -445,6 +445,10 @@ def main():
                 "delta_histogram": {f"{d:.0e}": int(c) for d, c in zip(*np.unique(table[:, 2], return_counts=True))},
                 "gamma_histogram": {f"{g:.0e}": int(c) for g, c in zip(*np.unique(table[:, 3], return_counts=True))},
                 "first_rows": table[:8].tolist(),
+                # the whole gathered table, for comparing a sharded run with a single-process one
+                # (tests/test_multi_gpu_readiness_gpu.py): problem order, status, delta, gamma
+                "table_sha256": __import__("hashlib").sha256(np.ascontiguousarray(table).tobytes()).hexdigest(),
+                "rows": int(table.shape[0]),
             }
     system.close()
     pp.close()

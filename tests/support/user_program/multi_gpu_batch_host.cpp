@@ -180,6 +180,13 @@ int main(int argc, char** argv) {
                   reg[2 * size_t(b)], reg[2 * size_t(b) + 1],
                   static_cast<unsigned long long>(fnv(1469598103934665603ull, p.data() + size_t(b) * dim, 8 * dim)));
   }
+  if (no_comm) {
+    // the hash rank 0 of an RCCL run prints, over this process's rows (RANK=0 WORLD_SIZE=1: all of them)
+    uint64_t h = 1469598103934665603ull;
+    for (int b = 0; b < mine; ++b) h = fnv(h, &rows[4 * size_t(b) + 2], 16);
+    std::printf("{\"ranks\": 1, \"problems\": %d, \"rows\": %d, \"regularization_hash\": \"%016llx\"}\n", total, mine,
+                static_cast<unsigned long long>(h));
+  }
   if (comm) {
     double* d_rows = nullptr;
     double* d_table = nullptr;

@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kkt_plan.hpp"
@@ -37,6 +38,10 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -257,6 +262,7 @@ struct IpmHost {
   IpmDirOut dir;
   IpmTrialOut trial;
   IpmErrOut err;
+  IpmErrOut err_ahead;  // the same quantities at the look-ahead iterate (ipm_lookahead)
 };
 
 struct StepTimings {
@@ -378,7 +384,14 @@ class DeviceNlp {
   void sweep_values_trial();                  // f, c_e, c_i at the trial x -> trial V
   void ipm_trial_metrics(double alpha, bool s_from_ci);  // alpha < 0: the device's alpha_max
   void ipm_commit(double alpha, double alpha_z, bool s_from_ci);
-  void ipm_errors(bool check_all_V, bool sums_ride = false);  // -> IpmHost::err (one launch; the last workgroup folds)
+  void ipm_errors(bool check_all_V, bool sums_ride = false, bool ahead = false);  // -> IpmHost::err (one launch; the last workgroup folds)
+  // Look-ahead iteration: the iterate the FULL step alpha_max would give — x, s, y, z with the z reset of
+  // interior_point.hpp:797-801 — in a second set of buffers, swept (values AND derivatives) and reduced to
+  // IpmHost::err_ahead speculatively; when the filter accepts that trial point the buffers change roles
+  // (ipm_accept_lookahead: no launch) and the iteration is complete after ONE host round trip.
+  void ipm_lookahead(double tau);             // step sizes, D_phi -> IpmHost::dir; the look-ahead iterate
+  void sweep_full_lookahead();                // the full tape at it, into the look-ahead V (sums ride in ipm_errors)
+  void ipm_accept_lookahead();                // the look-ahead iterate and its V become the current ones
   void ipm_soc_accumulate(double alpha, bool first, bool s_from_ci);
   void ipm_soc_rhs();                         // -> rhs
   void ipm_soc_backsub();                     // p -> p_s, p_z with the corrected c_i - s
@@ -558,12 +571,14 @@ class DeviceNlp {
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
+  bool m_fwd_single = true;  // SLPX_FWD_SINGLE=0: the forward substitution of a new right-hand side one launch per round
   hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
   hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
   hipEvent_t m_fork = nullptr, m_join = nullptr;
   std::vector<double> m_V_static;  // scaled static values (host copy)
   // interior-point iteration state (ipm_enable)
   bool m_ipm = false;
+  DevBuf<double> m_s_ahead, m_y_ahead, m_z_ahead;  // with m_trial_in (x | y | z) and m_V_trial: the look-ahead iterate
   DevBuf<double> m_trial_in, m_V_trial, m_soc_ce, m_soc_cims, m_p_keep, m_ps_keep, m_pz_keep, m_ipm_alpha, m_ipm_scales, m_ipm_partial;
   IpmHost* m_ipm_host = nullptr;   // pinned
   bool m_tape_reduce = true;       // launch_tape runs the separable-sum reductions itself

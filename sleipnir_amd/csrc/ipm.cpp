@@ -653,6 +653,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   constexpr double s_max = 100.0;
   int full_step_rejected_counter = 0;
   const bool identity = scaling_is_identity(st, scales);
+  const char* lookahead_env = std::getenv("SLPX_IPM_LOOKAHEAD");
+  const bool lookahead = lookahead_env == nullptr || lookahead_env[0] != '0';
   // util/kkt_error.hpp:92-146 from the reduced scalars
   auto E_mu_of = [&](const IpmErrOut& e, double m) {
     const double s_d = std::max(s_max, (e.y1 + e.z1) / double(m_e + m_i)) / s_max;
@@ -700,10 +702,23 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       mu_on_device = mu;
     }
     dev.build_kkt_for_step(/*with_reduce=*/false);
+    // Look-ahead (DeviceNlp::ipm_lookahead): instead of only f, c_e, c_i at the first trial point, the
+    // WHOLE next iterate the full step would give — updated s, y, z, the full tape at it, the error norms
+    // of :809-832 — is computed speculatively behind the step kernel, in a second set of buffers.  Most
+    // iterations take the first trial point: the iteration is then complete when these numbers arrive
+    // (one host round trip, four launches), and nothing is computed twice.  The feasible-IPM option
+    // derives the trial s from the trial c_i (:520-526): it keeps the trial-values chain below.
+    const bool ahead = lookahead && !s_from_ci;
     sys.set_after_attempt([&] {
-      dev.ipm_direction(tau);
-      dev.sweep_values_trial();
-      dev.ipm_trial_metrics(-1.0, s_from_ci);
+      if (ahead) {
+        dev.ipm_lookahead(tau);
+        dev.sweep_full_lookahead();
+        dev.ipm_errors(false, /*sums_ride=*/true, /*ahead=*/true);
+      } else {
+        dev.ipm_direction(tau);
+        dev.sweep_values_trial();
+        dev.ipm_trial_metrics(-1.0, s_from_ci);
+      }
     });
     auto info = sys.compute(/*solve_speculatively=*/true);
     sys.set_after_attempt(nullptr);
@@ -726,6 +741,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     double alpha_commit = alpha;
     bool commit_s_from_ci = s_from_ci;
     bool have_trial = true;  // the speculative chain already evaluated alpha_max
+    bool trial_is_ahead = ahead;  // ... as the complete look-ahead iterate
+    bool took_lookahead = false;
 
     while (true) {  // :512
       if (!have_trial) {
@@ -737,7 +754,9 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       }
       have_trial = false;
       alpha_commit = alpha;
-      IpmTrialOut tr = H.trial;
+      const bool from_ahead = trial_is_ahead;
+      trial_is_ahead = false;
+      IpmTrialOut tr = from_ahead ? IpmTrialOut{H.err_ahead.f, H.err_ahead.viol, H.err_ahead.logsum, H.err_ahead.finite} : H.trial;
 
       if (tr.finite == 0.0) {
         alpha *= alpha_reduction_factor;
@@ -749,7 +768,10 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       }
 
       const FilterEntry trial_entry{tr.f - mu * tr.logsum, tr.viol};
-      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
+      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) {
+        took_lookahead = from_ahead;
+        break;
+      }
 
       const double prev_violation = cur.viol;
       double next_violation = tr.viol;
@@ -880,15 +902,23 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       push_state();
     } else {
       if (alpha == alpha_max) full_step_rejected_counter = 0;
-      dev.ipm_commit(alpha_commit, alpha_z, commit_s_from_ci);  // :775-801
+      if (took_lookahead) {
+        dev.ipm_accept_lookahead();  // :775-801 happened in ipm_lookahead_kernel; the buffers change roles
+      } else {
+        dev.ipm_commit(alpha_commit, alpha_z, commit_s_from_ci);  // :775-801
+      }
       host_current = false;
     }
 
     // AD refresh (:809-812) and every norm the next decisions need
-    dev.sweep_full(/*with_reduce=*/false);
-    dev.ipm_errors(false, /*sums_ride=*/true);
-    dev.wait_published();
-    cur = H.err;
+    if (took_lookahead && !call_feasibility_restoration) {
+      cur = H.err_ahead;  // already there: the look-ahead chain swept and reduced this iterate
+    } else {
+      dev.sweep_full(/*with_reduce=*/false);
+      dev.ipm_errors(false, /*sums_ride=*/true);
+      dev.wait_published();
+      cur = H.err;
+    }
     rep.t_ad_refresh += since(t0);
 
     E_0 = E0_of(cur);

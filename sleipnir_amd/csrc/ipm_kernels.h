@@ -54,6 +54,14 @@ __device__ __forceinline__ double wave_reduce(double v, int op) {
   return ipm_combine(op, ipm_combine(op, r0, r1), ipm_combine(op, r2, r3));
 }
 
+// sum over the eight lanes 8 k .. 8 k + 7 of a wave, in every one of them (two quad permutes and a half-row mirror)
+__device__ __forceinline__ double ipm_group8_sum(double v) {
+  v += ipm_dpp<0xB1>(v);
+  v += ipm_dpp<0x4E>(v);
+  v += ipm_dpp<0x141>(v);
+  return v;
+}
+
 // Reduces NQ per-lane quantities (op per quantity) over a workgroup of THREADS lanes (full
 // waves, every lane must call); the results land in `vals` of every lane.  `scratch` =
 // (THREADS / 64 + 1) x NQ doubles of LDS.
@@ -119,6 +127,66 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
   block_reduce<3, kIpmThreads>(acc, ops, scratch);
   const double alpha = acc[0];
   for (int j = tid; j < K.n; j += kIpmThreads) trial_x[j] = x[j] + alpha * p[j];
+  if (tid == 0) {
+    alpha_dev[0] = acc[0];
+    alpha_dev[1] = acc[1];
+    out->alpha_max = acc[0];
+    out->alpha_z = acc[1];
+    out->D_phi = acc[2];
+  }
+}
+
+// ipm_direction_kernel + the whole look-ahead iterate: what ipm_commit_kernel would make of the step
+// (alpha_max, alpha_z) — x + alpha p_x, s + alpha p_s, y + alpha_z p_y, z + alpha_z p_z with the z reset —
+// written to a SECOND set of buffers (`in_t` = [x | y | z] as the tape reads it, s_t, y_t, z_t) instead of
+// over the current one.  The full tape and the error reductions run on those next (DeviceNlp::
+// ipm_lookahead); if the filter takes the point the buffers swap roles and nothing is recomputed.
+__global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
+    KktDev K, const double* __restrict__ V, const double* __restrict__ in, const double* __restrict__ s,
+    const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ p,
+    const double* __restrict__ ps, const double* __restrict__ pz, const double* __restrict__ mu_dev, double tau,
+    double* __restrict__ in_t, double* __restrict__ s_t, double* __restrict__ y_t, double* __restrict__ z_t,
+    double* __restrict__ alpha_dev, IpmDirOut* __restrict__ out, const LdltStats* __restrict__ stats) {
+  __shared__ double scratch[17 * 3];
+  const int tid = threadIdx.x;
+  // The factorization this direction comes from has the wrong inertia (or failed): the policy loop will
+  // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
+  // (one lane-uniform 16-byte load, issued with the others below)
+  const LdltStats st = stats[0];
+  const bool wrong = st.n_bad != 0 || st.n_pos != K.n || st.n_neg != K.m_e || st.n_zero != 0;
+  if (tid == 0) alpha_dev[2] = wrong ? 1.0 : 0.0;
+  if (wrong) return;
+  const double mu = mu_dev[0];
+  double acc[3] = {1.0, 1.0, 0.0};  // alpha_max, alpha_z, D_phi
+  for (int r = tid; r < K.m_i; r += kIpmThreads) {
+    const double sr = s[r], psr = ps[r], zr = z[r], pzr = pz[r];
+    if (psr < 0.0) acc[0] = fmin(acc[0], -tau / psr * sr);
+    if (pzr < 0.0) acc[1] = fmin(acc[1], -tau / pzr * zr);
+    acc[2] -= mu * ((1.0 / sr) * psr);
+  }
+  for (int j = tid; j < K.n; j += kIpmThreads) {
+    const int gs = K.g_src[j];
+    if (gs >= 0) acc[2] += V[gs] * p[j];
+  }
+  const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
+  block_reduce<3, kIpmThreads>(acc, ops, scratch);
+  const double alpha = acc[0], alpha_z = acc[1];
+  for (int j = tid; j < K.n; j += kIpmThreads) in_t[j] = in[j] + alpha * p[j];
+  for (int r = tid; r < K.m_e; r += kIpmThreads) {
+    const double v = y[r] + alpha_z * (-p[K.n + r]);
+    y_t[r] = v;
+    in_t[K.n + r] = v;
+  }
+  for (int r = tid; r < K.m_i; r += kIpmThreads) {
+    const double sn = s[r] + alpha * ps[r];
+    double zn = z[r] + alpha_z * pz[r];
+    constexpr double kappa = 1e10;
+    const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
+    zn = zn < lo ? lo : (zn > hi ? hi : zn);
+    s_t[r] = sn;
+    z_t[r] = zn;
+    in_t[K.n + K.m_e + r] = zn;
+  }
   if (tid == 0) {
     alpha_dev[0] = acc[0];
     alpha_dev[1] = acc[1];
@@ -220,6 +288,21 @@ __global__ __launch_bounds__(256) void ipm_commit_kernel(KktDev K, const double*
     s[r] = sn;
     z[r] = zn;
     in[K.n + K.m_e + r] = zn;
+  }
+}
+
+// (p, p_s, p_z) -> their keep buffers or back, in ONE launch (three device-to-device copies through the
+// runtime cost ~5 us each on the stream)
+__global__ __launch_bounds__(256) void ipm_copy_direction_kernel(int dim, int m_i, const double* __restrict__ p,
+                                                                 const double* __restrict__ ps, const double* __restrict__ pz,
+                                                                 double* __restrict__ p_to, double* __restrict__ ps_to,
+                                                                 double* __restrict__ pz_to) {
+  const int stride = gridDim.x * blockDim.x;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = t0; j < dim; j += stride) p_to[j] = p[j];
+  for (int r = t0; r < m_i; r += stride) {
+    ps_to[r] = ps[r];
+    pz_to[r] = pz[r];
   }
 }
 
@@ -327,6 +410,9 @@ struct IpmErrFinish {
   IpmErrOut* out = nullptr;
   unsigned long long* seq_dev = nullptr;
   volatile unsigned long long* seq_host = nullptr;
+  // (look-ahead chain) non-zero: the factorization before this chain has the wrong inertia — the attempt will
+  // be redone and nothing of this launch is looked at: workgroup 0 publishes, everybody leaves
+  const double* skip = nullptr;
 };
 
 // folds the per-workgroup partials in workgroup order and hands the result to the host;
@@ -338,15 +424,35 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
-  const int q = threadIdx.x;
-  if (q < NQ) {
+  // thread = (slice of the workgroups, quantity): eight slices walk the partials side by side, four loads in
+  // flight each, then the slices are combined in slice order (fixed order: the same bits run after run)
+  const int q = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double* part = tot + NQ;  // [8][NQ]
+  if (q < NQ && sl < 8) {
     int op = ops[0];
 #pragma unroll
     for (int k = 1; k < NQ; ++k)
       if (q == k) op = ops[k];
-    double v = coherent_load(&partial[q], in_launch);
-    for (int b = 1; b < n_blocks; ++b) v = ipm_combine(op, v, coherent_load(&partial[b * NQ + q], in_launch));
-    tot[q] = v;
+    double v = op == IPM_SUM ? 0.0 : (op == IPM_MAX ? -1e300 : 1e300);
+    int b = sl;
+    for (; b + 24 < n_blocks; b += 32) {
+      const double v0 = coherent_load(&partial[b * NQ + q], in_launch), v1 = coherent_load(&partial[(b + 8) * NQ + q], in_launch),
+                   v2 = coherent_load(&partial[(b + 16) * NQ + q], in_launch), v3 = coherent_load(&partial[(b + 24) * NQ + q], in_launch);
+      v = ipm_combine(op, ipm_combine(op, ipm_combine(op, ipm_combine(op, v, v0), v1), v2), v3);
+    }
+    for (; b < n_blocks; b += 8) v = ipm_combine(op, v, coherent_load(&partial[b * NQ + q], in_launch));
+    part[sl * NQ + q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const int qq = threadIdx.x;
+    int op = ops[0];
+#pragma unroll
+    for (int k = 1; k < NQ; ++k)
+      if (qq == k) op = ops[k];
+    double v = part[qq];
+    for (int k = 1; k < 8; ++k) v = ipm_combine(op, v, part[k * NQ + qq]);
+    tot[qq] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -382,7 +488,7 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
 // end of a workgroup of the one-launch error computation: count it in; the last one folds
 __device__ __forceinline__ void ipm_error_finish(const KktDev& K, const double* __restrict__ V,
                                                  const double* __restrict__ partial, const IpmErrFinish& fin) {
-  __shared__ double tot[kIpmErrQ];
+  __shared__ double tot[9 * kIpmErrQ];
   __shared__ int last;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this workgroup's coherent stores are in
   __syncthreads();
@@ -396,40 +502,19 @@ __device__ __forceinline__ void ipm_error_finish(const KktDev& K, const double* 
   ipm_error_fold(K, V, partial, fin.n_err_blocks, true, fin.out, fin.seq_dev, fin.seq_host, tot);
 }
 
-__global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
-    KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
-    const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
-    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial, IpmErrFinish fin) {
+// this lane's share of the 23 quantities: rows t0, t0 + stride, ..., columns t0 / 8, (t0 + stride) / 8, ...
+// (stride a multiple of 8; ipm_err: which is which)
+__device__ __forceinline__ void ipm_error_accumulate(const KktDev& K, const double* __restrict__ V, int nV,
+                                                     const double* __restrict__ x, const double* __restrict__ s,
+                                                     const double* __restrict__ y, const double* __restrict__ z,
+                                                     const double* __restrict__ scales, int check_all_V, int t0, int stride,
+                                                     double (&acc)[kIpmErrQ]) {
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
-  __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
-  // fin.n_err_blocks != 0: ONE launch — the tape's separable sums (which make f) ride as extra
-  // workgroups, and whichever workgroup finishes last folds the partials and publishes
-  // (ipm_error_finish); 0: the partials only, ipm_error_final_kernel follows.
-  if (fin.n_err_blocks != 0 && static_cast<int>(blockIdx.x) >= fin.n_err_blocks) {
-    const NlpStructure::SumReduce r = fin.red[blockIdx.x - fin.n_err_blocks];
-    const int tid = threadIdx.x;
-    double acc = 0.0;
-    if (tid < 64)
-      for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
-    if (tid < 64) scratch[tid] = acc;
-    __syncthreads();
-    for (int w = 32; w > 0; w >>= 1) {
-      if (tid < w) scratch[tid] += scratch[tid + w];
-      __syncthreads();
-    }
-    if (tid == 0)
-      coherent_store(&fin.Vw[r.dst], (r.scale_idx >= 0 ? fin.tape_scales[r.scale_idx] : 1.0) * scratch[0], true);
-    ipm_error_finish(K, V, partial, fin);
-    return;
-  }
-  const int n_blocks = fin.n_err_blocks != 0 ? fin.n_err_blocks : static_cast<int>(gridDim.x);
-  double acc[NQ];
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = ops[q] == IPM_MIN ? 1.0 : 0.0;
   acc[SZ_MIN] = 1e300;
-  const int t0 = blockIdx.x * kIpmErrThreads + threadIdx.x, stride = n_blocks * kIpmErrThreads;
   const double inv_f = 1.0 / scales[0];
   const double* d_ce = scales + 1;
   const double* d_ci = scales + 1 + K.m_e;
@@ -437,37 +522,44 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   const double* ci = V + K.off_ci;
   const double* Ae = V + K.off_Ae;
   const double* Ai = V + K.off_Ai;
-  for (int j = t0; j < K.n; j += stride) {
-    const int gs = K.g_src[j];
-    const double g = gs >= 0 ? V[gs] : 0.0;
-    double dual = g, dual_u = inv_f * g, aetce = 0.0, aitcp = 0.0;
-    double a1 = 0.0, a1u = 0.0;
-    for (int q = K.ae_colptr[j]; q < K.ae_colptr[j + 1]; ++q) {
+  // columns: EIGHT LANES per column, an entry of the column each (a column of A_e has 5-9 entries: walked
+  // by one lane they were as many dependent trips to memory; this is two), summed by DPP in lane order
+  const int lane8 = t0 & 7;
+  for (int j = t0 >> 3; j < K.n; j += stride >> 3) {
+    double a1 = 0.0, a1u = 0.0, aetce = 0.0;
+    for (int q = K.ae_colptr[j] + lane8; q < K.ae_colptr[j + 1]; q += 8) {
       const int r = K.ae_rowidx[q];
       const double a = Ae[q], dr = d_ce[r];
       a1 += a * y[r];
       a1u += ((1.0 / dr) * a) * (dr * y[r] * inv_f);
       aetce += a * ce[r];
     }
-    dual -= a1;
-    dual_u -= a1u;
-    double a2 = 0.0, a2u = 0.0;
-    for (int q = K.ai_colptr[j]; q < K.ai_colptr[j + 1]; ++q) {
+    double a2 = 0.0, a2u = 0.0, aitcp = 0.0;
+    for (int q = K.ai_colptr[j] + lane8; q < K.ai_colptr[j + 1]; q += 8) {
       const int r = K.ai_rowidx[q];
       const double a = Ai[q], dr = d_ci[r];
       a2 += a * z[r];
       a2u += ((1.0 / dr) * a) * (dr * z[r] * inv_f);
       aitcp += a * fmin(ci[r], 0.0);
     }
-    dual -= a2;
-    dual_u -= a2u;
-    acc[DUAL] = fmax(acc[DUAL], fabs(dual));
-    acc[DUAL_U] = fmax(acc[DUAL_U], fabs(dual_u));
-    acc[AETCE] += aetce * aetce;
-    acc[AITCP] += aitcp * aitcp;
+    const int gs = K.g_src[j];
+    const double g = gs >= 0 ? V[gs] : 0.0;
     const double xj = x[j];
-    acc[XINF] = fmax(acc[XINF], fabs(xj));
-    if (!isfinite(xj)) acc[FINITE] = 0.0;
+    a1 = ipm_group8_sum(a1);
+    a1u = ipm_group8_sum(a1u);
+    aetce = ipm_group8_sum(aetce);
+    a2 = ipm_group8_sum(a2);
+    a2u = ipm_group8_sum(a2u);
+    aitcp = ipm_group8_sum(aitcp);
+    if (lane8 == 0) {
+      const double dual = (g - a1) - a2, dual_u = (inv_f * g - a1u) - a2u;
+      acc[DUAL] = fmax(acc[DUAL], fabs(dual));
+      acc[DUAL_U] = fmax(acc[DUAL_U], fabs(dual_u));
+      acc[AETCE] += aetce * aetce;
+      acc[AITCP] += aitcp * aitcp;
+      acc[XINF] = fmax(acc[XINF], fabs(xj));
+      if (!isfinite(xj)) acc[FINITE] = 0.0;
+    }
   }
   for (int r = t0; r < K.m_e; r += stride) {
     const double c = ce[r], dr = d_ce[r], yr = y[r];
@@ -500,6 +592,44 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   if (check_all_V)
     for (int k = t0; k < nV; k += stride)
       if (!isfinite(V[k])) acc[FINITE] = 0.0;
+}
+
+__global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
+    KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
+    const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
+    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial, IpmErrFinish fin) {
+  using namespace ipm_err;
+  constexpr int NQ = kIpmErrQ;
+  __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
+  if (fin.skip != nullptr && fin.skip[0] != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ipm_publish(fin.seq_dev, fin.seq_host);
+    return;
+  }
+  // fin.n_err_blocks != 0: ONE launch — the tape's separable sums (which make f) ride as extra
+  // workgroups, and whichever workgroup finishes last folds the partials and publishes
+  // (ipm_error_finish); 0: the partials only, ipm_error_final_kernel follows.
+  if (fin.n_err_blocks != 0 && static_cast<int>(blockIdx.x) >= fin.n_err_blocks) {
+    const NlpStructure::SumReduce r = fin.red[blockIdx.x - fin.n_err_blocks];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    if (tid < 64)
+      for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
+    if (tid < 64) scratch[tid] = acc;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) scratch[tid] += scratch[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0)
+      coherent_store(&fin.Vw[r.dst], (r.scale_idx >= 0 ? fin.tape_scales[r.scale_idx] : 1.0) * scratch[0], true);
+    ipm_error_finish(K, V, partial, fin);
+    return;
+  }
+  const int n_blocks = fin.n_err_blocks != 0 ? fin.n_err_blocks : static_cast<int>(gridDim.x);
+  double acc[NQ];
+  const int ops[NQ] = SLPX_IPM_ERR_OPS;
+  ipm_error_accumulate(K, V, nV, x, s, y, z, scales, check_all_V, blockIdx.x * kIpmErrThreads + threadIdx.x,
+                       n_blocks * kIpmErrThreads, acc);
   block_reduce<NQ, kIpmErrThreads>(acc, ops, scratch);
   if (threadIdx.x == 0) {
 #pragma unroll
@@ -508,12 +638,12 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   if (fin.n_err_blocks != 0) ipm_error_finish(K, V, partial, fin);
 }
 
-__global__ __launch_bounds__(64) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,
+__global__ __launch_bounds__(256) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,
                                                              const double* __restrict__ partial, int n_blocks,
                                                              IpmErrOut* __restrict__ out,
                                                              unsigned long long* __restrict__ seq_dev,
                                                              volatile unsigned long long* seq_host) {
-  __shared__ double tot[kIpmErrQ];
+  __shared__ double tot[9 * kIpmErrQ];
   ipm_error_fold(K, V, partial, n_blocks, false, out, seq_dev, seq_host, tot);
 }
 

@@ -652,6 +652,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (const char* env = std::getenv("SLPX_IL_DIRECT")) m_il_direct = env[0] != '0';
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
+  if (const char* env = std::getenv("SLPX_FWD_SINGLE")) m_fwd_single = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
   // launch fusion (device.hpp: KktFuse / BacksubFuse): one problem, single-launch factorization
   m_fuse_launches = m_single_launch && batch == 1 && l.factor_lds_bytes >= 64 * sizeof(double);
@@ -1978,11 +1979,17 @@ void DeviceNlp::solve() {
     solve_after_factor();
     return;
   }
-  for (int r = 0; r < l.n_rounds; ++r) {
-    const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-    hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
-                       m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs,
-                       m_zv.p);
+  if (m_single_launch && m_batch == 1 && !m_capturing && m_fwd_single) {
+    // one problem: every round in ONE launch (the tasks order themselves through the round counters)
+    hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(static_cast<uint32_t>(l.tasks.size()), 1), dim3(256), l.solve_lds_bytes, m_stream,
+                       m_ldev, 0u, m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs, m_zv.p, m_fround_cnt.p);
+  } else {
+    for (int r = 0; r < l.n_rounds; ++r) {
+      const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+      hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(nt, m_batch), dim3(256), l.solve_lds_bytes, m_stream,
+                         m_ldev, l.round_ptr[r], m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs,
+                         m_zv.p, static_cast<unsigned int*>(nullptr));
+    }
   }
   m_mfb_rhs_in_fronts = false;  // z of THIS right-hand side is in zv: the pair-list backward solve from L
   solve_after_factor();
@@ -2159,7 +2166,11 @@ void DeviceNlp::ipm_enable() {
   m_p_keep.alloc(m_kdev.dim);
   m_ps_keep.alloc(std::max(1, s.m_i));
   m_pz_keep.alloc(std::max(1, s.m_i));
-  m_ipm_alpha.alloc(2);
+  m_ipm_alpha.alloc(4);  // alpha_max, alpha_z, "this attempt's look-ahead chain is void", -
+  m_ipm_alpha.zero();
+  m_s_ahead.alloc(std::max(1, s.m_i));
+  m_y_ahead.alloc(std::max(1, s.m_e));
+  m_z_ahead.alloc(std::max(1, s.m_i));
   SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_ipm_host), sizeof(IpmHost)));
   std::memset(m_ipm_host, 0, sizeof(IpmHost));
   m_ipm = true;
@@ -2201,6 +2212,33 @@ void DeviceNlp::ipm_direction(double tau) {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
+void DeviceNlp::ipm_lookahead(double tau) {
+  hipLaunchKernelGGL(ipm_lookahead_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V.p, m_in.p, m_s.p, m_y.p,
+                     m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_s_ahead.p, m_y_ahead.p, m_z_ahead.p,
+                     m_ipm_alpha.p, &m_ipm_host->dir, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
+  SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::sweep_full_lookahead() {
+  m_in_override = m_trial_in.p;
+  m_V_override = m_V_trial.p;
+  m_tape_reduce = false;  // the separable sums ride in ipm_errors(.., sums_ride, ahead)
+  launch_tape(m_full, true);
+  m_tape_reduce = true;
+  m_in_override = nullptr;
+  m_V_override = nullptr;
+}
+
+void DeviceNlp::ipm_accept_lookahead() {
+  // every launch takes these pointers when it is made: the next step reads the accepted iterate
+  m_in.swap(m_trial_in);
+  m_s.swap(m_s_ahead);
+  m_y.swap(m_y_ahead);
+  m_z.swap(m_z_ahead);
+  m_V.swap(m_V_trial);
+  m_lhs_stale = m_rhs_stale = true;
+}
+
 void DeviceNlp::ipm_trial_point(double alpha) {
   hipLaunchKernelGGL(ipm_trial_point_kernel, dim3(grid_for(m_kdev.n, 256)), dim3(256), 0, m_stream, m_kdev.n,
                      m_in.p, m_p.p, alpha, m_trial_in.p);
@@ -2225,9 +2263,10 @@ void DeviceNlp::ipm_commit(double alpha, double alpha_z, bool s_from_ci) {
 
 // `sums_ride`: the sweep before this call left the tape's separable sums out
 // (sweep_full(false)); they ride in this launch
-void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride) {
+void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride, bool ahead) {
   const int work = std::max({m_kdev.n, m_kdev.m_e, m_kdev.m_i, 1});
-  const int blocks = grid_for(work, kIpmErrThreads, 256);
+  // eight lanes per column (ipm_error_accumulate): up to 64 workgroups of 256
+  const int blocks = grid_for(8 * work, kIpmErrThreads, 64);
   if (m_ipm_partial.n < static_cast<size_t>(blocks) * kIpmErrQ) m_ipm_partial.alloc(static_cast<size_t>(256) * kIpmErrQ);
   if (m_ipm_err_done.n == 0) m_ipm_err_done.upload(std::vector<unsigned int>(1, 0u));
   const int n_sums = sums_ride ? static_cast<int>(m_reduces.n) : 0;
@@ -2236,14 +2275,15 @@ void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride) {
   fin.n_total_blocks = blocks + n_sums;
   fin.red = m_reduces.p;
   fin.tape_scales = m_scales.p;
-  fin.Vw = m_V.p;
+  fin.Vw = ahead ? m_V_trial.p : m_V.p;
   fin.done = m_ipm_err_done.p;
-  fin.out = &m_ipm_host->err;
+  fin.out = ahead ? &m_ipm_host->err_ahead : &m_ipm_host->err;
   fin.seq_dev = m_seq_dev.p;
   fin.seq_host = m_h_seq;
-  hipLaunchKernelGGL(ipm_error_partial_kernel, dim3(blocks + n_sums), dim3(kIpmErrThreads), 0, m_stream, m_kdev, m_V.p,
-                     m_s_ref.nV, m_in.p, m_s.p, m_y.p, m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0,
-                     m_ipm_partial.p, fin);
+  fin.skip = ahead ? m_ipm_alpha.p + 2 : nullptr;
+  hipLaunchKernelGGL(ipm_error_partial_kernel, dim3(blocks + n_sums), dim3(kIpmErrThreads), 0, m_stream, m_kdev, fin.Vw,
+                     m_s_ref.nV, ahead ? m_trial_in.p : m_in.p, ahead ? m_s_ahead.p : m_s.p, ahead ? m_y_ahead.p : m_y.p,
+                     ahead ? m_z_ahead.p : m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0, m_ipm_partial.p, fin);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
@@ -2272,19 +2312,15 @@ void DeviceNlp::ipm_soc_backsub() {
 }
 
 void DeviceNlp::ipm_save_direction() {
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_p_keep.p, m_p.p, m_kdev.dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-  if (m_kdev.m_i) {
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_ps_keep.p, m_ps.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_pz_keep.p, m_pz.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-  }
+  hipLaunchKernelGGL(ipm_copy_direction_kernel, dim3(grid_for(m_kdev.dim, 256)), dim3(256), 0, m_stream, m_kdev.dim, m_kdev.m_i,
+                     m_p.p, m_ps.p, m_pz.p, m_p_keep.p, m_ps_keep.p, m_pz_keep.p);
+  SLPX_HIP_CHECK(hipGetLastError());
 }
 
 void DeviceNlp::ipm_restore_direction() {
-  SLPX_HIP_CHECK(hipMemcpyAsync(m_p.p, m_p_keep.p, m_kdev.dim * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-  if (m_kdev.m_i) {
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_ps.p, m_ps_keep.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_pz.p, m_pz_keep.p, m_kdev.m_i * sizeof(double), hipMemcpyDeviceToDevice, m_stream));
-  }
+  hipLaunchKernelGGL(ipm_copy_direction_kernel, dim3(grid_for(m_kdev.dim, 256)), dim3(256), 0, m_stream, m_kdev.dim, m_kdev.m_i,
+                     m_p_keep.p, m_ps_keep.p, m_pz_keep.p, m_p.p, m_ps.p, m_pz.p);
+  SLPX_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace slpx

@@ -713,8 +713,13 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
 __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     LdltDev L, uint32_t task_base, const double* __restrict__ rhs, int n,
     const double* __restrict__ Lx, long long lx_stride, const double* __restrict__ D,
-    double* __restrict__ scontrib, int scontrib_stride, double* __restrict__ zv) {
+    double* __restrict__ scontrib, int scontrib_stride, double* __restrict__ zv,
+    unsigned int* __restrict__ round_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // round_cnt != nullptr: EVERY round in this launch (one problem; the grid is all tasks in round order, so
+  // whatever a workgroup waits for was dispatched before it) — a task waits for the round below it after
+  // it has staged its plan and gathered its part of L, and the partial sums cross workgroups coherently
+  const bool single = round_cnt != nullptr;
   const uint32_t task_index = task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   const int b = blockIdx.y;
@@ -769,10 +774,13 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
       vals[q + 768] = a3;
     }
     for (; q < n_items; q += 256) vals[q] = Lx[items[q].x];
+  }
+  if (single && t.round > 0) round_wait(&round_cnt[t.round - 1], L.round_ptr[t.round] - L.round_ptr[t.round - 1], nullptr);
+  {
     const uint32_t* scidx = L.scontrib_idx + t.scontrib_off;
     for (uint32_t i = tid; i < t.n_col; i += 256) {
       double acc = rhs[L.perm[colperm[i]]];
-      for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= scontrib[scidx[c]];
+      for (uint32_t c = fcptr[i]; c < fcptr[i + 1]; ++c) acc -= coherent_load(&scontrib[scidx[c]], single);
       y[i] = acc;
     }
   }
@@ -813,7 +821,12 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
     double acc = 0.0;
     for (uint32_t q = sptr[x] + (tid & 7); q < qe; q += 8) acc += Lx[sitems[q].lpos] * y[sitems[q].ref];
     acc = group8_sum(acc);
-    if ((tid & 7) == 0) scontrib[L.sext_dst[t.sext_off + x]] = acc;
+    if ((tid & 7) == 0) coherent_store(&scontrib[L.sext_dst[t.sext_off + x]], acc, single);
+  }
+  if (single) {
+    const int last = L.n_rounds - 1;
+    round_signal(round_cnt, static_cast<int>(t.round), L.n_rounds,
+                 static_cast<int>(t.round) == last ? L.round_ptr[last + 1] - L.round_ptr[last] : 0u);
   }
   for (uint32_t i = tid; i < t.n_col; i += 256) {
     const uint32_t pj = colperm[i];

@@ -1172,6 +1172,26 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         std::fprintf(stderr, "ldlt fronts round %d: deepest task %u levels, most fronts in a level %u, levels with more than 16 fronts %u of %u; passes of 16 waves per task %u..%u\n",
                      r, deepest, most, over, lv, least_passes, most_passes);
       }
+      if (const char* lv = std::getenv("SLPX_LDLT_VERBOSE"); lv != nullptr && std::atoi(lv) >= 2) {
+        // per task: round, levels, and per level "fronts:widest w" — where the critical path's imbalance sits
+        for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
+          const LdltTask& T = P.tasks[ti];
+          const LdltMfTask& M = P.mf_tasks[ti];
+          std::fprintf(stderr, "ldlt task %zu round %u cols %u ents %u anc %u levels %u:", ti, T.round, T.n_col, T.n_ent, M.n_anc, T.n_lvl);
+          for (uint32_t l = 0; l < T.n_lvl; ++l) {
+            const uint32_t b = P.mf_lvl_ptr[T.lvl_off + l], e = P.mf_lvl_ptr[T.lvl_off + l + 1];
+            uint32_t wmax = 0, nchmax = 0, rmax = 0;
+            for (uint32_t q = b; q < e; ++q) {
+              const LdltFront& F = P.mf_fronts[M.front_off + q];
+              wmax = std::max<uint32_t>(wmax, F.w);
+              nchmax = std::max<uint32_t>(nchmax, F.nch);
+              rmax = std::max<uint32_t>(rmax, F.nr - F.w - 1u);
+            }
+            std::fprintf(stderr, " %u:w%u,c%u,r%u", e - b, wmax, nchmax, rmax);
+          }
+          std::fprintf(stderr, "\n");
+        }
+      }
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u), fronts on the matrix cores %u\n",
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib, P.mf_n_mfma);
     }

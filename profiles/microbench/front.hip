@@ -71,7 +71,7 @@ int main() {
   };
   std::printf("empty body (two clock readings + one barrier of 8 waves): %lld clocks\n", run(Shape{0, 8, 0, 27}, 16, 1, 3));
   struct Case { uint32_t w, r, nch; };
-  const Case cases[] = {{1, 6, 0}, {1, 6, 2}, {2, 8, 2}, {3, 8, 2}, {4, 9, 2}, {5, 9, 2}, {8, 10, 2}, {4, 20, 2}, {8, 22, 2}};
+  const Case cases[] = {{1, 6, 0}, {1, 6, 2}, {2, 8, 2}, {3, 8, 2}, {4, 9, 2}, {5, 9, 2}, {6, 9, 2}, {7, 9, 2}, {8, 10, 2}, {4, 9, 3}, {5, 9, 3}, {5, 9, 5}, {6, 9, 3}, {4, 20, 2}, {8, 22, 2}};
   for (const Case& cs : cases) {
     const uint32_t w = cs.w, r = cs.r, nr = w + r + 1, nch = cs.nch;
     const uint32_t n_tr = col_off(w, nr), n_s = r * (r + 1) / 2 + r;

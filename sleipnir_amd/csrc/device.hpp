@@ -372,6 +372,10 @@ class DeviceNlp {
   void backsub_publish();
   void materialize_factor();                // batch-interleaved mode: refresh the batch-major L, D copies
   static bool interleaved_for(int batch);   // batches this large factor with one lane per problem
+  // ... and, among those, by fronts with four lanes per problem (ldlt_mfq_kernels.h) where the plan allows it
+  static bool il_fronts_enabled();                 // SLPX_IL_FRONTS=1 (default off: measured slower, kernels.hip)
+  static void il_fronts_options(LdltOptions& o);   // what such a plan needs: supernodes, fronts of <= 20 rows, small tasks
+  static bool il_fronts_fit(const LdltPlan& l);    // every front within the rows four lanes hold, every task within a CU's LDS
 
   // ---- interior-point iteration on the device (ipm_kernels.h; one problem) ----
   // All asynchronous on stream(); results arrive in ipm_host() after wait().
@@ -540,6 +544,7 @@ class DeviceNlp {
   int m_mfb_threads = 256, m_mfb_ppw = 0, m_mfb_wg_per_cu = 4, m_cus = 256;
   DevBuf<double> m_mfb_ust, m_mfb_invd;
   void build_mf_batch(const LdltPlan& l);
+  void build_mf_il(const LdltPlan& l);   // images + update slots of the interleaved fronts (m_il_fronts)
   void launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
                        hipStream_t stream);
   DevBuf<unsigned int> m_ipm_err_done;
@@ -571,6 +576,8 @@ class DeviceNlp {
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
+  bool m_il_fronts = false;          // batch-interleaved factorization by fronts (ldlt_mfq_factor_kernel)
+  uint32_t m_mfq_lds = 0;
   bool m_fwd_single = true;  // SLPX_FWD_SINGLE=0: the forward substitution of a new right-hand side one launch per round
   hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
   hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;

@@ -25,6 +25,7 @@
 #include "ldlt_kernels.h"
 #include "ldlt_mf_kernels.h"
 #include "ldlt_il_kernels.h"
+#include "ldlt_mfq_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
 #include "tape_kernels.h"
@@ -742,7 +743,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_rhs_il.alloc(C * l.n * W);
     m_Lx_il.alloc(C * std::max<int64_t>(1, l.nnzL) * W);
     m_D_il.alloc(C * l.n * W);
-    m_contrib_il.alloc(C * std::max<uint32_t>(1, l.n_contrib) * W);
+    if (il_fronts_enabled() && l.mf) build_mf_il(l);
+    m_contrib_il.alloc(C * std::max<uint32_t>(1, m_il_fronts ? l.mf_n_contrib : l.n_contrib) * W);
     m_scontrib_il.alloc(C * std::max<uint32_t>(1, l.n_scontrib) * W);
     m_zv_il.alloc(C * l.n * W);
     m_xg_il.alloc(C * l.n * W);
@@ -754,6 +756,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     uint32_t fbytes = 0, col = 0, solve_bytes = 0;
     std::vector<uint32_t> meta, meta_off;
     for (const LdltTask& t : l.tasks) {
+      if (m_il_fronts) {  // (the fronts bring their own tables: only the solves' LDS is sized here)
+        col = std::max(col, t.n_col + 1);
+        solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (3u * t.n_col + t.n_lvl + 4u) + 8u * t.n_bwd_items + 16u);
+        continue;
+      }
       const uint32_t n_cref = l.ent_contrib_ptr[t.contrib_ptr_off + t.n_ent];
       meta_off.push_back(static_cast<uint32_t>(meta.size()));
       const size_t head = meta.size();
@@ -792,8 +799,10 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       meta[head + 1] = n_words;
       fbytes = std::max(fbytes, std::max<uint32_t>((t.n_ent + t.n_col) * kIlW * 8u, 3u * kIlSlots * kIlW * 8u) + 4u * n_words + 16u);
       col = std::max(col, t.n_col + 1);
-      solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (2u * t.n_col + t.n_lvl + 4u) + 8u * t.n_bwd_items + 16u);
+      solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (3u * t.n_col + t.n_lvl + 4u) + 8u * t.n_bwd_items + 16u);
     }
+    if (meta.empty()) meta.push_back(0);
+    if (meta_off.empty()) meta_off.push_back(0);
     m_il_meta.upload(meta);
     m_il_meta_off.upload(meta_off);
     m_il_factor_lds = fbytes;
@@ -1451,6 +1460,87 @@ void DeviceNlp::build_mf_batch(const LdltPlan& l) {
   m_mfb = true;
 }
 
+// ---- batch-interleaved factorization by fronts (ldlt_mfq_kernels.h) ----
+bool DeviceNlp::il_fronts_enabled() {
+  // Built, parity green, measured — and left off (profiles/r04_il_fronts_probe.txt): 64 x N=500 163 k steps/s
+  // against the pair-list kernel's 248 k, 512 x N=1000 166 k against 511 k.  A front keeps ONE wave busy for
+  // ~5000 clocks (the update block's row-by-row trips to LDS) and sixteen problems' values fill the CU's LDS
+  // with one workgroup, of whose eight waves the levels of a task (16, 8, 3, 2, 1 fronts) use two on average;
+  // the pair-list kernel has every lane of a dozen waves per CU on an entry in every level.
+  const char* env = std::getenv("SLPX_IL_FRONTS");
+  return env != nullptr && env[0] == '1';
+}
+void DeviceNlp::il_fronts_options(LdltOptions& o) {
+  o.supernodal = true;
+  o.multifrontal = true;
+  o.min_supernode_width = 2;
+  o.relax_zeros = 8;
+  o.balance_supernode_cuts = true;
+  o.max_front_rows = kMfqMaxFrontRows;
+  o.mfma_min_entries = 0xffffffffu;  // (no matrix-core path in the batch kernel)
+}
+// bytes of the image of a task as build_mf_batch / build_mf_il lay it out (mf_carve from o_tab to the counters)
+static uint32_t mfq_task_lds(const LdltTask& t, const LdltMfTask& m) {
+  const MfCarve cv = mf_carve(t, m);
+  const uint32_t values = 128u * (t.n_ent + m.arena + t.n_col);
+  return std::max<uint32_t>(values + (cv.o_cnt - cv.o_tab), 12u * 1024u + 16u) + 16u;  // (the exit's counter planes reuse the front)
+}
+bool DeviceNlp::il_fronts_fit(const LdltPlan& l) {
+  if (!l.mf || l.mf_max_front_rows > kMfqMaxFrontRows) return false;
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti)
+    if (mfq_task_lds(l.tasks[ti], l.mf_tasks[ti]) > 160u * 1024u) return false;
+  return true;
+}
+
+void DeviceNlp::build_mf_il(const LdltPlan& l) {
+  if (!il_fronts_fit(l)) return;
+  uint32_t lds = 0;
+  std::vector<uint4> desc(l.tasks.size());
+  std::vector<std::vector<unsigned char>> blobs;
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
+    const LdltTask& t = l.tasks[ti];
+    const LdltMfTask& m = l.mf_tasks[ti];
+    const MfCarve cv = mf_carve(t, m);
+    lds = std::max(lds, mfq_task_lds(t, m));
+    std::vector<unsigned char> blob(cv.o_cnt - cv.o_tab, 0);
+    auto put = [&](uint32_t at, const void* src, size_t bytes) {
+      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
+      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
+    };
+    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
+    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
+    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
+    put(cv.o_src, l.ent_src.data() + t.ent_off, 4u * t.n_ent);
+    put(cv.o_flags, l.ent_flags.data() + t.ent_off, t.n_ent);
+    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
+    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
+    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
+    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
+    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
+    desc[ti] = uint4{0u, static_cast<uint32_t>(blob.size() / 16u), 0u, 0u};
+    blobs.push_back(std::move(blob));
+  }
+  size_t stride16 = 1;
+  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
+  std::vector<uint4> image(stride16 * blobs.size() + 4, uint4{0, 0, 0, 0});
+  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
+  hipFuncAttributes attr{};
+  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_mfq_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+  SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ldlt_mfq_factor_kernel)));
+  if (attr.sharedSizeBytes != 0) return;  // (the tables hold LDS byte addresses from 0)
+  if (std::getenv("SLPX_LDLT_VERBOSE"))
+    std::fprintf(stderr, "ldlt interleaved fronts: %zu tasks, LDS %u bytes, images %zu bytes, %d registers\n", l.tasks.size(), lds,
+                 16 * image.size(), attr.numRegs);
+  m_mf_tasks.upload(l.mf_tasks);
+  m_mf_fronts.upload(l.mf_fronts);
+  m_mf_image.upload(image);
+  m_mf_image_stride16 = static_cast<uint32_t>(stride16);
+  m_mf_image_desc.upload(desc);
+  m_mfq_lds = lds;
+  m_il_fronts = true;
+}
+
 void DeviceNlp::launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
                                 hipStream_t stream) {
   const LdltPlan& l = m_l_ref;
@@ -1747,7 +1837,35 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
     if (!m_rhs_in_il)
       hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, stream, m_rhs.p,
                          static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
-    for (int r = 0; r < l.n_rounds; ++r) {
+    if (m_il_fronts) {
+      MfDev md;
+      md.tasks = m_mf_tasks.p;
+      md.fronts = m_mf_fronts.p;
+      md.image = m_mf_image.p;
+      md.image_stride16 = m_mf_image_stride16;
+      md.image_desc = m_mf_image_desc.p;
+      md.n_tasks = static_cast<unsigned int>(l.tasks.size());
+      MfqDev q;
+      q.lhs_il = m_lhs_il.p;
+      q.rhs_il = m_rhs_il.p;
+      q.reg = reg;
+      q.Lx_il = m_Lx_il.p;
+      q.D_il = m_D_il.p;
+      q.zv_il = m_zv_il.p;
+      q.contrib_il = m_contrib_il.p;
+      q.stats_part = m_stats_part.p;
+      q.nnz_lhs = nnz;
+      q.nnzL = lxs;
+      q.n_contrib = static_cast<long long>(std::max<uint32_t>(1, l.mf_n_contrib));
+      q.n = l.n;
+      q.batch = m_batch;
+      for (int r = 0; r < l.n_rounds; ++r) {
+        const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
+        hipLaunchKernelGGL(ldlt_mfq_factor_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kMfqThreads), m_mfq_lds, stream, m_ldev, md,
+                           l.round_ptr[r], q);
+      }
+    }
+    for (int r = 0; r < l.n_rounds && !m_il_fronts; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
                          l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,

@@ -396,8 +396,9 @@ __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
   uint32_t* s_ptr = reinterpret_cast<uint32_t*>(il_smem + static_cast<size_t>(t.n_col) * kIlLanes);
   uint32_t* s_colperm = s_ptr + t.n_col + 1;
   uint32_t* s_lvl = s_colperm + t.n_col;
-  // (8-byte aligned: the x rows are a multiple of 512 bytes; the three word arrays together 2 n_col + n_lvl + 2 words)
-  LdltSolveItem* s_items = reinterpret_cast<LdltSolveItem*>(s_lvl + t.n_lvl + 1 + ((2 * t.n_col + t.n_lvl + 2) & 1u));
+  uint32_t* s_colsn = s_lvl + t.n_lvl + 1;  // position in its chain | width << 8 (LdltPlan::col_sn)
+  // (8-byte aligned: the x rows are a multiple of 512 bytes; the four word arrays together 3 n_col + n_lvl + 2 words)
+  LdltSolveItem* s_items = reinterpret_cast<LdltSolveItem*>(s_colsn + t.n_col + ((3 * t.n_col + t.n_lvl + 2) & 1u));
   {
     const uint32_t* g_ptr = L.bwd_ptr + t.colptr_off;
     const uint32_t* g_colperm = L.col_perm + t.col_off;
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
     for (uint32_t k = tid; k <= t.n_col; k += kThreads) s_ptr[k] = g_ptr[k];
     for (uint32_t k = tid; k < t.n_col; k += kThreads) s_colperm[k] = g_colperm[k];
     for (uint32_t k = tid; k <= t.n_lvl; k += kThreads) s_lvl[k] = g_lvl[k];
+    for (uint32_t k = tid; k < t.n_col; k += kThreads) s_colsn[k] = L.col_sn[t.col_off + k];
     for (uint32_t k = tid; k < t.n_bwd_items; k += kThreads) s_items[k] = g_items[k];
   }
   __syncthreads();
@@ -426,7 +428,11 @@ __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
   };
   for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
     const int lo = static_cast<int>(s_lvl[l]);
-    for (int i = static_cast<int>(s_lvl[l + 1]) - 1 - wave; i >= lo; i -= kIlBwdWaves) {
+    // the columns of a level are dealt to the waves — by CHAIN: the columns of a supernode (consecutive,
+    // one level) depend on each other top-down, so the wave that owns the chain's first column walks all of
+    // them, last first; its own stores to x are in order for it (lone columns: a chain of one)
+    for (int i = static_cast<int>(s_lvl[l + 1]) - 1; i >= lo; --i) {
+      if (((i - static_cast<int>(s_colsn[i] & 0xffu)) % kIlBwdWaves) != wave) continue;
       double acc = zv[static_cast<size_t>(s_colperm[i]) * kIlW];
       uint32_t q = s_ptr[i];
       const uint32_t qe = s_ptr[i + 1];

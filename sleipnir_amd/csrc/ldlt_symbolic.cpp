@@ -335,7 +335,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         while (chain.size() < opt.max_supernode_width) {
           const int32_t p = P.parent[k];
           if (p < 0 || sn[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
-              chain.size() + 1 + Lcol[p].size() + 1 > kSnRowsMax)
+              chain.size() + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
             break;
           sn[p] = sn[j];
           chain.push_back(p);
@@ -361,7 +361,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         if (used[J] || cols[J][0] != p || lvl[s] + 1 < lvl[J]) continue;  // joins at the head, deepest child only
         const auto& cj = cols[J];
         const size_t below = cj.size() + Lcol[cj.back()].size();  // rows under the joining columns
-        if (ch.size() + cj.size() > opt.max_supernode_width || ch.size() + below + 1 > kSnRowsMax) continue;
+        if (ch.size() + cj.size() > opt.max_supernode_width || ch.size() + below + 1 > opt.max_front_rows) continue;
         int64_t zeros = 0;
         for (size_t i = 0; i < ch.size(); ++i)
           zeros += static_cast<int64_t>(ch.size() - 1 - i + below) - static_cast<int64_t>(Lcol[ch[i]].size());
@@ -479,11 +479,28 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     std::vector<int32_t> chain{j};
     sn_of[j] = static_cast<int32_t>(sn_cols.size());
     int32_t k = j;
-    while (opt.supernodal && chain.size() < opt.max_supernode_width) {
+    // A chain longer than the widest supernode is cut into pieces of (nearly) EQUAL width — nine columns
+    // as 5 + 4, not 8 + 1: the dense pass of a front costs more than linearly in its width
+    // (profiles/r04_microbench_front.txt), and the one-column tail was a level of its own.
+    uint32_t cap = opt.max_supernode_width;
+    if (opt.supernodal && opt.balance_supernode_cuts) {
+      uint32_t len = 1;
+      for (int32_t q = j;;) {
+        const int32_t p = P.parent[q];
+        if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[q].size() != Lcol[p].size() + 1 ||
+            len + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
+          break;
+        ++len;
+        q = p;
+      }
+      const uint32_t pieces = (len + opt.max_supernode_width - 1) / opt.max_supernode_width;
+      cap = (len + pieces - 1) / pieces;
+    }
+    while (opt.supernodal && chain.size() < cap) {
       const int32_t p = P.parent[k];
       // rows of the trapezoid after adding p: chain + struct(L_p) + rhs row
       if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
-          chain.size() + 1 + Lcol[p].size() + 1 > kSnRowsMax)
+          chain.size() + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
         break;
       sn_of[p] = sn_of[j];
       sn_pos[p] = static_cast<int32_t>(chain.size());
@@ -1190,6 +1207,14 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
             std::fprintf(stderr, " %u:w%u,c%u,r%u", e - b, wmax, nchmax, rmax);
           }
           std::fprintf(stderr, "\n");
+          if (std::atoi(lv) >= 3 && T.round >= 1)
+            for (uint32_t l = 0; l < T.n_lvl; ++l)
+              for (uint32_t q = P.mf_lvl_ptr[T.lvl_off + l]; q < P.mf_lvl_ptr[T.lvl_off + l + 1]; ++q) {
+                const LdltFront& F = P.mf_fronts[M.front_off + q];
+                std::fprintf(stderr, "  level %u front w%u r%u nch%u original columns:", l, F.w, F.nr - F.w - 1u, F.nch);
+                for (uint32_t c = 0; c < F.w; ++c) std::fprintf(stderr, " %d", P.perm[P.col_perm[T.col_off + F.col0 + c]]);
+                std::fprintf(stderr, "\n");
+              }
         }
       }
       std::fprintf(stderr, "ldlt multifrontal plan: %s, %zu fronts, widest table %zu bytes, largest arena %zu doubles, most children per entry %u, update slots %u (pair plan: %u), fronts on the matrix cores %u\n",

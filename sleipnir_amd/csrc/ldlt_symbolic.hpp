@@ -217,6 +217,8 @@ struct LdltOptions {
   // chains are cut at this many columns; the device kernels hold a row of kSnWidthMax doubles in
   // registers, wider plans are for the host interpreter's what-if statistics only
   uint32_t max_supernode_width = kSnWidthMax;
+  uint32_t max_front_rows = kSnRowsMax;  // rows of a front (w + |R| + 1): the batch kernel with four lanes per problem holds 20
+  bool balance_supernode_cuts = false;  // chains longer than that in pieces of equal width (multifrontal plans)
   // Hubs (nodes adjacent to a large part of the graph: a timestep shared by every stage, the
   // dense border of an arrow matrix) are set aside and eliminated last, like the "dense rows" of
   // the sparse orderings: degree > max(hub_floor, hub_factor x median degree).  build_ldlt_plan

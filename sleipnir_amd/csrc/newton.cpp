@@ -50,6 +50,11 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
     // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
+    // ... unless the batch factorizes by FRONTS with four lanes per problem (ldlt_mfq_kernels.h; SLPX_IL_FRONTS=0:
+    // the pair-list kernel): the single problem's plan — relaxed supernodes, every one a front of at most 20 rows
+    const LdltOptions lopt_pairs = lopt;
+    const bool il_fronts = DeviceNlp::interleaved_for(opt.batch) && DeviceNlp::il_fronts_enabled();
+    if (il_fronts) DeviceNlp::il_fronts_options(lopt);
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
     // one problem: the multifrontal step (ldlt_mf_kernels.h) — every supernode a dense front, so a chain
     // of two columns already saves a level (the pair-list kernels' chain pass only paid from four)
@@ -64,8 +69,11 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
         lopt.multifrontal = true;
         lopt.min_supernode_width = 2;
         lopt.relax_zeros = 8;
+        lopt.balance_supernode_cuts = true;
       }
     }
+    if (const char* env = std::getenv("SLPX_SN_MAX_WIDTH")) lopt.max_supernode_width = std::clamp<uint32_t>(static_cast<uint32_t>(std::atoi(env)), 1u, kSnWidthMax);
+    if (const char* env = std::getenv("SLPX_SN_BALANCE")) lopt.balance_supernode_cuts = env[0] != '0';
     if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
     if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
@@ -81,6 +89,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
     m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    // (a front of more rows than four lanes hold, or a task beyond the LDS of a CU with sixteen problems side by
+    // side: the pair-list plan)
+    if (il_fronts && !DeviceNlp::il_fronts_fit(m_l)) m_l = build_ldlt_plan(m_k.lhs, st.n, lopt_pairs, user_perm, &diag_has_source);
     // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
     // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
     // and usually has a round more than necessary; twice the task size fixes both (cart-pole
@@ -164,8 +175,12 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
+  const LdltOptions lopt_pairs = lopt;
+  const bool il_fronts = DeviceNlp::interleaved_for(opt.batch) && DeviceNlp::il_fronts_enabled();
+  if (il_fronts) DeviceNlp::il_fronts_options(lopt);
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
   m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
+  if (il_fronts && !DeviceNlp::il_fronts_fit(m_l)) m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt_pairs, nullptr, &diag_has_source);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));
   reset_regularization();

@@ -136,12 +136,15 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (task_entries > 0) lopt.task_entries = task_entries;
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = env[0] != '0';
   if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
+  if (const char* env = std::getenv("SLPX_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
+  if (const char* env = std::getenv("SLPX_SN_BALANCE")) lopt.balance_supernode_cuts = env[0] != '0';
   if (const char* env = std::getenv("SLPX_HOSTCHECK_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
   if (const char* env = std::getenv("SLPX_LDLT_MF"))
     if (env[0] != '0') {
       lopt.multifrontal = true;
       if (std::getenv("SLPX_SN_MIN_WIDTH") == nullptr) lopt.min_supernode_width = 2;
       lopt.relax_zeros = 8;
+      if (std::getenv("SLPX_SN_BALANCE") == nullptr) lopt.balance_supernode_cuts = true;
     }
   if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
   if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));

@@ -70,7 +70,7 @@ def test_trajectory_tracks_oracle_at_the_start(fresh, slpx, orc, N):
     pp.close()
 
 
-@pytest.mark.parametrize("N", [100, 300, 500, 1000])
+@pytest.mark.parametrize("N", [50, 100, 300, 500, 1000])
 def test_whole_solve_status_at_baseline_horizons(fresh, slpx, orc, N):
     """whole solves of the swing-up at the BASELINE horizons, next to the oracle
     run with the same elimination order.  What can be pinned is limited by the reference algorithm
@@ -91,7 +91,13 @@ def test_whole_solve_status_at_baseline_horizons(fresh, slpx, orc, N):
     # (N=300: SUCCESS with the multifrontal step and the oracle; LOCALLY_INFEASIBLE with the pair-list step under
     # the switches of profiles/switch_matrix.sh that take the fronts away — r02's build had it the other way
     # round at N=150: which horizons get through moves with the summation order)
-    if N <= 100:
+    # (N=50, VERDICT r03 item 1d: the product needs ~25 restorations and, unperturbed, ends LOCALLY_INFEASIBLE
+    # where the oracle succeeds — but the outcome at that horizon hangs on the last bits of the input in BOTH:
+    # profiles/r04_n50_sensitivity.txt has the oracle at 7 of 8 and the product at 4 of 6 SUCCESS under
+    # 1e-13 relative perturbations of the initial guess, the two leaving each other after ~7 iterations
+    # and both entering restoration at iteration 23 — so what is asserted there is what is asserted
+    # everywhere: a clean exit of the algorithm and, on success, the swing-up)
+    if N == 100:
         assert status == so == 0
     if status == 0:
         # a KKT point of the problem: the swing-up is reached (cart_pole_problem_test.cpp:87-124)

@@ -576,6 +576,8 @@ class DeviceNlp {
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
+  bool m_il_single = false;          // interleaved factorization / backward solve: every round in one launch (small batches)
+  DevBuf<unsigned int> m_il_round_cnt;  // [groups][rounds] for the factorization, then [chunks][rounds] for the backward solve
   bool m_il_fronts = false;          // batch-interleaved factorization by fronts (ldlt_mfq_factor_kernel)
   uint32_t m_mfq_lds = 0;
   bool m_fwd_single = true;  // SLPX_FWD_SINGLE=0: the forward substitution of a new right-hand side one launch per round

@@ -749,6 +749,17 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_zv_il.alloc(C * l.n * W);
     m_xg_il.alloc(C * l.n * W);
     m_stats_part.alloc(l.tasks.size() * B);
+    // every round of the factorization / the backward solve in one launch: batches of up to SLPX_IL_SINGLE_MAX
+    // problems (default 0: never) — beyond that the later rounds' workgroups would sit on CUs waiting while the
+    // first round's are still queueing (r02 measured that for the per-task kernels at 512 problems)
+    {
+      // (measured, profiles/r04_il_single_probe.txt: 64 x N=500 224 k steps/s in one launch against 232 k with a launch per
+      // round, 128 x N=500 396 k against 403 k — the rounds' latency is inside them, not between them: off by default)
+      int single_max = 0;
+      if (const char* env = std::getenv("SLPX_IL_SINGLE_MAX")) single_max = std::atoi(env);
+      m_il_single = static_cast<int>(B) <= single_max;
+      m_il_round_cnt.upload(std::vector<unsigned int>((kIlRowsPerChunk + 1) * C * static_cast<size_t>(std::max(1, l.n_rounds)), 0u));
+    }
     for (auto* buf : {&m_Lx_il, &m_D_il, &m_zv_il, &m_xg_il, &m_contrib_il, &m_scontrib_il}) buf->zero();
     // per task: the plan slices the factor kernel keeps in LDS, packed back to back
     // [n_cref, n_words | pairs (2 words each) | pair ptr | src | out |
@@ -1865,11 +1876,19 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                            l.round_ptr[r], q);
       }
     }
-    for (int r = 0; r < l.n_rounds && !m_il_fronts; ++r) {
+    if (!m_il_fronts && m_il_single) {
+      // a small batch: every round in ONE launch, round-major (ldlt_factor_il_kernel)
+      const uint32_t groups = static_cast<uint32_t>(kIlRowsPerChunk * C);
+      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(static_cast<uint32_t>(l.tasks.size()) * groups), dim3(kIlFactorThreads),
+                         m_il_factor_lds, stream, m_ldev, 0u, m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
+                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p, m_il_round_cnt.p, groups);
+    }
+    for (int r = 0; r < l.n_rounds && !m_il_fronts && !m_il_single; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
                          l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
-                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p);
+                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p,
+                         static_cast<unsigned int*>(nullptr), 0u);
     }
     hipLaunchKernelGGL(ldlt_stats_il_kernel, dim3(m_batch), dim3(64), 0, stream, m_stats_part.p,
                        static_cast<int>(l.tasks.size()), reg, cur, m_batch);
@@ -2136,10 +2155,18 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   if (m_il) {
     const int C = (m_batch + 63) / 64;
+    if (m_il_single) {
+      hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(static_cast<uint32_t>(l.tasks.size()) * static_cast<uint32_t>(C)),
+                         dim3(kIlLanes * kIlBwdWaves), m_il_solve_lds, m_stream, m_ldev, 0u, l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p,
+                         m_p.p, m_batch, m_il_round_cnt.p + static_cast<size_t>(kIlRowsPerChunk) * C * l.n_rounds, static_cast<uint32_t>(C));
+      SLPX_HIP_CHECK(hipGetLastError());
+      return;
+    }
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes * kIlBwdWaves), m_il_solve_lds, m_stream, m_ldev,
-                         l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch);
+                         l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch,
+                         static_cast<unsigned int*>(nullptr), 0u);
     }
     SLPX_HIP_CHECK(hipGetLastError());
     return;

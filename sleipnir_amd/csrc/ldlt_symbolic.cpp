@@ -474,6 +474,24 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   // may have any number of other children: they just have to sit in lower levels.
   std::vector<int32_t> sn_of(n, -1), sn_pos(n, 0);
   std::vector<std::vector<int32_t>> sn_cols;
+  // A column joins its parent's chain only from the DEEPEST side (opt.chain_from_deepest_child): a chain is one
+  // front, scheduled after every child subtree of all its columns — a child k whose sibling subtree is as deep
+  // as its own would otherwise put its pivots on the critical path behind that sibling, where alone it runs a
+  // level earlier, beside it (seen at the ends of a dissected transcription: two separators of the same
+  // structure in one front of 9, 1.4 us of the round's 6).  From round chain_from_deepest_min_round up: in the
+  // leaf tasks, whose levels are full of fronts anyway, more and smaller fronts only cost tables and arena
+  // (cart-pole N=5000 no longer fit two workgroups per CU).  depth = columns on the longest path of the
+  // elimination tree below and including a column, inside its task.
+  std::vector<int32_t> col_depth(n, 1);
+  for (int j = 0; j < n; ++j)
+    for (int32_t c : children[j])
+      if (task_of[c] == task_of[j]) col_depth[j] = std::max(col_depth[j], col_depth[c] + 1);
+  auto joins_from_deepest_side = [&](int32_t k, int32_t p) {
+    if (!opt.chain_from_deepest_child || round_of[p] < opt.chain_from_deepest_min_round) return true;
+    for (int32_t c : children[p])
+      if (c != k && task_of[c] == task_of[p] && col_depth[c] >= col_depth[k]) return false;
+    return true;
+  };
   for (int j = 0; j < n; ++j) {
     if (sn_of[j] >= 0 || sn_of[j] == -2) continue;
     std::vector<int32_t> chain{j};
@@ -488,7 +506,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       for (int32_t q = j;;) {
         const int32_t p = P.parent[q];
         if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[q].size() != Lcol[p].size() + 1 ||
-            len + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
+            len + 1 + Lcol[p].size() + 1 > opt.max_front_rows || !joins_from_deepest_side(q, p))
           break;
         ++len;
         q = p;
@@ -500,7 +518,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       const int32_t p = P.parent[k];
       // rows of the trapezoid after adding p: chain + struct(L_p) + rhs row
       if (p < 0 || task_of[p] != task_of[j] || sn_of[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
-          chain.size() + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
+          chain.size() + 1 + Lcol[p].size() + 1 > opt.max_front_rows || !joins_from_deepest_side(k, p))
         break;
       sn_of[p] = sn_of[j];
       sn_pos[p] = static_cast<int32_t>(chain.size());

@@ -218,7 +218,9 @@ struct LdltOptions {
   // registers, wider plans are for the host interpreter's what-if statistics only
   uint32_t max_supernode_width = kSnWidthMax;
   uint32_t max_front_rows = kSnRowsMax;  // rows of a front (w + |R| + 1): the batch kernel with four lanes per problem holds 20
-  bool balance_supernode_cuts = false;  // chains longer than that in pieces of equal width (multifrontal plans)
+  bool balance_supernode_cuts = false;
+  bool chain_from_deepest_child = false;  // a column joins its parent's supernode only if no sibling subtree is as deep as its own
+  int chain_from_deepest_min_round = 1;   // ... in tasks of this round and later  // chains longer than that in pieces of equal width (multifrontal plans)
   // Hubs (nodes adjacent to a large part of the graph: a timestep shared by every stage, the
   // dense border of an arrow matrix) are set aside and eliminated last, like the "dense rows" of
   // the sparse orderings: degree > max(hub_floor, hub_factor x median degree).  build_ldlt_plan

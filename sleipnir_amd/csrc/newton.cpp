@@ -70,10 +70,16 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
         lopt.min_supernode_width = 2;
         lopt.relax_zeros = 8;
         lopt.balance_supernode_cuts = true;
+        lopt.chain_from_deepest_child = true;
+        lopt.chain_from_deepest_min_round = 0;
       }
     }
     if (const char* env = std::getenv("SLPX_SN_MAX_WIDTH")) lopt.max_supernode_width = std::clamp<uint32_t>(static_cast<uint32_t>(std::atoi(env)), 1u, kSnWidthMax);
     if (const char* env = std::getenv("SLPX_SN_BALANCE")) lopt.balance_supernode_cuts = env[0] != '0';
+    if (const char* env = std::getenv("SLPX_SN_DEEPEST")) {  // 0: off, 1: every task, 2: from round 1 up (default)
+    lopt.chain_from_deepest_child = env[0] != '0';
+    lopt.chain_from_deepest_min_round = env[0] == '1' ? 0 : 1;
+  }
     if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
     if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
@@ -97,9 +103,16 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // and usually has a round more than necessary; twice the task size fixes both (cart-pole
     // N=5000: 547 tasks / 4 rounds -> 265 / 3, factorization 73 -> 62 us, backward solve 42 -> 38;
     // at N=1000 the 137 tasks of the default are the better choice: 39 vs 45 us).
-    if (opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
-        std::getenv("SLPX_TASK_ENTRIES") == nullptr) {
-      lopt.task_entries *= 2;
+    // (more than ~250 tasks take two workgroups per CU, 80 KB of LDS each: there the chains-from-the-deepest-
+    // child rule stays out of the leaf tasks, where it only adds fronts — tables, arena — to full levels:
+    // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
+    const bool deepest_everywhere = lopt.chain_from_deepest_child && lopt.chain_from_deepest_min_round == 0 &&
+                                    std::getenv("SLPX_SN_DEEPEST") == nullptr;
+    const bool double_tasks = opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
+                              std::getenv("SLPX_TASK_ENTRIES") == nullptr;
+    if (double_tasks || (deepest_everywhere && m_l.tasks.size() > 250)) {
+      if (double_tasks) lopt.task_entries *= 2;
+      if (deepest_everywhere) lopt.chain_from_deepest_min_round = 1;
       m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
     }
   };

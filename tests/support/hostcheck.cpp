@@ -138,6 +138,10 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
   if (const char* env = std::getenv("SLPX_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
   if (const char* env = std::getenv("SLPX_SN_BALANCE")) lopt.balance_supernode_cuts = env[0] != '0';
+  if (const char* env = std::getenv("SLPX_SN_DEEPEST")) {  // 0: off, 1: every task, 2: from round 1 up (default)
+    lopt.chain_from_deepest_child = env[0] != '0';
+    lopt.chain_from_deepest_min_round = env[0] == '1' ? 0 : 1;
+  }
   if (const char* env = std::getenv("SLPX_HOSTCHECK_SN_MAX_WIDTH")) lopt.max_supernode_width = static_cast<uint32_t>(std::atoi(env));
   if (const char* env = std::getenv("SLPX_LDLT_MF"))
     if (env[0] != '0') {
@@ -145,6 +149,10 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
       if (std::getenv("SLPX_SN_MIN_WIDTH") == nullptr) lopt.min_supernode_width = 2;
       lopt.relax_zeros = 8;
       if (std::getenv("SLPX_SN_BALANCE") == nullptr) lopt.balance_supernode_cuts = true;
+      if (std::getenv("SLPX_SN_DEEPEST") == nullptr) {
+        lopt.chain_from_deepest_child = true;
+        lopt.chain_from_deepest_min_round = 0;
+      }
     }
   if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
   if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));

@@ -71,3 +71,14 @@ bash profiles/chain_ab.sh > $N/${TAG}_chain_ab.txt 2>&1
 [ -x profiles/microbench/anyorder_bin ] && ./profiles/microbench/anyorder_bin > $N/${TAG}_microbench_anyorder.txt 2>&1
 bash profiles/b64_probe.sh > $N/${TAG}_b64_probe.txt 2>&1
 tail -5 $O/collect.log
+# 8. (r04) the parity record of the timed kernels, the interior-point iteration: A/B of the look-ahead chain and
+#    kernel stats + launch timeline of whole solves, the supernode-chain rules, the batch experiments, N=50
+PYTHONPATH=$R timeout 900 python profiles/parity_errors.py > $N/${TAG}_parity_errors.txt 2>&1
+bash profiles/solve_ab.sh > $N/${TAG}_solve_ab.txt 2>&1
+bash profiles/solve_kernel_stats.sh 500 $O/solve_prof > /dev/null 2>&1
+cp $O/solve_prof/solve500_kernel_stats.csv $N/${TAG}_solve500_kernel_stats.csv
+cp $O/solve_prof/solve500_timeline.txt $N/${TAG}_solve500_timeline.txt
+bash profiles/sn_deepest_ab.sh > $N/${TAG}_sn_deepest_ab.txt 2>&1
+bash profiles/sn_width_ab.sh > $N/${TAG}_sn_width_ab.txt 2>&1
+PYTHONPATH=$R timeout 300 python profiles/product_sensitivity.py 50 > $N/${TAG}_product_sensitivity_N50.txt 2>&1
+tail -3 $N/${TAG}_parity_errors.txt

@@ -400,6 +400,8 @@ enum {
    IPM_MIN}
 }  // namespace ipm_err
 
+static_assert(sizeof(IpmErrOut) == 24 * sizeof(double), "ipm_error_fold writes IpmErrOut as 24 doubles");
+
 struct IpmErrFinish {
   int n_err_blocks = 0;   // 0: two launches (partials, then ipm_error_final_kernel)
   int n_total_blocks = 0; // error workgroups + one per separable sum
@@ -455,33 +457,18 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
     tot[qq] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    out->dual_inf_u = tot[DUAL_U];
-    out->sz_max_u = tot[SZ_MAX_U];
-    out->ce_inf_u = tot[CE_U];
-    out->cis_inf_u = tot[CIS_U];
-    out->y1_u = tot[Y1_U];
-    out->z1_u = tot[Z1_U];
-    out->dual_inf = tot[DUAL];
-    out->sz_min = K.m_i ? tot[SZ_MIN] : 0.0;
-    out->sz_max = tot[SZ_MAX];
-    out->ce_inf = tot[CE];
-    out->cis_inf = tot[CIS];
-    out->y1 = tot[Y1];
-    out->z1 = tot[Z1];
-    const double f = coherent_load(&V[K.off_f], in_launch);
-    out->f = f;
-    out->viol = tot[VIOL];
-    out->logsum = tot[LOGSUM];
-    out->aetce_sq = tot[AETCE];
-    out->ce_sq = tot[CESQ];
-    out->aitcp_sq = tot[AITCP];
-    out->cp_sq = tot[CPSQ];
-    out->x_inf = tot[XINF];
-    out->s_inf = tot[SINF];
-    out->finite = (tot[FINITE] != 0.0 && isfinite(f)) ? 1.0 : 0.0;
-    out->ci_all_pos = tot[CIPOS];
-    ipm_publish(seq_dev, seq_host);
+  // the 24 doubles of IpmErrOut by 24 lanes of the first wave (one burst towards the host instead of 24 stores of
+  // one lane), then the wave's system-scope fence and the sequence number
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    if (k < 24) {
+      const double f = coherent_load(&V[K.off_f], in_launch);
+      double v = k < 13 ? tot[k] : (k == 13 ? f : tot[k - 1]);  // (IpmErrOut: f sits between z1 and viol)
+      if (k == SZ_MIN) v = K.m_i ? v : 0.0;
+      if (k == FINITE + 1) v = (v != 0.0 && isfinite(f)) ? 1.0 : 0.0;
+      reinterpret_cast<double*>(out)[k] = v;
+    }
+    if (k == 0) ipm_publish(seq_dev, seq_host);
   }
 }
 
@@ -630,10 +617,28 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
   ipm_error_accumulate(K, V, nV, x, s, y, z, scales, check_all_V, blockIdx.x * kIpmErrThreads + threadIdx.x,
                        n_blocks * kIpmErrThreads, acc);
-  block_reduce<NQ, kIpmErrThreads>(acc, ops, scratch);
-  if (threadIdx.x == 0) {
+  // the workgroup's partial of every quantity: the lanes' values through LDS, transposed — thread (q, sub) folds
+  // 32 of the 256 values of quantity q in a fixed order, the eight subs by DPP; 23 wave reductions by butterfly
+  // were ~700 instructions per wave
+  {
+    constexpr int kPad = kIpmErrThreads + 1;
+    __shared__ double tr[NQ * kPad];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) coherent_store(&partial[blockIdx.x * NQ + q], acc[q], fin.n_err_blocks != 0);
+    for (int q = 0; q < NQ; ++q) tr[q * kPad + threadIdx.x] = acc[q];
+    __syncthreads();
+    const int q = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    if (q < NQ) {
+      int op = ops[0];
+#pragma unroll
+      for (int k = 1; k < NQ; ++k)
+        if (q == k) op = ops[k];
+      double v = tr[q * kPad + sub];
+      for (int k = sub + 8; k < kIpmErrThreads; k += 8) v = ipm_combine(op, v, tr[q * kPad + k]);
+      v = ipm_combine(op, v, ipm_dpp<0xB1>(v));
+      v = ipm_combine(op, v, ipm_dpp<0x4E>(v));
+      v = ipm_combine(op, v, ipm_dpp<0x141>(v));
+      if (sub == 0) coherent_store(&partial[blockIdx.x * NQ + q], v, fin.n_err_blocks != 0);
+    }
   }
   if (fin.n_err_blocks != 0) ipm_error_finish(K, V, partial, fin);
 }

@@ -1,5 +1,7 @@
 #include "ldlt_symbolic.hpp"
 
+#include "setup_timing.hpp"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -236,6 +238,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   for (int i = 0; i < n; ++i)
     has_diag[i] = diag_has_source ? (*diag_has_source)[i] : static_cast<uint8_t>(i < n_dec);
 
+  SetupLap lap;
   // ---- ordering -------------------------------------------------------------
   bool ordering_forced = false;
   if (user_perm != nullptr && !user_perm->empty()) {
@@ -279,6 +282,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   for (int k = 0; k < n; ++k)
     if (P.iperm[k] < 0) throw std::runtime_error("ldlt: permutation is not a bijection");
 
+  lap("  ldlt: ordering (nested dissection)");
   // ---- permuted A: per column, strictly-lower rows with their lhs source ------
   std::vector<std::vector<std::pair<int32_t, int32_t>>> Acol(n);  // (row, src)
   std::vector<int32_t> diag_src(n, -1);
@@ -319,6 +323,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   std::vector<uint8_t> diag_updated_exact(n, 0);
   for (int k = 0; k < n; ++k)
     for (int32_t r : Lcol[k]) diag_updated_exact[r] = 1;
+  lap("  ldlt: pattern of L, elimination tree");
   // ---- relaxed supernodes (LdltOptions::relax_zeros) -------------------------------------------------
   int relaxed_merges = 0;
   int64_t relaxed_zeros = 0;
@@ -397,6 +402,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     }
   }
 
+  lap("  ldlt: relaxed supernodes");
   // ---- tasks: subtrees that fit in LDS, grouped in rounds -------------------------
   const uint32_t cap = opt.task_entries;
   std::vector<int32_t> task_of(n, -1);
@@ -468,6 +474,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   std::vector<int32_t> tlevel(n, 0), lcol(n, -1);
   for (int t = 0; t < ntasks; ++t)
     for (int32_t j : tcols[t].cols) task_of[j] = t;
+  lap("  ldlt: tasks and rounds");
   // ---- supernodes: chains of the etree inside one task whose columns share their structure ----
   // (|struct(L_j)| = |struct(L_parent)| + 1 makes the two structures equal up to the parent
   // itself, since struct(L_j) \ {parent} is always contained in struct(L_parent).)  A column
@@ -572,6 +579,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     for (size_t i = 0; i < cols.size(); ++i) lcol[cols[i]] = static_cast<int32_t>(i);
   }
 
+  lap("  ldlt: supernodes, levels");
   // ---- entries ---------------------------------------------------------------------
   // local entry index of the diagonal of column j and of each L position.
   //
@@ -651,6 +659,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     }
   }
 
+  lap("  ldlt: entries, pair lists");
   // ---- solve lists ---------------------------------------------------------------
   // rows of L (CSR view): for row i the entries (i,k), k ascending
   std::vector<std::vector<std::pair<uint32_t, int32_t>>> Lrow(n);  // (lpos, k)
@@ -700,6 +709,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   }
 
   size_t n_real_pairs = 0;
+  lap("  ldlt: solve lists");
   // ---- flatten, tasks sorted by round ------------------------------------------------
   std::vector<int> torder(ntasks);
   std::iota(torder.begin(), torder.end(), 0);
@@ -873,6 +883,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     P.tasks.push_back(T);
   }
 
+  lap("  ldlt: flattened plan arrays");
   // ---- multifrontal plan (LdltFront, ldlt_symbolic.hpp) -------------------------------------------
   // The fronts are an optional accelerator: whatever keeps them from being built — a limit (16-bit reach,
   // children per entry) or a structural corner case its consistency checks trip over (MfRefused) — leaves
@@ -1254,6 +1265,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     P.mf_fronts.assign(16, LdltFront{});
   }
 
+  lap("  ldlt: fronts and their tables");
   // structural zero pivots of the unregularized matrix: a diagonal of the (2,2)
   // block (no lhs source other than the forced 0) that no earlier column updates
   for (int j = 0; j < n; ++j)

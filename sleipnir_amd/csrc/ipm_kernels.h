@@ -158,34 +158,92 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
   if (wrong) return;
   const double mu = mu_dev[0];
   double acc[3] = {1.0, 1.0, 0.0};  // alpha_max, alpha_z, D_phi
-  for (int r = tid; r < K.m_i; r += kIpmThreads) {
-    const double sr = s[r], psr = ps[r], zr = z[r], pzr = pz[r];
-    if (psr < 0.0) acc[0] = fmin(acc[0], -tau / psr * sr);
-    if (pzr < 0.0) acc[1] = fmin(acc[1], -tau / pzr * zr);
-    acc[2] -= mu * ((1.0 / sr) * psr);
-  }
-  for (int j = tid; j < K.n; j += kIpmThreads) {
-    const int gs = K.g_src[j];
-    if (gs >= 0) acc[2] += V[gs] * p[j];
-  }
-  const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
-  block_reduce<3, kIpmThreads>(acc, ops, scratch);
-  const double alpha = acc[0], alpha_z = acc[1];
-  for (int j = tid; j < K.n; j += kIpmThreads) in_t[j] = in[j] + alpha * p[j];
-  for (int r = tid; r < K.m_e; r += kIpmThreads) {
-    const double v = y[r] + alpha_z * (-p[K.n + r]);
-    y_t[r] = v;
-    in_t[K.n + r] = v;
-  }
-  for (int r = tid; r < K.m_i; r += kIpmThreads) {
-    const double sn = s[r] + alpha * ps[r];
-    double zn = z[r] + alpha_z * pz[r];
-    constexpr double kappa = 1e10;
-    const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
-    zn = zn < lo ? lo : (zn > hi ? hi : zn);
-    s_t[r] = sn;
-    z_t[r] = zn;
-    in_t[K.n + K.m_e + r] = zn;
+  // Systems of up to kPre x 1024 rows (every BASELINE horizon): EVERYTHING the kernel reads is requested before the
+  // reduction — the iterate and the direction for the second pass too — so that the launch is two trips to memory
+  // (g's sources, then the values) instead of four; a trip after a kernel boundary is ~1 us.
+  constexpr int kPre = 5;
+  if (K.n <= kPre * kIpmThreads && K.m_e <= kPre * kIpmThreads && K.m_i <= kPre * kIpmThreads) {
+    double xs[kPre], px[kPre], ys[kPre], py[kPre], ss[kPre], pss[kPre], zs[kPre], pzs[kPre], gv[kPre];
+    int gs[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int j = tid + k * kIpmThreads;
+      gs[k] = j < K.n ? K.g_src[j] : -1;
+      xs[k] = j < K.n ? in[j] : 0.0;
+      px[k] = j < K.n ? p[j] : 0.0;
+      ys[k] = j < K.m_e ? y[j] : 0.0;
+      py[k] = j < K.m_e ? p[K.n + j] : 0.0;
+      ss[k] = j < K.m_i ? s[j] : 1.0;
+      pss[k] = j < K.m_i ? ps[j] : 0.0;
+      zs[k] = j < K.m_i ? z[j] : 1.0;
+      pzs[k] = j < K.m_i ? pz[j] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) gv[k] = gs[k] >= 0 ? V[gs[k]] : 0.0;
+    // (the same order of accumulation as the loops below: rows r = tid, tid + 1024, ...; then the columns)
+#pragma unroll
+    for (int k = 0; k < kPre; ++k)
+      if (tid + k * kIpmThreads < K.m_i) {
+        if (pss[k] < 0.0) acc[0] = fmin(acc[0], -tau / pss[k] * ss[k]);
+        if (pzs[k] < 0.0) acc[1] = fmin(acc[1], -tau / pzs[k] * zs[k]);
+        acc[2] -= mu * ((1.0 / ss[k]) * pss[k]);
+      }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k)
+      if (gs[k] >= 0) acc[2] += gv[k] * px[k];
+    const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
+    block_reduce<3, kIpmThreads>(acc, ops, scratch);
+    const double alpha = acc[0], alpha_z = acc[1];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int j = tid + k * kIpmThreads;
+      if (j < K.n) in_t[j] = xs[k] + alpha * px[k];
+      if (j < K.m_e) {
+        const double v = ys[k] + alpha_z * (-py[k]);
+        y_t[j] = v;
+        in_t[K.n + j] = v;
+      }
+      if (j < K.m_i) {
+        const double sn = ss[k] + alpha * pss[k];
+        double zn = zs[k] + alpha_z * pzs[k];
+        constexpr double kappa = 1e10;
+        const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
+        zn = zn < lo ? lo : (zn > hi ? hi : zn);
+        s_t[j] = sn;
+        z_t[j] = zn;
+        in_t[K.n + K.m_e + j] = zn;
+      }
+    }
+  } else {
+    for (int r = tid; r < K.m_i; r += kIpmThreads) {
+      const double sr = s[r], psr = ps[r], zr = z[r], pzr = pz[r];
+      if (psr < 0.0) acc[0] = fmin(acc[0], -tau / psr * sr);
+      if (pzr < 0.0) acc[1] = fmin(acc[1], -tau / pzr * zr);
+      acc[2] -= mu * ((1.0 / sr) * psr);
+    }
+    for (int j = tid; j < K.n; j += kIpmThreads) {
+      const int gs = K.g_src[j];
+      if (gs >= 0) acc[2] += V[gs] * p[j];
+    }
+    const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
+    block_reduce<3, kIpmThreads>(acc, ops, scratch);
+    const double alpha = acc[0], alpha_z = acc[1];
+    for (int j = tid; j < K.n; j += kIpmThreads) in_t[j] = in[j] + alpha * p[j];
+    for (int r = tid; r < K.m_e; r += kIpmThreads) {
+      const double v = y[r] + alpha_z * (-p[K.n + r]);
+      y_t[r] = v;
+      in_t[K.n + r] = v;
+    }
+    for (int r = tid; r < K.m_i; r += kIpmThreads) {
+      const double sn = s[r] + alpha * ps[r];
+      double zn = z[r] + alpha_z * pz[r];
+      constexpr double kappa = 1e10;
+      const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
+      zn = zn < lo ? lo : (zn > hi ? hi : zn);
+      s_t[r] = sn;
+      z_t[r] = zn;
+      in_t[K.n + K.m_e + r] = zn;
+    }
   }
   if (tid == 0) {
     alpha_dev[0] = acc[0];
@@ -632,8 +690,19 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
 #pragma unroll
       for (int k = 1; k < NQ; ++k)
         if (q == k) op = ops[k];
-      double v = tr[q * kPad + sub];
-      for (int k = sub + 8; k < kIpmErrThreads; k += 8) v = ipm_combine(op, v, tr[q * kPad + k]);
+      // (all 32 values requested at once, and the three kinds of fold side by side — the kind is picked once at the
+      // end: as a loop of 31 load-select-combine steps this was 3.3 us of the launch's 14)
+      double x[kIpmErrThreads / 8];
+#pragma unroll
+      for (int k = 0; k < kIpmErrThreads / 8; ++k) x[k] = tr[q * kPad + sub + 8 * k];
+      double vs = x[0], vmax = x[0], vmin = x[0];
+#pragma unroll
+      for (int k = 1; k < kIpmErrThreads / 8; ++k) {
+        vs += x[k];
+        vmax = fmax(vmax, x[k]);
+        vmin = fmin(vmin, x[k]);
+      }
+      double v = op == IPM_SUM ? vs : (op == IPM_MAX ? vmax : vmin);
       v = ipm_combine(op, v, ipm_dpp<0xB1>(v));
       v = ipm_combine(op, v, ipm_dpp<0x4E>(v));
       v = ipm_combine(op, v, ipm_dpp<0x141>(v));

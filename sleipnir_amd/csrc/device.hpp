@@ -88,6 +88,7 @@ struct TapeDevice {
   DevBuf<uint32_t> tmpl_table[2];
   uint32_t tmpl_blocks[2] = {0, 0};
   uint32_t n_templated_tasks = 0;
+  bool tmpl_wide_for_chain = false;  // 256-thread workgroups only because the sweep runs beside the step kernel (tape_jit.cpp)
   double jit_seconds = 0.0;
   void upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inputs, int chain_mode = 0);
   TapeDev view() const;

@@ -463,6 +463,7 @@ void TapeDevice::upload(const TapeProgram& p, int batch, uint32_t n_unscaled_inp
   };
   std::vector<uint32_t> small_rest = interpreted(p.small_tasks), large_rest = interpreted(p.large_tasks);
   uint32_t ride_lds = p.small_lds_bytes;
+  tmpl_wide_for_chain = n_bodies && tmpl_threads == 256 && large_rest.empty() && chain_mode != 0;
   if (n_bodies && tmpl_threads == 256) {
     // (tape_jit.cpp: the generated kernel's workgroups are 256 threads: every interpreted task rides in its launch)
     small_rest.insert(small_rest.end(), large_rest.begin(), large_rest.end());
@@ -997,7 +998,7 @@ void DeviceNlp::sweep_full_for_step() {
   // multifrontal kernel, and no graph is being captured
   // (and its workgroups are single waves: g-fold's sweep, 256-thread workgroups interpreting its packs of
   // rows, shares the chip badly with the step kernel — 13.3 k steps/s chained against 13.6 k)
-  const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0 && t.tmpl_threads == 64;
+  const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0 && (t.tmpl_threads == 64 || t.tmpl_wide_for_chain);
   if (!m_chain_on || !one_kernel || !m_mf || m_batch != 1 || m_capturing || xg_other() == nullptr || !m_fuse_solve) {
     sweep_full(/*with_reduce=*/false);
     return;

@@ -85,7 +85,7 @@ def test_supernodal_levels(fresh, slpx, orc, hostcheck):
 
 @pytest.mark.parametrize("width,levels_cp,levels_gf", [(16, 18, 29), (32, 18, 24)])
 def test_wider_supernodes_what_if(fresh, slpx, orc, hostcheck, monkeypatch, width, levels_cp, levels_gf):
-    """DESIGN.md §4 (MFMA panels: measured, not built): what cutting chains at 16 / 32 columns
+    """DESIGN.md §4 (MFMA update blocks: built in r03 — ldlt_mf_kernels.h: mf_update_mfma — and tested in the GPU tier): what cutting chains at 16 / 32 columns
     instead of the kernels' 8 would do to the critical path — the plans are valid (the host
     interpreter reproduces the oracle's step with them), the device kernels do not take them."""
     from tests.support import gfold, model

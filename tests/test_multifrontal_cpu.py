@@ -101,3 +101,40 @@ def test_gfold_fronts_reach_the_matrix_cores(fresh, hostcheck, mf, monkeypatch):
     g = gfold.build(mp, 40)
     plan = hostcheck.HostCheck(g.p).mf_plan()
     assert plan["built"] and plan["mfma_fronts"] > 0 and plan["widest"] >= 4
+
+
+@pytest.mark.parametrize("env", [{"SLPX_SN_DEEPEST": "0"}, {"SLPX_SN_DEEPEST": "1"}, {"SLPX_SN_DEEPEST": "2"},
+                                 {"SLPX_SN_BALANCE": "0"}, {"SLPX_SN_MAX_WIDTH": "5"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_supernode_chain_rules_keep_the_step(fresh, slpx, orc, hostcheck, mf, monkeypatch, env):
+    """r04's rules for which columns form a supernode (LdltOptions::chain_from_deepest_child: a column joins its
+    parent's chain only if no sibling subtree is as deep as its own; balance_supernode_cuts: over-long chains in
+    equal pieces; max_supernode_width) change the fronts, never the step: every variant against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pp, op = cases.build_pair("cart_pole", 120, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    plan = hc.mf_plan()
+    assert plan["built"] and plan["widest"] <= int(env.get("SLPX_SN_MAX_WIDTH", 8))
+    parity.check_newton_step(hc, op, "interior")
+
+
+def test_chains_from_the_deepest_child_shorten_the_longest_pivot_chain(fresh, slpx, orc, hostcheck, mf, monkeypatch):
+    """What the rule is for: a separator merged into a parent whose other child subtree is as deep puts its pivots
+    behind that sibling.  With the rule the fronts are more and narrower (a 9-column chain at the end of the
+    dissected stages is no longer one 8 + 1); levels may differ by one either way — what shrinks is the longest run
+    of pivots, which a level count does not see (DESIGN.md section 4a has the kernel times)."""
+    def plan_with(deepest):
+        monkeypatch.setenv("SLPX_SN_DEEPEST", deepest)
+        slpx.lib().slpx_graph_reset()
+        orc.lib().orc_reset()
+        pp, _ = cases.build_pair("cart_pole", 500, slpx, orc)
+        hc = hostcheck.HostCheck(pp)
+        return hc.mf_plan(), hc.supernode_plan()
+
+    off, sn_off = plan_with("0")
+    on, sn_on = plan_with("1")
+    assert on["fronts"] > off["fronts"]
+    assert abs(sn_on["critical_levels"] - sn_off["critical_levels"]) <= 1
+    wide = lambda sn: sum(c for w, c in sn["width_hist"].items() if w >= 7)
+    assert wide(sn_on) < wide(sn_off)

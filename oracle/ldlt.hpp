@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
 #include <set>
@@ -346,6 +348,14 @@ class RegularizedLDLT {
   // sparse_regularized_ldlt.hpp:64-152 (dense_regularized_ldlt.hpp:59-136 is the
   // same loop over the dense solver)
   RegularizedLDLT& compute(const CSC& lhs) {
+    compute_policy(lhs);
+    // ORC_TRACE_FACTORIZATIONS=1: attempts per call and the regularization taken, one line each (how often
+    // a step needs a second attempt is what the product's twin attempt is sized on)
+    static const bool trace = std::getenv("ORC_TRACE_FACTORIZATIONS") != nullptr;
+    if (trace) std::fprintf(stderr, "orc attempts %d delta %.3e gamma %.3e\n", m_factorizations, m_prev_delta, m_prev_gamma);
+    return *this;
+  }
+  void compute_policy(const CSC& lhs) {
     m_factorizations = 0;
     // lhs + regularization(0, 0): forces the full diagonal into the pattern (:67)
     CSC unreg = add(lhs, regularization(0.0, 0.0));
@@ -358,7 +368,7 @@ class RegularizedLDLT {
       if (Inertia(D) == ideal && far) {  // :82-87
         m_prev_delta = 0.0;
         m_prev_gamma = 0.0;
-        return *this;
+        return;
       }
     }
     double delta = m_prev_delta == 0.0
@@ -372,7 +382,7 @@ class RegularizedLDLT {
         if (inertia == ideal) {
           m_prev_delta = delta;
           m_prev_gamma = gamma;
-          return *this;
+          return;
         } else if (inertia.zero > 0) {
           if (gamma == 0.0) {
             gamma = 1e-10;
@@ -393,7 +403,7 @@ class RegularizedLDLT {
         m_info = NumericalIssue;
         m_prev_delta = delta;
         m_prev_gamma = gamma;
-        return *this;
+        return;
       }
     }
   }

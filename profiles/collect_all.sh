@@ -69,6 +69,7 @@ rm -rf $O/pmc_mfma
 # 7. the round's measured experiments that stayed behind switches, and the small-batch probe
 bash profiles/chain_ab.sh > $N/${TAG}_chain_ab.txt 2>&1
 [ -x profiles/microbench/anyorder_bin ] && ./profiles/microbench/anyorder_bin > $N/${TAG}_microbench_anyorder.txt 2>&1
+[ -x profiles/microbench/launch_gap_bin ] && ./profiles/microbench/launch_gap_bin > $N/${TAG}_microbench_launch_gap.txt 2>&1
 bash profiles/b64_probe.sh > $N/${TAG}_b64_probe.txt 2>&1
 tail -5 $O/collect.log
 # 8. (r04) the parity record of the timed kernels, the interior-point iteration: A/B of the look-ahead chain and

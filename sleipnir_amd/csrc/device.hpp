@@ -374,6 +374,14 @@ class DeviceNlp {
   void materialize_factor();                // batch-interleaved mode: refresh the batch-major L, D copies
   static bool interleaved_for(int batch);   // batches this large factor with one lane per problem
   // ... and, among those, by fronts with four lanes per problem (ldlt_mfq_kernels.h) where the plan allows it
+  // Twin attempt (ldlt_mf_twin_kernel): the policy loop's attempt (delta0, gamma0) and the one it would make
+  // next (delta1, gamma1) in ONE launch; `mode` as IpmTwin::mode.  false: not possible now (the caller makes a
+  // single attempt).  read_stats() then has the first attempt's counters, read_twin_stats() the second's;
+  // adopt_twin() makes the second attempt's factor, direction and counters the system's.
+  bool twin_available();
+  bool factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode);
+  LdltStats read_twin_stats() const { return m_h_stats[1]; }
+  void adopt_twin();
   static bool il_fronts_enabled();                 // SLPX_IL_FRONTS=1 (default off: measured slower, kernels.hip)
   static void il_fronts_options(LdltOptions& o);   // what such a plan needs: supernodes, fronts of <= 20 rows, small tasks
   static bool il_fronts_fit(const LdltPlan& l);    // every front within the rows four lanes hold, every task within a CU's LDS
@@ -538,6 +546,13 @@ class DeviceNlp {
   DevBuf<uint4> m_mf_image;        // per task: everything static it keeps in LDS, in LDS order (one copy loop)
   DevBuf<uint4> m_mf_image_desc;   // per task {first 16-byte group, groups up to the end of the KKT terms, groups of back-substitution rows, terms groups}
   DevBuf<double> m_mf_contrib;
+  // the second attempt of a twin launch: its own factor, update slots, x hand-over (a pair, alternating like
+  // m_xg / m_xg2), direction and counters (a pair, alternating like m_stats)
+  int m_twin_state = 0;  // 0: not looked at yet, 1: available, -1: not (not resident at once, SLPX_TWIN=0, ...)
+  int m_twin_mode = 0;   // of the step launch in flight (IpmTwin::mode; 0: a single attempt)
+  DevBuf<double> m_Lx_tw, m_D_tw, m_zv_tw, m_p_tw, m_ps_tw, m_pz_tw, m_mf_contrib_tw, m_xg_tw, m_xg2_tw;
+  DevBuf<LdltStats> m_stats_tw;
+  int m_stats_tw_cur = 0, m_xg_tw_parity = 0;
   void build_mf(const LdltPlan& l);
   // the same fronts for a batch: one launch per round (ldlt_mf_batch_kernel)
   bool m_mfb = false;
@@ -607,6 +622,7 @@ class DeviceNlp {
   struct ChainArgs {
     unsigned int* chain = nullptr;
     unsigned int wait_step = 0, this_step = 0;
+    bool skip_flag = false;  // `chain` is the look-ahead chain's "rejected attempt" flag, not a chain buffer
   };
   ChainArgs m_chain_args;             // what launch_tape hands the generated kernel (null: an ordinary launch)
   const double* m_in_override = nullptr;  // launch_tape reads / writes these when set

@@ -621,9 +621,17 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     dev.upload_duals(s.data(), y.data(), z.data());
     host_current = true;
   };
+  long twin_launches = 0, twin_taken = 0;
   auto finish = [&](ExitStatus st_) {
     sys.set_after_attempt(nullptr);
     pull_state();
+    if (std::getenv("SLPX_TWIN_VERBOSE")) {
+      const long* h = sys.twin_histogram();
+      std::fprintf(stderr, "slpx twin attempts: %ld launches held two attempts, the policy took the second of %ld (%d factorizations, %d iterations); "
+                   "first attempts of this system so far: %ld accepted, %ld / %ld with too many negative pivots and the second accepted / not, "
+                   "%ld with zero pivots, %ld with too many positive, %ld failed\n",
+                   twin_launches, twin_taken, rep.factorizations, iterations, h[0], h[1], h[2], h[3], h[4], h[5]);
+    }
     return st_;
   };
 
@@ -720,8 +728,14 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         dev.ipm_trial_metrics(-1.0, s_from_ci);
       }
     });
+    // (twin attempts, NewtonSystem::compute_twin: the look-ahead launch takes the direction of whichever of a
+    // launch's two attempts the regularization policy takes — the other after_attempt chain does not)
+    sys.set_twin_attempts(ahead);
     auto info = sys.compute(/*solve_speculatively=*/true);
+    sys.set_twin_attempts(false);
     sys.set_after_attempt(nullptr);
+    twin_launches += sys.last_twin_launches();
+    twin_taken += sys.last_twin_taken();
     dev.wait_published();  // compute() returns when the inertia counters are in; the trial chain may still run
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();

@@ -141,19 +141,42 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
 // written to a SECOND set of buffers (`in_t` = [x | y | z] as the tape reads it, s_t, y_t, z_t) instead of
 // over the current one.  The full tape and the error reductions run on those next (DeviceNlp::
 // ipm_lookahead); if the filter takes the point the buffers swap roles and nothing is recomputed.
+// the second attempt of a twin launch (ldlt_mf_twin_kernel), for the launch that takes the direction
+struct IpmTwin {
+  int mode = 0;  // 0: one attempt; 1: the policy loop's attempt and its delta x 10; 2: the unregularized attempt and the first guess
+  const double *p = nullptr, *ps = nullptr, *pz = nullptr;
+  const LdltStats* stats = nullptr;
+};
+
 __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
     KktDev K, const double* __restrict__ V, const double* __restrict__ in, const double* __restrict__ s,
     const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ p,
     const double* __restrict__ ps, const double* __restrict__ pz, const double* __restrict__ mu_dev, double tau,
     double* __restrict__ in_t, double* __restrict__ s_t, double* __restrict__ y_t, double* __restrict__ z_t,
-    double* __restrict__ alpha_dev, IpmDirOut* __restrict__ out, const LdltStats* __restrict__ stats) {
+    double* __restrict__ alpha_dev, IpmDirOut* __restrict__ out, const LdltStats* __restrict__ stats, IpmTwin tw) {
   __shared__ double scratch[17 * 3];
   const int tid = threadIdx.x;
   // The factorization this direction comes from has the wrong inertia (or failed): the policy loop will
   // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
   // (one lane-uniform 16-byte load, issued with the others below)
   const LdltStats st = stats[0];
-  const bool wrong = st.n_bad != 0 || st.n_pos != K.n || st.n_neg != K.m_e || st.n_zero != 0;
+  bool wrong = st.n_bad != 0 || st.n_pos != K.n || st.n_neg != K.m_e || st.n_zero != 0;
+  if (tw.mode != 0) {
+    // A twin attempt (ldlt_mf_twin_kernel): the policy's choice between the two, from the same counters the host
+    // reads (NewtonSystem::compute_impl — keep the two in step).  The second attempt stands for the policy's next
+    // one only if the first failed the way that leads to it: beside the unregularized attempt (mode 2) any failure
+    // does (:82-102, also a pivot below 1e-4); in the loop (mode 1) too many negative pivots, nothing else (:127-130).
+    const LdltStats st2 = tw.stats[0];
+    if (tw.mode == 2 && !wrong && __longlong_as_double(static_cast<long long>(st.min_abs_bits)) < 1e-4) wrong = true;
+    const bool leads_to_second = tw.mode == 2 || (st.n_bad == 0 && st.n_zero == 0 && st.n_neg > K.m_e);
+    const bool second_good = st2.n_bad == 0 && st2.n_pos == K.n && st2.n_neg == K.m_e && st2.n_zero == 0;
+    if (wrong && leads_to_second && second_good) {
+      wrong = false;
+      p = tw.p;
+      ps = tw.ps;
+      pz = tw.pz;
+    }
+  }
   if (tid == 0) alpha_dev[2] = wrong ? 1.0 : 0.0;
   if (wrong) return;
   const double mu = mu_dev[0];

@@ -735,7 +735,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
     m_stats.upload(zero);
   }
-  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(B) * sizeof(double)));
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(std::max<int>(B, 2)) * sizeof(double)));  // (B = 1: a twin attempt's second pair)
   if (B > 8) m_reg_dev.alloc(2 * B);
   if (m_il) {
     // batch-interleaved LDLT (ldlt_il_kernels.h): [chunk of 64 problems][index][lane]
@@ -825,7 +825,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SLPX_HIP_CHECK(hipDeviceSynchronize());
   }
-  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(B) * sizeof(LdltStats)));
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_stats), static_cast<size_t>(std::max<int>(B, 2)) * sizeof(LdltStats)));
   {
     unsigned long long* seq = nullptr;
     SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&seq), sizeof(unsigned long long)));
@@ -959,7 +959,7 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     unsigned int* chain = m_chain_args.chain;
     unsigned int wait_step = m_chain_args.wait_step, this_step = m_chain_args.this_step;
     const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
-    unsigned int n_workgroups = grid * static_cast<unsigned>(m_batch);
+    unsigned int n_workgroups = m_chain_args.skip_flag ? 0u : grid * static_cast<unsigned>(m_batch);
     void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
                     &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
@@ -1921,6 +1921,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
 void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
                        const std::vector<uint8_t>& active) {
   write_reg(delta, gamma, active);
+  m_twin_mode = 0;
   m_stats_cur ^= 1;
   m_stats_in_host = false;
   enqueue_factor(m_stats_cur, m_stream);
@@ -1937,10 +1938,115 @@ void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std
     return;
   }
   write_reg(delta, gamma, active);
+  m_twin_mode = 0;
   m_stats_cur ^= 1;
   enqueue_factor_solve(m_stats_cur);
   if (!m_capturing) m_stats_seq = ++m_seq_expected;
   m_stats_in_host = true;
+}
+
+// ---- twin attempt (ldlt_mf_twin_kernel) ----
+bool DeviceNlp::twin_available() {
+  if (m_twin_state != 0) return m_twin_state > 0 && m_mf && xg_other() != nullptr && !m_capturing;
+  m_twin_state = -1;
+  const char* env = std::getenv("SLPX_TWIN");
+  if (env != nullptr && env[0] == '0') return false;
+  if (!m_mf || m_mf_mfma || m_batch != 1 || xg_other() == nullptr || !m_fuse_solve || !m_seq_poll) return false;
+  const LdltPlan& l = m_l_ref;
+  // both attempts' workgroups resident at once (their tasks wait for each other inside the launch)
+  int cus = 0, per_cu = 0;
+  SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+  auto resident = [&](auto kernel, int threads) {
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, m_mf_lds));
+    return 2 * l.tasks.size() + m_reduces.n <= static_cast<size_t>(per_cu) * cus;
+  };
+  const bool fits = m_mf_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024>, 1024) : resident(&ldlt_mf_twin_kernel<512>, 512);
+  if (std::getenv("SLPX_LDLT_VERBOSE"))
+    std::fprintf(stderr, "ldlt twin attempt: 2 x %zu tasks, %d workgroup(s) per CU x %d CUs%s\n", l.tasks.size(), per_cu, cus,
+                 fits ? "" : ": NOT resident at once");
+  if (!fits) return false;
+  for (auto [tw, first] : {std::pair{&m_Lx_tw, &m_Lx}, {&m_D_tw, &m_D}, {&m_zv_tw, &m_zv}, {&m_p_tw, &m_p}, {&m_ps_tw, &m_ps}, {&m_pz_tw, &m_pz}}) {
+    tw->alloc(std::max<size_t>(1, first->n));
+    tw->zero();
+  }
+  m_mf_contrib_tw.upload(std::vector<double>(std::max<size_t>(1, m_mf_contrib.n), std::bit_cast<double>(kSlotEmpty)));
+  const std::vector<double> armed(static_cast<size_t>(l.n), std::bit_cast<double>(kSlotEmpty));
+  m_xg_tw.upload(armed);
+  m_xg2_tw.upload(armed);
+  m_stats_tw.upload(std::vector<LdltStats>(2, LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull}));
+  SLPX_HIP_CHECK(hipDeviceSynchronize());  // (the memsets ran on the null stream)
+  m_twin_state = 1;
+  return true;
+}
+
+bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode) {
+  if (!twin_available() || m_stream.tape_pending) return false;
+  const LdltPlan& l = m_l_ref;
+  m_h_reg[0] = delta0;
+  m_h_reg[1] = gamma0;
+  m_h_reg[2] = delta1;
+  m_h_reg[3] = gamma1;
+  m_stats_cur ^= 1;
+  m_stats_tw_cur ^= 1;
+  if (!m_kkt_pending) materialize_kkt();
+  LdltStats* cur = m_stats.p + static_cast<size_t>(m_stats_cur);
+  LdltStats* next = m_stats.p + static_cast<size_t>(m_stats_cur ^ 1);
+  KktFuse f = take_kkt_fuse();
+  BacksubFuse bf = backsub_fuse(cur);
+  MfDev md;
+  md.tasks = m_mf_tasks.p;
+  md.fronts = m_mf_fronts.p;
+  md.image = m_mf_image.p;
+  md.image_stride16 = m_mf_image_stride16;
+  md.image_desc = m_mf_image_desc.p;
+  md.n_tasks = static_cast<unsigned int>(l.tasks.size());
+  md.exit_cnt = m_exit_cnt.p;
+  MfTwin tw;
+  tw.first_end = md.n_tasks + static_cast<unsigned int>(f.n_blocks);
+  tw.reg = m_h_reg + 2;
+  tw.Lx = m_Lx_tw.p;
+  tw.D = m_D_tw.p;
+  tw.contrib = m_mf_contrib_tw.p;
+  tw.zv = m_zv_tw.p;
+  tw.xg = m_xg_tw_parity ? m_xg2_tw.p : m_xg_tw.p;
+  tw.xg_next = m_xg_tw_parity ? m_xg_tw.p : m_xg2_tw.p;
+  tw.out = m_p_tw.p;
+  tw.ps = m_ps_tw.p;
+  tw.pz = m_pz_tw.p;
+  tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur);
+  tw.stats_next = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur ^ 1);
+  const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
+  md.n_workgroups = grid.x;
+  m_last_step_chained = false;
+  auto launch = [&](auto kernel, int threads) {
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p, l.n,
+                       m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw);
+  };
+  if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
+  else launch(&ldlt_mf_twin_kernel<512>, 512);
+  xg_flip();
+  m_xg_tw_parity ^= 1;
+  SLPX_HIP_CHECK(hipGetLastError());
+  m_stats_seq = ++m_seq_expected;
+  m_stats_in_host = true;
+  m_twin_mode = mode;
+  return true;
+}
+
+void DeviceNlp::adopt_twin() {
+  // every launch takes these pointers when it is made (ipm_accept_lookahead): later solves with this factorization,
+  // the committed direction and the counters are the second attempt's
+  m_Lx.swap(m_Lx_tw);
+  m_D.swap(m_D_tw);
+  m_zv.swap(m_zv_tw);
+  m_p.swap(m_p_tw);
+  m_ps.swap(m_ps_tw);
+  m_pz.swap(m_pz_tw);
+  m_stats.swap(m_stats_tw);
+  std::swap(m_stats_cur, m_stats_tw_cur);
+  m_h_stats[0] = m_h_stats[1];
+  m_twin_mode = 0;
 }
 
 void DeviceNlp::enqueue_factor_solve(int parity) {
@@ -2359,9 +2465,17 @@ void DeviceNlp::ipm_direction(double tau) {
 }
 
 void DeviceNlp::ipm_lookahead(double tau) {
+  IpmTwin tw;  // (a twin launch in flight: the kernel takes the direction of the attempt the policy takes)
+  if (m_twin_mode != 0) {
+    tw.mode = m_twin_mode;
+    tw.p = m_p_tw.p;
+    tw.ps = m_ps_tw.p;
+    tw.pz = m_pz_tw.p;
+    tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur);
+  }
   hipLaunchKernelGGL(ipm_lookahead_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V.p, m_in.p, m_s.p, m_y.p,
                      m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_s_ahead.p, m_y_ahead.p, m_z_ahead.p,
-                     m_ipm_alpha.p, &m_ipm_host->dir, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch);
+                     m_ipm_alpha.p, &m_ipm_host->dir, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch, tw);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -2369,7 +2483,14 @@ void DeviceNlp::sweep_full_lookahead() {
   m_in_override = m_trial_in.p;
   m_V_override = m_V_trial.p;
   m_tape_reduce = false;  // the separable sums ride in ipm_errors(.., sums_ride, ahead)
+  // (the generated kernel leaves at once when the look-ahead launch flagged the attempt as rejected: `chain` with
+  // n_workgroups = 0 is that flag, tape_jit.cpp)
+  if (m_full.n_bodies && m_ipm_alpha.p != nullptr) {
+    m_chain_args = ChainArgs{reinterpret_cast<unsigned int*>(m_ipm_alpha.p + 2), 0u, 0u};
+    m_chain_args.skip_flag = true;
+  }
   launch_tape(m_full, true);
+  m_chain_args = ChainArgs{};
   m_tape_reduce = true;
   m_in_override = nullptr;
   m_V_override = nullptr;

@@ -1122,6 +1122,19 @@ __device__ __forceinline__ void publish_stats(const BacksubFuse& F, bool coheren
   }
 }
 
+// a second attempt's counters beside them (ldlt_mf_twin_kernel); before publish_stats, whose fence and sequence
+// number cover both
+__device__ __forceinline__ void publish_stats_copy(const LdltStats* stats, LdltStats* host) {
+  LdltStats st;
+  const int* src = reinterpret_cast<const int*>(stats);
+  st.n_pos = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st.n_neg = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st.n_zero = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st.n_bad = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  st.min_abs_bits = __hip_atomic_load(&stats->min_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  host[0] = st;
+}
+
 __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx, long long lx_stride,
     const double* __restrict__ zv, double* __restrict__ xg, double* __restrict__ xg_next,

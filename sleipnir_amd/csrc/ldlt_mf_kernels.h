@@ -501,22 +501,26 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
 
 // CHAINED: the variant of a chained step (DeviceNlp::sweep_full_for_step) — it waits for its sweep after
 // staging and counts its workgroups out; the other variant has none of that code.
+// `block`: the workgroup's place among [ride-along sums | tasks]; `exit_total` workgroups count themselves out
+// before the verdict is published; `twin_stats`: the counters of a second attempt made in the same launch
+// (ldlt_mf_twin_kernel), published with this one's.
 template <int THREADS, bool MFMA, bool CHAINED>
-__global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
-    LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
+__device__ __forceinline__ void mf_step_body(
+    const LdltDev& L, const MfDev& Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
-    LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
+    LdltStats* __restrict__ stats_next, double* __restrict__ zv, const KktFuse& F, double* __restrict__ xg,
+    double* __restrict__ xg_next, double* __restrict__ out, const BacksubFuse& B, uint32_t block, unsigned int exit_total,
+    const LdltStats* twin_stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
+  if (static_cast<int>(block) < F.n_blocks) {
     if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
-    ride_along_sum(F, blockIdx.x, smem_raw);
+    ride_along_sum(F, block, smem_raw);
     if constexpr (CHAINED) mf_signal_done(Mf);
     return;
   }
   const int tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
+  const uint32_t task_index = block - static_cast<uint32_t>(F.n_blocks);
 #ifdef SLPX_CHAIN_STAMPS
   if (CHAINED && Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
 #endif
@@ -719,9 +723,12 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     if (threadIdx.x == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
       const unsigned int old = __hip_atomic_fetch_add(Mf.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1 == Mf.n_tasks) {
+      if (old + 1 == exit_total) {
         __hip_atomic_store(Mf.exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (B.stats_host != nullptr) publish_stats(B, true);
+        if (B.stats_host != nullptr) {
+          if (twin_stats != nullptr) publish_stats_copy(twin_stats, B.stats_host + 1);
+          publish_stats(B, true);
+        }
       }
     }
   };
@@ -843,6 +850,64 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
   SLPX_LDLT_CLOCK(20);
   if (top) exit_and_count();
   if constexpr (CHAINED) mf_signal_done(Mf);
+}
+
+template <int THREADS, bool MFMA, bool CHAINED>
+__global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
+    LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
+    double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
+    LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
+  mf_step_body<THREADS, MFMA, CHAINED>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B,
+                                       blockIdx.x, Mf.n_tasks, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// Twin attempt: TWO regularizations of the same system factored, solved and back-substituted in one launch —
+// the one the policy loop (sparse_regularized_ldlt.hpp:64-152) is at, and the one it would try next if this
+// one shows too many negative pivots (delta x 10, :127-130), or, beside the unregularized first attempt, its first
+// guess (:95-102).  The step kernel is bound by latency and leaves most of the chip idle at the horizons one
+// problem has (15 workgroups at N = 100, 69 at N = 500): the second attempt costs nothing but power, and a step
+// whose first attempt fails — every third to fourth interior-point iteration on BASELINE's cart-pole, which
+// regularizes throughout — no longer pays a host round trip and a second launch (~47 us).  Which of the two the
+// policy takes is decided twice from the same counters, by the host (NewtonSystem::compute_impl) and by the
+// launch that consumes the direction (ipm_lookahead_kernel), so the result is the sequential policy's bit for bit.
+// Workgroups [0, first_end) are the first attempt's (ride-along sums and tasks), the rest the second's tasks:
+// same plan, same V, their own factor, update slots, x hand-over, direction and counters.
+// ---------------------------------------------------------------------------
+struct MfTwin {
+  unsigned int first_end = 0;
+  const double* reg = nullptr;
+  double *Lx = nullptr, *D = nullptr, *contrib = nullptr, *zv = nullptr, *xg = nullptr, *xg_next = nullptr, *out = nullptr,
+         *ps = nullptr, *pz = nullptr;
+  LdltStats *stats = nullptr, *stats_next = nullptr;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
+    LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
+    double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
+    LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T) {
+  uint32_t block = blockIdx.x;
+  if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
+    block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
+    reg = T.reg;
+    Lx = T.Lx;
+    D = T.D;
+    contrib = T.contrib;
+    zv = T.zv;
+    xg = T.xg;
+    xg_next = T.xg_next;
+    out = T.out;
+    stats = T.stats;
+    stats_next = T.stats_next;
+    B.ps = T.ps;
+    B.pz = T.pz;
+    F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
+  }
+  mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
+                                      2u * Mf.n_tasks, T.stats);
 }
 
 // ---------------------------------------------------------------------------

@@ -218,6 +218,8 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   const bool solve_speculatively = mode >= 1;
   bool graph_pending = mode == 2;
   const int B = m_opt.batch;
+  m_last_twin_launches = m_last_twin_taken = 0;
+  if (mode == 1 && B == 1 && m_twin_attempts && m_dev->twin_available()) return compute_twin();
   // With solve_speculatively every factorization attempt is followed at once by the
   // triangular solves and the back-substitution, BEFORE the host has read the inertia
   // counters: the device never idles through the host round trip, and in the usual case
@@ -339,6 +341,113 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
     }
   }
   return info;
+}
+
+// The policy loop of compute_impl (sparse_regularized_ldlt.hpp:64-152) for one problem, two attempts per launch:
+// the attempt the loop is at and the one it makes next if this one has too many negative pivots (delta x 10,
+// :127-130) — beside the unregularized first attempt, the first guess (:95-102).  The attempts are judged in the
+// policy's order from their own counters, so the sequence of (delta, gamma) tried, the one accepted and the count of
+// factorizations are the sequential loop's; a second attempt the policy would not have made next is ignored.
+// ipm_lookahead_kernel makes the same choice on the device from the same counters: keep the two in step.
+std::vector<FactorInfo> NewtonSystem::compute_twin() {
+  const int n = m_s.n, m_e = m_s.m_e;
+  std::vector<FactorInfo> info(1, FactorInfo::Success);
+  m_last_factorizations = 0;
+  const double eps = std::numeric_limits<double>::epsilon();
+  auto good = [&](const LdltStats& st) { return st.n_bad == 0 && st.n_pos == n && st.n_neg == m_e && st.n_zero == 0; };
+  auto min_abs = [](const LdltStats& st) {
+    double d;
+    std::memcpy(&d, &st.min_abs_bits, sizeof(d));
+    return d;
+  };
+  std::vector<LdltStats> stats;
+  LdltStats first{}, second{};
+  bool have_second = false;
+  // one launch: (d0, g0) and, if the device can, (d1, g1) beside it
+  auto launch = [&](double d0, double g0, double d1, double g1, int mode) {
+    have_second = m_dev->factor_solve_publish_twin(d0, g0, d1, g1, mode);
+    if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
+    else ++m_last_twin_launches;
+    if (m_after_attempt) m_after_attempt();
+    m_dev->read_stats(stats);
+    first = stats[0];
+    if (have_second) {
+      second = m_dev->read_twin_stats();
+      const bool first_good = good(first) && (mode != 2 || min_abs(first) >= 1e-4);
+      const int kind = first_good ? 0
+                       : first.n_bad != 0 ? 5
+                       : first.n_zero > 0 ? 3
+                       : first.n_neg > m_e ? (good(second) ? 1 : 2)
+                                           : 4;
+      ++m_twin_hist[kind];
+    }
+  };
+  auto accept = [&](double d, double g, bool is_second) {
+    m_prev_delta[0] = d;
+    m_prev_gamma[0] = g;
+    if (is_second) {
+      m_dev->adopt_twin();
+      ++m_last_twin_taken;
+    }
+    return info;
+  };
+  // the loop's answer to a failed attempt (:114-141); true: it was "too many negative pivots"
+  auto advance = [&](const LdltStats& st, double& d, double& g) {
+    bool negative_pivots = false;
+    if (st.n_bad == 0) {
+      if (st.n_zero > 0) {
+        if (g == 0.0) {
+          g = 1e-10;
+        } else {
+          d *= 10.0;
+          g *= 10.0;
+        }
+      } else if (st.n_neg > m_e) {
+        d *= 10.0;
+        negative_pivots = true;
+      } else if (st.n_pos > n) {
+        g = g == 0.0 ? 1e-10 : g * 10.0;
+      }
+    } else {
+      d *= 10.0;
+      g = g == 0.0 ? 1e-10 : g * 10.0;
+    }
+    return negative_pivots;
+  };
+  auto gave_up = [&](double d, double g) {  // :145-150
+    if (!(d > 1e20 || g > 1e20)) return false;
+    info[0] = FactorInfo::NumericalIssue;
+    m_prev_delta[0] = d;
+    m_prev_gamma[0] = g;
+    return true;
+  };
+
+  double d = m_prev_delta[0] == 0.0 ? 1e-4 : std::max(m_prev_delta[0] / 2.0, eps);  // :95-98
+  double g = m_gamma_min;                                                             // :102
+  bool second_is_current = false;  // `second` holds the attempt at (d, g)
+  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
+  if (!skip_first) {  // :74-87
+    launch(0.0, 0.0, d, g, 2);
+    ++m_last_factorizations;
+    if (good(first) && min_abs(first) >= 1e-4) return accept(0.0, 0.0, false);
+    second_is_current = have_second;
+  }
+  while (true) {
+    if (!second_is_current) {
+      launch(d, g, d * 10.0, g, 1);
+      ++m_last_factorizations;
+      if (good(first)) return accept(d, g, false);
+      const bool negative_pivots = advance(first, d, g);
+      if (gave_up(d, g)) return info;
+      second_is_current = have_second && negative_pivots;  // (d, g) is now what the second attempt was made with
+      if (!second_is_current) continue;
+    }
+    second_is_current = false;
+    ++m_last_factorizations;
+    if (good(second)) return accept(d, g, true);
+    advance(second, d, g);
+    if (gave_up(d, g)) return info;
+  }
 }
 
 bool NewtonSystem::factor_unregularized() {

@@ -100,6 +100,15 @@ class NewtonSystem {
   // the inertia counters, so it costs no extra synchronization when the attempt is accepted
   // (the interior-point driver puts its step-size / trial-point kernels here).
   void set_after_attempt(std::function<void()> fn) { m_after_attempt = std::move(fn); }
+  // Twin attempts (DeviceNlp::factor_solve_publish_twin): compute(solve_speculatively) factors the policy's
+  // attempt and the one that would follow it in one launch.  Only for a caller whose after_attempt work takes the
+  // direction of whichever attempt the policy takes ON THE DEVICE (DeviceNlp::ipm_lookahead does).
+  void set_twin_attempts(bool on) { m_twin_attempts = on; }
+  // launches with two attempts since construction, by what the first attempt showed: accepted; too many negative
+  // pivots and the second accepted / not; zero pivots; too many positive; the factorization itself failed
+  const long* twin_histogram() const { return m_twin_hist; }
+  int last_twin_launches() const { return m_last_twin_launches; }   // step launches of the last compute() that held two attempts
+  int last_twin_taken() const { return m_last_twin_taken; }         // ... whose second attempt the policy took
 
   // One full Newton step on device-resident state: AD refresh, KKT lhs/rhs,
   // regularized factorization, solve, back-substitution
@@ -119,6 +128,10 @@ class NewtonSystem {
   std::vector<double> m_prev_delta, m_prev_gamma;
   int m_last_factorizations = 0;
   std::function<void()> m_after_attempt;
+  bool m_twin_attempts = false;
+  int m_last_twin_launches = 0, m_last_twin_taken = 0;
+  long m_twin_hist[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<FactorInfo> compute_twin();
   std::vector<int32_t> m_user_lhs_map;
 };
 

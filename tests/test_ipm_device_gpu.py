@@ -251,3 +251,50 @@ def test_a_solve_is_reproducible_bit_for_bit(resident):
         assert np.array_equal(x, x0)
         for a, b in zip(duals, duals0):
             assert np.array_equal(a, b)
+
+
+def _solve_with_env(make, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        pp = make()
+        status, rep = pp.solve()
+        return status, rep, pp.get_x(), pp.duals()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("name,make", [
+    ("cart_pole_50", lambda: models.cart_pole(50, 0.1)),
+    ("cart_pole_100", lambda: models.cart_pole(100, 0.05)),     # restoration on the way
+    ("cart_pole_300", lambda: models.cart_pole(300, 5.0 / 300)),
+    ("flywheel_50", lambda: models.flywheel(50, 0.005)),
+])
+def test_twin_attempts_follow_the_sequential_policy_bit_for_bit(name, make, capfd):
+    """Two regularizations per launch (ldlt_mf_twin_kernel, NewtonSystem::compute_twin) are judged in the
+    order sparse_regularized_ldlt.hpp:64-152 tries them: the iterates, the iteration count and the number of
+    factorizations the policy counts are those of one attempt per launch (SLPX_TWIN=0), to the bit — and on
+    the cart-pole, which regularizes throughout, the second attempt of a launch IS taken."""
+    capfd.readouterr()
+    st_t, rep_t, x_t, duals_t = _solve_with_env(make, SLPX_TWIN_VERBOSE="1")
+    err = capfd.readouterr().err
+    st_s, rep_s, x_s, duals_s = _solve_with_env(make, SLPX_TWIN="0")
+    assert st_t == st_s
+    assert rep_t["iterations"] == rep_s["iterations"] and rep_t["factorizations"] == rep_s["factorizations"]
+    assert np.array_equal(x_t, x_s)
+    for a, b in zip(duals_t, duals_s):
+        assert np.array_equal(a, b)
+    lines = [l for l in err.splitlines() if l.startswith("slpx twin attempts:")]
+    assert lines, err
+    launches = sum(int(l.split()[3]) for l in lines)
+    taken = sum(int(l.split("second of")[1].split()[0]) for l in lines)
+    if not cases.OUTER_SWITCHES:  # (the pair-list step, unfused launches, ... have no twin attempts)
+        assert launches > 0
+        if name.startswith("cart_pole"):
+            assert taken > 0, lines
+    print(f"{name}: {rep_t['iterations']} iterations, {rep_t['factorizations']} factorizations, {launches} twin launches, "
+          f"second attempt taken {taken} times")

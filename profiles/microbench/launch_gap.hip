@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -38,6 +39,23 @@ __global__ void kernel_b256(unsigned long long* start, Big256 a) {
 }
 __global__ void kernel_b768(unsigned long long* start, Big768 a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *start = wall_clock64() + (a.w[95] & 0);
+}
+// the same pair with workgroups that carry LDS like the step kernel's (57-160 KB of dynamic LDS, 1024 threads)
+__global__ void kernel_a_lds(volatile unsigned long long* host_end, unsigned long long ticks) {
+  extern __shared__ unsigned char lds[];
+  lds[threadIdx.x] = 1;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __threadfence_system();
+    *host_end = wall_clock64() + (lds[5] & 0);
+  }
+}
+__global__ void kernel_b_lds(unsigned long long* start, unsigned long long) {
+  extern __shared__ unsigned char lds[];
+  lds[threadIdx.x] = 1;
+  if (threadIdx.x == 0 && blockIdx.x == 0) *start = wall_clock64() + (lds[0] & 0);
 }
 // resident before the host decides: leaves when the host opens the gate (a pinned word), then stamps
 template <int SLEEP>
@@ -83,12 +101,33 @@ int main() {
   CHECK(hipMalloc(reinterpret_cast<void**>(&d_relay), 64));
   CHECK(hipMemset(d_relay, 0, 64));
   unsigned long long ticket = 0;
-  for (int variant = 0; variant < 10; ++variant) {
+  // (variants 10-12: B enqueued while A — 60 us here — is already running, 0 / 15 / 35 us after A's launch call returned)
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel_a_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel_b_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // (variants 13-18: LDS-carrying workgroups on one or both sides, B enqueued at once / 25 us into A)
+  for (int variant = 0; variant < 19; ++variant) {
     std::vector<double> gaps;
     for (int it = 0; it < 300; ++it) {
       *h_end = 0;
       unsigned long long start = 0;
-      if (variant >= 4) {
+      if (variant >= 13) {
+        const int k = variant - 13;  // 0,1: A lds, B small; 2,3: A small, B lds; 4,5: both lds
+        const bool a_lds = k < 2 || k >= 4, b_lds = k >= 2, late = (k & 1) != 0;
+        if (a_lds) hipLaunchKernelGGL(kernel_a_lds, dim3(137), dim3(1024), 100 * 1024, s, h_end, 5000ull);
+        else hipLaunchKernelGGL(kernel_a, dim3(1), dim3(64), 0, s, h_end, 5000ull);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (late && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 25.0) {
+        }
+        if (b_lds) hipLaunchKernelGGL(kernel_b_lds, dim3(137), dim3(1024), 100 * 1024, s, d_start, 0ull);
+        else hipLaunchKernelGGL(kernel_b16, dim3(137), dim3(1024), 0, s, d_start, 0ull);
+      } else if (variant >= 10) {
+        hipLaunchKernelGGL(kernel_a, dim3(1), dim3(64), 0, s, h_end, 6000ull);
+        const auto t0 = std::chrono::steady_clock::now();
+        const double wait_us = variant == 10 ? 0.0 : variant == 11 ? 15.0 : 35.0;
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < wait_us) {
+        }
+        hipLaunchKernelGGL(kernel_b16, dim3(137), dim3(1024), 0, s, d_start, 0ull);
+      } else if (variant >= 4) {
         // gated: B is launched right behind A and waits for the host's word
         ++ticket;
         hipLaunchKernelGGL(kernel_a, dim3(1), dim3(64), 0, s, h_end, ticks);
@@ -118,7 +157,11 @@ int main() {
                            "... B with 768 bytes of arguments", "B launched behind A at once (in-order floor)",
                            "B launched behind A at once, gated on a pinned word the host writes when it sees A's result (137 workgroups ask, s_sleep 4)",
                            "... 30 workgroups ask, s_sleep 4", "... 137 workgroups ask, s_sleep 32", "... 30 workgroups ask, s_sleep 32",
-                           "... one of 137 workgroups asks and passes the answer on through device memory", "... one of 30 workgroups asks and passes it on"};
+                           "... one of 137 workgroups asks and passes the answer on through device memory", "... one of 30 workgroups asks and passes it on",
+                           "B enqueued right behind A's launch call (A runs 60 us)", "B enqueued 15 us after A's launch call", "B enqueued 35 us after A's launch call",
+                           "A: 137 workgroups with 100 KB of LDS, 50 us; B without LDS, enqueued at once", "... B enqueued 25 us into A",
+                           "A without LDS; B: 137 workgroups with 100 KB of LDS, enqueued at once", "... B enqueued 25 us into A",
+                           "A and B with 100 KB of LDS, B enqueued at once", "... B enqueued 25 us into A"};
     std::printf("%-130s: ", names[variant]);
     stats(gaps);
   }

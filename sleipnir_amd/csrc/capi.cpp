@@ -464,9 +464,13 @@ int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_
     std::vector<int32_t> worst(sys.batch(), 0);
     for (int32_t k = 0; k < count; ++k) {
       if (forget_regularization) sys.reset_regularization();
+      // (all but the last step of the run launch their successor ahead: NewtonSystem::set_pipeline)
+      sys.set_pipeline(refresh_ad != 0 && k + 1 < count, forget_regularization != 0);
       auto res = sys.newton_step(refresh_ad != 0);
       for (size_t b = 0; b < res.size(); ++b) worst[b] |= static_cast<int32_t>(res[b]);
     }
+    sys.set_pipeline(false, false);
+    if (std::getenv("SLPX_TWIN_VERBOSE")) sys.device().debug_gate_stamps("newton steps");
     if (info) std::copy(worst.begin(), worst.end(), info);
   });
 }

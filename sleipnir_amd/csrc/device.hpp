@@ -229,6 +229,15 @@ struct BacksubFuse {
   volatile unsigned long long* seq_host = nullptr;
 };
 
+// A pre-launched step's gate (ldlt_mf_kernels.h: mf_gate_wait; DeviceNlp::prelaunch_step)
+struct MfGate {
+  const unsigned long long* word = nullptr;  // pinned, 16-byte aligned; nullptr: no gate
+  unsigned long long ticket = 0;
+  unsigned long long* relay = nullptr;       // device: {mu bits, 2 x ticket + abort} as the asking workgroup saw it
+  double* mu_out = nullptr;                  // != nullptr: mu comes through the gate; left here for the launches behind
+  unsigned long long* abandoned = nullptr;   // pinned: the ticket of a launch that gave up waiting (never expected)
+};
+
 // ldlt_factor_solve_kernel (ldlt_kernels.h): what the backward solve needs to run on the
 // factorization's LDS instead of on L and z in memory.
 struct SolveInPlace {
@@ -280,7 +289,20 @@ struct TrackedStream {
   hipStream_t tape = nullptr;
   hipEvent_t ev = nullptr;
   mutable bool tape_pending = false;
+  // a pre-launched step kernel waits in this stream for the host's word (DeviceNlp::prelaunch_step): whatever
+  // else is handed the stream would queue behind it — it is sent home first (the word of its ticket with the
+  // abort bit)
+  mutable volatile unsigned long long* gate_word = nullptr;
+  mutable unsigned long long gate_ticket = 0;
+  mutable bool gate_pending = false;
+  void abort_gate() const {
+    if (gate_pending) {
+      gate_pending = false;
+      gate_word[1] = 2ull * gate_ticket + 1ull;
+    }
+  }
   operator hipStream_t() const {
+    abort_gate();
     touched = true;
     if (tape_pending) {
       tape_pending = false;
@@ -374,6 +396,20 @@ class DeviceNlp {
   void materialize_factor();                // batch-interleaved mode: refresh the batch-major L, D copies
   static bool interleaved_for(int batch);   // batches this large factor with one lane per problem
   // ... and, among those, by fronts with four lanes per problem (ldlt_mfq_kernels.h) where the plan allows it
+  // A step launched ahead of the decision to take it (MfGate, ldlt_mf_kernels.h): the step kernel — `twin_mode`
+  // 0: one attempt (reg = {delta, gamma}), else a twin attempt (reg = {delta0, gamma0, delta1, gamma1}) — with the
+  // buffer roles of this moment, the system evaluated in the launch (`kkt_mode` as m_kkt_pending: 1 lhs + rhs, 2: + the
+  // tape's sums), behind a chained sweep if one is pending.  Nothing of the host's bookkeeping changes until
+  // open_gate() (mu: the barrier parameter the step takes, NaN: the one in device memory); anything else handed the
+  // stream first, or abort_gate(), sends the kernel home.  false: not possible (nothing was launched).
+  // `lookahead_roles`: with the look-ahead iterate and its V as the current ones (what ipm_accept_lookahead() will
+  // make them if the filter takes the point).
+  bool prelaunch_step(int twin_mode, const double* reg, int kkt_mode, bool mu_through_gate, bool lookahead_roles);
+  bool can_prelaunch(int twin_mode);
+  bool gate_pending() const { return m_stream.gate_pending; }
+  void debug_gate_stamps(const char* label);
+  void open_gate(double mu);
+  void abort_gate() { m_stream.abort_gate(); }
   // Twin attempt (ldlt_mf_twin_kernel): the policy loop's attempt (delta0, gamma0) and the one it would make
   // next (delta1, gamma1) in ONE launch; `mode` as IpmTwin::mode.  false: not possible now (the caller makes a
   // single attempt).  read_stats() then has the first attempt's counters, read_twin_stats() the second's;
@@ -548,6 +584,18 @@ class DeviceNlp {
   DevBuf<double> m_mf_contrib;
   // the second attempt of a twin launch: its own factor, update slots, x hand-over (a pair, alternating like
   // m_xg / m_xg2), direction and counters (a pair, alternating like m_stats)
+  // the pre-launched step (prelaunch_step): what open_gate() has to book
+  struct PendingStep {
+    int twin_mode = 0, kkt_mode = 0;
+    bool chained = false, mu_through_gate = false;
+  } m_pre;
+  unsigned long long* m_h_gate = nullptr;  // pinned, 64 bytes: [0, 1] the gate's word {mu, 2 x ticket + abort}, [2] the ticket of a launch that gave up
+  DevBuf<unsigned long long> m_gate_relay;
+  unsigned long long m_gate_ticket = 0;
+  int m_gate_state = 0;  // 0: not looked at yet, 1: usable, -1: not (SLPX_PRELAUNCH=0, ...)
+  KktFuse kkt_fuse_for(int kkt_mode) const;
+  void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const MfGate& gate);
+  void book_mf_step(int twin_mode, bool chained);
   int m_twin_state = 0;  // 0: not looked at yet, 1: available, -1: not (not resident at once, SLPX_TWIN=0, ...)
   int m_twin_mode = 0;   // of the step launch in flight (IpmTwin::mode; 0: a single attempt)
   DevBuf<double> m_Lx_tw, m_D_tw, m_zv_tw, m_p_tw, m_ps_tw, m_pz_tw, m_mf_contrib_tw, m_xg_tw, m_xg2_tw;

@@ -621,16 +621,20 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     dev.upload_duals(s.data(), y.data(), z.data());
     host_current = true;
   };
-  long twin_launches = 0, twin_taken = 0;
+  long twin_launches = 0, twin_taken = 0, prelaunched = 0, prelaunch_used = 0;
+  const char* prelaunch_env = std::getenv("SLPX_PRELAUNCH");
+  const bool prelaunch = prelaunch_env != nullptr && prelaunch_env[0] == '1';  // (off unless asked for)
   auto finish = [&](ExitStatus st_) {
+    sys.cancel_prelaunch();
     sys.set_after_attempt(nullptr);
     pull_state();
     if (std::getenv("SLPX_TWIN_VERBOSE")) {
+      dev.debug_gate_stamps("interior-point solve");
       const long* h = sys.twin_histogram();
       std::fprintf(stderr, "slpx twin attempts: %ld launches held two attempts, the policy took the second of %ld (%d factorizations, %d iterations); "
-                   "first attempts of this system so far: %ld accepted, %ld / %ld with too many negative pivots and the second accepted / not, "
-                   "%ld with zero pivots, %ld with too many positive, %ld failed\n",
-                   twin_launches, twin_taken, rep.factorizations, iterations, h[0], h[1], h[2], h[3], h[4], h[5]);
+                   "first attempts of this system so far: %ld accepted, %ld / %ld with the failure the second stood for and the second accepted / not, "
+                   "%ld with zero pivots, %ld with the other inertia failure, %ld failed; %ld steps launched ahead, %ld of them taken\n",
+                   twin_launches, twin_taken, rep.factorizations, iterations, h[0], h[1], h[2], h[3], h[4], h[5], prelaunched, prelaunch_used);
     }
     return st_;
   };
@@ -705,10 +709,15 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // ---- Newton step (:426-482), then speculatively: step sizes, first trial point ----
     auto t0 = clk::now();
     const bool s_from_ci = options.feasible_ipm && cur.ci_all_pos != 0.0;
+    const bool ahead = lookahead && !s_from_ci;
+    if (!ahead) sys.cancel_prelaunch();
     if (mu != mu_on_device) {
-      dev.upload_mu(&mu);
+      // (a step launched ahead takes mu through its gate and leaves it in device memory: nothing may queue behind
+      // it before the gate opens)
+      if (!dev.gate_pending()) dev.upload_mu(&mu);
       mu_on_device = mu;
     }
+    sys.set_step_mu(mu);
     dev.build_kkt_for_step(/*with_reduce=*/false);
     // Look-ahead (DeviceNlp::ipm_lookahead): instead of only f, c_e, c_i at the first trial point, the
     // WHOLE next iterate the full step would give — updated s, y, z, the full tape at it, the error norms
@@ -716,7 +725,6 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // iterations take the first trial point: the iteration is then complete when these numbers arrive
     // (one host round trip, four launches), and nothing is computed twice.  The feasible-IPM option
     // derives the trial s from the trial c_i (:520-526): it keeps the trial-values chain below.
-    const bool ahead = lookahead && !s_from_ci;
     sys.set_after_attempt([&] {
       if (ahead) {
         dev.ipm_lookahead(tau);
@@ -731,11 +739,19 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // (twin attempts, NewtonSystem::compute_twin: the look-ahead launch takes the direction of whichever of a
     // launch's two attempts the regularization policy takes — the other after_attempt chain does not)
     sys.set_twin_attempts(ahead);
+    if (dev.gate_pending()) ++prelaunch_used;
     auto info = sys.compute(/*solve_speculatively=*/true);
     sys.set_twin_attempts(false);
     sys.set_after_attempt(nullptr);
     twin_launches += sys.last_twin_launches();
     twin_taken += sys.last_twin_taken();
+    // The next iteration's step, launched now — the host has nothing to do until the chain's numbers arrive, ~25 us —
+    // on the look-ahead iterate, with the regularization the policy will start from: the kernel stages its plan and
+    // waits for the host's word (MfGate).  Most iterations take the look-ahead point; then the word is "go" with the
+    // barrier parameter decided below, and the step starts ~4 us after the numbers instead of ~11.  Anything else —
+    // backtracking, a correction, restoration, the end — sends the kernel home first (cancel_prelaunch; every other
+    // launch into the stream does it too).
+    if (ahead && prelaunch && callbacks.empty() && info[0] == FactorInfo::Success && sys.prelaunch_twin_step()) ++prelaunched;
     dev.wait_published();  // compute() returns when the inertia counters are in; the trial chain may still run
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();
@@ -751,6 +767,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     double alpha_z = H.dir.alpha_z;  // :497
     const double D_phi = H.dir.D_phi;  // :508-509
     bool call_feasibility_restoration = alpha < alpha_min;
+    if (call_feasibility_restoration) sys.cancel_prelaunch();
     const FilterEntry current_entry{cur.f - mu * cur.logsum, cur.viol};
     double alpha_commit = alpha;
     bool commit_s_from_ci = s_from_ci;
@@ -773,6 +790,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       IpmTrialOut tr = from_ahead ? IpmTrialOut{H.err_ahead.f, H.err_ahead.viol, H.err_ahead.logsum, H.err_ahead.finite} : H.trial;
 
       if (tr.finite == 0.0) {
+        sys.cancel_prelaunch();
         alpha *= alpha_reduction_factor;
         if (alpha < alpha_min) {
           call_feasibility_restoration = true;
@@ -786,6 +804,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         took_lookahead = from_ahead;
         break;
       }
+      sys.cancel_prelaunch();  // the step launched ahead assumed this point
 
       const double prev_violation = cur.viol;
       double next_violation = tr.viol;

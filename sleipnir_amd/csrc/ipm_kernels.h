@@ -95,6 +95,7 @@ __device__ __forceinline__ void block_reduce(double (&vals)[NQ], const int (&ops
 // sequence number the host spins on (DeviceNlp::wait_published) — it sees it a few
 // microseconds before the stream reports the kernel complete.
 __device__ __forceinline__ void ipm_publish(unsigned long long* seq_dev, volatile unsigned long long* seq_host) {
+  SLPX_GATE_STAMP_SET(0);
   __threadfence_system();
   const unsigned long long v = *seq_dev + 1;
   *seq_dev = v;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
 // ipm_lookahead); if the filter takes the point the buffers swap roles and nothing is recomputed.
 // the second attempt of a twin launch (ldlt_mf_twin_kernel), for the launch that takes the direction
 struct IpmTwin {
-  int mode = 0;  // 0: one attempt; 1: the policy loop's attempt and its delta x 10; 2: the unregularized attempt and the first guess
+  int mode = 0;  // 0: one attempt; 1: the policy loop's attempt and its delta x 10; 2: the unregularized attempt and the first guess; 3: the loop's attempt and its gamma x 10
   const double *p = nullptr, *ps = nullptr, *pz = nullptr;
   const LdltStats* stats = nullptr;
 };
@@ -159,16 +160,22 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
   // The factorization this direction comes from has the wrong inertia (or failed): the policy loop will
   // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
   // (one lane-uniform 16-byte load, issued with the others below)
+#ifdef SLPX_GATE_STAMPS
+  if (tid == 0) SLPX_GATE_STAMP_ADD(12, slpx_gate_stamps[1]);
+#endif
   const LdltStats st = stats[0];
   bool wrong = st.n_bad != 0 || st.n_pos != K.n || st.n_neg != K.m_e || st.n_zero != 0;
   if (tw.mode != 0) {
     // A twin attempt (ldlt_mf_twin_kernel): the policy's choice between the two, from the same counters the host
     // reads (NewtonSystem::compute_impl — keep the two in step).  The second attempt stands for the policy's next
     // one only if the first failed the way that leads to it: beside the unregularized attempt (mode 2) any failure
-    // does (:82-102, also a pivot below 1e-4); in the loop (mode 1) too many negative pivots, nothing else (:127-130).
+    // does (:82-102, also a pivot below 1e-4); in the loop too many negative pivots (mode 1: delta x 10, :127-130) or too
+    // many positive ones (mode 3: gamma x 10, :131-135), nothing else.
     const LdltStats st2 = tw.stats[0];
     if (tw.mode == 2 && !wrong && __longlong_as_double(static_cast<long long>(st.min_abs_bits)) < 1e-4) wrong = true;
-    const bool leads_to_second = tw.mode == 2 || (st.n_bad == 0 && st.n_zero == 0 && st.n_neg > K.m_e);
+    const bool inertia_only = st.n_bad == 0 && st.n_zero == 0;
+    const bool leads_to_second = tw.mode == 2 || (tw.mode == 1 && inertia_only && st.n_neg > K.m_e) ||
+                                 (tw.mode == 3 && inertia_only && st.n_neg <= K.m_e && st.n_pos > K.n);
     const bool second_good = st2.n_bad == 0 && st2.n_pos == K.n && st2.n_neg == K.m_e && st2.n_zero == 0;
     if (wrong && leads_to_second && second_good) {
       wrong = false;

@@ -12,6 +12,7 @@
 //   ldlt_fwd/bwd   (ldlt_kernels.h) triangular solves (sparse_regularized_ldlt.hpp:159-161)
 //   step_backsub   pˢ, pᶻ                 (interior_point.hpp:479-480)
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <bit>
@@ -735,7 +736,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
     m_stats.upload(zero);
   }
-  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(std::max<int>(B, 2)) * sizeof(double)));  // (B = 1: a twin attempt's second pair)
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(std::max<int>(B, 6)) * sizeof(double)));  // (B = 1: a twin attempt's second pair, two sets for pre-launched steps)
   if (B > 8) m_reg_dev.alloc(2 * B);
   if (m_il) {
     // batch-interleaved LDLT (ldlt_il_kernels.h): [chunk of 64 problems][index][lane]
@@ -840,6 +841,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 }
 
 DeviceNlp::~DeviceNlp() {
+  m_stream.abort_gate();
+  if (m_h_gate) {
+    (void)hipStreamSynchronize(m_stream.raw());
+    (void)hipHostFree(m_h_gate);
+  }
   if (m_h_reg) (void)hipHostFree(m_h_reg);
   if (m_h_stats) (void)hipHostFree(m_h_stats);
   if (m_h_seq) (void)hipHostFree(const_cast<unsigned long long*>(m_h_seq));
@@ -993,6 +999,7 @@ void DeviceNlp::sweep_full(bool with_reduce) {
   m_tape_reduce = true;
 }
 void DeviceNlp::sweep_full_for_step() {
+  m_stream.abort_gate();
   const TapeDevice& t = m_full;
   // one generated kernel is the whole sweep (nothing interpreted beside it), the step is the one-launch
   // multifrontal kernel, and no graph is being captured
@@ -1087,6 +1094,7 @@ void DeviceNlp::sweep_full_for_step() {
 // expected — a shared / preempted / serialized GPU).  Drain both streams, clear the words, keep this
 // system's steps unchained from now on and leave V as a fresh sweep of the current state writes it.
 void DeviceNlp::recover_from_chain_failure() {
+  m_stream.abort_gate();
   if (m_tape_stream != nullptr) SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
   if (m_chain.p != nullptr) SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
@@ -1779,11 +1787,11 @@ void DeviceNlp::write_reg(const std::vector<double>& delta, const std::vector<do
 
 
 // the system evaluated inside the factorization's launch, if a build_kkt_for_step() asked for it
-KktFuse DeviceNlp::take_kkt_fuse() {
+KktFuse DeviceNlp::kkt_fuse_for(int kkt_mode) const {
   KktFuse f;
-  if (m_kkt_pending) {
+  if (kkt_mode) {
     f.inline_kkt = 1;
-    f.n_blocks = m_kkt_pending == 2 ? static_cast<int>(m_reduces.n) : 0;
+    f.n_blocks = kkt_mode == 2 ? static_cast<int>(m_reduces.n) : 0;
     f.V = m_V.p;
     f.s = m_s.p;
     f.y = m_y.p;
@@ -1796,10 +1804,16 @@ KktFuse DeviceNlp::take_kkt_fuse() {
     if (m_fuse_kkt_store) {
       f.store_lhs = m_lhs.p;
       f.store_rhs = m_rhs.p;
-      m_lhs_stale = m_rhs_stale = false;
     }
     f.red = m_reduces.p;
     f.scales = m_scales.p;
+  }
+  return f;
+}
+KktFuse DeviceNlp::take_kkt_fuse() {
+  const KktFuse f = kkt_fuse_for(m_kkt_pending);
+  if (m_kkt_pending) {
+    if (m_fuse_kkt_store) m_lhs_stale = m_rhs_stale = false;
     m_kkt_pending = 0;
   }
   return f;
@@ -1920,6 +1934,7 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
 
 void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
                        const std::vector<uint8_t>& active) {
+  m_stream.abort_gate();
   write_reg(delta, gamma, active);
   m_twin_mode = 0;
   m_stats_cur ^= 1;
@@ -1937,6 +1952,7 @@ void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std
     solve_backsub_publish();
     return;
   }
+  m_stream.abort_gate();
   write_reg(delta, gamma, active);
   m_twin_mode = 0;
   m_stats_cur ^= 1;
@@ -1980,19 +1996,14 @@ bool DeviceNlp::twin_available() {
   return true;
 }
 
-bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode) {
-  if (!twin_available() || m_stream.tape_pending) return false;
+// One launch of the multifrontal step kernel (twin_mode != 0: two attempts, ldlt_mf_twin_kernel) with the buffer
+// roles, parities and chain numbers of this moment; book_mf_step() is what the launch changes on the host — at
+// once for a plain launch, when its gate opens for a pre-launched one.
+void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const MfGate& gate) {
   const LdltPlan& l = m_l_ref;
-  m_h_reg[0] = delta0;
-  m_h_reg[1] = gamma0;
-  m_h_reg[2] = delta1;
-  m_h_reg[3] = gamma1;
-  m_stats_cur ^= 1;
-  m_stats_tw_cur ^= 1;
-  if (!m_kkt_pending) materialize_kkt();
-  LdltStats* cur = m_stats.p + static_cast<size_t>(m_stats_cur);
-  LdltStats* next = m_stats.p + static_cast<size_t>(m_stats_cur ^ 1);
-  KktFuse f = take_kkt_fuse();
+  const int parity = m_stats_cur ^ 1;
+  LdltStats* cur = m_stats.p + static_cast<size_t>(parity);
+  LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1);
   BacksubFuse bf = backsub_fuse(cur);
   MfDev md;
   md.tasks = m_mf_tasks.p;
@@ -2002,36 +2013,180 @@ bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double d
   md.image_desc = m_mf_image_desc.p;
   md.n_tasks = static_cast<unsigned int>(l.tasks.size());
   md.exit_cnt = m_exit_cnt.p;
-  MfTwin tw;
-  tw.first_end = md.n_tasks + static_cast<unsigned int>(f.n_blocks);
-  tw.reg = m_h_reg + 2;
-  tw.Lx = m_Lx_tw.p;
-  tw.D = m_D_tw.p;
-  tw.contrib = m_mf_contrib_tw.p;
-  tw.zv = m_zv_tw.p;
-  tw.xg = m_xg_tw_parity ? m_xg2_tw.p : m_xg_tw.p;
-  tw.xg_next = m_xg_tw_parity ? m_xg_tw.p : m_xg2_tw.p;
-  tw.out = m_p_tw.p;
-  tw.ps = m_ps_tw.p;
-  tw.pz = m_pz_tw.p;
-  tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur);
-  tw.stats_next = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur ^ 1);
-  const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
-  md.n_workgroups = grid.x;
-  m_last_step_chained = false;
-  auto launch = [&](auto kernel, int threads) {
-    hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p, l.n,
-                       m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw);
-  };
-  if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
-  else launch(&ldlt_mf_twin_kernel<512>, 512);
-  xg_flip();
-  m_xg_tw_parity ^= 1;
+  // a chained step (sweep_full_for_step): the kernel variant that waits for its sweep itself and whose last
+  // workgroup tells the next step's sweep; the main stream stays "untouched" by a step's own launches
+  md.chain = chained ? m_chain.p : nullptr;
+  md.wait_step = chained ? m_chain_seq : 0u;
+  md.this_step = m_chain_seq;
+  if (twin_mode != 0) {
+    const int tw_parity = m_stats_tw_cur ^ 1;
+    MfTwin tw;
+    tw.first_end = md.n_tasks + static_cast<unsigned int>(f.n_blocks);
+    tw.reg = reg + 2;
+    tw.Lx = m_Lx_tw.p;
+    tw.D = m_D_tw.p;
+    tw.contrib = m_mf_contrib_tw.p;
+    tw.zv = m_zv_tw.p;
+    tw.xg = m_xg_tw_parity ? m_xg2_tw.p : m_xg_tw.p;
+    tw.xg_next = m_xg_tw_parity ? m_xg_tw.p : m_xg2_tw.p;
+    tw.out = m_p_tw.p;
+    tw.ps = m_ps_tw.p;
+    tw.pz = m_pz_tw.p;
+    tw.stats = m_stats_tw.p + static_cast<size_t>(tw_parity);
+    tw.stats_next = m_stats_tw.p + static_cast<size_t>(tw_parity ^ 1);
+    const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
+    md.n_workgroups = grid.x;
+    auto launch = [&](auto kernel, int threads) {
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p, l.n,
+                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, gate);
+    };
+    if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
+    else launch(&ldlt_mf_twin_kernel<512>, 512);
+  } else {
+    const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
+    md.n_workgroups = grid.x;
+    auto launch = [&](auto kernel, int threads) {
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p,
+                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, gate);
+    };
+    if (m_mf_threads == 1024) {
+      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, true>, 1024);
+      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, false>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, false>, 1024);
+    } else {
+      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, true>, 512) : launch(&ldlt_mf_step_kernel<512, false, true>, 512);
+      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, false>, 512) : launch(&ldlt_mf_step_kernel<512, false, false>, 512);
+    }
+  }
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::book_mf_step(int twin_mode, bool chained) {
+  m_stats_cur ^= 1;
+  if (twin_mode != 0) {
+    m_stats_tw_cur ^= 1;
+    m_xg_tw_parity ^= 1;
+  }
+  xg_flip();
+  m_stream.tape_pending = false;
+  m_last_step_chained = chained;
+  m_twin_mode = twin_mode;
+}
+
+bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode) {
+  m_stream.abort_gate();
+  if (!twin_available() || m_stream.tape_pending) return false;
+  m_h_reg[0] = delta0;
+  m_h_reg[1] = gamma0;
+  m_h_reg[2] = delta1;
+  m_h_reg[3] = gamma1;
+  if (!m_kkt_pending) materialize_kkt();
+  const KktFuse f = take_kkt_fuse();
+  launch_mf_step(mode, m_h_reg, f, false, MfGate{});
+  book_mf_step(mode, false);
   m_stats_seq = ++m_seq_expected;
   m_stats_in_host = true;
-  m_twin_mode = mode;
   return true;
+}
+
+// ---- a step launched ahead of the decision to take it (MfGate) ----
+// A launch that returns only when its kernel is through (AMD_SERIALIZE_KERNEL, some profiler modes) can never be
+// handed its word: the one-time probe waits up to 20 ms for a word the host writes right after the launch call.
+__global__ void gate_probe_kernel(const unsigned long long* word, unsigned long long* seen) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long v = 0;
+  while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0 && wall_clock64() - t0 < 2000000ull)
+    __builtin_amdgcn_s_sleep(8);
+  seen[0] = v;
+}
+
+bool DeviceNlp::can_prelaunch(int twin_mode) {
+  if (m_gate_state == 0) {
+    m_gate_state = -1;
+    const char* env = std::getenv("SLPX_PRELAUNCH");
+    // (off unless asked for: measured, it gains nothing — DESIGN.md section 4a, profiles/r04_prelaunch_ab.txt)
+    if (env != nullptr && env[0] == '1' && m_batch == 1 && m_seq_poll && m_fuse_solve && m_fuse_kkt) {
+      SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_gate), 64));
+      std::memset(m_h_gate, 0, 64);
+      m_gate_relay.upload(std::vector<unsigned long long>(2, 0ull));
+      m_stream.gate_word = m_h_gate;
+      hipLaunchKernelGGL(gate_probe_kernel, dim3(1), dim3(1), 0, m_stream.raw(), m_h_gate + 3, m_gate_relay.p);
+      *reinterpret_cast<volatile unsigned long long*>(m_h_gate + 3) = 1ull;
+      SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+      unsigned long long seen = 0;
+      SLPX_HIP_CHECK(hipMemcpy(&seen, m_gate_relay.p, sizeof(seen), hipMemcpyDeviceToHost));
+      SLPX_HIP_CHECK(hipMemset(m_gate_relay.p, 0, 2 * sizeof(unsigned long long)));
+      if (seen != 0) m_gate_state = 1;
+      else if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "slpx: launches return when their kernels are through here: no step is launched ahead\n");
+    }
+  }
+  if (m_gate_state < 0 || !m_mf || xg_other() == nullptr || m_capturing) return false;
+  if (twin_mode != 0 && (!twin_available() || m_stream.tape_pending)) return false;
+  return true;
+}
+
+bool DeviceNlp::prelaunch_step(int twin_mode, const double* reg, int kkt_mode, bool mu_through_gate, bool lookahead_roles) {
+  m_stream.abort_gate();
+  if (kkt_mode == 0 || !can_prelaunch(twin_mode)) return false;
+  auto swap_roles = [&] {
+    if (!lookahead_roles) return;
+    m_in.swap(m_trial_in);
+    m_s.swap(m_s_ahead);
+    m_y.swap(m_y_ahead);
+    m_z.swap(m_z_ahead);
+    m_V.swap(m_V_trial);
+  };
+  double* reg_pre = m_h_reg + 4 + 4 * (m_gate_ticket & 1ull);  // (the launch before may still be reading its own)
+  for (int k = 0; k < (twin_mode != 0 ? 4 : 2); ++k) reg_pre[k] = reg[k];
+  MfGate g;
+  g.word = m_h_gate;
+  g.ticket = ++m_gate_ticket;
+  g.relay = m_gate_relay.p;
+  g.mu_out = mu_through_gate ? m_mu.p : nullptr;
+  g.abandoned = m_h_gate + 2;
+  m_pre.twin_mode = twin_mode;
+  m_pre.kkt_mode = kkt_mode;
+  m_pre.chained = m_stream.tape_pending;
+  m_pre.mu_through_gate = mu_through_gate;
+  swap_roles();
+  launch_mf_step(twin_mode, reg_pre, kkt_fuse_for(kkt_mode), m_pre.chained, g);
+  swap_roles();
+  m_stream.gate_ticket = g.ticket;
+  m_stream.gate_pending = true;
+  return true;
+}
+
+void DeviceNlp::open_gate(double mu) {
+  if (!m_stream.gate_pending) throw std::runtime_error("slpx: open_gate() without a pre-launched step");
+  // {mu, 2 x ticket} in ONE 16-byte store: the kernel's 16-byte load sees both or neither
+  unsigned long long mu_bits;
+  std::memcpy(&mu_bits, &mu, sizeof(mu_bits));
+  _mm_store_si128(reinterpret_cast<__m128i*>(m_h_gate), _mm_set_epi64x(static_cast<long long>(2ull * m_stream.gate_ticket), static_cast<long long>(mu_bits)));
+  m_stream.gate_pending = false;
+  // what take_kkt_fuse() and the launch would have booked
+  if (m_pre.kkt_mode) {
+    if (m_fuse_kkt_store) m_lhs_stale = m_rhs_stale = false;
+    m_kkt_pending = 0;
+  }
+  book_mf_step(m_pre.twin_mode, m_pre.chained);
+  m_stats_seq = ++m_seq_expected;
+  m_stats_in_host = true;
+}
+
+// (-DSLPX_GATE_STAMPS) the sums the kernels left, in microseconds per step, to stderr; clears them
+void DeviceNlp::debug_gate_stamps(const char* label) {
+#ifdef SLPX_GATE_STAMPS
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
+  unsigned long long h[16];
+  SLPX_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(slpx_gate_stamps), sizeof(h)));
+  const double n = static_cast<double>(std::max<unsigned long long>(1, h[15]));
+  auto us = [&](int k) { return static_cast<double>(static_cast<long long>(h[k])) / 100.0 / n; };
+  std::fprintf(stderr, "slpx gate stamps (%s, %llu step kernels): numbers -> step kernel in %.2f us, in -> staged %.2f, staged -> through the gate %.2f, "
+               "gate -> counters out %.2f, counters out -> the launch behind in %.2f; the step before's counters out -> step kernel in %.2f\n", label, h[15], us(8), us(9), us(10), us(11), us(12), us(13));
+  std::memset(h, 0, sizeof(h));
+  SLPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(slpx_gate_stamps), h, sizeof(h)));
+#else
+  (void)label;
+#endif
 }
 
 void DeviceNlp::adopt_twin() {
@@ -2057,37 +2212,10 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
   KktFuse f = take_kkt_fuse();
   BacksubFuse bf = backsub_fuse(cur);
   if (m_mf && xg_other() != nullptr) {
-    MfDev md;
-    md.tasks = m_mf_tasks.p;
-    md.fronts = m_mf_fronts.p;
-    md.image = m_mf_image.p;
-    md.image_stride16 = m_mf_image_stride16;
-    md.image_desc = m_mf_image_desc.p;
-    md.n_tasks = static_cast<unsigned int>(l.tasks.size());
-    md.exit_cnt = m_exit_cnt.p;
-    const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
-    // a chained step (sweep_full_for_step): the kernel variant that waits for its sweep itself and whose last
-    // workgroup tells the next step's sweep; the main stream stays "untouched" by a step's own launches
     const bool chained = m_stream.tape_pending;
-    md.chain = chained ? m_chain.p : nullptr;
-    md.wait_step = chained ? m_chain_seq : 0u;
-    md.this_step = m_chain_seq;
-    md.n_workgroups = grid.x;
-    m_stream.tape_pending = false;
-    m_last_step_chained = chained;
-    auto launch = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, m_h_reg, m_Lx.p, m_D.p,
-                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
-    };
-    if (m_mf_threads == 1024) {
-      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, true>, 1024);
-      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, false>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, false>, 1024);
-    } else {
-      if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, true>, 512) : launch(&ldlt_mf_step_kernel<512, false, true>, 512);
-      else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, false>, 512) : launch(&ldlt_mf_step_kernel<512, false, false>, 512);
-    }
-    xg_flip();
-    SLPX_HIP_CHECK(hipGetLastError());
+    m_stats_cur = parity ^ 1;  // (the callers flipped it already; launch_mf_step / book_mf_step do it themselves)
+    launch_mf_step(0, m_h_reg, f, chained, MfGate{});
+    book_mf_step(0, chained);
     return;
   }
   hipLaunchKernelGGL(ldlt_factor_solve_kernel<kFactorThreadsSingle>,
@@ -2115,11 +2243,15 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
         const hipError_t st = hipStreamQuery(m_stream.raw());
         if (st != hipErrorNotReady) {
           SLPX_HIP_CHECK(st);
-          if (*m_h_seq < m_stats_seq) throw std::runtime_error("slpx: step finished without publishing its counters");
+          if (*m_h_seq < m_stats_seq)
+            throw std::runtime_error(m_h_gate != nullptr && m_h_gate[2] == m_gate_ticket
+                                         ? "slpx: a pre-launched step gave up waiting for its gate"
+                                         : "slpx: step finished without publishing its counters");
         }
       }
     }
   } else {
+    m_stream.abort_gate();
     hipError_t st;
     while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
     }
@@ -2452,6 +2584,7 @@ void DeviceNlp::wait_published() {
 }
 
 void DeviceNlp::wait() {
+  m_stream.abort_gate();
   hipError_t st;
   while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
   }

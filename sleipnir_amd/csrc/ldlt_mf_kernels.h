@@ -37,6 +37,7 @@ namespace slpx {
 
 using LdsU16 = __attribute__((address_space(3))) uint16_t;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 struct MfDev {
   const LdltMfTask* tasks = nullptr;
@@ -101,6 +102,55 @@ __device__ __forceinline__ void mf_signal_done(const MfDev& Mf) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// A step launched BEFORE the host knows that it wants it (DeviceNlp::prelaunch_step): the kernel goes
+// through the part of its work that depends on nothing — the image of its plan into LDS, ~3 us — and then waits for
+// the host's word, 16 bytes of pinned memory {mu, 2 x ticket + abort} written with one store: its own ticket
+// lets it through (with the barrier parameter of the step, decided together with the go), the abort bit sends
+// it home without a trace.  From a result in pinned memory to the first instruction of the kernel the host
+// launches because of it are ~7.5 us (profiles/microbench/launch_gap.hip); to a resident kernel's poll seeing the
+// host's store, 3-4.5.  ONE lane of the launch asks the host — a hundred workgroups polling over PCIe make a tail of
+// tens of microseconds in that measurement — and passes the answer on through a word in device memory.
+// ---------------------------------------------------------------------------
+// (struct MfGate: device.hpp)
+// true: go (mu_gate set if the gate carries it); false: leave.  `slot`: 8 bytes of LDS for the workgroup's copy.
+__device__ __forceinline__ bool mf_gate_wait(const MfGate& G, bool asks_host, double* slot, double& mu_gate) {
+  if (threadIdx.x == 0) {
+    unsigned long long lo = 0, hi = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      if (asks_host) {
+        u32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(G.word) : "memory");
+        lo = static_cast<unsigned long long>(v[0]) | (static_cast<unsigned long long>(v[1]) << 32);
+        hi = static_cast<unsigned long long>(v[2]) | (static_cast<unsigned long long>(v[3]) << 32);
+      } else {
+        hi = __hip_atomic_load(G.relay + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((hi >> 1) == G.ticket) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 300000000ull) {  // 3 s at 100 MHz: the host forgot this launch
+        hi = 2ull * G.ticket + 1ull;
+        if (asks_host && G.abandoned != nullptr) *G.abandoned = G.ticket;
+        break;
+      }
+    }
+    if (asks_host) {
+      __hip_atomic_store(G.relay, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);  // (mu before the word the others wait for)
+      __hip_atomic_store(G.relay + 1, hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if ((hi & 1ull) == 0 && G.mu_out != nullptr) G.mu_out[0] = __longlong_as_double(static_cast<long long>(lo));
+    } else {
+      lo = __hip_atomic_load(G.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    slot[0] = (hi & 1ull) ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double(static_cast<long long>(lo));
+    if ((hi & 1ull) == 0 && G.mu_out == nullptr) slot[0] = 0.0;
+  }
+  __syncthreads();
+  mu_gate = slot[0];
+  return mu_gate == mu_gate;
+}
+
 // LDS by byte address (what the tables hold)
 __device__ __forceinline__ double lds_ld(uint32_t addr) { return *reinterpret_cast<const LdsF64*>(static_cast<uintptr_t>(addr)); }
 __device__ __forceinline__ void lds_st(uint32_t addr, double v) { *reinterpret_cast<LdsF64*>(static_cast<uintptr_t>(addr)) = v; }
@@ -113,7 +163,6 @@ __device__ __forceinline__ uint32_t lds_ld16(uint32_t addr) { return *reinterpre
 // that the registers are written asynchronously, and a copy or spill of them between a separate load
 // and its wait would take the stale contents (seen: a memory fault).  A wave asks for the descriptor
 // of its front in the NEXT level at the end of this level's work, in front of the barrier.
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 __device__ __forceinline__ u32x4 s_load_desc(const LdltFront* p) {
   u32x4 r;
 #ifdef MF_DESC_VECTOR
@@ -510,9 +559,11 @@ __device__ __forceinline__ void mf_step_body(
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, const KktFuse& F, double* __restrict__ xg,
     double* __restrict__ xg_next, double* __restrict__ out, const BacksubFuse& B, uint32_t block, unsigned int exit_total,
-    const LdltStats* twin_stats) {
+    const LdltStats* twin_stats, const MfGate& G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double mu_gate = 0.0;
   if (static_cast<int>(block) < F.n_blocks) {
+    if (G.word != nullptr && !mf_gate_wait(G, blockIdx.x == 0, reinterpret_cast<double*>(smem_raw), mu_gate)) return;
     if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
     ride_along_sum(F, block, smem_raw);
     if constexpr (CHAINED) mf_signal_done(Mf);
@@ -521,13 +572,22 @@ __device__ __forceinline__ void mf_step_body(
   const int tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t task_index = block - static_cast<uint32_t>(F.n_blocks);
+#ifdef SLPX_GATE_STAMPS
+  unsigned long long stamp_in = 0, stamp_staged = 0;
+  const bool stamps = task_index == 0 && blockIdx.x == block && tid == 0;  // (the first attempt's first task)
+  if (stamps) {
+    stamp_in = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[8], stamp_in - slpx_gate_stamps[0]);
+    atomicAdd(&slpx_gate_stamps[13], stamp_in - slpx_gate_stamps[1]);
+    atomicAdd(&slpx_gate_stamps[15], 1ull);
+  }
+#endif
 #ifdef SLPX_CHAIN_STAMPS
   if (CHAINED && Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
 #endif
   const LdltTask t = L.tasks[task_index];
   const LdltMfTask m = Mf.tasks[task_index];
   const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
-  if (stats_next != nullptr && task_index == 0 && tid == 0) stats_next[0] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   const double delta = reg[0], gamma = reg[1];
   SLPX_LDLT_CLOCK(0);
   const MfCarve cv = mf_carve(t, m);
@@ -579,6 +639,21 @@ __device__ __forceinline__ void mf_step_body(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(1);
+#ifdef SLPX_GATE_STAMPS
+  if (stamps) {
+    stamp_staged = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[9], stamp_staged - stamp_in);
+  }
+#endif
+  // a pre-launched step: everything up to here depended on nothing; the host's word (mf_gate_wait)
+  if (G.word != nullptr && !mf_gate_wait(G, blockIdx.x == 0, reinterpret_cast<double*>(smem_raw + cv.o_cnt + 24u), mu_gate)) return;
+#ifdef SLPX_GATE_STAMPS
+  if (stamps) {
+    slpx_gate_stamps[2] = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[10], slpx_gate_stamps[2] - stamp_staged);
+  }
+#endif
+  if (stats_next != nullptr && task_index == 0 && tid == 0) stats_next[0] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
 
   // ---- matrix values (ldlt_factor_body) ----
@@ -591,7 +666,7 @@ __device__ __forceinline__ void mf_step_body(
       U[i] = s0 >= 0 ? base[s0] : 0.0;
     }
   } else {
-    const double mu = F.mu[0];
+    const double mu = G.mu_out != nullptr ? mu_gate : F.mu[0];
     const KktTerm* terms = reinterpret_cast<const KktTerm*>(s_terms);
     const uint32_t span = n_terms > t.n_ent ? n_terms : t.n_ent;
     for (uint32_t k = tid; k < span; k += THREADS) {
@@ -728,6 +803,7 @@ __device__ __forceinline__ void mf_step_body(
         if (B.stats_host != nullptr) {
           if (twin_stats != nullptr) publish_stats_copy(twin_stats, B.stats_host + 1);
           publish_stats(B, true);
+          SLPX_GATE_STAMP_ADD(11, slpx_gate_stamps[2]);
         }
       }
     }
@@ -815,7 +891,7 @@ __device__ __forceinline__ void mf_step_body(
     coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
   for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
   if (B.on) {
-    const double mu = B.mu[0];
+    const double mu = G.mu_out != nullptr ? mu_gate : B.mu[0];
     auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
     for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
       const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
@@ -857,9 +933,9 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfGate G) {
   mf_step_body<THREADS, MFMA, CHAINED>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B,
-                                       blockIdx.x, Mf.n_tasks, nullptr);
+                                       blockIdx.x, Mf.n_tasks, nullptr, G);
 }
 
 // ---------------------------------------------------------------------------
@@ -888,7 +964,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T, MfGate G) {
   uint32_t block = blockIdx.x;
   if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
     block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
@@ -907,7 +983,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
   }
   mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
-                                      2u * Mf.n_tasks, T.stats);
+                                      2u * Mf.n_tasks, T.stats, G);
 }
 
 // ---------------------------------------------------------------------------

@@ -225,16 +225,31 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   // counters: the device never idles through the host round trip, and in the usual case
   // (first attempt accepted) the step is complete when the counters arrive.  A rejected
   // attempt just has its solve overwritten by the next one.
+  bool first_launch = true;
   auto factor_once = [&](const std::vector<double>& d, const std::vector<double>& g,
                          const std::vector<uint8_t>& a) {
+    const bool first = first_launch;
+    first_launch = false;
+    // a step kernel launched ahead waits at its gate (prelaunch_next_step): this compute()'s first attempt, if it
+    // was launched with what the attempt is made with — anything else sends it home
+    bool opened = false;
+    if (m_dev->gate_pending()) {
+      if (first && B == 1 && mode == 1 && m_pre.twin_mode == 0 && d[0] == m_pre.reg[0] && g[0] == m_pre.reg[1]) {
+        m_dev->open_gate(std::numeric_limits<double>::quiet_NaN());
+        opened = true;
+      } else {
+        m_dev->abort_gate();
+      }
+    }
     if (graph_pending) {
       graph_pending = false;
       m_dev->launch_step_graph(refresh_ad, d, g, a);
       return;
     }
     if (solve_speculatively) {
-      m_dev->factor_solve_publish(d, g, a);
+      if (!opened) m_dev->factor_solve_publish(d, g, a);
       if (m_after_attempt) m_after_attempt();
+      if (first && m_pipeline && B == 1 && mode == 1) prelaunch_next_step(d[0], g[0]);
     } else {
       m_dev->factor(d, g, a);
     }
@@ -364,8 +379,23 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
   LdltStats first{}, second{};
   bool have_second = false;
   // one launch: (d0, g0) and, if the device can, (d1, g1) beside it
+  bool first_launch = true;
   auto launch = [&](double d0, double g0, double d1, double g1, int mode) {
-    have_second = m_dev->factor_solve_publish_twin(d0, g0, d1, g1, mode);
+    // (a later launch of the loop evaluates the system from V again, inside the launch, like the first — the
+    // caller's system IS the one V, s, y, z describe, set_twin_attempts — instead of two assembly launches first)
+    if (!first_launch) m_dev->build_kkt_for_step(/*with_reduce=*/false);
+    first_launch = false;
+    have_second = false;
+    if (m_dev->gate_pending()) {  // the step launched ahead (prelaunch_twin_step), if it is this one
+      if (m_pre.twin_mode == mode && m_pre.reg[0] == d0 && m_pre.reg[1] == g0 && m_pre.reg[2] == d1 && m_pre.reg[3] == g1) {
+        m_dev->open_gate(m_step_mu);
+        have_second = true;
+      } else {
+        m_dev->abort_gate();
+        if (m_step_mu == m_step_mu) m_dev->upload_mu(&m_step_mu);  // (it was to travel through the gate)
+      }
+    }
+    if (!have_second) have_second = m_dev->factor_solve_publish_twin(d0, g0, d1, g1, mode);
     if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
     else ++m_last_twin_launches;
     if (m_after_attempt) m_after_attempt();
@@ -374,11 +404,13 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     if (have_second) {
       second = m_dev->read_twin_stats();
       const bool first_good = good(first) && (mode != 2 || min_abs(first) >= 1e-4);
+      const bool neg = first.n_neg > m_e;
+      const bool second_stands = mode == 2 || (mode == 1 && neg) || (mode == 3 && !neg);
       const int kind = first_good ? 0
                        : first.n_bad != 0 ? 5
                        : first.n_zero > 0 ? 3
-                       : first.n_neg > m_e ? (good(second) ? 1 : 2)
-                                           : 4;
+                       : second_stands ? (good(second) ? 1 : 2)
+                                       : 4;
       ++m_twin_hist[kind];
     }
   };
@@ -392,8 +424,10 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     return info;
   };
   // the loop's answer to a failed attempt (:114-141); true: it was "too many negative pivots"
+  // (returns which of the loop's answers it was: 1 too many negative pivots, 3 too many positive — the numbers of
+  // the launch modes whose second attempt stands for that answer, IpmTwin::mode —, 0 anything else)
   auto advance = [&](const LdltStats& st, double& d, double& g) {
-    bool negative_pivots = false;
+    int answer = 0;
     if (st.n_bad == 0) {
       if (st.n_zero > 0) {
         if (g == 0.0) {
@@ -404,15 +438,16 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
         }
       } else if (st.n_neg > m_e) {
         d *= 10.0;
-        negative_pivots = true;
+        answer = 1;
       } else if (st.n_pos > n) {
         g = g == 0.0 ? 1e-10 : g * 10.0;
+        answer = 3;
       }
     } else {
       d *= 10.0;
       g = g == 0.0 ? 1e-10 : g * 10.0;
     }
-    return negative_pivots;
+    return answer;
   };
   auto gave_up = [&](double d, double g) {  // :145-150
     if (!(d > 1e20 || g > 1e20)) return false;
@@ -432,14 +467,26 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     if (good(first) && min_abs(first) >= 1e-4) return accept(0.0, 0.0, false);
     second_is_current = have_second;
   }
+  // Which answer the second attempt of a launch stands for: the one the loop's first attempt drew in the LAST
+  // compute() (a phase of the solve that needs a larger gamma needs it iteration after iteration — the loop starts
+  // from gamma_min every time, :102), too many negative pivots otherwise and for the later launches of a loop.
+  int expect = m_twin_expect;
+  bool loop_first = true;
   while (true) {
     if (!second_is_current) {
-      launch(d, g, d * 10.0, g, 1);
+      if (expect == 3) launch(d, g, d, g == 0.0 ? 1e-10 : g * 10.0, 3);
+      else launch(d, g, d * 10.0, g, 1);
       ++m_last_factorizations;
-      if (good(first)) return accept(d, g, false);
-      const bool negative_pivots = advance(first, d, g);
+      if (good(first)) {
+        if (loop_first) m_twin_expect = 1;
+        return accept(d, g, false);
+      }
+      const int answer = advance(first, d, g);
+      if (loop_first && answer != 0) m_twin_expect = answer;
+      loop_first = false;
       if (gave_up(d, g)) return info;
-      second_is_current = have_second && negative_pivots;  // (d, g) is now what the second attempt was made with
+      second_is_current = have_second && answer == expect;  // (d, g) is now what the second attempt was made with
+      expect = 1;
       if (!second_is_current) continue;
     }
     second_is_current = false;
@@ -449,6 +496,49 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     if (gave_up(d, g)) return info;
   }
 }
+
+// The first launch of the next compute(), assuming this one's attempt (delta_now, gamma_now) is accepted.
+static void first_attempt_after(double prev_delta, double gamma_min, bool skip_first, double out[2]) {
+  if (!skip_first) {
+    out[0] = out[1] = 0.0;  // :74
+    return;
+  }
+  out[0] = prev_delta == 0.0 ? 1e-4 : std::max(prev_delta / 2.0, std::numeric_limits<double>::epsilon());  // :95-98
+  out[1] = gamma_min;                                                                                          // :102
+}
+
+void NewtonSystem::prelaunch_next_step(double delta_now, double gamma_now) {
+  (void)gamma_now;
+  if (!m_dev->can_prelaunch(0)) return;
+  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
+  m_pre = PreStep{};
+  m_pre.refresh_ad = true;
+  first_attempt_after(m_pipeline_forget ? 0.0 : delta_now, m_gamma_min, skip_first, m_pre.reg);
+  m_dev->sweep_full_for_step();
+  m_dev->prelaunch_step(0, m_pre.reg, /*kkt_mode=*/2, /*mu_through_gate=*/false, /*lookahead_roles=*/false);
+}
+
+bool NewtonSystem::prelaunch_twin_step() {
+  if (!m_dev->can_prelaunch(1)) return false;
+  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
+  double guess[2];
+  first_attempt_after(m_prev_delta[0], m_gamma_min, /*skip_first=*/true, guess);
+  m_pre = PreStep{};
+  if (skip_first) {  // compute_twin's first launch: the guess and its delta x 10 ...
+    m_pre.twin_mode = m_twin_expect == 3 ? 3 : 1;
+    m_pre.reg[0] = guess[0];
+    m_pre.reg[1] = guess[1];
+    m_pre.reg[2] = m_twin_expect == 3 ? guess[0] : guess[0] * 10.0;
+    m_pre.reg[3] = m_twin_expect == 3 ? (guess[1] == 0.0 ? 1e-10 : guess[1] * 10.0) : guess[1];
+  } else {  // ... or the unregularized attempt and the guess
+    m_pre.twin_mode = 2;
+    m_pre.reg[2] = guess[0];
+    m_pre.reg[3] = guess[1];
+  }
+  return m_dev->prelaunch_step(m_pre.twin_mode, m_pre.reg, /*kkt_mode=*/1, /*mu_through_gate=*/true, /*lookahead_roles=*/true);
+}
+
+void NewtonSystem::cancel_prelaunch() { m_dev->abort_gate(); }
 
 bool NewtonSystem::factor_unregularized() {
   const int B = m_opt.batch;
@@ -469,10 +559,14 @@ std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
   // SLPX_HOST_TIMING=1: where the host's time per step goes (printed every 1000 steps)
   static const bool timing = std::getenv("SLPX_HOST_TIMING") != nullptr;
   if (!timing) {
+    // (this step's sweep and kernel went out behind the last step's: compute() opens the gate)
+    if (m_dev->gate_pending() && m_pre.twin_mode == 0 && m_pre.refresh_ad == refresh_ad) return compute(/*solve_speculatively=*/true);
+    m_dev->abort_gate();
     if (refresh_ad) m_dev->sweep_full_for_step();
     m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
     return compute(/*solve_speculatively=*/true);
   }
+  m_dev->abort_gate();
   using clk = std::chrono::steady_clock;
   static double t_sweep = 0, t_rest = 0;
   static long n = 0;

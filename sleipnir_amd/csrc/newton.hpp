@@ -10,6 +10,7 @@
 #pragma once
 
 #include <functional>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -102,10 +103,24 @@ class NewtonSystem {
   void set_after_attempt(std::function<void()> fn) { m_after_attempt = std::move(fn); }
   // Twin attempts (DeviceNlp::factor_solve_publish_twin): compute(solve_speculatively) factors the policy's
   // attempt and the one that would follow it in one launch.  Only for a caller whose after_attempt work takes the
-  // direction of whichever attempt the policy takes ON THE DEVICE (DeviceNlp::ipm_lookahead does).
+  // direction of whichever attempt the policy takes ON THE DEVICE (DeviceNlp::ipm_lookahead does), and whose system is
+  // the one the device's V, s, y, z describe (build_kkt_for_step — later launches of the loop evaluate it again).
   void set_twin_attempts(bool on) { m_twin_attempts = on; }
-  // launches with two attempts since construction, by what the first attempt showed: accepted; too many negative
-  // pivots and the second accepted / not; zero pivots; too many positive; the factorization itself failed
+  // Steps launched ahead (MfGate).  set_pipeline: newton_step(true) launches the NEXT step's sweep and step kernel
+  // as soon as its own are out — the kernel waits, its plan staged, for the host to have seen this step's verdict
+  // (slpx_newton_steps: all but the last of a run; `forget`: the caller clears the regularization memory between
+  // steps).  prelaunch_twin_step: the interior-point iteration's next step, after compute() returned, on the
+  // look-ahead iterate; set_step_mu: the barrier parameter the next compute()'s step takes through the gate.
+  void set_pipeline(bool on, bool forget_regularization) {
+    m_pipeline = on;
+    m_pipeline_forget = forget_regularization;
+  }
+  bool prelaunch_twin_step();
+  void set_step_mu(double mu) { m_step_mu = mu; }
+  void cancel_prelaunch();
+  // launches with two attempts since construction, by what the first attempt showed: accepted; the failure the
+  // second attempt stood for, and the second accepted / not; zero pivots; the other inertia failure; the
+  // factorization itself failed
   const long* twin_histogram() const { return m_twin_hist; }
   int last_twin_launches() const { return m_last_twin_launches; }   // step launches of the last compute() that held two attempts
   int last_twin_taken() const { return m_last_twin_taken; }         // ... whose second attempt the policy took
@@ -128,9 +143,19 @@ class NewtonSystem {
   std::vector<double> m_prev_delta, m_prev_gamma;
   int m_last_factorizations = 0;
   std::function<void()> m_after_attempt;
+  // a step kernel launched ahead (DeviceNlp::prelaunch_step): what it was launched with
+  struct PreStep {
+    bool refresh_ad = false;
+    int twin_mode = 0;
+    double reg[4] = {0, 0, 0, 0};
+  } m_pre;
+  bool m_pipeline = false, m_pipeline_forget = false;
+  double m_step_mu = std::numeric_limits<double>::quiet_NaN();
+  void prelaunch_next_step(double delta_now, double gamma_now);
   bool m_twin_attempts = false;
   int m_last_twin_launches = 0, m_last_twin_taken = 0;
   long m_twin_hist[6] = {0, 0, 0, 0, 0, 0};
+  int m_twin_expect = 1;  // what the loop's first attempt drew last time (compute_twin): 1 negative pivots, 3 positive
   std::vector<FactorInfo> compute_twin();
   std::vector<int32_t> m_user_lhs_map;
 };

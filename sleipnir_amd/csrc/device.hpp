@@ -229,6 +229,30 @@ struct BacksubFuse {
   volatile unsigned long long* seq_host = nullptr;
 };
 
+struct IpmDirOut;
+// the second attempt of a twin launch (ldlt_mf_twin_kernel), for the launch that takes the direction
+struct IpmTwin {
+  int mode = 0;  // 0: one attempt; 1: the policy loop's attempt and its delta x 10; 2: the unregularized attempt and the first guess; 3: the loop's attempt and its gamma x 10
+  const double *p = nullptr, *ps = nullptr, *pz = nullptr;
+  const LdltStats* stats = nullptr;
+};
+// ipm_lookahead_body (ipm_kernels.h): step sizes of the direction and the whole look-ahead iterate — a launch of
+// its own (ipm_lookahead_kernel), or (on) the last act of the step kernel's launch: the workgroup that is through
+// last, of all attempts, does it (done_cnt), one kernel boundary less per iteration.
+struct IpmLookaheadArgs {
+  int on = 0;
+  int n = 0, m_e = 0, m_i = 0;
+  const int32_t* g_src = nullptr;
+  const double *V = nullptr, *in = nullptr, *s = nullptr, *y = nullptr, *z = nullptr, *p = nullptr, *ps = nullptr, *pz = nullptr,
+               *mu = nullptr;
+  double tau = 0.0;
+  double *in_t = nullptr, *s_t = nullptr, *y_t = nullptr, *z_t = nullptr, *alpha_dev = nullptr;
+  IpmDirOut* out = nullptr;
+  const LdltStats* stats = nullptr;
+  IpmTwin tw;
+  unsigned int* done_cnt = nullptr;
+};
+
 // A pre-launched step's gate (ldlt_mf_kernels.h: mf_gate_wait; DeviceNlp::prelaunch_step)
 struct MfGate {
   const unsigned long long* word = nullptr;  // pinned, 16-byte aligned; nullptr: no gate
@@ -438,6 +462,9 @@ class DeviceNlp {
   // interior_point.hpp:797-801 — in a second set of buffers, swept (values AND derivatives) and reduced to
   // IpmHost::err_ahead speculatively; when the filter accepts that trial point the buffers change roles
   // (ipm_accept_lookahead: no launch) and the iteration is complete after ONE host round trip.
+  // ipm_lookahead() as the last act of every step launch from now on (tau < 0: off again): the launches made
+  // while it is on carry the look-ahead (IpmLookaheadArgs), and ipm_lookahead() after such a launch launches nothing
+  void ipm_lookahead_rides(double tau);
   void ipm_lookahead(double tau);             // step sizes, D_phi -> IpmHost::dir; the look-ahead iterate
   void sweep_full_lookahead();                // the full tape at it, into the look-ahead V (sums ride in ipm_errors)
   void ipm_accept_lookahead();                // the look-ahead iterate and its V become the current ones
@@ -596,6 +623,11 @@ class DeviceNlp {
   KktFuse kkt_fuse_for(int kkt_mode) const;
   void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const MfGate& gate);
   void book_mf_step(int twin_mode, bool chained);
+  double m_la_tau = -1.0;  // >= 0: the look-ahead rides in the step launches (ipm_lookahead_rides)
+  bool m_la_rode = false;  // ... and did in the last one
+  int m_la_state = 0;      // 0: not looked at yet, 1: allowed (SLPX_IPM_LOOKAHEAD_RIDE=1), -1: not
+  DevBuf<unsigned int> m_la_done;
+  IpmLookaheadArgs lookahead_args(double tau, int twin_mode);
   int m_twin_state = 0;  // 0: not looked at yet, 1: available, -1: not (not resident at once, SLPX_TWIN=0, ...)
   int m_twin_mode = 0;   // of the step launch in flight (IpmTwin::mode; 0: a single attempt)
   DevBuf<double> m_Lx_tw, m_D_tw, m_zv_tw, m_p_tw, m_ps_tw, m_pz_tw, m_mf_contrib_tw, m_xg_tw, m_xg2_tw;

@@ -626,6 +626,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   const bool prelaunch = prelaunch_env != nullptr && prelaunch_env[0] == '1';  // (off unless asked for)
   auto finish = [&](ExitStatus st_) {
     sys.cancel_prelaunch();
+    dev.ipm_lookahead_rides(-1.0);
     sys.set_after_attempt(nullptr);
     pull_state();
     if (std::getenv("SLPX_TWIN_VERBOSE")) {
@@ -740,7 +741,10 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // launch's two attempts the regularization policy takes — the other after_attempt chain does not)
     sys.set_twin_attempts(ahead);
     if (dev.gate_pending()) ++prelaunch_used;
+    // (the look-ahead iterate as the last act of the step launches themselves: DeviceNlp::ipm_lookahead_rides)
+    if (ahead) dev.ipm_lookahead_rides(tau);
     auto info = sys.compute(/*solve_speculatively=*/true);
+    dev.ipm_lookahead_rides(-1.0);
     sys.set_twin_attempts(false);
     sys.set_after_attempt(nullptr);
     twin_launches += sys.last_twin_launches();

@@ -142,78 +142,85 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
 // written to a SECOND set of buffers (`in_t` = [x | y | z] as the tape reads it, s_t, y_t, z_t) instead of
 // over the current one.  The full tape and the error reductions run on those next (DeviceNlp::
 // ipm_lookahead); if the filter takes the point the buffers swap roles and nothing is recomputed.
-// the second attempt of a twin launch (ldlt_mf_twin_kernel), for the launch that takes the direction
-struct IpmTwin {
-  int mode = 0;  // 0: one attempt; 1: the policy loop's attempt and its delta x 10; 2: the unregularized attempt and the first guess; 3: the loop's attempt and its gamma x 10
-  const double *p = nullptr, *ps = nullptr, *pz = nullptr;
-  const LdltStats* stats = nullptr;
-};
-
-__global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
-    KktDev K, const double* __restrict__ V, const double* __restrict__ in, const double* __restrict__ s,
-    const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ p,
-    const double* __restrict__ ps, const double* __restrict__ pz, const double* __restrict__ mu_dev, double tau,
-    double* __restrict__ in_t, double* __restrict__ s_t, double* __restrict__ y_t, double* __restrict__ z_t,
-    double* __restrict__ alpha_dev, IpmDirOut* __restrict__ out, const LdltStats* __restrict__ stats, IpmTwin tw) {
-  __shared__ double scratch[17 * 3];
+// (struct IpmTwin, struct IpmLookaheadArgs: device.hpp)
+// IN_LAUNCH: the body runs as the last act of the step kernel's launch (mf_step_body) — the direction and the
+// counters were written by other workgroups of this launch and are read past the caches.
+template <int THREADS, bool IN_LAUNCH>
+__device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* scratch) {
   const int tid = threadIdx.x;
+  auto ld = [](const double* q) { return IN_LAUNCH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q; };
+  auto ld_stats = [](const LdltStats* q) {
+    if (!IN_LAUNCH) return q[0];
+    LdltStats st;
+    const int* src = reinterpret_cast<const int*>(q);
+    st.n_pos = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_neg = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_zero = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.n_bad = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st.min_abs_bits = __hip_atomic_load(&q->min_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return st;
+  };
+  const int n = A.n, m_e = A.m_e, m_i = A.m_i;
+  const double *p = A.p, *ps = A.ps, *pz = A.pz;
   // The factorization this direction comes from has the wrong inertia (or failed): the policy loop will
   // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
   // (one lane-uniform 16-byte load, issued with the others below)
 #ifdef SLPX_GATE_STAMPS
   if (tid == 0) SLPX_GATE_STAMP_ADD(12, slpx_gate_stamps[1]);
 #endif
-  const LdltStats st = stats[0];
-  bool wrong = st.n_bad != 0 || st.n_pos != K.n || st.n_neg != K.m_e || st.n_zero != 0;
-  if (tw.mode != 0) {
+  const LdltStats st = ld_stats(A.stats);
+  bool wrong = st.n_bad != 0 || st.n_pos != n || st.n_neg != m_e || st.n_zero != 0;
+  if (A.tw.mode != 0) {
     // A twin attempt (ldlt_mf_twin_kernel): the policy's choice between the two, from the same counters the host
     // reads (NewtonSystem::compute_impl — keep the two in step).  The second attempt stands for the policy's next
     // one only if the first failed the way that leads to it: beside the unregularized attempt (mode 2) any failure
     // does (:82-102, also a pivot below 1e-4); in the loop too many negative pivots (mode 1: delta x 10, :127-130) or too
     // many positive ones (mode 3: gamma x 10, :131-135), nothing else.
-    const LdltStats st2 = tw.stats[0];
-    if (tw.mode == 2 && !wrong && __longlong_as_double(static_cast<long long>(st.min_abs_bits)) < 1e-4) wrong = true;
+    const LdltStats st2 = ld_stats(A.tw.stats);
+    if (A.tw.mode == 2 && !wrong && __longlong_as_double(static_cast<long long>(st.min_abs_bits)) < 1e-4) wrong = true;
     const bool inertia_only = st.n_bad == 0 && st.n_zero == 0;
-    const bool leads_to_second = tw.mode == 2 || (tw.mode == 1 && inertia_only && st.n_neg > K.m_e) ||
-                                 (tw.mode == 3 && inertia_only && st.n_neg <= K.m_e && st.n_pos > K.n);
-    const bool second_good = st2.n_bad == 0 && st2.n_pos == K.n && st2.n_neg == K.m_e && st2.n_zero == 0;
+    const bool leads_to_second = A.tw.mode == 2 || (A.tw.mode == 1 && inertia_only && st.n_neg > m_e) ||
+                                 (A.tw.mode == 3 && inertia_only && st.n_neg <= m_e && st.n_pos > n);
+    const bool second_good = st2.n_bad == 0 && st2.n_pos == n && st2.n_neg == m_e && st2.n_zero == 0;
     if (wrong && leads_to_second && second_good) {
       wrong = false;
-      p = tw.p;
-      ps = tw.ps;
-      pz = tw.pz;
+      p = A.tw.p;
+      ps = A.tw.ps;
+      pz = A.tw.pz;
     }
   }
-  if (tid == 0) alpha_dev[2] = wrong ? 1.0 : 0.0;
+  if (tid == 0) A.alpha_dev[2] = wrong ? 1.0 : 0.0;
   if (wrong) return;
-  const double mu = mu_dev[0];
+  const double mu = A.mu[0], tau = A.tau;
+  const double *V = A.V, *in = A.in, *s = A.s, *y = A.y, *z = A.z;
+  double *in_t = A.in_t, *s_t = A.s_t, *y_t = A.y_t, *z_t = A.z_t;
   double acc[3] = {1.0, 1.0, 0.0};  // alpha_max, alpha_z, D_phi
   // Systems of up to kPre x 1024 rows (every BASELINE horizon): EVERYTHING the kernel reads is requested before the
   // reduction — the iterate and the direction for the second pass too — so that the launch is two trips to memory
   // (g's sources, then the values) instead of four; a trip after a kernel boundary is ~1 us.
   constexpr int kPre = 5;
-  if (K.n <= kPre * kIpmThreads && K.m_e <= kPre * kIpmThreads && K.m_i <= kPre * kIpmThreads) {
+  if (THREADS == kIpmThreads && n <= kPre * THREADS && m_e <= kPre * THREADS && m_i <= kPre * THREADS) {
     double xs[kPre], px[kPre], ys[kPre], py[kPre], ss[kPre], pss[kPre], zs[kPre], pzs[kPre], gv[kPre];
     int gs[kPre];
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
-      const int j = tid + k * kIpmThreads;
-      gs[k] = j < K.n ? K.g_src[j] : -1;
-      xs[k] = j < K.n ? in[j] : 0.0;
-      px[k] = j < K.n ? p[j] : 0.0;
-      ys[k] = j < K.m_e ? y[j] : 0.0;
-      py[k] = j < K.m_e ? p[K.n + j] : 0.0;
-      ss[k] = j < K.m_i ? s[j] : 1.0;
-      pss[k] = j < K.m_i ? ps[j] : 0.0;
-      zs[k] = j < K.m_i ? z[j] : 1.0;
-      pzs[k] = j < K.m_i ? pz[j] : 0.0;
+      const int j = tid + k * THREADS;
+      gs[k] = j < n ? A.g_src[j] : -1;
+      xs[k] = j < n ? in[j] : 0.0;
+      px[k] = j < n ? ld(p + j) : 0.0;
+      ys[k] = j < m_e ? y[j] : 0.0;
+      py[k] = j < m_e ? ld(p + n + j) : 0.0;
+      ss[k] = j < m_i ? s[j] : 1.0;
+      pss[k] = j < m_i ? ld(ps + j) : 0.0;
+      zs[k] = j < m_i ? z[j] : 1.0;
+      pzs[k] = j < m_i ? ld(pz + j) : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < kPre; ++k) gv[k] = gs[k] >= 0 ? V[gs[k]] : 0.0;
     // (the same order of accumulation as the loops below: rows r = tid, tid + 1024, ...; then the columns)
 #pragma unroll
     for (int k = 0; k < kPre; ++k)
-      if (tid + k * kIpmThreads < K.m_i) {
+      if (tid + k * THREADS < m_i) {
         if (pss[k] < 0.0) acc[0] = fmin(acc[0], -tau / pss[k] * ss[k]);
         if (pzs[k] < 0.0) acc[1] = fmin(acc[1], -tau / pzs[k] * zs[k]);
         acc[2] -= mu * ((1.0 / ss[k]) * pss[k]);
@@ -222,18 +229,18 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
     for (int k = 0; k < kPre; ++k)
       if (gs[k] >= 0) acc[2] += gv[k] * px[k];
     const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
-    block_reduce<3, kIpmThreads>(acc, ops, scratch);
+    block_reduce<3, THREADS>(acc, ops, scratch);
     const double alpha = acc[0], alpha_z = acc[1];
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
-      const int j = tid + k * kIpmThreads;
-      if (j < K.n) in_t[j] = xs[k] + alpha * px[k];
-      if (j < K.m_e) {
+      const int j = tid + k * THREADS;
+      if (j < n) in_t[j] = xs[k] + alpha * px[k];
+      if (j < m_e) {
         const double v = ys[k] + alpha_z * (-py[k]);
         y_t[j] = v;
-        in_t[K.n + j] = v;
+        in_t[n + j] = v;
       }
-      if (j < K.m_i) {
+      if (j < m_i) {
         const double sn = ss[k] + alpha * pss[k];
         double zn = zs[k] + alpha_z * pzs[k];
         constexpr double kappa = 1e10;
@@ -241,47 +248,52 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(
         zn = zn < lo ? lo : (zn > hi ? hi : zn);
         s_t[j] = sn;
         z_t[j] = zn;
-        in_t[K.n + K.m_e + j] = zn;
+        in_t[n + m_e + j] = zn;
       }
     }
   } else {
-    for (int r = tid; r < K.m_i; r += kIpmThreads) {
-      const double sr = s[r], psr = ps[r], zr = z[r], pzr = pz[r];
+    for (int r = tid; r < m_i; r += THREADS) {
+      const double sr = s[r], psr = ld(ps + r), zr = z[r], pzr = ld(pz + r);
       if (psr < 0.0) acc[0] = fmin(acc[0], -tau / psr * sr);
       if (pzr < 0.0) acc[1] = fmin(acc[1], -tau / pzr * zr);
       acc[2] -= mu * ((1.0 / sr) * psr);
     }
-    for (int j = tid; j < K.n; j += kIpmThreads) {
-      const int gs = K.g_src[j];
-      if (gs >= 0) acc[2] += V[gs] * p[j];
+    for (int j = tid; j < n; j += THREADS) {
+      const int gs = A.g_src[j];
+      if (gs >= 0) acc[2] += V[gs] * ld(p + j);
     }
     const int ops[3] = {IPM_MIN, IPM_MIN, IPM_SUM};
-    block_reduce<3, kIpmThreads>(acc, ops, scratch);
+    block_reduce<3, THREADS>(acc, ops, scratch);
     const double alpha = acc[0], alpha_z = acc[1];
-    for (int j = tid; j < K.n; j += kIpmThreads) in_t[j] = in[j] + alpha * p[j];
-    for (int r = tid; r < K.m_e; r += kIpmThreads) {
-      const double v = y[r] + alpha_z * (-p[K.n + r]);
+    for (int j = tid; j < n; j += THREADS) in_t[j] = in[j] + alpha * ld(p + j);
+    for (int r = tid; r < m_e; r += THREADS) {
+      const double v = y[r] + alpha_z * (-ld(p + n + r));
       y_t[r] = v;
-      in_t[K.n + r] = v;
+      in_t[n + r] = v;
     }
-    for (int r = tid; r < K.m_i; r += kIpmThreads) {
-      const double sn = s[r] + alpha * ps[r];
-      double zn = z[r] + alpha_z * pz[r];
+    for (int r = tid; r < m_i; r += THREADS) {
+      const double sn = s[r] + alpha * ld(ps + r);
+      double zn = z[r] + alpha_z * ld(pz + r);
       constexpr double kappa = 1e10;
       const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
       zn = zn < lo ? lo : (zn > hi ? hi : zn);
       s_t[r] = sn;
       z_t[r] = zn;
-      in_t[K.n + K.m_e + r] = zn;
+      in_t[n + m_e + r] = zn;
     }
   }
   if (tid == 0) {
-    alpha_dev[0] = acc[0];
-    alpha_dev[1] = acc[1];
-    out->alpha_max = acc[0];
-    out->alpha_z = acc[1];
-    out->D_phi = acc[2];
+    A.alpha_dev[0] = acc[0];
+    A.alpha_dev[1] = acc[1];
+    A.out->alpha_max = acc[0];
+    A.out->alpha_z = acc[1];
+    A.out->D_phi = acc[2];
   }
+}
+
+__global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(IpmLookaheadArgs A) {
+  __shared__ double scratch[17 * 3];
+  ipm_lookahead_body<kIpmThreads, false>(A, scratch);
 }
 
 // trial_x = x + alpha p_x (backtracking)

@@ -1953,6 +1953,7 @@ void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std
     return;
   }
   m_stream.abort_gate();
+  m_la_rode = false;
   write_reg(delta, gamma, active);
   m_twin_mode = 0;
   m_stats_cur ^= 1;
@@ -2018,6 +2019,18 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
   md.chain = chained ? m_chain.p : nullptr;
   md.wait_step = chained ? m_chain_seq : 0u;
   md.this_step = m_chain_seq;
+  // the look-ahead iterate as the launch's last act (ipm_lookahead_rides; not in a launch held at a gate: tau is
+  // the host's to decide)
+  IpmLookaheadArgs la;
+  m_la_rode = false;
+  if (m_la_tau >= 0.0 && gate.word == nullptr && m_ipm_alpha.p != nullptr && m_batch == 1) {
+    la = lookahead_args(m_la_tau, twin_mode);
+    la.on = 1;
+    la.stats = cur;
+    if (twin_mode != 0) la.tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur ^ 1);
+    la.done_cnt = m_la_done.p;
+    m_la_rode = true;
+  }
   if (twin_mode != 0) {
     const int tw_parity = m_stats_tw_cur ^ 1;
     MfTwin tw;
@@ -2038,7 +2051,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p, l.n,
-                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, gate);
+                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, gate, la);
     };
     if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
     else launch(&ldlt_mf_twin_kernel<512>, 512);
@@ -2047,7 +2060,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p,
-                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, gate);
+                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, gate, la);
     };
     if (m_mf_threads == 1024) {
       if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, true>, 1024);
@@ -2597,18 +2610,54 @@ void DeviceNlp::ipm_direction(double tau) {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
-void DeviceNlp::ipm_lookahead(double tau) {
-  IpmTwin tw;  // (a twin launch in flight: the kernel takes the direction of the attempt the policy takes)
-  if (m_twin_mode != 0) {
-    tw.mode = m_twin_mode;
-    tw.p = m_p_tw.p;
-    tw.ps = m_ps_tw.p;
-    tw.pz = m_pz_tw.p;
-    tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur);
+IpmLookaheadArgs DeviceNlp::lookahead_args(double tau, int twin_mode) {
+  IpmLookaheadArgs a;
+  a.n = m_kdev.n;
+  a.m_e = m_kdev.m_e;
+  a.m_i = m_kdev.m_i;
+  a.g_src = m_kdev.g_src;
+  a.V = m_V.p;
+  a.in = m_in.p;
+  a.s = m_s.p;
+  a.y = m_y.p;
+  a.z = m_z.p;
+  a.p = m_p.p;
+  a.ps = m_ps.p;
+  a.pz = m_pz.p;
+  a.mu = m_mu.p;
+  a.tau = tau;
+  a.in_t = m_trial_in.p;
+  a.s_t = m_s_ahead.p;
+  a.y_t = m_y_ahead.p;
+  a.z_t = m_z_ahead.p;
+  a.alpha_dev = m_ipm_alpha.p;
+  a.out = &m_ipm_host->dir;
+  a.stats = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
+  if (twin_mode != 0) {  // (a twin launch: the kernel takes the direction of the attempt the policy takes)
+    a.tw.mode = twin_mode;
+    a.tw.p = m_p_tw.p;
+    a.tw.ps = m_ps_tw.p;
+    a.tw.pz = m_pz_tw.p;
+    a.tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur);
   }
-  hipLaunchKernelGGL(ipm_lookahead_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V.p, m_in.p, m_s.p, m_y.p,
-                     m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_s_ahead.p, m_y_ahead.p, m_z_ahead.p,
-                     m_ipm_alpha.p, &m_ipm_host->dir, m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch, tw);
+  return a;
+}
+
+void DeviceNlp::ipm_lookahead_rides(double tau) {
+  if (m_la_state == 0) {
+    const char* env = std::getenv("SLPX_IPM_LOOKAHEAD_RIDE");
+    m_la_state = env != nullptr && env[0] == '1' ? 1 : -1;  // (off unless asked for: measured no faster)
+    if (m_la_state > 0) m_la_done.upload(std::vector<unsigned int>(1, 0u));
+  }
+  m_la_tau = m_la_state > 0 ? tau : -1.0;
+}
+
+void DeviceNlp::ipm_lookahead(double tau) {
+  if (m_la_rode) {  // (it was the last act of the step launch)
+    m_la_rode = false;
+    return;
+  }
+  hipLaunchKernelGGL(ipm_lookahead_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, lookahead_args(tau, m_twin_mode));
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

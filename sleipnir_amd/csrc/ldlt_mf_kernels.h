@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ldlt_kernels.h"
+#include "ipm_kernels.h"
 
 namespace slpx {
 
@@ -559,7 +560,7 @@ __device__ __forceinline__ void mf_step_body(
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, const KktFuse& F, double* __restrict__ xg,
     double* __restrict__ xg_next, double* __restrict__ out, const BacksubFuse& B, uint32_t block, unsigned int exit_total,
-    const LdltStats* twin_stats, const MfGate& G) {
+    const LdltStats* twin_stats, const MfGate& G, const IpmLookaheadArgs& LA) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double mu_gate = 0.0;
   if (static_cast<int>(block) < F.n_blocks) {
@@ -889,7 +890,8 @@ __device__ __forceinline__ void mf_step_body(
   for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
   for (uint32_t i = tid; i < t.n_col; i += THREADS)
     coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
-  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
+  // (LA.on: the launch's last workgroup reads the direction — ipm_lookahead_body —: written through)
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&out[L.perm[colperm[i]]], x[i], LA.on != 0);
   if (B.on) {
     const double mu = G.mu_out != nullptr ? mu_gate : B.mu[0];
     auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
@@ -920,12 +922,31 @@ __device__ __forceinline__ void mf_step_body(
         const BsTerm bt = bs_terms[first + k];
         aipx = backsub_dot(aipx, B.V[bt.a], p_of(bt.ref));
       }
-      backsub_row(ci_r, s_r, z_r, mu, aipx, &B.ps[row.r], &B.pz[row.r]);
+      double ps_r, pz_r;
+      backsub_row(ci_r, s_r, z_r, mu, aipx, &ps_r, &pz_r);
+      coherent_store(&B.ps[row.r], ps_r, LA.on != 0);
+      coherent_store(&B.pz[row.r], pz_r, LA.on != 0);
     }
   }
   SLPX_LDLT_CLOCK(20);
   if (top) exit_and_count();
   if constexpr (CHAINED) mf_signal_done(Mf);
+  if (LA.on) {
+    // the look-ahead iterate as the launch's last act: whoever is through last, of all attempts, has every
+    // workgroup's p, p_s, p_z and counters in memory
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned int* s_last = reinterpret_cast<unsigned int*>(smem_raw);
+    if (tid == 0) {
+      const unsigned int old = __hip_atomic_fetch_add(LA.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == exit_total) __hip_atomic_store(LA.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last[0] = old + 1 == exit_total ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = s_last[0] != 0u;
+    __syncthreads();
+    if (last) ipm_lookahead_body<THREADS, true>(LA, reinterpret_cast<double*>(smem_raw));
+  }
 }
 
 template <int THREADS, bool MFMA, bool CHAINED>
@@ -933,9 +954,9 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfGate G) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfGate G, IpmLookaheadArgs LA) {
   mf_step_body<THREADS, MFMA, CHAINED>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B,
-                                       blockIdx.x, Mf.n_tasks, nullptr, G);
+                                       blockIdx.x, Mf.n_tasks, nullptr, G, LA);
 }
 
 // ---------------------------------------------------------------------------
@@ -964,7 +985,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T, MfGate G) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T, MfGate G, IpmLookaheadArgs LA) {
   uint32_t block = blockIdx.x;
   if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
     block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
@@ -983,7 +1004,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
   }
   mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
-                                      2u * Mf.n_tasks, T.stats, G);
+                                      2u * Mf.n_tasks, T.stats, G, LA);
 }
 
 // ---------------------------------------------------------------------------

@@ -325,3 +325,21 @@ def test_steps_launched_ahead_change_nothing_but_the_time(name, make, capfd):
     if not cases.OUTER_SWITCHES:
         assert 0 < taken <= ahead, lines
     print(f"{name}: {rep_a['iterations']} iterations, {ahead} steps launched ahead, {taken} taken")
+
+
+@pytest.mark.parametrize("name,make", [
+    ("cart_pole_100", lambda: models.cart_pole(100, 0.05)),
+    ("cart_pole_300", lambda: models.cart_pole(300, 5.0 / 300)),
+    ("flywheel_50", lambda: models.flywheel(50, 0.005)),
+])
+def test_the_look_ahead_inside_the_step_launch_gives_the_bits_of_its_own_launch(name, make):
+    """ipm_lookahead_body as the last act of the step kernel's launch (the workgroup that is through last reads
+    every workgroup's p, p_s, p_z past the caches; SLPX_IPM_LOOKAHEAD_RIDE=1 — off by default, it measured no faster)
+    against the same body as a launch of its own: the same iterates, to the bit."""
+    st_r, rep_r, x_r, duals_r = _solve_with_env(make, SLPX_IPM_LOOKAHEAD_RIDE="1")
+    st_k, rep_k, x_k, duals_k = _solve_with_env(make, SLPX_IPM_LOOKAHEAD_RIDE="0")
+    assert st_r == st_k
+    assert rep_r["iterations"] == rep_k["iterations"] and rep_r["factorizations"] == rep_k["factorizations"]
+    assert np.array_equal(x_r, x_k)
+    for a, b in zip(duals_r, duals_k):
+        assert np.array_equal(a, b)

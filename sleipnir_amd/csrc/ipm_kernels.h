@@ -96,6 +96,12 @@ __device__ __forceinline__ void block_reduce(double (&vals)[NQ], const int (&ops
 // microseconds before the stream reports the kernel complete.
 __device__ __forceinline__ void ipm_publish(unsigned long long* seq_dev, volatile unsigned long long* seq_host) {
   SLPX_GATE_STAMP_SET(0);
+#ifdef SLPX_GATE_STAMPS
+  if (slpx_gate_stamps[4] != 0) {
+    atomicAdd(&slpx_gate_stamps[18], slpx_gate_stamps[0] - slpx_gate_stamps[4]);
+    slpx_gate_stamps[4] = 0;
+  }
+#endif
   __threadfence_system();
   const unsigned long long v = *seq_dev + 1;
   *seq_dev = v;
@@ -166,7 +172,11 @@ __device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* s
   // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
   // (one lane-uniform 16-byte load, issued with the others below)
 #ifdef SLPX_GATE_STAMPS
-  if (tid == 0) SLPX_GATE_STAMP_ADD(12, slpx_gate_stamps[1]);
+  unsigned long long stamp_la_in = 0;
+  if (tid == 0) {
+    stamp_la_in = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[12], stamp_la_in - slpx_gate_stamps[1]);
+  }
 #endif
   const LdltStats st = ld_stats(A.stats);
   bool wrong = st.n_bad != 0 || st.n_pos != n || st.n_neg != m_e || st.n_zero != 0;
@@ -288,6 +298,10 @@ __device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* s
     A.out->alpha_max = acc[0];
     A.out->alpha_z = acc[1];
     A.out->D_phi = acc[2];
+#ifdef SLPX_GATE_STAMPS
+    slpx_gate_stamps[3] = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[16], slpx_gate_stamps[3] - stamp_la_in);
+#endif
   }
 }
 
@@ -688,6 +702,13 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
+#ifdef SLPX_GATE_STAMPS
+  if (fin.skip != nullptr && fin.skip[0] == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) {  // (the look-ahead chain's, not passed)
+    slpx_gate_stamps[4] = wall_clock64();
+    atomicAdd(&slpx_gate_stamps[17], slpx_gate_stamps[4] - slpx_gate_stamps[3]);
+    atomicAdd(&slpx_gate_stamps[20], 1ull);
+  }
+#endif
   if (fin.skip != nullptr && fin.skip[0] != 0.0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ipm_publish(fin.seq_dev, fin.seq_host);
     return;

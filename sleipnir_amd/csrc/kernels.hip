@@ -2189,12 +2189,16 @@ void DeviceNlp::open_gate(double mu) {
 void DeviceNlp::debug_gate_stamps(const char* label) {
 #ifdef SLPX_GATE_STAMPS
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
-  unsigned long long h[16];
+  unsigned long long h[32];
   SLPX_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(slpx_gate_stamps), sizeof(h)));
   const double n = static_cast<double>(std::max<unsigned long long>(1, h[15]));
   auto us = [&](int k) { return static_cast<double>(static_cast<long long>(h[k])) / 100.0 / n; };
   std::fprintf(stderr, "slpx gate stamps (%s, %llu step kernels): numbers -> step kernel in %.2f us, in -> staged %.2f, staged -> through the gate %.2f, "
                "gate -> counters out %.2f, counters out -> the launch behind in %.2f; the step before's counters out -> step kernel in %.2f\n", label, h[15], us(8), us(9), us(10), us(11), us(12), us(13));
+  const double ne = static_cast<double>(std::max<unsigned long long>(1, h[20]));
+  auto ue = [&](int k) { return static_cast<double>(static_cast<long long>(h[k])) / 100.0 / ne; };
+  std::fprintf(stderr, "slpx gate stamps (%s, %llu look-ahead chains that ran): look-ahead in -> out %.2f us (per step kernel), out -> error launch in "
+               "(the sweep between) %.2f, error launch in -> numbers out %.2f\n", label, h[20], us(16), ue(17), ue(18));
   std::memset(h, 0, sizeof(h));
   SLPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(slpx_gate_stamps), h, sizeof(h)));
 #else

@@ -31,7 +31,7 @@ namespace slpx {
 // numbers -> step kernel in, in -> staged, staged -> through the gate, gate -> counters out, counters out -> the
 // launch behind it in; [15] steps.  DeviceNlp::debug_gate_stamps() reads and clears them.
 #ifdef SLPX_GATE_STAMPS
-__device__ unsigned long long slpx_gate_stamps[16];
+__device__ unsigned long long slpx_gate_stamps[32];  // ([3] look-ahead out; [16..] more sums: look-ahead in -> out, out -> error launch in, in -> numbers out, [20] error launches)
 #define SLPX_GATE_STAMP_SET(k) slpx_gate_stamps[k] = wall_clock64()
 #define SLPX_GATE_STAMP_ADD(k, since) atomicAdd(&slpx_gate_stamps[k], wall_clock64() - (since))
 #else

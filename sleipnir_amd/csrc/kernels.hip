@@ -2019,6 +2019,9 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
   md.chain = chained ? m_chain.p : nullptr;
   md.wait_step = chained ? m_chain_seq : 0u;
   md.this_step = m_chain_seq;
+  md.delta = reg[0];  // (by value: MfDev)
+  md.gamma = reg[1];
+  const double* const reg_by_value = nullptr;
   // the look-ahead iterate as the launch's last act (ipm_lookahead_rides; not in a launch held at a gate: tau is
   // the host's to decide)
   IpmLookaheadArgs la;
@@ -2035,7 +2038,8 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     const int tw_parity = m_stats_tw_cur ^ 1;
     MfTwin tw;
     tw.first_end = md.n_tasks + static_cast<unsigned int>(f.n_blocks);
-    tw.reg = reg + 2;
+    tw.delta = reg[2];
+    tw.gamma = reg[3];
     tw.Lx = m_Lx_tw.p;
     tw.D = m_D_tw.p;
     tw.contrib = m_mf_contrib_tw.p;
@@ -2050,7 +2054,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p, l.n,
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p, l.n,
                          m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, gate, la);
     };
     if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
@@ -2059,7 +2063,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg, m_Lx.p, m_D.p,
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p,
                          l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, gate, la);
     };
     if (m_mf_threads == 1024) {

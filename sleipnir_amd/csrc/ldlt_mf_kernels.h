@@ -53,6 +53,10 @@ struct MfDev {
   // stream), and its last workgroup leaves this_step in chain[48] for the next step's sweep
   unsigned int* chain = nullptr;
   unsigned int wait_step = 0, this_step = 0, n_workgroups = 0;
+  // the attempt's regularization BY VALUE (the kernel's `reg` argument is then null): read from the pinned host
+  // array the batch kernels share, delta and gamma were a trip over PCIe at the top of every workgroup, waited for
+  // with the task's descriptors (scalar loads return together)
+  double delta = 0.0, gamma = 0.0;
 };
 
 // (-DSLPX_CHAIN_STAMPS: wall clocks of the last chained step for SLPX_CHAIN_DEBUG, words 64.. of the chain buffer)
@@ -589,7 +593,7 @@ __device__ __forceinline__ void mf_step_body(
   const LdltTask t = L.tasks[task_index];
   const LdltMfTask m = Mf.tasks[task_index];
   const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
-  const double delta = reg[0], gamma = reg[1];
+  const double delta = reg != nullptr ? reg[0] : Mf.delta, gamma = reg != nullptr ? reg[1] : Mf.gamma;
   SLPX_LDLT_CLOCK(0);
   const MfCarve cv = mf_carve(t, m);
   double* U = reinterpret_cast<double*>(smem_raw);
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
 // ---------------------------------------------------------------------------
 struct MfTwin {
   unsigned int first_end = 0;
-  const double* reg = nullptr;
+  double delta = 0.0, gamma = 0.0;  // (by value, as MfDev's)
   double *Lx = nullptr, *D = nullptr, *contrib = nullptr, *zv = nullptr, *xg = nullptr, *xg_next = nullptr, *out = nullptr,
          *ps = nullptr, *pz = nullptr;
   LdltStats *stats = nullptr, *stats_next = nullptr;
@@ -989,7 +993,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
   uint32_t block = blockIdx.x;
   if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
     block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
-    reg = T.reg;
+    Mf.delta = T.delta;
+    Mf.gamma = T.gamma;
     Lx = T.Lx;
     D = T.D;
     contrib = T.contrib;

@@ -289,7 +289,7 @@ def test_twin_attempts_follow_the_sequential_policy_bit_for_bit(name, make, capf
     for a, b in zip(duals_t, duals_s):
         assert np.array_equal(a, b)
     lines = [l for l in err.splitlines() if l.startswith("slpx twin attempts:")]
-    assert lines, err
+    assert lines or cases.OUTER_SWITCHES, err  # (the host-resident driver, SLPX_IPM_RESIDENT=0, prints none)
     launches = sum(int(l.split()[3]) for l in lines)
     taken = sum(int(l.split("second of")[1].split()[0]) for l in lines)
     if not cases.OUTER_SWITCHES:  # (the pair-list step, unfused launches, ... have no twin attempts)
@@ -319,7 +319,7 @@ def test_steps_launched_ahead_change_nothing_but_the_time(name, make, capfd):
     for a, b in zip(duals_a, duals_p):
         assert np.array_equal(a, b)
     lines = [l for l in err.splitlines() if l.startswith("slpx twin attempts:")]
-    assert lines, err
+    assert lines or cases.OUTER_SWITCHES, err
     ahead = sum(int(l.split(";")[-1].split()[0]) for l in lines)
     taken = sum(int(l.split(";")[-1].split("ahead,")[1].split()[0]) for l in lines)
     if not cases.OUTER_SWITCHES:

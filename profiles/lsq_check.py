@@ -1,10 +1,10 @@
 import sys, numpy as np
 sys.path.insert(0,'/root/repo')
 import sleipnir_amd as sa
-from tests.support import oracle, cases
+from tests.support import oracle, cases, models
 for N in (6,20):
     sa.lib().slpx_graph_reset(); oracle.lib().orc_reset()
-    pp=sa.Problem.cart_pole(N,5.0/N); op=oracle.OracleProblem.cart_pole(N,5.0/N)
+    pp=models.cart_pole(N,5.0/N); op=oracle.OracleProblem.cart_pole(N,5.0/N)
     n,me,mi=pp.dims
     scales=op.scaling()
     x,s,y,z,mu=cases.newton_state("interior",op.get_x(),n,me,mi,scales[0])

@@ -230,7 +230,7 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
     // (and the full sweep's kernel as a chained step launches it: DeviceNlp picks that variant for one
     // problem whose step kernel leaves the sweep room on the chip)
     slpx::TapeJitOptions copt = opt;
-    copt.chain_mode = 2;
+    copt.chain_mode = 1;
     const int c = slpx::prebuild_tape_templates(st.full, copt, where, log);
     if (a < 0 || b < 0 || c < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
     bodies = a + b;
@@ -464,13 +464,9 @@ int slpx_newton_steps(slpx_system* s, int32_t count, int refresh_ad, int forget_
     std::vector<int32_t> worst(sys.batch(), 0);
     for (int32_t k = 0; k < count; ++k) {
       if (forget_regularization) sys.reset_regularization();
-      // (all but the last step of the run launch their successor ahead: NewtonSystem::set_pipeline)
-      sys.set_pipeline(refresh_ad != 0 && k + 1 < count, forget_regularization != 0);
       auto res = sys.newton_step(refresh_ad != 0);
       for (size_t b = 0; b < res.size(); ++b) worst[b] |= static_cast<int32_t>(res[b]);
     }
-    sys.set_pipeline(false, false);
-    if (std::getenv("SLPX_TWIN_VERBOSE")) sys.device().debug_gate_stamps("newton steps");
     if (info) std::copy(worst.begin(), worst.end(), info);
   });
 }

@@ -236,11 +236,8 @@ struct IpmTwin {
   const double *p = nullptr, *ps = nullptr, *pz = nullptr;
   const LdltStats* stats = nullptr;
 };
-// ipm_lookahead_body (ipm_kernels.h): step sizes of the direction and the whole look-ahead iterate — a launch of
-// its own (ipm_lookahead_kernel), or (on) the last act of the step kernel's launch: the workgroup that is through
-// last, of all attempts, does it (done_cnt), one kernel boundary less per iteration.
+// ipm_lookahead_kernel (ipm_kernels.h): step sizes of the direction and the whole look-ahead iterate
 struct IpmLookaheadArgs {
-  int on = 0;
   int n = 0, m_e = 0, m_i = 0;
   const int32_t* g_src = nullptr;
   const double *V = nullptr, *in = nullptr, *s = nullptr, *y = nullptr, *z = nullptr, *p = nullptr, *ps = nullptr, *pz = nullptr,
@@ -250,16 +247,6 @@ struct IpmLookaheadArgs {
   IpmDirOut* out = nullptr;
   const LdltStats* stats = nullptr;
   IpmTwin tw;
-  unsigned int* done_cnt = nullptr;
-};
-
-// A pre-launched step's gate (ldlt_mf_kernels.h: mf_gate_wait; DeviceNlp::prelaunch_step)
-struct MfGate {
-  const unsigned long long* word = nullptr;  // pinned, 16-byte aligned; nullptr: no gate
-  unsigned long long ticket = 0;
-  unsigned long long* relay = nullptr;       // device: {mu bits, 2 x ticket + abort} as the asking workgroup saw it
-  double* mu_out = nullptr;                  // != nullptr: mu comes through the gate; left here for the launches behind
-  unsigned long long* abandoned = nullptr;   // pinned: the ticket of a launch that gave up waiting (never expected)
 };
 
 // ldlt_factor_solve_kernel (ldlt_kernels.h): what the backward solve needs to run on the
@@ -313,20 +300,7 @@ struct TrackedStream {
   hipStream_t tape = nullptr;
   hipEvent_t ev = nullptr;
   mutable bool tape_pending = false;
-  // a pre-launched step kernel waits in this stream for the host's word (DeviceNlp::prelaunch_step): whatever
-  // else is handed the stream would queue behind it — it is sent home first (the word of its ticket with the
-  // abort bit)
-  mutable volatile unsigned long long* gate_word = nullptr;
-  mutable unsigned long long gate_ticket = 0;
-  mutable bool gate_pending = false;
-  void abort_gate() const {
-    if (gate_pending) {
-      gate_pending = false;
-      gate_word[1] = 2ull * gate_ticket + 1ull;
-    }
-  }
   operator hipStream_t() const {
-    abort_gate();
     touched = true;
     if (tape_pending) {
       tape_pending = false;
@@ -401,10 +375,6 @@ class DeviceNlp {
   void factor(const std::vector<double>& delta, const std::vector<double>& gamma,
               const std::vector<uint8_t>& active);
   void read_stats(std::vector<LdltStats>& out);     // synchronizes
-  // [AD refresh,] assemble, rhs, one factorization attempt, solve, backsub as ONE HIP graph
-  // launch; follow with read_stats().
-  void launch_step_graph(bool refresh_ad, const std::vector<double>& delta,
-                         const std::vector<double>& gamma, const std::vector<uint8_t>& active);
   void solve();                                     // rhs -> p (dim per batch item)
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   bool step_is_one_launch() const { return m_fuse_solve && m_fuse_kkt; }
@@ -419,21 +389,6 @@ class DeviceNlp {
   void backsub_publish();
   void materialize_factor();                // batch-interleaved mode: refresh the batch-major L, D copies
   static bool interleaved_for(int batch);   // batches this large factor with one lane per problem
-  // ... and, among those, by fronts with four lanes per problem (ldlt_mfq_kernels.h) where the plan allows it
-  // A step launched ahead of the decision to take it (MfGate, ldlt_mf_kernels.h): the step kernel — `twin_mode`
-  // 0: one attempt (reg = {delta, gamma}), else a twin attempt (reg = {delta0, gamma0, delta1, gamma1}) — with the
-  // buffer roles of this moment, the system evaluated in the launch (`kkt_mode` as m_kkt_pending: 1 lhs + rhs, 2: + the
-  // tape's sums), behind a chained sweep if one is pending.  Nothing of the host's bookkeeping changes until
-  // open_gate() (mu: the barrier parameter the step takes, NaN: the one in device memory); anything else handed the
-  // stream first, or abort_gate(), sends the kernel home.  false: not possible (nothing was launched).
-  // `lookahead_roles`: with the look-ahead iterate and its V as the current ones (what ipm_accept_lookahead() will
-  // make them if the filter takes the point).
-  bool prelaunch_step(int twin_mode, const double* reg, int kkt_mode, bool mu_through_gate, bool lookahead_roles);
-  bool can_prelaunch(int twin_mode);
-  bool gate_pending() const { return m_stream.gate_pending; }
-  void debug_gate_stamps(const char* label);
-  void open_gate(double mu);
-  void abort_gate() { m_stream.abort_gate(); }
   // Twin attempt (ldlt_mf_twin_kernel): the policy loop's attempt (delta0, gamma0) and the one it would make
   // next (delta1, gamma1) in ONE launch; `mode` as IpmTwin::mode.  false: not possible now (the caller makes a
   // single attempt).  read_stats() then has the first attempt's counters, read_twin_stats() the second's;
@@ -442,9 +397,6 @@ class DeviceNlp {
   bool factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode);
   LdltStats read_twin_stats() const { return m_h_stats[1]; }
   void adopt_twin();
-  static bool il_fronts_enabled();                 // SLPX_IL_FRONTS=1 (default off: measured slower, kernels.hip)
-  static void il_fronts_options(LdltOptions& o);   // what such a plan needs: supernodes, fronts of <= 20 rows, small tasks
-  static bool il_fronts_fit(const LdltPlan& l);    // every front within the rows four lanes hold, every task within a CU's LDS
 
   // ---- interior-point iteration on the device (ipm_kernels.h; one problem) ----
   // All asynchronous on stream(); results arrive in ipm_host() after wait().
@@ -462,9 +414,6 @@ class DeviceNlp {
   // interior_point.hpp:797-801 — in a second set of buffers, swept (values AND derivatives) and reduced to
   // IpmHost::err_ahead speculatively; when the filter accepts that trial point the buffers change roles
   // (ipm_accept_lookahead: no launch) and the iteration is complete after ONE host round trip.
-  // ipm_lookahead() as the last act of every step launch from now on (tau < 0: off again): the launches made
-  // while it is on carry the look-ahead (IpmLookaheadArgs), and ipm_lookahead() after such a launch launches nothing
-  void ipm_lookahead_rides(double tau);
   void ipm_lookahead(double tau);             // step sizes, D_phi -> IpmHost::dir; the look-ahead iterate
   void sweep_full_lookahead();                // the full tape at it, into the look-ahead V (sums ride in ipm_errors)
   void ipm_accept_lookahead();                // the look-ahead iterate and its V become the current ones
@@ -557,12 +506,10 @@ class DeviceNlp {
   LdltStats* m_h_stats = nullptr;     // pinned read-back
   bool m_stats_in_host = false;       // the last launch already copied the counters out
   // one problem: the publishing kernel also bumps a sequence number the host spins on
-  // (SLPX_SEQ_POLL=0: poll the stream instead)
   volatile unsigned long long* m_h_seq = nullptr;  // pinned
   DevBuf<unsigned long long> m_seq_dev;
   unsigned long long m_seq_expected = 0;  // publishing launches enqueued so far
   unsigned long long m_stats_seq = 0;     // the one that carries the current inertia counters
-  bool m_seq_poll = true;
   bool m_fuse_kkt_store = false;
   bool m_fuse_kkt = false, m_fuse_backsub = false;  // the two halves of it (SLPX_FUSE_KKT, SLPX_FUSE_BACKSUB)
   bool m_fuse_launches = false;       // KKT assembly inside the factorization launch, back-substitution inside the solve's
@@ -570,17 +517,17 @@ class DeviceNlp {
   int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
   bool m_fuse_solve = false;          // ldlt_factor_solve_kernel (SLPX_FUSE_SOLVE)
   // backward solve: x of finished columns handed to the descendants through the values (two
-  // buffers, the solves alternate; a captured graph has its pointers baked in: counters there)
+  // buffers, the solves alternate)
   bool m_xg_by_data = false;
   int m_xg_parity = 0;
   DevBuf<double> m_xg2;
-  double* xg_now() { return (m_xg_by_data && !m_capturing && m_xg_parity) ? m_xg2.p : m_xg.p; }
+  double* xg_now() { return (m_xg_by_data && m_xg_parity) ? m_xg2.p : m_xg.p; }
   double* xg_other() {
-    if (!m_xg_by_data || m_capturing) return nullptr;
+    if (!m_xg_by_data) return nullptr;
     return m_xg_parity ? m_xg.p : m_xg2.p;
   }
   void xg_flip() {
-    if (m_xg_by_data && !m_capturing) m_xg_parity ^= 1;
+    if (m_xg_by_data) m_xg_parity ^= 1;
   }
   DevBuf<LdltSolveItem> m_bwd_items_u;
   DevBuf<uint32_t> m_col_zent;
@@ -611,22 +558,9 @@ class DeviceNlp {
   DevBuf<double> m_mf_contrib;
   // the second attempt of a twin launch: its own factor, update slots, x hand-over (a pair, alternating like
   // m_xg / m_xg2), direction and counters (a pair, alternating like m_stats)
-  // the pre-launched step (prelaunch_step): what open_gate() has to book
-  struct PendingStep {
-    int twin_mode = 0, kkt_mode = 0;
-    bool chained = false, mu_through_gate = false;
-  } m_pre;
-  unsigned long long* m_h_gate = nullptr;  // pinned, 64 bytes: [0, 1] the gate's word {mu, 2 x ticket + abort}, [2] the ticket of a launch that gave up
-  DevBuf<unsigned long long> m_gate_relay;
-  unsigned long long m_gate_ticket = 0;
-  int m_gate_state = 0;  // 0: not looked at yet, 1: usable, -1: not (SLPX_PRELAUNCH=0, ...)
   KktFuse kkt_fuse_for(int kkt_mode) const;
-  void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const MfGate& gate);
+  void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained);
   void book_mf_step(int twin_mode, bool chained);
-  double m_la_tau = -1.0;  // >= 0: the look-ahead rides in the step launches (ipm_lookahead_rides)
-  bool m_la_rode = false;  // ... and did in the last one
-  int m_la_state = 0;      // 0: not looked at yet, 1: allowed (SLPX_IPM_LOOKAHEAD_RIDE=1), -1: not
-  DevBuf<unsigned int> m_la_done;
   IpmLookaheadArgs lookahead_args(double tau, int twin_mode);
   int m_twin_state = 0;  // 0: not looked at yet, 1: available, -1: not (not resident at once, SLPX_TWIN=0, ...)
   int m_twin_mode = 0;   // of the step launch in flight (IpmTwin::mode; 0: a single attempt)
@@ -634,15 +568,6 @@ class DeviceNlp {
   DevBuf<LdltStats> m_stats_tw;
   int m_stats_tw_cur = 0, m_xg_tw_parity = 0;
   void build_mf(const LdltPlan& l);
-  // the same fronts for a batch: one launch per round (ldlt_mf_batch_kernel)
-  bool m_mfb = false;
-  bool m_mfb_rhs_in_fronts = false;  // the last factorization carried the right-hand side now in m_rhs
-  int m_mfb_threads = 256, m_mfb_ppw = 0, m_mfb_wg_per_cu = 4, m_cus = 256;
-  DevBuf<double> m_mfb_ust, m_mfb_invd;
-  void build_mf_batch(const LdltPlan& l);
-  void build_mf_il(const LdltPlan& l);   // images + update slots of the interleaved fronts (m_il_fronts)
-  void launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
-                       hipStream_t stream);
   DevBuf<unsigned int> m_ipm_err_done;
   DevBuf<BsRow> m_bs_plan;            // BacksubFuse::plan (rows and terms share the 8-byte element size)
   DevBuf<uint4> m_bs_task_plan;
@@ -655,16 +580,14 @@ class DeviceNlp {
   void build_inline_kkt(const NlpStructure& s, const KktPlan& k, const LdltPlan& l);
   bool m_lhs_stale = false, m_rhs_stale = false;  // memory does not hold the system of the current state
   void solve_after_factor_impl(const LdltStats* publish);
-  bool m_capturing = false;           // a step graph is being captured: launches do not run
-  bool m_fork_in_graph = false;       // capture independent kernels on a forked stream
   // all rounds of a factorization / backward solve in one launch (device-side round
   // counters, double-buffered like the inertia counters); SLPX_SINGLE_LAUNCH=0 disables
   bool m_single_launch = true;
   // batch-interleaved LDLT (ldlt_il_kernels.h)
   bool m_il = false, m_il_outputs_stale = false;
-  // the assembly kernels write the interleaved lhs / rhs themselves (SLPX_IL_DIRECT=0: batch-major + transposes);
-  // *_in_il: the current system is in the interleaved arrays only
-  bool m_il_direct = true, m_lhs_in_il = false, m_rhs_in_il = false;
+  // the assembly kernels write the interleaved lhs / rhs themselves; *_in_il: the current system is in the
+  // interleaved arrays only (a caller that wrote its own batch-major system: il_gather_kernel transposes it)
+  bool m_lhs_in_il = false, m_rhs_in_il = false;
   DevBuf<double> m_lhs_il, m_rhs_il, m_Lx_il, m_D_il, m_contrib_il, m_scontrib_il, m_zv_il, m_xg_il;
   DevBuf<LdltStats> m_stats_part;  // [task][problem]
   DevBuf<uint32_t> m_il_meta, m_il_meta_off;  // per task: the plan slices the factor kernel stages
@@ -672,14 +595,6 @@ class DeviceNlp {
   bool m_slot_handoff = false;        // factorization rounds hand over through the update block slots
   DevBuf<uint32_t> m_round_ptr;
   DevBuf<unsigned int> m_fround_cnt, m_bround_cnt;  // [2][batch][n_rounds]
-  bool m_il_single = false;          // interleaved factorization / backward solve: every round in one launch (small batches)
-  DevBuf<unsigned int> m_il_round_cnt;  // [groups][rounds] for the factorization, then [chunks][rounds] for the backward solve
-  bool m_il_fronts = false;          // batch-interleaved factorization by fronts (ldlt_mfq_factor_kernel)
-  uint32_t m_mfq_lds = 0;
-  bool m_fwd_single = true;  // SLPX_FWD_SINGLE=0: the forward substitution of a new right-hand side one launch per round
-  hipGraphExec_t m_step_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [parity][refresh]
-  hipStream_t m_aux_stream = nullptr, m_capture_stream = nullptr;
-  hipEvent_t m_fork = nullptr, m_join = nullptr;
   std::vector<double> m_V_static;  // scaled static values (host copy)
   // interior-point iteration state (ipm_enable)
   bool m_ipm = false;

@@ -621,21 +621,16 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     dev.upload_duals(s.data(), y.data(), z.data());
     host_current = true;
   };
-  long twin_launches = 0, twin_taken = 0, prelaunched = 0, prelaunch_used = 0;
-  const char* prelaunch_env = std::getenv("SLPX_PRELAUNCH");
-  const bool prelaunch = prelaunch_env != nullptr && prelaunch_env[0] == '1';  // (off unless asked for)
+  long twin_launches = 0, twin_taken = 0;
   auto finish = [&](ExitStatus st_) {
-    sys.cancel_prelaunch();
-    dev.ipm_lookahead_rides(-1.0);
     sys.set_after_attempt(nullptr);
     pull_state();
     if (std::getenv("SLPX_TWIN_VERBOSE")) {
-      dev.debug_gate_stamps("interior-point solve");
       const long* h = sys.twin_histogram();
       std::fprintf(stderr, "slpx twin attempts: %ld launches held two attempts, the policy took the second of %ld (%d factorizations, %d iterations); "
                    "first attempts of this system so far: %ld accepted, %ld / %ld with the failure the second stood for and the second accepted / not, "
-                   "%ld with zero pivots, %ld with the other inertia failure, %ld failed; %ld steps launched ahead, %ld of them taken\n",
-                   twin_launches, twin_taken, rep.factorizations, iterations, h[0], h[1], h[2], h[3], h[4], h[5], prelaunched, prelaunch_used);
+                   "%ld with zero pivots, %ld with the other inertia failure, %ld failed\n",
+                   twin_launches, twin_taken, rep.factorizations, iterations, h[0], h[1], h[2], h[3], h[4], h[5]);
     }
     return st_;
   };
@@ -711,14 +706,10 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     auto t0 = clk::now();
     const bool s_from_ci = options.feasible_ipm && cur.ci_all_pos != 0.0;
     const bool ahead = lookahead && !s_from_ci;
-    if (!ahead) sys.cancel_prelaunch();
     if (mu != mu_on_device) {
-      // (a step launched ahead takes mu through its gate and leaves it in device memory: nothing may queue behind
-      // it before the gate opens)
-      if (!dev.gate_pending()) dev.upload_mu(&mu);
+      dev.upload_mu(&mu);
       mu_on_device = mu;
     }
-    sys.set_step_mu(mu);
     dev.build_kkt_for_step(/*with_reduce=*/false);
     // Look-ahead (DeviceNlp::ipm_lookahead): instead of only f, c_e, c_i at the first trial point, the
     // WHOLE next iterate the full step would give — updated s, y, z, the full tape at it, the error norms
@@ -740,22 +731,11 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // (twin attempts, NewtonSystem::compute_twin: the look-ahead launch takes the direction of whichever of a
     // launch's two attempts the regularization policy takes — the other after_attempt chain does not)
     sys.set_twin_attempts(ahead);
-    if (dev.gate_pending()) ++prelaunch_used;
-    // (the look-ahead iterate as the last act of the step launches themselves: DeviceNlp::ipm_lookahead_rides)
-    if (ahead) dev.ipm_lookahead_rides(tau);
     auto info = sys.compute(/*solve_speculatively=*/true);
-    dev.ipm_lookahead_rides(-1.0);
     sys.set_twin_attempts(false);
     sys.set_after_attempt(nullptr);
     twin_launches += sys.last_twin_launches();
     twin_taken += sys.last_twin_taken();
-    // The next iteration's step, launched now — the host has nothing to do until the chain's numbers arrive, ~25 us —
-    // on the look-ahead iterate, with the regularization the policy will start from: the kernel stages its plan and
-    // waits for the host's word (MfGate).  Most iterations take the look-ahead point; then the word is "go" with the
-    // barrier parameter decided below, and the step starts ~4 us after the numbers instead of ~11.  Anything else —
-    // backtracking, a correction, restoration, the end — sends the kernel home first (cancel_prelaunch; every other
-    // launch into the stream does it too).
-    if (ahead && prelaunch && callbacks.empty() && info[0] == FactorInfo::Success && sys.prelaunch_twin_step()) ++prelaunched;
     dev.wait_published();  // compute() returns when the inertia counters are in; the trial chain may still run
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();
@@ -771,7 +751,6 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     double alpha_z = H.dir.alpha_z;  // :497
     const double D_phi = H.dir.D_phi;  // :508-509
     bool call_feasibility_restoration = alpha < alpha_min;
-    if (call_feasibility_restoration) sys.cancel_prelaunch();
     const FilterEntry current_entry{cur.f - mu * cur.logsum, cur.viol};
     double alpha_commit = alpha;
     bool commit_s_from_ci = s_from_ci;
@@ -794,7 +773,6 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       IpmTrialOut tr = from_ahead ? IpmTrialOut{H.err_ahead.f, H.err_ahead.viol, H.err_ahead.logsum, H.err_ahead.finite} : H.trial;
 
       if (tr.finite == 0.0) {
-        sys.cancel_prelaunch();
         alpha *= alpha_reduction_factor;
         if (alpha < alpha_min) {
           call_feasibility_restoration = true;
@@ -808,7 +786,6 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         took_lookahead = from_ahead;
         break;
       }
-      sys.cancel_prelaunch();  // the step launched ahead assumed this point
 
       const double prev_violation = cur.viol;
       double next_violation = tr.viol;

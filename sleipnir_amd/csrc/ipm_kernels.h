@@ -95,13 +95,6 @@ __device__ __forceinline__ void block_reduce(double (&vals)[NQ], const int (&ops
 // sequence number the host spins on (DeviceNlp::wait_published) — it sees it a few
 // microseconds before the stream reports the kernel complete.
 __device__ __forceinline__ void ipm_publish(unsigned long long* seq_dev, volatile unsigned long long* seq_host) {
-  SLPX_GATE_STAMP_SET(0);
-#ifdef SLPX_GATE_STAMPS
-  if (slpx_gate_stamps[4] != 0) {
-    atomicAdd(&slpx_gate_stamps[18], slpx_gate_stamps[0] - slpx_gate_stamps[4]);
-    slpx_gate_stamps[4] = 0;
-  }
-#endif
   __threadfence_system();
   const unsigned long long v = *seq_dev + 1;
   *seq_dev = v;
@@ -149,35 +142,16 @@ __global__ __launch_bounds__(kIpmThreads) void ipm_direction_kernel(
 // over the current one.  The full tape and the error reductions run on those next (DeviceNlp::
 // ipm_lookahead); if the filter takes the point the buffers swap roles and nothing is recomputed.
 // (struct IpmTwin, struct IpmLookaheadArgs: device.hpp)
-// IN_LAUNCH: the body runs as the last act of the step kernel's launch (mf_step_body) — the direction and the
-// counters were written by other workgroups of this launch and are read past the caches.
-template <int THREADS, bool IN_LAUNCH>
+template <int THREADS>
 __device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* scratch) {
   const int tid = threadIdx.x;
-  auto ld = [](const double* q) { return IN_LAUNCH ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q; };
-  auto ld_stats = [](const LdltStats* q) {
-    if (!IN_LAUNCH) return q[0];
-    LdltStats st;
-    const int* src = reinterpret_cast<const int*>(q);
-    st.n_pos = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st.n_neg = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st.n_zero = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st.n_bad = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st.min_abs_bits = __hip_atomic_load(&q->min_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return st;
-  };
+  auto ld = [](const double* q) { return *q; };
+  auto ld_stats = [](const LdltStats* q) { return q[0]; };
   const int n = A.n, m_e = A.m_e, m_i = A.m_i;
   const double *p = A.p, *ps = A.ps, *pz = A.pz;
   // The factorization this direction comes from has the wrong inertia (or failed): the policy loop will
   // redo the attempt and look at nothing of this chain — alpha_dev[2] tells its error launch to pass.
   // (one lane-uniform 16-byte load, issued with the others below)
-#ifdef SLPX_GATE_STAMPS
-  unsigned long long stamp_la_in = 0;
-  if (tid == 0) {
-    stamp_la_in = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[12], stamp_la_in - slpx_gate_stamps[1]);
-  }
-#endif
   const LdltStats st = ld_stats(A.stats);
   bool wrong = st.n_bad != 0 || st.n_pos != n || st.n_neg != m_e || st.n_zero != 0;
   if (A.tw.mode != 0) {
@@ -298,16 +272,12 @@ __device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* s
     A.out->alpha_max = acc[0];
     A.out->alpha_z = acc[1];
     A.out->D_phi = acc[2];
-#ifdef SLPX_GATE_STAMPS
-    slpx_gate_stamps[3] = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[16], slpx_gate_stamps[3] - stamp_la_in);
-#endif
   }
 }
 
 __global__ __launch_bounds__(kIpmThreads) void ipm_lookahead_kernel(IpmLookaheadArgs A) {
   __shared__ double scratch[17 * 3];
-  ipm_lookahead_body<kIpmThreads, false>(A, scratch);
+  ipm_lookahead_body<kIpmThreads>(A, scratch);
 }
 
 // trial_x = x + alpha p_x (backtracking)
@@ -702,13 +672,6 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
-#ifdef SLPX_GATE_STAMPS
-  if (fin.skip != nullptr && fin.skip[0] == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) {  // (the look-ahead chain's, not passed)
-    slpx_gate_stamps[4] = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[17], slpx_gate_stamps[4] - slpx_gate_stamps[3]);
-    atomicAdd(&slpx_gate_stamps[20], 1ull);
-  }
-#endif
   if (fin.skip != nullptr && fin.skip[0] != 0.0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ipm_publish(fin.seq_dev, fin.seq_host);
     return;

@@ -12,7 +12,6 @@
 //   ldlt_fwd/bwd   (ldlt_kernels.h) triangular solves (sparse_regularized_ldlt.hpp:159-161)
 //   step_backsub   pˢ, pᶻ                 (interior_point.hpp:479-480)
 #include <hip/hip_runtime.h>
-#include <emmintrin.h>
 
 #include <algorithm>
 #include <bit>
@@ -26,7 +25,6 @@
 #include "ldlt_kernels.h"
 #include "ldlt_mf_kernels.h"
 #include "ldlt_il_kernels.h"
-#include "ldlt_mfq_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
 #include "tape_kernels.h"
@@ -524,14 +522,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 
   // Chained steps (sweep_full_for_step): for one problem whose multifrontal step kernel leaves the sweep
   // room on the chip (at most CUs - 64 workgroups: cart-pole N=5000's 265 do not, and there chaining costs
-  // 25 %, profiles/r03_chain_ab.txt).  SLPX_CHAIN_TAPE=0: off; SLPX_CHAIN_STORE=fence: ordinary stores to V
-  // and a release fence per workgroup of the sweep instead of stores written through.
+  // 25 %, profiles/r03_chain_ab.txt).  SLPX_CHAIN_TAPE=0: off.
   {
     int cus = 0;
     SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
-    if (batch == 1 && l.mf && static_cast<int>(l.tasks.size() + s.reduces.size()) + 64 <= cus) m_chain_mode = 2;
-    if (const char* env = std::getenv("SLPX_CHAIN_STORE"))
-      if (m_chain_mode && std::string(env) == "fence") m_chain_mode = 1;
+    if (batch == 1 && l.mf && static_cast<int>(l.tasks.size() + s.reduces.size()) + 64 <= cus) m_chain_mode = 1;
     if (const char* env = std::getenv("SLPX_CHAIN_TAPE"))
       if (env[0] == '0') m_chain_mode = 0;
   }
@@ -652,11 +647,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
   m_il = interleaved_for(batch);
-  if (const char* env = std::getenv("SLPX_IL_DIRECT")) m_il_direct = env[0] != '0';
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
-  if (const char* env = std::getenv("SLPX_FWD_SINGLE")) m_fwd_single = env[0] != '0';
-  if (const char* env = std::getenv("SLPX_SEQ_POLL")) m_seq_poll = env[0] != '0';
   // launch fusion (device.hpp: KktFuse / BacksubFuse): one problem, single-launch factorization
   m_fuse_launches = m_single_launch && batch == 1 && l.factor_lds_bytes >= 64 * sizeof(double);
   if (const char* env = std::getenv("SLPX_FUSE_LAUNCHES")) m_fuse_launches = m_fuse_launches && env[0] != '0';
@@ -673,7 +665,6 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_sip_ok = m_fuse_solve;
   if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
   if (m_mf) m_fuse_solve = true;
-  if (batch > 1 && !m_il && !m_single_launch && l.mf) build_mf_batch(l);
   m_chain_on = m_mf && m_chain_mode != 0;
 
   const size_t B = static_cast<size_t>(batch);
@@ -700,7 +691,6 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       for (uint32_t c = 0; c < t.n_contrib_idx; ++c)
         single_reader = single_reader && ++readers[l.contrib_idx[t.contrib_off + c]] == 1;
     m_slot_handoff = m_single_launch && single_reader;
-    if (const char* env = std::getenv("SLPX_SLOT_HANDOFF")) m_slot_handoff = m_slot_handoff && env[0] != '0';
     if (m_slot_handoff) {
       std::vector<double> empty(m_contrib.n);
       const unsigned long long bits = kSlotEmpty;
@@ -723,9 +713,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     buf->zero();
   SLPX_HIP_CHECK(hipDeviceSynchronize());  // (the memsets ran on the null stream, the kernels will not)
   // the backward solve's hand-over through the data (ldlt_kernels.h: slot_read): two buffers of
-  // x, both armed; SLPX_XG_HANDOFF=0: round counters
+  // x, both armed
   m_xg_by_data = m_single_launch;
-  if (const char* env = std::getenv("SLPX_XG_HANDOFF")) m_xg_by_data = m_xg_by_data && env[0] != '0';
   if (m_xg_by_data) {
     const std::vector<double> armed(static_cast<size_t>(B) * l.n, std::bit_cast<double>(kSlotEmpty));
     m_xg.upload(armed);
@@ -736,7 +725,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     std::vector<LdltStats> zero(2 * static_cast<size_t>(B), LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull});
     m_stats.upload(zero);
   }
-  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(std::max<int>(B, 6)) * sizeof(double)));  // (B = 1: a twin attempt's second pair, two sets for pre-launched steps)
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_reg), 2 * static_cast<size_t>(std::max<int>(B, 6)) * sizeof(double)));  // (B = 1: a twin attempt's second pair)
   if (B > 8) m_reg_dev.alloc(2 * B);
   if (m_il) {
     // batch-interleaved LDLT (ldlt_il_kernels.h): [chunk of 64 problems][index][lane]
@@ -745,23 +734,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_rhs_il.alloc(C * l.n * W);
     m_Lx_il.alloc(C * std::max<int64_t>(1, l.nnzL) * W);
     m_D_il.alloc(C * l.n * W);
-    if (il_fronts_enabled() && l.mf) build_mf_il(l);
-    m_contrib_il.alloc(C * std::max<uint32_t>(1, m_il_fronts ? l.mf_n_contrib : l.n_contrib) * W);
+    m_contrib_il.alloc(C * std::max<uint32_t>(1, l.n_contrib) * W);
     m_scontrib_il.alloc(C * std::max<uint32_t>(1, l.n_scontrib) * W);
     m_zv_il.alloc(C * l.n * W);
     m_xg_il.alloc(C * l.n * W);
     m_stats_part.alloc(l.tasks.size() * B);
-    // every round of the factorization / the backward solve in one launch: batches of up to SLPX_IL_SINGLE_MAX
-    // problems (default 0: never) — beyond that the later rounds' workgroups would sit on CUs waiting while the
-    // first round's are still queueing (r02 measured that for the per-task kernels at 512 problems)
-    {
-      // (measured, profiles/r04_il_single_probe.txt: 64 x N=500 224 k steps/s in one launch against 232 k with a launch per
-      // round, 128 x N=500 396 k against 403 k — the rounds' latency is inside them, not between them: off by default)
-      int single_max = 0;
-      if (const char* env = std::getenv("SLPX_IL_SINGLE_MAX")) single_max = std::atoi(env);
-      m_il_single = static_cast<int>(B) <= single_max;
-      m_il_round_cnt.upload(std::vector<unsigned int>((kIlRowsPerChunk + 1) * C * static_cast<size_t>(std::max(1, l.n_rounds)), 0u));
-    }
     for (auto* buf : {&m_Lx_il, &m_D_il, &m_zv_il, &m_xg_il, &m_contrib_il, &m_scontrib_il}) buf->zero();
     // per task: the plan slices the factor kernel keeps in LDS, packed back to back
     // [n_cref, n_words | pairs (2 words each) | pair ptr | src | out |
@@ -769,11 +746,6 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     uint32_t fbytes = 0, col = 0, solve_bytes = 0;
     std::vector<uint32_t> meta, meta_off;
     for (const LdltTask& t : l.tasks) {
-      if (m_il_fronts) {  // (the fronts bring their own tables: only the solves' LDS is sized here)
-        col = std::max(col, t.n_col + 1);
-        solve_bytes = std::max(solve_bytes, t.n_col * 64u * 8u + 4u * (3u * t.n_col + t.n_lvl + 4u) + 8u * t.n_bwd_items + 16u);
-        continue;
-      }
       const uint32_t n_cref = l.ent_contrib_ptr[t.contrib_ptr_off + t.n_ent];
       meta_off.push_back(static_cast<uint32_t>(meta.size()));
       const size_t head = meta.size();
@@ -841,22 +813,10 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
 }
 
 DeviceNlp::~DeviceNlp() {
-  m_stream.abort_gate();
-  if (m_h_gate) {
-    (void)hipStreamSynchronize(m_stream.raw());
-    (void)hipHostFree(m_h_gate);
-  }
   if (m_h_reg) (void)hipHostFree(m_h_reg);
   if (m_h_stats) (void)hipHostFree(m_h_stats);
   if (m_h_seq) (void)hipHostFree(const_cast<unsigned long long*>(m_h_seq));
   if (m_ipm_host) (void)hipHostFree(m_ipm_host);
-  for (auto& row : m_step_graph)
-    for (hipGraphExec_t& e : row)
-      if (e) (void)hipGraphExecDestroy(e);
-  if (m_fork) (void)hipEventDestroy(m_fork);
-  if (m_join) (void)hipEventDestroy(m_join);
-  if (m_aux_stream) (void)hipStreamDestroy(m_aux_stream);
-  if (m_capture_stream) (void)hipStreamDestroy(m_capture_stream);
   if (m_tape_stream) {
     (void)hipStreamSynchronize(m_tape_stream);
     (void)hipStreamDestroy(m_tape_stream);
@@ -926,8 +886,7 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse) {
   launch_tape(t, reverse, m_stream, m_stream);
 }
 
-// The task classes are independent; `other` may be a forked stream (graph capture) so the
-// few large / global tasks run beside the many small ones.
+// The task classes are independent; `other`: the stream of the few large / global tasks.
 void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small_stream,
                             hipStream_t other) {
   const TapeDev view = t.view();
@@ -999,14 +958,13 @@ void DeviceNlp::sweep_full(bool with_reduce) {
   m_tape_reduce = true;
 }
 void DeviceNlp::sweep_full_for_step() {
-  m_stream.abort_gate();
   const TapeDevice& t = m_full;
   // one generated kernel is the whole sweep (nothing interpreted beside it), the step is the one-launch
-  // multifrontal kernel, and no graph is being captured
+  // multifrontal kernel
   // (and its workgroups are single waves: g-fold's sweep, 256-thread workgroups interpreting its packs of
   // rows, shares the chip badly with the step kernel — 13.3 k steps/s chained against 13.6 k)
   const bool one_kernel = t.n_bodies > 0 && t.n_large == 0 && t.n_global == 0 && (t.tmpl_threads == 64 || t.tmpl_wide_for_chain);
-  if (!m_chain_on || !one_kernel || !m_mf || m_batch != 1 || m_capturing || xg_other() == nullptr || !m_fuse_solve) {
+  if (!m_chain_on || !one_kernel || !m_mf || m_batch != 1 || xg_other() == nullptr || !m_fuse_solve) {
     sweep_full(/*with_reduce=*/false);
     return;
   }
@@ -1057,20 +1015,6 @@ void DeviceNlp::sweep_full_for_step() {
     m_tape_reduce = true;
     return;
   }
-  static const bool chain_debug = std::getenv("SLPX_CHAIN_DEBUG") != nullptr;
-  if (chain_debug && m_chain_seq % 500 == 499) {
-    // the wall clocks (100 MHz) the last chained step left (builds with -DSLPX_CHAIN_STAMPS): sweep first
-    // workgroup in / through its wait / last workgroup out, step kernel last workgroup in / staged / through
-    // its wait / last workgroup out
-    SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
-    SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
-    std::vector<unsigned int> w(128);
-    SLPX_HIP_CHECK(hipMemcpy(w.data(), m_chain.p, w.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    const unsigned long long* st = reinterpret_cast<const unsigned long long*>(w.data() + 64);
-    auto us = [&](unsigned long long v) { return (static_cast<double>(static_cast<long long>(v - st[0]))) / 100.0; };
-    std::fprintf(stderr, "chain step %u: sweep in 0.0, waited %.2f, out %.2f | step kernel in %.2f, staged %.2f, waited %.2f, out %.2f us\n",
-                 m_chain_seq, us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]), us(st[6]));
-  }
   // the step kernel before this sweep: a chained one tells the sweep itself when its last workgroup is
   // through; any other (the first step of a run, a re-attempt of the policy loop) through an event, once
   unsigned int wait_step = m_chain_seq;
@@ -1094,7 +1038,6 @@ void DeviceNlp::sweep_full_for_step() {
 // expected — a shared / preempted / serialized GPU).  Drain both streams, clear the words, keep this
 // system's steps unchained from now on and leave V as a fresh sweep of the current state writes it.
 void DeviceNlp::recover_from_chain_failure() {
-  m_stream.abort_gate();
   if (m_tape_stream != nullptr) SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
   if (m_chain.p != nullptr) SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
@@ -1402,213 +1345,6 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   m_mf = true;
 }
 
-// The fronts for a batch (ldlt_mf_batch_kernel): a task's tables as one image, U and 1/d of every
-// (problem, task) in memory between the factorization and the solve launches.
-void DeviceNlp::build_mf_batch(const LdltPlan& l) {
-  const char* on = std::getenv("SLPX_MF_BATCH");
-  if (on == nullptr || on[0] != '1') return;
-  uint32_t lds = 0;
-  std::vector<uint4> desc(l.tasks.size());
-  std::vector<std::vector<unsigned char>> blobs;
-  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const LdltTask& t = l.tasks[ti];
-    const LdltMfTask& m = l.mf_tasks[ti];
-    const MfCarve cv = mf_carve(t, m);
-    lds = std::max(lds, cv.o_terms);
-    std::vector<unsigned char> blob(cv.o_cnt - cv.o_tab, 0);
-    auto put = [&](uint32_t at, const void* src, size_t bytes) {
-      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
-      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
-    };
-    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
-    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
-    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
-    put(cv.o_src, l.ent_src.data() + t.ent_off, 4u * t.n_ent);
-    {
-      std::vector<uint8_t> fl(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
-      for (uint32_t j = 0; j < m.n_cent; ++j) fl[l.mf_cent[m.cent_off + j]] |= 0x20;  // takes update slots
-      put(cv.o_flags, fl.data(), t.n_ent);
-    }
-    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
-    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
-    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
-    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
-    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
-    desc[ti] = uint4{0u, static_cast<uint32_t>(blob.size() / 16u), 0u, 0u};
-    blobs.push_back(std::move(blob));
-  }
-  size_t stride16 = 1;
-  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
-  std::vector<uint4> image(stride16 * blobs.size() + 4, uint4{0, 0, 0, 0});
-  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
-  lds = mf_align16(lds) + 16u;
-  if (lds > 160u * 1024u) return;
-  m_mf_mfma = l.mf_n_mfma > 0;
-  m_mfb_threads = 256;
-  SLPX_HIP_CHECK(hipDeviceGetAttribute(&m_cus, hipDeviceAttributeMultiprocessorCount, m_device));
-  if (const char* env = std::getenv("SLPX_MFB_THREADS")) m_mfb_threads = std::atoi(env);
-  if (const char* env = std::getenv("SLPX_MFB_PPW")) m_mfb_ppw = std::atoi(env);
-  if (const char* env = std::getenv("SLPX_MFB_WG_PER_CU")) m_mfb_wg_per_cu = std::max(1, std::atoi(env));
-  if (m_mfb_threads != 256 && m_mfb_threads != 512 && m_mfb_threads != 1024) m_mfb_threads = 256;
-  hipFuncAttributes attr{};
-  auto prepare = [&](auto kernel) {
-    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)));
-    return attr.sharedSizeBytes == 0;  // (the tables hold LDS byte addresses from 0)
-  };
-  bool ok;
-  if (m_mfb_threads == 256) ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<256, true>) : prepare(&ldlt_mf_batch_kernel<256, false>);
-  else if (m_mfb_threads == 512) ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<512, true>) : prepare(&ldlt_mf_batch_kernel<512, false>);
-  else ok = m_mf_mfma ? prepare(&ldlt_mf_batch_kernel<1024, true>) : prepare(&ldlt_mf_batch_kernel<1024, false>);
-  if (!ok) return;
-  if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt multifrontal batch: %zu tasks, LDS %u bytes, images %zu bytes, %d threads per workgroup\n", l.tasks.size(), lds,
-                 16 * image.size(), m_mfb_threads);
-  m_mf_tasks.upload(l.mf_tasks);
-  m_mf_fronts.upload(l.mf_fronts);
-  m_mf_image.upload(image);
-  m_mf_image_stride16 = static_cast<uint32_t>(stride16);
-  m_mf_image_desc.upload(desc);
-  const size_t B = static_cast<size_t>(m_batch);
-  m_mf_contrib.alloc(B * std::max<uint32_t>(1, l.mf_n_contrib));
-  m_mf_contrib.zero();
-  m_mfb_ust.alloc(B * std::max<size_t>(1, l.ent_src.size()));
-  m_mfb_ust.zero();
-  m_mfb_invd.alloc(B * std::max<size_t>(1, l.col_perm.size()));
-  m_mfb_invd.zero();
-  m_mf_lds = lds;
-  m_mfb = true;
-}
-
-// ---- batch-interleaved factorization by fronts (ldlt_mfq_kernels.h) ----
-bool DeviceNlp::il_fronts_enabled() {
-  // Built, parity green, measured — and left off (profiles/r04_il_fronts_probe.txt): 64 x N=500 163 k steps/s
-  // against the pair-list kernel's 248 k, 512 x N=1000 166 k against 511 k.  A front keeps ONE wave busy for
-  // ~5000 clocks (the update block's row-by-row trips to LDS) and sixteen problems' values fill the CU's LDS
-  // with one workgroup, of whose eight waves the levels of a task (16, 8, 3, 2, 1 fronts) use two on average;
-  // the pair-list kernel has every lane of a dozen waves per CU on an entry in every level.
-  const char* env = std::getenv("SLPX_IL_FRONTS");
-  return env != nullptr && env[0] == '1';
-}
-void DeviceNlp::il_fronts_options(LdltOptions& o) {
-  o.supernodal = true;
-  o.multifrontal = true;
-  o.min_supernode_width = 2;
-  o.relax_zeros = 8;
-  o.balance_supernode_cuts = true;
-  o.max_front_rows = kMfqMaxFrontRows;
-  o.mfma_min_entries = 0xffffffffu;  // (no matrix-core path in the batch kernel)
-}
-// bytes of the image of a task as build_mf_batch / build_mf_il lay it out (mf_carve from o_tab to the counters)
-static uint32_t mfq_task_lds(const LdltTask& t, const LdltMfTask& m) {
-  const MfCarve cv = mf_carve(t, m);
-  const uint32_t values = 128u * (t.n_ent + m.arena + t.n_col);
-  return std::max<uint32_t>(values + (cv.o_cnt - cv.o_tab), 12u * 1024u + 16u) + 16u;  // (the exit's counter planes reuse the front)
-}
-bool DeviceNlp::il_fronts_fit(const LdltPlan& l) {
-  if (!l.mf || l.mf_max_front_rows > kMfqMaxFrontRows) return false;
-  for (size_t ti = 0; ti < l.tasks.size(); ++ti)
-    if (mfq_task_lds(l.tasks[ti], l.mf_tasks[ti]) > 160u * 1024u) return false;
-  return true;
-}
-
-void DeviceNlp::build_mf_il(const LdltPlan& l) {
-  if (!il_fronts_fit(l)) return;
-  uint32_t lds = 0;
-  std::vector<uint4> desc(l.tasks.size());
-  std::vector<std::vector<unsigned char>> blobs;
-  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const LdltTask& t = l.tasks[ti];
-    const LdltMfTask& m = l.mf_tasks[ti];
-    const MfCarve cv = mf_carve(t, m);
-    lds = std::max(lds, mfq_task_lds(t, m));
-    std::vector<unsigned char> blob(cv.o_cnt - cv.o_tab, 0);
-    auto put = [&](uint32_t at, const void* src, size_t bytes) {
-      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
-      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
-    };
-    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
-    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
-    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
-    put(cv.o_src, l.ent_src.data() + t.ent_off, 4u * t.n_ent);
-    put(cv.o_flags, l.ent_flags.data() + t.ent_off, t.n_ent);
-    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
-    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
-    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
-    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
-    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
-    desc[ti] = uint4{0u, static_cast<uint32_t>(blob.size() / 16u), 0u, 0u};
-    blobs.push_back(std::move(blob));
-  }
-  size_t stride16 = 1;
-  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
-  std::vector<uint4> image(stride16 * blobs.size() + 4, uint4{0, 0, 0, 0});
-  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
-  hipFuncAttributes attr{};
-  SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_mfq_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-  SLPX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&ldlt_mfq_factor_kernel)));
-  if (attr.sharedSizeBytes != 0) return;  // (the tables hold LDS byte addresses from 0)
-  if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt interleaved fronts: %zu tasks, LDS %u bytes, images %zu bytes, %d registers\n", l.tasks.size(), lds,
-                 16 * image.size(), attr.numRegs);
-  m_mf_tasks.upload(l.mf_tasks);
-  m_mf_fronts.upload(l.mf_fronts);
-  m_mf_image.upload(image);
-  m_mf_image_stride16 = static_cast<uint32_t>(stride16);
-  m_mf_image_desc.upload(desc);
-  m_mfq_lds = lds;
-  m_il_fronts = true;
-}
-
-void DeviceNlp::launch_mf_batch(uint32_t task_base, uint32_t n_tasks, bool solve_phase, const double* reg, LdltStats* cur, LdltStats* next,
-                                hipStream_t stream) {
-  const LdltPlan& l = m_l_ref;
-  MfDev md;
-  md.tasks = m_mf_tasks.p;
-  md.fronts = m_mf_fronts.p;
-  md.image = m_mf_image.p;
-  md.image_stride16 = m_mf_image_stride16;
-  md.image_desc = m_mf_image_desc.p;
-  md.n_tasks = static_cast<unsigned int>(l.tasks.size());
-  MfBatch bt;
-  bt.lhs = m_lhs.p;
-  bt.rhs = m_rhs.p;
-  bt.reg = reg;
-  bt.Lx = m_Lx.p;
-  bt.D = m_D.p;
-  bt.zv = m_zv.p;
-  bt.contrib = m_mf_contrib.p;
-  bt.ust = m_mfb_ust.p;
-  bt.invd = m_mfb_invd.p;
-  bt.xg = m_xg.p;
-  bt.out = m_p.p;
-  bt.stats = cur;
-  bt.stats_next = next;
-  bt.nnz_lhs = m_kdev.nnz_lhs;
-  bt.nnzL = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
-  bt.n_contrib = static_cast<long long>(std::max<uint32_t>(1, l.mf_n_contrib));
-  bt.n_ent = static_cast<long long>(std::max<size_t>(1, l.ent_src.size()));
-  bt.n_colp = static_cast<long long>(std::max<size_t>(1, l.col_perm.size()));
-  bt.n = l.n;
-  bt.batch = m_batch;
-  // problems per workgroup: as many as still leave every CU a few workgroups of this round
-  {
-    const long long pairs = static_cast<long long>(n_tasks) * m_batch;
-    long long ppw = pairs / (static_cast<long long>(m_cus) * m_mfb_wg_per_cu);
-    ppw = std::clamp<long long>(ppw, 1, 16);
-    if (m_mfb_ppw > 0) ppw = m_mfb_ppw;
-    bt.ppw = static_cast<int>(std::min<long long>(ppw, m_batch));
-  }
-  const dim3 grid(n_tasks, (m_batch + bt.ppw - 1) / bt.ppw);
-  auto launch = [&](auto kernel, int threads) {
-    hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, stream, m_ldev, md, task_base, solve_phase ? 1 : 0, bt);
-  };
-  if (m_mfb_threads == 256) m_mf_mfma ? launch(&ldlt_mf_batch_kernel<256, true>, 256) : launch(&ldlt_mf_batch_kernel<256, false>, 256);
-  else if (m_mfb_threads == 512) m_mf_mfma ? launch(&ldlt_mf_batch_kernel<512, true>, 512) : launch(&ldlt_mf_batch_kernel<512, false>, 512);
-  else m_mf_mfma ? launch(&ldlt_mf_batch_kernel<1024, true>, 1024) : launch(&ldlt_mf_batch_kernel<1024, false>, 1024);
-}
-
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
 void DeviceNlp::materialize_kkt() {
   if (m_kkt_pending) {  // the factorization that was to evaluate the system never came
@@ -1645,7 +1381,7 @@ void DeviceNlp::materialize_batch_major() {
 void DeviceNlp::assemble() {
   m_lhs_stale = false;
   m_lhs_in_il = false;
-  if (m_il && m_il_direct) {
+  if (m_il) {
     hipLaunchKernelGGL(kkt_assemble_il_kernel, dim3(grid_for(m_kdev.nnz_lhs, 64), il_groups(m_batch)), dim3(256), 0, m_stream,
                        m_kdev, m_V.p, m_s_ref.nV, m_s.p, m_z.p, m_lhs_il.p, m_batch);
     m_lhs_in_il = true;
@@ -1665,7 +1401,7 @@ void DeviceNlp::assemble() {
 // lhs + rhs (+ the separable-sum reductions a sweep_full(false) left out) in one launch
 void DeviceNlp::build_kkt(bool with_reduce) {
   if (m_batch >= kBatchPerThread) {  // throughput regime: the batch kernels, separately
-    if (m_il && m_il_direct) {
+    if (m_il) {
       // (interleaved lhs and rhs: one launch, kkt_build_il_kernel)
       const int na = grid_for(m_kdev.nnz_lhs, 64), nr = (m_kdev.dim + 63) / 64;
       hipLaunchKernelGGL(kkt_build_il_kernel, dim3(na + nr, il_groups(m_batch)), dim3(256), 0, m_stream, m_kdev, m_V.p,
@@ -1753,7 +1489,7 @@ void DeviceNlp::refresh_params(const Graph& g) {
 void DeviceNlp::build_rhs() {
   m_rhs_stale = false;
   m_rhs_in_il = false;
-  if (m_il && m_il_direct) {
+  if (m_il) {
     hipLaunchKernelGGL(kkt_rhs_il_kernel, dim3((m_kdev.dim + 63) / 64, il_groups(m_batch)), dim3(256), 0, m_stream, m_kdev,
                        m_V.p, m_s_ref.nV, m_s.p, m_y.p, m_z.p, m_mu.p, m_rhs_il.p, m_batch);
     m_rhs_in_il = true;
@@ -1863,55 +1599,15 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
     if (!m_rhs_in_il)
       hipLaunchKernelGGL(il_gather_kernel, dim3((l.n + 63) / 64, C), dim3(256), 0, stream, m_rhs.p,
                          static_cast<long long>(l.n), l.n, m_rhs_il.p, m_batch);
-    if (m_il_fronts) {
-      MfDev md;
-      md.tasks = m_mf_tasks.p;
-      md.fronts = m_mf_fronts.p;
-      md.image = m_mf_image.p;
-      md.image_stride16 = m_mf_image_stride16;
-      md.image_desc = m_mf_image_desc.p;
-      md.n_tasks = static_cast<unsigned int>(l.tasks.size());
-      MfqDev q;
-      q.lhs_il = m_lhs_il.p;
-      q.rhs_il = m_rhs_il.p;
-      q.reg = reg;
-      q.Lx_il = m_Lx_il.p;
-      q.D_il = m_D_il.p;
-      q.zv_il = m_zv_il.p;
-      q.contrib_il = m_contrib_il.p;
-      q.stats_part = m_stats_part.p;
-      q.nnz_lhs = nnz;
-      q.nnzL = lxs;
-      q.n_contrib = static_cast<long long>(std::max<uint32_t>(1, l.mf_n_contrib));
-      q.n = l.n;
-      q.batch = m_batch;
-      for (int r = 0; r < l.n_rounds; ++r) {
-        const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
-        hipLaunchKernelGGL(ldlt_mfq_factor_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kMfqThreads), m_mfq_lds, stream, m_ldev, md,
-                           l.round_ptr[r], q);
-      }
-    }
-    if (!m_il_fronts && m_il_single) {
-      // a small batch: every round in ONE launch, round-major (ldlt_factor_il_kernel)
-      const uint32_t groups = static_cast<uint32_t>(kIlRowsPerChunk * C);
-      hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(static_cast<uint32_t>(l.tasks.size()) * groups), dim3(kIlFactorThreads),
-                         m_il_factor_lds, stream, m_ldev, 0u, m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
-                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p, m_il_round_cnt.p, groups);
-    }
-    for (int r = 0; r < l.n_rounds && !m_il_fronts && !m_il_single; ++r) {
+    for (int r = 0; r < l.n_rounds; ++r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_factor_il_kernel, dim3(nt, kIlRowsPerChunk * C), dim3(kIlFactorThreads), m_il_factor_lds, stream, m_ldev,
                          l.round_ptr[r], m_lhs_il.p, nnz, m_rhs_il.p, l.n, reg, m_Lx_il.p, lxs, m_D_il.p,
-                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p,
-                         static_cast<unsigned int*>(nullptr), 0u);
+                         m_contrib_il.p, cs, m_zv_il.p, m_stats_part.p, m_batch, m_il_meta.p, m_il_meta_off.p);
     }
     hipLaunchKernelGGL(ldlt_stats_il_kernel, dim3(m_batch), dim3(64), 0, stream, m_stats_part.p,
                        static_cast<int>(l.tasks.size()), reg, cur, m_batch);
     m_il_outputs_stale = true;
-  } else if (m_mfb) {
-    for (int r = 0; r < l.n_rounds; ++r)
-      launch_mf_batch(l.round_ptr[r], l.round_ptr[r + 1] - l.round_ptr[r], false, reg, cur, r == 0 ? next : nullptr, stream);
-    m_mfb_rhs_in_fronts = true;
   } else if (m_single_launch) {
     KktFuse f = take_kkt_fuse();
     // every round in one launch; tasks wait on device-side round counters
@@ -1934,7 +1630,6 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
 
 void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<double>& gamma,
                        const std::vector<uint8_t>& active) {
-  m_stream.abort_gate();
   write_reg(delta, gamma, active);
   m_twin_mode = 0;
   m_stats_cur ^= 1;
@@ -1944,31 +1639,28 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
 
 void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
                                      const std::vector<uint8_t>& active) {
-  // (the multifrontal step hands x over through the two x buffers: not inside a captured graph; the
-  // pair-list one-launch kernel needs every task's 1024-thread workgroup resident at once)
+  // (the pair-list one-launch kernel needs every task's 1024-thread workgroup resident at once)
   const bool mf_now = m_mf && xg_other() != nullptr;
   if (!m_fuse_solve || (!mf_now && !m_sip_ok)) {
     factor(delta, gamma, active);
     solve_backsub_publish();
     return;
   }
-  m_stream.abort_gate();
-  m_la_rode = false;
   write_reg(delta, gamma, active);
   m_twin_mode = 0;
   m_stats_cur ^= 1;
   enqueue_factor_solve(m_stats_cur);
-  if (!m_capturing) m_stats_seq = ++m_seq_expected;
+  m_stats_seq = ++m_seq_expected;
   m_stats_in_host = true;
 }
 
 // ---- twin attempt (ldlt_mf_twin_kernel) ----
 bool DeviceNlp::twin_available() {
-  if (m_twin_state != 0) return m_twin_state > 0 && m_mf && xg_other() != nullptr && !m_capturing;
+  if (m_twin_state != 0) return m_twin_state > 0 && m_mf && xg_other() != nullptr;
   m_twin_state = -1;
   const char* env = std::getenv("SLPX_TWIN");
   if (env != nullptr && env[0] == '0') return false;
-  if (!m_mf || m_mf_mfma || m_batch != 1 || xg_other() == nullptr || !m_fuse_solve || !m_seq_poll) return false;
+  if (!m_mf || m_mf_mfma || m_batch != 1 || xg_other() == nullptr || !m_fuse_solve) return false;
   const LdltPlan& l = m_l_ref;
   // both attempts' workgroups resident at once (their tasks wait for each other inside the launch)
   int cus = 0, per_cu = 0;
@@ -1998,9 +1690,8 @@ bool DeviceNlp::twin_available() {
 }
 
 // One launch of the multifrontal step kernel (twin_mode != 0: two attempts, ldlt_mf_twin_kernel) with the buffer
-// roles, parities and chain numbers of this moment; book_mf_step() is what the launch changes on the host — at
-// once for a plain launch, when its gate opens for a pre-launched one.
-void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const MfGate& gate) {
+// roles, parities and chain numbers of this moment; book_mf_step() is what the launch changes on the host.
+void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained) {
   const LdltPlan& l = m_l_ref;
   const int parity = m_stats_cur ^ 1;
   LdltStats* cur = m_stats.p + static_cast<size_t>(parity);
@@ -2022,18 +1713,6 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
   md.delta = reg[0];  // (by value: MfDev)
   md.gamma = reg[1];
   const double* const reg_by_value = nullptr;
-  // the look-ahead iterate as the launch's last act (ipm_lookahead_rides; not in a launch held at a gate: tau is
-  // the host's to decide)
-  IpmLookaheadArgs la;
-  m_la_rode = false;
-  if (m_la_tau >= 0.0 && gate.word == nullptr && m_ipm_alpha.p != nullptr && m_batch == 1) {
-    la = lookahead_args(m_la_tau, twin_mode);
-    la.on = 1;
-    la.stats = cur;
-    if (twin_mode != 0) la.tw.stats = m_stats_tw.p + static_cast<size_t>(m_stats_tw_cur ^ 1);
-    la.done_cnt = m_la_done.p;
-    m_la_rode = true;
-  }
   if (twin_mode != 0) {
     const int tw_parity = m_stats_tw_cur ^ 1;
     MfTwin tw;
@@ -2055,7 +1734,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p, l.n,
-                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, gate, la);
+                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw);
     };
     if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
     else launch(&ldlt_mf_twin_kernel<512>, 512);
@@ -2064,7 +1743,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p,
-                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, gate, la);
+                         l.n, m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf);
     };
     if (m_mf_threads == 1024) {
       if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<1024, true, true>, 1024) : launch(&ldlt_mf_step_kernel<1024, false, true>, 1024);
@@ -2090,7 +1769,6 @@ void DeviceNlp::book_mf_step(int twin_mode, bool chained) {
 }
 
 bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode) {
-  m_stream.abort_gate();
   if (!twin_available() || m_stream.tape_pending) return false;
   m_h_reg[0] = delta0;
   m_h_reg[1] = gamma0;
@@ -2098,116 +1776,11 @@ bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double d
   m_h_reg[3] = gamma1;
   if (!m_kkt_pending) materialize_kkt();
   const KktFuse f = take_kkt_fuse();
-  launch_mf_step(mode, m_h_reg, f, false, MfGate{});
+  launch_mf_step(mode, m_h_reg, f, false);
   book_mf_step(mode, false);
   m_stats_seq = ++m_seq_expected;
   m_stats_in_host = true;
   return true;
-}
-
-// ---- a step launched ahead of the decision to take it (MfGate) ----
-// A launch that returns only when its kernel is through (AMD_SERIALIZE_KERNEL, some profiler modes) can never be
-// handed its word: the one-time probe waits up to 20 ms for a word the host writes right after the launch call.
-__global__ void gate_probe_kernel(const unsigned long long* word, unsigned long long* seen) {
-  const unsigned long long t0 = wall_clock64();
-  unsigned long long v = 0;
-  while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0 && wall_clock64() - t0 < 2000000ull)
-    __builtin_amdgcn_s_sleep(8);
-  seen[0] = v;
-}
-
-bool DeviceNlp::can_prelaunch(int twin_mode) {
-  if (m_gate_state == 0) {
-    m_gate_state = -1;
-    const char* env = std::getenv("SLPX_PRELAUNCH");
-    // (off unless asked for: measured, it gains nothing — DESIGN.md section 4a, profiles/r04_prelaunch_ab.txt)
-    if (env != nullptr && env[0] == '1' && m_batch == 1 && m_seq_poll && m_fuse_solve && m_fuse_kkt) {
-      SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_h_gate), 64));
-      std::memset(m_h_gate, 0, 64);
-      m_gate_relay.upload(std::vector<unsigned long long>(2, 0ull));
-      m_stream.gate_word = m_h_gate;
-      hipLaunchKernelGGL(gate_probe_kernel, dim3(1), dim3(1), 0, m_stream.raw(), m_h_gate + 3, m_gate_relay.p);
-      *reinterpret_cast<volatile unsigned long long*>(m_h_gate + 3) = 1ull;
-      SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
-      unsigned long long seen = 0;
-      SLPX_HIP_CHECK(hipMemcpy(&seen, m_gate_relay.p, sizeof(seen), hipMemcpyDeviceToHost));
-      SLPX_HIP_CHECK(hipMemset(m_gate_relay.p, 0, 2 * sizeof(unsigned long long)));
-      if (seen != 0) m_gate_state = 1;
-      else if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "slpx: launches return when their kernels are through here: no step is launched ahead\n");
-    }
-  }
-  if (m_gate_state < 0 || !m_mf || xg_other() == nullptr || m_capturing) return false;
-  if (twin_mode != 0 && (!twin_available() || m_stream.tape_pending)) return false;
-  return true;
-}
-
-bool DeviceNlp::prelaunch_step(int twin_mode, const double* reg, int kkt_mode, bool mu_through_gate, bool lookahead_roles) {
-  m_stream.abort_gate();
-  if (kkt_mode == 0 || !can_prelaunch(twin_mode)) return false;
-  auto swap_roles = [&] {
-    if (!lookahead_roles) return;
-    m_in.swap(m_trial_in);
-    m_s.swap(m_s_ahead);
-    m_y.swap(m_y_ahead);
-    m_z.swap(m_z_ahead);
-    m_V.swap(m_V_trial);
-  };
-  double* reg_pre = m_h_reg + 4 + 4 * (m_gate_ticket & 1ull);  // (the launch before may still be reading its own)
-  for (int k = 0; k < (twin_mode != 0 ? 4 : 2); ++k) reg_pre[k] = reg[k];
-  MfGate g;
-  g.word = m_h_gate;
-  g.ticket = ++m_gate_ticket;
-  g.relay = m_gate_relay.p;
-  g.mu_out = mu_through_gate ? m_mu.p : nullptr;
-  g.abandoned = m_h_gate + 2;
-  m_pre.twin_mode = twin_mode;
-  m_pre.kkt_mode = kkt_mode;
-  m_pre.chained = m_stream.tape_pending;
-  m_pre.mu_through_gate = mu_through_gate;
-  swap_roles();
-  launch_mf_step(twin_mode, reg_pre, kkt_fuse_for(kkt_mode), m_pre.chained, g);
-  swap_roles();
-  m_stream.gate_ticket = g.ticket;
-  m_stream.gate_pending = true;
-  return true;
-}
-
-void DeviceNlp::open_gate(double mu) {
-  if (!m_stream.gate_pending) throw std::runtime_error("slpx: open_gate() without a pre-launched step");
-  // {mu, 2 x ticket} in ONE 16-byte store: the kernel's 16-byte load sees both or neither
-  unsigned long long mu_bits;
-  std::memcpy(&mu_bits, &mu, sizeof(mu_bits));
-  _mm_store_si128(reinterpret_cast<__m128i*>(m_h_gate), _mm_set_epi64x(static_cast<long long>(2ull * m_stream.gate_ticket), static_cast<long long>(mu_bits)));
-  m_stream.gate_pending = false;
-  // what take_kkt_fuse() and the launch would have booked
-  if (m_pre.kkt_mode) {
-    if (m_fuse_kkt_store) m_lhs_stale = m_rhs_stale = false;
-    m_kkt_pending = 0;
-  }
-  book_mf_step(m_pre.twin_mode, m_pre.chained);
-  m_stats_seq = ++m_seq_expected;
-  m_stats_in_host = true;
-}
-
-// (-DSLPX_GATE_STAMPS) the sums the kernels left, in microseconds per step, to stderr; clears them
-void DeviceNlp::debug_gate_stamps(const char* label) {
-#ifdef SLPX_GATE_STAMPS
-  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
-  unsigned long long h[32];
-  SLPX_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(slpx_gate_stamps), sizeof(h)));
-  const double n = static_cast<double>(std::max<unsigned long long>(1, h[15]));
-  auto us = [&](int k) { return static_cast<double>(static_cast<long long>(h[k])) / 100.0 / n; };
-  std::fprintf(stderr, "slpx gate stamps (%s, %llu step kernels): numbers -> step kernel in %.2f us, in -> staged %.2f, staged -> through the gate %.2f, "
-               "gate -> counters out %.2f, counters out -> the launch behind in %.2f; the step before's counters out -> step kernel in %.2f\n", label, h[15], us(8), us(9), us(10), us(11), us(12), us(13));
-  const double ne = static_cast<double>(std::max<unsigned long long>(1, h[20]));
-  auto ue = [&](int k) { return static_cast<double>(static_cast<long long>(h[k])) / 100.0 / ne; };
-  std::fprintf(stderr, "slpx gate stamps (%s, %llu look-ahead chains that ran): look-ahead in -> out %.2f us (per step kernel), out -> error launch in "
-               "(the sweep between) %.2f, error launch in -> numbers out %.2f\n", label, h[20], us(16), ue(17), ue(18));
-  std::memset(h, 0, sizeof(h));
-  SLPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(slpx_gate_stamps), h, sizeof(h)));
-#else
-  (void)label;
-#endif
 }
 
 void DeviceNlp::adopt_twin() {
@@ -2235,7 +1808,7 @@ void DeviceNlp::enqueue_factor_solve(int parity) {
   if (m_mf && xg_other() != nullptr) {
     const bool chained = m_stream.tape_pending;
     m_stats_cur = parity ^ 1;  // (the callers flipped it already; launch_mf_step / book_mf_step do it themselves)
-    launch_mf_step(0, m_h_reg, f, chained, MfGate{});
+    launch_mf_step(0, m_h_reg, f, chained);
     book_mf_step(0, chained);
     return;
   }
@@ -2255,7 +1828,7 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
                                   m_batch * sizeof(LdltStats), hipMemcpyDeviceToHost, m_stream));
   // Busy-poll instead of a blocking wait: the interrupt-driven wake-up of
   // hipStreamSynchronize costs tens of microseconds, a tenth of a whole Newton step.
-  if (m_stats_in_host && m_batch == 1 && m_seq_poll) {
+  if (m_stats_in_host && m_batch == 1) {
     // the publishing kernel's sequence number (see step_backsub_kernel); the stream is
     // consulted now and then so that a failed launch cannot hang the host
     unsigned spins = 0;
@@ -2265,94 +1838,17 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
         if (st != hipErrorNotReady) {
           SLPX_HIP_CHECK(st);
           if (*m_h_seq < m_stats_seq)
-            throw std::runtime_error(m_h_gate != nullptr && m_h_gate[2] == m_gate_ticket
-                                         ? "slpx: a pre-launched step gave up waiting for its gate"
-                                         : "slpx: step finished without publishing its counters");
+            throw std::runtime_error("slpx: step finished without publishing its counters");
         }
       }
     }
   } else {
-    m_stream.abort_gate();
     hipError_t st;
     while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
     }
     SLPX_HIP_CHECK(st);
   }
   std::copy(m_h_stats, m_h_stats + m_batch, out.begin());
-}
-
-// One whole first-attempt Newton step as a HIP graph: [AD refresh] → assemble ‖ rhs →
-// factorization rounds → forward/backward solves → back-substitution → counters to pinned
-// host memory.  One host call instead of ~16, and the independent kernels (small/large
-// tape tasks; lhs/rhs assembly) run side by side on a forked capture stream.  Captured
-// once per (counter-buffer parity, refresh_ad).
-void DeviceNlp::launch_step_graph(bool refresh_ad, const std::vector<double>& delta,
-                                  const std::vector<double>& gamma,
-                                  const std::vector<uint8_t>& active) {
-  write_reg(delta, gamma, active);
-  m_stats_cur ^= 1;
-  m_xg_by_data = false;  // a graph's pointers are baked in: round counters from here on (they do not care what x holds)
-  hipGraphExec_t& exec = m_step_graph[m_stats_cur][refresh_ad ? 1 : 0];
-  if (exec == nullptr) {
-    if (m_aux_stream == nullptr) {
-      SLPX_HIP_CHECK(hipStreamCreateWithFlags(&m_aux_stream, hipStreamNonBlocking));
-      SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_fork, hipEventDisableTiming));
-      SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_join, hipEventDisableTiming));
-    }
-    hipStream_t cap = m_capture_stream;
-    if (cap == nullptr) {
-      SLPX_HIP_CHECK(hipStreamCreateWithFlags(&m_capture_stream, hipStreamNonBlocking));
-      cap = m_capture_stream;
-    }
-    hipStream_t saved = m_stream;
-    SLPX_HIP_CHECK(hipStreamSynchronize(saved));
-    SLPX_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    m_stream = cap;
-    m_capturing = true;
-    auto fork = [&] {
-      SLPX_HIP_CHECK(hipEventRecord(m_fork, cap));
-      SLPX_HIP_CHECK(hipStreamWaitEvent(m_aux_stream, m_fork, 0));
-    };
-    auto join = [&] {
-      SLPX_HIP_CHECK(hipEventRecord(m_join, m_aux_stream));
-      SLPX_HIP_CHECK(hipStreamWaitEvent(cap, m_join, 0));
-    };
-    // Measured (rocprofv3 kernel trace, MI355X): a cross-queue join costs ≈10 µs, more
-    // than running the large tape task (16 µs) or the rhs kernel (4 µs) after their
-    // sibling, and the 152 KB-LDS large task cannot start anyway while the small tasks
-    // hold every CU's LDS.  So the graph is a single chain unless forking is asked for.
-    if (m_fork_in_graph) {
-      if (refresh_ad) {
-        fork();
-        launch_tape(m_full, true, /*small_stream=*/cap, /*other_stream=*/m_aux_stream);
-        join();
-      }
-      fork();
-      assemble();
-      m_stream = m_aux_stream;
-      build_rhs();
-      m_stream = cap;
-      join();
-    } else {
-      if (refresh_ad) sweep_full(/*with_reduce=*/false);
-      build_kkt_for_step(/*with_reduce=*/refresh_ad);
-    }
-    if (m_fuse_solve && m_sip_ok) {
-      enqueue_factor_solve(m_stats_cur);
-    } else {
-      enqueue_factor(m_stats_cur, cap);
-      solve_backsub_publish();
-    }
-    m_stream = saved;
-    m_capturing = false;
-    hipGraph_t graph = nullptr;
-    SLPX_HIP_CHECK(hipStreamEndCapture(cap, &graph));
-    SLPX_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    SLPX_HIP_CHECK(hipGraphDestroy(graph));
-  }
-  SLPX_HIP_CHECK(hipGraphLaunch(exec, m_stream));
-  if (m_batch == 1) m_stats_seq = ++m_seq_expected;  // the replayed back-substitution publishes once
-  m_stats_in_host = true;
 }
 
 // Full solve for a right-hand side that arrived AFTER the factorization (second-order
@@ -2376,7 +1872,7 @@ void DeviceNlp::solve() {
     solve_after_factor();
     return;
   }
-  if (m_single_launch && m_batch == 1 && !m_capturing && m_fwd_single) {
+  if (m_single_launch && m_batch == 1) {
     // one problem: every round in ONE launch (the tasks order themselves through the round counters)
     hipLaunchKernelGGL(ldlt_fwd_kernel, dim3(static_cast<uint32_t>(l.tasks.size()), 1), dim3(256), l.solve_lds_bytes, m_stream,
                        m_ldev, 0u, m_rhs.p, l.n, m_Lx.p, lxs, m_D.p, m_scontrib.p, scs, m_zv.p, m_fround_cnt.p);
@@ -2388,7 +1884,6 @@ void DeviceNlp::solve() {
                          m_zv.p, static_cast<unsigned int*>(nullptr));
     }
   }
-  m_mfb_rhs_in_fronts = false;  // z of THIS right-hand side is in zv: the pair-list backward solve from L
   solve_after_factor();
 }
 
@@ -2402,7 +1897,7 @@ void DeviceNlp::solve_backsub_publish() {
   const LdltStats* src = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
   if (m_fuse_backsub) {
     solve_after_factor_impl(src);
-    if (m_batch == 1 && !m_capturing) m_stats_seq = ++m_seq_expected;
+    if (m_batch == 1) m_stats_seq = ++m_seq_expected;
   } else {
     solve_after_factor_impl(nullptr);
     backsub_and_publish(src);
@@ -2415,25 +1910,11 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   if (m_il) {
     const int C = (m_batch + 63) / 64;
-    if (m_il_single) {
-      hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(static_cast<uint32_t>(l.tasks.size()) * static_cast<uint32_t>(C)),
-                         dim3(kIlLanes * kIlBwdWaves), m_il_solve_lds, m_stream, m_ldev, 0u, l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p,
-                         m_p.p, m_batch, m_il_round_cnt.p + static_cast<size_t>(kIlRowsPerChunk) * C * l.n_rounds, static_cast<uint32_t>(C));
-      SLPX_HIP_CHECK(hipGetLastError());
-      return;
-    }
     for (int r = l.n_rounds - 1; r >= 0; --r) {
       const uint32_t nt = l.round_ptr[r + 1] - l.round_ptr[r];
       hipLaunchKernelGGL(ldlt_bwd_il_kernel, dim3(nt, C), dim3(kIlLanes * kIlBwdWaves), m_il_solve_lds, m_stream, m_ldev,
-                         l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch,
-                         static_cast<unsigned int*>(nullptr), 0u);
+                         l.round_ptr[r], l.n, m_Lx_il.p, lxs, m_zv_il.p, m_xg_il.p, m_p.p, m_batch);
     }
-    SLPX_HIP_CHECK(hipGetLastError());
-    return;
-  }
-  if (m_mfb && m_mfb_rhs_in_fronts) {
-    for (int r = l.n_rounds - 1; r >= 0; --r)
-      launch_mf_batch(l.round_ptr[r], l.round_ptr[r + 1] - l.round_ptr[r], true, nullptr, nullptr, nullptr, m_stream);
     SLPX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -2547,8 +2028,7 @@ void DeviceNlp::backsub_and_publish(const LdltStats* stats_src) {
                      dim3(256), 0, m_stream, m_kdev, m_V.p, m_s_ref.nV, m_p.p, m_s.p, m_z.p, m_mu.p,
                      m_ps.p, m_pz.p, stats_src, stats_src ? m_h_stats : nullptr, m_seq_dev.p,
                      (stats_src && m_batch == 1) ? m_h_seq : nullptr);
-  // (while a graph is being captured nothing runs: launch_step_graph counts each replay)
-  if (stats_src && m_batch == 1 && !m_capturing) m_stats_seq = ++m_seq_expected;
+  if (stats_src && m_batch == 1) m_stats_seq = ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -2591,7 +2071,6 @@ void DeviceNlp::ipm_set_error_scaling(const std::vector<double>& scales) {
 // After ipm_trial_metrics() / ipm_errors(): spins on the sequence number those launches
 // publish (the stream is consulted now and then so a failed launch cannot hang the host).
 void DeviceNlp::wait_published() {
-  if (!m_seq_poll) return wait();
   unsigned spins = 0;
   while (*m_h_seq < m_seq_expected) {
     if ((++spins & 0xfffu) == 0) {
@@ -2605,7 +2084,6 @@ void DeviceNlp::wait_published() {
 }
 
 void DeviceNlp::wait() {
-  m_stream.abort_gate();
   hipError_t st;
   while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
   }
@@ -2651,20 +2129,7 @@ IpmLookaheadArgs DeviceNlp::lookahead_args(double tau, int twin_mode) {
   return a;
 }
 
-void DeviceNlp::ipm_lookahead_rides(double tau) {
-  if (m_la_state == 0) {
-    const char* env = std::getenv("SLPX_IPM_LOOKAHEAD_RIDE");
-    m_la_state = env != nullptr && env[0] == '1' ? 1 : -1;  // (off unless asked for: measured no faster)
-    if (m_la_state > 0) m_la_done.upload(std::vector<unsigned int>(1, 0u));
-  }
-  m_la_tau = m_la_state > 0 ? tau : -1.0;
-}
-
 void DeviceNlp::ipm_lookahead(double tau) {
-  if (m_la_rode) {  // (it was the last act of the step launch)
-    m_la_rode = false;
-    return;
-  }
   hipLaunchKernelGGL(ipm_lookahead_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, lookahead_args(tau, m_twin_mode));
   SLPX_HIP_CHECK(hipGetLastError());
 }

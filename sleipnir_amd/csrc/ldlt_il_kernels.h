@@ -107,29 +107,12 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
     const double* __restrict__ rhs_il, int n, const double* __restrict__ reg, double* __restrict__ Lx_il,
     long long nnzL, double* __restrict__ D_il, double* __restrict__ contrib_il, int n_contrib,
     double* __restrict__ zv_il, LdltStats* __restrict__ stats_part, int batch,
-    const uint32_t* __restrict__ il_meta, const uint32_t* __restrict__ il_meta_off,
-    unsigned int* __restrict__ round_cnt, uint32_t n_groups) {
+    const uint32_t* __restrict__ il_meta, const uint32_t* __restrict__ il_meta_off) {
   extern __shared__ __attribute__((aligned(16))) double il_smem[];
-  // round_cnt != nullptr: EVERY round in this launch (small batches: a launch per round is ~20 us of latency
-  // each, mostly the plan and the matrix values coming in — which do not depend on the round below).  The grid
-  // is one-dimensional, ROUND-major — all groups' tasks of round 0, then round 1, ... — so whatever a workgroup
-  // waits for was dispatched before it; a task waits for the round below it (per group of 16 problems) between
-  // its matrix values and its update blocks, which then cross workgroups coherently.
-  const bool single = round_cnt != nullptr;
-  uint32_t task_index = task_base + blockIdx.x;
-  int g = blockIdx.y;  // g: group of 16 problems
-  if (single) {
-    uint32_t at = blockIdx.x;
-    for (int r = 0; r < L.n_rounds; ++r) {
-      const uint32_t nt = L.round_ptr[r + 1] - L.round_ptr[r];
-      if (at < nt * n_groups) {
-        g = static_cast<int>(at / nt);
-        task_index = L.round_ptr[r] + at % nt;
-        break;
-      }
-      at -= nt * n_groups;
-    }
-  }
+  // (every round of a small batch in ONE launch, round counters per group of problems, was measured equal to
+  // slower — profiles/r04_il_single_probe.txt: the ~20 us of a round are inside it — and removed)
+  const uint32_t task_index = task_base + blockIdx.x;
+  const int g = blockIdx.y;  // g: group of 16 problems
   const LdltTask t = L.tasks[task_index];
   const int lane = threadIdx.x;
   const int slot = lane >> kIlWShift, pl = lane & (kIlW - 1);  // slot: 0 .. kIlSlots - 1
@@ -231,8 +214,6 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
     }
     for (; e < t.n_ent; e += kIlSlots) U[e * kIlW] = matrix_value(e);
   }
-  if (single && t.round > 0)
-    round_wait(&round_cnt[static_cast<size_t>(g) * L.n_rounds + t.round - 1], L.round_ptr[t.round] - L.round_ptr[t.round - 1], nullptr);
   {
     // (a slot only touches its own entries: no cross-slot ordering needed before this)
     uint32_t r = s_crptr[slot];
@@ -240,11 +221,11 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
     for (; r + 7 < re; r += 8) {
       double v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = coherent_load(&contrib[static_cast<size_t>(s_cref[2 * (r + j) + 1]) * kIlW], single);
+      for (int j = 0; j < 8; ++j) v[j] = contrib[static_cast<size_t>(s_cref[2 * (r + j) + 1]) * kIlW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) U[s_cref[2 * (r + j)] * kIlW] -= v[j];  // same entry: in list order
     }
-    for (; r < re; ++r) U[s_cref[2 * r] * kIlW] -= coherent_load(&contrib[static_cast<size_t>(s_cref[2 * r + 1]) * kIlW], single);
+    for (; r < re; ++r) U[s_cref[2 * r] * kIlW] -= contrib[static_cast<size_t>(s_cref[2 * r + 1]) * kIlW];
   }
   __syncthreads();  // (one wave: orders the LDS traffic of the four slots)
   SLPX_IL_CLOCK(2);
@@ -276,12 +257,7 @@ __global__ __launch_bounds__(kIlFactorThreads) void ldlt_factor_il_kernel(
   // attempt keep what an earlier, accepted attempt left for their problem
   for (uint32_t x = slot; x < t.n_ext; x += kIlSlots) {
     const double v = pair_sum(s_pptr[t.n_ent + x], s_pptr[t.n_ent + x + 1]);
-    if (active) coherent_store(&contrib[static_cast<size_t>(s_ext[x]) * kIlW], v, single);
-  }
-  if (single) {
-    const int last = L.n_rounds - 1;
-    round_signal(&round_cnt[static_cast<size_t>(g) * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
-                 static_cast<int>(t.round) == last ? L.round_ptr[last + 1] - L.round_ptr[last] : 0u);
+    if (active) contrib[static_cast<size_t>(s_ext[x]) * kIlW] = v;
   }
   SLPX_IL_CLOCK(4);
   // results: L = U / d, and z = D⁻¹L⁻¹Pb from the right-hand-side row
@@ -411,26 +387,10 @@ __global__ __launch_bounds__(kIlLanes) void ldlt_fwd_il_kernel(
 constexpr int kIlBwdWaves = 4;
 __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
     LdltDev L, uint32_t task_base, int n, const double* __restrict__ Lx_il, long long nnzL,
-    const double* __restrict__ zv_il, double* __restrict__ xg_il, double* __restrict__ out, int batch,
-    unsigned int* __restrict__ round_cnt, uint32_t n_chunks) {
+    const double* __restrict__ zv_il, double* __restrict__ xg_il, double* __restrict__ out, int batch) {
   extern __shared__ __attribute__((aligned(16))) double il_smem[];
-  // round_cnt != nullptr: every round in this launch, LAST round first in the one-dimensional grid (see
-  // ldlt_factor_il_kernel); a task waits for the round above it, per chunk of 64 problems, after staging
-  const bool single = round_cnt != nullptr;
-  uint32_t task_index = task_base + blockIdx.x;
-  int c = blockIdx.y;
-  if (single) {
-    uint32_t at = blockIdx.x;
-    for (int r = L.n_rounds - 1; r >= 0; --r) {
-      const uint32_t nt = L.round_ptr[r + 1] - L.round_ptr[r];
-      if (at < nt * n_chunks) {
-        c = static_cast<int>(at / nt);
-        task_index = L.round_ptr[r] + at % nt;
-        break;
-      }
-      at -= nt * n_chunks;
-    }
-  }
+  const uint32_t task_index = task_base + blockIdx.x;
+  const int c = blockIdx.y;
   const LdltTask t = L.tasks[task_index];
   const int tid = threadIdx.x, lane = tid & (kIlLanes - 1), wave = tid >> 6;
   const int b = c * kIlLanes + lane;
@@ -459,12 +419,10 @@ __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
     for (uint32_t k = tid; k < t.n_bwd_items; k += kThreads) s_items[k] = g_items[k];
   }
   __syncthreads();
-  if (single && static_cast<int>(t.round) + 1 < L.n_rounds)
-    round_wait(&round_cnt[static_cast<size_t>(c) * L.n_rounds + t.round + 1], L.round_ptr[t.round + 2] - L.round_ptr[t.round + 1], nullptr);
   // a column's items reference later levels' columns or rows of ancestor tasks (bit 31: global permuted
-  // row, final since an earlier launch — or an earlier round of this one)
+  // row, final since an earlier launch)
   auto operand = [&](const LdltSolveItem it) {
-    return (it.ref & 0x80000000u) ? coherent_load(&xg[static_cast<size_t>(it.ref & 0x7fffffffu) * kIlW], single) : x[it.ref * kIlLanes];
+    return (it.ref & 0x80000000u) ? xg[static_cast<size_t>(it.ref & 0x7fffffffu) * kIlW] : x[it.ref * kIlLanes];
   };
   // eight items of a column from q on (masked beyond qe): the L values, and the records for the operands
   auto request = [&](uint32_t q, uint32_t qe, double (&lv)[8], LdltSolveItem (&its)[8]) {
@@ -508,11 +466,9 @@ __global__ __launch_bounds__(kIlLanes* kIlBwdWaves) void ldlt_bwd_il_kernel(
   for (uint32_t i = wave; i < t.n_col; i += kIlBwdWaves) {
     const uint32_t pj = s_colperm[i];
     const double v = x[i * kIlLanes];
-    coherent_store(&xg[static_cast<size_t>(pj) * kIlW], v, single);
+    xg[static_cast<size_t>(pj) * kIlW] = v;
     if (b < batch) out[static_cast<size_t>(b) * n + L.perm[pj]] = v;
   }
-  if (single) round_signal(&round_cnt[static_cast<size_t>(c) * L.n_rounds], static_cast<int>(t.round), L.n_rounds,
-                           t.round == 0 ? L.round_ptr[1] - L.round_ptr[0] : 0u);
 }
 
 }  // namespace slpx

@@ -26,20 +26,6 @@
 
 namespace slpx {
 
-// -DSLPX_GATE_STAMPS (profiles/gate_stamps.sh): 100 MHz wall clocks between the kernels of an iteration, summed in
-// device memory — [0] the last publication of an iteration's numbers, [1] of a step's counters; [8+k] sums:
-// numbers -> step kernel in, in -> staged, staged -> through the gate, gate -> counters out, counters out -> the
-// launch behind it in; [15] steps.  DeviceNlp::debug_gate_stamps() reads and clears them.
-#ifdef SLPX_GATE_STAMPS
-__device__ unsigned long long slpx_gate_stamps[32];  // ([3] look-ahead out; [16..] more sums: look-ahead in -> out, out -> error launch in, in -> numbers out, [20] error launches)
-#define SLPX_GATE_STAMP_SET(k) slpx_gate_stamps[k] = wall_clock64()
-#define SLPX_GATE_STAMP_ADD(k, since) atomicAdd(&slpx_gate_stamps[k], wall_clock64() - (since))
-#else
-#define SLPX_GATE_STAMP_SET(k)
-#define SLPX_GATE_STAMP_ADD(k, since)
-#endif
-
-
 // Phase clocks (wall_clock64, 100 MHz) of the first task of the selected round in the last
 // launch of each kernel: [0,8) factor, [8,16) fwd, [16,24) bwd (debug aid,
 // slpx_debug_ldlt_clocks).
@@ -1128,7 +1114,6 @@ __device__ __forceinline__ void publish_stats(const BacksubFuse& F, bool coheren
     st = F.stats_src[0];
   }
   F.stats_host[0] = st;
-  SLPX_GATE_STAMP_SET(1);
   if (F.seq_host != nullptr) {
     __threadfence_system();
     const unsigned long long v = *F.seq_dev + 1;

@@ -59,17 +59,9 @@ struct MfDev {
   double delta = 0.0, gamma = 0.0;
 };
 
-// (-DSLPX_CHAIN_STAMPS: wall clocks of the last chained step for SLPX_CHAIN_DEBUG, words 64.. of the chain buffer)
-#ifdef SLPX_CHAIN_STAMPS
-#define SLPX_CHAIN_STAMP(k) \
-  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[k] = wall_clock64()
-#else
-#define SLPX_CHAIN_STAMP(k)
-#endif
 // the sweep this step reads is complete (one lane asks; the workgroup's other waves come through the barrier)
 __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* stats) {
   if (Mf.wait_step != 0u) {
-    SLPX_CHAIN_STAMP(4);  // (the last workgroup dispatched: staged)
     if (threadIdx.x == 0) {
       unsigned int spins = 0, seen;
       // (bit 31 of the word: a workgroup of that sweep gave up waiting for the step kernel before it — V may
@@ -87,7 +79,6 @@ __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* st
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // V as the sweep's workgroups left it, not as this XCD's L2 remembers it
     }
     __syncthreads();
-    SLPX_CHAIN_STAMP(5);
   }
 }
 // this workgroup has read everything it will of V, s, z: the next step's sweep may overwrite V
@@ -97,63 +88,11 @@ __device__ __forceinline__ void mf_signal_done(const MfDev& Mf) {
     if (threadIdx.x == 0) {
       const unsigned int old = __hip_atomic_fetch_add(Mf.chain + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old + 1u == Mf.n_workgroups) {
-#ifdef SLPX_CHAIN_STAMPS
-        reinterpret_cast<unsigned long long*>(Mf.chain + 64)[6] = wall_clock64();
-#endif
         __hip_atomic_store(Mf.chain + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(Mf.chain + 48, Mf.this_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// A step launched BEFORE the host knows that it wants it (DeviceNlp::prelaunch_step): the kernel goes
-// through the part of its work that depends on nothing — the image of its plan into LDS, ~3 us — and then waits for
-// the host's word, 16 bytes of pinned memory {mu, 2 x ticket + abort} written with one store: its own ticket
-// lets it through (with the barrier parameter of the step, decided together with the go), the abort bit sends
-// it home without a trace.  From a result in pinned memory to the first instruction of the kernel the host
-// launches because of it are ~7.5 us (profiles/microbench/launch_gap.hip); to a resident kernel's poll seeing the
-// host's store, 3-4.5.  ONE lane of the launch asks the host — a hundred workgroups polling over PCIe make a tail of
-// tens of microseconds in that measurement — and passes the answer on through a word in device memory.
-// ---------------------------------------------------------------------------
-// (struct MfGate: device.hpp)
-// true: go (mu_gate set if the gate carries it); false: leave.  `slot`: 8 bytes of LDS for the workgroup's copy.
-__device__ __forceinline__ bool mf_gate_wait(const MfGate& G, bool asks_host, double* slot, double& mu_gate) {
-  if (threadIdx.x == 0) {
-    unsigned long long lo = 0, hi = 0;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-      if (asks_host) {
-        u32x4 v;
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(G.word) : "memory");
-        lo = static_cast<unsigned long long>(v[0]) | (static_cast<unsigned long long>(v[1]) << 32);
-        hi = static_cast<unsigned long long>(v[2]) | (static_cast<unsigned long long>(v[3]) << 32);
-      } else {
-        hi = __hip_atomic_load(G.relay + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if ((hi >> 1) == G.ticket) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > 300000000ull) {  // 3 s at 100 MHz: the host forgot this launch
-        hi = 2ull * G.ticket + 1ull;
-        if (asks_host && G.abandoned != nullptr) *G.abandoned = G.ticket;
-        break;
-      }
-    }
-    if (asks_host) {
-      __hip_atomic_store(G.relay, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_s_waitcnt(0);  // (mu before the word the others wait for)
-      __hip_atomic_store(G.relay + 1, hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if ((hi & 1ull) == 0 && G.mu_out != nullptr) G.mu_out[0] = __longlong_as_double(static_cast<long long>(lo));
-    } else {
-      lo = __hip_atomic_load(G.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    slot[0] = (hi & 1ull) ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double(static_cast<long long>(lo));
-    if ((hi & 1ull) == 0 && G.mu_out == nullptr) slot[0] = 0.0;
-  }
-  __syncthreads();
-  mu_gate = slot[0];
-  return mu_gate == mu_gate;
 }
 
 // LDS by byte address (what the tables hold)
@@ -564,11 +503,9 @@ __device__ __forceinline__ void mf_step_body(
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, const KktFuse& F, double* __restrict__ xg,
     double* __restrict__ xg_next, double* __restrict__ out, const BacksubFuse& B, uint32_t block, unsigned int exit_total,
-    const LdltStats* twin_stats, const MfGate& G, const IpmLookaheadArgs& LA) {
+    const LdltStats* twin_stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double mu_gate = 0.0;
   if (static_cast<int>(block) < F.n_blocks) {
-    if (G.word != nullptr && !mf_gate_wait(G, blockIdx.x == 0, reinterpret_cast<double*>(smem_raw), mu_gate)) return;
     if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
     ride_along_sum(F, block, smem_raw);
     if constexpr (CHAINED) mf_signal_done(Mf);
@@ -577,19 +514,6 @@ __device__ __forceinline__ void mf_step_body(
   const int tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t task_index = block - static_cast<uint32_t>(F.n_blocks);
-#ifdef SLPX_GATE_STAMPS
-  unsigned long long stamp_in = 0, stamp_staged = 0;
-  const bool stamps = task_index == 0 && blockIdx.x == block && tid == 0;  // (the first attempt's first task)
-  if (stamps) {
-    stamp_in = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[8], stamp_in - slpx_gate_stamps[0]);
-    atomicAdd(&slpx_gate_stamps[13], stamp_in - slpx_gate_stamps[1]);
-    atomicAdd(&slpx_gate_stamps[15], 1ull);
-  }
-#endif
-#ifdef SLPX_CHAIN_STAMPS
-  if (CHAINED && Mf.wait_step != 0u && tid == 0 && blockIdx.x == gridDim.x - 1) reinterpret_cast<unsigned long long*>(Mf.chain + 64)[3] = wall_clock64();
-#endif
   const LdltTask t = L.tasks[task_index];
   const LdltMfTask m = Mf.tasks[task_index];
   const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
@@ -644,20 +568,6 @@ __device__ __forceinline__ void mf_step_body(
   }
   __syncthreads();
   SLPX_LDLT_CLOCK(1);
-#ifdef SLPX_GATE_STAMPS
-  if (stamps) {
-    stamp_staged = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[9], stamp_staged - stamp_in);
-  }
-#endif
-  // a pre-launched step: everything up to here depended on nothing; the host's word (mf_gate_wait)
-  if (G.word != nullptr && !mf_gate_wait(G, blockIdx.x == 0, reinterpret_cast<double*>(smem_raw + cv.o_cnt + 24u), mu_gate)) return;
-#ifdef SLPX_GATE_STAMPS
-  if (stamps) {
-    slpx_gate_stamps[2] = wall_clock64();
-    atomicAdd(&slpx_gate_stamps[10], slpx_gate_stamps[2] - stamp_staged);
-  }
-#endif
   if (stats_next != nullptr && task_index == 0 && tid == 0) stats_next[0] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
 
@@ -671,7 +581,7 @@ __device__ __forceinline__ void mf_step_body(
       U[i] = s0 >= 0 ? base[s0] : 0.0;
     }
   } else {
-    const double mu = G.mu_out != nullptr ? mu_gate : F.mu[0];
+    const double mu = F.mu[0];
     const KktTerm* terms = reinterpret_cast<const KktTerm*>(s_terms);
     const uint32_t span = n_terms > t.n_ent ? n_terms : t.n_ent;
     for (uint32_t k = tid; k < span; k += THREADS) {
@@ -808,7 +718,6 @@ __device__ __forceinline__ void mf_step_body(
         if (B.stats_host != nullptr) {
           if (twin_stats != nullptr) publish_stats_copy(twin_stats, B.stats_host + 1);
           publish_stats(B, true);
-          SLPX_GATE_STAMP_ADD(11, slpx_gate_stamps[2]);
         }
       }
     }
@@ -894,10 +803,9 @@ __device__ __forceinline__ void mf_step_body(
   for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
   for (uint32_t i = tid; i < t.n_col; i += THREADS)
     coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
-  // (LA.on: the launch's last workgroup reads the direction — ipm_lookahead_body —: written through)
-  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&out[L.perm[colperm[i]]], x[i], LA.on != 0);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
   if (B.on) {
-    const double mu = G.mu_out != nullptr ? mu_gate : B.mu[0];
+    const double mu = B.mu[0];
     auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
     for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
       const bool ahead = bs_mine && j == static_cast<uint32_t>(tid);
@@ -928,29 +836,13 @@ __device__ __forceinline__ void mf_step_body(
       }
       double ps_r, pz_r;
       backsub_row(ci_r, s_r, z_r, mu, aipx, &ps_r, &pz_r);
-      coherent_store(&B.ps[row.r], ps_r, LA.on != 0);
-      coherent_store(&B.pz[row.r], pz_r, LA.on != 0);
+      B.ps[row.r] = ps_r;
+      B.pz[row.r] = pz_r;
     }
   }
   SLPX_LDLT_CLOCK(20);
   if (top) exit_and_count();
   if constexpr (CHAINED) mf_signal_done(Mf);
-  if (LA.on) {
-    // the look-ahead iterate as the launch's last act: whoever is through last, of all attempts, has every
-    // workgroup's p, p_s, p_z and counters in memory
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned int* s_last = reinterpret_cast<unsigned int*>(smem_raw);
-    if (tid == 0) {
-      const unsigned int old = __hip_atomic_fetch_add(LA.done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1 == exit_total) __hip_atomic_store(LA.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last[0] = old + 1 == exit_total ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = s_last[0] != 0u;
-    __syncthreads();
-    if (last) ipm_lookahead_body<THREADS, true>(LA, reinterpret_cast<double*>(smem_raw));
-  }
 }
 
 template <int THREADS, bool MFMA, bool CHAINED>
@@ -958,9 +850,9 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_step_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfGate G, IpmLookaheadArgs LA) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B) {
   mf_step_body<THREADS, MFMA, CHAINED>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B,
-                                       blockIdx.x, Mf.n_tasks, nullptr, G, LA);
+                                       blockIdx.x, Mf.n_tasks, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -989,7 +881,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T, MfGate G, IpmLookaheadArgs LA) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T) {
   uint32_t block = blockIdx.x;
   if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
     block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
@@ -1009,207 +901,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
   }
   mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
-                                      2u * Mf.n_tasks, T.stats, G, LA);
-}
-
-// ---------------------------------------------------------------------------
-// The same fronts for a BATCH of problems that share the plan (multistart.hpp:45-74: the same
-// model from many starting points).  Throughput, not latency: one launch per round (no workgroup
-// waits for another — the rounds of thousands of (task, problem) pairs are not resident at once),
-// a workgroup stages its task's tables ONCE and then takes `ppw` problems through them one after
-// the other; between the factorization launches (rounds up) and the solve launches (rounds down)
-// a task's U and 1/d wait in memory in the layout they have in LDS.
-// LDS: the step kernel's carve-up up to the counters (mf_carve), `src` = where an entry comes from in
-// lhs / rhs (L.ent_src) instead of the KKT sources.
-// ---------------------------------------------------------------------------
-struct MfBatch {
-  const double* lhs = nullptr;   // [b][nnz_lhs]
-  const double* rhs = nullptr;   // [b][n]
-  const double* reg = nullptr;   // [b]{delta, gamma}; delta = NaN: not part of this attempt
-  double* Lx = nullptr;          // [b][nnzL]
-  double* D = nullptr;           // [b][n]
-  double* zv = nullptr;          // [b][n]
-  double* contrib = nullptr;     // [b][n_contrib]: update slots between tasks
-  double* ust = nullptr;         // [b][n_ent_total]: U of every task as it sits in LDS
-  double* invd = nullptr;        // [b][n_colp]: 1/d by (task, local column) — the tasks' column slices are padded
-  double* xg = nullptr;          // [b][n]: x by permuted row
-  double* out = nullptr;         // [b][n]: x by row
-  LdltStats* stats = nullptr;    // [b]
-  LdltStats* stats_next = nullptr;
-  long long nnz_lhs = 0, nnzL = 0, n_contrib = 0, n_ent = 0, n_colp = 0;
-  int n = 0, batch = 0, ppw = 1;
-};
-
-template <int THREADS, bool MFMA>
-__global__ __launch_bounds__(THREADS) void ldlt_mf_batch_kernel(LdltDev L, MfDev Mf, uint32_t task_base, int solve_phase, MfBatch Bt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int tid = threadIdx.x;
-  const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t task_index = task_base + blockIdx.x;
-  const LdltTask t = L.tasks[task_index];
-  const LdltMfTask m = Mf.tasks[task_index];
-  const MfCarve cv = mf_carve(t, m);
-  double* U = reinterpret_cast<double*>(smem_raw);
-  double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
-  double* invd = reinterpret_cast<double*>(smem_raw + cv.o_invd);
-  double* x = reinterpret_cast<double*>(smem_raw + cv.o_x);
-  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
-  const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
-  const int32_t* src = reinterpret_cast<const int32_t*>(smem_raw + cv.o_src);
-  const uint8_t* flags = reinterpret_cast<const uint8_t*>(smem_raw + cv.o_flags);
-  const uint16_t* cent = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_cent);
-  const uint32_t* cptr = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cptr);
-  const uint32_t* cidx = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cidx);
-  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cp);
-  const uint32_t* anc = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_anc);
-  int* s_cnt = reinterpret_cast<int*>(smem_raw + cv.o_cnt);
-  unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
-  {
-    const uint4* src16 = Mf.image + static_cast<size_t>(task_index) * Mf.image_stride16;
-    uint4* dst16 = reinterpret_cast<uint4*>(smem_raw + cv.o_tab);
-    const uint32_t n16 = Mf.image_desc[task_index].y;
-    uint32_t i = tid;
-    for (; i + 3 * THREADS < n16; i += 4 * THREADS) {
-      const uint4 a = src16[i], b = src16[i + THREADS], c = src16[i + 2 * THREADS], d = src16[i + 3 * THREADS];
-      dst16[i] = a;
-      dst16[i + THREADS] = b;
-      dst16[i + 2 * THREADS] = c;
-      dst16[i + 3 * THREADS] = d;
-    }
-    for (; i < n16; i += THREADS) dst16[i] = src16[i];
-  }
-  if (tid == 0) {
-    arena[0] = 0.0;
-    arena[1] = 0.0;
-    x[t.n_col + m.n_anc] = 1.0;
-  }
-  __syncthreads();
-  const LdltFront* gfr = Mf.fronts + m.front_off;
-  const uint32_t last_front = m.n_front ? m.n_front - 1u : 0u;
-  const uint32_t* g_out = L.ent_out + t.ent_off;
-  const uint16_t* g_col = L.ent_col + t.ent_off;
-  const int b_end = min(Bt.batch, static_cast<int>(blockIdx.y + 1) * Bt.ppw);
-  for (int b = static_cast<int>(blockIdx.y) * Bt.ppw; b < b_end; ++b) {
-    const size_t sb = static_cast<size_t>(b);
-    double* ust = Bt.ust + sb * Bt.n_ent + t.ent_off;
-    double* invd_g = Bt.invd + sb * Bt.n_colp + t.col_off;
-    if (!solve_phase) {
-      if (Bt.stats_next != nullptr && task_index == 0 && tid == 0) Bt.stats_next[b] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
-      const double delta = Bt.reg[2 * b], gamma = Bt.reg[2 * b + 1];
-      if (delta != delta) continue;  // (the whole workgroup: the problem is not part of this attempt)
-      const double* lhs = Bt.lhs + sb * Bt.nnz_lhs;
-      const double* rhs = Bt.rhs + sb * Bt.n;
-      double* contrib = Bt.contrib + sb * Bt.n_contrib;
-      // ---- matrix values + regularization; entries with update slots: below ----
-      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-        const uint8_t fl = flags[i];
-        if (fl & 0x20) continue;
-        const int32_t s0 = src[i];
-        const double* base = (fl & 4) ? rhs : lhs;
-        double v = s0 >= 0 ? base[s0] : 0.0;
-        if (fl & 1) v += (fl & 2) ? -gamma : delta;
-        U[i] = v;
-      }
-      for (uint32_t j = tid; j < m.n_cent; j += THREADS) {
-        const uint32_t i = cent[j];
-        const uint8_t fl = flags[i];
-        const int32_t s0 = src[i];
-        const double* base = (fl & 4) ? rhs : lhs;
-        double acc = s0 >= 0 ? base[s0] : 0.0;
-        if (fl & 1) acc += (fl & 2) ? -gamma : delta;
-        const uint32_t cb = cptr[j], ce = cptr[j + 1];
-        for (uint32_t c = cb; c < ce; c += 4) {  // (four in flight, subtracted in list order)
-          const double v0 = contrib[cidx[c]];
-          const double v1 = contrib[cidx[c + 1 < ce ? c + 1 : c]];
-          const double v2 = contrib[cidx[c + 2 < ce ? c + 2 : c]];
-          const double v3 = contrib[cidx[c + 3 < ce ? c + 3 : c]];
-          acc -= v0;
-          if (c + 1 < ce) acc -= v1;
-          if (c + 2 < ce) acc -= v2;
-          if (c + 3 < ce) acc -= v3;
-        }
-        U[i] = acc;
-      }
-      if (tid < 4) s_cnt[tid] = 0;
-      if (tid == 4) *s_minp = 0x7ff0000000000000ull;
-      __syncthreads();
-      // ---- levels: a wave per front ----
-      {
-        uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[0]), end = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[1] : 0);
-        for (uint32_t l = 0; l < t.n_lvl; ++l) {
-          const uint32_t next_end = __builtin_amdgcn_readfirstlane(lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl]);
-          for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-            const u32x4 d = s_load_desc(gfr + q);
-            const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
-            mf_front<MFMA>(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
-                           contrib, lane);
-          }
-          __syncthreads();
-          beg = end;
-          end = next_end;
-        }
-      }
-      // ---- results: U and 1/d for the solve launches, L, D, z in their public layout, inertia ----
-      double* Lx = Bt.Lx + sb * Bt.nnzL;
-      double* D = Bt.D + sb * Bt.n;
-      double* zv = Bt.zv + sb * Bt.n;
-      for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-        const double u = U[i];
-        const uint8_t fl = flags[i];
-        const uint32_t o = g_out[i];
-        ust[i] = u;
-        if (fl & 1) {
-          D[o] = u;
-          const double eps = 2.220446049250313e-16;
-          if (u > eps) atomicAdd(&s_cnt[0], 1);
-          else if (u < -eps) atomicAdd(&s_cnt[1], 1);
-          else atomicAdd(&s_cnt[2], 1);
-          if (u == 0.0 || !isfinite(u)) atomicAdd(&s_cnt[3], 1);
-          else atomicMin(s_minp, static_cast<unsigned long long>(__double_as_longlong(fabs(u))));
-        } else if (fl & 4) {
-          zv[o] = u * invd[g_col[i]];
-        } else {
-          Lx[o] = u * invd[g_col[i]];
-        }
-      }
-      for (uint32_t i = tid; i < t.n_col; i += THREADS) invd_g[i] = invd[i];
-      __syncthreads();
-      if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&Bt.stats[b]) + tid, s_cnt[tid]);
-      if (tid == 0) atomicMin(&Bt.stats[b].min_abs_bits, *s_minp);
-      __syncthreads();  // (the counters and U are the next problem's from here on)
-    } else {
-      // ---- backward solve on what the factorization left: U, 1/d back into LDS, x of the ancestors' rows ----
-      const double* xg_r = Bt.xg + sb * Bt.n;
-      for (uint32_t i = tid; i < t.n_ent; i += THREADS) U[i] = ust[i];
-      for (uint32_t i = tid; i < t.n_col; i += THREADS) invd[i] = invd_g[i];
-      for (uint32_t a = tid; a < m.n_anc; a += THREADS) x[t.n_col + a] = xg_r[anc[a]];
-      __syncthreads();
-      {
-        uint32_t end = __builtin_amdgcn_readfirstlane(lvl[t.n_lvl]), beg = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[t.n_lvl - 1] : 0);
-        for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
-          const uint32_t next_beg = __builtin_amdgcn_readfirstlane(lvl[l >= 1 ? l - 1 : 0]);
-          for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-            const u32x4 d = s_load_desc(gfr + q);
-            const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
-            const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
-            mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);
-          }
-          __syncthreads();
-          end = beg;
-          beg = next_beg;
-        }
-      }
-      double* xg_w = Bt.xg + sb * Bt.n;
-      double* out = Bt.out + sb * Bt.n;
-      for (uint32_t i = tid; i < t.n_col; i += THREADS) {
-        const uint32_t pj = colperm[i];
-        const double v = x[i];
-        xg_w[pj] = v;
-        out[L.perm[pj]] = v;
-      }
-      __syncthreads();
-    }
-  }
+                                      2u * Mf.n_tasks, T.stats);
 }
 
 }  // namespace slpx

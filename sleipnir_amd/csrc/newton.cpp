@@ -18,9 +18,6 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
                            const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
                            const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
     : m_opt(opt), m_graph(&g), m_x_nodes(x), m_ce_nodes(c_e), m_ci_nodes(c_i) {
-  // SLPX_STEP_GRAPH=0 falls back to one launch per kernel (profilers that cannot see into
-  // graph launches, A/B measurements)
-  if (const char* env = std::getenv("SLPX_STEP_GRAPH")) m_opt.use_step_graph = env[0] != '0';
   SetupLap lap;
   // the HIP runtime comes up (context, first allocation: 50-700 ms in a fresh process) while the
   // host compiles the model
@@ -50,20 +47,10 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
     // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
-    // ... unless the batch factorizes by FRONTS with four lanes per problem (ldlt_mfq_kernels.h; SLPX_IL_FRONTS=0:
-    // the pair-list kernel): the single problem's plan — relaxed supernodes, every one a front of at most 20 rows
-    const LdltOptions lopt_pairs = lopt;
-    const bool il_fronts = DeviceNlp::interleaved_for(opt.batch) && DeviceNlp::il_fronts_enabled();
-    if (il_fronts) DeviceNlp::il_fronts_options(lopt);
     if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
     // one problem: the multifrontal step (ldlt_mf_kernels.h) — every supernode a dense front, so a chain
     // of two columns already saves a level (the pair-list kernels' chain pass only paid from four)
-    // a batch below the lane-per-problem threshold: the same fronts, a launch per round (ldlt_mf_batch_kernel)
-    // (off unless SLPX_MF_BATCH=1 — measured, 64 x N=500: 180 k steps/s against the pair-list per-task
-    // kernels' 224 k; profiles/r03_mfb_probe.txt)
-    bool mf_batch = false;
-    if (const char* env = std::getenv("SLPX_MF_BATCH")) mf_batch = opt.batch > 1 && !DeviceNlp::interleaved_for(opt.batch) && env[0] == '1';
-    if ((opt.batch == 1 || mf_batch) && lopt.supernodal) {
+    if (opt.batch == 1 && lopt.supernodal) {
       const char* env = std::getenv("SLPX_LDLT_MF");
       if (env == nullptr || env[0] != '0') {
         lopt.multifrontal = true;
@@ -74,15 +61,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
         lopt.chain_from_deepest_min_round = 0;
       }
     }
-    if (const char* env = std::getenv("SLPX_SN_MAX_WIDTH")) lopt.max_supernode_width = std::clamp<uint32_t>(static_cast<uint32_t>(std::atoi(env)), 1u, kSnWidthMax);
-    if (const char* env = std::getenv("SLPX_SN_BALANCE")) lopt.balance_supernode_cuts = env[0] != '0';
-    if (const char* env = std::getenv("SLPX_SN_DEEPEST")) {  // 0: off, 1: every task, 2: from round 1 up (default)
-    lopt.chain_from_deepest_child = env[0] != '0';
-    lopt.chain_from_deepest_min_round = env[0] == '1' ? 0 : 1;
-  }
     if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
-    if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
     if (const char* env = std::getenv("SLPX_SN_MIN_WIDTH")) lopt.min_supernode_width = std::atoi(env);
+    if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
     // One problem (or a handful: the same plan, so that a small batch and single problems agree to
     // the bit), smaller than the BASELINE horizon: smaller tasks (less plan to stage per
     // task, shorter level passes, more of the chip in the leaf round) — task size with the square
@@ -93,11 +74,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
       lopt.task_entries = std::clamp<uint32_t>(256u * static_cast<uint32_t>(std::lround(scaled / 256.0)), 1024u, 2048u);
     }
     if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
-    if (const char* env = std::getenv("SLPX_LEAF_SIZE")) lopt.leaf_size = std::atoi(env);
     m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
-    // (a front of more rows than four lanes hold, or a task beyond the LDS of a CU with sixteen problems side by
-    // side: the pair-list plan)
-    if (il_fronts && !DeviceNlp::il_fronts_fit(m_l)) m_l = build_ldlt_plan(m_k.lhs, st.n, lopt_pairs, user_perm, &diag_has_source);
     // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
     // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
     // and usually has a round more than necessary; twice the task size fixes both (cart-pole
@@ -106,8 +83,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // (more than ~250 tasks take two workgroups per CU, 80 KB of LDS each: there the chains-from-the-deepest-
     // child rule stays out of the leaf tasks, where it only adds fronts — tables, arena — to full levels:
     // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
-    const bool deepest_everywhere = lopt.chain_from_deepest_child && lopt.chain_from_deepest_min_round == 0 &&
-                                    std::getenv("SLPX_SN_DEEPEST") == nullptr;
+    const bool deepest_everywhere = lopt.chain_from_deepest_child && lopt.chain_from_deepest_min_round == 0;
     const bool double_tasks = opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
                               std::getenv("SLPX_TASK_ENTRIES") == nullptr;
     if (double_tasks || (deepest_everywhere && m_l.tasks.size() > 250)) {
@@ -188,12 +164,8 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
-  const LdltOptions lopt_pairs = lopt;
-  const bool il_fronts = DeviceNlp::interleaved_for(opt.batch) && DeviceNlp::il_fronts_enabled();
-  if (il_fronts) DeviceNlp::il_fronts_options(lopt);
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
   m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
-  if (il_fronts && !DeviceNlp::il_fronts_fit(m_l)) m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt_pairs, nullptr, &diag_has_source);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));
   reset_regularization();
@@ -208,15 +180,12 @@ void NewtonSystem::reset_regularization() {
 // Each trip through the loop is one device factorization of the still-active
 // problems followed by one small stats read-back.
 std::vector<FactorInfo> NewtonSystem::compute(bool solve_speculatively) {
-  return compute_impl(solve_speculatively ? 1 : 0, false);
+  return compute_impl(solve_speculatively ? 1 : 0);
 }
 
-// mode 0: factorization attempts only; 1: each attempt followed by solve + backsub;
-// 2: like 1, and the FIRST attempt is launched as one HIP graph that also contains the
-// AD refresh (if refresh_ad), the lhs and the rhs assembly.
-std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
+// mode 0: factorization attempts only; 1: each attempt followed by solve + backsub.
+std::vector<FactorInfo> NewtonSystem::compute_impl(int mode) {
   const bool solve_speculatively = mode >= 1;
-  bool graph_pending = mode == 2;
   const int B = m_opt.batch;
   m_last_twin_launches = m_last_twin_taken = 0;
   if (mode == 1 && B == 1 && m_twin_attempts && m_dev->twin_available()) return compute_twin();
@@ -225,31 +194,11 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode, bool refresh_ad) {
   // counters: the device never idles through the host round trip, and in the usual case
   // (first attempt accepted) the step is complete when the counters arrive.  A rejected
   // attempt just has its solve overwritten by the next one.
-  bool first_launch = true;
   auto factor_once = [&](const std::vector<double>& d, const std::vector<double>& g,
                          const std::vector<uint8_t>& a) {
-    const bool first = first_launch;
-    first_launch = false;
-    // a step kernel launched ahead waits at its gate (prelaunch_next_step): this compute()'s first attempt, if it
-    // was launched with what the attempt is made with — anything else sends it home
-    bool opened = false;
-    if (m_dev->gate_pending()) {
-      if (first && B == 1 && mode == 1 && m_pre.twin_mode == 0 && d[0] == m_pre.reg[0] && g[0] == m_pre.reg[1]) {
-        m_dev->open_gate(std::numeric_limits<double>::quiet_NaN());
-        opened = true;
-      } else {
-        m_dev->abort_gate();
-      }
-    }
-    if (graph_pending) {
-      graph_pending = false;
-      m_dev->launch_step_graph(refresh_ad, d, g, a);
-      return;
-    }
     if (solve_speculatively) {
-      if (!opened) m_dev->factor_solve_publish(d, g, a);
+      m_dev->factor_solve_publish(d, g, a);
       if (m_after_attempt) m_after_attempt();
-      if (first && m_pipeline && B == 1 && mode == 1) prelaunch_next_step(d[0], g[0]);
     } else {
       m_dev->factor(d, g, a);
     }
@@ -385,21 +334,21 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     // caller's system IS the one V, s, y, z describe, set_twin_attempts — instead of two assembly launches first)
     if (!first_launch) m_dev->build_kkt_for_step(/*with_reduce=*/false);
     first_launch = false;
-    have_second = false;
-    if (m_dev->gate_pending()) {  // the step launched ahead (prelaunch_twin_step), if it is this one
-      if (m_pre.twin_mode == mode && m_pre.reg[0] == d0 && m_pre.reg[1] == g0 && m_pre.reg[2] == d1 && m_pre.reg[3] == g1) {
-        m_dev->open_gate(m_step_mu);
-        have_second = true;
-      } else {
-        m_dev->abort_gate();
-        if (m_step_mu == m_step_mu) m_dev->upload_mu(&m_step_mu);  // (it was to travel through the gate)
-      }
+    auto once = [&] {
+      have_second = m_dev->factor_solve_publish_twin(d0, g0, d1, g1, mode);
+      if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
+      if (m_after_attempt) m_after_attempt();
+      m_dev->read_stats(stats);
+    };
+    once();
+    // (a chained step that lost its hand-over — compute_impl's factor(): redone unchained from a fresh sweep.
+    // A twin launch itself is never chained, the single-attempt fallback above can be.)
+    if ((stats[0].n_bad & kLdltChainFailure) != 0) {
+      m_dev->recover_from_chain_failure();
+      m_dev->build_kkt_for_step(/*with_reduce=*/true);
+      once();
     }
-    if (!have_second) have_second = m_dev->factor_solve_publish_twin(d0, g0, d1, g1, mode);
-    if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
-    else ++m_last_twin_launches;
-    if (m_after_attempt) m_after_attempt();
-    m_dev->read_stats(stats);
+    if (have_second) ++m_last_twin_launches;
     first = stats[0];
     if (have_second) {
       second = m_dev->read_twin_stats();
@@ -497,49 +446,6 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
   }
 }
 
-// The first launch of the next compute(), assuming this one's attempt (delta_now, gamma_now) is accepted.
-static void first_attempt_after(double prev_delta, double gamma_min, bool skip_first, double out[2]) {
-  if (!skip_first) {
-    out[0] = out[1] = 0.0;  // :74
-    return;
-  }
-  out[0] = prev_delta == 0.0 ? 1e-4 : std::max(prev_delta / 2.0, std::numeric_limits<double>::epsilon());  // :95-98
-  out[1] = gamma_min;                                                                                          // :102
-}
-
-void NewtonSystem::prelaunch_next_step(double delta_now, double gamma_now) {
-  (void)gamma_now;
-  if (!m_dev->can_prelaunch(0)) return;
-  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
-  m_pre = PreStep{};
-  m_pre.refresh_ad = true;
-  first_attempt_after(m_pipeline_forget ? 0.0 : delta_now, m_gamma_min, skip_first, m_pre.reg);
-  m_dev->sweep_full_for_step();
-  m_dev->prelaunch_step(0, m_pre.reg, /*kkt_mode=*/2, /*mu_through_gate=*/false, /*lookahead_roles=*/false);
-}
-
-bool NewtonSystem::prelaunch_twin_step() {
-  if (!m_dev->can_prelaunch(1)) return false;
-  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
-  double guess[2];
-  first_attempt_after(m_prev_delta[0], m_gamma_min, /*skip_first=*/true, guess);
-  m_pre = PreStep{};
-  if (skip_first) {  // compute_twin's first launch: the guess and its delta x 10 ...
-    m_pre.twin_mode = m_twin_expect == 3 ? 3 : 1;
-    m_pre.reg[0] = guess[0];
-    m_pre.reg[1] = guess[1];
-    m_pre.reg[2] = m_twin_expect == 3 ? guess[0] : guess[0] * 10.0;
-    m_pre.reg[3] = m_twin_expect == 3 ? (guess[1] == 0.0 ? 1e-10 : guess[1] * 10.0) : guess[1];
-  } else {  // ... or the unregularized attempt and the guess
-    m_pre.twin_mode = 2;
-    m_pre.reg[2] = guess[0];
-    m_pre.reg[3] = guess[1];
-  }
-  return m_dev->prelaunch_step(m_pre.twin_mode, m_pre.reg, /*kkt_mode=*/1, /*mu_through_gate=*/true, /*lookahead_roles=*/true);
-}
-
-void NewtonSystem::cancel_prelaunch() { m_dev->abort_gate(); }
-
 bool NewtonSystem::factor_unregularized() {
   const int B = m_opt.batch;
   std::vector<double> zero(B, 0.0);
@@ -555,18 +461,13 @@ bool NewtonSystem::factor_unregularized() {
 }
 
 std::vector<FactorInfo> NewtonSystem::newton_step(bool refresh_ad) {
-  if (m_opt.use_step_graph) return compute_impl(2, refresh_ad);
   // SLPX_HOST_TIMING=1: where the host's time per step goes (printed every 1000 steps)
   static const bool timing = std::getenv("SLPX_HOST_TIMING") != nullptr;
   if (!timing) {
-    // (this step's sweep and kernel went out behind the last step's: compute() opens the gate)
-    if (m_dev->gate_pending() && m_pre.twin_mode == 0 && m_pre.refresh_ad == refresh_ad) return compute(/*solve_speculatively=*/true);
-    m_dev->abort_gate();
     if (refresh_ad) m_dev->sweep_full_for_step();
     m_dev->build_kkt_for_step(/*with_reduce=*/refresh_ad);
     return compute(/*solve_speculatively=*/true);
   }
-  m_dev->abort_gate();
   using clk = std::chrono::steady_clock;
   static double t_sweep = 0, t_rest = 0;
   static long n = 0;

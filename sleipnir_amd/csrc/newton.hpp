@@ -27,10 +27,6 @@ struct NewtonOptions {
   int batch = 1;
   int device = 0;
   bool skip_structurally_singular_attempt = true;
-  // newton_step(): first attempt as one HIP graph launch instead of five kernel launches
-  // (SLPX_STEP_GRAPH=1).  Off by default: with the step down to five launches the eager path
-  // measures 1 % faster (9.64 k vs 9.52 k steps/s at cart-pole N=1000).
-  bool use_step_graph = false;
 };
 
 // Eigen::ComputationInfo stand-in
@@ -87,7 +83,7 @@ class NewtonSystem {
   // Returns per-problem info; fills the regularization that was used.
   // solve_speculatively: also run solve() + backsub() after every attempt (see newton.cpp).
   std::vector<FactorInfo> compute(bool solve_speculatively = false);
-  std::vector<FactorInfo> compute_impl(int mode, bool refresh_ad);
+  std::vector<FactorInfo> compute_impl(int mode);
   // One factorization of the lhs in device memory with delta = gamma = 0, accepted whenever it
   // has no zero / non-finite pivot and the ideal inertia — no |D| threshold, no regularization
   // memory touched.  For systems that are not KKT systems of the barrier problem: the
@@ -106,18 +102,6 @@ class NewtonSystem {
   // direction of whichever attempt the policy takes ON THE DEVICE (DeviceNlp::ipm_lookahead does), and whose system is
   // the one the device's V, s, y, z describe (build_kkt_for_step — later launches of the loop evaluate it again).
   void set_twin_attempts(bool on) { m_twin_attempts = on; }
-  // Steps launched ahead (MfGate).  set_pipeline: newton_step(true) launches the NEXT step's sweep and step kernel
-  // as soon as its own are out — the kernel waits, its plan staged, for the host to have seen this step's verdict
-  // (slpx_newton_steps: all but the last of a run; `forget`: the caller clears the regularization memory between
-  // steps).  prelaunch_twin_step: the interior-point iteration's next step, after compute() returned, on the
-  // look-ahead iterate; set_step_mu: the barrier parameter the next compute()'s step takes through the gate.
-  void set_pipeline(bool on, bool forget_regularization) {
-    m_pipeline = on;
-    m_pipeline_forget = forget_regularization;
-  }
-  bool prelaunch_twin_step();
-  void set_step_mu(double mu) { m_step_mu = mu; }
-  void cancel_prelaunch();
   // launches with two attempts since construction, by what the first attempt showed: accepted; the failure the
   // second attempt stood for, and the second accepted / not; zero pivots; the other inertia failure; the
   // factorization itself failed
@@ -143,15 +127,6 @@ class NewtonSystem {
   std::vector<double> m_prev_delta, m_prev_gamma;
   int m_last_factorizations = 0;
   std::function<void()> m_after_attempt;
-  // a step kernel launched ahead (DeviceNlp::prelaunch_step): what it was launched with
-  struct PreStep {
-    bool refresh_ad = false;
-    int twin_mode = 0;
-    double reg[4] = {0, 0, 0, 0};
-  } m_pre;
-  bool m_pipeline = false, m_pipeline_forget = false;
-  double m_step_mu = std::numeric_limits<double>::quiet_NaN();
-  void prelaunch_next_step(double delta_now, double gamma_now);
   bool m_twin_attempts = false;
   int m_last_twin_launches = 0, m_last_twin_taken = 0;
   long m_twin_hist[6] = {0, 0, 0, 0, 0, 0};

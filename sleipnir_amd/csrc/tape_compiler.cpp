@@ -71,16 +71,58 @@ struct UnionFind {
 
 }  // namespace
 
-TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
-                         const std::vector<TapeValueOut>& value_outs,
-                         const std::vector<TapeRow>& rows, const TapeCompileOptions& opt) {
+// the staged kernel reads whole 16-byte groups: every array it stages ends in 16 spare elements
+static void add_tail_padding(TapeProgram& prog) {
+  for (int k = 0; k < 16; ++k) {
+    prog.node_rec16.push_back(0);
+    prog.edges16.push_back(0);
+    prog.slot_edge_ptr16.push_back(0);
+    prog.lvl_ptr.push_back(0);
+    prog.slvl_ptr.push_back(0);
+    prog.leaf_src.push_back(0);
+  }
+}
+
+// What the flat compiler reports about every task it emitted, in terms of the caller's graph nodes, value outputs and
+// rows: what compile_tape_families needs to instantiate the task for the other members of its family.
+struct TapeTrace {
+  struct Task {
+    std::vector<NodeId> leaf_nodes;                     // graph node of every leaf, in the task's leaf order
+    std::vector<uint32_t> vouts;                        // index into value_outs of every value output, in the task's order
+    std::vector<std::pair<uint32_t, NodeId>> jouts;     // (index into rows, wrt node) of every derivative output
+    uint32_t comp_nodes = 0;                            // interior nodes of its components (without private copies)
+    uint32_t n_comps = 0;
+    int cls = 0;
+  };
+  std::vector<Task> tasks;
+};
+
+// The flat compiler: everything reachable from the selected value outputs (`vsel`: indices into value_outs) and rows
+// (`rsel`) as one program.  `tail_padding`: the 16 trailing elements the staged kernel's 16-byte loads may touch.
+static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                                     const std::vector<TapeValueOut>& value_outs_all, const std::vector<TapeRow>& rows_all,
+                                     const std::vector<uint32_t>& vsel, const std::vector<uint32_t>& rsel,
+                                     const TapeCompileOptions& opt, TapeTrace* trace, bool tail_padding) {
   TapeProgram prog;
+  // (the selection, addressed like the whole lists were)
+  struct ValueOutView {
+    const std::vector<TapeValueOut>& all;
+    const std::vector<uint32_t>& sel;
+    size_t size() const { return sel.size(); }
+    const TapeValueOut& operator[](size_t i) const { return all[sel[i]]; }
+  } value_outs{value_outs_all, vsel};
+  struct RowView {
+    const std::vector<TapeRow>& all;
+    const std::vector<uint32_t>& sel;
+    size_t size() const { return sel.size(); }
+    const TapeRow& operator[](size_t i) const { return all[sel[i]]; }
+  } rows{rows_all, rsel};
 
   SetupLap lap;
   // ---- A. working copy of everything reachable from the roots ---------------
   std::vector<NodeId> roots;
-  for (auto& v : value_outs) roots.push_back(v.node);
-  for (auto& r : rows) roots.push_back(r.root);
+  for (size_t v = 0; v < value_outs.size(); ++v) roots.push_back(value_outs[v].node);
+  for (size_t r = 0; r < rows.size(); ++r) roots.push_back(rows[r].root);
 
   std::vector<NodeId> reach;
   {
@@ -783,6 +825,16 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
     }
     t.n_vout = static_cast<uint32_t>(prog.vout_src.size() - t.vout_off);
     t.n_jout = static_cast<uint32_t>(prog.jout_slot.size() - t.jout_off);
+    if (trace != nullptr) {
+      TapeTrace::Task tt;
+      for (int32_t lf : leaves) tt.leaf_nodes.push_back(cg.src[lf]);
+      for (size_t v : vouts) tt.vouts.push_back(vsel[v]);
+      for (int32_t sl : tslots)
+        if (slots[sl].out_dst >= 0) tt.jouts.emplace_back(rsel[slots[sl].row], cg.src[slots[sl].node]);
+      for (size_t c : pk.comps) tt.comp_nodes += static_cast<uint32_t>(comp_nodes[c].size());
+      tt.n_comps = static_cast<uint32_t>(pk.comps.size());
+      trace->tasks.push_back(std::move(tt));
+    }
     t.lds_doubles = t.n_leaf + 3 * t.n_node + t.n_slot;
     auto q16 = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
     t.lds_bytes = q16(t.n_node, 2) + q16(t.n_edge, 4) + q16(t.n_slot + 1, 8) + q16(t.n_lvl + 1, 4) +
@@ -806,21 +858,485 @@ TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>
       t.scratch_off = static_cast<uint32_t>(prog.global_scratch_doubles);
       prog.global_scratch_doubles += t.lds_doubles;
     }
+    if (trace != nullptr) trace->tasks.back().cls = cls;
     prog.tasks.push_back(t);
     prog.total_nodes += t.n_node;
     prog.total_slots += t.n_slot;
     prog.total_leaves += t.n_leaf;
   }
-  // tail padding: the staged kernel reads whole 16-byte groups
-  for (int k = 0; k < 16; ++k) {
-    prog.node_rec16.push_back(0);
-    prog.edges16.push_back(0);
-    prog.slot_edge_ptr16.push_back(0);
-    prog.lvl_ptr.push_back(0);
-    prog.slvl_ptr.push_back(0);
-    prog.leaf_src.push_back(0);
-  }
+  if (tail_padding) add_tail_padding(prog);
   lap("  tape: emit");
+  return prog;
+}
+
+// ---------------------------------------------------------------------------
+// Families ("compile one stage, replicate").  A transcribed optimal-control problem is the same
+// stage N times over: the same expressions on shifted variables.  The flat compiler above used to put every one of
+// them through its passes — working copy, adjoint slots and edges, emission, 0.4 s at cart-pole N=1000 — only to
+// find at the very end that the tasks are byte-identical.  Here the stages are found FIRST, on the raw graph, by a
+// few linear passes:
+//   1. components of interior nodes (the flat compiler's rule: nodes joined through interior operands; a node on
+//      top of leaves only — depth <= 2, one interior operand — is private to each of its users);
+//   2. every component's reachable set in ascending node order — its members, the private nodes it uses, its
+//      leaves — written down as a sequence (opcode, position of operand 0, position of operand 1) followed by its
+//      rows (position of the root, positions of the wrt leaves) and value outputs.  The flat compiler is a
+//      deterministic function of exactly that sequence (node numbers enter only through their order), so two
+//      components with EQUAL sequences compile to the same task, leaf for leaf, slot for slot;
+//   3. one member of every family of kTapeFamilyMin or more goes through the flat compiler alone (with a trace of
+//      which graph node every leaf, which row every output came from); the others are instantiated from it by
+//      position: their leaf bindings and output destinations, nothing else;
+//   4. what is in no family (unique components, rows of bare leaves, small packs) goes through the flat compiler
+//      together, as before.
+// The resulting program computes what the flat compiler's does, task for task (tests/test_tape_families_cpu.py:
+// the same V to the bit); the order of the tasks in it differs.
+// ---------------------------------------------------------------------------
+static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                                  const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                                  const TapeCompileOptions& opt, TapeProgram& out) {
+  SetupLap lap;
+  const size_t G = g.size();
+  constexpr uint8_t kReach = 1, kRoot = 2, kRepl = 4;
+  std::vector<uint8_t> flag(G, 0);
+  // ---- 1. reachable nodes, roots ----
+  {
+    std::vector<NodeId> stack;
+    auto seed = [&](NodeId r) {
+      if (r == kNull) return;
+      flag[r] |= kRoot;
+      if (!(flag[r] & kReach)) {
+        flag[r] |= kReach;
+        stack.push_back(r);
+      }
+    };
+    for (auto& v : value_outs) seed(v.node);
+    for (auto& r : rows) seed(r.root);
+    while (!stack.empty()) {
+      const NodeId n = stack.back();
+      stack.pop_back();
+      for (NodeId a : {g.a0[n], g.a1[n]})
+        if (a != kNull && !(flag[a] & kReach)) {
+          flag[a] |= kReach;
+          stack.push_back(a);
+        }
+    }
+  }
+  auto is_leaf = [&](NodeId n) { return g.a0[n] == kNull; };
+  // ---- components (children have smaller numbers than their parents: ascending order is children first) ----
+  std::vector<int32_t> parent(G);  // union-find over interior, not private nodes
+  auto find = [&](int32_t x) {
+    while (parent[x] != x) {
+      parent[x] = parent[parent[x]];
+      x = parent[x];
+    }
+    return x;
+  };
+  {
+    std::vector<uint8_t> depth(G, 0);
+    for (size_t n = 0; n < G; ++n) {
+      parent[n] = static_cast<int32_t>(n);
+      if (!(flag[n] & kReach) || is_leaf(static_cast<NodeId>(n))) continue;
+      if (!(flag[n] & kRoot)) {
+        uint8_t d = 1;
+        bool ok = true;
+        int interior_operands = 0;
+        for (NodeId a : {g.a0[n], g.a1[n]}) {
+          if (a == kNull || is_leaf(a)) continue;
+          ++interior_operands;
+          if (depth[a] == 0) ok = false;
+          else d = std::max<uint8_t>(d, static_cast<uint8_t>(depth[a] + 1));
+        }
+        if (ok && d <= 2 && interior_operands <= 1) {
+          depth[n] = d;
+          flag[n] |= kRepl;
+          continue;
+        }
+      }
+      for (NodeId a : {g.a0[n], g.a1[n]})
+        if (a != kNull && !is_leaf(a) && !(flag[a] & kRepl)) {
+          const int32_t ra = find(a), rn = find(static_cast<int32_t>(n));
+          if (ra != rn) parent[std::max(ra, rn)] = std::min(ra, rn);
+        }
+    }
+  }
+  // component numbers in order of their smallest node; members by component, ascending
+  std::vector<int32_t> comp_of(G, -1);
+  std::vector<uint32_t> comp_start{0};
+  std::vector<NodeId> members;
+  {
+    std::vector<uint32_t> count;
+    for (size_t n = 0; n < G; ++n) {
+      if (!(flag[n] & kReach) || (flag[n] & kRepl) || is_leaf(static_cast<NodeId>(n))) continue;
+      const int32_t r = find(static_cast<int32_t>(n));
+      if (comp_of[r] < 0) {  // (the representative is the smallest node of the component: met first)
+        comp_of[r] = static_cast<int32_t>(count.size());
+        count.push_back(0);
+      }
+      comp_of[n] = comp_of[r];
+      ++count[comp_of[n]];
+    }
+    comp_start.resize(count.size() + 1);
+    for (size_t c = 0; c < count.size(); ++c) comp_start[c + 1] = comp_start[c] + count[c];
+    members.resize(comp_start.back());
+    std::vector<uint32_t> fill(comp_start.begin(), comp_start.end() - 1);
+    for (size_t n = 0; n < G; ++n)
+      if (comp_of[n] >= 0) members[fill[comp_of[n]]++] = static_cast<NodeId>(n);
+  }
+  const size_t ncomp = comp_start.size() - 1;
+  if (ncomp < kTapeFamilyMin) return false;
+  // rows and value outputs by component (in the order of the lists); what belongs to none: a bare leaf
+  std::vector<uint32_t> crow_start(ncomp + 1, 0), cvout_start(ncomp + 1, 0), crow, cvout, loose_rows, loose_vouts;
+  {
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+      const NodeId r = rows[ri].root;
+      if (r != kNull && comp_of[r] >= 0) ++crow_start[comp_of[r] + 1];
+      else loose_rows.push_back(static_cast<uint32_t>(ri));
+    }
+    for (size_t v = 0; v < value_outs.size(); ++v) {
+      const NodeId r = value_outs[v].node;
+      if (r != kNull && comp_of[r] >= 0) ++cvout_start[comp_of[r] + 1];
+      else loose_vouts.push_back(static_cast<uint32_t>(v));
+    }
+    for (size_t c = 0; c < ncomp; ++c) {
+      crow_start[c + 1] += crow_start[c];
+      cvout_start[c + 1] += cvout_start[c];
+    }
+    crow.resize(crow_start.back());
+    cvout.resize(cvout_start.back());
+    std::vector<uint32_t> fr(crow_start.begin(), crow_start.end() - 1), fv(cvout_start.begin(), cvout_start.end() - 1);
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+      const NodeId r = rows[ri].root;
+      if (r != kNull && comp_of[r] >= 0) crow[fr[comp_of[r]]++] = static_cast<uint32_t>(ri);
+    }
+    for (size_t v = 0; v < value_outs.size(); ++v) {
+      const NodeId r = value_outs[v].node;
+      if (r != kNull && comp_of[r] >= 0) cvout[fv[comp_of[r]]++] = static_cast<uint32_t>(v);
+    }
+  }
+  lap("  tape families: components");
+
+  // ---- 2. every component's sequence ----
+  std::vector<int32_t> input_idx(G, -1);
+  int32_t n_inputs = 0;
+  for (auto& [node, idx] : inputs) {
+    input_idx[node] = idx;
+    n_inputs = std::max(n_inputs, idx + 1);
+  }
+  std::vector<int32_t> stamp(G, -1);
+  std::vector<uint32_t> local(G, 0);
+  std::vector<NodeId> all_nodes;           // every component's reachable set, ascending
+  std::vector<uint32_t> all_start{0};
+  std::vector<uint32_t> seq;               // every component's sequence
+  std::vector<uint32_t> seq_start{0};
+  std::vector<uint64_t> seq_hash(ncomp);
+  all_nodes.reserve(members.size() + members.size() / 4);
+  seq.reserve(4 * members.size());
+  {
+    std::vector<NodeId> ext, stack;
+    for (size_t c = 0; c < ncomp; ++c) {
+      ext.clear();
+      const int32_t ci = static_cast<int32_t>(c);
+      for (uint32_t q = comp_start[c]; q < comp_start[c + 1]; ++q) {
+        const NodeId n = members[q];
+        for (NodeId a : {g.a0[n], g.a1[n]}) {
+          if (a == kNull || comp_of[a] >= 0 || stamp[a] == ci) continue;  // (a member: of this component, by construction)
+          stamp[a] = ci;
+          ext.push_back(a);
+          if (!is_leaf(a)) stack.push_back(a);
+          while (!stack.empty()) {  // a private node's own operands: private nodes or leaves
+            const NodeId p = stack.back();
+            stack.pop_back();
+            for (NodeId b : {g.a0[p], g.a1[p]}) {
+              if (b == kNull || stamp[b] == ci) continue;
+              stamp[b] = ci;
+              ext.push_back(b);
+              if (!is_leaf(b)) stack.push_back(b);
+            }
+          }
+        }
+      }
+      std::sort(ext.begin(), ext.end());
+      // merge
+      const size_t base = all_nodes.size();
+      {
+        uint32_t q = comp_start[c];
+        size_t e = 0;
+        const uint32_t qe = comp_start[c + 1];
+        while (q < qe || e < ext.size()) {
+          if (e == ext.size() || (q < qe && members[q] < ext[e])) all_nodes.push_back(members[q++]);
+          else all_nodes.push_back(ext[e++]);
+        }
+      }
+      const size_t cnt = all_nodes.size() - base;
+      for (size_t i = 0; i < cnt; ++i) local[all_nodes[base + i]] = static_cast<uint32_t>(i);
+      all_start.push_back(static_cast<uint32_t>(all_nodes.size()));
+      // sequence
+      for (size_t i = 0; i < cnt; ++i) {
+        const NodeId n = all_nodes[base + i];
+        uint32_t w0 = g.op[n];
+        if (is_leaf(n)) {
+          // (what a leaf is bound to: a constant, an input, a parameter — its value or index is the instance's own)
+          w0 |= (g.op[n] == OP_CONST ? 1u : (input_idx[n] >= 0 ? 2u : 3u)) << 8;
+          seq.push_back(w0);
+        } else {
+          if (flag[n] & kRepl) w0 |= 1u << 16;
+          if (flag[n] & kRoot) w0 |= 1u << 17;
+          seq.push_back(w0);
+          seq.push_back(local[g.a0[n]]);
+          seq.push_back(g.a1[n] == kNull ? 0xffffffffu : local[g.a1[n]]);
+        }
+      }
+      for (uint32_t q = cvout_start[c]; q < cvout_start[c + 1]; ++q) {
+        seq.push_back(0xfffffff0u);
+        seq.push_back(local[value_outs[cvout[q]].node]);
+      }
+      for (uint32_t q = crow_start[c]; q < crow_start[c + 1]; ++q) {
+        const TapeRow& row = rows[crow[q]];
+        seq.push_back(0xfffffff1u);
+        seq.push_back(local[row.root]);
+        seq.push_back(static_cast<uint32_t>(row.outputs.size()));
+        for (auto& o : row.outputs) seq.push_back(stamp[o.wrt] == ci ? local[o.wrt] : 0xffffffffu);
+      }
+      seq_start.push_back(static_cast<uint32_t>(seq.size()));
+      uint64_t h = 1469598103934665603ull;
+      for (size_t k = seq_start[c]; k < seq.size(); ++k) {
+        h = (h ^ seq[k]) * 1099511628211ull;
+        h ^= h >> 29;
+      }
+      seq_hash[c] = h;
+    }
+  }
+  lap("  tape families: sequences");
+
+  // ---- families: equal sequences ----
+  struct Family {
+    uint32_t rep;
+    std::vector<uint32_t> comps;
+  };
+  std::vector<Family> fams;
+  {
+    std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash;  // hash -> families with it
+    by_hash.reserve(64);
+    for (size_t c = 0; c < ncomp; ++c) {
+      std::vector<uint32_t>& cand = by_hash[seq_hash[c]];
+      const size_t len = seq_start[c + 1] - seq_start[c];
+      int64_t hit = -1;
+      for (uint32_t f : cand) {
+        const uint32_t r = fams[f].rep;
+        if (seq_start[r + 1] - seq_start[r] == len &&
+            std::equal(seq.begin() + seq_start[c], seq.begin() + seq_start[c + 1], seq.begin() + seq_start[r])) {
+          hit = f;
+          break;
+        }
+      }
+      if (hit < 0) {
+        hit = static_cast<int64_t>(fams.size());
+        cand.push_back(static_cast<uint32_t>(fams.size()));
+        fams.push_back(Family{static_cast<uint32_t>(c), {}});
+      }
+      fams[hit].comps.push_back(static_cast<uint32_t>(c));
+    }
+  }
+  lap("  tape families: classes");
+
+  // ---- 3. one member of every family through the flat compiler ----
+  struct Accepted {
+    uint32_t fam;
+    TapeProgram prog;
+    TapeTrace::Task tt;
+  };
+  std::vector<Accepted> accepted;
+  std::vector<uint8_t> comp_in_family(ncomp, 0);
+  for (size_t f = 0; f < fams.size(); ++f) {
+    const Family& fam = fams[f];
+    if (fam.comps.size() < kTapeFamilyMin) continue;
+    const uint32_t r = fam.rep;
+    if (comp_start[r + 1] - comp_start[r] < 8) continue;  // (far from the 16 nodes a task of its own takes: not worth a trial)
+    std::vector<uint32_t> vsel(cvout.begin() + cvout_start[r], cvout.begin() + cvout_start[r + 1]);
+    std::vector<uint32_t> rsel(crow.begin() + crow_start[r], crow.begin() + crow_start[r + 1]);
+    TapeTrace trace;
+    TapeProgram rp = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, &trace, /*tail_padding=*/false);
+    // (what the flat compiler gives a family member: a task of its own — from 16 nodes)
+    if (rp.tasks.size() != 1 || trace.tasks.size() != 1 || trace.tasks[0].n_comps != 1 || trace.tasks[0].comp_nodes < 16) continue;
+    // every leaf must be findable by position in the member's reachable set
+    bool ok = true;
+    for (uint32_t q = all_start[r]; q < all_start[r + 1]; ++q) local[all_nodes[q]] = q - all_start[r];
+    for (NodeId n : trace.tasks[0].leaf_nodes)
+      ok = ok && n != kNull && local[n] < all_start[r + 1] - all_start[r] && all_nodes[all_start[r] + local[n]] == n;
+    if (!ok) continue;
+    for (uint32_t c : fam.comps) comp_in_family[c] = 1;
+    accepted.push_back(Accepted{static_cast<uint32_t>(f), std::move(rp), std::move(trace.tasks[0])});
+  }
+  if (accepted.empty()) return false;
+
+  // ---- 4. everything else through the flat compiler together ----
+  {
+    std::vector<uint32_t> vsel = loose_vouts, rsel = loose_rows;
+    for (size_t c = 0; c < ncomp; ++c) {
+      if (comp_in_family[c]) continue;
+      vsel.insert(vsel.end(), cvout.begin() + cvout_start[c], cvout.begin() + cvout_start[c + 1]);
+      rsel.insert(rsel.end(), crow.begin() + crow_start[c], crow.begin() + crow_start[c + 1]);
+    }
+    std::sort(vsel.begin(), vsel.end());
+    std::sort(rsel.begin(), rsel.end());
+    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false);
+  }
+  lap("  tape families: representatives + remainder");
+  TapeProgram& prog = out;
+  prog.n_inputs = std::max(prog.n_inputs, n_inputs);
+  // constants: one pool for the whole program (a parameter's slot is never shared with a literal)
+  std::unordered_map<double, uint32_t> const_pool;
+  std::unordered_map<NodeId, uint32_t> param_slot;
+  {
+    std::vector<uint8_t> is_param(prog.consts.size(), 0);
+    for (auto& [node, slot] : prog.params) {
+      is_param[slot] = 1;
+      param_slot.emplace(node, slot);
+    }
+    for (size_t i = 0; i < prog.consts.size(); ++i)
+      if (!is_param[i]) const_pool.emplace(prog.consts[i], static_cast<uint32_t>(i));
+  }
+  auto leaf_binding = [&](NodeId n) -> uint32_t {
+    if (g.op[n] == OP_CONST) {
+      auto it = const_pool.find(g.val[n]);
+      if (it == const_pool.end()) {
+        it = const_pool.emplace(g.val[n], static_cast<uint32_t>(prog.consts.size())).first;
+        prog.consts.push_back(g.val[n]);
+      }
+      return kLeafConstFlag | it->second;
+    }
+    if (input_idx[n] >= 0) return static_cast<uint32_t>(input_idx[n]);
+    auto pit = param_slot.find(n);
+    if (pit == param_slot.end()) {
+      const uint32_t i = static_cast<uint32_t>(prog.consts.size());
+      prog.consts.push_back(g.val[n]);
+      prog.params.emplace_back(n, i);
+      pit = param_slot.emplace(n, i).first;
+    }
+    return kLeafConstFlag | pit->second;
+  };
+  for (Accepted& acc : accepted) {
+    const Family& fam = fams[acc.fam];
+    const TapeProgram& rp = acc.prog;
+    const uint32_t r = fam.rep;
+    // the family's structure, once
+    while ((prog.node_rec.size() / 3) % 2) {
+      for (int k = 0; k < 3; ++k) prog.node_rec.push_back(0);
+      for (int k = 0; k < 4; ++k) prog.node_rec16.push_back(0);
+    }
+    while (prog.edges.size() % 4) {
+      prog.edges.push_back({0, 0});
+      prog.edges16.push_back(0);
+      prog.edges16.push_back(0);
+    }
+    while (prog.slot_edge_ptr.size() % 8) {
+      prog.slot_edge_ptr.push_back(0);
+      prog.slot_edge_ptr16.push_back(0);
+    }
+    while (prog.lvl_ptr.size() % 4) prog.lvl_ptr.push_back(0);
+    while (prog.slvl_ptr.size() % 4) prog.slvl_ptr.push_back(0);
+    TapeTask base = rp.tasks[0];
+    base.node_off += static_cast<uint32_t>(prog.node_rec.size() / 3);
+    base.lvl_off += static_cast<uint32_t>(prog.lvl_ptr.size());
+    base.slot_off += static_cast<uint32_t>(prog.slot_edge_ptr.size());
+    base.slvl_off += static_cast<uint32_t>(prog.slvl_ptr.size());
+    base.edge_off += static_cast<uint32_t>(prog.edges.size());
+    prog.node_rec.insert(prog.node_rec.end(), rp.node_rec.begin(), rp.node_rec.end());
+    prog.node_rec16.insert(prog.node_rec16.end(), rp.node_rec16.begin(), rp.node_rec16.end());
+    prog.lvl_ptr.insert(prog.lvl_ptr.end(), rp.lvl_ptr.begin(), rp.lvl_ptr.end());
+    prog.slot_edge_ptr.insert(prog.slot_edge_ptr.end(), rp.slot_edge_ptr.begin(), rp.slot_edge_ptr.end());
+    prog.slot_edge_ptr16.insert(prog.slot_edge_ptr16.end(), rp.slot_edge_ptr16.begin(), rp.slot_edge_ptr16.end());
+    prog.slvl_ptr.insert(prog.slvl_ptr.end(), rp.slvl_ptr.begin(), rp.slvl_ptr.end());
+    prog.edges.insert(prog.edges.end(), rp.edges.begin(), rp.edges.end());
+    prog.edges16.insert(prog.edges16.end(), rp.edges16.begin(), rp.edges16.end());
+    prog.basic_ops = prog.basic_ops && rp.basic_ops;
+    prog.max_levels = std::max(prog.max_levels, rp.max_levels);
+    prog.max_slot_levels = std::max(prog.max_slot_levels, rp.max_slot_levels);
+    // positions, in the member's reachable set / row list / value-output list, of what the trace names
+    const TapeTrace::Task& tt = acc.tt;
+    for (uint32_t q = all_start[r]; q < all_start[r + 1]; ++q) local[all_nodes[q]] = q - all_start[r];
+    std::vector<uint32_t> leaf_pos(tt.leaf_nodes.size()), vout_pos(tt.vouts.size());
+    std::vector<std::pair<uint32_t, uint32_t>> jout_pos(tt.jouts.size());  // (row of the member, output of the row)
+    bool ok = true;
+    for (size_t i = 0; i < tt.leaf_nodes.size(); ++i) leaf_pos[i] = local[tt.leaf_nodes[i]];
+    for (size_t i = 0; i < tt.vouts.size(); ++i) {
+      const auto b = cvout.begin() + cvout_start[r], e = cvout.begin() + cvout_start[r + 1];
+      const auto it = std::find(b, e, tt.vouts[i]);
+      ok = ok && it != e;
+      vout_pos[i] = static_cast<uint32_t>(it - b);
+    }
+    for (size_t i = 0; i < tt.jouts.size(); ++i) {
+      const auto b = crow.begin() + crow_start[r], e = crow.begin() + crow_start[r + 1];
+      const auto it = std::find(b, e, tt.jouts[i].first);
+      ok = ok && it != e;
+      if (!ok) break;
+      const TapeRow& row = rows[*it];
+      size_t j = 0;
+      while (j < row.outputs.size() && row.outputs[j].wrt != tt.jouts[i].second) ++j;
+      ok = ok && j < row.outputs.size();
+      jout_pos[i] = {static_cast<uint32_t>(it - b), static_cast<uint32_t>(j)};
+    }
+    if (!ok) throw std::runtime_error("slpx tape compiler: a family representative's trace does not match its component");
+    const int cls = tt.cls;
+    for (uint32_t c : fam.comps) {
+      while (prog.leaf_src.size() % 4) prog.leaf_src.push_back(0);
+      TapeTask t = base;
+      t.leaf_off = static_cast<uint32_t>(prog.leaf_src.size());
+      t.vout_off = static_cast<uint32_t>(prog.vout_src.size());
+      t.jout_off = static_cast<uint32_t>(prog.jout_slot.size());
+      const NodeId* nodes_c = all_nodes.data() + all_start[c];
+      for (uint32_t pos : leaf_pos) prog.leaf_src.push_back(leaf_binding(nodes_c[pos]));
+      for (size_t i = 0; i < vout_pos.size(); ++i) {
+        const TapeValueOut& vo = value_outs[cvout[cvout_start[c] + vout_pos[i]]];
+        prog.vout_src.push_back(rp.vout_src[rp.tasks[0].vout_off + i]);
+        prog.vout_dst.push_back(static_cast<uint32_t>(vo.dst));
+        prog.vout_scale.push_back(vo.scale_idx);
+      }
+      for (size_t i = 0; i < jout_pos.size(); ++i) {
+        const TapeRow& row = rows[crow[crow_start[c] + jout_pos[i].first]];
+        prog.jout_slot.push_back(rp.jout_slot[rp.tasks[0].jout_off + i]);
+        prog.jout_dst.push_back(static_cast<uint32_t>(row.outputs[jout_pos[i].second].dst));
+        prog.jout_scale.push_back(row.scale_idx);
+      }
+      const uint32_t ti = static_cast<uint32_t>(prog.tasks.size());
+      if (cls == 0) {
+        prog.small_tasks.push_back(ti);
+        prog.small_lds_bytes = std::max(prog.small_lds_bytes, t.lds_bytes);
+      } else if (cls == 1) {
+        prog.large_tasks.push_back(ti);
+        prog.large_lds_bytes = std::max(prog.large_lds_bytes, t.lds_bytes);
+      } else {
+        prog.global_tasks.push_back(ti);
+        t.scratch_off = static_cast<uint32_t>(prog.global_scratch_doubles);
+        prog.global_scratch_doubles += t.lds_doubles;
+      }
+      prog.tasks.push_back(t);
+      prog.total_nodes += t.n_node;
+      prog.total_slots += t.n_slot;
+      prog.total_leaves += t.n_leaf;
+      prog.total_edges += t.n_edge;
+      if (c != r) ++prog.shared_tasks;
+    }
+  }
+  add_tail_padding(prog);
+  lap("  tape families: instances");
+  return true;
+}
+
+
+TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                         const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                         const TapeCompileOptions& opt) {
+  bool families = opt.families;
+  if (const char* env = std::getenv("SLPX_TAPE_TEMPLATES")) families = env[0] != '0';
+  TapeProgram prog;
+  bool done = false;
+  if (families && value_outs.size() + rows.size() >= 64) done = compile_tape_families(g, inputs, value_outs, rows, opt, prog);
+  if (!done) {
+    std::vector<uint32_t> vsel(value_outs.size()), rsel(rows.size());
+    std::iota(vsel.begin(), vsel.end(), 0u);
+    std::iota(rsel.begin(), rsel.end(), 0u);
+    prog = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/true);
+  }
   for (auto& v : value_outs) prog.n_outputs = std::max(prog.n_outputs, v.dst + 1);
   for (auto& r : rows)
     for (auto& o : r.outputs) prog.n_outputs = std::max(prog.n_outputs, o.dst + 1);

@@ -94,6 +94,9 @@ constexpr uint32_t kTapeFamilyMin = 8;
 
 struct TapeCompileOptions {
   bool cse = true;                        // merge structurally identical interior nodes (SLPX_TAPE_CSE=0: off)
+  // compile ONE member of every family of structurally identical components and instantiate the others from it
+  // (compile_tape_families; SLPX_TAPE_TEMPLATES=0: every component through the flat compiler, the same program)
+  bool families = true;
   uint32_t small_lds_bytes = 40 * 1024;   // 64-thread workgroups, four per CU
   uint32_t large_lds_bytes = 152 * 1024;  // 256-thread workgroups, one per CU
   bool rebalance_sums = true;

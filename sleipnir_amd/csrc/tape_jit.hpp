@@ -66,8 +66,8 @@ struct TapeJitOptions {
   // inputs [0, n) whose scale factor (in_scale) is identically 1: the decision variables
   // (DeviceNlp::set_scaling scales only the multiplier inputs); leaves bound to them skip the factor
   uint32_t n_unscaled_inputs = 0;
-  // 0: the kernel is the sweep; 1 / 2: it waits and signals through the `chain` words (DeviceNlp::sweep_full_for_step),
-  // with ordinary stores to V and a release fence per workgroup / with stores written through to memory
+  // 0: the kernel is the sweep; 1: it waits and signals through the `chain` words (DeviceNlp::sweep_full_for_step),
+  // its stores to V written through to memory
   int chain_mode = 0;
   // non-empty: generate + compile WITHOUT a device and store the code object there (prebuild_tape_templates)
   std::string prebuild_dir;

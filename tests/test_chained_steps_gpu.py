@@ -12,14 +12,11 @@ from tests.support import cases
 pytestmark = pytest.mark.gpu
 
 
-def _run(slpx, pp, states, scales, chained, monkeypatch, ahead=True):
-    """`ahead`: steps of a run launched behind their predecessors, waiting at a gate for the host's word
-    (NewtonSystem::set_pipeline, MfGate; SLPX_PRELAUNCH=1 — measured to gain nothing, it is off by default, DESIGN.md §4a)."""
+def _run(slpx, pp, states, scales, chained, monkeypatch):
     if chained:
         monkeypatch.delenv("SLPX_CHAIN_TAPE", raising=False)
     else:
         monkeypatch.setenv("SLPX_CHAIN_TAPE", "0")
-    monkeypatch.setenv("SLPX_PRELAUNCH", "1" if ahead else "0")
     system = slpx.System(pp, batch=1, device=0)
     out = []
     try:
@@ -44,12 +41,11 @@ def test_chained_steps_give_the_bits_of_the_unchained_ones(fresh, slpx, orc, mon
     n, me, mi = pp.dims
     scales = op.scaling()
     states = [cases.newton_state("interior", op.get_x(), n, me, mi, scales[0], seed=cases.SEED + k) for k in range(3)]
-    plain = _run(slpx, pp, states, scales, False, monkeypatch, ahead=False)
-    for chained, ahead in ((True, True), (True, False), (False, True)):
-        other = _run(slpx, pp, states, scales, chained, monkeypatch, ahead=ahead)
-        for a, b in zip(plain, other):
-            for u, v in zip(a, b):
-                assert np.array_equal(u, v), (chained, ahead)
+    plain = _run(slpx, pp, states, scales, False, monkeypatch)
+    other = _run(slpx, pp, states, scales, True, monkeypatch)
+    for a, b in zip(plain, other):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
     # (and the states do differ: the comparison is not of one repeated step)
     assert not np.array_equal(plain[0][0], plain[2][0])
 

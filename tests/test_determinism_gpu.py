@@ -16,9 +16,7 @@ from tests.support import models
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("step_graph", ["1", "0"])
-def test_batched_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_graph):
-    monkeypatch.setenv("SLPX_STEP_GRAPH", step_graph)
+def test_batched_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch):
     N, B, iters = 500, 64, 400
     pp = models.cart_pole(N, 5.0 / N)
     n, me, mi = pp.dims
@@ -38,13 +36,11 @@ def test_batched_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_g
         system.close()
 
 
-@pytest.mark.parametrize("step_graph", ["1", "0"])
-def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch, step_graph):
+def test_single_problem_steps_are_bitwise_reproducible(fresh, slpx, monkeypatch):
     """One problem takes the latency path: every round of the factorization in ONE launch
     (hand-over through the update-block slots, ldlt_kernels.h: slot_take), every round of the
     backward solve in one launch (round counters), completion signalled by a sequence number
     in pinned memory.  A lost ordering anywhere in there is a rare wrong step."""
-    monkeypatch.setenv("SLPX_STEP_GRAPH", step_graph)
     N, iters = 300, 1500
     pp = models.cart_pole(N, 5.0 / N)
     n, me, mi = pp.dims

@@ -298,48 +298,3 @@ def test_twin_attempts_follow_the_sequential_policy_bit_for_bit(name, make, capf
             assert taken > 0, lines
     print(f"{name}: {rep_t['iterations']} iterations, {rep_t['factorizations']} factorizations, {launches} twin launches, "
           f"second attempt taken {taken} times")
-
-
-@pytest.mark.parametrize("name,make", [
-    ("cart_pole_100", lambda: models.cart_pole(100, 0.05)),     # restoration on the way
-    ("cart_pole_500", lambda: models.cart_pole(500, 0.01)),     # corrections and backtracking: steps sent home
-    ("flywheel_50", lambda: models.flywheel(50, 0.005)),
-])
-def test_steps_launched_ahead_change_nothing_but_the_time(name, make, capfd):
-    """The next iteration's step kernel is launched while the host waits for this iteration's numbers and held
-    at a gate (MfGate, NewtonSystem::prelaunch_twin_step; SLPX_PRELAUNCH=1 — off by default, it measured no
-    faster): taken or sent home, a solve gives the iterates of the default to the bit."""
-    capfd.readouterr()
-    st_a, rep_a, x_a, duals_a = _solve_with_env(make, SLPX_TWIN_VERBOSE="1", SLPX_PRELAUNCH="1")
-    err = capfd.readouterr().err
-    st_p, rep_p, x_p, duals_p = _solve_with_env(make, SLPX_PRELAUNCH="0")
-    assert st_a == st_p
-    assert rep_a["iterations"] == rep_p["iterations"] and rep_a["factorizations"] == rep_p["factorizations"]
-    assert np.array_equal(x_a, x_p)
-    for a, b in zip(duals_a, duals_p):
-        assert np.array_equal(a, b)
-    lines = [l for l in err.splitlines() if l.startswith("slpx twin attempts:")]
-    assert lines or cases.OUTER_SWITCHES, err
-    ahead = sum(int(l.split(";")[-1].split()[0]) for l in lines)
-    taken = sum(int(l.split(";")[-1].split("ahead,")[1].split()[0]) for l in lines)
-    if not cases.OUTER_SWITCHES:
-        assert 0 < taken <= ahead, lines
-    print(f"{name}: {rep_a['iterations']} iterations, {ahead} steps launched ahead, {taken} taken")
-
-
-@pytest.mark.parametrize("name,make", [
-    ("cart_pole_100", lambda: models.cart_pole(100, 0.05)),
-    ("cart_pole_300", lambda: models.cart_pole(300, 5.0 / 300)),
-    ("flywheel_50", lambda: models.flywheel(50, 0.005)),
-])
-def test_the_look_ahead_inside_the_step_launch_gives_the_bits_of_its_own_launch(name, make):
-    """ipm_lookahead_body as the last act of the step kernel's launch (the workgroup that is through last reads
-    every workgroup's p, p_s, p_z past the caches; SLPX_IPM_LOOKAHEAD_RIDE=1 — off by default, it measured no faster)
-    against the same body as a launch of its own: the same iterates, to the bit."""
-    st_r, rep_r, x_r, duals_r = _solve_with_env(make, SLPX_IPM_LOOKAHEAD_RIDE="1")
-    st_k, rep_k, x_k, duals_k = _solve_with_env(make, SLPX_IPM_LOOKAHEAD_RIDE="0")
-    assert st_r == st_k
-    assert rep_r["iterations"] == rep_k["iterations"] and rep_r["factorizations"] == rep_k["factorizations"]
-    assert np.array_equal(x_r, x_k)
-    for a, b in zip(duals_r, duals_k):
-        assert np.array_equal(a, b)

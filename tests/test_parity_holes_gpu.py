@@ -187,7 +187,7 @@ def test_system_evaluated_inside_the_factorization_equals_the_assembled_one(fres
     # SLPX_FUSE_*=0 — there is no multifrontal step to ask for)
     is_mf = bool(got["inline"]["mf"])
     switched = any(os.environ.get(k) == "0" for k in ("SLPX_SUPERNODAL", "SLPX_FUSE_LAUNCHES", "SLPX_FUSE_BACKSUB",
-                                                       "SLPX_FUSE_SOLVE", "SLPX_SINGLE_LAUNCH", "SLPX_XG_HANDOFF"))
+                                                       "SLPX_FUSE_SOLVE", "SLPX_SINGLE_LAUNCH"))
     assert (is_mf == (mf == "1") or switched) and not got["assembled"]["mf"] and not (is_mf and mf == "0")
     for k in ("lhs", "rhs"):
         assert np.array_equal(got["inline"][k], got["assembled"][k]), k

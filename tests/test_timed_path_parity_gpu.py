@@ -150,27 +150,3 @@ def test_config5_gfold_matrix_core_fronts_against_oracle(fresh, slpx, monkeypatc
                                                 f"({system.info['ldlt_mfma_fronts']} of {system.info['ldlt_fronts']})")
     finally:
         system.close()
-
-
-@pytest.mark.parametrize("N,B,items", [(500, 64, (0, 63)), (60, 200, (0, 64, 199))])
-def test_batch_fronts_with_four_lanes_per_problem_against_oracle(fresh, slpx, orc, monkeypatch, N, B, items):
-    """SLPX_IL_FRONTS=1: the batch factorization by fronts, sixteen problems side by side, four lanes each
-    (ldlt_mfq_kernels.h — measured slower than the pair-list kernel and off by default):
-    the same plan as the single problem's, so its chains also go through the interleaved backward solve."""
-    monkeypatch.setenv("SLPX_IL_FRONTS", "1")
-    pp, op = cases.build_pair("cart_pole", N, slpx, orc)
-    n, me, mi = pp.dims
-    scales = op.scaling()
-    st = [cases.newton_state("interior", op.get_x(), n, me, mi, scales[0], seed=cases.SEED + b) for b in range(B)]
-    system = slpx.System(pp, batch=B, device=0)
-    try:
-        assert cases.OUTER_SWITCHES or system.info["ldlt_multifrontal"] == 1
-        system.set_scaling(scales)
-        system.set_state(*(np.stack([s[k] for s in st]) for k in range(4)), np.array([s[4] for s in st]))
-        system.reset_regularization()
-        assert np.all(system.newton_step(True) == 0)
-        snap = parity.snapshot_step(system)
-        for b in items:
-            parity.check_timed_step(system, op, st[b], b=b, verbose=True, label=f"{B} x N={N} item {b} (fronts)", snap=snap)
-    finally:
-        system.close()

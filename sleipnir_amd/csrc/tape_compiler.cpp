@@ -102,7 +102,8 @@ struct TapeTrace {
 static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
                                      const std::vector<TapeValueOut>& value_outs_all, const std::vector<TapeRow>& rows_all,
                                      const std::vector<uint32_t>& vsel, const std::vector<uint32_t>& rsel,
-                                     const TapeCompileOptions& opt, TapeTrace* trace, bool tail_padding) {
+                                     const TapeCompileOptions& opt, TapeTrace* trace, bool tail_padding,
+                                     const std::vector<NodeId>* param_order = nullptr) {
   TapeProgram prog;
   // (the selection, addressed like the whole lists were)
   struct ValueOutView {
@@ -613,6 +614,25 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
     return static_cast<uint32_t>(it->second);
   };
 
+  // Parameters get their slots FIRST and in node order (`param_order`: the caller's list, which may name more than
+  // this program reaches), not in the order in which tasks happen to meet them: the slot of "parameter j of stage i"
+  // is then base + stride * i whatever the packing, and the generated kernel computes such words instead of loading
+  // them — with the same generic source for every horizon (tape_jit.cpp).
+  {
+    auto claim = [&](NodeId s) {
+      if (param_slot.count(s)) return;
+      const uint32_t i = static_cast<uint32_t>(prog.consts.size());
+      prog.consts.push_back(g.val[s]);
+      prog.params.emplace_back(s, i);
+      param_slot.emplace(s, i);
+    };
+    if (param_order != nullptr) {
+      for (NodeId s : *param_order) claim(s);
+    } else {
+      for (size_t n = 0; n < ncg; ++n)
+        if (live[n] && cg.is_leaf(static_cast<int32_t>(n)) && cg.op[n] == OP_VAR && input_of.find(cg.src[n]) == input_of.end()) claim(cg.src[n]);
+    }
+  }
   std::unordered_multimap<uint64_t, uint32_t> templates;  // structure hash -> first task with it
   std::vector<int32_t> local_of(ncg, -1);       // CG node -> local value index
   std::vector<int32_t> local_slot(slots.size(), -1);
@@ -1178,7 +1198,11 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     }
     std::sort(vsel.begin(), vsel.end());
     std::sort(rsel.begin(), rsel.end());
-    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false);
+    // (every parameter leaf the whole program reaches, in node order: flat compiler, "parameters first")
+    std::vector<NodeId> param_order;
+    for (size_t n = 0; n < G; ++n)
+      if ((flag[n] & kReach) && g.op[n] == OP_VAR && input_idx[n] < 0) param_order.push_back(static_cast<NodeId>(n));
+    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false, &param_order);
   }
   lap("  tape families: representatives + remainder");
   TapeProgram& prog = out;

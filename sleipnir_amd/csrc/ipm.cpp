@@ -1185,8 +1185,11 @@ ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
   double mu_fr = fr_mu;
   const int it_before = iterations;
   const auto t_inner = clk::now();
+  // (the inner solve reports ITS error measure into rep.final_error: the report keeps the outer problem's)
+  const double outer_error = rep.final_error;
   const ExitStatus status = ipm_core(fr, fr_scales, callbacks, options, true, fr_x, fr_s, fr_y, fr_z,
                                      mu_fr, iterations, rep, solve_start);
+  rep.final_error = outer_error;
   rep.restoration_iterations += iterations - it_before;
   rep.t_restoration += since(t_inner);
 

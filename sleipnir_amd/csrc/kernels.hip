@@ -29,6 +29,7 @@
 #include "ipm_kernels.h"
 #include "tape_kernels.h"
 #include "tape_ops.h"
+#include "setup_timing.hpp"
 
 namespace slpx {
 
@@ -519,6 +520,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     throw std::runtime_error("slpx: no HIP device available (the product path has no CPU fallback)");
   SLPX_HIP_CHECK(hipSetDevice(device));
+  SetupLap lap;
 
   // Chained steps (sweep_full_for_step): for one problem whose multifrontal step kernel leaves the sweep
   // room on the chip (at most CUs - 64 workgroups: cart-pole N=5000's 265 do not, and there chaining costs
@@ -533,6 +535,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   m_full.upload(s.full, batch, static_cast<uint32_t>(s.n), m_chain_mode);
   m_values.upload(s.values, batch, static_cast<uint32_t>(s.n));
   m_reduces.upload(s.reduces);
+  lap("  upload: tapes (+ code objects)");
   // allow > 64 KB dynamic LDS
   for (const void* fn : {reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, true>),
                          reinterpret_cast<const void*>(&tape_sweep_lds_kernel<256, false>),
@@ -576,6 +579,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
                   m_ai_col.p,    m_ai_src.p,   m_fast_src.p, s.off_f,      s.off_ce,     s.off_ci,     s.off_g,
                   s.off_Ae,      s.off_Ai};
 
+  lap("  upload: kernel attributes, KKT plan");
   m_ltasks.upload(l.tasks);
   m_ent_src.upload(l.ent_src);
   m_ent_flags.upload(l.ent_flags);
@@ -646,6 +650,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // single problem: 137 tasks on 256 CUs).  With a batch the later-round workgroups would
   // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
+  lap("  upload: LDLT plan");
   m_il = interleaved_for(batch);
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
@@ -666,6 +671,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
   if (m_mf) m_fuse_solve = true;
   m_chain_on = m_mf && m_chain_mode != 0;
+  lap("  upload: inline KKT / back-substitution / multifrontal images");
 
   const size_t B = static_cast<size_t>(batch);
   m_in.alloc(B * s.n_inputs());
@@ -809,7 +815,9 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   }
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
+  lap("  upload: value buffers");
   set_scaling(std::vector<double>(s.n_scales(), 1.0));
+  lap("  upload: scaling, static V");
 }
 
 DeviceNlp::~DeviceNlp() {

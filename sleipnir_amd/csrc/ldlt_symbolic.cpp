@@ -227,9 +227,10 @@ struct Orderer {
 
 }  // namespace
 
-static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const LdltOptions& opt,
+static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const LdltOptions& opt_in,
                                      const std::vector<int32_t>* user_perm,
                                      const std::vector<uint8_t>* diag_has_source) {
+  LdltOptions opt = opt_in;  // (single_problem_task_rules may adjust it after the first task partition)
   LdltPlan P;
   const int n = lower.cols;
   P.n = n;
@@ -404,7 +405,6 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
 
   lap("  ldlt: relaxed supernodes");
   // ---- tasks: subtrees that fit in LDS, grouped in rounds -------------------------
-  const uint32_t cap = opt.task_entries;
   std::vector<int32_t> task_of(n, -1);
   std::vector<int32_t> round_of(n, -1);
   struct TaskCols {
@@ -413,7 +413,10 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     int round = 0;
   };
   std::vector<TaskCols> tcols;
-  {
+  for (int partition_pass = 0; partition_pass < 2; ++partition_pass) {
+    const uint32_t cap = opt.task_entries;
+    std::fill(round_of.begin(), round_of.end(), -1);
+    tcols.clear();
     std::vector<uint32_t> w(n), W(n);
     for (int j = 0; j < n; ++j) {
       // LDS cost in "entry equivalents" (~32 B): the column's entries plus the
@@ -468,6 +471,17 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       ++round;
     }
     P.n_rounds = round;
+    if (partition_pass == 0 && opt.single_problem_task_rules) {
+      bool again = false;
+      if (opt.task_entries == LdltOptions{}.task_entries && tcols.size() > 400) {
+        opt.task_entries *= 2;
+        again = true;
+      }
+      if (opt.chain_from_deepest_child && opt.chain_from_deepest_min_round == 0 && tcols.size() > 250)
+        opt.chain_from_deepest_min_round = 1;  // (read by the supernode pass below: no new partition for it)
+      if (again) continue;
+    }
+    break;
   }
   const int ntasks = static_cast<int>(tcols.size());
   // column levels inside a task and local ordering

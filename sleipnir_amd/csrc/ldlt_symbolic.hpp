@@ -205,6 +205,11 @@ struct LdltOptions {
   // LDS budget per task in entry-equivalents (one L entry ~ 32 B incl. its
   // descriptors; four update pairs ~ one entry).  2048 keeps a task near 64-96 KB.
   uint32_t task_entries = 2048;
+  // One problem, every round in one launch (NewtonSystem): a partition of more than 400 tasks is redone with twice
+  // the task size, one of more than 250 keeps the chains-from-the-deepest-child rule out of the leaf tasks (newton.cpp
+  // has the measurements).  Decided INSIDE the build, right after the task partition — the ordering, the pattern of L
+  // and the relaxed supernodes do not depend on either — where it used to be a second full build (0.18 s at N=5000).
+  bool single_problem_task_rules = false;
   bool defer_constraints = true;
   // levels are supernodes (chains of equal-structure columns) instead of single columns:
   // cart-pole N=1000 50 -> 16 levels on the critical path, g-fold N=100 68 -> 16.  The

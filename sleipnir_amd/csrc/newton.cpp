@@ -74,7 +74,6 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
       lopt.task_entries = std::clamp<uint32_t>(256u * static_cast<uint32_t>(std::lround(scaled / 256.0)), 1024u, 2048u);
     }
     if (const char* env = std::getenv("SLPX_TASK_ENTRIES")) lopt.task_entries = static_cast<uint32_t>(std::atoi(env));
-    m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
     // One problem, all rounds in one launch: about 512 of the 1024-thread task workgroups are
     // resident at a time (two per CU).  A plan with more tasks than that serializes its tail
     // and usually has a round more than necessary; twice the task size fixes both (cart-pole
@@ -83,14 +82,9 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // (more than ~250 tasks take two workgroups per CU, 80 KB of LDS each: there the chains-from-the-deepest-
     // child rule stays out of the leaf tasks, where it only adds fronts — tables, arena — to full levels:
     // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
-    const bool deepest_everywhere = lopt.chain_from_deepest_child && lopt.chain_from_deepest_min_round == 0;
-    const bool double_tasks = opt.batch == 1 && lopt.task_entries == LdltOptions{}.task_entries && m_l.tasks.size() > 400 &&
-                              std::getenv("SLPX_TASK_ENTRIES") == nullptr;
-    if (double_tasks || (deepest_everywhere && m_l.tasks.size() > 250)) {
-      if (double_tasks) lopt.task_entries *= 2;
-      if (deepest_everywhere) lopt.chain_from_deepest_min_round = 1;
-      m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
-    }
+    // Both rules are applied inside the build, after its first task partition (LdltOptions::single_problem_task_rules).
+    lopt.single_problem_task_rules = opt.batch == 1 && std::getenv("SLPX_TASK_ENTRIES") == nullptr;
+    m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
   };
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
   lap("= AD structure + tape compile, KKT plan, LDLT symbolic");

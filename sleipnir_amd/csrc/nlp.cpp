@@ -56,40 +56,70 @@ void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, std::vector<d
   }
 }
 
-MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::vector<NodeId>& wrt,
-                         int nrows, int ncols, bool lower, std::vector<double>& adj_scratch) {
-  MatrixBuild mb;
-  std::vector<std::vector<NodeId>> tops(rows.size());
-  std::vector<std::vector<std::pair<int32_t, NodeId>>> outs(rows.size());
-  // topological_sort uses `scratch` too; like the reference, build all lists first
-  // (jacobian.hpp:60-62) and only then tag each wrt node with its column (:64-66).
-  for (size_t r = 0; r < rows.size(); ++r) tops[r] = g.topological_sort(rows[r]);
-  for (size_t c = 0; c < wrt.size(); ++c) g.scratch[wrt[c]] = static_cast<int32_t>(c);
-  for (size_t r = 0; r < rows.size(); ++r)
-    for (NodeId n : tops[r])
-      if (g.scratch[n] != -1) outs[r].emplace_back(g.scratch[n], n);
-  for (size_t c = 0; c < wrt.size(); ++c) g.scratch[wrt[c]] = -1;
+// Row visits of build_matrix: a stamp per graph node (which row saw it last) and a stack, shared by the five matrices.
+struct RowVisit {
+  std::vector<int32_t> seen, col;  // col: the column of a wrt node, -1 otherwise (Graph::scratch is topological_sort's)
+  std::vector<NodeId> stack;
+  int32_t stamp = 0;
+};
 
+MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::vector<NodeId>& wrt,
+                         int nrows, int ncols, bool lower, std::vector<double>& adj_scratch, RowVisit& visit) {
+  MatrixBuild mb;
+  // Like the reference, tag each wrt node with its column (jacobian.hpp:64-66).  A LINEAR row needs its
+  // parent->child list (topological_sort; the order fixes how its constant adjoints are summed); of a nonlinear row
+  // only the SET of wrt nodes it reaches is needed here (the tape compiler makes its own lists): one marking walk,
+  // every node of the row touched once — the lists of all rows of a Hessian were 1.2 million entries at N=1000.
   if (adj_scratch.size() < g.size()) adj_scratch.resize(g.size(), 0.0);
+  if (visit.seen.size() < g.size()) visit.seen.resize(g.size(), -1);
+  if (visit.col.size() < g.size()) visit.col.resize(g.size(), -1);
+  std::vector<int32_t>& col_of = visit.col;
+  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = static_cast<int32_t>(c);
+  std::vector<std::pair<int32_t, NodeId>> outs;
   for (size_t r = 0; r < rows.size(); ++r) {
     if (rows[r] == kNull) continue;
     const uint8_t t = g.type[rows[r]];
     if (t == T_LINEAR) {
       ++mb.linear_rows;
-      if (tops[r].empty()) continue;
-      linear_row_adjoints(g, tops[r], adj_scratch);
-      for (auto& [col, node] : outs[r]) {
-        if (lower && col > static_cast<int32_t>(r)) continue;
-        mb.entries.push_back({static_cast<int32_t>(r), col, node, adj_scratch[node], true});
+      const std::vector<NodeId> top = g.topological_sort(rows[r]);
+      if (top.empty()) continue;
+      linear_row_adjoints(g, top, adj_scratch);
+      for (NodeId n : top) {
+        const int32_t col = col_of[n];
+        if (col == -1 || (lower && col > static_cast<int32_t>(r))) continue;
+        mb.entries.push_back({static_cast<int32_t>(r), col, n, adj_scratch[n], true});
       }
     } else if (t > T_LINEAR) {
       mb.nonlinear_rows.push_back(static_cast<int32_t>(r));
-      for (auto& [col, node] : outs[r]) {
+      const int32_t stamp = visit.stamp++;
+      std::vector<NodeId>& stack = visit.stack;
+      stack.assign(1, rows[r]);
+      visit.seen[rows[r]] = stamp;
+      outs.clear();
+      while (!stack.empty()) {
+        const NodeId n = stack.back();
+        stack.pop_back();
+        const NodeId l = g.a0[n], rr = g.a1[n];
+        if (l == kNull) {
+          if (col_of[n] != -1) outs.emplace_back(col_of[n], n);
+          continue;
+        }
+        if (visit.seen[l] != stamp) {
+          visit.seen[l] = stamp;
+          stack.push_back(l);
+        }
+        if (rr != kNull && visit.seen[rr] != stamp) {
+          visit.seen[rr] = stamp;
+          stack.push_back(rr);
+        }
+      }
+      for (auto& [col, node] : outs) {
         if (lower && col > static_cast<int32_t>(r)) continue;
         mb.entries.push_back({static_cast<int32_t>(r), col, node, 0.0, false});
       }
     }
   }
+  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = -1;
   // CSC order (setFromTriplets: column-major, rows ascending)
   std::stable_sort(mb.entries.begin(), mb.entries.end(), [](const RowEntry& a, const RowEntry& b) {
     return a.col != b.col ? a.col < b.col : a.row < b.row;
@@ -126,6 +156,8 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
 
   NodeId f = f_in == kNull ? g.constant(0.0) : f_in;  // problem.hpp:318
 
+  // (the gradient trees below add about twice the model's own nodes: one allocation instead of a dozen doublings)
+  g.reserve(g.size() + 2 * g.size() + 4 * static_cast<size_t>(m_e + m_i) + 1024);
   // problem.hpp:519-520: dual variables as fresh decision-variable leaves
   for (int j = 0; j < m_e; ++j) s.y_nodes.push_back(g.variable(0.0));
   for (int j = 0; j < m_i; ++j) s.z_nodes.push_back(g.variable(0.0));
@@ -149,11 +181,12 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   lap("gradient trees (Hessian rows)");
 
   std::vector<double> adj;
-  MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, adj);        // problem.hpp:535
-  MatrixBuild mHf = build_matrix(g, Hf_rows, x, n, n, true, adj);
-  MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, adj);
-  MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, adj);     // problem.hpp:555
-  MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, adj);     // problem.hpp:560
+  RowVisit visit;
+  MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, adj, visit);        // problem.hpp:535
+  MatrixBuild mHf = build_matrix(g, Hf_rows, x, n, n, true, adj, visit);
+  MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, adj, visit);
+  MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, adj, visit);     // problem.hpp:555
+  MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, adj, visit);     // problem.hpp:560
   lap("row lists + patterns");
 
   s.g_pat = mg.pat;

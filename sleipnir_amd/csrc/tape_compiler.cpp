@@ -5,8 +5,12 @@
 #include "setup_timing.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <future>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 namespace slpx {
@@ -940,6 +944,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
         }
     }
   }
+  lap("  tape families:   reach");
   auto is_leaf = [&](NodeId n) { return g.a0[n] == kNull; };
   // ---- components (children have smaller numbers than their parents: ascending order is children first) ----
   std::vector<int32_t> parent(G);  // union-find over interior, not private nodes
@@ -978,6 +983,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
         }
     }
   }
+  lap("  tape families:   union");
   // component numbers in order of their smallest node; members by component, ascending
   std::vector<int32_t> comp_of(G, -1);
   std::vector<uint32_t> comp_start{0};
@@ -1001,6 +1007,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     for (size_t n = 0; n < G; ++n)
       if (comp_of[n] >= 0) members[fill[comp_of[n]]++] = static_cast<NodeId>(n);
   }
+  lap("  tape families:   numbering");
   const size_t ncomp = comp_start.size() - 1;
   if (ncomp < kTapeFamilyMin) return false;
   // rows and value outputs by component (in the order of the lists); what belongs to none: a bare leaf
@@ -1041,18 +1048,42 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     input_idx[node] = idx;
     n_inputs = std::max(n_inputs, idx + 1);
   }
-  std::vector<int32_t> stamp(G, -1);
-  std::vector<uint32_t> local(G, 0);
   std::vector<NodeId> all_nodes;           // every component's reachable set, ascending
   std::vector<uint32_t> all_start{0};
   std::vector<uint32_t> seq;               // every component's sequence
   std::vector<uint32_t> seq_start{0};
   std::vector<uint64_t> seq_hash(ncomp);
-  all_nodes.reserve(members.size() + members.size() / 4);
-  seq.reserve(4 * members.size());
+  // (components are independent of each other: big models on a few threads, each with its own scratch — a stamp and
+  // a position per graph node — over a contiguous range of components of about the same number of members)
+  struct Chunk {
+    size_t c_begin = 0, c_end = 0;
+    std::vector<NodeId> all_nodes;
+    std::vector<uint32_t> all_count, seq, seq_count;
+  };
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  size_t n_chunks = members.size() < 100000 ? 1 : std::min<size_t>(4, std::max(1u, hw / 2));
+  if (const char* env = std::getenv("SLPX_SETUP_THREADS")) n_chunks = std::clamp<size_t>(static_cast<size_t>(std::atoi(env)), 1, 16);
+  std::vector<Chunk> chunks(n_chunks);
   {
+    size_t c = 0;
+    for (size_t k = 0; k < n_chunks; ++k) {
+      chunks[k].c_begin = c;
+      const size_t target = members.size() * (k + 1) / n_chunks;
+      while (c < ncomp && (k + 1 == n_chunks || comp_start[c + 1] <= target)) ++c;
+      chunks[k].c_end = c;
+    }
+  }
+  auto run_chunk = [&](Chunk& ch) {
+    const auto t0_ = std::chrono::steady_clock::now();
+    std::vector<int32_t> stamp(G, -1);
+    std::vector<uint32_t> local(G, 0);
     std::vector<NodeId> ext, stack;
-    for (size_t c = 0; c < ncomp; ++c) {
+    std::vector<NodeId>& nodes = ch.all_nodes;
+    std::vector<uint32_t>& sq = ch.seq;
+    const size_t n_mem = comp_start[ch.c_end] - comp_start[ch.c_begin];
+    nodes.reserve(n_mem + n_mem / 4);
+    sq.reserve(4 * n_mem);
+    for (size_t c = ch.c_begin; c < ch.c_end; ++c) {
       ext.clear();
       const int32_t ci = static_cast<int32_t>(c);
       for (uint32_t q = comp_start[c]; q < comp_start[c + 1]; ++q) {
@@ -1076,55 +1107,83 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       }
       std::sort(ext.begin(), ext.end());
       // merge
-      const size_t base = all_nodes.size();
+      const size_t base = nodes.size();
       {
         uint32_t q = comp_start[c];
         size_t e = 0;
         const uint32_t qe = comp_start[c + 1];
         while (q < qe || e < ext.size()) {
-          if (e == ext.size() || (q < qe && members[q] < ext[e])) all_nodes.push_back(members[q++]);
-          else all_nodes.push_back(ext[e++]);
+          if (e == ext.size() || (q < qe && members[q] < ext[e])) nodes.push_back(members[q++]);
+          else nodes.push_back(ext[e++]);
         }
       }
-      const size_t cnt = all_nodes.size() - base;
-      for (size_t i = 0; i < cnt; ++i) local[all_nodes[base + i]] = static_cast<uint32_t>(i);
-      all_start.push_back(static_cast<uint32_t>(all_nodes.size()));
+      const size_t cnt = nodes.size() - base;
+      for (size_t i = 0; i < cnt; ++i) local[nodes[base + i]] = static_cast<uint32_t>(i);
+      ch.all_count.push_back(static_cast<uint32_t>(cnt));
       // sequence
+      const size_t s0 = sq.size();
       for (size_t i = 0; i < cnt; ++i) {
-        const NodeId n = all_nodes[base + i];
+        const NodeId n = nodes[base + i];
         uint32_t w0 = g.op[n];
         if (is_leaf(n)) {
           // (what a leaf is bound to: a constant, an input, a parameter — its value or index is the instance's own)
           w0 |= (g.op[n] == OP_CONST ? 1u : (input_idx[n] >= 0 ? 2u : 3u)) << 8;
-          seq.push_back(w0);
+          sq.push_back(w0);
         } else {
           if (flag[n] & kRepl) w0 |= 1u << 16;
           if (flag[n] & kRoot) w0 |= 1u << 17;
-          seq.push_back(w0);
-          seq.push_back(local[g.a0[n]]);
-          seq.push_back(g.a1[n] == kNull ? 0xffffffffu : local[g.a1[n]]);
+          sq.push_back(w0);
+          sq.push_back(local[g.a0[n]]);
+          sq.push_back(g.a1[n] == kNull ? 0xffffffffu : local[g.a1[n]]);
         }
       }
       for (uint32_t q = cvout_start[c]; q < cvout_start[c + 1]; ++q) {
-        seq.push_back(0xfffffff0u);
-        seq.push_back(local[value_outs[cvout[q]].node]);
+        sq.push_back(0xfffffff0u);
+        sq.push_back(local[value_outs[cvout[q]].node]);
       }
       for (uint32_t q = crow_start[c]; q < crow_start[c + 1]; ++q) {
         const TapeRow& row = rows[crow[q]];
-        seq.push_back(0xfffffff1u);
-        seq.push_back(local[row.root]);
-        seq.push_back(static_cast<uint32_t>(row.outputs.size()));
-        for (auto& o : row.outputs) seq.push_back(stamp[o.wrt] == ci ? local[o.wrt] : 0xffffffffu);
+        sq.push_back(0xfffffff1u);
+        sq.push_back(local[row.root]);
+        sq.push_back(static_cast<uint32_t>(row.outputs.size()));
+        for (auto& o : row.outputs) sq.push_back(stamp[o.wrt] == ci ? local[o.wrt] : 0xffffffffu);
       }
-      seq_start.push_back(static_cast<uint32_t>(seq.size()));
+      ch.seq_count.push_back(static_cast<uint32_t>(sq.size() - s0));
       uint64_t h = 1469598103934665603ull;
-      for (size_t k = seq_start[c]; k < seq.size(); ++k) {
-        h = (h ^ seq[k]) * 1099511628211ull;
+      for (size_t k = s0; k < sq.size(); ++k) {
+        h = (h ^ sq[k]) * 1099511628211ull;
         h ^= h >> 29;
       }
       seq_hash[c] = h;
     }
+    if (std::getenv("SLPX_SETUP_TIMING")) std::fprintf(stderr, "    chunk %zu-%zu: %.4f s, %u members, %zu nodes, %zu seq words\n", ch.c_begin, ch.c_end, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(), comp_start[ch.c_end] - comp_start[ch.c_begin], ch.all_nodes.size(), ch.seq.size());
+  };
+  {
+    std::vector<std::future<void>> jobs;
+    for (size_t k = 1; k < n_chunks; ++k) jobs.push_back(std::async(std::launch::async, [&, k] { run_chunk(chunks[k]); }));
+    run_chunk(chunks[0]);
+    for (auto& j : jobs) j.get();
+    size_t n_all = 0, n_seq = 0;
+    for (const Chunk& ch : chunks) {
+      n_all += ch.all_nodes.size();
+      n_seq += ch.seq.size();
+    }
+    all_nodes.reserve(n_all);
+    seq.reserve(n_seq);
+    for (Chunk& ch : chunks) {
+      if (n_chunks == 1) {
+        all_nodes = std::move(ch.all_nodes);
+        seq = std::move(ch.seq);
+      } else {
+        all_nodes.insert(all_nodes.end(), ch.all_nodes.begin(), ch.all_nodes.end());
+        seq.insert(seq.end(), ch.seq.begin(), ch.seq.end());
+      }
+      for (uint32_t cnt : ch.all_count) all_start.push_back(all_start.back() + cnt);
+      for (uint32_t cnt : ch.seq_count) seq_start.push_back(seq_start.back() + cnt);
+      ch = Chunk{};
+    }
   }
+  std::vector<uint32_t> local(G, 0);  // (scratch of the passes below)
   lap("  tape families: sequences");
 
   // ---- families: equal sequences ----

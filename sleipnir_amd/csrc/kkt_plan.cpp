@@ -1,7 +1,8 @@
 #include "kkt_plan.hpp"
 
+#include "setup_timing.hpp"
+
 #include <algorithm>
-#include <map>
 
 namespace slpx {
 
@@ -29,22 +30,37 @@ void csc_to_csr(const CscPattern& a, int voff, std::vector<int32_t>& rowptr,
 
 KktPlan build_kkt_plan(const NlpStructure& s) {
   KktPlan k;
+  SetupLap lap;
   k.n = s.n;
   k.m_e = s.m_e;
   k.m_i = s.m_i;
   k.dim = s.n + s.m_e;
   const int n = s.n;
 
-  // (col, row) -> sources; std::map keeps CSC order (col major, rows ascending)
-  std::map<std::pair<int32_t, int32_t>, Sources> ent;
+  // every (col, row) that has a source, in the order the sources are found (H_f before H_c inside a column,
+  // the products of a row of A_i in (a, b) order, rows ascending — the order the sums are taken in); the
+  // entries themselves = the distinct keys in CSC order (col major, rows ascending)
+  auto key_of = [](int32_t col, int32_t row) { return (static_cast<uint64_t>(static_cast<uint32_t>(col)) << 32) | static_cast<uint32_t>(row); };
+  std::vector<uint64_t> dkey, pkey;
+  std::vector<int32_t> dval, pav, pbv, prv;
+  dkey.reserve(s.Hf.nnz() + s.Hc.nnz() + s.Ae.nnz());
+  dval.reserve(dkey.capacity());
   // H = d_f H_f + H_c (problem.hpp:635); V already carries the d_f factor
   for (int c = 0; c < n; ++c) {
-    for (int p = s.Hf.colptr[c]; p < s.Hf.colptr[c + 1]; ++p)
-      ent[{c, s.Hf.rowidx[p]}].direct.push_back(s.off_Hf + p);
-    for (int p = s.Hc.colptr[c]; p < s.Hc.colptr[c + 1]; ++p)
-      ent[{c, s.Hc.rowidx[p]}].direct.push_back(s.off_Hc + p);
+    for (int p = s.Hf.colptr[c]; p < s.Hf.colptr[c + 1]; ++p) {
+      dkey.push_back(key_of(c, s.Hf.rowidx[p]));
+      dval.push_back(s.off_Hf + p);
+    }
+    for (int p = s.Hc.colptr[c]; p < s.Hc.colptr[c + 1]; ++p) {
+      dkey.push_back(key_of(c, s.Hc.rowidx[p]));
+      dval.push_back(s.off_Hc + p);
+    }
   }
-  k.nnz_H_union = static_cast<int>(ent.size());
+  {
+    std::vector<uint64_t> hk(dkey);
+    std::sort(hk.begin(), hk.end());
+    k.nnz_H_union = static_cast<int>(std::unique(hk.begin(), hk.end()) - hk.begin());
+  }
   // tril(AᵢᵀΣAᵢ) (interior_point.hpp:432-433): entry (p,q), p>=q, sums over rows r
   csc_to_csr(s.Ai, s.off_Ai, k.ai_rowptr, k.ai_col, k.ai_src);
   csc_to_csr(s.Ae, s.off_Ae, k.ae_rowptr, k.ae_col, k.ae_src);
@@ -53,34 +69,61 @@ KktPlan build_kkt_plan(const NlpStructure& s) {
       for (int b = k.ai_rowptr[r]; b < k.ai_rowptr[r + 1]; ++b) {
         int32_t row = k.ai_col[a], col = k.ai_col[b];
         if (row < col) continue;
-        Sources& e = ent[{col, row}];
-        e.pa.push_back(k.ai_src[a]);  // (AᵢᵀΣ)(row, r) = Aᵢ(r,row) σ_r
-        e.pb.push_back(k.ai_src[b]);  // Aᵢ(r, col)
-        e.pr.push_back(r);
+        pkey.push_back(key_of(col, row));
+        pav.push_back(k.ai_src[a]);  // (AᵢᵀΣ)(row, r) = Aᵢ(r,row) σ_r
+        pbv.push_back(k.ai_src[b]);  // Aᵢ(r, col)
+        prv.push_back(r);
       }
   }
   // A_e block below (append_as_triplets.hpp:38-46, row offset n)
   for (int c = 0; c < n; ++c)
-    for (int p = s.Ae.colptr[c]; p < s.Ae.colptr[c + 1]; ++p)
-      ent[{c, n + s.Ae.rowidx[p]}].direct.push_back(s.off_Ae + p);
+    for (int p = s.Ae.colptr[c]; p < s.Ae.colptr[c + 1]; ++p) {
+      dkey.push_back(key_of(c, n + s.Ae.rowidx[p]));
+      dval.push_back(s.off_Ae + p);
+    }
+  std::vector<uint64_t> keys;
+  keys.reserve(dkey.size() + pkey.size() + k.dim);
+  keys.insert(keys.end(), dkey.begin(), dkey.end());
+  keys.insert(keys.end(), pkey.begin(), pkey.end());
   // forced diagonal (sparse_regularized_ldlt.hpp:67: lhs + regularization(0, 0))
-  for (int d = 0; d < k.dim; ++d) ent[{d, d}];
+  for (int d = 0; d < k.dim; ++d) keys.push_back(key_of(d, d));
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  const size_t nnz = keys.size();
+  auto entry_of = [&](uint64_t key) { return static_cast<size_t>(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin()); };
 
   k.lhs.rows = k.lhs.cols = k.dim;
   k.lhs.colptr.assign(k.dim + 1, 0);
-  k.dptr.push_back(0);
-  k.pptr.push_back(0);
-  for (auto& [key, src] : ent) {
-    ++k.lhs.colptr[key.first + 1];
-    k.lhs.rowidx.push_back(key.second);
-    k.dsrc.insert(k.dsrc.end(), src.direct.begin(), src.direct.end());
-    k.pa.insert(k.pa.end(), src.pa.begin(), src.pa.end());
-    k.pb.insert(k.pb.end(), src.pb.begin(), src.pb.end());
-    k.pr.insert(k.pr.end(), src.pr.begin(), src.pr.end());
-    k.dptr.push_back(static_cast<int32_t>(k.dsrc.size()));
-    k.pptr.push_back(static_cast<int32_t>(k.pa.size()));
+  k.lhs.rowidx.resize(nnz);
+  for (size_t e = 0; e < nnz; ++e) {
+    ++k.lhs.colptr[static_cast<int32_t>(keys[e] >> 32) + 1];
+    k.lhs.rowidx[e] = static_cast<int32_t>(keys[e] & 0xffffffffu);
   }
   for (int c = 0; c < k.dim; ++c) k.lhs.colptr[c + 1] += k.lhs.colptr[c];
+  // counting sort of the sources by entry: the order of discovery is kept inside an entry
+  std::vector<uint32_t> dent(dkey.size()), pent(pkey.size());
+  k.dptr.assign(nnz + 1, 0);
+  k.pptr.assign(nnz + 1, 0);
+  for (size_t i = 0; i < dkey.size(); ++i) ++k.dptr[(dent[i] = static_cast<uint32_t>(entry_of(dkey[i]))) + 1];
+  for (size_t i = 0; i < pkey.size(); ++i) ++k.pptr[(pent[i] = static_cast<uint32_t>(entry_of(pkey[i]))) + 1];
+  for (size_t e = 0; e < nnz; ++e) {
+    k.dptr[e + 1] += k.dptr[e];
+    k.pptr[e + 1] += k.pptr[e];
+  }
+  k.dsrc.resize(dkey.size());
+  k.pa.resize(pkey.size());
+  k.pb.resize(pkey.size());
+  k.pr.resize(pkey.size());
+  {
+    std::vector<int32_t> dnext(k.dptr.begin(), k.dptr.end() - 1), pnext(k.pptr.begin(), k.pptr.end() - 1);
+    for (size_t i = 0; i < dkey.size(); ++i) k.dsrc[dnext[dent[i]]++] = dval[i];
+    for (size_t i = 0; i < pkey.size(); ++i) {
+      const int32_t q = pnext[pent[i]]++;
+      k.pa[q] = pav[i];
+      k.pb[q] = pbv[i];
+      k.pr[q] = prv[i];
+    }
+  }
 
   k.g_src.assign(n, -1);
   for (int c = 0; c < n; ++c)
@@ -95,6 +138,7 @@ KktPlan build_kkt_plan(const NlpStructure& s) {
     k.fast_src[e] = (np == 0 && nd == 1) ? k.dsrc[k.dptr[e]] : ((np == 0 && nd == 0) ? -1 : -2);
   }
   k.rhs_bytes = 16LL * n + 24LL * s.m_e + 24LL * s.m_i + 12 * (a + i);
+  lap("  kkt plan");
   return k;
 }
 

@@ -1,13 +1,16 @@
 #include "ldlt_symbolic.hpp"
 
 #include "setup_timing.hpp"
+#include "setup_threads.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 namespace slpx {
@@ -24,7 +27,12 @@ struct Orderer {
   const std::vector<uint8_t>& has_diag;
   const LdltOptions& opt;
   std::vector<int32_t> stamp, dist;
-  int32_t cur_stamp = 0;
+  // The two sides of a separator are dissected on two threads (down to a few levels: parallel_depth): they
+  // share no node and no edge, every call marks its nodes with a stamp of its own, and what the sides do
+  // share — the `avail` counts of the separator nodes above them, which both add to and nobody reads before
+  // both are through — is updated atomically.  The order is the sequential one: left, right, separator.
+  std::atomic<int32_t> cur_stamp{0};
+  int32_t new_stamp() { return cur_stamp.fetch_add(1, std::memory_order_relaxed) + 1; }
   std::vector<int32_t> order;
   // Pairing state for nodes whose unregularized diagonal is structurally zero
   // (constraint rows, variables that appear only linearly): such a node z may only be
@@ -36,15 +44,23 @@ struct Orderer {
   // nonsingular.
   std::vector<uint8_t> gone, claimed;
   std::vector<int32_t> avail;  // # eliminated, unclaimed original neighbours
-  bool forced = false;         // some node had to be eliminated without a partner
+  std::atomic<bool> forced{false};  // some node had to be eliminated without a partner
+  int parallel_depth = 0;
+  size_t parallel_min_nodes = 1500;
 
   Orderer(const Adj& a, const std::vector<uint8_t>& hd, const LdltOptions& o)
       : adj(a), has_diag(hd), opt(o), stamp(a.size(), 0), dist(a.size(), 0),
-        gone(a.size(), 0), claimed(a.size(), 0), avail(a.size(), 0) {}
+        gone(a.size(), 0), claimed(a.size(), 0), avail(a.size(), 0) {
+    unsigned t = SetupPool::get().threads();
+    while (t > 1) {
+      ++parallel_depth;
+      t >>= 1;
+    }
+  }
 
   bool ready(int32_t v) const { return !opt.defer_constraints || has_diag[v] || avail[v] > 0; }
 
-  void eliminate(int32_t v) {
+  void eliminate(int32_t v, std::vector<int32_t>& out) {
     if (opt.defer_constraints && !has_diag[v]) {
       // claim the partner that the fewest other waiting zero-diagonal nodes could use
       int32_t partner = -1, partner_demand = 0;
@@ -59,20 +75,20 @@ struct Orderer {
         }
       }
       if (partner < 0) {
-        forced = true;
+        forced.store(true, std::memory_order_relaxed);
       } else {
         claimed[partner] = 1;
-        for (int32_t u : adj[partner]) --avail[u];
+        for (int32_t u : adj[partner]) __atomic_fetch_sub(&avail[u], 1, __ATOMIC_RELAXED);
       }
     }
     gone[v] = 1;
-    order.push_back(v);
-    for (int32_t u : adj[v]) ++avail[u];
+    out.push_back(v);
+    for (int32_t u : adj[v]) __atomic_fetch_add(&avail[u], 1, __ATOMIC_RELAXED);
   }
 
   // Minimum degree on the subgraph induced by `nodes`; with defer_constraints a
   // zero-diagonal node is only eligible while it has an unclaimed eliminated partner.
-  void min_degree(const std::vector<int32_t>& nodes) {
+  void min_degree(const std::vector<int32_t>& nodes, std::vector<int32_t>& out) {
     const int m = static_cast<int>(nodes.size());
     std::unordered_map<int32_t, int32_t> loc;
     loc.reserve(m * 2);
@@ -94,7 +110,7 @@ struct Orderer {
           if (best < 0 || a[i].size() < a[best].size()) best = i;
         }
       done[best] = 1;
-      eliminate(nodes[best]);
+      eliminate(nodes[best], out);
       for (int32_t u : a[best]) {
         merged.clear();
         std::set_union(a[u].begin(), a[u].end(), a[best].begin(), a[best].end(),
@@ -110,7 +126,7 @@ struct Orderer {
 
   // Separator nodes: variables with a diagonal first, then zero-diagonal nodes as they
   // find partners.
-  void order_separator(std::vector<int32_t> sep) {
+  void order_separator(std::vector<int32_t> sep, std::vector<int32_t>& out) {
     std::sort(sep.begin(), sep.end());
     std::vector<uint8_t> done(sep.size(), 0);
     for (size_t step = 0; step < sep.size(); ++step) {
@@ -122,67 +138,72 @@ struct Orderer {
           if (pass == 0 ? (has_diag[v] != 0) : (pass == 1 ? ready(v) : true)) best = static_cast<int>(i);
         }
       done[best] = 1;
-      eliminate(sep[best]);
+      eliminate(sep[best], out);
     }
   }
 
-  // BFS inside the current subset (marked by stamp == s); returns level lists
-  std::vector<std::vector<int32_t>> bfs_levels(int32_t start, int32_t s) {
-    std::vector<std::vector<int32_t>> levels;
-    std::vector<int32_t> frontier{start};
-    ++cur_stamp;
-    const int32_t visited = cur_stamp;
+  // BFS inside the current subset (marked by stamp == s): the nodes in visiting order, and where each level starts
+  struct Levels {
+    std::vector<int32_t> nodes, ptr;  // level l = nodes[ptr[l] .. ptr[l + 1])
+    size_t size() const { return ptr.size() - 1; }
+    size_t count(size_t l) const { return static_cast<size_t>(ptr[l + 1] - ptr[l]); }
+    const int32_t* begin(size_t l) const { return nodes.data() + ptr[l]; }
+    const int32_t* end(size_t l) const { return nodes.data() + ptr[l + 1]; }
+  };
+  void bfs_levels(int32_t start, int32_t s, size_t expected, Levels& L) {
+    L.nodes.clear();
+    L.ptr.clear();
+    L.nodes.reserve(expected);
+    const int32_t visited = new_stamp();
     dist[start] = visited;
-    while (!frontier.empty()) {
-      levels.push_back(frontier);
-      std::vector<int32_t> next;
-      for (int32_t v : frontier)
-        for (int32_t w : adj[v])
+    L.nodes.push_back(start);
+    L.ptr.push_back(0);
+    size_t lo = 0;
+    while (lo < L.nodes.size()) {
+      const size_t hi = L.nodes.size();
+      L.ptr.push_back(static_cast<int32_t>(hi));
+      for (size_t q = lo; q < hi; ++q)
+        for (int32_t w : adj[L.nodes[q]])
           if (stamp[w] == s && dist[w] != visited) {
             dist[w] = visited;
-            next.push_back(w);
+            L.nodes.push_back(w);
           }
-      frontier.swap(next);
+      lo = hi;
     }
-    return levels;
   }
 
-  void dissect(std::vector<int32_t> nodes) {
+  void dissect(std::vector<int32_t> nodes, std::vector<int32_t>& out, int depth = 0) {
     if (nodes.empty()) return;
     if (static_cast<int>(nodes.size()) <= opt.leaf_size) {
-      min_degree(nodes);
+      min_degree(nodes, out);
       return;
     }
-    ++cur_stamp;
-    const int32_t s = cur_stamp;
+    const int32_t s = new_stamp();
     for (int32_t v : nodes) stamp[v] = s;
     // pseudo-peripheral start: two BFS sweeps
-    auto levels = bfs_levels(nodes[0], s);
-    size_t reached = 0;
-    for (auto& l : levels) reached += l.size();
+    Levels levels;
+    bfs_levels(nodes[0], s, nodes.size(), levels);
+    const size_t reached = levels.nodes.size();
     if (reached < nodes.size()) {
       // disconnected: order each component on its own
       std::vector<int32_t> comp, rest;
-      ++cur_stamp;
-      const int32_t mark = cur_stamp;
-      for (auto& l : levels)
-        for (int32_t v : l) {
-          dist[v] = mark;
-          comp.push_back(v);
-        }
+      const int32_t mark = new_stamp();
+      for (int32_t v : levels.nodes) {
+        dist[v] = mark;
+        comp.push_back(v);
+      }
       for (int32_t v : nodes)
         if (dist[v] != mark) rest.push_back(v);
-      dissect(std::move(comp));
-      dissect(std::move(rest));
+      dissect(std::move(comp), out, depth);
+      dissect(std::move(rest), out, depth);
       return;
     }
     for (int sweep = 0; sweep < 2; ++sweep) {
-      int32_t far = levels.back().front();
-      ++cur_stamp;  // bfs_levels uses cur_stamp for `visited`; keep `s` valid
-      levels = bfs_levels(far, s);
+      const int32_t far = *levels.begin(levels.size() - 1);
+      bfs_levels(far, s, nodes.size(), levels);
     }
     if (levels.size() < 3) {
-      min_degree(nodes);
+      min_degree(nodes, out);
       return;
     }
     // separator level: balance the two sides
@@ -190,21 +211,22 @@ struct Orderer {
     size_t best_gap = total;
     for (size_t m = 0; m + 1 < levels.size(); ++m) {
       if (m >= 1) {
-        size_t left = acc, right = total - acc - levels[m].size();
+        size_t left = acc, right = total - acc - levels.count(m);
         size_t gap = left > right ? left - right : right - left;
         if (gap < best_gap) {
           best_gap = gap;
           best_m = m;
         }
       }
-      acc += levels[m].size();
+      acc += levels.count(m);
     }
     // shrink the separator to the nodes that actually touch the next level
-    ++cur_stamp;
-    const int32_t nextmark = cur_stamp;
-    for (int32_t v : levels[best_m + 1]) dist[v] = nextmark;
+    const int32_t nextmark = new_stamp();
+    for (const int32_t* v = levels.begin(best_m + 1); v != levels.end(best_m + 1); ++v) dist[*v] = nextmark;
     std::vector<int32_t> sep, left, right;
-    for (int32_t v : levels[best_m]) {
+    left.reserve(static_cast<size_t>(levels.ptr[best_m + 1]));
+    for (const int32_t* pv = levels.begin(best_m); pv != levels.end(best_m); ++pv) {
+      const int32_t v = *pv;
       bool touches = false;
       for (int32_t w : adj[v])
         if (stamp[w] == s && dist[w] == nextmark) {
@@ -213,15 +235,36 @@ struct Orderer {
         }
       (touches ? sep : left).push_back(v);
     }
-    for (size_t m = 0; m < best_m; ++m) left.insert(left.end(), levels[m].begin(), levels[m].end());
-    for (size_t m = best_m + 1; m < levels.size(); ++m)
-      right.insert(right.end(), levels[m].begin(), levels[m].end());
+    left.insert(left.end(), levels.nodes.begin(), levels.nodes.begin() + levels.ptr[best_m]);
+    right.assign(levels.nodes.begin() + levels.ptr[best_m + 1], levels.nodes.end());
     std::sort(left.begin(), left.end());
     std::sort(right.begin(), right.end());
-    dissect(std::move(left));
-    dissect(std::move(right));
+    if (std::getenv("SLPX_ND_DEBUG")) std::fprintf(stderr, "nd depth %d: %zu nodes, %zu levels, sep %zu left %zu right %zu\n", depth, nodes.size(), levels.size(), sep.size(), left.size(), right.size());
+    if (depth < parallel_depth && std::min(left.size(), right.size()) >= parallel_min_nodes) {
+      std::vector<int32_t> right_out;
+      std::exception_ptr failed;
+      std::thread other([&] {
+        try {
+          dissect(std::move(right), right_out, depth + 1);
+        } catch (...) {
+          failed = std::current_exception();
+        }
+      });
+      try {
+        dissect(std::move(left), out, depth + 1);
+      } catch (...) {
+        other.join();
+        throw;
+      }
+      other.join();
+      if (failed) std::rethrow_exception(failed);
+      out.insert(out.end(), right_out.begin(), right_out.end());
+    } else {
+      dissect(std::move(left), out, depth);
+      dissect(std::move(right), out, depth);
+    }
     // separator last
-    order_separator(std::move(sep));
+    order_separator(std::move(sep), out);
   }
 };
 
@@ -258,6 +301,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       std::sort(a.begin(), a.end());
       a.erase(std::unique(a.begin(), a.end()), a.end());
     }
+    lap("  ldlt:   adjacency");
     Orderer ord(adj, has_diag, opt);
     // Hubs (LdltOptions::hub_factor) defeat level-set dissection — everything is two steps from
     // everything — so they are taken out of the graph that is dissected and eliminated last.
@@ -272,10 +316,13 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
           std::max<size_t>(opt.hub_floor, static_cast<size_t>(opt.hub_factor * static_cast<double>(median)));
       for (int v = 0; v < n; ++v) (degs[v] > hub_degree ? hubs : rest).push_back(v);
     }
-    ord.dissect(std::move(rest));
-    if (!hubs.empty()) ord.order_separator(std::move(hubs));
+    ord.order.reserve(n);
+    lap("  ldlt:   hubs");
+    ord.dissect(std::move(rest), ord.order);
+    lap("  ldlt:   dissect");
+    if (!hubs.empty()) ord.order_separator(std::move(hubs), ord.order);
     P.perm = std::move(ord.order);
-    ordering_forced = ord.forced;
+    ordering_forced = ord.forced.load();
   }
   if (static_cast<int>(P.perm.size()) != n) throw std::runtime_error("ldlt: bad permutation size");
   P.iperm.assign(n, -1);

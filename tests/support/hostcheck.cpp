@@ -178,6 +178,80 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (std::getenv("SLPX_TAPE_JIT_VERBOSE")) (void)build_tape_templates(h->s.full);
 }
 
+// FNV-1a over every array of the compiled plans: setup refactorings (threads, flat arrays) are checked
+// to leave the plans the same to the byte (tests/test_plans_cpu.py::test_plan_hashes_are_stable).
+namespace {
+struct PlanHash {
+  uint64_t h = 1469598103934665603ull;
+  void bytes(const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  }
+  template <class T> void vec(const std::vector<T>& v) {
+    const uint64_t n = v.size();
+    bytes(&n, sizeof n);
+    if (!v.empty()) bytes(v.data(), v.size() * sizeof(T));
+  }
+  template <class T> void pod(const T& v) { bytes(&v, sizeof v); }
+};
+uint64_t hash_tape(const TapeProgram& P) {
+  PlanHash H;
+  H.pod(P.n_inputs); H.pod(P.n_outputs);
+  H.vec(P.tasks); H.vec(P.small_tasks); H.vec(P.large_tasks); H.vec(P.global_tasks); H.vec(P.leaf_src); H.vec(P.consts);
+  for (auto& pr : P.params) { H.pod(pr.first); H.pod(pr.second); }
+  H.pod(P.shared_tasks);
+  H.vec(P.node_rec); H.vec(P.lvl_ptr); H.vec(P.slot_edge_ptr); H.vec(P.slvl_ptr); H.vec(P.edges);
+  H.vec(P.node_rec16); H.vec(P.slot_edge_ptr16); H.vec(P.edges16);
+  H.vec(P.vout_src); H.vec(P.vout_dst); H.vec(P.vout_scale); H.vec(P.jout_slot); H.vec(P.jout_dst); H.vec(P.jout_scale);
+  H.pod(P.small_lds_bytes); H.pod(P.large_lds_bytes); H.pod(P.global_scratch_doubles);
+  H.pod(P.total_nodes); H.pod(P.total_slots); H.pod(P.total_edges); H.pod(P.total_leaves); H.pod(P.max_levels); H.pod(P.max_slot_levels);
+  return H.h;
+}
+void hash_csc(PlanHash& H, const CscPattern& c) { H.pod(c.rows); H.pod(c.cols); H.vec(c.colptr); H.vec(c.rowidx); }
+}  // namespace
+
+extern "C" void hc_plan_hash(hc_handle* h, uint64_t* out) {
+  {
+    PlanHash H;
+    const NlpStructure& s = h->s;
+    H.pod(s.n); H.pod(s.m_e); H.pod(s.m_i); H.pod(s.nV); H.pod(s.off_g); H.pod(s.off_Ae); H.pod(s.off_Ai); H.pod(s.off_Hf); H.pod(s.off_Hc);
+    hash_csc(H, s.g_pat); hash_csc(H, s.Ae); hash_csc(H, s.Ai); hash_csc(H, s.Hf); hash_csc(H, s.Hc);
+    H.vec(s.V_static_raw); H.vec(s.V_scale_idx); H.vec(s.V_is_static);
+    for (auto& r : s.reduces) H.pod(r);
+    out[0] = H.h;
+  }
+  out[1] = hash_tape(h->s.full);
+  out[2] = hash_tape(h->s.values);
+  {
+    PlanHash H;
+    const KktPlan& k = h->k;
+    hash_csc(H, k.lhs);
+    H.vec(k.dptr); H.vec(k.dsrc); H.vec(k.pptr); H.vec(k.pa); H.vec(k.pb); H.vec(k.pr); H.vec(k.fast_src); H.vec(k.g_src);
+    H.vec(k.ai_rowptr); H.vec(k.ai_col); H.vec(k.ai_src); H.vec(k.ae_rowptr); H.vec(k.ae_col); H.vec(k.ae_src);
+    H.pod(k.assemble_bytes); H.pod(k.rhs_bytes); H.pod(k.nnz_H_union);
+    out[3] = H.h;
+  }
+  {
+    PlanHash H;
+    const LdltPlan& l = h->l;
+    H.pod(l.n); H.pod(l.n_dec); H.vec(l.perm); H.vec(l.iperm); H.vec(l.parent); H.vec(l.Lp); H.vec(l.Li); H.pod(l.nnzL);
+    H.pod(l.etree_height); H.pod(l.n_rounds); H.pod(l.structurally_singular_unregularized);
+    H.vec(l.tasks); H.vec(l.round_ptr); H.pod(l.max_lds_doubles); H.pod(l.max_solve_lds_doubles); H.pod(l.factor_lds_bytes); H.pod(l.solve_lds_bytes);
+    H.vec(l.ent_src); H.vec(l.ent_flags); H.vec(l.ent_col); H.vec(l.ent_out); H.vec(l.ent_pair_ptr); H.vec(l.ent_contrib_ptr);
+    H.vec(l.contrib_idx); H.vec(l.ext_dst); H.vec(l.lvl_ptr); H.vec(l.pairs); H.pod(l.n_contrib);
+    H.vec(l.col_perm); H.vec(l.col_lvl_ptr); H.vec(l.fwd_ptr); H.vec(l.fwd_contrib_ptr); H.vec(l.scontrib_idx); H.vec(l.fwd_items);
+    H.vec(l.sext_ptr); H.vec(l.sext_dst); H.vec(l.sext_items); H.vec(l.bwd_ptr); H.vec(l.bwd_items); H.pod(l.n_scontrib);
+    H.vec(l.sn_desc); H.vec(l.sn_lvl_ptr); H.vec(l.col_sn); H.pod(l.n_supernodes); H.pod(l.widest_supernode); H.pod(l.critical_levels);
+    H.vec(l.sn_width_hist);
+    out[4] = H.h;
+    PlanHash M;
+    M.pod(l.mf); M.vec(l.mf_tasks); M.vec(l.mf_fronts); M.vec(l.mf_lvl_ptr); M.vec(l.mf_tab); M.vec(l.mf_ext); M.vec(l.mf_contrib_ptr);
+    M.vec(l.mf_contrib_idx); M.vec(l.mf_cent); M.vec(l.mf_anc); M.pod(l.mf_n_contrib); M.pod(l.mf_max_nch); M.pod(l.mf_max_front_rows); M.pod(l.mf_n_mfma);
+    M.pod(l.factor_bytes); M.pod(l.solve_bytes); M.pod(l.flops);
+    out[5] = M.h;
+  }
+}
+
 extern "C" {
 void hc_destroy(hc_handle* h) { delete h; }
 

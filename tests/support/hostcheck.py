@@ -52,6 +52,7 @@ def lib():
 
     sig("hc_create", vp, vp, vp, i32, i32, i32)
     sig("hc_destroy", None, vp)
+    sig("hc_plan_hash", None, vp, vp)
     sig("hc_tape_jit_compiles", i32, vp)
     sig("hc_supernodes", None, vp, vp)
     sig("hc_ldlt_tree", None, vp, vp, vp)
@@ -99,6 +100,12 @@ class HostCheck:
         if self._h:
             lib().hc_destroy(self._h)
             self._h = None
+
+    def plan_hash(self):
+        """FNV-1a of [structure, full tape, values tape, KKT plan, LDLT plan, multifrontal plan]"""
+        out = np.zeros(6, dtype=np.uint64)
+        lib().hc_plan_hash(self._h, out.ctypes.data)
+        return [int(v) for v in out]
 
     def tape_jit_compiles(self):
         """Bodies of the run-time generated tape kernel that hipRTC compiled for gfx950 (-1: rejected)."""

@@ -17,7 +17,18 @@ namespace slpx {
 
 namespace {
 
-using Adj = std::vector<std::vector<int32_t>>;
+// the graph of the matrix: neighbours of v = idx[ptr[v] .. ptr[v + 1]), ascending, no duplicates
+struct Adj {
+  std::vector<int32_t> ptr, idx;
+  struct Range {
+    const int32_t *b, *e;
+    const int32_t* begin() const { return b; }
+    const int32_t* end() const { return e; }
+    size_t size() const { return static_cast<size_t>(e - b); }
+  };
+  Range operator[](int32_t v) const { return {idx.data() + ptr[v], idx.data() + ptr[v + 1]}; }
+  size_t size() const { return ptr.size() - 1; }
+};
 
 // ---------------------------------------------------------------------------
 // Ordering: nested dissection with (constrained) minimum-degree leaves
@@ -90,6 +101,43 @@ struct Orderer {
   // zero-diagonal node is only eligible while it has an unclaimed eliminated partner.
   void min_degree(const std::vector<int32_t>& nodes, std::vector<int32_t>& out) {
     const int m = static_cast<int>(nodes.size());
+    if (m <= 64) {
+      // the usual case (a dissection leaf): neighbour sets as bit masks, membership through a stamp of the leaf's own
+      const int32_t s = new_stamp();
+      for (int i = 0; i < m; ++i) {
+        stamp[nodes[i]] = s;
+        dist[nodes[i]] = i;  // (position in the leaf: dist is free once a set is down to a leaf)
+      }
+      uint64_t a[64];
+      for (int i = 0; i < m; ++i) {
+        uint64_t bits = 0;
+        for (int32_t w : adj[nodes[i]])
+          if (stamp[w] == s) bits |= 1ull << dist[w];
+        a[i] = bits;
+      }
+      uint64_t done = 0;
+      for (int step = 0; step < m; ++step) {
+        int best = -1, best_deg = 0;
+        for (int pass = 0; pass < 2 && best < 0; ++pass)
+          for (int i = 0; i < m; ++i) {
+            if (((done >> i) & 1) || (pass == 0 && !ready(nodes[i]))) continue;
+            const int deg = __builtin_popcountll(a[i]);
+            if (best < 0 || deg < best_deg) {
+              best = i;
+              best_deg = deg;
+            }
+          }
+        done |= 1ull << best;
+        eliminate(nodes[best], out);
+        const uint64_t nb = a[best];
+        for (uint64_t rest = nb; rest != 0; rest &= rest - 1) {
+          const int u = __builtin_ctzll(rest);
+          a[u] = (a[u] | nb) & ~((1ull << u) | (1ull << best));
+        }
+        a[best] = 0;
+      }
+      return;
+    }
     std::unordered_map<int32_t, int32_t> loc;
     loc.reserve(m * 2);
     for (int i = 0; i < m; ++i) loc[nodes[i]] = i;
@@ -288,18 +336,47 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   if (user_perm != nullptr && !user_perm->empty()) {
     P.perm = *user_perm;
   } else {
-    Adj adj(n);
-    for (int c = 0; c < n; ++c)
-      for (int p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
-        int r = lower.rowidx[p];
-        if (r != c) {
-          adj[r].push_back(c);
-          adj[c].push_back(r);
+    Adj adj;
+    {
+      // (the pattern holds each pair once, below the diagonal: no duplicates to remove)
+      adj.ptr.assign(n + 1, 0);
+      for (int c = 0; c < n; ++c)
+        for (int p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
+          const int r = lower.rowidx[p];
+          if (r != c) {
+            ++adj.ptr[r + 1];
+            ++adj.ptr[c + 1];
+          }
         }
+      for (int v = 0; v < n; ++v) adj.ptr[v + 1] += adj.ptr[v];
+      adj.idx.resize(adj.ptr[n]);
+      std::vector<int32_t> next(adj.ptr.begin(), adj.ptr.end() - 1);
+      for (int c = 0; c < n; ++c)
+        for (int p = lower.colptr[c]; p < lower.colptr[c + 1]; ++p) {
+          const int r = lower.rowidx[p];
+          if (r != c) {
+            adj.idx[next[r]++] = c;
+            adj.idx[next[c]++] = r;
+          }
+        }
+      bool dup = false;
+      for (int v = 0; v < n; ++v) {
+        int32_t* b = adj.idx.data() + adj.ptr[v];
+        int32_t* e = adj.idx.data() + adj.ptr[v + 1];
+        if (!std::is_sorted(b, e)) std::sort(b, e);
+        dup = dup || std::adjacent_find(b, e) != e;
       }
-    for (auto& a : adj) {
-      std::sort(a.begin(), a.end());
-      a.erase(std::unique(a.begin(), a.end()), a.end());
+      if (dup) {  // (a pattern that names an entry twice: compact the lists)
+        std::vector<int32_t> ptr2(n + 1, 0), idx2;
+        for (int v = 0; v < n; ++v) {
+          int32_t* b = adj.idx.data() + adj.ptr[v];
+          int32_t* e = std::unique(b, adj.idx.data() + adj.ptr[v + 1]);
+          idx2.insert(idx2.end(), b, e);
+          ptr2[v + 1] = static_cast<int32_t>(idx2.size());
+        }
+        adj.ptr.swap(ptr2);
+        adj.idx.swap(idx2);
+      }
     }
     lap("  ldlt:   adjacency");
     Orderer ord(adj, has_diag, opt);
@@ -379,23 +456,40 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     for (int round = 0; round < 8; ++round) {
       // the chains as they stand (exact structure), their levels
       std::vector<int32_t> sn(n, -1);
-      std::vector<std::vector<int32_t>> cols;
+      std::vector<int32_t> chain_ptr{0}, chain_cols;  // chain c = chain_cols[chain_ptr[c] .. chain_ptr[c + 1])
+      chain_cols.reserve(n);
       for (int j = 0; j < n; ++j) {
         if (sn[j] >= 0) continue;
-        sn[j] = static_cast<int32_t>(cols.size());
-        std::vector<int32_t> chain{j};
+        const int32_t id = static_cast<int32_t>(chain_ptr.size()) - 1;
+        sn[j] = id;
+        chain_cols.push_back(j);
+        size_t len = 1;
         int32_t k = j;
-        while (chain.size() < opt.max_supernode_width) {
+        while (len < opt.max_supernode_width) {
           const int32_t p = P.parent[k];
           if (p < 0 || sn[p] >= 0 || Lcol[k].size() != Lcol[p].size() + 1 ||
-              chain.size() + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
+              len + 1 + Lcol[p].size() + 1 > opt.max_front_rows)
             break;
-          sn[p] = sn[j];
-          chain.push_back(p);
+          sn[p] = id;
+          chain_cols.push_back(p);
+          ++len;
           k = p;
         }
-        cols.push_back(std::move(chain));
+        chain_ptr.push_back(static_cast<int32_t>(chain_cols.size()));
       }
+      struct ChainView {
+        const int32_t *b, *e;
+        size_t size() const { return static_cast<size_t>(e - b); }
+        int32_t operator[](size_t i) const { return b[i]; }
+        int32_t back() const { return e[-1]; }
+        const int32_t* begin() const { return b; }
+        const int32_t* end() const { return e; }
+      };
+      struct ChainList {
+        const std::vector<int32_t>&ptr, &col;
+        size_t size() const { return ptr.size() - 1; }
+        ChainView operator[](size_t c) const { return {col.data() + ptr[c], col.data() + ptr[c + 1]}; }
+      } cols{chain_ptr, chain_cols};
       std::vector<int32_t> lvl(cols.size(), 0);
       for (int j = 0; j < n; ++j)
         for (int32_t c : children[j])
@@ -407,12 +501,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       int merged = 0;
       for (int32_t s : by_level) {
         if (used[s]) continue;
-        const auto& ch = cols[s];
+        const ChainView ch = cols[s];
         const int32_t p = P.parent[ch.back()];
         if (p < 0) continue;
         const int32_t J = sn[p];
         if (used[J] || cols[J][0] != p || lvl[s] + 1 < lvl[J]) continue;  // joins at the head, deepest child only
-        const auto& cj = cols[J];
+        const ChainView cj = cols[J];
         const size_t below = cj.size() + Lcol[cj.back()].size();  // rows under the joining columns
         if (ch.size() + cj.size() > opt.max_supernode_width || ch.size() + below + 1 > opt.max_front_rows) continue;
         int64_t zeros = 0;
@@ -662,17 +756,56 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     task_nent[t] = e;
     if (e > 65535u) throw std::runtime_error("ldlt: task exceeds 16-bit local indexing");
   }
-  // pair lists per (task, local entry) and pseudo entries per task
-  std::vector<std::vector<std::vector<LdltPair>>> epairs(ntasks);
-  for (int t = 0; t < ntasks; ++t) epairs[t].resize(task_nent[t]);
-  struct Ext {
-    uint32_t dst;  // contribution slot
-    std::vector<LdltPair> pairs;
-  };
-  std::vector<std::vector<Ext>> exts(ntasks);
-  std::vector<std::unordered_map<uint64_t, uint32_t>> ext_map(ntasks);
-  std::vector<std::vector<std::vector<uint32_t>>> econtrib(ntasks);
-  for (int t = 0; t < ntasks; ++t) econtrib[t].resize(task_nent[t]);
+  // Pair lists per entry, pseudo entries (update blocks for other tasks) per task, update slots per receiving
+  // entry — as flat arrays (nested vectors of vectors were most of this pass: a million small allocations at
+  // N=5000).  Entries are numbered globally, task by task: ge = task_ent_base[t] + local entry.
+  std::vector<uint32_t> task_ent_base(ntasks + 1, 0);
+  for (int t = 0; t < ntasks; ++t) task_ent_base[t + 1] = task_ent_base[t] + task_nent[t];
+  const uint32_t total_ent = task_ent_base[ntasks];
+  // (bucket, pair) in the order the pairs are found; a stable counting sort by bucket afterwards
+  std::vector<std::pair<uint32_t, LdltPair>> own_found, ext_found;
+  own_found.reserve(static_cast<size_t>(P.nnzL) * 4);
+  // a pseudo entry = (source task, receiving entry): numbered in the order of their first pair, which is also
+  // their slot in the contribution buffer
+  std::vector<uint32_t> ext_task, ext_target;  // by slot: source task, receiving entry (global)
+  struct SlotTable {  // open addressing, key = source task << 32 | receiving entry
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> vals;
+    size_t used = 0, mask = 0;
+    SlotTable() { grow(1u << 12); }
+    void grow(size_t cap) {
+      std::vector<uint64_t> ok;
+      std::vector<uint32_t> ov;
+      ok.swap(keys);
+      ov.swap(vals);
+      keys.assign(cap, ~0ull);
+      vals.assign(cap, 0);
+      mask = cap - 1;
+      for (size_t i = 0; i < ok.size(); ++i)
+        if (ok[i] != ~0ull) *find(ok[i]).second = ov[i];
+    }
+    static uint64_t mix(uint64_t k) {
+      k ^= k >> 33;
+      k *= 0xff51afd7ed558ccdull;
+      k ^= k >> 33;
+      return k;
+    }
+    // (is new, where its value lives)
+    std::pair<bool, uint32_t*> find(uint64_t key) {
+      size_t i = mix(key) & mask;
+      while (keys[i] != ~0ull && keys[i] != key) i = (i + 1) & mask;
+      const bool fresh = keys[i] == ~0ull;
+      keys[i] = key;
+      return {fresh, &vals[i]};
+    }
+    uint32_t* insert(uint64_t key, bool& fresh) {
+      if (2 * (used + 1) > keys.size()) grow(2 * keys.size());
+      auto r = find(key);
+      fresh = r.first;
+      used += fresh;
+      return r.second;
+    }
+  } slots;
 
   for (int k = 0; k < n; ++k) {
     const int tk = task_of[k];
@@ -683,21 +816,20 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       const int tj = task_of[j];
       const uint32_t ent_jk = lent[P.Lp[k] + a];
       // updates between two columns of one supernode are done in registers (ldlt_kernels.h)
-      const bool in_chain = sn_of[k] == sn_of[j];
+      if (sn_of[k] == sn_of[j]) continue;
+      const uint32_t base_j = task_ent_base[tj];
       auto add_pair = [&](uint32_t target, const LdltPair& pr) {
-        if (in_chain) return;
         if (tk == tj) {
-          epairs[tj][target].push_back(pr);
+          own_found.emplace_back(base_j + target, pr);
         } else {
-          uint64_t key = (static_cast<uint64_t>(tj) << 32) | target;
-          auto it = ext_map[tk].find(key);
-          if (it == ext_map[tk].end()) {
-            it = ext_map[tk].emplace(key, static_cast<uint32_t>(exts[tk].size())).first;
-            exts[tk].push_back({P.n_contrib, {}});
-            econtrib[tj][target].push_back(P.n_contrib);
-            ++P.n_contrib;
+          bool fresh;
+          uint32_t* slot = slots.insert((static_cast<uint64_t>(tk) << 32) | (base_j + target), fresh);
+          if (fresh) {
+            *slot = P.n_contrib++;
+            ext_task.push_back(static_cast<uint32_t>(tk));
+            ext_target.push_back(base_j + target);
           }
-          exts[tk][it->second].pairs.push_back(pr);
+          ext_found.emplace_back(*slot, pr);
         }
       };
       // rhs row: U_b(j) -= U_b(k) · U(j,k) / d_k
@@ -719,37 +851,78 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       }
     }
   }
+  // stable counting sorts: pairs of an entry / of a pseudo entry in the order they were found
+  auto sort_pairs = [](const std::vector<std::pair<uint32_t, LdltPair>>& found, size_t buckets, std::vector<uint32_t>& ptr,
+                       std::vector<LdltPair>& out) {
+    ptr.assign(buckets + 1, 0);
+    for (auto& f : found) ++ptr[f.first + 1];
+    for (size_t i = 0; i < buckets; ++i) ptr[i + 1] += ptr[i];
+    out.resize(found.size());
+    std::vector<uint32_t> next(ptr.begin(), ptr.end() - 1);
+    for (auto& f : found) out[next[f.first]++] = f.second;
+  };
+  std::vector<uint32_t> own_ptr, extp_ptr;
+  std::vector<LdltPair> own_pairs, extp;
+  sort_pairs(own_found, total_ent, own_ptr, own_pairs);
+  sort_pairs(ext_found, P.n_contrib, extp_ptr, extp);
+  own_found = {};
+  ext_found = {};
+  // the pseudo entries of a task (ascending slot = the order they were made in); the slots an entry takes
+  std::vector<uint32_t> task_ext_ptr(ntasks + 1, 0), task_ext(P.n_contrib), ec_ptr(total_ent + 1, 0), ec(P.n_contrib);
+  for (uint32_t d = 0; d < P.n_contrib; ++d) {
+    ++task_ext_ptr[ext_task[d] + 1];
+    ++ec_ptr[ext_target[d] + 1];
+  }
+  for (int t = 0; t < ntasks; ++t) task_ext_ptr[t + 1] += task_ext_ptr[t];
+  for (uint32_t e = 0; e < total_ent; ++e) ec_ptr[e + 1] += ec_ptr[e];
+  {
+    std::vector<uint32_t> tn(task_ext_ptr.begin(), task_ext_ptr.end() - 1), en(ec_ptr.begin(), ec_ptr.end() - 1);
+    for (uint32_t d = 0; d < P.n_contrib; ++d) {
+      task_ext[tn[ext_task[d]]++] = d;
+      ec[en[ext_target[d]]++] = d;
+    }
+  }
 
   lap("  ldlt: entries, pair lists");
   // ---- solve lists ---------------------------------------------------------------
   // rows of L (CSR view): for row i the entries (i,k), k ascending
-  std::vector<std::vector<std::pair<uint32_t, int32_t>>> Lrow(n);  // (lpos, k)
-  for (int k = 0; k < n; ++k)
-    for (int32_t p = P.Lp[k]; p < P.Lp[k + 1]; ++p) Lrow[P.Li[p]].emplace_back(p, k);
-  struct SExt {
-    uint32_t dst;
-    std::vector<LdltSolveItem> items;
-  };
-  std::vector<std::vector<SExt>> sexts(ntasks);
-  std::vector<std::unordered_map<int32_t, uint32_t>> sext_map(ntasks);
-  std::vector<std::vector<LdltSolveItem>> fwd(n), bwd(n);
-  std::vector<std::vector<uint32_t>> fcontrib(n);
+  std::vector<int32_t> Lrow_ptr(n + 1, 0);
+  for (int32_t p = 0; p < P.nnzL; ++p) ++Lrow_ptr[P.Li[p] + 1];
+  for (int i = 0; i < n; ++i) Lrow_ptr[i + 1] += Lrow_ptr[i];
+  std::vector<std::pair<uint32_t, int32_t>> Lrow(static_cast<size_t>(P.nnzL));  // (lpos, k)
+  {
+    std::vector<int32_t> next(Lrow_ptr.begin(), Lrow_ptr.end() - 1);
+    for (int k = 0; k < n; ++k)
+      for (int32_t p = P.Lp[k]; p < P.Lp[k + 1]; ++p) Lrow[next[P.Li[p]]++] = {static_cast<uint32_t>(p), k};
+  }
+  // forward items of a column (same-task columns outside its supernode, then its chain), backward items (its
+  // column of L), the pseudo rows a task computes for rows of other tasks: (source task, row), numbered in the
+  // order they are first needed — their slot in the solve's contribution buffer
+  std::vector<uint32_t> fwd_all_ptr(n + 1, 0), bwd_all_ptr(n + 1, 0);
+  std::vector<LdltSolveItem> fwd_all, bwd_all;
+  fwd_all.reserve(static_cast<size_t>(P.nnzL));
+  bwd_all.reserve(static_cast<size_t>(P.nnzL));
+  std::vector<std::pair<uint32_t, LdltSolveItem>> sext_found;
+  std::vector<uint32_t> sext_task, sext_row;  // by slot
+  SlotTable sslots;
   for (int j = 0; j < n; ++j) {
     const int tj = task_of[j];
-    for (auto& [lpos, k] : Lrow[j]) {
+    for (int32_t q = Lrow_ptr[j]; q < Lrow_ptr[j + 1]; ++q) {
+      const uint32_t lpos = Lrow[q].first;
+      const int32_t k = Lrow[q].second;
       const int tk = task_of[k];
       LdltSolveItem it{lpos, static_cast<uint32_t>(lcol[k])};
       if (tk == tj) {
-        if (sn_of[k] != sn_of[j]) fwd[j].push_back(it);  // the chain's own columns follow below
+        if (sn_of[k] != sn_of[j]) fwd_all.push_back(it);  // the chain's own columns follow below
       } else {
-        auto f = sext_map[tk].find(j);
-        if (f == sext_map[tk].end()) {
-          f = sext_map[tk].emplace(j, static_cast<uint32_t>(sexts[tk].size())).first;
-          sexts[tk].push_back({P.n_scontrib, {}});
-          fcontrib[j].push_back(P.n_scontrib);
-          ++P.n_scontrib;
+        bool fresh;
+        uint32_t* slot = sslots.insert((static_cast<uint64_t>(tk) << 32) | static_cast<uint32_t>(j), fresh);
+        if (fresh) {
+          *slot = P.n_scontrib++;
+          sext_task.push_back(static_cast<uint32_t>(tk));
+          sext_row.push_back(static_cast<uint32_t>(j));
         }
-        sexts[tk][f->second].items.push_back(it);
+        sext_found.emplace_back(*slot, it);
       }
     }
     // row j against the earlier columns of its own supernode: the LAST sn_pos[j] items, chain order
@@ -759,13 +932,38 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       const int32_t* e = P.Li.data() + P.Lp[k + 1];
       const int32_t* f = std::lower_bound(b, e, j);
       if (f == e || *f != j) throw std::runtime_error("ldlt: supernode column lacks a chain row");
-      fwd[j].push_back({static_cast<uint32_t>(f - P.Li.data()), static_cast<uint32_t>(lcol[k])});
+      fwd_all.push_back({static_cast<uint32_t>(f - P.Li.data()), static_cast<uint32_t>(lcol[k])});
     }
+    fwd_all_ptr[j + 1] = static_cast<uint32_t>(fwd_all.size());
     for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
       int32_t i = P.Li[p];
       uint32_t ref = task_of[i] == tj ? static_cast<uint32_t>(lcol[i])
                                       : (0x80000000u | static_cast<uint32_t>(i));
-      bwd[j].push_back({static_cast<uint32_t>(p), ref});
+      bwd_all.push_back({static_cast<uint32_t>(p), ref});
+    }
+    bwd_all_ptr[j + 1] = static_cast<uint32_t>(bwd_all.size());
+  }
+  std::vector<uint32_t> sext_item_ptr(P.n_scontrib + 1, 0);
+  std::vector<LdltSolveItem> sext_item(sext_found.size());
+  for (auto& f : sext_found) ++sext_item_ptr[f.first + 1];
+  for (uint32_t d = 0; d < P.n_scontrib; ++d) sext_item_ptr[d + 1] += sext_item_ptr[d];
+  {
+    std::vector<uint32_t> next(sext_item_ptr.begin(), sext_item_ptr.end() - 1);
+    for (auto& f : sext_found) sext_item[next[f.first]++] = f.second;
+  }
+  sext_found = {};
+  std::vector<uint32_t> task_sext_ptr(ntasks + 1, 0), task_sext(P.n_scontrib), fc_ptr(n + 1, 0), fc(P.n_scontrib);
+  for (uint32_t d = 0; d < P.n_scontrib; ++d) {
+    ++task_sext_ptr[sext_task[d] + 1];
+    ++fc_ptr[sext_row[d] + 1];
+  }
+  for (int t = 0; t < ntasks; ++t) task_sext_ptr[t + 1] += task_sext_ptr[t];
+  for (int j = 0; j < n; ++j) fc_ptr[j + 1] += fc_ptr[j];
+  {
+    std::vector<uint32_t> tn(task_sext_ptr.begin(), task_sext_ptr.end() - 1), jn(fc_ptr.begin(), fc_ptr.end() - 1);
+    for (uint32_t d = 0; d < P.n_scontrib; ++d) {
+      task_sext[tn[sext_task[d]]++] = d;
+      fc[jn[sext_row[d]]++] = d;
     }
   }
 
@@ -815,7 +1013,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     T.round = static_cast<uint32_t>(tcols[t].round);
     T.n_col = static_cast<uint32_t>(cols.size());
     T.n_ent = task_nent[t];
-    T.n_ext = static_cast<uint32_t>(exts[t].size());
+    T.n_ext = task_ext_ptr[t + 1] - task_ext_ptr[t];
     T.ent_off = static_cast<uint32_t>(P.ent_src.size());
     T.col_off = static_cast<uint32_t>(P.col_perm.size());
     T.lvl_off = static_cast<uint32_t>(P.lvl_ptr.size());
@@ -825,7 +1023,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     T.fwd_item_off = static_cast<uint32_t>(P.fwd_items.size());
     T.bwd_item_off = static_cast<uint32_t>(P.bwd_items.size());
     T.sext_off = static_cast<uint32_t>(P.sext_dst.size());
-    T.n_sext = static_cast<uint32_t>(sexts[t].size());
+    T.n_sext = task_sext_ptr[t + 1] - task_sext_ptr[t];
     T.sext_item_off = static_cast<uint32_t>(P.sext_items.size());
     T.scontrib_off = static_cast<uint32_t>(P.scontrib_idx.size());
     T.pair_ptr_off = static_cast<uint32_t>(P.ent_pair_ptr.size());
@@ -863,10 +1061,11 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         P.ent_out.push_back(out);
         P.ent_pair_ptr.push_back(pair_count);
         P.ent_contrib_ptr.push_back(contrib_count);
-        for (auto& pr : epairs[t][le]) P.pairs.push_back(pr);
-        pair_count += static_cast<uint32_t>(epairs[t][le].size());
-        for (uint32_t cidx : econtrib[t][le]) P.contrib_idx.push_back(cidx);
-        contrib_count += static_cast<uint32_t>(econtrib[t][le].size());
+        const uint32_t ge = task_ent_base[t] + le;
+        P.pairs.insert(P.pairs.end(), own_pairs.begin() + own_ptr[ge], own_pairs.begin() + own_ptr[ge + 1]);
+        pair_count += own_ptr[ge + 1] - own_ptr[ge];
+        P.contrib_idx.insert(P.contrib_idx.end(), ec.begin() + ec_ptr[ge], ec.begin() + ec_ptr[ge + 1]);
+        contrib_count += ec_ptr[ge + 1] - ec_ptr[ge];
       };
       const bool gamma_kind = P.perm[j] >= n_dec;
       // bit 3: entry of the diagonal block of a supernode with w >= 2 — finished (and written
@@ -888,14 +1087,14 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       emit_entry(bent[j], P.perm[j], 4, static_cast<uint32_t>(j));
       // solve lists
       P.fwd_ptr.push_back(fwd_count);
-      for (auto& it : fwd[j]) P.fwd_items.push_back(it);
-      fwd_count += static_cast<uint32_t>(fwd[j].size());
+      P.fwd_items.insert(P.fwd_items.end(), fwd_all.begin() + fwd_all_ptr[j], fwd_all.begin() + fwd_all_ptr[j + 1]);
+      fwd_count += fwd_all_ptr[j + 1] - fwd_all_ptr[j];
       P.fwd_contrib_ptr.push_back(sc_count);
-      for (uint32_t cidx : fcontrib[j]) P.scontrib_idx.push_back(cidx);
-      sc_count += static_cast<uint32_t>(fcontrib[j].size());
+      P.scontrib_idx.insert(P.scontrib_idx.end(), fc.begin() + fc_ptr[j], fc.begin() + fc_ptr[j + 1]);
+      sc_count += fc_ptr[j + 1] - fc_ptr[j];
       P.bwd_ptr.push_back(bwd_count);
-      for (auto& it : bwd[j]) P.bwd_items.push_back(it);
-      bwd_count += static_cast<uint32_t>(bwd[j].size());
+      P.bwd_items.insert(P.bwd_items.end(), bwd_all.begin() + bwd_all_ptr[j], bwd_all.begin() + bwd_all_ptr[j + 1]);
+      bwd_count += bwd_all_ptr[j + 1] - bwd_all_ptr[j];
     }
     P.lvl_ptr.push_back(T.n_ent);
     P.col_lvl_ptr.push_back(T.n_col);
@@ -903,11 +1102,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     T.n_sn = static_cast<uint32_t>(P.sn_desc.size()) - T.sn_off;
     P.sn_lvl_ptr.push_back(T.n_sn);
     // pseudo entries continue the pair_ptr array
-    for (auto& ex : exts[t]) {
-      P.ext_dst.push_back(ex.dst);
+    for (uint32_t q = task_ext_ptr[t]; q < task_ext_ptr[t + 1]; ++q) {
+      const uint32_t d = task_ext[q];
+      P.ext_dst.push_back(d);
       P.ent_pair_ptr.push_back(pair_count);
-      for (auto& pr : ex.pairs) P.pairs.push_back(pr);
-      pair_count += static_cast<uint32_t>(ex.pairs.size());
+      P.pairs.insert(P.pairs.end(), extp.begin() + extp_ptr[d], extp.begin() + extp_ptr[d + 1]);
+      pair_count += extp_ptr[d + 1] - extp_ptr[d];
     }
     P.ent_pair_ptr.push_back(pair_count);
     n_real_pairs += pair_count;
@@ -921,11 +1121,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     P.fwd_contrib_ptr.push_back(sc_count);
     P.bwd_ptr.push_back(bwd_count);
     uint32_t sitem = 0;
-    for (auto& sx : sexts[t]) {
-      P.sext_dst.push_back(sx.dst);
+    for (uint32_t q = task_sext_ptr[t]; q < task_sext_ptr[t + 1]; ++q) {
+      const uint32_t d = task_sext[q];
+      P.sext_dst.push_back(d);
       P.sext_ptr.push_back(sitem);
-      for (auto& it : sx.items) P.sext_items.push_back(it);
-      sitem += static_cast<uint32_t>(sx.items.size());
+      P.sext_items.insert(P.sext_items.end(), sext_item.begin() + sext_item_ptr[d], sext_item.begin() + sext_item_ptr[d + 1]);
+      sitem += sext_item_ptr[d + 1] - sext_item_ptr[d];
     }
     P.sext_ptr.push_back(sitem);
     P.max_lds_doubles = std::max(P.max_lds_doubles, T.n_ent + T.n_col);
@@ -1030,8 +1231,10 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       });
     }
     // update slots between tasks: one per entry of a root front's block
-    std::vector<std::vector<std::vector<uint32_t>>> mcontrib(ntasks);
-    for (int t = 0; t < ntasks; ++t) mcontrib[t].resize(task_nent[t]);
+    std::vector<std::pair<uint32_t, uint32_t>> mc_found;  // (receiving entry, global; slot) in slot order
+    std::vector<uint16_t> cell_vals;  // per front: the children's values of every table cell, `kids` slots a cell
+    std::vector<uint8_t> cell_cnt;
+    std::vector<uint32_t> to;
     auto entry_of = [&](int32_t row, int32_t col) -> uint32_t {  // row = -1: the right-hand-side row
       if (row == col) return diag_ent[col];
       if (row < 0) return bent[col];
@@ -1107,12 +1310,15 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         const uint32_t w = static_cast<uint32_t>(f.cols.size()), r = static_cast<uint32_t>(f.R.size()), nr = f.nr;
         const uint32_t base0 = diag_ent[f.cols[0]];
         auto tr = [&](uint32_t c, uint32_t row) { return base0 + c * nr - (c * (c - 1)) / 2 + (row - c); };
-        // where the rows of each child land in this front
-        std::vector<std::vector<uint16_t>> piv(static_cast<size_t>(nr) * w), upd(f.n_s);
+        // where the rows of each child land in this front (a child's block has at most one value for a cell:
+        // the cells' lists are the children's values in child order)
+        const size_t n_kids = f.kids.size(), n_piv = static_cast<size_t>(nr) * w, n_cells = n_piv + f.n_s;
+        cell_cnt.assign(n_cells, 0);
+        if (cell_vals.size() < n_cells * n_kids) cell_vals.resize(n_cells * n_kids);
         for (int ki : f.kids) {
           const Front& k = fronts[ki];
           const uint32_t rk = static_cast<uint32_t>(k.R.size());
-          std::vector<uint32_t> to(rk + 1);
+          to.resize(rk + 1);
           for (uint32_t a = 0; a < rk; ++a) {
             const int32_t i = k.R[a];
             auto ic = std::lower_bound(f.cols.begin(), f.cols.end(), i);
@@ -1129,17 +1335,25 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
             for (uint32_t b = 0; b < rk && b <= a; ++b) {
               const uint32_t ta = to[a], tb = to[b];
               const uint16_t src = s_addr(k, a * (a + 1) / 2 + b);
-              if (tb < w) piv[static_cast<size_t>(ta) * w + tb].push_back(src);
-              else upd[(ta - w) * (ta - w + 1) / 2 + (tb - w)].push_back(src);
+              const size_t cell = tb < w ? static_cast<size_t>(ta) * w + tb : n_piv + (ta - w) * (ta - w + 1) / 2 + (tb - w);
+              if (cell_cnt[cell] == 255 || cell_cnt[cell] >= n_kids) {
+                ok = false;
+                break;
+              }
+              cell_vals[cell * n_kids + cell_cnt[cell]++] = src;
             }
         }
+        if (!ok) break;
         uint32_t nch = 0;
-        for (auto& v : piv) nch = std::max<uint32_t>(nch, static_cast<uint32_t>(v.size()));
-        for (auto& v : upd) nch = std::max<uint32_t>(nch, static_cast<uint32_t>(v.size()));
-        if (nch > 255u) {
-          ok = false;
-          break;
-        }
+        for (size_t c = 0; c < n_cells; ++c) nch = std::max<uint32_t>(nch, cell_cnt[c]);
+        auto piv_at = [&](uint32_t row, uint32_t c, uint32_t kk) {
+          const size_t cell = static_cast<size_t>(row) * w + c;
+          return kk < cell_cnt[cell] ? cell_vals[cell * n_kids + kk] : kZero;
+        };
+        auto upd_at = [&](uint32_t e, uint32_t kk) {
+          const size_t cell = n_piv + e;
+          return kk < cell_cnt[cell] ? cell_vals[cell * n_kids + kk] : kZero;
+        };
         LdltFront F{};
         F.tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
         F.base0 = static_cast<uint16_t>(base0);
@@ -1165,7 +1379,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
             for (uint32_t c = 0; c < w; ++c) {
               uint16_t v;
               if (k == 0) v = row >= c ? u_addr(tr(c, row)) : kScratch;
-              else v = (row >= c && k - 1 < piv[static_cast<size_t>(row) * w + c].size()) ? piv[static_cast<size_t>(row) * w + c][k - 1] : kZero;
+              else v = row >= c ? piv_at(row, c, k - 1) : kZero;
               P.mf_tab.push_back(v);
             }
         // update table: out, U(a, 0), U(b, 0), children
@@ -1175,12 +1389,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
             P.mf_tab.push_back(root ? static_cast<uint16_t>(e) : s_addr(f, e));
             P.mf_tab.push_back(u_addr(tr(0, w + a)));
             P.mf_tab.push_back(u_addr(tr(0, w + b)));
-            for (uint32_t k = 0; k < nch; ++k) P.mf_tab.push_back(k < upd[e].size() ? upd[e][k] : kZero);
+            for (uint32_t k = 0; k < nch; ++k) P.mf_tab.push_back(upd_at(e, k));
             if (root) {
               const int32_t gb = f.R[b], ga = a < r ? f.R[a] : -1;
               const int tj = task_of[gb];
               const uint32_t slot = P.mf_n_contrib++;
-              mcontrib[tj][entry_of(ga, gb)].push_back(slot);
+              mc_found.emplace_back(task_ent_base[tj] + entry_of(ga, gb), slot);
               P.mf_ext.push_back(slot);
               ++n_ext;
             }
@@ -1208,6 +1422,13 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       while (P.mf_fronts.size() % 1) P.mf_fronts.push_back(LdltFront{});
     }
     // update slots per receiving entry (the tasks' entries are numbered in emission order)
+    std::vector<uint32_t> mc_ptr(total_ent + 1, 0), mc(mc_found.size());
+    for (auto& f : mc_found) ++mc_ptr[f.first + 1];
+    for (uint32_t e = 0; e < total_ent; ++e) mc_ptr[e + 1] += mc_ptr[e];
+    {
+      std::vector<uint32_t> next(mc_ptr.begin(), mc_ptr.end() - 1);
+      for (auto& f : mc_found) mc[next[f.first]++] = f.second;
+    }
     for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
       const int t = torder[ti];
       LdltMfTask& M = P.mf_tasks[ti];
@@ -1218,11 +1439,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       M.cent_off = static_cast<uint32_t>(P.mf_cent.size());
       uint32_t count = 0, n_cent = 0;
       for (uint32_t e = 0; e < task_nent[t]; ++e) {
-        if (mcontrib[t][e].empty()) continue;
+        const uint32_t ge = task_ent_base[t] + e;
+        if (mc_ptr[ge + 1] == mc_ptr[ge]) continue;
         P.mf_cent.push_back(static_cast<uint16_t>(e));
         P.mf_contrib_ptr.push_back(count);
-        for (uint32_t s : mcontrib[t][e]) P.mf_contrib_idx.push_back(s);
-        count += static_cast<uint32_t>(mcontrib[t][e].size());
+        P.mf_contrib_idx.insert(P.mf_contrib_idx.end(), mc.begin() + mc_ptr[ge], mc.begin() + mc_ptr[ge + 1]);
+        count += mc_ptr[ge + 1] - mc_ptr[ge];
         ++n_cent;
       }
       P.mf_contrib_ptr.push_back(count);

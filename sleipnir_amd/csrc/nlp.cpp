@@ -1,6 +1,7 @@
 #include "nlp.hpp"
 
 #include "setup_timing.hpp"
+#include "setup_threads.hpp"
 
 #include <unordered_map>
 
@@ -58,9 +59,7 @@ void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, std::vector<d
 
 // Row visits of build_matrix: a stamp per graph node (which row saw it last) and a stack, shared by the five matrices.
 struct RowVisit {
-  std::vector<int32_t> seen, col;  // col: the column of a wrt node, -1 otherwise (Graph::scratch is topological_sort's)
-  std::vector<NodeId> stack;
-  int32_t stamp = 0;
+  std::vector<int32_t> col;  // the column of a wrt node, -1 otherwise (Graph::scratch is topological_sort's)
 };
 
 MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::vector<NodeId>& wrt,
@@ -71,67 +70,107 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
   // only the SET of wrt nodes it reaches is needed here (the tape compiler makes its own lists): one marking walk,
   // every node of the row touched once — the lists of all rows of a Hessian were 1.2 million entries at N=1000.
   if (adj_scratch.size() < g.size()) adj_scratch.resize(g.size(), 0.0);
-  if (visit.seen.size() < g.size()) visit.seen.resize(g.size(), -1);
   if (visit.col.size() < g.size()) visit.col.resize(g.size(), -1);
   std::vector<int32_t>& col_of = visit.col;
   for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = static_cast<int32_t>(c);
-  std::vector<std::pair<int32_t, NodeId>> outs;
+  // the rows in chunks on the setup threads (a walk only reads the graph; every chunk has its own marks): the
+  // entries of a chunk in row order, the chunks one after the other — the order a single thread finds them in
+  struct Chunk {
+    std::vector<RowEntry> entries;
+    std::vector<int32_t> nonlinear_rows;
+    int linear_rows = 0;
+  };
+  const unsigned n_chunks = std::max(1u, parallel_chunk_count(rows.size(), 256));
+  std::vector<Chunk> chunks(n_chunks);
+  // LINEAR rows first, on this thread: their sort uses the graph's own scratch marks and refreshes node values
+  std::vector<std::vector<RowEntry>> linear_entries;  // per linear row, in row order
+  std::vector<int32_t> linear_row_index;
   for (size_t r = 0; r < rows.size(); ++r) {
-    if (rows[r] == kNull) continue;
-    const uint8_t t = g.type[rows[r]];
-    if (t == T_LINEAR) {
-      ++mb.linear_rows;
-      const std::vector<NodeId> top = g.topological_sort(rows[r]);
-      if (top.empty()) continue;
-      linear_row_adjoints(g, top, adj_scratch);
-      for (NodeId n : top) {
-        const int32_t col = col_of[n];
-        if (col == -1 || (lower && col > static_cast<int32_t>(r))) continue;
-        mb.entries.push_back({static_cast<int32_t>(r), col, n, adj_scratch[n], true});
-      }
-    } else if (t > T_LINEAR) {
-      mb.nonlinear_rows.push_back(static_cast<int32_t>(r));
-      const int32_t stamp = visit.stamp++;
-      std::vector<NodeId>& stack = visit.stack;
-      stack.assign(1, rows[r]);
-      visit.seen[rows[r]] = stamp;
-      outs.clear();
-      while (!stack.empty()) {
-        const NodeId n = stack.back();
-        stack.pop_back();
-        const NodeId l = g.a0[n], rr = g.a1[n];
-        if (l == kNull) {
-          if (col_of[n] != -1) outs.emplace_back(col_of[n], n);
-          continue;
-        }
-        if (visit.seen[l] != stamp) {
-          visit.seen[l] = stamp;
-          stack.push_back(l);
-        }
-        if (rr != kNull && visit.seen[rr] != stamp) {
-          visit.seen[rr] = stamp;
-          stack.push_back(rr);
-        }
-      }
-      for (auto& [col, node] : outs) {
-        if (lower && col > static_cast<int32_t>(r)) continue;
-        mb.entries.push_back({static_cast<int32_t>(r), col, node, 0.0, false});
-      }
+    if (rows[r] == kNull || g.type[rows[r]] != T_LINEAR) continue;
+    linear_row_index.push_back(static_cast<int32_t>(r));
+    linear_entries.emplace_back();
+    const std::vector<NodeId> top = g.topological_sort(rows[r]);
+    if (top.empty()) continue;
+    linear_row_adjoints(g, top, adj_scratch);
+    for (NodeId n : top) {
+      const int32_t col = col_of[n];
+      if (col == -1 || (lower && col > static_cast<int32_t>(r))) continue;
+      linear_entries.back().push_back({static_cast<int32_t>(r), col, n, adj_scratch[n], true});
     }
   }
-  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = -1;
-  // CSC order (setFromTriplets: column-major, rows ascending)
-  std::stable_sort(mb.entries.begin(), mb.entries.end(), [](const RowEntry& a, const RowEntry& b) {
-    return a.col != b.col ? a.col < b.col : a.row < b.row;
+  const size_t graph_size = g.size();
+  parallel_chunks(rows.size(), 256, [&](size_t r_begin, size_t r_end, unsigned ci) {
+    Chunk& ch = chunks[ci];
+    // marks of this THREAD (whichever chunks it gets): stamps only grow, so marks left by earlier rows, matrices
+    // or graphs never match
+    static thread_local std::vector<int32_t> seen;
+    static thread_local int32_t stamp = 0;
+    std::vector<NodeId> stack;
+    std::vector<std::pair<int32_t, NodeId>> outs;
+    size_t lin = static_cast<size_t>(std::lower_bound(linear_row_index.begin(), linear_row_index.end(), static_cast<int32_t>(r_begin)) - linear_row_index.begin());
+    for (size_t r = r_begin; r < r_end; ++r) {
+      if (rows[r] == kNull) continue;
+      const uint8_t t = g.type[rows[r]];
+      if (t == T_LINEAR) {
+        ++ch.linear_rows;
+        ch.entries.insert(ch.entries.end(), linear_entries[lin].begin(), linear_entries[lin].end());
+        ++lin;
+      } else if (t > T_LINEAR) {
+        ch.nonlinear_rows.push_back(static_cast<int32_t>(r));
+        if (seen.size() < graph_size) seen.resize(graph_size, -1);
+        const int32_t st = stamp++;
+        stack.assign(1, rows[r]);
+        seen[rows[r]] = st;
+        outs.clear();
+        while (!stack.empty()) {
+          const NodeId n = stack.back();
+          stack.pop_back();
+          const NodeId l = g.a0[n], rr = g.a1[n];
+          if (l == kNull) {
+            if (col_of[n] != -1) outs.emplace_back(col_of[n], n);
+            continue;
+          }
+          if (seen[l] != st) {
+            seen[l] = st;
+            stack.push_back(l);
+          }
+          if (rr != kNull && seen[rr] != st) {
+            seen[rr] = st;
+            stack.push_back(rr);
+          }
+        }
+        for (auto& [col, node] : outs) {
+          if (lower && col > static_cast<int32_t>(r)) continue;
+          ch.entries.push_back({static_cast<int32_t>(r), col, node, 0.0, false});
+        }
+      }
+    }
   });
+  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = -1;
+  // CSC order (setFromTriplets: column-major, rows ascending): the entries come row by row, so a stable
+  // counting sort by column leaves the rows of a column ascending
   mb.pat.rows = nrows;
   mb.pat.cols = ncols;
   mb.pat.colptr.assign(ncols + 1, 0);
-  for (auto& e : mb.entries) {
-    ++mb.pat.colptr[e.col + 1];
-    mb.pat.rowidx.push_back(e.row);
+  size_t total = 0;
+  for (const Chunk& ch : chunks) {
+    total += ch.entries.size();
+    for (const RowEntry& e : ch.entries) ++mb.pat.colptr[e.col + 1];
+    mb.nonlinear_rows.insert(mb.nonlinear_rows.end(), ch.nonlinear_rows.begin(), ch.nonlinear_rows.end());
+    mb.linear_rows += ch.linear_rows;
   }
   for (int c = 0; c < ncols; ++c) mb.pat.colptr[c + 1] += mb.pat.colptr[c];
+  mb.entries.resize(total);
+  mb.pat.rowidx.resize(total);
+  {
+    std::vector<int32_t> next(mb.pat.colptr.begin(), mb.pat.colptr.end() - 1);
+    for (const Chunk& ch : chunks)
+      for (const RowEntry& e : ch.entries) {
+        const int32_t q = next[e.col]++;
+        mb.entries[q] = e;
+        mb.pat.rowidx[q] = e.row;
+      }
+  }
   return mb;
 }
 

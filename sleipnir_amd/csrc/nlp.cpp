@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <future>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 
 namespace slpx {
@@ -34,7 +35,7 @@ struct MatrixBuild {
 // can appear in a LINEAR expression (expression.hpp:155-348), and the formulas
 // below are the reference's grad_l/grad_r for exactly those ops
 // (expression.hpp:444-515, 616-694, 696-730).
-void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, std::vector<double>& adj) {
+void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, double* adj) {
   g.update_values(top);
   for (NodeId n : top) adj[n] = 0.0;
   adj[top[0]] = 1.0;
@@ -60,16 +61,24 @@ void linear_row_adjoints(Graph& g, const std::vector<NodeId>& top, std::vector<d
 // Row visits of build_matrix: a stamp per graph node (which row saw it last) and a stack, shared by the five matrices.
 struct RowVisit {
   std::vector<int32_t> col;  // the column of a wrt node, -1 otherwise (Graph::scratch is topological_sort's)
+  std::unique_ptr<double[]> adj;
+  size_t adj_size = 0;
 };
 
 MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::vector<NodeId>& wrt,
-                         int nrows, int ncols, bool lower, std::vector<double>& adj_scratch, RowVisit& visit) {
+                         int nrows, int ncols, bool lower, RowVisit& visit) {
   MatrixBuild mb;
   // Like the reference, tag each wrt node with its column (jacobian.hpp:64-66).  A LINEAR row needs its
   // parent->child list (topological_sort; the order fixes how its constant adjoints are summed); of a nonlinear row
   // only the SET of wrt nodes it reaches is needed here (the tape compiler makes its own lists): one marking walk,
   // every node of the row touched once — the lists of all rows of a Hessian were 1.2 million entries at N=1000.
-  if (adj_scratch.size() < g.size()) adj_scratch.resize(g.size(), 0.0);
+  // adjoints of a LINEAR row's nodes: written before they are read (linear_row_adjoints), so the buffer is left
+  // as it comes — a zeroed vector of a million doubles was 2 ms of page faults for a matrix with one row
+  if (visit.adj_size < g.size()) {
+    visit.adj.reset(new double[g.size()]);
+    visit.adj_size = g.size();
+  }
+  double* adj_scratch = visit.adj.get();
   if (visit.col.size() < g.size()) visit.col.resize(g.size(), -1);
   std::vector<int32_t>& col_of = visit.col;
   for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = static_cast<int32_t>(c);
@@ -219,13 +228,19 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   s.graph_nodes_after = g.size();
   lap("gradient trees (Hessian rows)");
 
-  std::vector<double> adj;
-  RowVisit visit;
-  MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, adj, visit);        // problem.hpp:535
-  MatrixBuild mHf = build_matrix(g, Hf_rows, x, n, n, true, adj, visit);
-  MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, adj, visit);
-  MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, adj, visit);     // problem.hpp:555
-  MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, adj, visit);     // problem.hpp:560
+  // (kept by the thread between models: build_matrix leaves `col` blank again)
+  static thread_local RowVisit visit;
+  SetupLap lap_m;
+  MatrixBuild mg = build_matrix(g, {f}, x, 1, n, false, visit);        // problem.hpp:535
+  lap_m("  rows: g");
+  MatrixBuild mHf = build_matrix(g, Hf_rows, x, n, n, true, visit);
+  lap_m("  rows: H_f");
+  MatrixBuild mHc = build_matrix(g, Hc_rows, x, n, n, true, visit);
+  lap_m("  rows: H_c");
+  MatrixBuild mAe = build_matrix(g, c_e, x, m_e, n, false, visit);     // problem.hpp:555
+  lap_m("  rows: A_e");
+  MatrixBuild mAi = build_matrix(g, c_i, x, m_i, n, false, visit);     // problem.hpp:560
+  lap_m("  rows: A_i");
   lap("row lists + patterns");
 
   s.g_pat = mg.pat;
@@ -294,12 +309,14 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
     s.nonlinear_rows += static_cast<int>(mb.nonlinear_rows.size());
     s.linear_rows += mb.linear_rows;
   };
+  lap("  V layout: offsets, value outputs");
   add_matrix(mg, {f}, s.off_g, [](int32_t) { return 0; });
   add_matrix(mAe, c_e, s.off_Ae, [](int32_t r) { return 1 + r; });
   add_matrix(mAi, c_i, s.off_Ai, [m_e](int32_t r) { return 1 + m_e + r; });
   add_matrix(mHf, Hf_rows, s.off_Hf, [](int32_t) { return 0; });
   add_matrix(mHc, Hc_rows, s.off_Hc, [](int32_t) { return -1; });
 
+  lap("  V layout: matrices");
   // ---- long separable sums ----------------------------------------------------------
   // A cost like sum_k u_k^2 is ONE connected component (its ADD tree) however independent
   // its terms are: at N=1000 a 152 KB-LDS task, at N=5000 one that only fits in HBM scratch,
@@ -309,26 +326,51 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   // sum into a hidden tail of V and differentiates ITS terms (d f / d partial = 1), and a
   // tiny reduce kernel adds the partials in a fixed order.
   if (f_in != kNull && opt.split_sum_min_terms > 0) {
-    std::vector<int32_t> uses(g.size(), 0);
-    for (size_t k = 0; k < g.size(); ++k) {
-      if (g.a0[k] != kNull) ++uses[g.a0[k]];
-      if (g.a1[k] != kNull) ++uses[g.a1[k]];
+    // the chain of additions under f: f = ((t_0 + t_1) + t_2) + ...; a link of it used by anything else ends it.
+    // (Only the links' use counts matter: the candidates are marked, and the whole graph — six million nodes at
+    // N=5000 — is scanned for references to marked nodes only, in chunks on the setup threads.)
+    std::vector<NodeId> links;
+    for (NodeId cur = f; g.op[cur] == OP_ADD; cur = g.a0[cur]) links.push_back(cur);
+    std::vector<int32_t> link_of(static_cast<size_t>(f) + 1, -1);
+    for (size_t i = 0; i < links.size(); ++i) link_of[links[i]] = static_cast<int32_t>(i);
+    std::vector<int32_t> link_uses(links.size(), 0);
+    if (!links.empty()) {
+      const unsigned n_chunks = std::max(1u, parallel_chunk_count(g.size(), 1u << 16));
+      std::vector<std::vector<int32_t>> hits(n_chunks);
+      parallel_chunks(g.size(), 1u << 16, [&](size_t b, size_t e, unsigned ci) {
+        for (size_t k = b; k < e; ++k) {
+          const NodeId l = g.a0[k], r = g.a1[k];
+          if (l != kNull && l <= f && link_of[l] >= 0) hits[ci].push_back(link_of[l]);
+          if (r != kNull && r <= f && link_of[r] >= 0) hits[ci].push_back(link_of[r]);
+        }
+      });
+      for (auto& h : hits)
+        for (int32_t i : h) ++link_uses[i];
     }
     std::vector<NodeId> terms;
     NodeId cur = f;
-    while (g.op[cur] == OP_ADD && (cur == f || uses[cur] == 1)) {
+    while (g.op[cur] == OP_ADD && (cur == f || link_uses[link_of[cur]] == 1)) {
       terms.push_back(g.a1[cur]);
       cur = g.a0[cur];
     }
     terms.push_back(cur);
     std::reverse(terms.begin(), terms.end());
     if (terms.size() >= opt.split_sum_min_terms) {
-      std::unordered_map<NodeId, int32_t> xindex;
-      for (int i = 0; i < n; ++i) xindex.emplace(x[i], i);
+      // (everything below f has a smaller number than f)
+      std::vector<int32_t> xindex_of(static_cast<size_t>(f) + 1, -1);
+      for (int i = 0; i < n; ++i)
+        if (x[i] <= f) xindex_of[x[i]] = i;
+      struct {
+        const std::vector<int32_t>& v;
+        int32_t at(NodeId node) const {
+          if (static_cast<size_t>(node) >= v.size() || v[node] < 0) throw std::runtime_error("slpx: a gradient entry of the cost outside its variables");
+          return v[node];
+        }
+      } xindex{xindex_of};
       const size_t gs = opt.split_sum_group;
       const size_t G = (terms.size() + gs - 1) / gs;
       std::vector<int32_t> group_of_var(n, -1);
-      std::vector<int32_t> stamp(g.size(), -1);
+      std::vector<int32_t> stamp(static_cast<size_t>(f) + 1, -1);
       bool separable = true;
       std::vector<NodeId> stack;
       for (size_t t = 0; t < terms.size() && separable; ++t) {
@@ -339,10 +381,10 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
           stack.pop_back();
           if (stamp[v] == static_cast<int32_t>(t)) continue;
           stamp[v] = static_cast<int32_t>(t);
-          auto it = xindex.find(v);
-          if (it != xindex.end()) {
-            if (group_of_var[it->second] >= 0 && group_of_var[it->second] != grp) separable = false;
-            group_of_var[it->second] = grp;
+          const int32_t xi = xindex_of[v];
+          if (xi >= 0) {
+            if (group_of_var[xi] >= 0 && group_of_var[xi] != grp) separable = false;
+            group_of_var[xi] = grp;
           }
           if (g.a0[v] != kNull) stack.push_back(g.a0[v]);
           if (g.a1[v] != kNull) stack.push_back(g.a1[v]);
@@ -403,9 +445,11 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
 
   lap("V layout, separable sums");
   // the two tapes only read the graph: the small one (values only) compiles on a second thread
-  auto values_job = std::async(std::launch::async, [&] { return compile_tape(g, inputs, live_vouts, {}, opt); });
+  // (SLPX_SETUP_THREADS=1: one after the other on this thread — the phase times then add up)
+  const auto policy = SetupPool::get().threads() > 1 ? std::launch::async : std::launch::deferred;
+  auto values_job = std::async(policy, [&] { return compile_tape(g, inputs, live_vouts, {}, opt); });
   std::future<void> patterns_job;
-  if (on_patterns) patterns_job = std::async(std::launch::async, [&] { on_patterns(s); });
+  if (on_patterns) patterns_job = std::async(policy, [&] { on_patterns(s); });
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);
   lap("tape compile (full)");
   s.values = values_job.get();

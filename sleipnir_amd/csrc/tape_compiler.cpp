@@ -3,11 +3,14 @@
 #include <cstdlib>
 
 #include "setup_timing.hpp"
+#include "setup_threads.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <future>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
@@ -101,14 +104,35 @@ struct TapeTrace {
   std::vector<Task> tasks;
 };
 
+// Per-graph-node tables of the flat compiler, kept between its calls by a caller that makes many (one per family
+// representative: a call on a hundred nodes paid for tables of a million): `seen` and `to_cg` are returned to their
+// blank state by the call that used them.
+struct FlatScratch {
+  std::vector<uint8_t> seen;      // reachable from the call's roots
+  std::vector<int32_t> to_cg;     // graph node -> working-copy node, -1
+  std::vector<int32_t> input_idx; // graph node -> tape input, -1
+  int32_t n_inputs = 0;
+  FlatScratch(size_t G, const std::vector<std::pair<NodeId, int32_t>>& inputs) : seen(G, 0), to_cg(G, -1), input_idx(G, -1) {
+    for (auto& [node, idx] : inputs) {
+      input_idx[node] = idx;
+      n_inputs = std::max(n_inputs, idx + 1);
+    }
+  }
+};
+
 // The flat compiler: everything reachable from the selected value outputs (`vsel`: indices into value_outs) and rows
 // (`rsel`) as one program.  `tail_padding`: the 16 trailing elements the staged kernel's 16-byte loads may touch.
 static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
                                      const std::vector<TapeValueOut>& value_outs_all, const std::vector<TapeRow>& rows_all,
                                      const std::vector<uint32_t>& vsel, const std::vector<uint32_t>& rsel,
                                      const TapeCompileOptions& opt, TapeTrace* trace, bool tail_padding,
-                                     const std::vector<NodeId>* param_order = nullptr) {
+                                     const std::vector<NodeId>* param_order = nullptr, FlatScratch* scratch = nullptr) {
   TapeProgram prog;
+  std::unique_ptr<FlatScratch> own_scratch;
+  if (scratch == nullptr) {
+    own_scratch = std::make_unique<FlatScratch>(g.size(), inputs);
+    scratch = own_scratch.get();
+  }
   // (the selection, addressed like the whole lists were)
   struct ValueOutView {
     const std::vector<TapeValueOut>& all;
@@ -131,7 +155,7 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
 
   std::vector<NodeId> reach;
   {
-    std::vector<uint8_t> seen(g.size(), 0);
+    std::vector<uint8_t>& seen = scratch->seen;
     std::vector<NodeId> stack;
     for (NodeId r : roots)
       if (r != kNull && !seen[r]) {
@@ -148,19 +172,36 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
           stack.push_back(a);
         }
     }
-    // ascending ids (children first): read off the marks instead of sorting the visit order
+    // ascending ids (children first): read off the marks instead of sorting the visit order — unless the set is a
+    // small part of the graph (a family's representative)
     const size_t count = reach.size();
-    reach.clear();
-    reach.reserve(count);
-    for (size_t n = 0; n < seen.size(); ++n)
-      if (seen[n]) reach.push_back(static_cast<NodeId>(n));
+    if (count * 24 < seen.size()) {
+      std::sort(reach.begin(), reach.end());
+      for (NodeId n : reach) seen[n] = 0;
+    } else {
+      reach.clear();
+      reach.reserve(count);
+      for (size_t n = 0; n < seen.size(); ++n)
+        if (seen[n]) {
+          reach.push_back(static_cast<NodeId>(n));
+          seen[n] = 0;
+        }
+    }
   }
   // graph node -> working-copy node (-1: not reachable); a flat table, the lookups are hot
   struct NodeTable {
-    std::vector<int32_t> v;
+    std::vector<int32_t>& v;
     int32_t at(NodeId n) const { return v[n]; }
     int32_t& operator[](NodeId n) { return v[n]; }
-  } to_cg{std::vector<int32_t>(g.size(), -1)};
+  } to_cg{scratch->to_cg};
+  // (blank again when the call is over, whichever way it ends)
+  struct Blank {
+    std::vector<int32_t>& v;
+    const std::vector<NodeId>& touched;
+    ~Blank() {
+      for (NodeId n : touched) v[n] = -1;
+    }
+  } blank_to_cg{scratch->to_cg, reach};
   CG cg;
   {
     // Common-subexpression elimination while copying (ascending node ids = children first):
@@ -223,12 +264,8 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
       to_cg[n] = cg.add(g.op[n], l, r, n);
     }
   }
-  std::unordered_map<NodeId, int32_t> input_of;
-  input_of.reserve(inputs.size() * 2);
-  for (auto& [node, idx] : inputs) {
-    input_of[node] = idx;
-    prog.n_inputs = std::max(prog.n_inputs, idx + 1);
-  }
+  const std::vector<int32_t>& input_idx = scratch->input_idx;
+  prog.n_inputs = std::max(prog.n_inputs, scratch->n_inputs);
 
   lap("  tape: A working copy");
   // ---- B/C. rebalance long left-deep ADD chains ---------------------------
@@ -600,12 +637,12 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
   auto leaf_binding = [&](int32_t n) -> uint32_t {
     NodeId s = cg.src[n];
     if (cg.op[n] == OP_CONST) return kLeafConstFlag | const_index(g.val[s]);
-    auto it = input_of.find(s);
+    const int32_t in_idx = input_idx[s];
     // A free Variable that is not a decision variable acts as a parameter: in the
     // reference it is just a leaf holding its current value during solve().  It gets a
     // constant slot of its own, initialised with its value at compile time and
     // refreshable afterwards (TapeProgram::params).
-    if (it == input_of.end()) {
+    if (in_idx < 0) {
       auto pit = param_slot.find(s);
       if (pit == param_slot.end()) {
         const uint32_t i = static_cast<uint32_t>(prog.consts.size());
@@ -615,7 +652,7 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
       }
       return kLeafConstFlag | pit->second;
     }
-    return static_cast<uint32_t>(it->second);
+    return static_cast<uint32_t>(in_idx);
   };
 
   // Parameters get their slots FIRST and in node order (`param_order`: the caller's list, which may name more than
@@ -634,7 +671,7 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
       for (NodeId s : *param_order) claim(s);
     } else {
       for (size_t n = 0; n < ncg; ++n)
-        if (live[n] && cg.is_leaf(static_cast<int32_t>(n)) && cg.op[n] == OP_VAR && input_of.find(cg.src[n]) == input_of.end()) claim(cg.src[n]);
+        if (live[n] && cg.is_leaf(static_cast<int32_t>(n)) && cg.op[n] == OP_VAR && input_idx[cg.src[n]] < 0) claim(cg.src[n]);
     }
   }
   std::unordered_multimap<uint64_t, uint32_t> templates;  // structure hash -> first task with it
@@ -1060,9 +1097,10 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     std::vector<NodeId> all_nodes;
     std::vector<uint32_t> all_count, seq, seq_count;
   };
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  size_t n_chunks = members.size() < 100000 ? 1 : std::min<size_t>(4, std::max(1u, hw / 2));
-  if (const char* env = std::getenv("SLPX_SETUP_THREADS")) n_chunks = std::clamp<size_t>(static_cast<size_t>(std::atoi(env)), 1, 16);
+  // (chunks of about the same number of members, a few per setup thread; a thread's marks — a stamp and a position
+  // per graph node — stay with the thread between chunks and between compilations: stamps are handed out from one
+  // counter and never repeat)
+  const size_t n_chunks = std::max<size_t>(1, std::min<size_t>(members.size() / 16384, 4u * SetupPool::get().threads()));
   std::vector<Chunk> chunks(n_chunks);
   {
     size_t c = 0;
@@ -1073,10 +1111,30 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       chunks[k].c_end = c;
     }
   }
+  static std::mutex stamp_mutex;
+  static int32_t stamp_next = 0, stamp_generation = 0;
+  int32_t stamp_base, generation;
+  {
+    std::lock_guard<std::mutex> lk(stamp_mutex);
+    if (static_cast<int64_t>(stamp_next) + static_cast<int64_t>(ncomp) >= 0x7fffffff) {  // (every thread starts over)
+      stamp_next = 0;
+      ++stamp_generation;
+    }
+    stamp_base = stamp_next;
+    stamp_next += static_cast<int32_t>(ncomp);
+    generation = stamp_generation;
+  }
   auto run_chunk = [&](Chunk& ch) {
     const auto t0_ = std::chrono::steady_clock::now();
-    std::vector<int32_t> stamp(G, -1);
-    std::vector<uint32_t> local(G, 0);
+    static thread_local std::vector<int32_t> stamp;
+    static thread_local std::vector<uint32_t> local;
+    static thread_local int32_t my_generation = -1;
+    if (my_generation != generation) {
+      stamp.assign(G, -1);
+      my_generation = generation;
+    }
+    if (stamp.size() < G) stamp.resize(G, -1);
+    if (local.size() < G) local.resize(G, 0);
     std::vector<NodeId> ext, stack;
     std::vector<NodeId>& nodes = ch.all_nodes;
     std::vector<uint32_t>& sq = ch.seq;
@@ -1085,7 +1143,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     sq.reserve(4 * n_mem);
     for (size_t c = ch.c_begin; c < ch.c_end; ++c) {
       ext.clear();
-      const int32_t ci = static_cast<int32_t>(c);
+      const int32_t ci = stamp_base + static_cast<int32_t>(c);
       for (uint32_t q = comp_start[c]; q < comp_start[c + 1]; ++q) {
         const NodeId n = members[q];
         for (NodeId a : {g.a0[n], g.a1[n]}) {
@@ -1159,10 +1217,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     if (std::getenv("SLPX_SETUP_TIMING")) std::fprintf(stderr, "    chunk %zu-%zu: %.4f s, %u members, %zu nodes, %zu seq words\n", ch.c_begin, ch.c_end, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(), comp_start[ch.c_end] - comp_start[ch.c_begin], ch.all_nodes.size(), ch.seq.size());
   };
   {
-    std::vector<std::future<void>> jobs;
-    for (size_t k = 1; k < n_chunks; ++k) jobs.push_back(std::async(std::launch::async, [&, k] { run_chunk(chunks[k]); }));
-    run_chunk(chunks[0]);
-    for (auto& j : jobs) j.get();
+    SetupPool::get().run(static_cast<unsigned>(n_chunks), [&](unsigned k) { run_chunk(chunks[k]); });
     size_t n_all = 0, n_seq = 0;
     for (const Chunk& ch : chunks) {
       n_all += ch.all_nodes.size();
@@ -1218,6 +1273,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   lap("  tape families: classes");
 
   // ---- 3. one member of every family through the flat compiler ----
+  FlatScratch flat_scratch(G, inputs);
   struct Accepted {
     uint32_t fam;
     TapeProgram prog;
@@ -1233,7 +1289,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     std::vector<uint32_t> vsel(cvout.begin() + cvout_start[r], cvout.begin() + cvout_start[r + 1]);
     std::vector<uint32_t> rsel(crow.begin() + crow_start[r], crow.begin() + crow_start[r + 1]);
     TapeTrace trace;
-    TapeProgram rp = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, &trace, /*tail_padding=*/false);
+    TapeProgram rp = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, &trace, /*tail_padding=*/false, nullptr, &flat_scratch);
     // (what the flat compiler gives a family member: a task of its own — from 16 nodes)
     if (rp.tasks.size() != 1 || trace.tasks.size() != 1 || trace.tasks[0].n_comps != 1 || trace.tasks[0].comp_nodes < 16) continue;
     // every leaf must be findable by position in the member's reachable set
@@ -1261,7 +1317,7 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     std::vector<NodeId> param_order;
     for (size_t n = 0; n < G; ++n)
       if ((flag[n] & kReach) && g.op[n] == OP_VAR && input_idx[n] < 0) param_order.push_back(static_cast<NodeId>(n));
-    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false, &param_order);
+    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false, &param_order, &flat_scratch);
   }
   lap("  tape families: representatives + remainder");
   TapeProgram& prog = out;

@@ -79,9 +79,17 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
     visit.adj_size = g.size();
   }
   double* adj_scratch = visit.adj.get();
-  if (visit.col.size() < g.size()) visit.col.resize(g.size(), -1);
-  std::vector<int32_t>& col_of = visit.col;
-  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = static_cast<int32_t>(c);
+  // (the table reaches as far as the last wrt node — the decision variables are among a model's first nodes —
+  // not over the whole graph: `col_at` answers -1 beyond it)
+  NodeId last_wrt = -1;
+  for (NodeId w : wrt) last_wrt = std::max(last_wrt, w);
+  if (visit.col.size() < static_cast<size_t>(last_wrt) + 1) visit.col.resize(static_cast<size_t>(last_wrt) + 1, -1);
+  struct ColOf {
+    std::vector<int32_t>& v;
+    NodeId last;
+    int32_t operator[](NodeId n) const { return n <= last ? v[n] : -1; }
+  } col_of{visit.col, last_wrt};
+  for (size_t c = 0; c < wrt.size(); ++c) visit.col[wrt[c]] = static_cast<int32_t>(c);
   // the rows in chunks on the setup threads (a walk only reads the graph; every chunk has its own marks): the
   // entries of a chunk in row order, the chunks one after the other — the order a single thread finds them in
   struct Chunk {
@@ -155,7 +163,7 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
       }
     }
   });
-  for (size_t c = 0; c < wrt.size(); ++c) col_of[wrt[c]] = -1;
+  for (size_t c = 0; c < wrt.size(); ++c) visit.col[wrt[c]] = -1;
   // CSC order (setFromTriplets: column-major, rows ascending): the entries come row by row, so a stable
   // counting sort by column leaves the rows of a column ascending
   mb.pat.rows = nrows;

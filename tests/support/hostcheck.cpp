@@ -179,7 +179,7 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
 }
 
 // FNV-1a over every array of the compiled plans: setup refactorings (threads, flat arrays) are checked
-// to leave the plans the same to the byte (tests/test_plans_cpu.py::test_plan_hashes_are_stable).
+// to leave the plans the same to the byte (tests/test_plans_cpu.py::test_plans_do_not_depend_on_the_thread_count).
 namespace {
 struct PlanHash {
   uint64_t h = 1469598103934665603ull;

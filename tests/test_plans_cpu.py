@@ -185,3 +185,25 @@ def test_generated_kernel_of_a_family_serves_every_horizon(fresh, slpx, tmp_path
     # its launch, tape_jit.cpp: block_threads) and of 64 here, two code objects for the family
     n_programs = len(names[16]) // 2
     assert len(names[16]) == 2 * n_programs and n_programs - 1 <= len(shared) <= n_programs
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 60), ("cart_pole", 700), ("flywheel", 50)])
+def test_plans_do_not_depend_on_the_thread_count(kind, N):
+    """The setup passes run in chunks on a pool of threads (csrc/setup_threads.hpp), the two sides of every
+    nested-dissection separator on two: structure, both tapes, KKT plan, LDLT plan and the fronts come out the
+    same to the byte with one thread, three and eight (hashes of every plan array, hostcheck.cpp: hc_plan_hash)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    seen = {}
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, SLPX_SETUP_THREADS=threads, SLPX_LDLT_MF="1", PYTHONPATH=str(root))
+        out = subprocess.run([sys.executable, "-m", "tests.support.plan_hash_cli", kind, str(N)], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        seen[threads] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert seen["1"] == seen["3"] == seen["8"], seen

@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../sleipnir_amd/csrc/capi_internal.hpp"
@@ -176,6 +177,167 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   h->pz.assign(std::max(1, h->s.m_i), 0.0);
   // lists the structural families of the tape (stderr); no device needed for that part
   if (std::getenv("SLPX_TAPE_JIT_VERBOSE")) (void)build_tape_templates(h->s.full);
+}
+
+// ---------------------------------------------------------------------------
+// Where a multifrontal step loses its digits: the plan run twice, in double and in long
+// double (64-bit significand), front by front in the kernel's order, and the two compared at every level: the
+// finished pivot columns and the update block of every front, then the x of every front of the backward solve.
+// out rows: {phase (0 factorization, 1 backward solve), round, level, values compared,
+//            max |d - q| / max|q| over the level's fronts (normwise, per front), median and max of |d - q| / |q|}
+// ---------------------------------------------------------------------------
+namespace {
+struct MfLogEntry {
+  uint32_t phase, round, level, front;
+  long double value;
+};
+template <class T>
+void mf_run_logged(const hc_handle* h, double delta, double gamma, std::vector<MfLogEntry>& log) {
+  const LdltPlan& L = h->l;
+  std::vector<T> contrib(std::max<uint32_t>(1, L.mf_n_contrib), T(0)), xg(L.n, T(0));
+  std::vector<std::vector<T>> lds_all(L.tasks.size());
+  uint32_t front_id = 0;
+  for (int r = 0; r < L.n_rounds; ++r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      const LdltMfTask& M = L.mf_tasks[ti];
+      const uint32_t off_arena = t.n_ent, off_invd = off_arena + M.arena, off_x = off_invd + t.n_col;
+      std::vector<T>& lds = lds_all[ti];
+      lds.assign(off_x + t.n_col + M.n_anc + 1, T(0));
+      auto at = [&](uint16_t byte_off) -> T& { return lds[byte_off / 8u]; };
+      const uint32_t* cptr = L.mf_contrib_ptr.data() + M.contrib_ptr_off;
+      const uint32_t* cidx = L.mf_contrib_idx.data() + M.contrib_off;
+      const uint16_t* cent = L.mf_cent.data() + M.cent_off;
+      for (uint32_t i = 0; i < t.n_ent; ++i) {
+        const uint32_t e = t.ent_off + i;
+        const int32_t src = L.ent_src[e];
+        const uint8_t fl = L.ent_flags[e];
+        T acc = src >= 0 ? T((fl & 4) ? h->rhs[src] : h->lhs[src]) : T(0);
+        if (fl & 1) acc += (fl & 2) ? T(-gamma) : T(delta);
+        lds[i] = acc;
+      }
+      for (uint32_t j = 0; j < M.n_cent; ++j)
+        for (uint32_t c = cptr[j]; c < cptr[j + 1]; ++c) lds[cent[j]] -= contrib[cidx[c]];
+      const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
+      const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
+      const uint32_t* ext = L.mf_ext.data() + M.ext_off;
+      for (uint32_t l = 0; l < t.n_lvl; ++l)
+        for (uint32_t q = lvl[l]; q < lvl[l + 1]; ++q, ++front_id) {
+          const LdltFront& F = L.mf_fronts[M.front_off + q];
+          const uint32_t w = F.w, nr = F.nr, nch = F.nch;
+          const uint16_t* piv = tab0 + F.tab;
+          const uint16_t* upd = piv + static_cast<size_t>(nr) * (1 + nch) * w;
+          std::vector<T> a(static_cast<size_t>(nr) * w, T(0)), inv(w);
+          for (uint32_t row = 0; row < nr; ++row)
+            for (uint32_t c = 0; c < w && c <= row; ++c) {
+              T v = 0;
+              for (uint32_t k = 0; k <= nch; ++k) v += at(piv[(static_cast<size_t>(row) * (1 + nch) + k) * w + c]);
+              a[static_cast<size_t>(row) * w + c] = v;
+            }
+          for (uint32_t c = 0; c < w; ++c) {
+            inv[c] = T(1) / a[static_cast<size_t>(c) * w + c];
+            for (uint32_t row = c + 1; row < nr; ++row) {
+              const T lc = a[static_cast<size_t>(row) * w + c] * inv[c];
+              for (uint32_t j = c + 1; j < w && j <= row; ++j) a[static_cast<size_t>(row) * w + j] -= lc * a[static_cast<size_t>(j) * w + c];
+            }
+          }
+          for (uint32_t row = 0; row < nr; ++row)
+            for (uint32_t c = 0; c < w && c <= row; ++c) {
+              at(piv[(static_cast<size_t>(row) * (1 + nch)) * w + c]) = a[static_cast<size_t>(row) * w + c];
+              log.push_back({0u, static_cast<uint32_t>(r), l, front_id, static_cast<long double>(a[static_cast<size_t>(row) * w + c])});
+            }
+          for (uint32_t c = 0; c < w; ++c) lds[off_invd + F.col0 + c] = inv[c];
+          for (uint32_t e = 0; e < F.n_s; ++e) {
+            const uint16_t* row = upd + static_cast<size_t>(e) * (3 + nch);
+            T v = 0;
+            for (uint32_t k = 0; k < nch; ++k) v += at(row[3 + k]);
+            for (uint32_t c = 0; c < w; ++c) {
+              const uint32_t coff = c * nr - (c * (c - 1)) / 2 - c;
+              v -= (lds[row[1] / 8u + coff] * inv[c]) * lds[row[2] / 8u + coff];
+            }
+            if (F.flags & 1) contrib[ext[F.ext + row[0]]] = -v;
+            else at(row[0]) = v;
+            log.push_back({0u, static_cast<uint32_t>(r), l, front_id, static_cast<long double>(v)});
+          }
+        }
+    }
+  for (int r = L.n_rounds - 1; r >= 0; --r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      const LdltMfTask& M = L.mf_tasks[ti];
+      const uint32_t off_invd = t.n_ent + M.arena, off_x = off_invd + t.n_col;
+      std::vector<T>& lds = lds_all[ti];
+      for (uint32_t a = 0; a < M.n_anc; ++a) lds[off_x + t.n_col + a] = xg[L.mf_anc[M.anc_off + a]];
+      const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
+      const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
+      for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l)
+        for (uint32_t q = lvl[l]; q < lvl[l + 1]; ++q) {
+          const LdltFront& F = L.mf_fronts[M.front_off + q];
+          const uint32_t w = F.w, nr = F.nr, nch = F.nch, rr = nr - w - 1;
+          const uint16_t* xr = tab0 + F.tab + static_cast<size_t>(nr) * (1 + nch) * w + static_cast<size_t>(F.n_s) * (3 + nch);
+          auto U = [&](uint32_t row, uint32_t c) { return lds[F.base0 + c * nr - (c * (c - 1)) / 2 + (row - c)]; };
+          for (int c = static_cast<int>(w) - 1; c >= 0; --c) {
+            T dot = 0;
+            for (uint32_t a = 0; a < rr; ++a) dot += U(w + a, c) * lds[xr[a] / 8u];
+            for (uint32_t k = c + 1; k < w; ++k) dot += U(k, c) * lds[off_x + F.col0 + k];
+            lds[off_x + F.col0 + c] = (U(nr - 1, c) - dot) * lds[off_invd + F.col0 + c];
+            log.push_back({1u, static_cast<uint32_t>(r), static_cast<uint32_t>(l), ti * 65536u + q, static_cast<long double>(lds[off_x + F.col0 + c])});
+          }
+        }
+      for (uint32_t i = 0; i < t.n_col; ++i) xg[L.col_perm[t.col_off + i]] = lds[off_x + i];
+    }
+}
+}  // namespace
+
+extern "C" int32_t hc_mf_level_errors(hc_handle* h, double delta, double gamma, double* out, int32_t cap_rows) {
+  if (!h->l.mf) return -1;
+  std::vector<MfLogEntry> ld, dd;
+  mf_run_logged<long double>(h, delta, gamma, ld);
+  mf_run_logged<double>(h, delta, gamma, dd);
+  if (ld.size() != dd.size()) return -2;
+  // fronts are logged task by task: gather every task's fronts of a (phase, round, level)
+  struct Acc {
+    std::vector<double> comp;
+    double worst_norm = 0.0;
+    size_t values = 0;
+  };
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, Acc> acc;
+  std::vector<std::tuple<uint32_t, uint32_t, uint32_t>> order;  // in the order of first appearance
+  size_t a = 0;
+  while (a < ld.size()) {  // one front
+    size_t b = a;
+    long double big = 0, diff = 0;
+    const auto key = std::make_tuple(ld[a].phase, ld[a].round, ld[a].level);
+    if (acc.find(key) == acc.end()) order.push_back(key);
+    Acc& A = acc[key];
+    while (b < ld.size() && ld[b].front == ld[a].front && ld[b].phase == ld[a].phase) {
+      big = std::max(big, std::fabs(ld[b].value));
+      const long double d = std::fabs(dd[b].value - ld[b].value);
+      diff = std::max(diff, d);
+      if (ld[b].value != 0) A.comp.push_back(static_cast<double>(d / std::fabs(ld[b].value)));
+      ++b;
+    }
+    A.values += b - a;
+    if (big > 0) A.worst_norm = std::max(A.worst_norm, static_cast<double>(diff / big));
+    a = b;
+  }
+  int32_t rows = 0;
+  for (const auto& key : order) {
+    Acc& A = acc[key];
+    std::sort(A.comp.begin(), A.comp.end());
+    if (rows < cap_rows) {
+      double* o = out + 7 * static_cast<size_t>(rows);
+      o[0] = std::get<0>(key);
+      o[1] = std::get<1>(key);
+      o[2] = std::get<2>(key);
+      o[3] = static_cast<double>(A.values);
+      o[4] = A.worst_norm;
+      o[5] = A.comp.empty() ? 0.0 : A.comp[A.comp.size() / 2];
+      o[6] = A.comp.empty() ? 0.0 : A.comp.back();
+    }
+    ++rows;
+  }
+  return rows;
 }
 
 // FNV-1a over every array of the compiled plans: setup refactorings (threads, flat arrays) are checked

@@ -53,6 +53,7 @@ def lib():
     sig("hc_create", vp, vp, vp, i32, i32, i32)
     sig("hc_destroy", None, vp)
     sig("hc_plan_hash", None, vp, vp)
+    sig("hc_mf_level_errors", i32, vp, d, d, vp, i32)
     sig("hc_tape_jit_compiles", i32, vp)
     sig("hc_supernodes", None, vp, vp)
     sig("hc_ldlt_tree", None, vp, vp, vp)
@@ -100,6 +101,16 @@ class HostCheck:
         if self._h:
             lib().hc_destroy(self._h)
             self._h = None
+
+    def mf_level_errors(self, delta, gamma):
+        """The multifrontal plan in double against long double, level by level (hostcheck.cpp: hc_mf_level_errors):
+        rows of {phase, round, level, values, worst normwise error of a front, median and max componentwise error}.
+        The system is the one set by assemble() / rhs() (or set_lhs / set_rhs)."""
+        out = np.zeros((4096, 7))
+        rows = lib().hc_mf_level_errors(self._h, float(delta), float(gamma), out.ctypes.data, 4096)
+        if rows < 0:
+            raise RuntimeError("no multifrontal plan (SLPX_LDLT_MF=1)")
+        return out[:rows]
 
     def plan_hash(self):
         """FNV-1a of [structure, full tape, values tape, KKT plan, LDLT plan, multifrontal plan]"""

@@ -64,17 +64,22 @@ class GpuBackend:
         return self.sys.get("p_s")[0], self.sys.get("p_z")[0]
 
 
-# Forward-error rule for the step ("a test changed to fit the code" — the escape clause
-# 1e-3 kappa eta that came with the multifrontal kernel is gone).  A backward-stable solve lands
-# anywhere within kappa x eta of the true solution, so two correct codes can differ by an order of
-# magnitude in where they land (N=1000 interior, kappa 1.4e10, both residuals 2-5e-12: oracle 4.7e-7,
-# pair lists 3.3e-6, fronts 9e-6).  What a CORRECT factorization guarantees and a wrong one cannot
-# fake: one step of iterative refinement with ITS OWN factors (residual in extended precision on the
-# host, correction solved on the backend) contracts the error by ~kappa x eta_factorization << 1.
-# Asserted: the step is within 10 x the oracle's distance to the refined solution — or, failing
-# that, within MAX_DISTANCE_RATIO x of it AND one refinement step with the backend's own factors
-# brings it to the oracle's distance (or 1e-8).  The refined distance is recorded either way.
-MAX_DISTANCE_RATIO = 50.0  # observed worst case: 19 x (N=1000 interior, multifrontal step, r03/r04)
+# Forward-error rule for the step.  A backward-stable solve lands anywhere within a few kappa x eps of the true
+# solution, and WHERE in that ball is decided by the order of the sums: over 24 seeded interior states of cart-pole
+# N=1000 (profiles/r05_forward_error_sweep_*.txt; all three codes factor the same matrix in the same elimination
+# order) the oracle's distance to the refined solution is 0.09 .. 22 kappa eps (median 0.94), the multifrontal plan's
+# 0.1 .. 10.3 (median 0.65), the column plan's 0.2 .. 10.5 (median 0.67); the ratio fronts / oracle runs from 0.04
+# to 22.6 with a geometric mean of 0.61.  The state the suite uses (seed 0) happens to be one where the oracle lands
+# at 0.15 kappa eps — the "19 x" of rounds 3 and 4 was that draw, not a decimal lost in the fronts; and
+# profiles/r05_mf_level_errors.txt (the plan in double against long double, level by level) shows why no order of
+# summation can do better: from the fourth level of the leaf tasks on the entries of the factors themselves have no
+# correct digits (gamma = 1e-10 pivots are differences of O(1) terms), only their product has.
+# Asserted: the step is within 10 x the oracle's distance to the refined solution — or within FORWARD_ENVELOPE x
+# kappa x eps of the refined solution itself (no reference to the oracle's draw) AND one step of iterative
+# refinement with the backend's OWN factors (residual in extended precision on the host, correction solved on the
+# backend) brings it to the oracle's distance (or 1e-8): what a correct factorization guarantees and a wrong one
+# cannot fake.  (r03/r04 had "within 50 x the oracle's" here, a constant read off the one observed 19 x.)
+FORWARD_ENVELOPE = 32.0  # kappa eps; observed over the sweep: 22 (the oracle), 10.5 (the product's plans)
 
 
 def residual_longdouble(colptr, rowidx, val, rhs, x):
@@ -95,7 +100,8 @@ def assert_forward_error(errs, solve_correction, lcp, lri, Kreg, rhs, p, p_true,
     d = solve_correction(residual_longdouble(lcp, lri, Kreg, rhs, p))
     errs["p1_vs_true"] = cases.max_rel(p + d, p_true)
     direct = errs["p_vs_true"] <= max(tol_step, 10.0 * errs["po_vs_true"])
-    refined = (errs["p_vs_true"] <= max(tol_step, MAX_DISTANCE_RATIO * errs["po_vs_true"]) and
+    errs["p_vs_true_kappa_eps"] = errs["p_vs_true"] / (errs["kappa"] * np.finfo(float).eps)
+    refined = (errs["p_vs_true"] <= max(tol_step, FORWARD_ENVELOPE * errs["kappa"] * np.finfo(float).eps) and
                errs["p1_vs_true"] <= max(tol_step, errs["po_vs_true"]))
     errs["forward_rule"] = "direct" if direct else "refined" if refined else "FAILED"
     assert direct or refined, (label, errs)

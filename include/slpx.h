@@ -36,8 +36,9 @@ typedef struct slpx_system slpx_system;
  * slpx_problem_solve_sized(p, &opt, sizeof opt, &report) (present since version 5: check
  * slpx_abi_version() >= 5 before binding it); the two benchmark-model constructors of versions <= 4
  * (slpx_problem_cart_pole / _flywheel) are gone: a model is the CALLER's program, built through the
- * slp:: surface or slpx_expr_* / slpx_problem_* (tests/support/models/ holds the benchmarks' as fixtures). */
-#define SLPX_ABI_VERSION 5
+ * slp:: surface or slpx_expr_* / slpx_problem_* (tests/support/models/ holds the benchmarks' as fixtures).
+ * 6: SLPX_INFO_LDLT_DENSE appended to the info array (SLPX_INFO_COUNT grew by one). */
+#define SLPX_ABI_VERSION 6
 int slpx_abi_version(void);
 const char* slpx_last_error(void);
 int slpx_device_count(void);
@@ -206,6 +207,9 @@ enum {
   /* since ABI version 5: the multifrontal plan — 1 if the single-problem step runs on fronts, their
    * number, and how many of them send their update block through the matrix cores */
   SLPX_INFO_LDLT_MULTIFRONTAL, SLPX_INFO_LDLT_FRONTS, SLPX_INFO_LDLT_MFMA_FRONTS,
+  /* since ABI version 6: 1 if the system is factored as a dense matrix (the reference's dense branch,
+   * util/dense_regularized_ldlt.hpp: where a column of L does not fit a task of the sparse plan) */
+  SLPX_INFO_LDLT_DENSE,
   SLPX_INFO_COUNT
 };
 int slpx_system_info(const slpx_system* s, int64_t* out /* SLPX_INFO_COUNT */);

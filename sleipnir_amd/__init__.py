@@ -20,7 +20,7 @@ _ROOT = _PKG.parent
 # (SLPX_LIB: another build of the library, e.g. for an A/B on one box)
 LIB_PATH = Path(os.environ["SLPX_LIB"]).resolve() if os.environ.get("SLPX_LIB") else _PKG / "libslpx.so"
 
-ABI_VERSION = 5  # include/slpx.h: SLPX_ABI_VERSION (struct layouts and entry points below)
+ABI_VERSION = 6  # include/slpx.h: SLPX_ABI_VERSION (struct layouts and entry points below)
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -34,7 +34,7 @@ INFO_KEYS = [
     "factor_bytes", "solve_bytes", "sweep_bytes", "struct_singular", "off_g", "off_Ae", "off_Ai",
     "off_Hf", "off_Hc", "graph_nodes", "nonlinear_rows", "tape_global_tasks", "tape_shared_tasks",
     "tape_program_bytes", "ldlt_levels", "ldlt_supernodes", "ldlt_widest_supernode",
-    "ldlt_multifrontal", "ldlt_fronts", "ldlt_mfma_fronts",
+    "ldlt_multifrontal", "ldlt_fronts", "ldlt_mfma_fronts", "ldlt_dense",
 ]
 
 # slpx_op

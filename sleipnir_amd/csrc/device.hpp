@@ -379,6 +379,7 @@ class DeviceNlp {
   void solve_after_factor();                        // p for the rhs that was in place at factor()
   bool step_is_one_launch() const { return m_fuse_solve && m_fuse_kkt; }
   bool step_is_multifrontal() const { return m_mf; }
+  bool factorization_is_dense() const { return m_dense; }
   void solve_backsub_publish();                     // solve_after_factor() + backsub_publish(), one launch where possible
   // factor() + solve_backsub_publish(): ONE launch where every task's workgroup fits on the device at once
   void factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
@@ -490,6 +491,11 @@ class DeviceNlp {
   DevBuf<LdltPair> m_pairs;
   DevBuf<LdltSn> m_sn_desc;
   DevBuf<int32_t> m_lhs_colptr, m_lhs_rowidx, m_lhs_rowptr, m_lhs_rowent, m_lhs_rowcol;  // refine_solution (uploaded on first use)
+  // the dense branch (LdltPlan::dense, ldlt_dense_kernels.h): the factors of every problem as a dim x dim matrix
+  bool m_dense = false;
+  DevBuf<double> m_dense_A;
+  DevBuf<int32_t> m_dense_colptr, m_dense_rowidx;
+  uint32_t m_dense_lds = 0;
   DevBuf<double> m_rhs0, m_p_acc;
   DevBuf<uint32_t> m_sn_lvl_ptr, m_col_sn, m_lvl_pack, m_col_lvl_pack;
   DevBuf<uint2> m_bwd_range;

@@ -24,6 +24,7 @@
 #include "kkt_kernels.h"
 #include "ldlt_kernels.h"
 #include "ldlt_mf_kernels.h"
+#include "ldlt_dense_kernels.h"
 #include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
@@ -651,7 +652,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // spin on CUs the earlier rounds of other problems are waiting for (measured at batch
   // 512: factorization 0.93 -> 4.2 ms), so batches keep one launch per round.
   lap("  upload: LDLT plan");
-  m_il = interleaved_for(batch);
+  m_dense = l.dense;
+  m_il = !m_dense && interleaved_for(batch);
   m_single_launch = !m_il && static_cast<size_t>(batch) * l.tasks.size() <= 1024;
   if (const char* env = std::getenv("SLPX_SINGLE_LAUNCH")) m_single_launch = env[0] != '0';
   // launch fusion (device.hpp: KktFuse / BacksubFuse): one problem, single-launch factorization
@@ -705,6 +707,16 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
       std::fill(empty.begin(), empty.end(), e);
       SLPX_HIP_CHECK(hipMemcpy(m_contrib.p, empty.data(), empty.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+  }
+  if (m_dense) {
+    // dim x dim per problem, the pattern of lhs for the scatter; LDS: column k and its scaled copy
+    m_dense_A.alloc(B * static_cast<size_t>(l.n) * l.n);
+    m_dense_colptr.upload(k.lhs.colptr);
+    m_dense_rowidx.upload(k.lhs.rowidx);
+    m_dense_lds = 16u * static_cast<uint32_t>(l.n) + 64u;
+    if (m_dense_lds > 160u * 1024u) throw std::runtime_error("slpx: the dense factorization holds two columns in LDS: at most 10 000 rows");
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_dense_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_dense_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   m_scontrib.alloc(B * std::max<uint32_t>(1, l.n_scontrib));
   m_zv.alloc(B * l.n);
@@ -1597,6 +1609,12 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
                                   hipMemcpyHostToDevice, stream));
     reg = m_reg_dev.p;
   }
+  if (m_dense) {
+    hipLaunchKernelGGL(ldlt_dense_factor_kernel, dim3(m_batch), dim3(kDenseThreads), m_dense_lds, stream, l.n, l.n_dec,
+                       m_dense_colptr.p, m_dense_rowidx.p, m_kdev.nnz_lhs, m_lhs.p, reg, m_dense_A.p, m_D.p, m_Lx.p, lxs, cur, next);
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (m_il) {
     const int C = (m_batch + 63) / 64;
     const int nnz = m_kdev.nnz_lhs;
@@ -1864,6 +1882,10 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
 void DeviceNlp::solve() {
   if (m_rhs_stale) build_rhs();
   const LdltPlan& l = m_l_ref;
+  if (m_dense) {
+    solve_after_factor();
+    return;
+  }
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
   const int scs = static_cast<int>(std::max<uint32_t>(1, l.n_scontrib));
   if (m_il) {
@@ -1916,6 +1938,13 @@ void DeviceNlp::solve_backsub_publish() {
 void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   const LdltPlan& l = m_l_ref;
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));
+  if (m_dense) {  // (nothing rides in a dense factorization: forward and backward substitution from the rhs in memory)
+    if (m_rhs_stale) build_rhs();
+    hipLaunchKernelGGL(ldlt_dense_solve_kernel, dim3(m_batch), dim3(kDenseThreads), 8u * static_cast<uint32_t>(l.n) + 16u, m_stream, l.n,
+                       m_dense_A.p, m_rhs.p, m_p.p);
+    SLPX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (m_il) {
     const int C = (m_batch + 63) / 64;
     for (int r = l.n_rounds - 1; r >= 0; --r) {

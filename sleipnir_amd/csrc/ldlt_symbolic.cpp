@@ -1645,14 +1645,80 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   return P;
 }
 
+bool ldlt_plan_error_is_too_big(const std::exception& e) {
+  const std::string what = e.what();
+  return what.find("exceeds the LDS task budget") != std::string::npos || what.find("exceeds the 160 KB LDS") != std::string::npos ||
+         what.find("exceeds 16-bit local indexing") != std::string::npos;
+}
+
+LdltPlan build_dense_ldlt_plan(const CscPattern& lower, int n_dec) {
+  LdltPlan P;
+  const int n = lower.cols;
+  P.n = n;
+  P.n_dec = n_dec;
+  P.dense = true;
+  P.perm.resize(n);
+  std::iota(P.perm.begin(), P.perm.end(), 0);
+  P.iperm = P.perm;
+  P.parent.assign(n, -1);
+  for (int j = 0; j + 1 < n; ++j) P.parent[j] = j + 1;
+  P.nnzL = static_cast<int64_t>(n) * (n - 1) / 2;
+  P.Lp.assign(n + 1, 0);
+  for (int j = 0; j < n; ++j) P.Lp[j + 1] = P.Lp[j] + (n - 1 - j);
+  P.Li.reserve(static_cast<size_t>(P.nnzL));
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) P.Li.push_back(i);
+  P.etree_height = n;
+  P.n_rounds = 0;
+  P.round_ptr.assign(1, 0);
+  P.n_supernodes = n;
+  P.critical_levels = n;
+  // (the padding the uploads and the staged kernels' 16-byte reads expect of every plan)
+  for (int k = 0; k < 16; ++k) {
+    P.ent_src.push_back(-1);
+    P.ent_flags.push_back(0);
+    P.ent_col.push_back(0);
+    P.ent_out.push_back(0);
+    P.pairs.push_back({});
+    P.ent_pair_ptr.push_back(0);
+    P.ent_contrib_ptr.push_back(0);
+    P.contrib_idx.push_back(0);
+    P.ext_dst.push_back(0);
+    P.lvl_ptr.push_back(0);
+    P.col_lvl_ptr.push_back(0);
+    P.col_perm.push_back(0);
+    P.fwd_ptr.push_back(0);
+    P.fwd_contrib_ptr.push_back(0);
+    P.scontrib_idx.push_back(0);
+    P.bwd_ptr.push_back(0);
+    P.fwd_items.push_back({});
+    P.bwd_items.push_back({});
+    P.sext_ptr.push_back(0);
+    P.sext_dst.push_back(0);
+    P.sext_items.push_back({});
+    P.sn_desc.push_back({});
+    P.col_sn.push_back(0);
+    P.sn_lvl_ptr.push_back(0);
+    P.mf_tab.push_back(0);
+    P.mf_ext.push_back(0);
+    P.mf_contrib_ptr.push_back(0);
+    P.mf_contrib_idx.push_back(0);
+    P.mf_cent.push_back(0);
+    P.mf_anc.push_back(0);
+    P.mf_lvl_ptr.push_back(0);
+    P.mf_fronts.push_back(LdltFront{});
+  }
+  // the traffic of a dense factorization and of its two triangular solves
+  P.factor_bytes = 12LL * lower.nnz() + 16LL * (P.nnzL + n);
+  P.solve_bytes = 32LL * P.nnzL + 16LL * n;
+  P.flops = static_cast<int64_t>(n) * n * n / 3;
+  return P;
+}
+
 LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt,
                          const std::vector<int32_t>* user_perm,
                          const std::vector<uint8_t>* diag_has_source) {
-  auto too_big = [](const std::runtime_error& e) {
-    const std::string what = e.what();
-    return what.find("exceeds the LDS task budget") != std::string::npos ||
-           what.find("exceeds the 160 KB LDS") != std::string::npos;
-  };
+  auto too_big = [](const std::runtime_error& e) { return ldlt_plan_error_is_too_big(e); };
   try {
     return build_ldlt_plan_once(lower, n_dec, opt, user_perm, diag_has_source);
   } catch (const std::runtime_error& e) {

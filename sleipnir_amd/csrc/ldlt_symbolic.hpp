@@ -23,6 +23,7 @@
 #pragma once
 
 #include <cstdint>
+#include <exception>
 #include <vector>
 
 #include "nlp.hpp"
@@ -191,6 +192,11 @@ struct LdltPlan {
   uint32_t mf_n_contrib = 0;
   uint32_t mf_max_nch = 0, mf_max_front_rows = 0, mf_n_mfma = 0;
 
+  // ---- dense plan (build_dense_ldlt_plan): no tasks, no lists — the matrix is factored as a dense one in
+  // memory (ldlt_dense_kernels.h), the reference's dense branch (util/dense_regularized_ldlt.hpp:59-136,
+  // chosen there by density, interior_point.hpp:340-352; here also whenever a column of L does not fit a task)
+  bool dense = false;
+
   // traffic model: factor = 12k + 16ℓ, solve = 32ℓ + 16 n
   int64_t factor_bytes = 0, solve_bytes = 0;
   int64_t flops = 0;  // 2 * number of pair products
@@ -252,5 +258,10 @@ struct LdltOptions {
 LdltPlan build_ldlt_plan(const CscPattern& lower, int n_dec, const LdltOptions& opt = {},
                          const std::vector<int32_t>* user_perm = nullptr,
                          const std::vector<uint8_t>* diag_has_source = nullptr);
+
+// The dense plan of an order-n system: identity permutation, L the full lower triangle, nothing else.
+LdltPlan build_dense_ldlt_plan(const CscPattern& lower, int n_dec);
+// what build_ldlt_plan throws when a column of L (or a task's working set) does not fit the LDS of a CU
+bool ldlt_plan_error_is_too_big(const std::exception& e);
 
 }  // namespace slpx

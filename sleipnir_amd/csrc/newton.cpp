@@ -14,6 +14,24 @@
 
 namespace slpx {
 
+// The sparse plan, or — where a column of L does not fit the LDS of a task (a Hessian dense in hundreds of
+// variables: single shooting), or SLPX_DENSE=1 asks for it — the dense one: the reference's dense branch
+// (util/dense_regularized_ldlt.hpp, chosen there by density: interior_point.hpp:340-352) instead of a refusal.
+static LdltPlan plan_or_dense(const CscPattern& lhs, int n_dec, const LdltOptions& lopt, const std::vector<int32_t>* user_perm,
+                              const std::vector<uint8_t>* diag_has_source) {
+  constexpr int kDenseMaxOrder = 8192;  // 512 MB of factors per problem, two columns in LDS
+  const char* env = std::getenv("SLPX_DENSE");
+  if (env != nullptr && env[0] == '1' && lhs.cols <= kDenseMaxOrder) return build_dense_ldlt_plan(lhs, n_dec);
+  try {
+    return build_ldlt_plan(lhs, n_dec, lopt, user_perm, diag_has_source);
+  } catch (const std::runtime_error& e) {
+    if (!ldlt_plan_error_is_too_big(e) || lhs.cols > kDenseMaxOrder || (env != nullptr && env[0] == '0')) throw;
+    if (std::getenv("SLPX_LDLT_VERBOSE"))
+      std::fprintf(stderr, "ldlt: %s — the system of order %d is factored as a dense matrix\n", e.what(), lhs.cols);
+    return build_dense_ldlt_plan(lhs, n_dec);
+  }
+}
+
 NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
                            const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
                            const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
@@ -84,7 +102,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
     // Both rules are applied inside the build, after its first task partition (LdltOptions::single_problem_task_rules).
     lopt.single_problem_task_rules = opt.batch == 1 && std::getenv("SLPX_TASK_ENTRIES") == nullptr;
-    m_l = build_ldlt_plan(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    m_l = plan_or_dense(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
   };
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
   lap("= AD structure + tape compile, KKT plan, LDLT symbolic");
@@ -159,7 +177,7 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
-  m_l = build_ldlt_plan(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
+  m_l = plan_or_dense(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));
   reset_regularization();

@@ -31,6 +31,7 @@ struct hc_handle {
   LdltPlan l;
   std::vector<double> scales, in_scale, V, lhs, rhs, Lx, D, contrib, scontrib, zv, xg, p, ps, pz;
   std::vector<double> z_factor;  // z left behind by the factorization (rhs carried as a row)
+  std::vector<double> dense_A;   // the dense plan's factors (column-major, L below the diagonal, D on it)
   // multifrontal plan (SLPX_LDLT_MF=1): the update slots between tasks, and every task's first
   // 64 KB of LDS as the factorization leaves it (the in-place backward solve reads U and 1/d there)
   std::vector<double> mf_contrib;
@@ -157,7 +158,18 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
     }
   if (const char* env = std::getenv("SLPX_RELAX_ZEROS")) lopt.relax_zeros = std::atoi(env);
   if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
-  h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
+  // (the product's rule, newton.cpp: plan_or_dense)
+  const char* dense_env = std::getenv("SLPX_DENSE");
+  if (dense_env != nullptr && dense_env[0] == '1') {
+    h->l = build_dense_ldlt_plan(h->k.lhs, h->s.n);
+  } else {
+    try {
+      h->l = build_ldlt_plan(h->k.lhs, h->s.n, lopt, up.empty() ? nullptr : &up, &diag_has_source);
+    } catch (const std::runtime_error& e) {
+      if (!ldlt_plan_error_is_too_big(e)) throw;
+      h->l = build_dense_ldlt_plan(h->k.lhs, h->s.n);
+    }
+  }
   h->scales.assign(h->s.n_scales(), 1.0);
   h->in_scale.assign(h->s.n_inputs(), 1.0);
   h->V = h->s.V_static_raw;
@@ -371,6 +383,8 @@ uint64_t hash_tape(const TapeProgram& P) {
 }
 void hash_csc(PlanHash& H, const CscPattern& c) { H.pod(c.rows); H.pod(c.cols); H.vec(c.colptr); H.vec(c.rowidx); }
 }  // namespace
+
+extern "C" int32_t hc_is_dense(hc_handle* h) { return h->l.dense ? 1 : 0; }
 
 extern "C" void hc_plan_hash(hc_handle* h, uint64_t* out) {
   {
@@ -702,12 +716,60 @@ static void hc_backward_mf(hc_handle* h, double* p_out) {
   if (p_out) std::copy(h->p.begin(), h->p.end(), p_out);
 }
 
+// The dense plan (LdltPlan::dense; ldlt_dense_kernels.h): right-looking LDLT of the regularized matrix as a dense
+// one in the natural order, the kernel's arithmetic (reciprocal of the pivot, fused multiply-add updates).
+static void hc_factor_dense(hc_handle* h, double delta, double gamma) {
+  const LdltPlan& L = h->l;
+  const KktPlan& K = h->k;
+  const int dim = L.n;
+  std::vector<double>& A = h->dense_A;
+  A.assign(static_cast<size_t>(dim) * dim, 0.0);
+  for (int c = 0; c < dim; ++c) {
+    for (int p = K.lhs.colptr[c]; p < K.lhs.colptr[c + 1]; ++p) A[static_cast<size_t>(c) * dim + K.lhs.rowidx[p]] += h->lhs[p];
+    A[static_cast<size_t>(c) * dim + c] += c < L.n_dec ? delta : -gamma;
+  }
+  for (int k = 0; k < dim; ++k) {
+    double* colk = A.data() + static_cast<size_t>(k) * dim;
+    const double inv = 1.0 / colk[k];
+    std::vector<double> u(colk + k + 1, colk + dim);
+    for (int i = k + 1; i < dim; ++i) colk[i] = u[i - k - 1] * inv;
+    for (int j = k + 1; j < dim; ++j) {
+      double* colj = A.data() + static_cast<size_t>(j) * dim;
+      for (int i = j; i < dim; ++i) colj[i] = std::fma(-colk[i], u[j - k - 1], colj[i]);
+    }
+  }
+  for (int k = 0; k < dim; ++k) {
+    const double u = A[static_cast<size_t>(k) * dim + k];
+    h->D[k] = u;
+    const double eps = 2.220446049250313e-16;
+    if (u > eps) ++h->stats[0];
+    else if (u < -eps) ++h->stats[1];
+    else ++h->stats[2];
+    if (u == 0.0 || !std::isfinite(u)) ++h->stats[3];
+    else h->min_abs = std::min(h->min_abs, std::fabs(u));
+    for (int i = k + 1; i < dim; ++i) h->Lx[L.Lp[k] + (i - k - 1)] = A[static_cast<size_t>(k) * dim + i];
+  }
+}
+static void hc_solve_dense(hc_handle* h, double* p_out) {
+  const int dim = h->l.n;
+  const std::vector<double>& A = h->dense_A;
+  std::vector<double> x(h->rhs.begin(), h->rhs.begin() + dim);
+  for (int k = 0; k < dim; ++k)
+    for (int i = k + 1; i < dim; ++i) x[i] = std::fma(-A[static_cast<size_t>(k) * dim + i], x[k], x[i]);
+  for (int i = 0; i < dim; ++i) x[i] = x[i] / A[static_cast<size_t>(i) * dim + i];
+  for (int k = dim - 1; k >= 0; --k)
+    for (int i = 0; i < k; ++i) x[i] = std::fma(-A[static_cast<size_t>(i) * dim + k], x[k], x[i]);
+  h->p = x;
+  if (p_out) std::copy(h->p.begin(), h->p.end(), p_out);
+}
+
 void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* stats_out) {
   const LdltPlan& L = h->l;
   std::memset(h->stats, 0, sizeof(h->stats));
   h->min_abs = INFINITY;
-  if (L.mf) {
-    hc_factor_mf(h, delta, gamma);
+  if (L.dense || L.mf) {
+    if (L.dense) hc_factor_dense(h, delta, gamma);
+    else hc_factor_mf(h, delta, gamma);
     if (D_out) std::copy(h->D.begin(), h->D.end(), D_out);
     if (stats_out) {
       for (int i = 0; i < 4; ++i) stats_out[i] = h->stats[i];
@@ -796,6 +858,10 @@ static void hc_backward(hc_handle* h, double* p_out);
 // backward substitution only, on the z the factorization left behind (the path the
 // Newton step takes on the device)
 void hc_solve_after_factor(hc_handle* h, double* p_out) {
+  if (h->l.dense) {
+    hc_solve_dense(h, p_out);
+    return;
+  }
   if (h->l.mf) {
     hc_backward_mf(h, p_out);
     return;
@@ -806,6 +872,10 @@ void hc_solve_after_factor(hc_handle* h, double* p_out) {
 
 void hc_solve(hc_handle* h, double* p_out) {
   const LdltPlan& L = h->l;
+  if (L.dense) {
+    hc_solve_dense(h, p_out);
+    return;
+  }
   for (int r = 0; r < L.n_rounds; ++r)
     for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
       const LdltTask& t = L.tasks[ti];

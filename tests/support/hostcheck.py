@@ -53,6 +53,7 @@ def lib():
     sig("hc_create", vp, vp, vp, i32, i32, i32)
     sig("hc_destroy", None, vp)
     sig("hc_plan_hash", None, vp, vp)
+    sig("hc_is_dense", i32, vp)
     sig("hc_mf_level_errors", i32, vp, d, d, vp, i32)
     sig("hc_tape_jit_compiles", i32, vp)
     sig("hc_supernodes", None, vp, vp)
@@ -96,6 +97,7 @@ class HostCheck:
         lib().hc_info(self._h, out.ctypes.data)
         self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
         self.n, self.m_e, self.m_i = self.info["n"], self.info["m_e"], self.info["m_i"]
+        self.dense = bool(lib().hc_is_dense(self._h))
 
     def close(self):
         if self._h:
@@ -111,6 +113,10 @@ class HostCheck:
         if rows < 0:
             raise RuntimeError("no multifrontal plan (SLPX_LDLT_MF=1)")
         return out[:rows]
+
+    def is_dense(self):
+        """the system is factored as a dense matrix (no column of L fits a task of the sparse plan, or SLPX_DENSE=1)"""
+        return bool(lib().hc_is_dense(self._h))
 
     def plan_hash(self):
         """FNV-1a of [structure, full tape, values tape, KKT plan, LDLT plan, multifrontal plan]"""

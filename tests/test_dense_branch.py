@@ -1,0 +1,75 @@
+"""The dense branch of the regularized LDLT (util/dense_regularized_ldlt.hpp:59-136; chosen by the reference where the
+KKT system is dense, interior_point.hpp:340-352): a model whose Hessian is dense in hundreds of variables — single
+shooting, optimization/ocp.hpp:382-400 — used to be REFUSED by the product ("a single column exceeds the LDS task
+budget"); it is now factored as a dense matrix (ldlt_dense_kernels.h, LdltPlan::dense).  CPU tier: the plan and the
+host interpreter of the dense factorization against the oracle; GPU tier: the kernels, and whole solves."""
+import numpy as np
+import pytest
+
+from tests.support import model, parity, shooting
+
+
+def build_both(N, **kw):
+    mo = model.Model(model.OracleBackend())
+    mo.be.reset()
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    return shooting.build(mo, N, **kw), shooting.build(mp, N, **kw)
+
+
+@pytest.mark.parametrize("N,with_eq", [(300, False), (300, True)])
+def test_single_shooting_takes_the_dense_plan(fresh, hostcheck, N, with_eq):
+    """300 steps: a column of L has 300 entries, ~11 000 entry-equivalents against a task's 2048 (5120 at most)."""
+    po, pp = build_both(N, final_state_constraint=with_eq)
+    assert po.p.dims == pp.p.dims == (N, 1 if with_eq else 0, 2 * N)
+    hc = hostcheck.HostCheck(pp.p)
+    assert hc.is_dense()
+    cp, ri = hc.pattern(5)
+    assert len(ri) == (N + with_eq) * (N + with_eq + 1) // 2  # the lower triangle is full
+    for case in ("step0", "interior"):
+        errs = parity.check_newton_step(hc, po.p, case)
+        assert errs["p"] <= 1e-8, errs
+
+
+def test_small_models_keep_the_sparse_plan_unless_asked(fresh, hostcheck, monkeypatch):
+    po, pp = build_both(40)
+    assert not hostcheck.HostCheck(pp.p).is_dense()
+    monkeypatch.setenv("SLPX_DENSE", "1")
+    hc = hostcheck.HostCheck(pp.p)
+    assert hc.is_dense()
+    parity.check_newton_step(hc, po.p, "interior")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,with_eq", [(300, False), (300, True), (40, True)])
+def test_dense_newton_step_gpu(fresh, slpx, monkeypatch, N, with_eq):
+    """ldlt_dense_factor_kernel / ldlt_dense_solve_kernel under the oracle: lhs, rhs, inertia, D, p, p_s, p_z."""
+    if N < 100:
+        monkeypatch.setenv("SLPX_DENSE", "1")
+    po, pp = build_both(N, final_state_constraint=with_eq)
+    system = slpx.System(pp.p, batch=1, device=0)
+    try:
+        assert system.info["ldlt_dense"] == 1 and system.info["ldlt_tasks"] == 0
+        for case in ("step0", "interior"):
+            errs = parity.check_newton_step(parity.GpuBackend(system), po.p, case)
+            assert errs["p"] <= 1e-8, errs
+    finally:
+        system.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,with_eq", [(300, False), (300, True)])
+def test_single_shooting_solve_matches_the_oracle_gpu(fresh, slpx, N, with_eq):
+    """The whole solve (interior point on the resident iterate, every factorization the dense kernel's): exit
+    status, inputs and the states they give against the oracle's (which takes the reference's dense branch)."""
+    po, pp = build_both(N, final_state_constraint=with_eq)
+    so = po.solve()
+    sp = pp.solve()
+    assert sp == so == model.NlpProblem.SUCCESS
+    uo, up = po.p.get_x(), pp.p.get_x()
+    xo, xp = shooting.rollout(uo), shooting.rollout(up)
+    assert np.max(np.abs(np.array(xo) - np.array(xp))) <= 1e-6
+    assert np.max(np.abs(uo - up)) <= 1e-4 * shooting.U_MAX
+    assert abs(xp[-1] - shooting.R) <= (1e-6 if with_eq else 1e-2)
+    # bang, then hold: the first input at its bound, the last near the steady-state value r
+    assert abs(up[0] - shooting.U_MAX) <= 1e-3 and abs(up[-2] - shooting.R) <= 0.5

@@ -80,14 +80,16 @@ def test_ocp_helper_builds_the_models_of_the_reference_test(slpx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method,kind,steps", [(0, 0, 1000), (0, 1, 1000), (1, 0, 1000), (2, 0, 50), (2, 1, 50)])
+@pytest.mark.parametrize("method,kind,steps", [(0, 0, 1000), (0, 1, 1000), (1, 0, 1000), (2, 0, 50), (2, 1, 50),
+                                               (2, 0, 300), (2, 1, 1000)])
 def test_ocp_helper_flywheel_known_answer_on_the_gpu(slpx, method, kind, steps):
     """flywheel_ocp_test.cpp:87-140: bang-then-hold input, states within 1e-2 of the discrete
     model's, final state r = 10 within 2e-6 — direct transcription and collocation at the
     reference's own size (1000 steps of 5 ms).  Single shooting makes the Hessian dense in the
-    inputs; the reference then takes its DENSE LDLT branch (interior_point.hpp:340-349), which is
-    outside SURVEY.md §8 — the sparse factorization here holds a column in LDS and says so when
-    one does not fit (1000 steps), so that method is exercised at 50 steps."""
+    inputs; the reference then takes its DENSE LDLT branch (interior_point.hpp:340-349) — and so does
+    the product where a column of L no longer fits a task of its sparse plan (r05: LdltPlan::dense,
+    ldlt_dense_kernels.h; through r04 that was a refusal and the method was exercised at 50 steps only):
+    300 steps, and the reference's own 1000."""
     build_ocp_program(slpx) if not _fresh(OCP_BIN, OCP_SRC, slpx) else None
     res = subprocess.run([str(OCP_BIN), str(method), str(kind), str(steps)], capture_output=True, text=True,
                          timeout=900)

@@ -1045,9 +1045,8 @@ RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs
 
 namespace {
 
-NewtonSystem& restoration_system(NewtonSystem& outer) {
+void build_restoration_system(NewtonSystem& outer) {
   auto& R = outer.restoration();
-  if (R.sys) return *R.sys;
   RestorationModel M = build_restoration_model(outer.graph(), outer.x_nodes(), outer.c_e_nodes(), outer.c_i_nodes());
   R.vars = std::move(M.vars);
   R.x_ref = std::move(M.x_ref);
@@ -1057,7 +1056,47 @@ NewtonSystem& restoration_system(NewtonSystem& outer) {
   NewtonOptions opt = outer.options();
   opt.batch = 1;
   R.sys = std::make_unique<NewtonSystem>(outer.graph(), R.vars, M.cost, M.c_e, M.c_i, opt);
+}
+
+NewtonSystem& restoration_system(NewtonSystem& outer) {
+  auto& R = outer.restoration();
+  if (R.prefetch.valid()) {
+    try {
+      R.prefetch.get();
+    } catch (...) {  // (whatever went wrong on the other thread happens again below, where it can be reported)
+      R.sys.reset();
+    }
+  }
+  if (R.sys) return *R.sys;
+  build_restoration_system(outer);
   return *R.sys;
+}
+
+// The reference enters feasibility restoration without any setup (feasibility_restoration.hpp:347-628 composes the
+// restoration problem out of the outer problem's callbacks); here it is a second compiled system — tape, KKT plan,
+// symbolic LDLT, upload: as long as a hundred interior-point iterations at N=300.  A solve of a model big enough
+// for that to matter therefore starts compiling it at once, on a thread of its own, while the outer iterations run on
+// the device: by the time the filter gives up on a step the system is (nearly) there.  Not with iteration callbacks
+// (a callback may evaluate expressions: the graph is appended to on the other thread), not for small models.
+// SLPX_RESTORATION_PREFETCH=0: off; =1: whatever the size.
+void restoration_prefetch(NewtonSystem& outer, bool has_callbacks) {
+  auto& R = outer.restoration();
+  if (R.sys || R.prefetch.valid() || has_callbacks) return;
+  const NlpStructure& st = outer.structure();
+  bool on = st.m_e + st.m_i >= 512;
+  if (const char* env = std::getenv("SLPX_RESTORATION_PREFETCH")) on = env[0] == '1' || (on && env[0] != '0');
+  if (!on || st.m_e + st.m_i == 0) return;
+  R.prefetch = std::async(std::launch::async, [&outer] { build_restoration_system(outer); });
+}
+// (before the solve hands the model back to its owner, who may go on building expressions)
+void restoration_prefetch_join(NewtonSystem& outer) {
+  auto& R = outer.restoration();
+  if (!R.prefetch.valid()) return;
+  try {
+    R.prefetch.get();
+  } catch (...) {
+    R.sys.reset();
+  }
 }
 
 // util/lagrange_multiplier_estimate.hpp:56-133: least-squares (y, z) of
@@ -1625,13 +1664,20 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
   Vec s(st.m_i, 1.0), y(st.m_e, 0.0), z(st.m_i, 1.0);
   double mu = 0.1 * scales[0];
   int iterations = 0;
-  const ExitStatus status =
-      ipm_core(sys, scales, callbacks, options, false, x, s, y, z, mu, iterations, rep, solve_start);
+  restoration_prefetch(sys, !callbacks.empty());
+  ExitStatus status;
+  try {
+    status = ipm_core(sys, scales, callbacks, options, false, x, s, y, z, mu, iterations, rep, solve_start);
+  } catch (...) {
+    restoration_prefetch_join(sys);
+    throw;
+  }
+  restoration_prefetch_join(sys);
+  rep.t_total = since(solve_start);
   if (s_out) *s_out = s;
   if (y_out) *y_out = y;
   if (z_out) *z_out = z;
   rep.iterations = iterations;
-  rep.t_total = since(solve_start);
   return status;
 }
 

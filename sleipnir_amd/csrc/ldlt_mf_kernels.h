@@ -904,4 +904,168 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
                                       2u * Mf.n_tasks, T.stats);
 }
 
+// ---------------------------------------------------------------------------
+// A NEW right-hand side through the fronts (second-order corrections, interior_point.hpp:611-619: up to five per
+// iteration; the multiplier estimate; refinement; RegularizedLDLT::solve, sparse_regularized_ldlt.hpp:159-161): the
+// factor the step kernel left in memory (Lx, D) goes back into every task's front layout, the forward
+// substitution runs as the right-hand-side ROW of the factorization did — per front: the row's entries of the
+// pivot columns (own value + the children's), eliminated against the finished columns, then its part of the update
+// block, a lane per row of R —, the backward solve is the step kernel's (mf_solve_front).  One launch, every task
+// resident, hand-overs through the update slots (forward: only the slots of right-hand-side entries are written
+// and taken; the others stay armed) and through x itself (backward).  The pair-list kernels took two launches and
+// 24 + 17.5 us for this at cart-pole N=500 (ldlt_fwd_kernel, ldlt_bwd_kernel on L in memory).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mf_fwd_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t root, uint32_t invd_addr,
+                                             const uint32_t* __restrict__ ext, double* __restrict__ contrib, uint32_t lane) {
+  tab = __builtin_amdgcn_readfirstlane(tab);
+  w = __builtin_amdgcn_readfirstlane(w);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  nch = __builtin_amdgcn_readfirstlane(nch);
+  root = __builtin_amdgcn_readfirstlane(root);
+  invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
+  const uint32_t stride = 2u * w * (1u + nch);  // bytes of a row of the pivot table
+  const uint32_t prow = tab + (nr - 1u) * stride;  // the right-hand-side row
+  const uint32_t r = nr - w - 1u;
+  // the row's entries of the pivot columns: every lane the same (uniform addresses: broadcast reads)
+  double ub[kSnWidthMax], li[kSnWidthMax];
+#pragma unroll
+  for (int c = 0; c < static_cast<int>(kSnWidthMax); ++c) {
+    ub[c] = 0.0;
+    li[c] = 0.0;
+    if (static_cast<uint32_t>(c) < w) {
+      const uint32_t own = lds_ld16(prow + 2u * c);
+      double v = lds_ld(own);
+      for (uint32_t k = 1; k <= nch; ++k) v += lds_ld(lds_ld16(prow + 2u * (w * k + c)));
+#pragma unroll
+      for (int c2 = 0; c2 < c; ++c2)  // U(c, c2): row c (a pivot column's own row) of finished column c2
+        v = __builtin_fma(-li[c2], lds_ld(lds_ld16(tab + static_cast<uint32_t>(c) * stride + 2u * c2)), v);
+      ub[c] = v;
+      li[c] = v * lds_ld(invd_addr + 8u * c);
+      if (lane == 0) lds_st(own, v);
+    }
+  }
+  if (lane < r) {  // its part of the update block: entry (rhs row, R_lane)
+    const uint32_t upd = tab + nr * stride, ustride = 2u * (3u + nch);
+    const uint32_t ur = upd + __umul24((r * (r + 1u)) / 2u + lane, ustride);
+    const uint32_t o = lds_ld16(ur), pb = lds_ld16(ur + 4u);
+    double v = 0.0;
+    for (uint32_t k = 0; k < nch; ++k) v += lds_ld(lds_ld16(ur + 6u + 2u * k));
+#pragma unroll
+    for (int c = 0; c < static_cast<int>(kSnWidthMax); ++c)
+      if (static_cast<uint32_t>(c) < w) v = __builtin_fma(-li[c], lds_ld(pb + mf_coff(c, nr)), v);
+    if (root & 1u) coherent_store(&contrib[ext[o]], -v, true);
+    else lds_st(o, v);
+  }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ldlt_mf_solve_kernel(LdltDev L, MfDev Mf, const double* __restrict__ Lx,
+                                                                 const double* __restrict__ D, const double* __restrict__ rhs,
+                                                                 double* __restrict__ contrib, double* __restrict__ xg,
+                                                                 double* __restrict__ xg_next, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t task_index = blockIdx.x;
+  const LdltTask t = L.tasks[task_index];
+  const LdltMfTask m = Mf.tasks[task_index];
+  const MfCarve cv = mf_carve(t, m);
+  double* U = reinterpret_cast<double*>(smem_raw);
+  double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
+  double* invd = reinterpret_cast<double*>(smem_raw + cv.o_invd);
+  double* x = reinterpret_cast<double*>(smem_raw + cv.o_x);
+  const uint32_t* lvl = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_lvl);
+  const uint32_t* ext = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_ext);
+  const uint8_t* flags = reinterpret_cast<const uint8_t*>(smem_raw + cv.o_flags);
+  const uint16_t* cent = reinterpret_cast<const uint16_t*>(smem_raw + cv.o_cent);
+  const uint32_t* cptr = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cptr);
+  const uint32_t* cidx = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cidx);
+  const uint32_t* colperm = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_cp);
+  const uint32_t* anc = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_anc);
+  // ---- the task's tables (the step kernel's image, up to the KKT terms) ----
+  {
+    constexpr int kInFlight = kMfImageGroups / THREADS;
+    uint4 stage_v[kInFlight];
+    const uint4* src16 = Mf.image + static_cast<size_t>(task_index) * Mf.image_stride16;
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) stage_v[k] = src16[tid + k * THREADS];
+    const uint4 img = Mf.image_desc[task_index];
+    uint4* dst_a = reinterpret_cast<uint4*>(smem_raw + cv.o_tab);
+    const uint32_t n_a = (cv.o_terms - cv.o_tab) / 16u < img.y ? (cv.o_terms - cv.o_tab) / 16u : img.y;
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) {
+      const uint32_t i = tid + k * THREADS;
+      if (i < n_a) dst_a[i] = stage_v[k];
+    }
+  }
+  if (tid == 0) {
+    arena[0] = 0.0;
+    arena[1] = 0.0;
+    x[t.n_col + m.n_anc] = 1.0;
+  }
+  __syncthreads();
+  // ---- the factor back into the fronts' layout: U = L d, 1/d; the new right-hand side into its row ----
+  {
+    const uint32_t* g_out = L.ent_out + t.ent_off;
+    const uint16_t* g_col = L.ent_col + t.ent_off;
+    const int32_t* g_src = L.ent_src + t.ent_off;
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const uint8_t fl = flags[i];
+      const uint32_t o = g_out[i];
+      if (fl & 1) {
+        const double d = D[o];
+        U[i] = d;
+        invd[g_col[i]] = chain_reciprocal(d);
+      } else if (fl & 4) {
+        U[i] = rhs[g_src[i]];
+      } else {
+        U[i] = Lx[o] * D[colperm[g_col[i]]];
+      }
+    }
+  }
+  __syncthreads();
+  // right-hand-side entries that take update slots from child tasks (ldlt_mf_step_kernel: the same slots, of
+  // which this launch fills and empties only those of the right-hand-side row)
+  for (uint32_t j = tid; j < m.n_cent; j += THREADS) {
+    const uint32_t i = cent[j];
+    if (!(flags[i] & 4)) continue;
+    double acc = U[i];
+    for (uint32_t c = cptr[j]; c < cptr[j + 1]; ++c) {
+      double* p = &contrib[cidx[c]];
+      const double v = slot_read(p);
+      __hip_atomic_store(p, __longlong_as_double(static_cast<long long>(kSlotEmpty)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc -= v;
+    }
+    U[i] = acc;
+  }
+  __syncthreads();
+  const LdltFront* gfr = Mf.fronts + m.front_off;
+  for (uint32_t l = 0; l < t.n_lvl; ++l) {
+    const uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[l]), end = __builtin_amdgcn_readfirstlane(lvl[l + 1]);
+    for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+      const u32x4 d = s_load_desc(gfr + q);
+      const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
+      mf_fwd_front(cv.o_tab + 2u * d[0], w, nr, nch, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16), contrib, lane);
+    }
+    __syncthreads();
+  }
+  // ---- backward solve (ldlt_mf_step_kernel's) ----
+  for (uint32_t a = tid; a < m.n_anc; a += THREADS) x[t.n_col + a] = slot_read(&xg[anc[a]]);
+  __syncthreads();
+  for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
+    const uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[l]), end = __builtin_amdgcn_readfirstlane(lvl[l + 1]);
+    for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
+      const u32x4 d = s_load_desc(gfr + q);
+      const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
+      const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
+      mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS)
+    coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
+  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
+}
+
 }  // namespace slpx

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <functional>
+#include <future>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -61,8 +62,14 @@ class NewtonSystem {
     std::vector<NodeId> x_ref, weight;  // parameters: x_R and zeta * D_R (n each)
     std::vector<NodeId> d_ce, d_ci;     // parameters: the outer problem's row scalings
     std::vector<NodeId> vars;           // [x, p_e, n_e, p_i, n_i]
+    // the system being compiled on a thread of its own while the outer solve iterates (ipm.cpp:
+    // restoration_prefetch); whoever needs `sys` waits for it first
+    std::future<void> prefetch;
   };
   Restoration& restoration() { return m_restoration; }
+  ~NewtonSystem() {
+    if (m_restoration.prefetch.valid()) m_restoration.prefetch.wait();  // (it reads this system's model)
+  }
 
   const NlpStructure& structure() const { return m_s; }
   const KktPlan& kkt() const { return m_k; }

@@ -546,6 +546,7 @@ class DeviceNlp {
   uint32_t m_factor_solve_lds = 0;
   // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
   bool m_mf = false;
+  bool m_mf_solve = false;  // a new right-hand side goes through the fronts too (ldlt_mf_solve_kernel; SLPX_MF_SOLVE=0: the pair lists)
   bool m_mf_mfma = false;             // the plan has fronts on the matrix cores: the kernel variant with that path
   int m_mf_threads = 1024;            // 512 where the 1024-thread workgroups of every task are not resident at once
   bool m_sip_ok = false;              // the pair-list one-launch kernel is usable too (build_solve_in_place)

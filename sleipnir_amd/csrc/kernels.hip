@@ -1363,6 +1363,20 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   if (m_exit_cnt.n == 0) m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
   m_mf_lds = lds;
   m_mf = true;
+  // new right-hand sides through the fronts (one launch: every task resident, as the step kernel's)
+  {
+    const char* env = std::getenv("SLPX_MF_SOLVE");
+    m_mf_solve = env == nullptr || env[0] != '0';
+    if (m_mf_solve) {
+      const void* fn = m_mf_threads == 1024 ? reinterpret_cast<const void*>(&ldlt_mf_solve_kernel<1024>)
+                                            : reinterpret_cast<const void*>(&ldlt_mf_solve_kernel<512>);
+      SLPX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      int per_cu_solve = 0;
+      if (m_mf_threads == 1024) SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_solve, &ldlt_mf_solve_kernel<1024>, 1024, lds));
+      else SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_solve, &ldlt_mf_solve_kernel<512>, 512, lds));
+      m_mf_solve = l.tasks.size() <= static_cast<size_t>(per_cu_solve) * cus;
+    }
+  }
 }
 
 // lhs / rhs of the CURRENT state into memory, if the last step did without them
@@ -1884,6 +1898,25 @@ void DeviceNlp::solve() {
   const LdltPlan& l = m_l_ref;
   if (m_dense) {
     solve_after_factor();
+    return;
+  }
+  if (m_mf && m_mf_solve && m_batch == 1 && xg_other() != nullptr) {
+    MfDev md;
+    md.tasks = m_mf_tasks.p;
+    md.fronts = m_mf_fronts.p;
+    md.image = m_mf_image.p;
+    md.image_stride16 = m_mf_image_stride16;
+    md.image_desc = m_mf_image_desc.p;
+    md.n_tasks = static_cast<unsigned int>(l.tasks.size());
+    const dim3 grid(static_cast<uint32_t>(l.tasks.size()));
+    if (m_mf_threads == 1024)
+      hipLaunchKernelGGL(ldlt_mf_solve_kernel<1024>, grid, dim3(1024), m_mf_lds, m_stream, m_ldev, md, m_Lx.p, m_D.p, m_rhs.p,
+                         m_mf_contrib.p, xg_now(), xg_other(), m_p.p);
+    else
+      hipLaunchKernelGGL(ldlt_mf_solve_kernel<512>, grid, dim3(512), m_mf_lds, m_stream, m_ldev, md, m_Lx.p, m_D.p, m_rhs.p,
+                         m_mf_contrib.p, xg_now(), xg_other(), m_p.p);
+    xg_flip();
+    SLPX_HIP_CHECK(hipGetLastError());
     return;
   }
   const long long lxs = static_cast<long long>(std::max<int64_t>(1, l.nnzL));

@@ -870,10 +870,81 @@ void hc_solve_after_factor(hc_handle* h, double* p_out) {
   hc_backward(h, p_out);
 }
 
+// A new right-hand side through the fronts (ldlt_mf_kernels.h: ldlt_mf_solve_kernel): the factor in memory (Lx, D)
+// back into every task's front layout, the forward substitution as the right-hand-side row of the factorization
+// — per front the row's entries of the pivot columns, then its part of the update block —, then hc_backward_mf.
+static void hc_forward_mf(hc_handle* h) {
+  const LdltPlan& L = h->l;
+  for (int r = 0; r < L.n_rounds; ++r)
+    for (uint32_t ti = L.round_ptr[r]; ti < L.round_ptr[r + 1]; ++ti) {
+      const LdltTask& t = L.tasks[ti];
+      const LdltMfTask& M = L.mf_tasks[ti];
+      const uint32_t off_arena = t.n_ent, off_invd = off_arena + M.arena, off_x = off_invd + t.n_col;
+      std::vector<double>& lds = h->mf_lds[ti];
+      lds.assign(off_x + t.n_col + M.n_anc + 1, 0.0);
+      auto at = [&](uint16_t byte_off) -> double& { return lds[byte_off / 8u]; };
+      for (uint32_t i = 0; i < t.n_ent; ++i) {
+        const uint32_t e = t.ent_off + i;
+        const uint8_t fl = L.ent_flags[e];
+        const uint32_t o = L.ent_out[e];
+        if (fl & 1) {
+          lds[i] = h->D[o];
+          lds[off_invd + L.ent_col[e]] = 1.0 / h->D[o];
+        } else if (fl & 4) {
+          lds[i] = h->rhs[L.ent_src[e]];
+        } else {
+          lds[i] = h->Lx[o] * h->D[L.col_perm[t.col_off + L.ent_col[e]]];
+        }
+      }
+      const uint32_t* cptr = L.mf_contrib_ptr.data() + M.contrib_ptr_off;
+      const uint32_t* cidx = L.mf_contrib_idx.data() + M.contrib_off;
+      const uint16_t* cent = L.mf_cent.data() + M.cent_off;
+      for (uint32_t j = 0; j < M.n_cent; ++j) {
+        if (!(L.ent_flags[t.ent_off + cent[j]] & 4)) continue;
+        for (uint32_t c = cptr[j]; c < cptr[j + 1]; ++c) lds[cent[j]] -= h->mf_contrib[cidx[c]];
+      }
+      const uint32_t* lvl = L.mf_lvl_ptr.data() + t.lvl_off;
+      const uint16_t* tab0 = L.mf_tab.data() + M.tab_off;
+      const uint32_t* ext = L.mf_ext.data() + M.ext_off;
+      for (uint32_t l = 0; l < t.n_lvl; ++l)
+        for (uint32_t q = lvl[l]; q < lvl[l + 1]; ++q) {
+          const LdltFront& F = L.mf_fronts[M.front_off + q];
+          const uint32_t w = F.w, nr = F.nr, nch = F.nch, rr = nr - w - 1;
+          const uint16_t* piv = tab0 + F.tab;
+          const uint16_t* upd = piv + static_cast<size_t>(nr) * (1 + nch) * w;
+          const uint16_t* prow = piv + static_cast<size_t>(nr - 1) * (1 + nch) * w;
+          std::vector<double> li(w);
+          for (uint32_t c = 0; c < w; ++c) {
+            double v = at(prow[c]);
+            for (uint32_t k = 1; k <= nch; ++k) v += at(prow[k * w + c]);
+            for (uint32_t c2 = 0; c2 < c; ++c2) v = std::fma(-li[c2], at(piv[(static_cast<size_t>(c) * (1 + nch)) * w + c2]), v);
+            at(prow[c]) = v;
+            li[c] = v * lds[off_invd + F.col0 + c];
+          }
+          for (uint32_t b = 0; b < rr; ++b) {
+            const uint16_t* row = upd + static_cast<size_t>(rr * (rr + 1) / 2 + b) * (3 + nch);
+            double v = 0.0;
+            for (uint32_t k = 0; k < nch; ++k) v += at(row[3 + k]);
+            for (uint32_t c = 0; c < w; ++c) {
+              const uint32_t coff = c * nr - (c * (c - 1)) / 2 - c;
+              v = std::fma(-li[c], lds[row[2] / 8u + coff], v);
+            }
+            if (F.flags & 1) h->mf_contrib[ext[F.ext + row[0]]] = -v;
+            else at(row[0]) = v;
+          }
+        }
+    }
+}
+
 void hc_solve(hc_handle* h, double* p_out) {
   const LdltPlan& L = h->l;
   if (L.dense) {
     hc_solve_dense(h, p_out);
+    return;
+  }
+  if (L.mf && std::getenv("SLPX_MF_SOLVE") == nullptr) {
+    hc_forward_mf(h);
+    hc_backward_mf(h, p_out);
     return;
   }
   for (int r = 0; r < L.n_rounds; ++r)

@@ -138,3 +138,37 @@ def test_chains_from_the_deepest_child_shorten_the_longest_pivot_chain(fresh, sl
     assert abs(sn_on["critical_levels"] - sn_off["critical_levels"]) <= 1
     wide = lambda sn: sum(c for w, c in sn["width_hist"].items() if w >= 7)
     assert wide(sn_on) < wide(sn_off)
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 37), ("cart_pole", 300), ("flywheel", 50)])
+def test_a_new_right_hand_side_through_the_fronts(fresh, slpx, orc, hostcheck, mf, monkeypatch, kind, N):
+    """ldlt_mf_solve_kernel as the host interprets it (hc_forward_mf + hc_backward_mf): the factor in memory back in
+    the fronts' layout, the forward substitution as the right-hand-side row of the factorization, the step kernel's
+    backward solve — against the solve that rode in the factorization, against the pair lists (SLPX_MF_SOLVE=0) and,
+    for a right-hand side that was NOT there at the factorization, against a dense solve of the same matrix."""
+    pp, op = cases.build_pair(kind, N, slpx, orc)
+    hc = hostcheck.HostCheck(pp)
+    n, me, mi = hc.n, hc.m_e, hc.m_i
+    scales = op.scaling()
+    hc.set_scaling(scales)
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+    hc.sweep(x, y, z, True)
+    lhs = hc.assemble(s, z)
+    rhs = hc.rhs(s, y, z, mu)
+    hc.factor(1e-4, 1e-10)
+    p_fused = hc.solve_after_factor()
+    p_fronts = hc.solve()
+    assert cases.max_rel(p_fronts, p_fused) <= 1e-9
+    rng = np.random.default_rng(5)
+    b2 = rng.uniform(-1, 1, n + me)
+    hc.set_rhs(b2)
+    p2 = hc.solve()
+    monkeypatch.setenv("SLPX_MF_SOLVE", "0")
+    p2_pairs = hc.solve()
+    monkeypatch.delenv("SLPX_MF_SOLVE")
+    assert cases.max_rel(p2, p2_pairs) <= 1e-9
+    lcp, lri = hc.pattern(5)
+    Kreg = cases.regularized(lcp, lri, lhs, n, 1e-4, 1e-10)
+    resid = cases.lower_csc_matvec(lcp, lri, Kreg, p2) - b2
+    assert np.max(np.abs(resid)) <= 1e-9 * max(1.0, float(np.max(np.abs(p2))) * float(np.max(np.abs(Kreg))))
+    hc.close()

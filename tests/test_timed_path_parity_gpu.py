@@ -150,3 +150,69 @@ def test_config5_gfold_matrix_core_fronts_against_oracle(fresh, slpx, monkeypatc
                                                 f"({system.info['ldlt_mfma_fronts']} of {system.info['ldlt_fronts']})")
     finally:
         system.close()
+
+
+@pytest.mark.parametrize("kind,N", [("cart_pole", 1000), ("cart_pole", 100), ("cart_pole", 5000), ("gfold", 100)])
+def test_a_new_right_hand_side_through_the_fronts(fresh, slpx, orc, monkeypatch, kind, N):
+    """ldlt_mf_solve_kernel (r05; second-order corrections, interior_point.hpp:611-619, the multiplier estimate,
+    slpx_system_solve): K p = b for a right-hand side that was not there when the step kernel factored K — against
+    the residual of the regularized system, against the pair-list kernels on the same factor (SLPX_MF_SOLVE=0, a
+    second system), and repeated (the hand-over slots and both x buffers are left armed by every launch)."""
+    def build():
+        if kind == "gfold":
+            mo = model.Model(model.OracleBackend())
+            mo.be.reset()
+            mp = model.Model(model.ProductBackend("hostcheck"))
+            mp.be.reset()
+            return gfold.build(mp, N).p, gfold.build(mo, N).p
+        return cases.build_pair(kind, N, slpx, orc)
+
+    pp, op = build()
+    system = slpx.System(pp, batch=1, device=0)
+    monkeypatch.setenv("SLPX_MF_SOLVE", "0")
+    other = slpx.System(pp, batch=1, device=0)
+    monkeypatch.delenv("SLPX_MF_SOLVE")
+    try:
+        assert system.info["ldlt_multifrontal"] == 1
+        n, me, mi = system.info["n"], system.info["m_e"], system.info["m_i"]
+        scales = op.scaling()
+        state = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+        x, s, y, z, mu = state
+        results = []
+        for sy in (system, other):
+            sy.set_scaling(scales)
+            sy.set_state(x, s, y, z, np.array([mu]))
+            sy.reset_regularization()
+            assert np.all(sy.newton_step(True) == 0)
+        delta, gamma = (float(v) for v in system.regularization()[0])
+        lhs = system.get("lhs")[0]
+        lcp, lri = system.pattern(5)
+        Kreg = cases.regularized(lcp, lri, lhs, n, delta, gamma)
+        k_inf = float(np.max(cases.lower_csc_matvec(lcp, lri, np.abs(Kreg), np.ones(n + me))))
+        rng = np.random.default_rng(11)
+        for trial in range(3):
+            b = rng.uniform(-1, 1, n + me)
+            ps = []
+            for sy in (system, other):
+                sy.set_rhs(b[None, :])
+                sy.solve()
+                ps.append(sy.get("p")[0])
+            p_fronts, p_pairs = ps
+            resid = float(np.max(np.abs(cases.lower_csc_matvec(lcp, lri, Kreg, p_fronts) - b)))
+            assert resid <= 1e-9 * max(1.0, k_inf * float(np.max(np.abs(p_fronts)))), (trial, resid)
+            resid_pairs = float(np.max(np.abs(cases.lower_csc_matvec(lcp, lri, Kreg, p_pairs) - b)))
+            assert resid <= max(1e-12 * k_inf * float(np.max(np.abs(p_fronts))), 10.0 * resid_pairs), (trial, resid, resid_pairs)
+        # and the step after it is the step before it, to the bit: nothing the solves left behind disturbs a factorization
+        p_before = system.get("p")[0].copy()
+        system.reset_regularization()
+        assert np.all(system.newton_step(True) == 0)
+        first = system.get("p")[0].copy()
+        system.set_rhs(rng.uniform(-1, 1, n + me)[None, :])
+        system.solve()
+        system.reset_regularization()
+        assert np.all(system.newton_step(True) == 0)
+        assert np.array_equal(system.get("p")[0], first)
+        del p_before
+    finally:
+        system.close()
+        other.close()

@@ -1045,7 +1045,8 @@ RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs
 
 namespace {
 
-void build_restoration_system(NewtonSystem& outer) {
+// `host_only`: everything that reads the expression graph, nothing of the device (NewtonSystem::finish_device)
+void build_restoration_system(NewtonSystem& outer, bool host_only) {
   auto& R = outer.restoration();
   RestorationModel M = build_restoration_model(outer.graph(), outer.x_nodes(), outer.c_e_nodes(), outer.c_i_nodes());
   R.vars = std::move(M.vars);
@@ -1055,7 +1056,7 @@ void build_restoration_system(NewtonSystem& outer) {
   R.d_ci = std::move(M.d_ci);
   NewtonOptions opt = outer.options();
   opt.batch = 1;
-  R.sys = std::make_unique<NewtonSystem>(outer.graph(), R.vars, M.cost, M.c_e, M.c_i, opt);
+  R.sys = std::make_unique<NewtonSystem>(outer.graph(), R.vars, M.cost, M.c_e, M.c_i, opt, nullptr, host_only);
 }
 
 NewtonSystem& restoration_system(NewtonSystem& outer) {
@@ -1067,8 +1068,8 @@ NewtonSystem& restoration_system(NewtonSystem& outer) {
       R.sys.reset();
     }
   }
-  if (R.sys) return *R.sys;
-  build_restoration_system(outer);
+  if (!R.sys) build_restoration_system(outer, /*host_only=*/false);
+  R.sys->finish_device();  // (a system compiled ahead has no device part yet)
   return *R.sys;
 }
 
@@ -1076,7 +1077,10 @@ NewtonSystem& restoration_system(NewtonSystem& outer) {
 // restoration problem out of the outer problem's callbacks); here it is a second compiled system — tape, KKT plan,
 // symbolic LDLT, upload: as long as a hundred interior-point iterations at N=300.  A solve of a model big enough
 // for that to matter therefore starts compiling it at once, on a thread of its own, while the outer iterations run on
-// the device: by the time the filter gives up on a step the system is (nearly) there.  Not with iteration callbacks
+// the device: by the time the filter gives up on a step the system is (nearly) there.  Only the HOST part — what
+// reads the expression graph: AD structure, tapes, KKT plan, symbolic LDLT, two thirds of the whole — so that a solve
+// that never enters restoration waits for milliseconds at its end, never for a hipRTC compilation of a kernel
+// nobody runs; device memory, uploads and the kernel come when restoration is entered.  Not with iteration callbacks
 // (a callback may evaluate expressions: the graph is appended to on the other thread), not for small models.
 // SLPX_RESTORATION_PREFETCH=0: off; =1: whatever the size.
 void restoration_prefetch(NewtonSystem& outer, bool has_callbacks) {
@@ -1086,7 +1090,7 @@ void restoration_prefetch(NewtonSystem& outer, bool has_callbacks) {
   bool on = st.m_e + st.m_i >= 512;
   if (const char* env = std::getenv("SLPX_RESTORATION_PREFETCH")) on = env[0] == '1' || (on && env[0] != '0');
   if (!on || st.m_e + st.m_i == 0) return;
-  R.prefetch = std::async(std::launch::async, [&outer] { build_restoration_system(outer); });
+  R.prefetch = std::async(std::launch::async, [&outer] { build_restoration_system(outer, /*host_only=*/true); });
 }
 // (before the solve hands the model back to its owner, who may go on building expressions)
 void restoration_prefetch_join(NewtonSystem& outer) {

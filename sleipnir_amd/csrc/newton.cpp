@@ -34,15 +34,17 @@ static LdltPlan plan_or_dense(const CscPattern& lhs, int n_dec, const LdltOption
 
 NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
                            const std::vector<NodeId>& c_e, const std::vector<NodeId>& c_i,
-                           const NewtonOptions& opt, const std::vector<int32_t>* user_perm)
+                           const NewtonOptions& opt, const std::vector<int32_t>* user_perm, bool defer_device)
     : m_opt(opt), m_graph(&g), m_x_nodes(x), m_ce_nodes(c_e), m_ci_nodes(c_i) {
   SetupLap lap;
   // the HIP runtime comes up (context, first allocation: 50-700 ms in a fresh process) while the
   // host compiles the model
-  auto device_job = std::async(std::launch::async, [device = opt.device] {
-    if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
-    (void)hipGetLastError();
-  });
+  std::future<void> device_job;
+  if (!defer_device)
+    device_job = std::async(std::launch::async, [device = opt.device] {
+      if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+      (void)hipGetLastError();
+    });
   // the KKT plan and the symbolic factorization (25 ms at N=1000) alongside the tape compiler
   auto plan_linear_algebra = [&](const NlpStructure& st) {
     m_k = build_kkt_plan(st);
@@ -106,10 +108,17 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   };
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
   lap("= AD structure + tape compile, KKT plan, LDLT symbolic");
-  device_job.get();
-  m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, opt.batch, opt.device);
-  lap("= device upload + tape JIT");
   reset_regularization();
+  if (defer_device) return;
+  device_job.get();
+  finish_device();
+}
+
+void NewtonSystem::finish_device() {
+  if (m_dev) return;
+  SetupLap lap;
+  m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, m_opt.device);
+  lap("= device upload + tape JIT");
 }
 
 NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const NewtonOptions& opt)

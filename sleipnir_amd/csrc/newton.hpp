@@ -37,7 +37,12 @@ class NewtonSystem {
  public:
   NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f, const std::vector<NodeId>& c_e,
                const std::vector<NodeId>& c_i, const NewtonOptions& opt,
-               const std::vector<int32_t>* user_perm = nullptr);
+               const std::vector<int32_t>* user_perm = nullptr, bool defer_device = false);
+  // `defer_device`: the constructor stops after the host part — AD structure, tapes, KKT plan, symbolic
+  // factorization: everything that reads the expression graph — and finish_device() does the rest (device
+  // memory, uploads, the generated tape kernel: from the caches or hipRTC) when the system is first needed.
+  bool has_device() const { return m_dev != nullptr; }
+  void finish_device();
 
   // Linear-solver seam only (RegularizedLDLT, util/regularized_ldlt.hpp:45-51, sparse
   // branch): no expression graph, no tape, no KKT assembly — just the lower-triangular CSC

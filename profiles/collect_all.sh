@@ -20,8 +20,8 @@ grep '^{' $O/bench_unprofiled.log | tail -1 > $N/${TAG}_bench_unprofiled.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $FAST > $O/bench_profiled.log 2> $O/bench_profiled.err
 grep '^{' $O/bench_profiled.log | tail -1 > $N/${TAG}_bench.json
 # 2. counters, each in its own pass
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 2 --repeats 1 --fixed-repeats $FAST > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 2 --repeats 1 --fixed-repeats $FAST > $O/pmc_write.log 2>&1
 python profiles/collect.py $TAG $O/prof $O/pmc_fetch $O/pmc_write > $O/collect.log 2>&1
 KT=$(ls $O/prof/*/*kernel_trace.csv | head -1)
 python profiles/timeline.py $KT > $N/${TAG}_step_timeline.txt 2>> $O/collect.log
@@ -33,8 +33,8 @@ for CFG in "N5000:--N 5000" "gfold:--workload gfold" "b64xN500:--workload batch5
   ARGS=${CFG#*:}
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py $ARGS --steps 50 --warmup 5 --repeats 3 $FAST > $O/bench_$NAME.log 2> $O/bench_$NAME.err
   grep '^{' $O/bench_$NAME.log | tail -1 > $N/${TAG}_${NAME}_bench.json
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_fetch_$NAME.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 $FAST > $O/pmc_write_$NAME.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 --fixed-repeats $FAST > $O/pmc_fetch_$NAME.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py $ARGS --steps 5 --warmup 1 --repeats 1 --fixed-repeats $FAST > $O/pmc_write_$NAME.log 2>&1
   python profiles/collect.py ${TAG}_$NAME $O/prof $O/pmc_fetch $O/pmc_write >> $O/collect.log 2>&1
   cp profiles/${TAG}_${NAME}_kernel_stats.csv profiles/${TAG}_${NAME}_traffic.json $N/
   rm -rf $O/prof $O/pmc_fetch $O/pmc_write
@@ -63,7 +63,7 @@ for v in all nosolve none; do cp $O/timeline_$v.txt $N/${TAG}_step_timeline_fuse
 } > $N/${TAG}_mf_ab.txt 2>&1
 # MFMA counters of the g-fold step with the matrix-core path on for every front of >= 128 entries: own pass, no trace
 rm -rf $O/pmc_mfma
-SLPX_MFMA_MIN_ENTRIES=128 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_mfma -- python bench.py --workload gfold --steps 20 --warmup 2 --repeats 1 $FAST > $O/pmc_mfma.log 2>&1
+SLPX_MFMA_MIN_ENTRIES=128 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_mfma -- python bench.py --workload gfold --steps 20 --warmup 2 --repeats 1 --fixed-repeats $FAST > $O/pmc_mfma.log 2>&1
 python profiles/mfma_counters.py $O/pmc_mfma > $N/${TAG}_gfold_mfma.json 2>> $O/collect.log
 rm -rf $O/pmc_mfma
 # 7. the round's measured experiments that stayed behind switches, and the small-batch probe

@@ -1533,7 +1533,11 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
                    ok ? "built" : "NOT built", P.mf_fronts.size() - 16, 2 * tab, arena, P.mf_max_nch, P.mf_n_contrib, P.n_contrib, P.mf_n_mfma);
     }
   } catch (const MfRefused& refused) {
-    if (std::getenv("SLPX_LDLT_VERBOSE")) std::fprintf(stderr, "ldlt multifrontal plan: NOT built (%s)\n", refused.why);
+    // (a consistency check of the fronts tripped: the pair-list plan takes over — a slower step, never a wrong one —
+    // and says so once, whatever the verbosity: a defect of the symbolic phase must not hide as a slow-down)
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true) || std::getenv("SLPX_LDLT_VERBOSE"))
+      std::fprintf(stderr, "slpx: the multifrontal plan of an order-%d system was refused (%s); the pair-list plan is used\n", n, refused.why);
     P.mf = false;
     P.mf_tasks.assign(ntasks, LdltMfTask{});
     P.mf_n_contrib = P.mf_max_nch = P.mf_max_front_rows = P.mf_n_mfma = 0;

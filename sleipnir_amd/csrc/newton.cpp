@@ -105,6 +105,15 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // Both rules are applied inside the build, after its first task partition (LdltOptions::single_problem_task_rules).
     lopt.single_problem_task_rules = opt.batch == 1 && std::getenv("SLPX_TASK_ENTRIES") == nullptr;
     m_l = plan_or_dense(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    if (lopt.multifrontal && !m_l.mf && !m_l.dense) {
+      // the fronts were not built (a limit of their addressing, or a refused plan): the pair-list kernels run this
+      // system, with THEIR tuning — chains from four columns, exact structures — not the fronts'
+      LdltOptions pair = opt.ldlt;
+      pair.task_entries = lopt.task_entries;
+      pair.supernodal = lopt.supernodal;
+      pair.single_problem_task_rules = false;
+      m_l = plan_or_dense(m_k.lhs, st.n, pair, user_perm, &diag_has_source);
+    }
   };
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
   lap("= AD structure + tape compile, KKT plan, LDLT symbolic");

@@ -172,3 +172,24 @@ def test_a_new_right_hand_side_through_the_fronts(fresh, slpx, orc, hostcheck, m
     resid = cases.lower_csc_matvec(lcp, lri, Kreg, p2) - b2
     assert np.max(np.abs(resid)) <= 1e-9 * max(1.0, float(np.max(np.abs(p2))) * float(np.max(np.abs(Kreg))))
     hc.close()
+
+
+def test_the_baseline_models_get_the_multifrontal_plan(fresh, slpx, orc, hostcheck, mf):
+    """A refused multifrontal plan (ldlt_symbolic.cpp: MfRefused, or a limit of the fronts' 16-bit addressing) degrades
+    to the pair-list plan: a slower step, and nothing else would tell.  The BASELINE configurations must not get there
+    (cart-pole N=1000 and N=5000, g-fold N=100)."""
+    from tests.support import gfold, model
+
+    for N in (1000, 5000):
+        slpx.lib().slpx_graph_reset()
+        orc.lib().orc_reset()
+        pp, _ = cases.build_pair("cart_pole", N, slpx, orc)
+        hc = hostcheck.HostCheck(pp)
+        plan = hc.mf_plan()
+        assert plan["built"] and plan["fronts"] > N, (N, plan)
+        hc.close()
+    mp = model.Model(model.ProductBackend("hostcheck"))
+    mp.be.reset()
+    hc = hostcheck.HostCheck(gfold.build(mp, 100).p)
+    assert hc.mf_plan()["built"]
+    hc.close()

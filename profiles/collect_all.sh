@@ -44,7 +44,7 @@ PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>
 PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
 PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
 for B in latency icache chain front; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
-PYTHONPATH=$R python profiles/setup_time.py 2>&1 | grep "^model\|^system\|= \|tape kernel" > $N/${TAG}_setup_time.txt
+PYTHONPATH=$R python profiles/setup_time.py 1000 5000 100 300 500 2>&1 | grep -v "tape family\|row group\|chunk\|tape: " > $N/${TAG}_setup_time.txt
 # 5. whole solves over the BASELINE horizons; the launch-fusion switches one by one
 PYTHONPATH=$R timeout 600 python profiles/horizon_sweep.py > $N/${TAG}_horizon_sweep.txt 2>&1
 bash profiles/ab_fuse.sh > $N/${TAG}_fusion_ab.txt 2>&1
@@ -79,7 +79,8 @@ bash profiles/solve_ab.sh > $N/${TAG}_solve_ab.txt 2>&1
 bash profiles/solve_kernel_stats.sh 500 $O/solve_prof > /dev/null 2>&1
 cp $O/solve_prof/solve500_kernel_stats.csv $N/${TAG}_solve500_kernel_stats.csv
 cp $O/solve_prof/solve500_timeline.txt $N/${TAG}_solve500_timeline.txt
-bash profiles/sn_deepest_ab.sh > $N/${TAG}_sn_deepest_ab.txt 2>&1
-bash profiles/sn_width_ab.sh > $N/${TAG}_sn_width_ab.txt 2>&1
+# (r05) the forward error of the step kernel over 24 seeded states; a new right-hand side through the fronts against the pair lists
+PYTHONPATH=$R timeout 900 python profiles/forward_error_sweep.py gpu 1000 24 > $N/${TAG}_forward_error_sweep_gpu.txt 2>&1
+PYTHONPATH=$R timeout 300 python profiles/mf_solve_time.py 100 500 1000 5000 > $N/${TAG}_mf_solve_time.txt 2>&1
 PYTHONPATH=$R timeout 300 python profiles/product_sensitivity.py 50 > $N/${TAG}_product_sensitivity_N50.txt 2>&1
 tail -3 $N/${TAG}_parity_errors.txt

@@ -25,6 +25,7 @@
 #include "ldlt_kernels.h"
 #include "ldlt_mf_kernels.h"
 #include "ldlt_dense_kernels.h"
+#include "setup_threads.hpp"
 #include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
 #include "ipm_kernels.h"
@@ -1279,53 +1280,68 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   // one copy loop with every load in flight is a single trip.
   uint32_t lds = 0;
   std::vector<uint4> image, desc(l.tasks.size());
-  std::vector<std::vector<unsigned char>> blobs;
+  // sizes first (the slots are of one size: the largest image), then every task's image written straight into its
+  // slot, the tasks in chunks on the setup threads
+  std::vector<uint32_t> blob_bytes(l.tasks.size());
+  size_t stride16 = 1;
   for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const LdltTask& t = l.tasks[ti];
-    const LdltMfTask& m = l.mf_tasks[ti];
-    const MfCarve cv = mf_carve(t, m);
+    const MfCarve cv = mf_carve(l.tasks[ti], l.mf_tasks[ti]);
     const uint32_t terms16 = m_h_task_terms[ti].y, bs16 = m_h_bs_task_plan[ti].y;
     const uint32_t n_terms = terms16 * 4u / 3u;
     const uint32_t end_terms = cv.o_terms + 16u * terms16;
     lds = std::max(lds, mf_align16(end_terms + 8u * n_terms) + 16u * bs16);
-    std::vector<unsigned char> blob(end_terms - cv.o_tab + 16u * bs16, 0);
-    auto put = [&](uint32_t at, const void* src, size_t bytes) {
-      if (at < cv.o_tab || at - cv.o_tab + bytes > blob.size()) throw std::runtime_error("slpx: task image layout out of bounds");
-      if (bytes) std::memcpy(blob.data() + (at - cv.o_tab), src, bytes);
-    };
-    put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
-    put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
-    put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
-    put(cv.o_src, m_h_vsrc.data() + t.ent_off, 4u * t.n_ent);
-    {
-      // (bit 5: the entry takes update slots)
-      std::vector<uint8_t> fl(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
-      for (uint32_t j = 0; j < m.n_cent; ++j) fl[l.mf_cent[m.cent_off + j]] |= 0x20;
-      put(cv.o_flags, fl.data(), t.n_ent);
-    }
-    put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
-    put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
-    put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
-    put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
-    put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
-    {
-      // the inertia counters start at zero, the smallest |d| at +inf
-      const unsigned long long inf = 0x7ff0000000000000ull;
-      put(cv.o_cnt + 16u, &inf, 8);
-    }
-    put(cv.o_terms, reinterpret_cast<const unsigned char*>(m_h_terms.data()) + 16u * static_cast<size_t>(m_h_task_terms[ti].x),
-        16u * terms16);
-    put(end_terms, reinterpret_cast<const unsigned char*>(m_h_bs_plan.data()) + 16u * static_cast<size_t>(m_h_bs_task_plan[ti].x),
-        16u * bs16);
+    blob_bytes[ti] = end_terms - cv.o_tab + 16u * bs16;
+    stride16 = std::max<size_t>(stride16, blob_bytes[ti] / 16u);
     desc[ti] = uint4{0u, (end_terms - cv.o_tab) / 16u, bs16, terms16};
-    blobs.push_back(std::move(blob));
   }
-  // fixed-size slots (the kernel requests a task's image before it knows its length) + one round of padding
-  size_t stride16 = 1;
-  for (auto& b : blobs) stride16 = std::max(stride16, b.size() / 16u);
   if (stride16 > kMfImageGroups) return;  // (a task image beyond what the staging loop requests)
-  image.assign(stride16 * blobs.size() + kMfImageGroups, uint4{0, 0, 0, 0});
-  for (size_t ti = 0; ti < blobs.size(); ++ti) std::memcpy(image.data() + ti * stride16, blobs[ti].data(), blobs[ti].size());
+  // fixed-size slots (the kernel requests a task's image before it knows its length) + one round of padding
+  image.assign(stride16 * l.tasks.size() + kMfImageGroups, uint4{0, 0, 0, 0});
+  std::atomic<bool> out_of_bounds{false};
+  parallel_chunks(l.tasks.size(), 8, [&](size_t t_begin, size_t t_end, unsigned) {
+    std::vector<uint8_t> fl;
+    for (size_t ti = t_begin; ti < t_end; ++ti) {
+      const LdltTask& t = l.tasks[ti];
+      const LdltMfTask& m = l.mf_tasks[ti];
+      const MfCarve cv = mf_carve(t, m);
+      const uint32_t terms16 = m_h_task_terms[ti].y, bs16 = m_h_bs_task_plan[ti].y;
+      const uint32_t end_terms = cv.o_terms + 16u * terms16;
+      unsigned char* blob = reinterpret_cast<unsigned char*>(image.data() + ti * stride16);
+      const size_t blob_size = blob_bytes[ti];
+      auto put = [&](uint32_t at, const void* src, size_t bytes) {
+        if (at < cv.o_tab || at - cv.o_tab + bytes > blob_size) {
+          out_of_bounds = true;
+          return;
+        }
+        if (bytes) std::memcpy(blob + (at - cv.o_tab), src, bytes);
+      };
+      put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
+      put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
+      put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
+      put(cv.o_src, m_h_vsrc.data() + t.ent_off, 4u * t.n_ent);
+      {
+        // (bit 5: the entry takes update slots)
+        fl.assign(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
+        for (uint32_t j = 0; j < m.n_cent; ++j) fl[l.mf_cent[m.cent_off + j]] |= 0x20;
+        put(cv.o_flags, fl.data(), t.n_ent);
+      }
+      put(cv.o_cent, l.mf_cent.data() + m.cent_off, 2u * m.n_cent);
+      put(cv.o_cptr, l.mf_contrib_ptr.data() + m.contrib_ptr_off, 4u * (m.n_cent + 1));
+      put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
+      put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
+      put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
+      {
+        // the inertia counters start at zero, the smallest |d| at +inf
+        const unsigned long long inf = 0x7ff0000000000000ull;
+        put(cv.o_cnt + 16u, &inf, 8);
+      }
+      put(cv.o_terms, reinterpret_cast<const unsigned char*>(m_h_terms.data()) + 16u * static_cast<size_t>(m_h_task_terms[ti].x),
+          16u * terms16);
+      put(end_terms, reinterpret_cast<const unsigned char*>(m_h_bs_plan.data()) + 16u * static_cast<size_t>(m_h_bs_task_plan[ti].x),
+          16u * bs16);
+    }
+  });
+  if (out_of_bounds) throw std::runtime_error("slpx: task image layout out of bounds");
   lds = mf_align16(lds) + 16u;
   int per_cu = 0, cus = 0;
   hipFuncAttributes attr{};

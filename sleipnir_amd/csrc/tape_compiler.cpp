@@ -112,11 +112,28 @@ struct FlatScratch {
   std::vector<int32_t> to_cg;     // graph node -> working-copy node, -1
   std::vector<int32_t> input_idx; // graph node -> tape input, -1
   int32_t n_inputs = 0;
-  FlatScratch(size_t G, const std::vector<std::pair<NodeId, int32_t>>& inputs) : seen(G, 0), to_cg(G, -1), input_idx(G, -1) {
+  const std::vector<std::pair<NodeId, int32_t>>* bound = nullptr;
+  FlatScratch() = default;
+  FlatScratch(size_t G, const std::vector<std::pair<NodeId, int32_t>>& inputs) { bind(G, inputs); }
+  // (the tables only grow; a thread that compiles model after model keeps them — and their pages — for good)
+  void bind(size_t G, const std::vector<std::pair<NodeId, int32_t>>& inputs) {
+    unbind();
+    if (seen.size() < G) {
+      seen.resize(G, 0);
+      to_cg.resize(G, -1);
+      input_idx.resize(G, -1);
+    }
+    n_inputs = 0;
     for (auto& [node, idx] : inputs) {
       input_idx[node] = idx;
       n_inputs = std::max(n_inputs, idx + 1);
     }
+    bound = &inputs;
+  }
+  void unbind() {
+    if (bound != nullptr)
+      for (auto& [node, idx] : *bound) input_idx[node] = -1;
+    bound = nullptr;
   }
 };
 
@@ -957,7 +974,17 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   SetupLap lap;
   const size_t G = g.size();
   constexpr uint8_t kReach = 1, kRoot = 2, kRepl = 4;
-  std::vector<uint8_t> flag(G, 0);
+  // (tables of one entry per graph node, kept by the thread between compilations: a fresh 20 MB of them was
+  // mostly page faults)
+  struct NodeTables {
+    std::vector<uint8_t> flag, depth;
+    std::vector<int32_t> parent, comp_of, input_idx;
+    std::vector<uint32_t> local;
+    FlatScratch flat;
+  };
+  static thread_local NodeTables tables;
+  std::vector<uint8_t>& flag = tables.flag;
+  flag.assign(G, 0);
   // ---- 1. reachable nodes, roots ----
   {
     std::vector<NodeId> stack;
@@ -984,7 +1011,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   lap("  tape families:   reach");
   auto is_leaf = [&](NodeId n) { return g.a0[n] == kNull; };
   // ---- components (children have smaller numbers than their parents: ascending order is children first) ----
-  std::vector<int32_t> parent(G);  // union-find over interior, not private nodes
+  std::vector<int32_t>& parent = tables.parent;  // union-find over interior, not private nodes
+  if (parent.size() < G) parent.resize(G);
   auto find = [&](int32_t x) {
     while (parent[x] != x) {
       parent[x] = parent[parent[x]];
@@ -993,7 +1021,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     return x;
   };
   {
-    std::vector<uint8_t> depth(G, 0);
+    std::vector<uint8_t>& depth = tables.depth;
+    depth.assign(G, 0);
     for (size_t n = 0; n < G; ++n) {
       parent[n] = static_cast<int32_t>(n);
       if (!(flag[n] & kReach) || is_leaf(static_cast<NodeId>(n))) continue;
@@ -1022,7 +1051,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   }
   lap("  tape families:   union");
   // component numbers in order of their smallest node; members by component, ascending
-  std::vector<int32_t> comp_of(G, -1);
+  std::vector<int32_t>& comp_of = tables.comp_of;
+  comp_of.assign(G, -1);
   std::vector<uint32_t> comp_start{0};
   std::vector<NodeId> members;
   {
@@ -1079,7 +1109,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   lap("  tape families: components");
 
   // ---- 2. every component's sequence ----
-  std::vector<int32_t> input_idx(G, -1);
+  std::vector<int32_t>& input_idx = tables.input_idx;
+  input_idx.assign(G, -1);
   int32_t n_inputs = 0;
   for (auto& [node, idx] : inputs) {
     input_idx[node] = idx;
@@ -1238,7 +1269,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       ch = Chunk{};
     }
   }
-  std::vector<uint32_t> local(G, 0);  // (scratch of the passes below)
+  std::vector<uint32_t>& local = tables.local;  // (scratch of the passes below)
+  if (local.size() < G) local.resize(G, 0);
   lap("  tape families: sequences");
 
   // ---- families: equal sequences ----
@@ -1273,7 +1305,12 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   lap("  tape families: classes");
 
   // ---- 3. one member of every family through the flat compiler ----
-  FlatScratch flat_scratch(G, inputs);
+  FlatScratch& flat_scratch = tables.flat;
+  flat_scratch.bind(G, inputs);
+  struct Unbind {
+    FlatScratch& f;
+    ~Unbind() { f.unbind(); }
+  } unbind_flat{flat_scratch};
   struct Accepted {
     uint32_t fam;
     TapeProgram prog;

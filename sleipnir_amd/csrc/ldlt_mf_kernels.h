@@ -915,6 +915,9 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
 // and taken; the others stay armed) and through x itself (backward).  The pair-list kernels took two launches and
 // 24 + 17.5 us for this at cart-pole N=500 (ldlt_fwd_kernel, ldlt_bwd_kernel on L in memory).
 // ---------------------------------------------------------------------------
+// (laid out like mf_front_w: every table word first, then every value — a lane per pivot column for the row's own
+// entries and their couplings, a lane per row of R for the update block —, then the chain with v_readlane broadcasts:
+// three dependent trips to LDS and w steps, where a lane walking the chain alone made ~40 trips)
 __device__ __forceinline__ void mf_fwd_front(uint32_t tab, uint32_t w, uint32_t nr, uint32_t nch, uint32_t root, uint32_t invd_addr,
                                              const uint32_t* __restrict__ ext, double* __restrict__ contrib, uint32_t lane) {
   tab = __builtin_amdgcn_readfirstlane(tab);
@@ -923,38 +926,60 @@ __device__ __forceinline__ void mf_fwd_front(uint32_t tab, uint32_t w, uint32_t 
   nch = __builtin_amdgcn_readfirstlane(nch);
   root = __builtin_amdgcn_readfirstlane(root);
   invd_addr = __builtin_amdgcn_readfirstlane(invd_addr);
-  const uint32_t stride = 2u * w * (1u + nch);  // bytes of a row of the pivot table
+  constexpr int W = static_cast<int>(kSnWidthMax);
+  const uint32_t stride = 2u * w * (1u + nch);     // bytes of a row of the pivot table
   const uint32_t prow = tab + (nr - 1u) * stride;  // the right-hand-side row
   const uint32_t r = nr - w - 1u;
-  // the row's entries of the pivot columns: every lane the same (uniform addresses: broadcast reads)
-  double ub[kSnWidthMax], li[kSnWidthMax];
+  const uint32_t c = lane < w ? lane : w - 1u;     // (idle lanes shadow the last column: same loads, no stores)
+  const uint32_t b = lane < r ? lane : (r ? r - 1u : 0u);
+  const uint32_t upd = tab + nr * stride, ustride = 2u * (3u + nch);
+  const uint32_t ur = upd + __umul24((r * (r + 1u)) / 2u + b, ustride);
+  // ---- trip 1: table words ----
+  const uint32_t own = lds_ld16(prow + 2u * c);
+  uint32_t cua[W - 1];
 #pragma unroll
-  for (int c = 0; c < static_cast<int>(kSnWidthMax); ++c) {
-    ub[c] = 0.0;
-    li[c] = 0.0;
-    if (static_cast<uint32_t>(c) < w) {
-      const uint32_t own = lds_ld16(prow + 2u * c);
-      double v = lds_ld(own);
-      for (uint32_t k = 1; k <= nch; ++k) v += lds_ld(lds_ld16(prow + 2u * (w * k + c)));
+  for (int c2 = 0; c2 < W - 1; ++c2) {
+    const uint32_t cc = static_cast<uint32_t>(c2) < c ? static_cast<uint32_t>(c2) : 0u;
+    cua[c2] = lds_ld16(tab + c * stride + 2u * cc);  // U(c, c2): row c of finished column c2 (c2 < c; else unused)
+  }
+  uint32_t o = 0, pb = 0;
+  if (r) {
+    o = lds_ld16(ur);
+    pb = lds_ld16(ur + 4u);
+  }
+  // ---- trip 2: values ----
+  double v = lds_ld(own);
+  const double inv = lds_ld(invd_addr + 8u * c);
+  double cu[W - 1];
 #pragma unroll
-      for (int c2 = 0; c2 < c; ++c2)  // U(c, c2): row c (a pivot column's own row) of finished column c2
-        v = __builtin_fma(-li[c2], lds_ld(lds_ld16(tab + static_cast<uint32_t>(c) * stride + 2u * c2)), v);
-      ub[c] = v;
-      li[c] = v * lds_ld(invd_addr + 8u * c);
-      if (lane == 0) lds_st(own, v);
+  for (int c2 = 0; c2 < W - 1; ++c2) cu[c2] = lds_ld(cua[c2]);
+  double rb[W];
+#pragma unroll
+  for (int cc = 0; cc < W; ++cc) rb[cc] = (r && static_cast<uint32_t>(cc) < w) ? lds_ld(pb + mf_coff(static_cast<uint32_t>(cc), nr)) : 0.0;
+  double acc = 0.0;
+  for (uint32_t k = 1; k <= nch; ++k) {  // the children's values: of the row's entries, of its part of the update block
+    const uint32_t ca = lds_ld16(prow + 2u * (w * k + c));
+    const uint32_t sa = r ? lds_ld16(ur + 4u + 2u * k) : ca;
+    v += lds_ld(ca);
+    if (r) acc += lds_ld(sa);
+  }
+  // ---- the chain: column c2 is final once the columns before it are in ----
+  double li[W];
+#pragma unroll
+  for (int c2 = 0; c2 < W; ++c2) {
+    li[c2] = 0.0;
+    if (static_cast<uint32_t>(c2) < w) {
+      const double l = readlane_f64(v, c2) * readlane_f64(inv, c2);
+      li[c2] = l;
+      if (c2 < W - 1 && lane > static_cast<uint32_t>(c2) && lane < w) v = __builtin_fma(-l, cu[c2 < W - 1 ? c2 : 0], v);
     }
   }
+  if (lane < w) lds_st(own, v);
   if (lane < r) {  // its part of the update block: entry (rhs row, R_lane)
-    const uint32_t upd = tab + nr * stride, ustride = 2u * (3u + nch);
-    const uint32_t ur = upd + __umul24((r * (r + 1u)) / 2u + lane, ustride);
-    const uint32_t o = lds_ld16(ur), pb = lds_ld16(ur + 4u);
-    double v = 0.0;
-    for (uint32_t k = 0; k < nch; ++k) v += lds_ld(lds_ld16(ur + 6u + 2u * k));
 #pragma unroll
-    for (int c = 0; c < static_cast<int>(kSnWidthMax); ++c)
-      if (static_cast<uint32_t>(c) < w) v = __builtin_fma(-li[c], lds_ld(pb + mf_coff(c, nr)), v);
-    if (root & 1u) coherent_store(&contrib[ext[o]], -v, true);
-    else lds_st(o, v);
+    for (int cc = 0; cc < W; ++cc) acc = __builtin_fma(-li[cc], rb[cc], acc);
+    if (root & 1u) coherent_store(&contrib[ext[o]], -acc, true);
+    else lds_st(o, acc);
   }
 }
 

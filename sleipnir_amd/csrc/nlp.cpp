@@ -455,7 +455,10 @@ NlpStructure build_nlp_structure(Graph& g, const std::vector<NodeId>& x, NodeId 
   // the two tapes only read the graph: the small one (values only) compiles on a second thread
   // (SLPX_SETUP_THREADS=1: one after the other on this thread — the phase times then add up)
   const auto policy = SetupPool::get().threads() > 1 ? std::launch::async : std::launch::deferred;
-  auto values_job = std::async(policy, [&] { return compile_tape(g, inputs, live_vouts, {}, opt); });
+  auto values_job = std::async(policy, [&] {
+    SetupPool::InlineScope leave_the_pool_to_the_full_tape;
+    return compile_tape(g, inputs, live_vouts, {}, opt);
+  });
   std::future<void> patterns_job;
   if (on_patterns) patterns_job = std::async(policy, [&] { on_patterns(s); });
   s.full = compile_tape(g, inputs, live_vouts, rows, opt);

@@ -25,6 +25,13 @@ class SetupPool {
     return pool;
   }
   unsigned threads() const { return m_threads; }
+  // For the lifetime of one of these the calling thread runs its parallel regions itself, in order (a side job
+  // that should leave the pool to the job on the critical path: the values-only tape beside the full one).
+  struct InlineScope {
+    bool was;
+    InlineScope() : was(t_inside) { t_inside = true; }
+    ~InlineScope() { t_inside = was; }
+  };
 
   // runs job(k) for k in [0, count) on the pool's threads and the caller's; returns when all are done.
   // Nested calls (a job that calls run) execute inline on the calling thread.

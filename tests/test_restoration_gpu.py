@@ -105,3 +105,26 @@ def test_whole_solve_status_at_baseline_horizons(fresh, slpx, orc, N):
         assert np.max(np.abs(X[:, 0])) <= 1e-6 and np.max(np.abs(X[:, -1] - np.array([1.0, np.pi, 0.0, 0.0]))) <= 1e-6
         assert np.max(np.abs(U)) <= 20.0 + 1e-6
     pp.close()
+
+
+@pytest.mark.parametrize("N", [300, 50])
+def test_the_restoration_system_compiled_ahead_changes_nothing_but_the_time(fresh, slpx, monkeypatch, N):
+    """ipm.cpp: restoration_prefetch — the host part of the restoration system is compiled on a thread of its own
+    from the start of the solve (models with 512 constraints and more; SLPX_RESTORATION_PREFETCH=1: any size), its device
+    part when restoration is entered.  Cart-pole N=300 enters restoration once, N=50 twenty times: the same exit
+    status, iteration and factorization counts and the same solution TO THE BIT with the switch off, on and forced."""
+    from tests.support import models
+
+    seen = []
+    for env in ("0", None, "1"):
+        if env is None:
+            monkeypatch.delenv("SLPX_RESTORATION_PREFETCH", raising=False)
+        else:
+            monkeypatch.setenv("SLPX_RESTORATION_PREFETCH", env)
+        slpx.lib().slpx_graph_reset()
+        pp = models.cart_pole(N, 5.0 / N)
+        st, rep = pp.solve()
+        seen.append((st, rep["iterations"], rep["factorizations"], rep["restorations"], pp.get_x().tobytes()))
+        assert rep["restorations"] >= 1
+        pp.close()
+    assert seen[0] == seen[1] == seen[2], [(s[0], s[1], s[2], s[3]) for s in seen]

@@ -243,7 +243,13 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
       ropt.n_unscaled_inputs = static_cast<uint32_t>(rs.n);
       const int ra = slpx::prebuild_tape_templates(rs.full, ropt, where, log);
       const int rb = slpx::prebuild_tape_templates(rs.values, ropt, where, log);
-      if (ra < 0 || rb < 0) throw std::runtime_error("slpx_problem_prebuild_kernels (restoration): " + log);
+      // (a restoration system small enough for chained steps — up to a few hundred stages — loads the chained
+      // variant of its full sweep, as the outer system does: without it the first restoration of a fresh machine
+      // waited 0.6 s for hipRTC, profiles/r04_horizon_sweep.txt N=50)
+      slpx::TapeJitOptions rcopt = ropt;
+      rcopt.chain_mode = 1;
+      const int rc = slpx::prebuild_tape_templates(rs.full, rcopt, where, log);
+      if (ra < 0 || rb < 0 || rc < 0) throw std::runtime_error("slpx_problem_prebuild_kernels (restoration): " + log);
       bodies += ra + rb;
     }
   });

@@ -73,3 +73,38 @@ def test_single_shooting_solve_matches_the_oracle_gpu(fresh, slpx, N, with_eq):
     assert abs(xp[-1] - shooting.R) <= (1e-6 if with_eq else 1e-2)
     # bang, then hold: the first input at its bound, the last near the steady-state value r
     assert abs(up[0] - shooting.U_MAX) <= 1e-3 and abs(up[-2] - shooting.R) <= 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3, 70])
+def test_linear_solver_seam_on_the_dense_branch(monkeypatch, batch):
+    """slpx_ldlt_create / set_matrix / compute / solve (RegularizedLDLT with use_sparse = false,
+    util/regularized_ldlt.hpp:45-87) on the dense kernels, single and batched (a workgroup per problem): a
+    quasidefinite matrix needs no regularization, an indefinite Hessian is regularized to the ideal inertia — against
+    dense numpy solves of the regularized matrices."""
+    import sleipnir_amd as sa
+    from tests.test_linear_solver_gpu import _check_solution, _kkt
+
+    monkeypatch.setenv("SLPX_DENSE", "1")
+    rng = np.random.default_rng(31)
+    n, m_e = 48, 20
+    for definite in (True, False):
+        K, colptr, rowidx, vals = _kkt(rng, n, m_e, definite=definite, c22=1e-2 if definite else 0.0)
+        scale = 1.0 + 0.1 * rng.random((batch, 1))
+        ls = sa.System.linear_solver(n, m_e, colptr, rowidx, batch=batch)
+        assert ls.info["ldlt_dense"] == 1
+        ls.reset_regularization(1e-10)
+        ls.set_matrix(vals[None, :] * scale)
+        info, reg, nfact = ls.compute()
+        assert (info == 0).all()
+        if definite:
+            assert nfact == 1 and np.all(reg == 0.0)
+        else:
+            assert np.all(reg[:, 0] > 0.0)
+        rhs = rng.standard_normal((batch, n + m_e))
+        ls.set_rhs(rhs)
+        ls.solve()
+        x = ls.get("p")
+        for b in sorted({0, batch // 2, batch - 1}):
+            _check_solution(K * scale[b, 0], n, reg[b], rhs[b], x[b])
+        ls.close()

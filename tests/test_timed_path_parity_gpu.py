@@ -173,7 +173,9 @@ def test_a_new_right_hand_side_through_the_fronts(fresh, slpx, orc, monkeypatch,
     other = slpx.System(pp, batch=1, device=0)
     monkeypatch.delenv("SLPX_MF_SOLVE")
     try:
-        assert system.info["ldlt_multifrontal"] == 1
+        # (under an outer switch that takes the fronts away — the switch matrix — both systems solve on the pair lists:
+        # the residual checks below still hold)
+        assert cases.OUTER_SWITCHES or system.info["ldlt_multifrontal"] == 1
         n, me, mi = system.info["n"], system.info["m_e"], system.info["m_i"]
         scales = op.scaling()
         state = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])

@@ -125,6 +125,8 @@ def test_the_restoration_system_compiled_ahead_changes_nothing_but_the_time(fres
         pp = models.cart_pole(N, 5.0 / N)
         st, rep = pp.solve()
         seen.append((st, rep["iterations"], rep["factorizations"], rep["restorations"], pp.get_x().tobytes()))
-        assert rep["restorations"] >= 1
+        # (on the default path both horizons enter restoration; under an outer switch — the switch matrix — the
+        # solve takes another path and may not: the bit equality is asserted either way)
+        assert cases.OUTER_SWITCHES or rep["restorations"] >= 1
         pp.close()
     assert seen[0] == seen[1] == seen[2], [(s[0], s[1], s[2], s[3]) for s in seen]

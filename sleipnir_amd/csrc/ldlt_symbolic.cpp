@@ -762,17 +762,20 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   std::vector<uint32_t> task_ent_base(ntasks + 1, 0);
   for (int t = 0; t < ntasks; ++t) task_ent_base[t + 1] = task_ent_base[t] + task_nent[t];
   const uint32_t total_ent = task_ent_base[ntasks];
-  // (bucket, pair) in the order the pairs are found; a stable counting sort by bucket afterwards
-  std::vector<std::pair<uint32_t, LdltPair>> own_found, ext_found;
-  own_found.reserve(static_cast<size_t>(P.nnzL) * 4);
-  // a pseudo entry = (source task, receiving entry): numbered in the order of their first pair, which is also
-  // their slot in the contribution buffer
-  std::vector<uint32_t> ext_task, ext_target;  // by slot: source task, receiving entry (global)
-  struct SlotTable {  // open addressing, key = source task << 32 | receiving entry
+  // Every pair is found by the task of its column k, the columns of a task in ascending order — the order the
+  // single pass over all columns found them in, restricted to the task: the tasks in chunks on the setup threads.
+  // A pseudo entry = (source task, receiving entry), numbered in the order of their first pair OVER ALL COLUMNS — also
+  // their slot in the contribution buffer: the tasks note the column that made each of theirs, the numbers are handed
+  // out afterwards by one walk over the columns.
+  struct SlotTable {  // open addressing, key = receiving entry (global)
     std::vector<uint64_t> keys;
     std::vector<uint32_t> vals;
     size_t used = 0, mask = 0;
-    SlotTable() { grow(1u << 12); }
+    SlotTable() { grow(1u << 10); }
+    void clear() {
+      std::fill(keys.begin(), keys.end(), ~0ull);
+      used = 0;
+    }
     void grow(size_t cap) {
       std::vector<uint64_t> ok;
       std::vector<uint32_t> ov;
@@ -805,68 +808,128 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       used += fresh;
       return r.second;
     }
-  } slots;
-
-  for (int k = 0; k < n; ++k) {
-    const int tk = task_of[k];
-    const int32_t* rows = P.Li.data() + P.Lp[k];
-    const int c = P.Lp[k + 1] - P.Lp[k];
-    for (int a = 0; a < c; ++a) {
-      const int32_t j = rows[a];  // target column
-      const int tj = task_of[j];
-      const uint32_t ent_jk = lent[P.Lp[k] + a];
-      // updates between two columns of one supernode are done in registers (ldlt_kernels.h)
-      if (sn_of[k] == sn_of[j]) continue;
-      const uint32_t base_j = task_ent_base[tj];
-      auto add_pair = [&](uint32_t target, const LdltPair& pr) {
-        if (tk == tj) {
-          own_found.emplace_back(base_j + target, pr);
-        } else {
-          bool fresh;
-          uint32_t* slot = slots.insert((static_cast<uint64_t>(tk) << 32) | (base_j + target), fresh);
-          if (fresh) {
-            *slot = P.n_contrib++;
-            ext_task.push_back(static_cast<uint32_t>(tk));
-            ext_target.push_back(base_j + target);
+  };
+  struct TaskPairs {
+    std::vector<std::pair<uint32_t, LdltPair>> own, ext;  // (local entry | local pseudo entry, pair) as found
+    std::vector<uint32_t> ext_target;                     // per local pseudo entry: receiving entry (global)
+    std::vector<int32_t> ext_made_at;                     // ... and the column whose pair made it
+    std::vector<uint32_t> ext_slot;                       // ... and its number (filled below)
+  };
+  std::vector<TaskPairs> tp(ntasks);
+  std::vector<int32_t> cols_ptr(ntasks + 1, 0), cols_asc(n);  // the columns of a task, ascending
+  for (int k = 0; k < n; ++k) ++cols_ptr[task_of[k] + 1];
+  for (int t = 0; t < ntasks; ++t) cols_ptr[t + 1] += cols_ptr[t];
+  {
+    std::vector<int32_t> next(cols_ptr.begin(), cols_ptr.end() - 1);
+    for (int k = 0; k < n; ++k) cols_asc[next[task_of[k]]++] = k;
+  }
+  std::atomic<bool> inconsistent{false};
+  parallel_chunks(static_cast<size_t>(ntasks), 4, [&](size_t t_begin, size_t t_end, unsigned) {
+    SlotTable slots;
+    for (size_t tt = t_begin; tt < t_end; ++tt) {
+      const int tk = static_cast<int>(tt);
+      TaskPairs& T = tp[tt];
+      slots.clear();
+      for (int32_t ck = cols_ptr[tt]; ck < cols_ptr[tt + 1]; ++ck) {
+        const int k = cols_asc[ck];
+        const int32_t* rows = P.Li.data() + P.Lp[k];
+        const int c = P.Lp[k + 1] - P.Lp[k];
+        for (int a = 0; a < c; ++a) {
+          const int32_t j = rows[a];  // target column
+          const int tj = task_of[j];
+          const uint32_t ent_jk = lent[P.Lp[k] + a];
+          // updates between two columns of one supernode are done in registers (ldlt_kernels.h)
+          if (sn_of[k] == sn_of[j]) continue;
+          const uint32_t base_j = task_ent_base[tj];
+          auto add_pair = [&](uint32_t target, const LdltPair& pr) {
+            if (tk == tj) {
+              T.own.emplace_back(target, pr);
+            } else {
+              bool fresh;
+              uint32_t* slot = slots.insert(base_j + target, fresh);
+              if (fresh) {
+                *slot = static_cast<uint32_t>(T.ext_target.size());
+                T.ext_target.push_back(base_j + target);
+                T.ext_made_at.push_back(k);
+              }
+              T.ext.emplace_back(*slot, pr);
+            }
+          };
+          // rhs row: U_b(j) -= U_b(k) · U(j,k) / d_k
+          add_pair(bent[j], LdltPair{static_cast<uint16_t>(bent[k]), static_cast<uint16_t>(ent_jk),
+                                     static_cast<uint16_t>(lcol[k]), 0});
+          int32_t q = P.Lp[j];  // walk column j's rows
+          for (int b = a; b < c; ++b) {
+            const int32_t i = rows[b];
+            uint32_t target;
+            if (b == a) {
+              target = diag_ent[j];
+            } else {
+              while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
+              if (q >= P.Lp[j + 1]) {
+                inconsistent = true;
+                return;
+              }
+              target = lent[q];
+            }
+            add_pair(target, LdltPair{static_cast<uint16_t>(lent[P.Lp[k] + b]),
+                                      static_cast<uint16_t>(ent_jk), static_cast<uint16_t>(lcol[k]), 0});
           }
-          ext_found.emplace_back(*slot, pr);
         }
-      };
-      // rhs row: U_b(j) -= U_b(k) · U(j,k) / d_k
-      add_pair(bent[j], LdltPair{static_cast<uint16_t>(bent[k]), static_cast<uint16_t>(ent_jk),
-                                 static_cast<uint16_t>(lcol[k]), 0});
-      int32_t q = P.Lp[j];  // walk column j's rows
-      for (int b = a; b < c; ++b) {
-        const int32_t i = rows[b];
-        uint32_t target;
-        if (b == a) {
-          target = diag_ent[j];
-        } else {
-          while (q < P.Lp[j + 1] && P.Li[q] != i) ++q;
-          if (q >= P.Lp[j + 1]) throw std::runtime_error("ldlt: fill pattern inconsistency");
-          target = lent[q];
-        }
-        add_pair(target, LdltPair{static_cast<uint16_t>(lent[P.Lp[k] + b]),
-                                  static_cast<uint16_t>(ent_jk), static_cast<uint16_t>(lcol[k]), 0});
+      }
+    }
+  });
+  if (inconsistent) throw std::runtime_error("ldlt: fill pattern inconsistency");
+  // the pseudo entries' numbers: in the order of the columns that made them (within a column: the order its task
+  // made them in)
+  std::vector<uint32_t> ext_task, ext_target;  // by slot: source task, receiving entry (global)
+  {
+    std::vector<uint32_t> cursor(ntasks, 0);
+    for (int t = 0; t < ntasks; ++t) tp[t].ext_slot.resize(tp[t].ext_target.size());
+    for (int k = 0; k < n; ++k) {
+      const int t = task_of[k];
+      TaskPairs& T = tp[t];
+      uint32_t& cur = cursor[t];
+      while (cur < T.ext_made_at.size() && T.ext_made_at[cur] == k) {
+        T.ext_slot[cur] = P.n_contrib++;
+        ext_task.push_back(static_cast<uint32_t>(t));
+        ext_target.push_back(T.ext_target[cur]);
+        ++cur;
       }
     }
   }
-  // stable counting sorts: pairs of an entry / of a pseudo entry in the order they were found
-  auto sort_pairs = [](const std::vector<std::pair<uint32_t, LdltPair>>& found, size_t buckets, std::vector<uint32_t>& ptr,
-                       std::vector<LdltPair>& out) {
-    ptr.assign(buckets + 1, 0);
-    for (auto& f : found) ++ptr[f.first + 1];
-    for (size_t i = 0; i < buckets; ++i) ptr[i + 1] += ptr[i];
-    out.resize(found.size());
-    std::vector<uint32_t> next(ptr.begin(), ptr.end() - 1);
-    for (auto& f : found) out[next[f.first]++] = f.second;
-  };
-  std::vector<uint32_t> own_ptr, extp_ptr;
-  std::vector<LdltPair> own_pairs, extp;
-  sort_pairs(own_found, total_ent, own_ptr, own_pairs);
-  sort_pairs(ext_found, P.n_contrib, extp_ptr, extp);
-  own_found = {};
-  ext_found = {};
+  // stable counting sorts: the pairs of an entry / of a pseudo entry in the order they were found — entries of a
+  // task are consecutive, the pairs of a pseudo entry all its task's: every task writes its own ranges
+  std::vector<uint32_t> own_ptr(total_ent + 1, 0), extp_ptr(P.n_contrib + 1, 0);
+  std::vector<uint64_t> own_base(ntasks + 1, 0);
+  for (int t = 0; t < ntasks; ++t) own_base[t + 1] = own_base[t] + tp[t].own.size();
+  for (int t = 0; t < ntasks; ++t) {
+    const TaskPairs& T = tp[t];
+    std::vector<uint32_t> cnt(T.ext_target.size(), 0);
+    for (auto& f : T.ext) ++cnt[f.first];
+    for (size_t x = 0; x < cnt.size(); ++x) extp_ptr[T.ext_slot[x] + 1] = cnt[x];
+  }
+  for (uint32_t d = 0; d < P.n_contrib; ++d) extp_ptr[d + 1] += extp_ptr[d];
+  std::vector<LdltPair> own_pairs(static_cast<size_t>(own_base[ntasks])), extp(extp_ptr[P.n_contrib]);
+  parallel_chunks(static_cast<size_t>(ntasks), 4, [&](size_t t_begin, size_t t_end, unsigned) {
+    std::vector<uint32_t> next;
+    for (size_t tt = t_begin; tt < t_end; ++tt) {
+      TaskPairs& T = tp[tt];
+      const uint32_t base = task_ent_base[tt], ne = task_nent[tt];
+      next.assign(ne + 1, 0);
+      for (auto& f : T.own) ++next[f.first + 1];
+      for (uint32_t e = 0; e < ne; ++e) next[e + 1] += next[e];
+      const uint32_t first = static_cast<uint32_t>(own_base[tt]);
+      for (uint32_t e = 0; e < ne; ++e) own_ptr[base + e] = first + next[e];
+      for (auto& f : T.own) own_pairs[first + next[f.first]++] = f.second;
+      next.assign(T.ext_target.size(), 0);
+      for (size_t x = 0; x < next.size(); ++x) next[x] = extp_ptr[T.ext_slot[x]];
+      for (auto& f : T.ext) extp[next[f.first]++] = f.second;
+      T.own = {};
+      T.ext = {};
+    }
+  });
+  own_ptr[total_ent] = static_cast<uint32_t>(own_base[ntasks]);
   // the pseudo entries of a task (ascending slot = the order they were made in); the slots an entry takes
   std::vector<uint32_t> task_ext_ptr(ntasks + 1, 0), task_ext(P.n_contrib), ec_ptr(total_ent + 1, 0), ec(P.n_contrib);
   for (uint32_t d = 0; d < P.n_contrib; ++d) {
@@ -882,6 +945,7 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       ec[en[ext_target[d]]++] = d;
     }
   }
+  tp = {};
 
   lap("  ldlt: entries, pair lists");
   // ---- solve lists ---------------------------------------------------------------
@@ -978,9 +1042,182 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
   for (int t = 0; t < ntasks; ++t) ++P.round_ptr[tcols[t].round + 1];
   for (int r = 0; r < P.n_rounds; ++r) P.round_ptr[r + 1] += P.round_ptr[r];
 
-  for (int t : torder) {
-    // 16-byte alignment of every per-task slice (the kernels stage them into LDS with
-    // unrolled 16-byte loads)
+  // Every task's slices into a plan of its own (the same member names), the tasks in chunks on the setup threads;
+  // joined below in round order with the alignment padding in front of every slice.
+  std::vector<LdltPlan> flat(ntasks);
+  parallel_chunks(static_cast<size_t>(ntasks), 4, [&](size_t ti_begin, size_t ti_end, unsigned) {
+    for (size_t ti = ti_begin; ti < ti_end; ++ti) {
+      const int t = torder[ti];
+      LdltPlan& O = flat[ti];
+      // 16-byte alignment of every per-task slice (the kernels stage them into LDS with
+      // unrolled 16-byte loads)
+      auto pad = [](auto& v, size_t multiple) {
+        while (v.size() % multiple) v.push_back({});
+      };
+      while (O.ent_src.size() % 16) {
+        O.ent_src.push_back(-1);
+        O.ent_flags.push_back(0);
+        O.ent_col.push_back(0);
+        O.ent_out.push_back(0);
+      }
+      pad(O.pairs, 2);
+      pad(O.ent_pair_ptr, 4);
+      pad(O.ent_contrib_ptr, 4);
+      while (O.lvl_ptr.size() % 4) {
+        O.lvl_ptr.push_back(0);
+        O.col_lvl_ptr.push_back(0);
+      }
+      pad(O.col_perm, 4);
+      while (O.fwd_ptr.size() % 4) {
+        O.fwd_ptr.push_back(0);
+        O.fwd_contrib_ptr.push_back(0);
+        O.bwd_ptr.push_back(0);
+      }
+      pad(O.fwd_items, 2);
+      pad(O.bwd_items, 2);
+      pad(O.sn_desc, 4);  // 12-byte records: four of them are three 16-byte groups
+      pad(O.col_sn, 4);
+      pad(O.sn_lvl_ptr, 4);
+      LdltTask T{};
+      const auto& cols = tcols[t].cols;
+      T.round = static_cast<uint32_t>(tcols[t].round);
+      T.n_col = static_cast<uint32_t>(cols.size());
+      T.n_ent = task_nent[t];
+      T.n_ext = task_ext_ptr[t + 1] - task_ext_ptr[t];
+      T.ent_off = static_cast<uint32_t>(O.ent_src.size());
+      T.col_off = static_cast<uint32_t>(O.col_perm.size());
+      T.lvl_off = static_cast<uint32_t>(O.lvl_ptr.size());
+      T.ext_off = static_cast<uint32_t>(O.ext_dst.size());
+      T.pair_off = static_cast<uint32_t>(O.pairs.size());
+      T.contrib_off = static_cast<uint32_t>(O.contrib_idx.size());
+      T.fwd_item_off = static_cast<uint32_t>(O.fwd_items.size());
+      T.bwd_item_off = static_cast<uint32_t>(O.bwd_items.size());
+      T.sext_off = static_cast<uint32_t>(O.sext_dst.size());
+      T.n_sext = task_sext_ptr[t + 1] - task_sext_ptr[t];
+      T.sext_item_off = static_cast<uint32_t>(O.sext_items.size());
+      T.scontrib_off = static_cast<uint32_t>(O.scontrib_idx.size());
+      T.pair_ptr_off = static_cast<uint32_t>(O.ent_pair_ptr.size());
+      T.contrib_ptr_off = static_cast<uint32_t>(O.ent_contrib_ptr.size());
+      T.colptr_off = static_cast<uint32_t>(O.fwd_ptr.size());
+      T.sext_ptr_off = static_cast<uint32_t>(O.sext_ptr.size());
+      T.sn_off = static_cast<uint32_t>(O.sn_desc.size());
+      if (O.col_sn.size() != O.col_perm.size() || O.sn_lvl_ptr.size() != O.lvl_ptr.size())
+        throw std::runtime_error("ldlt: supernode arrays out of step with the column arrays");
+
+      int32_t cur_level = -1;
+      uint32_t pair_count = 0, contrib_count = 0, fwd_count = 0, bwd_count = 0, sc_count = 0;
+      for (size_t ci = 0; ci < cols.size(); ++ci) {
+        const int32_t j = cols[ci];
+        if (tlevel[j] != cur_level) {
+          O.lvl_ptr.push_back(diag_ent[j]);
+          O.col_lvl_ptr.push_back(static_cast<uint32_t>(ci));
+          O.sn_lvl_ptr.push_back(static_cast<uint32_t>(O.sn_desc.size()) - T.sn_off);
+          cur_level = tlevel[j];
+        }
+        O.col_perm.push_back(static_cast<uint32_t>(j));
+        const uint32_t w = static_cast<uint32_t>(sn_width(j)), pos = static_cast<uint32_t>(sn_pos[j]);
+        O.col_sn.push_back(pos | (w << 8));
+        if (w >= 2 && pos == 0) {
+          // rows of the trapezoid: the chain, the common structure below it, the rhs row
+          const uint32_t nr = w + static_cast<uint32_t>(Lcol[sn_cols[sn_of[j]].back()].size()) + 1;
+          if (nr > kSnRowsMax) throw std::runtime_error("ldlt: supernode has more rows than a wave has lanes");
+          O.sn_desc.push_back(LdltSn{diag_ent[j], static_cast<uint16_t>(w), static_cast<uint16_t>(nr),
+                                     static_cast<uint16_t>(ci), 0});
+        }
+        auto emit_entry = [&](uint32_t le, int32_t src, uint8_t flags, uint32_t out) {
+          O.ent_src.push_back(src);
+          O.ent_flags.push_back(flags);
+          O.ent_col.push_back(static_cast<uint16_t>(ci));
+          O.ent_out.push_back(out);
+          O.ent_pair_ptr.push_back(pair_count);
+          O.ent_contrib_ptr.push_back(contrib_count);
+          const uint32_t ge = task_ent_base[t] + le;
+          O.pairs.insert(O.pairs.end(), own_pairs.begin() + own_ptr[ge], own_pairs.begin() + own_ptr[ge + 1]);
+          pair_count += own_ptr[ge + 1] - own_ptr[ge];
+          O.contrib_idx.insert(O.contrib_idx.end(), ec.begin() + ec_ptr[ge], ec.begin() + ec_ptr[ge + 1]);
+          contrib_count += ec_ptr[ge + 1] - ec_ptr[ge];
+        };
+        const bool gamma_kind = P.perm[j] >= n_dec;
+        // bit 3: entry of the diagonal block of a supernode with w >= 2 — finished (and written
+        // out) by the lanes that work on the supernode, not by the generic passes
+        const uint8_t in_block = w >= 2 ? 8 : 0;
+        emit_entry(diag_ent[j], diag_src[j], static_cast<uint8_t>(1 | (gamma_kind ? 2 : 0) | in_block),
+                   static_cast<uint32_t>(j));
+        // off-diagonal entries: A source by merge with Acol[j]
+        size_t ap = 0;
+        for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
+          int32_t src = -1;
+          while (ap < Acol[j].size() && Acol[j][ap].first < P.Li[p]) ++ap;
+          if (ap < Acol[j].size() && Acol[j][ap].first == P.Li[p]) src = Acol[j][ap].second;
+          // the first w - pos - 1 rows of the column are the later columns of its chain
+          const bool block_row = static_cast<uint32_t>(p - P.Lp[j]) + pos + 1 < w;
+          emit_entry(lent[p], src, block_row ? in_block : 0, static_cast<uint32_t>(p));
+        }
+        // rhs-row entry: source = rhs[perm[j]], result z_j = U_b(j)/d_j
+        emit_entry(bent[j], P.perm[j], 4, static_cast<uint32_t>(j));
+        // solve lists
+        O.fwd_ptr.push_back(fwd_count);
+        O.fwd_items.insert(O.fwd_items.end(), fwd_all.begin() + fwd_all_ptr[j], fwd_all.begin() + fwd_all_ptr[j + 1]);
+        fwd_count += fwd_all_ptr[j + 1] - fwd_all_ptr[j];
+        O.fwd_contrib_ptr.push_back(sc_count);
+        O.scontrib_idx.insert(O.scontrib_idx.end(), fc.begin() + fc_ptr[j], fc.begin() + fc_ptr[j + 1]);
+        sc_count += fc_ptr[j + 1] - fc_ptr[j];
+        O.bwd_ptr.push_back(bwd_count);
+        O.bwd_items.insert(O.bwd_items.end(), bwd_all.begin() + bwd_all_ptr[j], bwd_all.begin() + bwd_all_ptr[j + 1]);
+        bwd_count += bwd_all_ptr[j + 1] - bwd_all_ptr[j];
+      }
+      O.lvl_ptr.push_back(T.n_ent);
+      O.col_lvl_ptr.push_back(T.n_col);
+      T.n_lvl = static_cast<uint32_t>(O.lvl_ptr.size() - T.lvl_off - 1);
+      T.n_sn = static_cast<uint32_t>(O.sn_desc.size()) - T.sn_off;
+      O.sn_lvl_ptr.push_back(T.n_sn);
+      // pseudo entries continue the pair_ptr array
+      for (uint32_t q = task_ext_ptr[t]; q < task_ext_ptr[t + 1]; ++q) {
+        const uint32_t d = task_ext[q];
+        O.ext_dst.push_back(d);
+        O.ent_pair_ptr.push_back(pair_count);
+        O.pairs.insert(O.pairs.end(), extp.begin() + extp_ptr[d], extp.begin() + extp_ptr[d + 1]);
+        pair_count += extp_ptr[d + 1] - extp_ptr[d];
+      }
+      O.ent_pair_ptr.push_back(pair_count);
+      T.n_pairs = pair_count;
+      T.n_fwd_items = fwd_count;
+      T.n_bwd_items = bwd_count;
+      O.ent_contrib_ptr.push_back(contrib_count);
+      T.n_contrib_idx = contrib_count;
+      while (O.contrib_idx.size() % 4 != 0) O.contrib_idx.push_back(0);  // 16-byte slices: staged into LDS
+      O.fwd_ptr.push_back(fwd_count);
+      O.fwd_contrib_ptr.push_back(sc_count);
+      O.bwd_ptr.push_back(bwd_count);
+      uint32_t sitem = 0;
+      for (uint32_t q = task_sext_ptr[t]; q < task_sext_ptr[t + 1]; ++q) {
+        const uint32_t d = task_sext[q];
+        O.sext_dst.push_back(d);
+        O.sext_ptr.push_back(sitem);
+        O.sext_items.insert(O.sext_items.end(), sext_item.begin() + sext_item_ptr[d], sext_item.begin() + sext_item_ptr[d + 1]);
+        sitem += sext_item_ptr[d + 1] - sext_item_ptr[d];
+      }
+      O.sext_ptr.push_back(sitem);
+      O.max_lds_doubles = std::max(O.max_lds_doubles, T.n_ent + T.n_col);
+      O.max_solve_lds_doubles = std::max(O.max_solve_lds_doubles, T.n_col);
+      // LDS working sets of the staged kernels (see ldlt_kernels.h for the carve-up)
+      auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
+      const uint32_t fb = q(pair_count, 2) + q(T.n_ent + T.n_ext + 1, 4) + q(T.n_lvl + 1, 4) +
+                          q(T.n_ent, 4) + q(T.n_ent, 8) + q(T.n_ent, 16) + q(T.n_ent, 4) +
+                          q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32 + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4) +
+                          q(T.n_contrib_idx, 4);
+      const uint32_t items = std::max(fwd_count, bwd_count);
+      const uint32_t sb = q(items, 2) + 2 * q(T.n_col + 1, 4) + q(T.n_lvl + 1, 4) + q(T.n_col, 4) +
+                          8 * items + 8 * (T.n_col + 1) + 32 + q(T.n_col, 4) + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);
+      O.factor_lds_bytes = std::max(O.factor_lds_bytes, fb);
+      O.solve_lds_bytes = std::max(O.solve_lds_bytes, sb);
+      O.tasks.push_back(T);
+      O.flops = 2 * static_cast<int64_t>(pair_count);  // (carries the task's pair count to the join)
+    }
+  });
+  for (size_t ti = 0; ti < flat.size(); ++ti) {
+    LdltPlan& O = flat[ti];
+    // 16-byte alignment of every per-task slice (the kernels stage them into LDS with unrolled 16-byte loads)
     auto pad = [](auto& v, size_t multiple) {
       while (v.size() % multiple) v.push_back({});
     };
@@ -1008,141 +1245,57 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
     pad(P.sn_desc, 4);  // 12-byte records: four of them are three 16-byte groups
     pad(P.col_sn, 4);
     pad(P.sn_lvl_ptr, 4);
-    LdltTask T{};
-    const auto& cols = tcols[t].cols;
-    T.round = static_cast<uint32_t>(tcols[t].round);
-    T.n_col = static_cast<uint32_t>(cols.size());
-    T.n_ent = task_nent[t];
-    T.n_ext = task_ext_ptr[t + 1] - task_ext_ptr[t];
-    T.ent_off = static_cast<uint32_t>(P.ent_src.size());
-    T.col_off = static_cast<uint32_t>(P.col_perm.size());
-    T.lvl_off = static_cast<uint32_t>(P.lvl_ptr.size());
-    T.ext_off = static_cast<uint32_t>(P.ext_dst.size());
-    T.pair_off = static_cast<uint32_t>(P.pairs.size());
-    T.contrib_off = static_cast<uint32_t>(P.contrib_idx.size());
-    T.fwd_item_off = static_cast<uint32_t>(P.fwd_items.size());
-    T.bwd_item_off = static_cast<uint32_t>(P.bwd_items.size());
-    T.sext_off = static_cast<uint32_t>(P.sext_dst.size());
-    T.n_sext = task_sext_ptr[t + 1] - task_sext_ptr[t];
-    T.sext_item_off = static_cast<uint32_t>(P.sext_items.size());
-    T.scontrib_off = static_cast<uint32_t>(P.scontrib_idx.size());
-    T.pair_ptr_off = static_cast<uint32_t>(P.ent_pair_ptr.size());
-    T.contrib_ptr_off = static_cast<uint32_t>(P.ent_contrib_ptr.size());
-    T.colptr_off = static_cast<uint32_t>(P.fwd_ptr.size());
-    T.sext_ptr_off = static_cast<uint32_t>(P.sext_ptr.size());
-    T.sn_off = static_cast<uint32_t>(P.sn_desc.size());
     if (P.col_sn.size() != P.col_perm.size() || P.sn_lvl_ptr.size() != P.lvl_ptr.size())
       throw std::runtime_error("ldlt: supernode arrays out of step with the column arrays");
-
-    int32_t cur_level = -1;
-    uint32_t pair_count = 0, contrib_count = 0, fwd_count = 0, bwd_count = 0, sc_count = 0;
-    for (size_t ci = 0; ci < cols.size(); ++ci) {
-      const int32_t j = cols[ci];
-      if (tlevel[j] != cur_level) {
-        P.lvl_ptr.push_back(diag_ent[j]);
-        P.col_lvl_ptr.push_back(static_cast<uint32_t>(ci));
-        P.sn_lvl_ptr.push_back(static_cast<uint32_t>(P.sn_desc.size()) - T.sn_off);
-        cur_level = tlevel[j];
-      }
-      P.col_perm.push_back(static_cast<uint32_t>(j));
-      const uint32_t w = static_cast<uint32_t>(sn_width(j)), pos = static_cast<uint32_t>(sn_pos[j]);
-      P.col_sn.push_back(pos | (w << 8));
-      if (w >= 2 && pos == 0) {
-        // rows of the trapezoid: the chain, the common structure below it, the rhs row
-        const uint32_t nr = w + static_cast<uint32_t>(Lcol[sn_cols[sn_of[j]].back()].size()) + 1;
-        if (nr > kSnRowsMax) throw std::runtime_error("ldlt: supernode has more rows than a wave has lanes");
-        P.sn_desc.push_back(LdltSn{diag_ent[j], static_cast<uint16_t>(w), static_cast<uint16_t>(nr),
-                                   static_cast<uint16_t>(ci), 0});
-      }
-      auto emit_entry = [&](uint32_t le, int32_t src, uint8_t flags, uint32_t out) {
-        P.ent_src.push_back(src);
-        P.ent_flags.push_back(flags);
-        P.ent_col.push_back(static_cast<uint16_t>(ci));
-        P.ent_out.push_back(out);
-        P.ent_pair_ptr.push_back(pair_count);
-        P.ent_contrib_ptr.push_back(contrib_count);
-        const uint32_t ge = task_ent_base[t] + le;
-        P.pairs.insert(P.pairs.end(), own_pairs.begin() + own_ptr[ge], own_pairs.begin() + own_ptr[ge + 1]);
-        pair_count += own_ptr[ge + 1] - own_ptr[ge];
-        P.contrib_idx.insert(P.contrib_idx.end(), ec.begin() + ec_ptr[ge], ec.begin() + ec_ptr[ge + 1]);
-        contrib_count += ec_ptr[ge + 1] - ec_ptr[ge];
-      };
-      const bool gamma_kind = P.perm[j] >= n_dec;
-      // bit 3: entry of the diagonal block of a supernode with w >= 2 — finished (and written
-      // out) by the lanes that work on the supernode, not by the generic passes
-      const uint8_t in_block = w >= 2 ? 8 : 0;
-      emit_entry(diag_ent[j], diag_src[j], static_cast<uint8_t>(1 | (gamma_kind ? 2 : 0) | in_block),
-                 static_cast<uint32_t>(j));
-      // off-diagonal entries: A source by merge with Acol[j]
-      size_t ap = 0;
-      for (int32_t p = P.Lp[j]; p < P.Lp[j + 1]; ++p) {
-        int32_t src = -1;
-        while (ap < Acol[j].size() && Acol[j][ap].first < P.Li[p]) ++ap;
-        if (ap < Acol[j].size() && Acol[j][ap].first == P.Li[p]) src = Acol[j][ap].second;
-        // the first w - pos - 1 rows of the column are the later columns of its chain
-        const bool block_row = static_cast<uint32_t>(p - P.Lp[j]) + pos + 1 < w;
-        emit_entry(lent[p], src, block_row ? in_block : 0, static_cast<uint32_t>(p));
-      }
-      // rhs-row entry: source = rhs[perm[j]], result z_j = U_b(j)/d_j
-      emit_entry(bent[j], P.perm[j], 4, static_cast<uint32_t>(j));
-      // solve lists
-      P.fwd_ptr.push_back(fwd_count);
-      P.fwd_items.insert(P.fwd_items.end(), fwd_all.begin() + fwd_all_ptr[j], fwd_all.begin() + fwd_all_ptr[j + 1]);
-      fwd_count += fwd_all_ptr[j + 1] - fwd_all_ptr[j];
-      P.fwd_contrib_ptr.push_back(sc_count);
-      P.scontrib_idx.insert(P.scontrib_idx.end(), fc.begin() + fc_ptr[j], fc.begin() + fc_ptr[j + 1]);
-      sc_count += fc_ptr[j + 1] - fc_ptr[j];
-      P.bwd_ptr.push_back(bwd_count);
-      P.bwd_items.insert(P.bwd_items.end(), bwd_all.begin() + bwd_all_ptr[j], bwd_all.begin() + bwd_all_ptr[j + 1]);
-      bwd_count += bwd_all_ptr[j + 1] - bwd_all_ptr[j];
-    }
-    P.lvl_ptr.push_back(T.n_ent);
-    P.col_lvl_ptr.push_back(T.n_col);
-    T.n_lvl = static_cast<uint32_t>(P.lvl_ptr.size() - T.lvl_off - 1);
-    T.n_sn = static_cast<uint32_t>(P.sn_desc.size()) - T.sn_off;
-    P.sn_lvl_ptr.push_back(T.n_sn);
-    // pseudo entries continue the pair_ptr array
-    for (uint32_t q = task_ext_ptr[t]; q < task_ext_ptr[t + 1]; ++q) {
-      const uint32_t d = task_ext[q];
-      P.ext_dst.push_back(d);
-      P.ent_pair_ptr.push_back(pair_count);
-      P.pairs.insert(P.pairs.end(), extp.begin() + extp_ptr[d], extp.begin() + extp_ptr[d + 1]);
-      pair_count += extp_ptr[d + 1] - extp_ptr[d];
-    }
-    P.ent_pair_ptr.push_back(pair_count);
-    n_real_pairs += pair_count;
-    T.n_pairs = pair_count;
-    T.n_fwd_items = fwd_count;
-    T.n_bwd_items = bwd_count;
-    P.ent_contrib_ptr.push_back(contrib_count);
-    T.n_contrib_idx = contrib_count;
-    while (P.contrib_idx.size() % 4 != 0) P.contrib_idx.push_back(0);  // 16-byte slices: staged into LDS
-    P.fwd_ptr.push_back(fwd_count);
-    P.fwd_contrib_ptr.push_back(sc_count);
-    P.bwd_ptr.push_back(bwd_count);
-    uint32_t sitem = 0;
-    for (uint32_t q = task_sext_ptr[t]; q < task_sext_ptr[t + 1]; ++q) {
-      const uint32_t d = task_sext[q];
-      P.sext_dst.push_back(d);
-      P.sext_ptr.push_back(sitem);
-      P.sext_items.insert(P.sext_items.end(), sext_item.begin() + sext_item_ptr[d], sext_item.begin() + sext_item_ptr[d + 1]);
-      sitem += sext_item_ptr[d + 1] - sext_item_ptr[d];
-    }
-    P.sext_ptr.push_back(sitem);
-    P.max_lds_doubles = std::max(P.max_lds_doubles, T.n_ent + T.n_col);
-    P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, T.n_col);
-    // LDS working sets of the staged kernels (see ldlt_kernels.h for the carve-up)
-    auto q = [](uint32_t count, uint32_t per16) { return 16u * ((count + per16 - 1) / per16); };
-    const uint32_t fb = q(pair_count, 2) + q(T.n_ent + T.n_ext + 1, 4) + q(T.n_lvl + 1, 4) +
-                        q(T.n_ent, 4) + q(T.n_ent, 8) + q(T.n_ent, 16) + q(T.n_ent, 4) +
-                        q(T.n_ent + 1, 4) + 8 * T.n_ent + 8 * T.n_col + 32 + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4) +
-                        q(T.n_contrib_idx, 4);
-    const uint32_t items = std::max(fwd_count, bwd_count);
-    const uint32_t sb = q(items, 2) + 2 * q(T.n_col + 1, 4) + q(T.n_lvl + 1, 4) + q(T.n_col, 4) +
-                        8 * items + 8 * (T.n_col + 1) + 32 + q(T.n_col, 4) + q(3 * T.n_sn, 4) + q(T.n_lvl + 1, 4);
-    P.factor_lds_bytes = std::max(P.factor_lds_bytes, fb);
-    P.solve_lds_bytes = std::max(P.solve_lds_bytes, sb);
+    LdltTask T = O.tasks.at(0);
+    T.ent_off += static_cast<uint32_t>(P.ent_src.size());
+    T.col_off += static_cast<uint32_t>(P.col_perm.size());
+    T.lvl_off += static_cast<uint32_t>(P.lvl_ptr.size());
+    T.ext_off += static_cast<uint32_t>(P.ext_dst.size());
+    T.pair_off += static_cast<uint32_t>(P.pairs.size());
+    T.contrib_off += static_cast<uint32_t>(P.contrib_idx.size());
+    T.fwd_item_off += static_cast<uint32_t>(P.fwd_items.size());
+    T.bwd_item_off += static_cast<uint32_t>(P.bwd_items.size());
+    T.sext_off += static_cast<uint32_t>(P.sext_dst.size());
+    T.sext_item_off += static_cast<uint32_t>(P.sext_items.size());
+    T.scontrib_off += static_cast<uint32_t>(P.scontrib_idx.size());
+    T.pair_ptr_off += static_cast<uint32_t>(P.ent_pair_ptr.size());
+    T.contrib_ptr_off += static_cast<uint32_t>(P.ent_contrib_ptr.size());
+    T.colptr_off += static_cast<uint32_t>(P.fwd_ptr.size());
+    T.sext_ptr_off += static_cast<uint32_t>(P.sext_ptr.size());
+    T.sn_off += static_cast<uint32_t>(P.sn_desc.size());
+    auto join = [](auto& dst, auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    join(P.ent_src, O.ent_src);
+    join(P.ent_flags, O.ent_flags);
+    join(P.ent_col, O.ent_col);
+    join(P.ent_out, O.ent_out);
+    join(P.ent_pair_ptr, O.ent_pair_ptr);
+    join(P.ent_contrib_ptr, O.ent_contrib_ptr);
+    join(P.pairs, O.pairs);
+    join(P.contrib_idx, O.contrib_idx);
+    join(P.ext_dst, O.ext_dst);
+    join(P.lvl_ptr, O.lvl_ptr);
+    join(P.col_lvl_ptr, O.col_lvl_ptr);
+    join(P.sn_lvl_ptr, O.sn_lvl_ptr);
+    join(P.col_perm, O.col_perm);
+    join(P.col_sn, O.col_sn);
+    join(P.sn_desc, O.sn_desc);
+    join(P.fwd_ptr, O.fwd_ptr);
+    join(P.fwd_contrib_ptr, O.fwd_contrib_ptr);
+    join(P.bwd_ptr, O.bwd_ptr);
+    join(P.fwd_items, O.fwd_items);
+    join(P.bwd_items, O.bwd_items);
+    join(P.scontrib_idx, O.scontrib_idx);
+    join(P.sext_dst, O.sext_dst);
+    join(P.sext_ptr, O.sext_ptr);
+    join(P.sext_items, O.sext_items);
+    P.max_lds_doubles = std::max(P.max_lds_doubles, O.max_lds_doubles);
+    P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, O.max_solve_lds_doubles);
+    P.factor_lds_bytes = std::max(P.factor_lds_bytes, O.factor_lds_bytes);
+    P.solve_lds_bytes = std::max(P.solve_lds_bytes, O.solve_lds_bytes);
+    n_real_pairs += static_cast<size_t>(O.flops / 2);
     P.tasks.push_back(T);
+    O = LdltPlan{};
   }
 
   lap("  ldlt: flattened plan arrays");
@@ -1230,11 +1383,23 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         return fa.cols.size() * 64 + fa.R.size() > fb.cols.size() * 64 + fb.R.size();
       });
     }
-    // update slots between tasks: one per entry of a root front's block
-    std::vector<std::pair<uint32_t, uint32_t>> mc_found;  // (receiving entry, global; slot) in slot order
-    std::vector<uint16_t> cell_vals;  // per front: the children's values of every table cell, `kids` slots a cell
-    std::vector<uint8_t> cell_cnt;
-    std::vector<uint32_t> to;
+    // update slots between tasks: one per entry of a root front's block.  Every task builds its fronts' tables into
+    // buffers of its own — the tasks in chunks on the setup threads — and the buffers are joined in task order
+    // afterwards: offsets, slot numbers and the slots' receiving entries shifted by what came before.
+    struct TaskOut {
+      std::vector<uint32_t> mf_anc, mf_lvl_ptr, mf_ext;
+      std::vector<uint16_t> mf_tab;
+      std::vector<LdltFront> mf_fronts;
+      std::vector<std::pair<uint32_t, uint32_t>> mc_found;  // (receiving entry, global; slot of this task) in slot order
+      uint32_t n_slots = 0, n_mfma = 0, max_nch = 0, max_front_rows = 0;
+      bool ok = true;
+      const char* refused = nullptr;
+    };
+    struct Scratch {
+      std::vector<uint16_t> cell_vals;  // per front: the children's values of every table cell, `kids` slots a cell
+      std::vector<uint8_t> cell_cnt;
+      std::vector<uint32_t> to;
+    };
     auto entry_of = [&](int32_t row, int32_t col) -> uint32_t {  // row = -1: the right-hand-side row
       if (row == col) return diag_ent[col];
       if (row < 0) return bent[col];
@@ -1245,10 +1410,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       return lent[f - P.Li.data()];
     };
     P.mf_tasks.assign(ntasks, LdltMfTask{});
-    for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
+    std::vector<TaskOut> outs(P.tasks.size());
+    auto build_task = [&](size_t ti, Scratch& S) {
       const int t = torder[ti];
       const LdltTask& T = P.tasks[ti];
       LdltMfTask& M = P.mf_tasks[ti];
+      TaskOut& O = outs[ti];
       const auto& fl = task_fronts[t];
       // ---- S blocks: a block lives from its front's level to its parent's; first fit over the free gaps
       uint32_t arena = 2;  // [0] = 0.0, [1] = scratch
@@ -1279,32 +1446,30 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
           if (task_of[i] != t) anc.push_back(i);
       std::sort(anc.begin(), anc.end());
       anc.erase(std::unique(anc.begin(), anc.end()), anc.end());
-      M.anc_off = static_cast<uint32_t>(P.mf_anc.size());
+      M.anc_off = static_cast<uint32_t>(O.mf_anc.size());
       M.n_anc = static_cast<uint32_t>(anc.size());
-      for (int32_t i : anc) P.mf_anc.push_back(static_cast<uint32_t>(i));
-      while (P.mf_anc.size() % 4) P.mf_anc.push_back(0);
+      for (int32_t i : anc) O.mf_anc.push_back(static_cast<uint32_t>(i));
       // ---- the 64 KB every table offset must reach
       const uint32_t off_arena = 8u * T.n_ent, off_invd = off_arena + 8u * arena, off_x = off_invd + 8u * T.n_col;
       const uint32_t reach = off_x + 8u * (T.n_col + M.n_anc + 1u);
       if (reach > 0x10000u) {
-        ok = false;
-        break;
+        O.ok = false;
+        return;
       }
       const uint16_t kZero = static_cast<uint16_t>(off_arena), kScratch = static_cast<uint16_t>(off_arena + 8u);
       auto s_addr = [&](const Front& f, uint32_t e) { return static_cast<uint16_t>(off_arena + 8u * (f.s_base + e)); };
       auto u_addr = [&](uint32_t ent) { return static_cast<uint16_t>(8u * ent); };
       // ---- fronts and their tables
-      M.front_off = static_cast<uint32_t>(P.mf_fronts.size());
+      M.front_off = static_cast<uint32_t>(O.mf_fronts.size());
       M.n_front = static_cast<uint32_t>(fl.size());
-      M.tab_off = static_cast<uint32_t>(P.mf_tab.size());
-      M.ext_off = static_cast<uint32_t>(P.mf_ext.size());
-      while (P.mf_lvl_ptr.size() < T.lvl_off) P.mf_lvl_ptr.push_back(0);
+      M.tab_off = static_cast<uint32_t>(O.mf_tab.size());
+      M.ext_off = static_cast<uint32_t>(O.mf_ext.size());
       int cur_level = -1;
       uint32_t n_ext = 0;
       for (size_t q = 0; q < fl.size(); ++q) {
         const Front& f = fronts[fl[q]];
         if (f.level != cur_level) {
-          P.mf_lvl_ptr.push_back(static_cast<uint32_t>(q));
+          O.mf_lvl_ptr.push_back(static_cast<uint32_t>(q));
           cur_level = f.level;
         }
         const uint32_t w = static_cast<uint32_t>(f.cols.size()), r = static_cast<uint32_t>(f.R.size()), nr = f.nr;
@@ -1313,11 +1478,12 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         // where the rows of each child land in this front (a child's block has at most one value for a cell:
         // the cells' lists are the children's values in child order)
         const size_t n_kids = f.kids.size(), n_piv = static_cast<size_t>(nr) * w, n_cells = n_piv + f.n_s;
-        cell_cnt.assign(n_cells, 0);
-        if (cell_vals.size() < n_cells * n_kids) cell_vals.resize(n_cells * n_kids);
+        S.cell_cnt.assign(n_cells, 0);
+        if (S.cell_vals.size() < n_cells * n_kids) S.cell_vals.resize(n_cells * n_kids);
         for (int ki : f.kids) {
           const Front& k = fronts[ki];
           const uint32_t rk = static_cast<uint32_t>(k.R.size());
+          std::vector<uint32_t>& to = S.to;
           to.resize(rk + 1);
           for (uint32_t a = 0; a < rk; ++a) {
             const int32_t i = k.R[a];
@@ -1336,26 +1502,26 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
               const uint32_t ta = to[a], tb = to[b];
               const uint16_t src = s_addr(k, a * (a + 1) / 2 + b);
               const size_t cell = tb < w ? static_cast<size_t>(ta) * w + tb : n_piv + (ta - w) * (ta - w + 1) / 2 + (tb - w);
-              if (cell_cnt[cell] == 255 || cell_cnt[cell] >= n_kids) {
-                ok = false;
+              if (S.cell_cnt[cell] == 255 || S.cell_cnt[cell] >= n_kids) {
+                O.ok = false;
                 break;
               }
-              cell_vals[cell * n_kids + cell_cnt[cell]++] = src;
+              S.cell_vals[cell * n_kids + S.cell_cnt[cell]++] = src;
             }
         }
-        if (!ok) break;
+        if (!O.ok) break;
         uint32_t nch = 0;
-        for (size_t c = 0; c < n_cells; ++c) nch = std::max<uint32_t>(nch, cell_cnt[c]);
+        for (size_t c = 0; c < n_cells; ++c) nch = std::max<uint32_t>(nch, S.cell_cnt[c]);
         auto piv_at = [&](uint32_t row, uint32_t c, uint32_t kk) {
           const size_t cell = static_cast<size_t>(row) * w + c;
-          return kk < cell_cnt[cell] ? cell_vals[cell * n_kids + kk] : kZero;
+          return kk < S.cell_cnt[cell] ? S.cell_vals[cell * n_kids + kk] : kZero;
         };
         auto upd_at = [&](uint32_t e, uint32_t kk) {
           const size_t cell = n_piv + e;
-          return kk < cell_cnt[cell] ? cell_vals[cell * n_kids + kk] : kZero;
+          return kk < S.cell_cnt[cell] ? S.cell_vals[cell * n_kids + kk] : kZero;
         };
         LdltFront F{};
-        F.tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
+        F.tab = static_cast<uint32_t>(O.mf_tab.size()) - M.tab_off;
         F.base0 = static_cast<uint16_t>(base0);
         F.col0 = static_cast<uint16_t>(lcol[f.cols[0]]);
         F.w = static_cast<uint8_t>(w);
@@ -1367,10 +1533,10 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
         // lane-per-entry passes cover (ldlt_mf_kernels.h: mf_update_mfma)
         const bool mfma = w >= 4 && f.n_s > opt.mfma_min_entries;
         F.flags = static_cast<uint8_t>((root ? 1 : 0) | (mfma ? 2 : 0));
-        P.mf_n_mfma += mfma;
+        O.n_mfma += mfma;
         F.ext = static_cast<uint16_t>(n_ext);
         if (root && n_ext + f.n_s > 0xffffu) {
-          ok = false;
+          O.ok = false;
           break;
         }
         // pivot table: rows x [k][c]
@@ -1380,22 +1546,22 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
               uint16_t v;
               if (k == 0) v = row >= c ? u_addr(tr(c, row)) : kScratch;
               else v = row >= c ? piv_at(row, c, k - 1) : kZero;
-              P.mf_tab.push_back(v);
+              O.mf_tab.push_back(v);
             }
         // update table: out, U(a, 0), U(b, 0), children
         for (uint32_t a = 0; a <= r; ++a)
           for (uint32_t b = 0; b < r && b <= a; ++b) {
             const uint32_t e = a * (a + 1) / 2 + b;
-            P.mf_tab.push_back(root ? static_cast<uint16_t>(e) : s_addr(f, e));
-            P.mf_tab.push_back(u_addr(tr(0, w + a)));
-            P.mf_tab.push_back(u_addr(tr(0, w + b)));
-            for (uint32_t k = 0; k < nch; ++k) P.mf_tab.push_back(upd_at(e, k));
+            O.mf_tab.push_back(root ? static_cast<uint16_t>(e) : s_addr(f, e));
+            O.mf_tab.push_back(u_addr(tr(0, w + a)));
+            O.mf_tab.push_back(u_addr(tr(0, w + b)));
+            for (uint32_t k = 0; k < nch; ++k) O.mf_tab.push_back(upd_at(e, k));
             if (root) {
               const int32_t gb = f.R[b], ga = a < r ? f.R[a] : -1;
               const int tj = task_of[gb];
-              const uint32_t slot = P.mf_n_contrib++;
-              mc_found.emplace_back(task_ent_base[tj] + entry_of(ga, gb), slot);
-              P.mf_ext.push_back(slot);
+              const uint32_t slot = O.n_slots++;
+              O.mc_found.emplace_back(task_ent_base[tj] + entry_of(ga, gb), slot);
+              O.mf_ext.push_back(slot);
               ++n_ext;
             }
           }
@@ -1405,21 +1571,60 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
           uint32_t xi;
           if (task_of[i] == t) xi = static_cast<uint32_t>(lcol[i]);
           else xi = T.n_col + static_cast<uint32_t>(std::lower_bound(anc.begin(), anc.end(), i) - anc.begin());
-          P.mf_tab.push_back(static_cast<uint16_t>(off_x + 8u * xi));
+          O.mf_tab.push_back(static_cast<uint16_t>(off_x + 8u * xi));
         }
-        P.mf_fronts.push_back(F);
-        P.mf_max_nch = std::max(P.mf_max_nch, nch);
-        P.mf_max_front_rows = std::max(P.mf_max_front_rows, nr);
+        O.mf_fronts.push_back(F);
+        O.max_nch = std::max(O.max_nch, nch);
+        O.max_front_rows = std::max(O.max_front_rows, nr);
       }
-      if (!ok) break;
-      P.mf_lvl_ptr.push_back(static_cast<uint32_t>(fl.size()));
-      if (P.mf_lvl_ptr.size() != T.lvl_off + T.n_lvl + 1)
+      if (!O.ok) return;
+      O.mf_lvl_ptr.push_back(static_cast<uint32_t>(fl.size()));
+      if (O.mf_lvl_ptr.size() != T.n_lvl + 1)
         throw MfRefused{"front levels out of step with the column levels"};
       M.n_ext = n_ext;
-      M.n_tab = static_cast<uint32_t>(P.mf_tab.size()) - M.tab_off;
+      M.n_tab = static_cast<uint32_t>(O.mf_tab.size()) - M.tab_off;
+    };
+    if (ok)
+      parallel_chunks(P.tasks.size(), 4, [&](size_t t_begin, size_t t_end, unsigned) {
+        Scratch S;
+        for (size_t ti = t_begin; ti < t_end; ++ti) {
+          try {
+            build_task(ti, S);
+          } catch (const MfRefused& r) {
+            outs[ti].refused = r.why;
+          }
+        }
+      });
+    std::vector<std::pair<uint32_t, uint32_t>> mc_found;  // (receiving entry, global; slot) in slot order
+    for (size_t ti = 0; ti < P.tasks.size() && ok; ++ti) {
+      TaskOut& O = outs[ti];
+      if (O.refused != nullptr) throw MfRefused{O.refused};
+      if (!O.ok) {
+        ok = false;
+        break;
+      }
+      const LdltTask& T = P.tasks[ti];
+      LdltMfTask& M = P.mf_tasks[ti];
+      M.anc_off = static_cast<uint32_t>(P.mf_anc.size());
+      P.mf_anc.insert(P.mf_anc.end(), O.mf_anc.begin(), O.mf_anc.end());
+      while (P.mf_anc.size() % 4) P.mf_anc.push_back(0);
+      M.front_off = static_cast<uint32_t>(P.mf_fronts.size());
+      M.tab_off = static_cast<uint32_t>(P.mf_tab.size());
+      M.ext_off = static_cast<uint32_t>(P.mf_ext.size());
+      while (P.mf_lvl_ptr.size() < T.lvl_off) P.mf_lvl_ptr.push_back(0);
+      P.mf_lvl_ptr.insert(P.mf_lvl_ptr.end(), O.mf_lvl_ptr.begin(), O.mf_lvl_ptr.end());
+      if (P.mf_lvl_ptr.size() != T.lvl_off + T.n_lvl + 1) throw MfRefused{"front levels out of step with the column levels"};
+      P.mf_fronts.insert(P.mf_fronts.end(), O.mf_fronts.begin(), O.mf_fronts.end());
+      P.mf_tab.insert(P.mf_tab.end(), O.mf_tab.begin(), O.mf_tab.end());
+      for (uint32_t slot : O.mf_ext) P.mf_ext.push_back(P.mf_n_contrib + slot);
+      for (auto& f : O.mc_found) mc_found.emplace_back(f.first, P.mf_n_contrib + f.second);
+      P.mf_n_contrib += O.n_slots;
+      P.mf_n_mfma += O.n_mfma;
+      P.mf_max_nch = std::max(P.mf_max_nch, O.max_nch);
+      P.mf_max_front_rows = std::max(P.mf_max_front_rows, O.max_front_rows);
       while (P.mf_tab.size() % 8) P.mf_tab.push_back(0);
       while (P.mf_ext.size() % 4) P.mf_ext.push_back(0);
-      while (P.mf_fronts.size() % 1) P.mf_fronts.push_back(LdltFront{});
+      O = TaskOut{};
     }
     // update slots per receiving entry (the tasks' entries are numbered in emission order)
     std::vector<uint32_t> mc_ptr(total_ent + 1, 0), mc(mc_found.size());

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -132,7 +133,18 @@ inline unsigned parallel_chunks(size_t n, size_t grain, F&& f) {
     f(size_t{0}, n, 0u);
     return 1;
   }
-  SetupPool::get().run(chunks, [&](unsigned c) { f(n * c / chunks, n * (c + 1) / chunks, c); });
+  // (an exception of a chunk — on whichever thread — is the call's: the first one thrown is rethrown here)
+  std::exception_ptr failed;
+  std::mutex failed_mutex;
+  SetupPool::get().run(chunks, [&](unsigned c) {
+    try {
+      f(n * c / chunks, n * (c + 1) / chunks, c);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(failed_mutex);
+      if (!failed) failed = std::current_exception();
+    }
+  });
+  if (failed) std::rethrow_exception(failed);
   return chunks;
 }
 // the number of chunks parallel_chunks(n, grain, ..) will make (to size per-chunk buffers beforehand)

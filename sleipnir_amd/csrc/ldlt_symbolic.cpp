@@ -1215,87 +1215,110 @@ static LdltPlan build_ldlt_plan_once(const CscPattern& lower, int n_dec, const L
       O.flops = 2 * static_cast<int64_t>(pair_count);  // (carries the task's pair count to the join)
     }
   });
-  for (size_t ti = 0; ti < flat.size(); ++ti) {
-    LdltPlan& O = flat[ti];
-    // 16-byte alignment of every per-task slice (the kernels stage them into LDS with unrolled 16-byte loads)
-    auto pad = [](auto& v, size_t multiple) {
-      while (v.size() % multiple) v.push_back({});
+  // The join: where every task's slice of every array starts is known from the slices' lengths (16-byte alignment of
+  // every slice: the kernels stage them into LDS with unrolled 16-byte loads), so the arrays are sized once and the
+  // slices copied in, the tasks in chunks on the setup threads.
+  {
+    const size_t nt = flat.size();
+    // offsets[a][ti], array a in the order of `place` below
+    auto place = [&](auto member, size_t multiple, auto padval, std::vector<uint32_t>& offs) {
+      offs.resize(nt);
+      size_t off = 0;
+      for (size_t ti = 0; ti < nt; ++ti) {
+        off = (off + multiple - 1) / multiple * multiple;
+        offs[ti] = static_cast<uint32_t>(off);
+        off += (flat[ti].*member).size();
+      }
+      (P.*member).assign(off, padval);
     };
-    while (P.ent_src.size() % 16) {
-      P.ent_src.push_back(-1);
-      P.ent_flags.push_back(0);
-      P.ent_col.push_back(0);
-      P.ent_out.push_back(0);
+    std::vector<uint32_t> o_ent, o_flags, o_col, o_out, o_pairs, o_pptr, o_cptr, o_lvl, o_clvl, o_snlvl, o_colperm, o_colsn, o_sn,
+        o_fptr, o_fcptr, o_bptr, o_fit, o_bit, o_ext, o_cidx, o_scidx, o_sdst, o_sptr, o_sit;
+    place(&LdltPlan::ent_src, 16, int32_t{-1}, o_ent);
+    place(&LdltPlan::ent_flags, 16, uint8_t{0}, o_flags);
+    place(&LdltPlan::ent_col, 16, uint16_t{0}, o_col);
+    place(&LdltPlan::ent_out, 16, uint32_t{0}, o_out);
+    place(&LdltPlan::pairs, 2, LdltPair{}, o_pairs);
+    place(&LdltPlan::ent_pair_ptr, 4, uint32_t{0}, o_pptr);
+    place(&LdltPlan::ent_contrib_ptr, 4, uint32_t{0}, o_cptr);
+    place(&LdltPlan::lvl_ptr, 4, uint32_t{0}, o_lvl);
+    place(&LdltPlan::col_lvl_ptr, 4, uint32_t{0}, o_clvl);
+    place(&LdltPlan::sn_lvl_ptr, 4, uint32_t{0}, o_snlvl);
+    place(&LdltPlan::col_perm, 4, uint32_t{0}, o_colperm);
+    place(&LdltPlan::col_sn, 4, uint32_t{0}, o_colsn);
+    place(&LdltPlan::sn_desc, 4, LdltSn{}, o_sn);
+    place(&LdltPlan::fwd_ptr, 4, uint32_t{0}, o_fptr);
+    place(&LdltPlan::fwd_contrib_ptr, 4, uint32_t{0}, o_fcptr);
+    place(&LdltPlan::bwd_ptr, 4, uint32_t{0}, o_bptr);
+    place(&LdltPlan::fwd_items, 2, LdltSolveItem{}, o_fit);
+    place(&LdltPlan::bwd_items, 2, LdltSolveItem{}, o_bit);
+    place(&LdltPlan::ext_dst, 1, uint32_t{0}, o_ext);
+    place(&LdltPlan::contrib_idx, 1, uint32_t{0}, o_cidx);
+    place(&LdltPlan::scontrib_idx, 1, uint32_t{0}, o_scidx);
+    place(&LdltPlan::sext_dst, 1, uint32_t{0}, o_sdst);
+    place(&LdltPlan::sext_ptr, 1, uint32_t{0}, o_sptr);
+    place(&LdltPlan::sext_items, 1, LdltSolveItem{}, o_sit);
+    for (size_t ti = 0; ti < nt; ++ti)
+      if (o_ent[ti] != o_flags[ti] || o_ent[ti] != o_col[ti] || o_ent[ti] != o_out[ti] || o_lvl[ti] != o_clvl[ti] ||
+          o_lvl[ti] != o_snlvl[ti] || o_colperm[ti] != o_colsn[ti] || o_fptr[ti] != o_fcptr[ti] || o_fptr[ti] != o_bptr[ti])
+        throw std::runtime_error("ldlt: supernode arrays out of step with the column arrays");
+    P.tasks.resize(nt);
+    parallel_chunks(nt, 4, [&](size_t ti_begin, size_t ti_end, unsigned) {
+      for (size_t ti = ti_begin; ti < ti_end; ++ti) {
+        LdltPlan& O = flat[ti];
+        auto put = [&](auto member, uint32_t off) { std::copy((O.*member).begin(), (O.*member).end(), (P.*member).begin() + off); };
+        put(&LdltPlan::ent_src, o_ent[ti]);
+        put(&LdltPlan::ent_flags, o_flags[ti]);
+        put(&LdltPlan::ent_col, o_col[ti]);
+        put(&LdltPlan::ent_out, o_out[ti]);
+        put(&LdltPlan::pairs, o_pairs[ti]);
+        put(&LdltPlan::ent_pair_ptr, o_pptr[ti]);
+        put(&LdltPlan::ent_contrib_ptr, o_cptr[ti]);
+        put(&LdltPlan::lvl_ptr, o_lvl[ti]);
+        put(&LdltPlan::col_lvl_ptr, o_clvl[ti]);
+        put(&LdltPlan::sn_lvl_ptr, o_snlvl[ti]);
+        put(&LdltPlan::col_perm, o_colperm[ti]);
+        put(&LdltPlan::col_sn, o_colsn[ti]);
+        put(&LdltPlan::sn_desc, o_sn[ti]);
+        put(&LdltPlan::fwd_ptr, o_fptr[ti]);
+        put(&LdltPlan::fwd_contrib_ptr, o_fcptr[ti]);
+        put(&LdltPlan::bwd_ptr, o_bptr[ti]);
+        put(&LdltPlan::fwd_items, o_fit[ti]);
+        put(&LdltPlan::bwd_items, o_bit[ti]);
+        put(&LdltPlan::ext_dst, o_ext[ti]);
+        put(&LdltPlan::contrib_idx, o_cidx[ti]);
+        put(&LdltPlan::scontrib_idx, o_scidx[ti]);
+        put(&LdltPlan::sext_dst, o_sdst[ti]);
+        put(&LdltPlan::sext_ptr, o_sptr[ti]);
+        put(&LdltPlan::sext_items, o_sit[ti]);
+        LdltTask T = O.tasks.at(0);
+        T.ent_off += o_ent[ti];
+        T.col_off += o_colperm[ti];
+        T.lvl_off += o_lvl[ti];
+        T.ext_off += o_ext[ti];
+        T.pair_off += o_pairs[ti];
+        T.contrib_off += o_cidx[ti];
+        T.fwd_item_off += o_fit[ti];
+        T.bwd_item_off += o_bit[ti];
+        T.sext_off += o_sdst[ti];
+        T.sext_item_off += o_sit[ti];
+        T.scontrib_off += o_scidx[ti];
+        T.pair_ptr_off += o_pptr[ti];
+        T.contrib_ptr_off += o_cptr[ti];
+        T.colptr_off += o_fptr[ti];
+        T.sext_ptr_off += o_sptr[ti];
+        T.sn_off += o_sn[ti];
+        P.tasks[ti] = T;
+      }
+    });
+    for (size_t ti = 0; ti < nt; ++ti) {
+      const LdltPlan& O = flat[ti];
+      P.max_lds_doubles = std::max(P.max_lds_doubles, O.max_lds_doubles);
+      P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, O.max_solve_lds_doubles);
+      P.factor_lds_bytes = std::max(P.factor_lds_bytes, O.factor_lds_bytes);
+      P.solve_lds_bytes = std::max(P.solve_lds_bytes, O.solve_lds_bytes);
+      n_real_pairs += static_cast<size_t>(O.flops / 2);
     }
-    pad(P.pairs, 2);
-    pad(P.ent_pair_ptr, 4);
-    pad(P.ent_contrib_ptr, 4);
-    while (P.lvl_ptr.size() % 4) {
-      P.lvl_ptr.push_back(0);
-      P.col_lvl_ptr.push_back(0);
-    }
-    pad(P.col_perm, 4);
-    while (P.fwd_ptr.size() % 4) {
-      P.fwd_ptr.push_back(0);
-      P.fwd_contrib_ptr.push_back(0);
-      P.bwd_ptr.push_back(0);
-    }
-    pad(P.fwd_items, 2);
-    pad(P.bwd_items, 2);
-    pad(P.sn_desc, 4);  // 12-byte records: four of them are three 16-byte groups
-    pad(P.col_sn, 4);
-    pad(P.sn_lvl_ptr, 4);
-    if (P.col_sn.size() != P.col_perm.size() || P.sn_lvl_ptr.size() != P.lvl_ptr.size())
-      throw std::runtime_error("ldlt: supernode arrays out of step with the column arrays");
-    LdltTask T = O.tasks.at(0);
-    T.ent_off += static_cast<uint32_t>(P.ent_src.size());
-    T.col_off += static_cast<uint32_t>(P.col_perm.size());
-    T.lvl_off += static_cast<uint32_t>(P.lvl_ptr.size());
-    T.ext_off += static_cast<uint32_t>(P.ext_dst.size());
-    T.pair_off += static_cast<uint32_t>(P.pairs.size());
-    T.contrib_off += static_cast<uint32_t>(P.contrib_idx.size());
-    T.fwd_item_off += static_cast<uint32_t>(P.fwd_items.size());
-    T.bwd_item_off += static_cast<uint32_t>(P.bwd_items.size());
-    T.sext_off += static_cast<uint32_t>(P.sext_dst.size());
-    T.sext_item_off += static_cast<uint32_t>(P.sext_items.size());
-    T.scontrib_off += static_cast<uint32_t>(P.scontrib_idx.size());
-    T.pair_ptr_off += static_cast<uint32_t>(P.ent_pair_ptr.size());
-    T.contrib_ptr_off += static_cast<uint32_t>(P.ent_contrib_ptr.size());
-    T.colptr_off += static_cast<uint32_t>(P.fwd_ptr.size());
-    T.sext_ptr_off += static_cast<uint32_t>(P.sext_ptr.size());
-    T.sn_off += static_cast<uint32_t>(P.sn_desc.size());
-    auto join = [](auto& dst, auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
-    join(P.ent_src, O.ent_src);
-    join(P.ent_flags, O.ent_flags);
-    join(P.ent_col, O.ent_col);
-    join(P.ent_out, O.ent_out);
-    join(P.ent_pair_ptr, O.ent_pair_ptr);
-    join(P.ent_contrib_ptr, O.ent_contrib_ptr);
-    join(P.pairs, O.pairs);
-    join(P.contrib_idx, O.contrib_idx);
-    join(P.ext_dst, O.ext_dst);
-    join(P.lvl_ptr, O.lvl_ptr);
-    join(P.col_lvl_ptr, O.col_lvl_ptr);
-    join(P.sn_lvl_ptr, O.sn_lvl_ptr);
-    join(P.col_perm, O.col_perm);
-    join(P.col_sn, O.col_sn);
-    join(P.sn_desc, O.sn_desc);
-    join(P.fwd_ptr, O.fwd_ptr);
-    join(P.fwd_contrib_ptr, O.fwd_contrib_ptr);
-    join(P.bwd_ptr, O.bwd_ptr);
-    join(P.fwd_items, O.fwd_items);
-    join(P.bwd_items, O.bwd_items);
-    join(P.scontrib_idx, O.scontrib_idx);
-    join(P.sext_dst, O.sext_dst);
-    join(P.sext_ptr, O.sext_ptr);
-    join(P.sext_items, O.sext_items);
-    P.max_lds_doubles = std::max(P.max_lds_doubles, O.max_lds_doubles);
-    P.max_solve_lds_doubles = std::max(P.max_solve_lds_doubles, O.max_solve_lds_doubles);
-    P.factor_lds_bytes = std::max(P.factor_lds_bytes, O.factor_lds_bytes);
-    P.solve_lds_bytes = std::max(P.solve_lds_bytes, O.solve_lds_bytes);
-    n_real_pairs += static_cast<size_t>(O.flops / 2);
-    P.tasks.push_back(T);
-    O = LdltPlan{};
+    flat = {};
   }
 
   lap("  ldlt: flattened plan arrays");

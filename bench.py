@@ -45,7 +45,7 @@ sys.path.insert(0, str(ROOT))
 from tests.support import models
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r04"    # profiles/<tag>_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r05"    # profiles/<tag>_traffic.json feeds roofline.traffic
 
 
 def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
@@ -388,7 +388,7 @@ def main():
                       "kkt_factor_solve": ("ldlt_mf_step_kernel", "ldlt_factor_solve_kernel"),
                       "kkt_assemble": "kkt_assemble_kernel",
                       "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
-                      "ldlt_solve": ("ldlt_fwd", "ldlt_bwd")}
+                      "ldlt_solve": ("ldlt_fwd", "ldlt_bwd", "ldlt_mf_solve_kernel")}
             traffic_by_group = {}
             for grp, pre in prefix.items():
                 pres = pre if isinstance(pre, tuple) else (pre,)

@@ -9,7 +9,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -30,10 +32,74 @@ namespace slpx {
                                " at " #expr);                                             \
   } while (0)
 
+// The read-only plan arrays of a system (a hundred of them: tape tables, KKT maps, LDLT lists, task images) in a
+// few large device allocations filled by ONE copy each, instead of a hipMalloc and a synchronous hipMemcpy per array
+// (2-3 ms of a 7 ms upload at cart-pole N=1000): while an arena is the thread's current one (DeviceArena::Scope,
+// DeviceNlp's constructor), DevBuf::upload() places its data in the arena — the device pointer is valid at once, the
+// bytes arrive with commit(), before anything is launched.
+class DeviceArena {
+ public:
+  DeviceArena() = default;
+  DeviceArena(const DeviceArena&) = delete;
+  DeviceArena& operator=(const DeviceArena&) = delete;
+  ~DeviceArena() {
+    for (Chunk& c : m_chunks)
+      if (c.dev) (void)hipFree(c.dev);
+  }
+  void* place(const void* src, size_t bytes) {
+    constexpr size_t kAlign = 256, kChunk = 2u << 20, kSlack = 128u << 10;  // (slack: kernels that request a padded round past an array's end)
+    if (m_chunks.empty() || m_chunks.back().used + bytes + kSlack > m_chunks.back().cap) {
+      Chunk c;
+      c.cap = std::max(kChunk, bytes + 2 * kSlack);
+      if (hipMalloc(reinterpret_cast<void**>(&c.dev), c.cap) != hipSuccess) throw std::runtime_error("slpx: hipMalloc of a plan arena failed");
+      m_chunks.push_back(std::move(c));
+    }
+    Chunk& c = m_chunks.back();
+    const size_t at = c.used;
+    if (c.host.capacity() < c.cap) c.host.reserve(c.cap);
+    if (c.host.size() < at + bytes) c.host.resize(at + bytes);
+    std::memcpy(c.host.data() + at, src, bytes);
+    c.used = (at + bytes + kAlign - 1) / kAlign * kAlign;
+    return c.dev + at;
+  }
+  void commit() {
+    for (Chunk& c : m_chunks) {
+      if (c.host.size() > c.committed) {
+        if (hipMemcpy(c.dev + c.committed, c.host.data() + c.committed, c.host.size() - c.committed, hipMemcpyHostToDevice) != hipSuccess)
+          throw std::runtime_error("slpx: upload of a plan arena failed");
+        c.committed = c.host.size();
+      }
+      if (&c != &m_chunks.back()) std::vector<char>().swap(c.host);
+    }
+    if (!m_chunks.empty()) {  // (the open chunk keeps no mirror either: later placements start a new one)
+      std::vector<char>().swap(m_chunks.back().host);
+      m_chunks.back().cap = m_chunks.back().used;
+    }
+  }
+  static DeviceArena*& current() {
+    static thread_local DeviceArena* arena = nullptr;
+    return arena;
+  }
+  struct Scope {
+    DeviceArena* prev;
+    explicit Scope(DeviceArena* a) : prev(current()) { current() = a; }
+    ~Scope() { current() = prev; }
+  };
+
+ private:
+  struct Chunk {
+    char* dev = nullptr;
+    std::vector<char> host;  // mirror of [0, used) until commit()
+    size_t used = 0, committed = 0, cap = 0;
+  };
+  std::vector<Chunk> m_chunks;
+};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;  // false: a slice of a DeviceArena
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -41,11 +107,13 @@ struct DevBuf {
   void swap(DevBuf& o) {
     std::swap(p, o.p);
     std::swap(n, o.n);
+    std::swap(owned, o.owned);
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
   }
   void alloc(size_t count) {
     release();
@@ -53,6 +121,14 @@ struct DevBuf {
     if (count) SLPX_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
   }
   void upload(const std::vector<T>& h) {
+    // (the small arrays — most of them — share an arena; a big one gains nothing from a second host copy)
+    if (DeviceArena* arena = DeviceArena::current(); arena != nullptr && !h.empty() && h.size() * sizeof(T) <= (64u << 10)) {
+      release();
+      p = static_cast<T*>(arena->place(h.data(), h.size() * sizeof(T)));
+      n = h.size();
+      owned = false;
+      return;
+    }
     alloc(h.size());
     if (!h.empty()) SLPX_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   }
@@ -467,6 +543,7 @@ class DeviceNlp {
                  const std::vector<uint8_t>& active);
   void enqueue_factor(int parity, hipStream_t stream);
 
+  DeviceArena m_arena;  // the plan arrays uploaded by the constructor (DevBuf::upload places them here)
   const NlpStructure& m_s_ref;
   const KktPlan& m_k_ref;
   const LdltPlan& m_l_ref;

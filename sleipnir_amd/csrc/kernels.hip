@@ -523,6 +523,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     throw std::runtime_error("slpx: no HIP device available (the product path has no CPU fallback)");
   SLPX_HIP_CHECK(hipSetDevice(device));
   SetupLap lap;
+  // every upload() of this constructor goes into the system's arena: a few allocations, one copy each (commit below)
+  struct ArenaGuard {
+    ~ArenaGuard() { DeviceArena::current() = nullptr; }
+  } arena_guard;
+  DeviceArena::current() = &m_arena;
 
   // Chained steps (sweep_full_for_step): for one problem whose multifrontal step kernel leaves the sweep
   // room on the chip (at most CUs - 64 workgroups: cart-pole N=5000's 265 do not, and there chaining costs
@@ -665,13 +670,17 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   if (const char* env = std::getenv("SLPX_FUSE_BACKSUB")) m_fuse_backsub = m_fuse_backsub && env[0] != '0';
   if (const char* env = std::getenv("SLPX_FUSE_KKT_STORE")) m_fuse_kkt_store = env[0] != '0';
   if (m_fuse_kkt) build_inline_kkt(s, k, l);
+  lap("    images: inline KKT terms");
   if (m_fuse_backsub) build_inline_backsub(k, l);
+  lap("    images: back-substitution rows");
   m_fuse_solve = m_fuse_launches && m_fuse_backsub;
   if (const char* env = std::getenv("SLPX_FUSE_SOLVE")) m_fuse_solve = m_fuse_solve && env[0] != '0';
   const bool want_one_launch = m_fuse_solve;
   if (m_fuse_solve) build_solve_in_place(l);
+  lap("    images: solve in place");
   m_sip_ok = m_fuse_solve;
   if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
+  lap("    images: multifrontal task images");
   if (m_mf) m_fuse_solve = true;
   m_chain_on = m_mf && m_chain_mode != 0;
   lap("  upload: inline KKT / back-substitution / multifrontal images");
@@ -828,6 +837,8 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   }
   const uint64_t scratch = std::max(s.full.global_scratch_doubles, s.values.global_scratch_doubles);
   m_scratch.alloc(B * std::max<uint64_t>(1, scratch));
+  DeviceArena::current() = nullptr;
+  m_arena.commit();
   lap("  upload: value buffers");
   set_scaling(std::vector<double>(s.n_scales(), 1.0));
   lap("  upload: scaling, static V");
@@ -1228,17 +1239,26 @@ void DeviceNlp::build_solve_in_place(const LdltPlan& l) {
   std::vector<uint32_t> zent(l.col_perm.size(), 0);
   uint32_t widest_cols = 0;
   bool ok = true;
-  for (const LdltTask& t : l.tasks) {
-    std::unordered_map<uint32_t, uint32_t> entry_of;  // position in Lx -> entry of the task
+  // position in Lx -> (task, entry of the task): every position of L is one entry of one task (a table over nnz(L)
+  // instead of a hash map per task: 2.6 ms of a 30 ms setup at cart-pole N=1000)
+  std::vector<uint32_t> entry_at(static_cast<size_t>(std::max<int64_t>(1, l.nnzL)), 0xffffffffu), task_at(entry_at.size(), 0xffffffffu);
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
+    const LdltTask& t = l.tasks[ti];
     for (uint32_t i = 0; i < t.n_ent; ++i) {
       const uint8_t fl = l.ent_flags[t.ent_off + i];
       if (fl & 4) zent[t.col_off + l.ent_col[t.ent_off + i]] = i;
-      else if (!(fl & 1)) entry_of[l.ent_out[t.ent_off + i]] = i;
+      else if (!(fl & 1)) {
+        entry_at[l.ent_out[t.ent_off + i]] = i;
+        task_at[l.ent_out[t.ent_off + i]] = static_cast<uint32_t>(ti);
+      }
     }
+  }
+  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
+    const LdltTask& t = l.tasks[ti];
     for (uint32_t q = 0; q < t.n_bwd_items; ++q) {
-      auto it = entry_of.find(l.bwd_items[t.bwd_item_off + q].lpos);
-      if (it == entry_of.end()) ok = false;
-      else items[t.bwd_item_off + q].lpos = it->second;
+      const uint32_t lpos = l.bwd_items[t.bwd_item_off + q].lpos;
+      if (lpos >= entry_at.size() || task_at[lpos] != ti) ok = false;
+      else items[t.bwd_item_off + q].lpos = entry_at[lpos];
     }
     widest_cols = std::max(widest_cols, t.n_col);
   }

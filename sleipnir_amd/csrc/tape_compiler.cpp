@@ -986,26 +986,22 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   std::vector<uint8_t>& flag = tables.flag;
   flag.assign(G, 0);
   // ---- 1. reachable nodes, roots ----
+  // (operands have smaller numbers than the nodes that use them: ONE descending pass over the graph marks
+  // everything below the roots — no stack, no second visit; a depth-first walk took twice as long at N=5000)
   {
-    std::vector<NodeId> stack;
+    NodeId highest = -1;
     auto seed = [&](NodeId r) {
       if (r == kNull) return;
-      flag[r] |= kRoot;
-      if (!(flag[r] & kReach)) {
-        flag[r] |= kReach;
-        stack.push_back(r);
-      }
+      flag[r] |= kRoot | kReach;
+      highest = std::max(highest, r);
     };
     for (auto& v : value_outs) seed(v.node);
     for (auto& r : rows) seed(r.root);
-    while (!stack.empty()) {
-      const NodeId n = stack.back();
-      stack.pop_back();
-      for (NodeId a : {g.a0[n], g.a1[n]})
-        if (a != kNull && !(flag[a] & kReach)) {
-          flag[a] |= kReach;
-          stack.push_back(a);
-        }
+    for (NodeId n = highest; n >= 0; --n) {
+      if (!(flag[n] & kReach)) continue;
+      const NodeId a = g.a0[n], b = g.a1[n];
+      if (a != kNull) flag[a] |= kReach;
+      if (b != kNull) flag[b] |= kReach;
     }
   }
   lap("  tape families:   reach");

@@ -27,22 +27,19 @@ nb = used.sum()
 print("template blocks", nt, "blocks recorded", nb, "kernel span us", en[used].max())
 # per chunk of blocks: start range, end range, duration
 def show(lo, hi, label):
+    if hi <= lo:
+        return
     s, e = st[lo:hi], en[lo:hi]
     print(f"{label:28s} [{lo:4d},{hi:4d}) start {s.min():6.2f}..{s.max():6.2f} end {e.min():6.2f}..{e.max():6.2f} dur {(e-s).min():6.2f}..{(e-s).max():6.2f}")
 show(0, nt, "all template blocks")
 # first family: 16 instance-chunks x 7 groups (block = chunk*ng + g)
-ng = 7
-nch = (N + 63) // 64
-for g in range(ng):
-    idx = np.arange(g, nch * ng, ng)
-    s, e = st[idx], en[idx]
-    print(f"  stage family group {g}: start {s.min():6.2f}..{s.max():6.2f} dur {(e-s).min():6.2f}..{(e-s).max():6.2f} end max {e.max():6.2f}")
-show(nch * ng, nt, "other families")
 show(nt, nb, "interpreted tasks")
 d = en - st
 order = np.argsort(-en[:nb])[:8]
 print("last finishers:", [(int(b), round(float(st[b]), 2), round(float(en[b]), 2)) for b in order])
 
-for b in (0, 1, 6, 28, nt - 2, nt - 1, nt, nb - 1):
+for b in sorted(set(list(range(min(nt, 32))) + [nt - 1, nt, nb - 1])):
+    if b < 0 or b >= NB or c8[b, 0] <= 0:
+        continue
     r = (c8[b] - t0) / 100.0
     print(f"block {b}: entry {r[0]:.2f} body {r[2]:.2f} leaves {r[3]:.2f} forward {r[4]:.2f} exit {r[1]:.2f}")

@@ -1317,9 +1317,10 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
   if (stride16 > kMfImageGroups) return;  // (a task image beyond what the staging loop requests)
   // fixed-size slots (the kernel requests a task's image before it knows its length) + one round of padding
   image.assign(stride16 * l.tasks.size() + kMfImageGroups, uint4{0, 0, 0, 0});
-  std::atomic<bool> out_of_bounds{false};
+  std::atomic<bool> out_of_bounds{false}, terms_do_not_fit{false};
   parallel_chunks(l.tasks.size(), 8, [&](size_t t_begin, size_t t_end, unsigned) {
     std::vector<uint8_t> fl;
+    std::vector<int32_t> vs;
     for (size_t ti = t_begin; ti < t_end; ++ti) {
       const LdltTask& t = l.tasks[ti];
       const LdltMfTask& m = l.mf_tasks[ti];
@@ -1338,7 +1339,34 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
       put(cv.o_tab, l.mf_tab.data() + m.tab_off, 2u * m.n_tab);
       put(cv.o_lvl, l.mf_lvl_ptr.data() + t.lvl_off, 4u * (t.n_lvl + 1));
       put(cv.o_ext, l.mf_ext.data() + m.ext_off, 4u * m.n_ext);
-      put(cv.o_src, m_h_vsrc.data() + t.ent_off, 4u * t.n_ent);
+      {
+        // where an entry's value comes from; an entry that is a sum of terms says how many of each kind
+        // (kkt_terms_sum_grouped: the terms lie kind by kind)
+        vs.assign(m_h_vsrc.begin() + t.ent_off, m_h_vsrc.begin() + t.ent_off + t.n_ent);
+        const KktTerm* tt = m_h_terms.data() + static_cast<size_t>(m_h_task_terms[ti].x) * 4u / 3u;
+        for (uint32_t i = 0; i < t.n_ent; ++i) {
+          if (vs[i] >= -1) continue;
+          const uint32_t code = static_cast<uint32_t>(-(vs[i] + 2));
+          const uint32_t first = code & 0xfffffu, cnt = code >> 20;
+          uint32_t has_g = 0, n_a = 0, n_b = 0;
+          bool sorted = true;
+          int last = -1;
+          for (uint32_t q = first; q < first + cnt; ++q) {
+            const int kind = tt[q].b >> 28;
+            sorted = sorted && kind >= last;
+            last = kind;
+            if (kind == 1) ++has_g;
+            else if (kind == 0 || kind == 2) ++n_a;
+            else ++n_b;
+          }
+          if (!sorted || has_g > 1 || !mf_term_code_fits(first, n_a, n_b)) {
+            terms_do_not_fit = true;
+            break;
+          }
+          vs[i] = -static_cast<int32_t>(2u + mf_term_code(first, has_g, n_a, n_b));
+        }
+        put(cv.o_src, vs.data(), 4u * t.n_ent);
+      }
       {
         // (bit 5: the entry takes update slots)
         fl.assign(l.ent_flags.begin() + t.ent_off, l.ent_flags.begin() + t.ent_off + t.n_ent);
@@ -1350,6 +1378,7 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
       put(cv.o_cidx, l.mf_contrib_idx.data() + m.contrib_off, 4u * m.n_contrib_idx);
       put(cv.o_cp, l.col_perm.data() + t.col_off, 4u * t.n_col);
       put(cv.o_anc, l.mf_anc.data() + m.anc_off, 4u * m.n_anc);
+      put(cv.o_fr, l.mf_fronts.data() + m.front_off, sizeof(LdltFront) * m.n_front);
       {
         // the inertia counters start at zero, the smallest |d| at +inf
         const unsigned long long inf = 0x7ff0000000000000ull;
@@ -1362,6 +1391,7 @@ void DeviceNlp::build_mf(const LdltPlan& l) {
     }
   });
   if (out_of_bounds) throw std::runtime_error("slpx: task image layout out of bounds");
+  if (terms_do_not_fit) return;  // (an entry of hundreds of terms: the pair-list kernels' encoding holds 2047)
   lds = mf_align16(lds) + 16u;
   int per_cu = 0, cus = 0;
   hipFuncAttributes attr{};
@@ -1540,8 +1570,19 @@ void DeviceNlp::debug_tape_clocks(unsigned long long* out16) {
 
 void DeviceNlp::debug_ldlt_clocks(unsigned int next_round, unsigned long long* out24) {
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+#ifdef SLPX_MF_CLOCKS
+  if ((next_round >> 16) == 0xffffu) {  // (the instrumented build: the slots of task (next_round & 0xffff) in the last launch)
+    SLPX_HIP_CHECK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_mf_clocks), 24 * sizeof(unsigned long long),
+                                       24 * sizeof(unsigned long long) * (next_round & 0xffffu)));
+    return;
+  }
+#endif
   SLPX_HIP_CHECK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_ldlt_clocks), 24 * sizeof(unsigned long long)));
-  m_ldev.clock_task = next_round < static_cast<unsigned int>(m_l_ref.n_rounds) ? m_l_ref.round_ptr[next_round] : 0xffffffffu;
+  // (bits 8 and up: which task of the round, 0 = its first)
+  const unsigned int round = next_round & 0xffu, within = next_round >> 8;
+  m_ldev.clock_task = 0xffffffffu;
+  if (round < static_cast<unsigned int>(m_l_ref.n_rounds) && m_l_ref.round_ptr[round] + within < m_l_ref.round_ptr[round + 1])
+    m_ldev.clock_task = m_l_ref.round_ptr[round] + within;
 }
 
 void DeviceNlp::refresh_params(const Graph& g) {

@@ -189,6 +189,49 @@ __device__ __forceinline__ double kkt_terms_sum(const KktTerm* __restrict__ term
   return is_rhs ? -g + aey + ait : direct + pr;
 }
 
+// The same sum for the step kernel of the fronts, whose image says how many terms of each kind an entry has
+// (kMfTerm*: DeviceNlp::build_mf re-encodes the entry's word; the terms of an entry are laid down kind by kind —
+// [g] [A_e^T y ...] [A_i^T ...] for a right-hand-side row, [direct ...] [products ...] for an entry of the matrix,
+// DeviceNlp::build_inline_kkt), so the kinds need not be read back and nothing branches on them: one trip to LDS
+// per four terms of both groups, one select and one add per term.  The loop above compiles to a chain of divergent
+// branches, ~100 instructions per term, and a lane's entry has up to a dozen terms (a right-hand-side row sums a
+// column of A_e^T y): 2 us of the step's critical path at cart-pole N=1000 by the kernel's own clocks.  Same
+// accumulators, same order, same bits: acc + 0.0 is acc for every acc but -0.0, which a sum that starts at +0.0
+// never is.
+constexpr uint32_t kMfTermFirstBits = 14, kMfTermABits = 8, kMfTermBBits = 7;  // + 1 bit: the row has a gradient term
+__host__ __device__ inline bool mf_term_code_fits(uint32_t first, uint32_t n_a, uint32_t n_b) {
+  return first < (1u << kMfTermFirstBits) && n_a < (1u << kMfTermABits) && n_b < (1u << kMfTermBBits);
+}
+__host__ __device__ inline uint32_t mf_term_code(uint32_t first, uint32_t has_g, uint32_t n_a, uint32_t n_b) {
+  return first | (n_a << kMfTermFirstBits) | (n_b << (kMfTermFirstBits + kMfTermABits)) |
+         (has_g << (kMfTermFirstBits + kMfTermABits + kMfTermBBits));
+}
+__device__ __forceinline__ double kkt_terms_sum_grouped(const double* __restrict__ prod, uint32_t code, bool is_rhs) {
+  const uint32_t first = code & ((1u << kMfTermFirstBits) - 1u);
+  const uint32_t n_a = (code >> kMfTermFirstBits) & ((1u << kMfTermABits) - 1u);
+  const uint32_t n_b = (code >> (kMfTermFirstBits + kMfTermABits)) & ((1u << kMfTermBBits) - 1u);
+  const uint32_t has_g = code >> (kMfTermFirstBits + kMfTermABits + kMfTermBBits);
+  const double g = prod[first];  // (read whether it is one or not: a select, not a branch)
+  const uint32_t p_a = first + has_g, p_b = p_a + n_a;
+  const uint32_t n = n_a > n_b ? n_a : n_b;
+  double a = 0.0, b = 0.0;
+  for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+    double va[4], vb[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      va[u] = prod[p_a + (i0 + u < n_a ? i0 + u : 0u)];
+      vb[u] = prod[p_b + (i0 + u < n_b ? i0 + u : 0u)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      a += i0 + u < n_a ? va[u] : 0.0;
+      b += i0 + u < n_b ? vb[u] : 0.0;
+    }
+  }
+  // (kkt_terms_sum: -g + aey + ait with g = 0.0 where the row has no gradient term; direct + pr)
+  return is_rhs ? -(has_g ? g : 0.0) + a + b : a + b;
+}
+
 // (`vblock` of `vgrid`: the block's position among the blocks doing this job — the fused
 // kkt_build_kernel gives each job a slice of one launch)
 template <bool COHERENT = false>

@@ -100,28 +100,21 @@ __device__ __forceinline__ double lds_ld(uint32_t addr) { return *reinterpret_ca
 __device__ __forceinline__ void lds_st(uint32_t addr, double v) { *reinterpret_cast<LdsF64*>(static_cast<uintptr_t>(addr)) = v; }
 __device__ __forceinline__ uint32_t lds_ld16(uint32_t addr) { return *reinterpret_cast<const LdsU16*>(static_cast<uintptr_t>(addr)); }
 
-// A front's descriptor (16 bytes, wave-uniform) through the SCALAR cache into scalar registers: a vector
-// load would hold four vector registers across the front's whole body (the kernel sits at the 128 the
-// 1024-thread workgroup allows: measured, a descriptor prefetched into vector registers was spilled to
-// scratch and reloaded every level).  Load and wait are ONE asm statement: the compiler does not know
-// that the registers are written asynchronously, and a copy or spill of them between a separate load
-// and its wait would take the stale contents (seen: a memory fault).  A wave asks for the descriptor
-// of its front in the NEXT level at the end of this level's work, in front of the barrier.
-__device__ __forceinline__ u32x4 s_load_desc(const LdltFront* p) {
+// A front's descriptor (16 bytes, wave-uniform) from the task's image in LDS into scalar registers: one 16-byte
+// read, four v_readfirstlane — the vector registers are free again at once (held across a front's body they were
+// spilled: the kernel sits near the 128 the 1024-thread workgroup allows).  The descriptors used to come through
+// the scalar cache from the plan in memory, load and wait in one asm statement at the end of every level: a miss
+// was a trip to L2 or beyond in front of the level's barrier — by the front microbenchmark a level of the kernel
+// cost 400 clocks more than its widest front in the factorization and 300-400 more in the backward solve,
+// 28 levels a step.  A wave asks for the descriptor of its front in the NEXT level at the end of this level's work.
+__device__ __forceinline__ u32x4 lds_load_desc(uint32_t addr) {
+  using LdsU32x4 = __attribute__((address_space(3))) u32x4;
+  const u32x4 v = *reinterpret_cast<const LdsU32x4*>(static_cast<uintptr_t>(addr));
   u32x4 r;
-#ifdef MF_DESC_VECTOR
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  r[0] = __builtin_amdgcn_readfirstlane(v.x);
-  r[1] = __builtin_amdgcn_readfirstlane(v.y);
-  r[2] = __builtin_amdgcn_readfirstlane(v.z);
-  r[3] = __builtin_amdgcn_readfirstlane(v.w);
-  return r;
-#endif
-  const uint64_t a = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
-  const uint64_t u = (static_cast<uint64_t>(hi) << 32) | lo;
-  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(u) : "memory");
+  r[0] = __builtin_amdgcn_readfirstlane(v[0]);
+  r[1] = __builtin_amdgcn_readfirstlane(v[1]);
+  r[2] = __builtin_amdgcn_readfirstlane(v[2]);
+  r[3] = __builtin_amdgcn_readfirstlane(v[3]);
   return r;
 }
 
@@ -138,6 +131,21 @@ __device__ __forceinline__ uint32_t mf_coff(uint32_t c, uint32_t nr) { return 8u
 // as a compile-time constant (0, 1, 2) or kMfNchAny: a run-time loop.
 // ---------------------------------------------------------------------------
 constexpr int kMfNchAny = 3;
+
+// Phase clocks of the step kernel (profiles/ldlt_clocks.sh builds a library with -DSLPX_MF_CLOCKS): kept in LDS and
+// written out when the task is through.  A clock stored to memory where it is taken is waited for at the next barrier
+// (a workgroup barrier waits for the wave's outstanding stores): ~1 us of instrument per clock point, in a kernel
+// whose phases are one to five microseconds.  The ordinary build carries no clock code in this kernel.
+#ifdef SLPX_MF_CLOCKS
+constexpr uint32_t kMfClockBytes = 192;  // the 24 slots of g_ldlt_clocks
+constexpr uint32_t kMfClockTasks = 1024;
+__device__ unsigned long long g_mf_clocks[kMfClockTasks * 24];  // EVERY task's slots of the last launch (one timeline)
+#define SLPX_MF_CLOCK(k) \
+  if (threadIdx.x == 0) s_clk[k] = wall_clock64()
+#else
+constexpr uint32_t kMfClockBytes = 0;
+#define SLPX_MF_CLOCK(k)
+#endif
 constexpr uint32_t kMfImageGroups = 6144;  // 16-byte groups of a task's image the staging loop requests: 96 KB
 
 // ---------------------------------------------------------------------------
@@ -464,11 +472,11 @@ __device__ __forceinline__ void mf_solve_front(uint32_t xr, uint32_t u0, uint32_
 // LDS (bytes; the first four regions are what the tables address, so they start at 0):
 //   U[n_ent] f64 | arena f64 | 1/d[n_col] f64 | x[n_col + n_anc + 1] f64 |
 //   tables u16 | levels u32 | ext u32 | src i32 | flags u8 | entries with update slots u16 | their slot ranges u32 | slots u32 |
-//   colperm u32 | anc u32 | counters 32 B | KKT terms + products | back-substitution rows
+//   colperm u32 | anc u32 | front descriptors 16 B | counters 32 B | KKT terms + products | back-substitution rows
 // ---------------------------------------------------------------------------
 struct MfCarve {
   uint32_t o_arena, o_invd, o_x, o_tab, o_lvl, o_ext, o_src, o_flags, o_cent, o_cptr, o_cidx, o_cp, o_anc,
-      o_cnt, o_terms;
+      o_fr, o_cnt, o_terms;
 };
 __host__ __device__ inline uint32_t mf_align16(uint32_t v) { return (v + 15u) & ~15u; }
 __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask& m) {
@@ -487,8 +495,9 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
   c.o_cidx = c.o_cptr + q(m.n_cent + 1u, 4);
   c.o_cp = c.o_cidx + q(m.n_contrib_idx, 4);
   c.o_anc = c.o_cp + q(t.n_col, 4);
-  c.o_cnt = c.o_anc + q(m.n_anc, 4);
-  c.o_terms = c.o_cnt + 32u;
+  c.o_fr = c.o_anc + q(m.n_anc, 4);
+  c.o_cnt = c.o_fr + 16u * m.n_front;
+  c.o_terms = c.o_cnt + 32u + kMfClockBytes;
   return c;
 }
 
@@ -518,7 +527,9 @@ __device__ __forceinline__ void mf_step_body(
   const LdltMfTask m = Mf.tasks[task_index];
   const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
   const double delta = reg != nullptr ? reg[0] : Mf.delta, gamma = reg != nullptr ? reg[1] : Mf.gamma;
-  SLPX_LDLT_CLOCK(0);
+#ifdef SLPX_MF_CLOCKS
+  const unsigned long long clk_entry = wall_clock64();  // (slot 0, stored behind the staging loop: the image covers the slots)
+#endif
   const MfCarve cv = mf_carve(t, m);
   double* U = reinterpret_cast<double*>(smem_raw);
   double* arena = reinterpret_cast<double*>(smem_raw + cv.o_arena);
@@ -535,6 +546,9 @@ __device__ __forceinline__ void mf_step_body(
   const uint32_t* anc = reinterpret_cast<const uint32_t*>(smem_raw + cv.o_anc);
   int* s_cnt = reinterpret_cast<int*>(smem_raw + cv.o_cnt);
   unsigned long long* s_minp = reinterpret_cast<unsigned long long*>(s_cnt + 4);
+#ifdef SLPX_MF_CLOCKS
+  unsigned long long* s_clk = reinterpret_cast<unsigned long long*>(smem_raw + cv.o_cnt + 32u);
+#endif
   uint4* s_terms = reinterpret_cast<uint4*>(smem_raw + cv.o_terms);
   auto g16 = [&](uint32_t o) { return reinterpret_cast<uint4*>(smem_raw + o); };
 
@@ -567,11 +581,16 @@ __device__ __forceinline__ void mf_step_body(
     x[t.n_col + m.n_anc] = 1.0;
   }
   __syncthreads();
-  SLPX_LDLT_CLOCK(1);
+#ifdef SLPX_MF_CLOCKS
+  if (threadIdx.x == 0) s_clk[0] = clk_entry;
+#endif
+  SLPX_MF_CLOCK(1);
   if (stats_next != nullptr && task_index == 0 && tid == 0) stats_next[0] = LdltStats{0, 0, 0, 0, 0x7ff0000000000000ull};
   if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
+  SLPX_MF_CLOCK(14);  // (slot 14: the sweep's numbers may be read)
 
   // ---- matrix values (ldlt_factor_body) ----
+  bool regularized = false;  // (uniform)
   if (!F.inline_kkt) {
     // (a re-attempt of the policy loop on the system already in memory: the image holds what every
     // entry is MADE of, where it sits in lhs / rhs comes from the plan in memory)
@@ -584,22 +603,50 @@ __device__ __forceinline__ void mf_step_body(
     const double mu = F.mu[0];
     const KktTerm* terms = reinterpret_cast<const KktTerm*>(s_terms);
     const uint32_t span = n_terms > t.n_ent ? n_terms : t.n_ent;
-    for (uint32_t k = tid; k < span; k += THREADS) {
-      const int w = k < t.n_ent ? src[k] : -1;
-      const double v = w >= 0 ? F.V[w & 0x3fffffff] : 0.0;
-      const bool on = k < n_terms;
-      const KktTermLoads tl = kkt_term_fetch(on ? terms[k] : KktTerm{0, 0, 0}, on, F.V, F.s, F.y, F.z);
-      if (k < t.n_ent && w >= -1) U[k] = (w & 0x40000000) && w >= 0 ? -v : v;
-      if (on) tprod[k] = kkt_term_product(tl, mu);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-      const int w = src[i];
-      if (w < -1) {
-        const uint32_t code = static_cast<uint32_t>(-(w + 2));
-        U[i] = kkt_terms_sum(terms, tprod, code & 0xfffffu, code >> 20, (flags[i] & 4) != 0);
+    // (three rounds of the workgroup are requested together: ONE trip to memory for a task of up to 3 THREADS entries
+    // and terms — a loop of one round per pass made as many dependent trips as it had passes, two to three per task)
+    constexpr int kEv = 3;
+    for (uint32_t k0 = tid; k0 < span; k0 += kEv * THREADS) {
+      int w[kEv];
+      double v[kEv];
+      KktTermLoads tl[kEv];
+#pragma unroll
+      for (int u = 0; u < kEv; ++u) {
+        const uint32_t k = k0 + u * THREADS;
+        w[u] = k < t.n_ent ? src[k] : -1;
+        v[u] = w[u] >= 0 ? F.V[w[u] & 0x3fffffff] : 0.0;
+        const bool on = k < n_terms;
+        tl[u] = kkt_term_fetch(on ? terms[k] : KktTerm{0, 0, 0}, on, F.V, F.s, F.y, F.z);
+      }
+#pragma unroll
+      for (int u = 0; u < kEv; ++u) {
+        const uint32_t k = k0 + u * THREADS;
+        if (k < t.n_ent && w[u] >= -1) U[k] = (w[u] & 0x40000000) && w[u] >= 0 ? -v[u] : v[u];
+        if (k < n_terms) tprod[k] = kkt_term_product(tl[u], mu);
       }
     }
+    __syncthreads();
+    SLPX_MF_CLOCK(15);  // (slot 15: values and products are in LDS)
+    // the sums of terms and, in the same pass, the regularization (a lane reads back what it wrote itself; flag
+    // bit 5, set in the task's image only: the entry takes update slots and is regularized below, with them)
+    const bool fold_reg = F.store_lhs == nullptr;  // (tests ask for the evaluated system as an assembly pass leaves it: unregularized)
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const int w = src[i];
+      const uint8_t fl = flags[i];
+      const bool summed = w < -1, reg_here = fold_reg && (fl & 0x21) == 1;
+      if (summed || reg_here) {
+        double u;
+        if (summed) {
+          u = kkt_terms_sum_grouped(tprod, static_cast<uint32_t>(-(w + 2)), (fl & 4) != 0);
+        } else {
+          u = U[i];
+        }
+        if (reg_here) u += (fl & 2) ? -gamma : delta;
+        U[i] = u;
+      }
+    }
+    regularized = fold_reg;
+    SLPX_MF_CLOCK(4);  // (slot 4: this wave's sums are done)
     if (F.store_lhs != nullptr) {
       __syncthreads();
       for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
@@ -609,12 +656,14 @@ __device__ __forceinline__ void mf_step_body(
     }
   }
   __syncthreads();
+  SLPX_MF_CLOCK(13);  // (slot 13: every wave's)
   // ---- regularization + update blocks of child tasks (slots: ldlt_factor_body) ----
   // (flag bit 5, set in the task's image only: the entry takes update slots and is handled below)
-  for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
-    const uint8_t fl = flags[i];
-    if ((fl & 0x21) == 1) U[i] += (fl & 2) ? -gamma : delta;
-  }
+  if (!regularized)
+    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+      const uint8_t fl = flags[i];
+      if ((fl & 0x21) == 1) U[i] += (fl & 2) ? -gamma : delta;
+    }
   for (uint32_t j = tid; j < m.n_cent; j += THREADS) {
     const uint32_t i = cent[j];
     const uint8_t fl = flags[i];
@@ -659,31 +708,31 @@ __device__ __forceinline__ void mf_step_body(
     U[i] = acc;
   }
   __syncthreads();
-  SLPX_LDLT_CLOCK(2);
+  SLPX_MF_CLOCK(2);
 
   // ---- levels: a wave per front ----
   // (the descriptor of the wave's front in the NEXT level is requested before this level's work)
-  const LdltFront* gfr = Mf.fronts + m.front_off;
+  const uint32_t gfr = cv.o_fr;  // (LDS byte address of the task's front descriptors)
   const uint32_t last_front = m.n_front ? m.n_front - 1u : 0u;
   {
     uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[0]), end = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[1] : 0);
-    u32x4 d = s_load_desc(gfr + (beg + wave < last_front ? beg + wave : last_front));
+    u32x4 d = lds_load_desc(gfr + 16u * (beg + wave < last_front ? beg + wave : last_front));
     for (uint32_t l = 0; l < t.n_lvl; ++l) {
       const uint32_t next_end = __builtin_amdgcn_readfirstlane(lvl[l + 2 <= t.n_lvl ? l + 2 : t.n_lvl]);
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-        if (q != beg + wave) d = s_load_desc(gfr + q);
+        if (q != beg + wave) d = lds_load_desc(gfr + 16u * q);
         const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
         mf_front<MFMA>(cv.o_tab + 2u * d[0], w, nr, nch, d[3] & 0xffffu, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16),
                  contrib, lane);
       }
-      d = s_load_desc(gfr + (end + wave < last_front ? end + wave : last_front));
+      d = lds_load_desc(gfr + 16u * (end + wave < last_front ? end + wave : last_front));
       __syncthreads();
+      if (l < 8u) SLPX_MF_CLOCK(8u + l);  // (slots 8..15: the end of the first eight levels)
       beg = end;
       end = next_end;
     }
   }
-  SLPX_LDLT_CLOCK(3);
-  SLPX_LDLT_CLOCK(4);
+  SLPX_MF_CLOCK(3);
   // results + inertia (ldlt_factor_exit; where an entry goes and whose 1/d scales it: streamed from the
   // plan in memory — off the critical path, and 6 bytes per entry that need not sit in LDS)
   auto exit_and_count = [&] {
@@ -723,7 +772,7 @@ __device__ __forceinline__ void mf_step_body(
     }
   };
   if (!top) exit_and_count();  // (its store acknowledgements come in while the task waits for its ancestors)
-  SLPX_LDLT_CLOCK(5);
+  SLPX_MF_CLOCK(5);
 
   // ---- backward solve on what the factorization left in LDS ----
   // this lane's row of the back-substitution (ldlt_bwd_run): everything but p is known now
@@ -761,7 +810,7 @@ __device__ __forceinline__ void mf_step_body(
         bs_ref[k] = bt.ref;
       }
   }
-  SLPX_LDLT_CLOCK(17);
+  SLPX_MF_CLOCK(17);
   // x of the ancestor tasks' rows the fronts reach: handed over through the values themselves
   for (uint32_t a = tid; a < m.n_anc; a += THREADS) x[t.n_col + a] = slot_read(&xg[anc[a]]);
   if (bs_mine) {
@@ -780,25 +829,29 @@ __device__ __forceinline__ void mf_step_body(
     }
   }
   __syncthreads();
-  SLPX_LDLT_CLOCK(18);
+  SLPX_MF_CLOCK(18);
   {
     uint32_t end = __builtin_amdgcn_readfirstlane(lvl[t.n_lvl]), beg = __builtin_amdgcn_readfirstlane(t.n_lvl ? lvl[t.n_lvl - 1] : 0);
-    u32x4 d = s_load_desc(gfr + (beg + wave < last_front ? beg + wave : last_front));
+    u32x4 d = lds_load_desc(gfr + 16u * (beg + wave < last_front ? beg + wave : last_front));
     for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
       const uint32_t next_beg = __builtin_amdgcn_readfirstlane(lvl[l >= 1 ? l - 1 : 0]);
       for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-        if (q != beg + wave) d = s_load_desc(gfr + q);
+        if (q != beg + wave) d = lds_load_desc(gfr + 16u * q);
         const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
         const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
         mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);
       }
-      d = s_load_desc(gfr + (next_beg + wave < last_front ? next_beg + wave : last_front));
+      d = lds_load_desc(gfr + 16u * (next_beg + wave < last_front ? next_beg + wave : last_front));
       __syncthreads();
+      {  // (slots 6, 7, 21, 22, 23: the end of the first five levels of the backward solve, top level first)
+        const uint32_t k = t.n_lvl - 1u - static_cast<uint32_t>(l);
+        if (k < 5u) SLPX_MF_CLOCK(k < 2u ? 6u + k : 19u + k);
+      }
       end = beg;
       beg = next_beg;
     }
   }
-  SLPX_LDLT_CLOCK(19);
+  SLPX_MF_CLOCK(19);
   // the descendants wait for x alone: hand it over before anything else goes out
   for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
   for (uint32_t i = tid; i < t.n_col; i += THREADS)
@@ -840,9 +893,18 @@ __device__ __forceinline__ void mf_step_body(
       B.pz[row.r] = pz_r;
     }
   }
-  SLPX_LDLT_CLOCK(20);
+  SLPX_MF_CLOCK(20);
   if (top) exit_and_count();
   if constexpr (CHAINED) mf_signal_done(Mf);
+#ifdef SLPX_MF_CLOCKS
+  if (threadIdx.x == 0) {
+    s_clk[16] = wall_clock64();  // (slot 16: the task is through)
+    if (task_index == L.clock_task)
+      for (int k = 0; k < 24; ++k) g_ldlt_clocks[k] = s_clk[k];
+    if (task_index < kMfClockTasks)
+      for (int k = 0; k < 24; ++k) g_mf_clocks[task_index * 24u + k] = s_clk[k];
+  }
+#endif
 }
 
 template <int THREADS, bool MFMA, bool CHAINED>
@@ -1064,11 +1126,11 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_solve_kernel(LdltDev L, MfDev
     U[i] = acc;
   }
   __syncthreads();
-  const LdltFront* gfr = Mf.fronts + m.front_off;
+  const uint32_t gfr = cv.o_fr;  // (LDS byte address of the task's front descriptors)
   for (uint32_t l = 0; l < t.n_lvl; ++l) {
     const uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[l]), end = __builtin_amdgcn_readfirstlane(lvl[l + 1]);
     for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-      const u32x4 d = s_load_desc(gfr + q);
+      const u32x4 d = lds_load_desc(gfr + 16u * q);
       const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, root = (d[2] >> 24) & 3u;
       mf_fwd_front(cv.o_tab + 2u * d[0], w, nr, nch, root, cv.o_invd + 8u * (d[1] >> 16), ext + (d[3] >> 16), contrib, lane);
     }
@@ -1080,7 +1142,7 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_solve_kernel(LdltDev L, MfDev
   for (int l = static_cast<int>(t.n_lvl) - 1; l >= 0; --l) {
     const uint32_t beg = __builtin_amdgcn_readfirstlane(lvl[l]), end = __builtin_amdgcn_readfirstlane(lvl[l + 1]);
     for (uint32_t q = beg + wave; q < end; q += THREADS / 64) {
-      const u32x4 d = s_load_desc(gfr + q);
+      const u32x4 d = lds_load_desc(gfr + 16u * q);
       const uint32_t w = d[2] & 0xffu, nr = (d[2] >> 8) & 0xffu, nch = (d[2] >> 16) & 0xffu, n_s = d[3] & 0xffffu;
       const uint32_t xr = cv.o_tab + 2u * (d[0] + nr * w * (1u + nch) + n_s * (3u + nch));
       mf_solve_front(xr, 8u * (d[1] & 0xffffu), w, nr, cv.o_invd + 8u * (d[1] >> 16), cv.o_x + 8u * (d[1] >> 16), lane);

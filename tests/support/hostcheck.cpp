@@ -1135,6 +1135,29 @@ extern "C" void hc_mf_plan(hc_handle* h, int64_t* out) {
   out[9] = L.mf_n_contrib;
 }
 
+// every front of the plan, 8 numbers each: task, round, level, w, nr, nch, n_s, flags (profiles/mf_front_stats.py)
+extern "C" int32_t hc_mf_fronts(hc_handle* h, int32_t* out, int32_t cap_fronts) {
+  const LdltPlan& L = h->l;
+  if (!L.mf) return 0;
+  int32_t n = 0;
+  for (size_t ti = 0; ti < L.tasks.size(); ++ti) {
+    const LdltTask& T = L.tasks[ti];
+    const LdltMfTask& M = L.mf_tasks[ti];
+    const uint32_t* lp = L.mf_lvl_ptr.data() + T.lvl_off;
+    for (uint32_t l = 0; l < T.n_lvl; ++l)
+      for (uint32_t q = lp[l]; q < lp[l + 1]; ++q) {
+        const LdltFront& f = L.mf_fronts[M.front_off + q];
+        if (n < cap_fronts) {
+          int32_t* o = out + 8 * static_cast<size_t>(n);
+          o[0] = static_cast<int32_t>(ti); o[1] = static_cast<int32_t>(T.round); o[2] = static_cast<int32_t>(l);
+          o[3] = f.w; o[4] = f.nr; o[5] = f.nch; o[6] = f.n_s; o[7] = f.flags;
+        }
+        ++n;
+      }
+  }
+  return n;
+}
+
 extern "C" void hc_supernode_plan(hc_handle* h, int64_t* out, int32_t cap) {
   const LdltPlan& L = h->l;
   for (int i = 0; i < cap; ++i) out[i] = 0;

@@ -61,6 +61,7 @@ def lib():
     sig("hc_supernode_plan", None, vp, vp, i32)
     sig("hc_mf_plan", None, vp, vp)
     sig("hc_info", None, vp, vp)
+    sig("hc_mf_fronts", i32, vp, vp, i32)
     sig("hc_pattern", i32, vp, ctypes.c_int, vp, vp)
     sig("hc_perm", None, vp, vp)
     sig("hc_set_scaling", None, vp, vp)
@@ -150,6 +151,13 @@ class HostCheck:
         d = dict(zip(keys, (int(v) for v in out)))
         d["built"] = bool(d["built"])
         return d
+
+    def mf_fronts(self):
+        """Every front of the multifrontal plan: rows of (task, round, level, w, nr, nch, n_s, flags)."""
+        n = lib().hc_mf_fronts(self._h, None, 0)
+        out = np.zeros((max(n, 1), 8), dtype=np.int32)
+        lib().hc_mf_fronts(self._h, out.ctypes.data, n)
+        return out[:n]
 
     def ldlt_tree(self):
         """(parent, column count) of the elimination tree in the permuted space."""

@@ -697,7 +697,10 @@ class DeviceNlp {
   DevBuf<unsigned int> m_chain;
   int m_chain_failures = 0;
   bool m_debug_break_chain = false;
-  unsigned int m_chain_seq = 0;       // number of the last chained step, in [1, 2^30): 0 is the kernels' "no wait", bit 31 their failure flag
+  unsigned int m_chain_seq = 0;       // number of the last chained step
+  // running totals of the workgroups of chained sweeps / chained step kernels launched: what the kernels wait for
+  // in chain[16] / chain[48] (kept below 2^29: bits 30, 31 of the words are the failure flag)
+  unsigned int m_chain_sweep_wgs = 0, m_chain_step_wgs = 0, m_last_tape_workgroups = 0;
   struct ChainArgs {
     unsigned int* chain = nullptr;
     unsigned int wait_step = 0, this_step = 0;

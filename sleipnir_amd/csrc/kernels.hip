@@ -13,6 +13,8 @@
 //   step_backsub   pˢ, pᶻ                 (interior_point.hpp:479-480)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <bit>
 #include <cstdio>
@@ -957,6 +959,7 @@ void DeviceNlp::launch_tape(const TapeDevice& t, bool reverse, hipStream_t small
     unsigned int wait_step = m_chain_args.wait_step, this_step = m_chain_args.this_step;
     const unsigned grid = t.tmpl_blocks[mode] + (small_rides ? t.n_small : 0u);
     unsigned int n_workgroups = m_chain_args.skip_flag ? 0u : grid * static_cast<unsigned>(m_batch);
+    m_last_tape_workgroups = grid * static_cast<unsigned>(m_batch);
     void* args[] = {&table,  &n_bodies, &inst,         &leaf_src, &consts,     &in,       &in_stride_arg,
                     &in_scale, &scales, &V,            &v_stride_arg, &vout_dst, &vout_scale, &jout_dst,
                     &jout_scale, &view_arg, &task_list, &n_template_blocks, &do_reverse,
@@ -1028,13 +1031,14 @@ void DeviceNlp::sweep_full_for_step() {
     (void)static_cast<hipStream_t>(m_stream);  // waits for that sweep, marks the stream touched
     m_last_step_chained = false;
   }
-  if (m_chain_seq >= (1u << 30) - 1u) {
+  if (m_chain_seq >= (1u << 30) - 1u || m_chain_sweep_wgs >= (1u << 29) || m_chain_step_wgs >= (1u << 29)) {
     // step numbers stay in [1, 2^30) (the kernels compare them as signed differences, use 0 for "no wait"
     // and bit 31 for failure): every ~14 hours of chained steps, one unchained step and a fresh count
     SLPX_HIP_CHECK(hipStreamSynchronize(m_tape_stream));
     SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
     SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
     m_chain_seq = 0;
+    m_chain_sweep_wgs = m_chain_step_wgs = 0;
     m_last_step_chained = false;
     m_stream.touched = true;
   }
@@ -1049,7 +1053,7 @@ void DeviceNlp::sweep_full_for_step() {
   }
   // the step kernel before this sweep: a chained one tells the sweep itself when its last workgroup is
   // through; any other (the first step of a run, a re-attempt of the policy loop) through an event, once
-  unsigned int wait_step = m_chain_seq;
+  unsigned int wait_step = m_chain_step_wgs;  // (every workgroup of the chained step kernels so far)
   if (!m_last_step_chained) {
     SLPX_HIP_CHECK(hipEventRecord(m_chain_ev, m_stream.raw()));
     SLPX_HIP_CHECK(hipStreamWaitEvent(m_tape_stream, m_chain_ev, 0));
@@ -1057,11 +1061,12 @@ void DeviceNlp::sweep_full_for_step() {
   }
   if (m_debug_break_chain && wait_step != 0u) {
     m_debug_break_chain = false;
-    wait_step += 7u;  // (slpx_debug_chain) a step kernel nobody launched
+    wait_step += 1u << 20;  // (slpx_debug_chain) step kernels nobody launched
   }
   ++m_chain_seq;
   m_chain_args = ChainArgs{m_chain.p, wait_step, m_chain_seq};
   launch_tape(m_full, true, m_tape_stream, m_tape_stream);
+  m_chain_sweep_wgs += m_last_tape_workgroups;
   m_tape_reduce = true;
   m_chain_args = ChainArgs{};
   m_stream.tape_pending = true;  // until the step kernel that waits for this sweep is launched
@@ -1074,6 +1079,7 @@ void DeviceNlp::recover_from_chain_failure() {
   SLPX_HIP_CHECK(hipStreamSynchronize(m_stream.raw()));
   if (m_chain.p != nullptr) SLPX_HIP_CHECK(hipMemset(m_chain.p, 0, 64 * sizeof(unsigned int)));
   m_chain_on = false;
+  m_chain_sweep_wgs = m_chain_step_wgs = 0;
   m_last_step_chained = false;
   m_stream.tape_pending = false;
   m_stream.touched = true;
@@ -1825,7 +1831,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
   // a chained step (sweep_full_for_step): the kernel variant that waits for its sweep itself and whose last
   // workgroup tells the next step's sweep; the main stream stays "untouched" by a step's own launches
   md.chain = chained ? m_chain.p : nullptr;
-  md.wait_step = chained ? m_chain_seq : 0u;
+  md.wait_step = chained ? m_chain_sweep_wgs : 0u;  // (every workgroup of the chained sweeps so far, this step's included)
   md.this_step = m_chain_seq;
   md.delta = reg[0];  // (by value: MfDev)
   md.gamma = reg[1];
@@ -1869,6 +1875,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
       if (chained) m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, true>, 512) : launch(&ldlt_mf_step_kernel<512, false, true>, 512);
       else m_mf_mfma ? launch(&ldlt_mf_step_kernel<512, true, false>, 512) : launch(&ldlt_mf_step_kernel<512, false, false>, 512);
     }
+    if (chained) m_chain_step_wgs += md.n_workgroups;  // (what the next chained sweep waits for in chain[48])
   }
   SLPX_HIP_CHECK(hipGetLastError());
 }
@@ -1966,6 +1973,17 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
     SLPX_HIP_CHECK(st);
   }
   std::copy(m_h_stats, m_h_stats + m_batch, out.begin());
+  // (an experiment's knob: the host sits on the verdict for so many nanoseconds — how much of its reaction a step
+  // hides: profiles/host_slack.sh)
+  static const long delay_ns = [] {
+    const char* env = std::getenv("SLPX_DEBUG_STATS_DELAY_NS");
+    return env ? std::atol(env) : 0L;
+  }();
+  if (delay_ns > 0) {
+    const auto until = std::chrono::steady_clock::now() + std::chrono::nanoseconds(delay_ns);
+    while (std::chrono::steady_clock::now() < until) {
+    }
+  }
 }
 
 // Full solve for a right-hand side that arrived AFTER the factorization (second-order

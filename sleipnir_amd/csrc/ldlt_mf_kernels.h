@@ -49,8 +49,9 @@ struct MfDev {
   unsigned int n_tasks = 0;
   unsigned int* exit_cnt = nullptr;  // workgroups through their exit phase (the last one publishes)
   // chained steps (DeviceNlp::sweep_full_for_step): the AD sweep of this step runs on another stream; the
-  // kernel stages its plan, then waits for chain[16] >= wait_step (0: the sweep came before in this
-  // stream), and its last workgroup leaves this_step in chain[48] for the next step's sweep
+  // kernel stages its plan, then waits until chain[16], the count of sweep workgroups through, reaches wait_step
+  // (0: the sweep came before in this stream), and its workgroups count themselves out in chain[48] for the next
+  // step's sweep
   unsigned int* chain = nullptr;
   unsigned int wait_step = 0, this_step = 0, n_workgroups = 0;
   // the attempt's regularization BY VALUE (the kernel's `reg` argument is then null): read from the pinned host
@@ -59,14 +60,15 @@ struct MfDev {
   double delta = 0.0, gamma = 0.0;
 };
 
-// the sweep this step reads is complete (one lane asks; the workgroup's other waves come through the barrier)
+// the sweep this step reads is complete (one lane asks; the workgroup's other waves come through the barrier):
+// every workgroup of the chained sweeps so far has counted itself out — Mf.wait_step of them, the host's running
+// total, below 2^29; bits 30, 31 of the word: one of them gave up waiting for the step kernel before it (V may have
+// been overwritten under that kernel)
 __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* stats) {
   if (Mf.wait_step != 0u) {
     if (threadIdx.x == 0) {
       unsigned int spins = 0, seen;
-      // (bit 31 of the word: a workgroup of that sweep gave up waiting for the step kernel before it — V may
-      // have been overwritten under that kernel; step numbers stay below 2^30)
-      while (static_cast<int>(((seen = __hip_atomic_load(Mf.chain + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x7fffffffu) - Mf.wait_step) < 0) {
+      while (((seen = __hip_atomic_load(Mf.chain + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x3fffffffu) < Mf.wait_step) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
           seen = 0x80000000u;
@@ -75,23 +77,18 @@ __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* st
       }
       // kLdltChainFailure (device.hpp) in n_bad — bit 30, above anything the counts can reach: the host
       // (NewtonSystem::compute_impl) redoes the step with the chain off
-      if (seen & 0x80000000u) atomicOr(&stats[0].n_bad, kLdltChainFailure);
+      if (seen >> 30) atomicOr(&stats[0].n_bad, kLdltChainFailure);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // V as the sweep's workgroups left it, not as this XCD's L2 remembers it
     }
     __syncthreads();
   }
 }
-// this workgroup has read everything it will of V, s, z: the next step's sweep may overwrite V
+// this workgroup has read everything it will of V, s, z: counted out, not waited for (the next step's sweep asks for
+// the total)
 __device__ __forceinline__ void mf_signal_done(const MfDev& Mf) {
   if (Mf.chain != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned int old = __hip_atomic_fetch_add(Mf.chain + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1u == Mf.n_workgroups) {
-        __hip_atomic_store(Mf.chain + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(Mf.chain + 48, Mf.this_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(Mf.chain + 48, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -40,8 +40,26 @@ for CFG in "N5000:--N 5000" "gfold:--workload gfold" "b64xN500:--workload batch5
   rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 done
 # 4. phase clocks inside the LDLT kernels and the latency microbenchmarks
-PYTHONPATH=$R python profiles/ldlt_clocks.py 1000 > $N/${TAG}_ldlt_clocks.txt 2>&1
-PYTHONPATH=$R python profiles/ldlt_clocks.py 5000 >> $N/${TAG}_ldlt_clocks.txt 2>&1
+# (the step kernel of the fronts keeps its clocks in LDS in a library built for it: profiles/ldlt_clocks.sh; a whole
+# launch as a timeline of all its tasks, one chained step as a timeline of both kernels, the host's slack)
+bash profiles/ldlt_clocks.sh $TAG 1000 5000 > /dev/null 2>&1
+cp $O/${TAG}_ldlt_clocks.txt $N/${TAG}_ldlt_clocks.txt
+{
+  D=$R/build/clocks_lib
+  export PYTHONPATH=$R
+  rm -f $R/tests/support/libslpx_models.so $R/tests/support/libslpx_hostcheck.so
+  for c in 0 1; do SLPX_LIB=$D/libslpx.so LD_LIBRARY_PATH=$D python profiles/mf_timeline.py 1000 $c 2>&1 | grep -v "^slpx"; done
+  SLPX_LIB=$D/libslpx.so LD_LIBRARY_PATH=$D python profiles/mf_timeline.py 5000 0 2>&1 | grep -v "^slpx"
+  rm -f $R/tests/support/libslpx_models.so $R/tests/support/libslpx_hostcheck.so
+} > $N/${TAG}_mf_timeline.txt 2>&1
+{
+  D=$R/build/clocks_lib
+  rm -f $R/tests/support/libslpx_models.so $R/tests/support/libslpx_hostcheck.so
+  for i in 1 2 3; do SLPX_LIB=$D/libslpx.so LD_LIBRARY_PATH=$D python profiles/chain_timeline.py 1000 300 2>&1 | grep -v "^slpx"; done
+  rm -f $R/tests/support/libslpx_models.so $R/tests/support/libslpx_hostcheck.so
+} > $N/${TAG}_chain_timeline.txt 2>&1
+bash profiles/host_slack.sh 2 > $N/${TAG}_host_slack.txt 2>&1
+PYTHONPATH=$R python profiles/mf_front_stats.py 1000 > $N/${TAG}_mf_front_stats.txt 2>&1
 PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
 for B in latency icache chain front; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
 PYTHONPATH=$R python profiles/setup_time.py 1000 5000 100 300 500 2>&1 | grep -v "tape family\|row group\|chunk\|tape: " > $N/${TAG}_setup_time.txt

@@ -61,4 +61,3 @@ for r in sorted(set(round_of)):
             continue
         v = v[ok]
         print(f"   {name:36s} {v.min():7.2f} {np.median(v):7.2f} {v.max():7.2f}   (task {int(idx[ok][np.argmax(v)])})")
-np.save(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", f"mf_timeline_{N}_{CHAINED}.npy"), us)

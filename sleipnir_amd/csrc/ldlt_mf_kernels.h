@@ -85,9 +85,12 @@ __device__ __forceinline__ void mf_wait_for_sweep(const MfDev& Mf, LdltStats* st
 }
 // this workgroup has read everything it will of V, s, z: counted out, not waited for (the next step's sweep asks for
 // the total)
+// (the bare barrier: every wave is past its last READ of V — the values were used — and that is all the sweep behind
+// this kernel needs; __syncthreads() would also wait for the acknowledgements of the results just stored, a
+// microsecond at the end of every chained step)
 __device__ __forceinline__ void mf_signal_done(const MfDev& Mf) {
   if (Mf.chain != nullptr) {
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(Mf.chain + 48, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -49,13 +49,14 @@ out = np.zeros(8 * NB, dtype=np.uint64)
 nt = L.slpx_debug_tmpl_clocks(sy._h, out.ctypes.data, NB)
 S = out.reshape(NB, 8).astype(np.int64)
 S = S[S[:, 0] > 0]
+body = S[S[:, 2] > 0][:, 2]  # (the generated bodies' blocks; an interpreted task has no such clock)
 t0 = S[:, 0].min()
 us = lambda v: (v - t0) / 100.0  # noqa: E731
 print(f"cart-pole N={N}: {STEPS} chained steps, {period:.2f} us a step by the host's clock (both kernels instrumented); the last step, us after its sweep's first block came in")
-print(f"  sweep ({len(S)} blocks): came in {us(S[:, 0].min()):6.2f} .. {us(S[:, 0].max()):6.2f}   wait over (body) {us(S[:, 2].min()):6.2f} .. {us(S[:, 2].max()):6.2f}"
+print(f"  sweep ({len(S)} blocks): came in {us(S[:, 0].min()):6.2f} .. {us(S[:, 0].max()):6.2f}   wait over, plan read {us(body.min()):6.2f} .. {us(body.max()):6.2f}"
       f"   out {us(S[:, 1].min()):6.2f} .. {us(S[:, 1].max()):6.2f}")
 print(f"  step kernel ({T} tasks): came in {us(C[:, 0].min()):6.2f} .. {us(C[:, 0].max()):6.2f}   image staged {us(C[:, 1].min()):6.2f} .. {us(C[:, 1].max()):6.2f}"
       f"   sweep seen {us(C[:, 14].min()):6.2f} .. {us(C[:, 14].max()):6.2f}   through {us(C[:, 16].min()):6.2f} .. {us(C[:, 16].max()):6.2f}")
-print(f"  the sweep waited {us(S[:, 2].min()) - us(S[:, 0].min()):.2f} us; the step kernel saw it {us(C[:, 14].min()) - us(S[:, 1].max()):.2f} us after its last block;"
+print(f"  the sweep's first block waited {us(body.min()) - us(S[:, 0].min()):.2f} us; the step kernel saw it {us(C[:, 14].min()) - us(S[:, 1].max()):.2f} us after its last block;"
       f" from there to the last task {us(C[:, 16].max()) - us(C[:, 14].min()):.2f} us; in steady state the step kernel before this one was through at about"
       f" {us(C[:, 16].max()) - period:.2f}")

@@ -42,6 +42,7 @@ done
 # 4. phase clocks inside the LDLT kernels and the latency microbenchmarks
 # (the step kernel of the fronts keeps its clocks in LDS in a library built for it: profiles/ldlt_clocks.sh; a whole
 # launch as a timeline of all its tasks, one chained step as a timeline of both kernels, the host's slack)
+set +x
 bash profiles/ldlt_clocks.sh $TAG 1000 5000 > /dev/null 2>&1
 cp $O/${TAG}_ldlt_clocks.txt $N/${TAG}_ldlt_clocks.txt
 {
@@ -60,6 +61,7 @@ cp $O/${TAG}_ldlt_clocks.txt $N/${TAG}_ldlt_clocks.txt
 } > $N/${TAG}_chain_timeline.txt 2>&1
 bash profiles/host_slack.sh 2 > $N/${TAG}_host_slack.txt 2>&1
 PYTHONPATH=$R python profiles/mf_front_stats.py 1000 > $N/${TAG}_mf_front_stats.txt 2>&1
+set -x
 PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
 for B in latency icache chain front; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
 PYTHONPATH=$R python profiles/setup_time.py 1000 5000 100 300 500 2>&1 | grep -v "tape family\|row group\|chunk\|tape: " > $N/${TAG}_setup_time.txt

@@ -1008,7 +1008,18 @@ void DeviceNlp::sweep_full_for_step() {
     SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_chain_ev, hipEventDisableTiming));
     SLPX_HIP_CHECK(hipEventCreateWithFlags(&m_stream.ev, hipEventDisableTiming));
     m_stream.tape = m_tape_stream;
-    m_chain.upload(std::vector<unsigned int>(128, 0u));
+    {
+      // (tests: the running totals start so far below their bound, so that a few thousand chained steps cross it —
+      // SLPX_DEBUG_CHAIN_TOTALS_HEADROOM workgroups of headroom — and the restart of the counts is exercised)
+      std::vector<unsigned int> words(128, 0u);
+      if (const char* env = std::getenv("SLPX_DEBUG_CHAIN_TOTALS_HEADROOM")) {
+        const unsigned int headroom = static_cast<unsigned int>(std::max(1L, std::atol(env)));
+        m_chain_sweep_wgs = m_chain_step_wgs = (1u << 29) - std::min(headroom, 1u << 28);
+        words[16] = m_chain_sweep_wgs;
+        words[48] = m_chain_step_wgs;
+      }
+      m_chain.upload(words);
+    }
     // (words 96, 97: the concurrency probe, see chain_probe_wait_kernel)
     hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(1), 0, m_tape_stream, m_chain.p + 96);
     hipLaunchKernelGGL(chain_probe_set_kernel, dim3(1), dim3(1), 0, m_stream.raw(), m_chain.p + 96);

@@ -50,6 +50,44 @@ def test_chained_steps_give_the_bits_of_the_unchained_ones(fresh, slpx, orc, mon
     assert not np.array_equal(plain[0][0], plain[2][0])
 
 
+def test_the_running_totals_of_the_hand_overs_start_over(fresh, slpx, orc, monkeypatch):
+    """The kernels of chained steps count themselves out in two words and their readers wait for the host's running
+    totals, which stay below 2^29 (bits 30, 31 of the words carry the give-up flag): at the bound both streams are
+    drained, the words cleared and the counts start over with one unchained step.  With the totals preset a few
+    thousand steps below the bound (SLPX_DEBUG_CHAIN_TOTALS_HEADROOM) the steps before, across and after it are the
+    unchained step to the bit, and no hand-over is lost."""
+    pp, op = cases.build_pair("cart_pole", 100, slpx, orc)
+    n, me, mi = pp.dims
+    scales = op.scaling()
+    x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])
+
+    def run(headroom):
+        if headroom:
+            monkeypatch.setenv("SLPX_DEBUG_CHAIN_TOTALS_HEADROOM", str(headroom))
+        else:
+            monkeypatch.delenv("SLPX_DEBUG_CHAIN_TOTALS_HEADROOM", raising=False)
+        system = slpx.System(pp, batch=1, device=0)
+        try:
+            system.set_scaling(scales)
+            system.set_state(x, s, y, z, np.array([mu]))
+            tasks = system.info["ldlt_tasks"]
+            seen = []
+            for _ in range(6):
+                assert np.all(system.newton_steps(500) == 0)
+                seen.append([system.get(w)[0].copy() for w in ("p", "p_s", "p_z")])
+            assert slpx.lib().slpx_debug_chain(system._h, 0) == 0  # (no chained step lost its hand-over)
+            return seen, tasks
+        finally:
+            system.close()
+
+    plain, tasks = run(0)
+    # 3000 steps of `tasks` + a few dozen sweep workgroups each: the bound is crossed about half way
+    crossed, _ = run(1500 * (tasks + 8))
+    for a, b in zip(plain, crossed):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+
+
 def test_no_chaining_where_kernels_run_one_at_a_time(tmp_path):
     """A profiler collecting hardware counters (rocprofv3 --pmc) or AMD_SERIALIZE_KERNEL runs one kernel at a
     time: a step kernel dispatched beside its sweep would wait for a sweep that cannot start.  The one-time

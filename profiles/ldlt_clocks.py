@@ -35,6 +35,8 @@ for r in range(info["ldlt_rounds"]):
         sy.newton_step(True)
     L.slpx_debug_ldlt_clocks(sy._h, ((r + 1) % info["ldlt_rounds"]) | (WITHIN << 8), out.ctypes.data)
     f = out[0:6].astype(np.int64)
+    if info.get("ldlt_multifrontal") and int(f[0]) == 0:
+        sys.exit("this library carries no clocks in the step kernel of the fronts: bash profiles/ldlt_clocks.sh builds one that does")
     if r > 0 and int(f[0]) == last_entry:
         continue  # (the round has no task number WITHIN: nothing was recorded)
     last_entry = int(f[0])

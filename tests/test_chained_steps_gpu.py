@@ -121,14 +121,19 @@ def test_no_chaining_where_kernels_run_one_at_a_time(tmp_path):
         assert "steps are not chained" in res.stderr, res.stderr[-2000:]
 
 
-def test_a_lost_hand_over_is_reported_and_the_step_redone_unchained(fresh, slpx, orc, monkeypatch):
-    """a chained sweep whose wait for the step kernel before it runs into its spin
+@pytest.mark.parametrize("N", [100, 256, 1000])
+def test_a_lost_hand_over_is_reported_and_the_step_redone_unchained(fresh, slpx, orc, monkeypatch, N):
+    """the give-up flag is OR-ed into the hand-over word (sticky), not added: with the flag summed
+    in, a sweep grid whose workgroups all give up together — they wait on the same word — could carry it out of
+    bits 30/31 again (any multiple of four workgroups clears bit 30 ... bit 31 after the next); horizons with 4, 8 and
+    16 template workgroups are covered here.
+    ADVICE r03 (medium): a chained sweep whose wait for the step kernel before it runs into its spin
     bound used to go ahead silently.  Now its last workgroup publishes the failure with the step number,
     the step kernel puts kLdltChainFailure into its counters, and the policy loop redoes the step with the
     chain off (slpx_debug_chain(1) makes the next chained sweep wait for a kernel that does not exist).
     The redone step has the bits of the unchained one, the failure is counted, later steps succeed."""
     monkeypatch.delenv("SLPX_CHAIN_TAPE", raising=False)
-    pp, op = cases.build_pair("cart_pole", 100, slpx, orc)
+    pp, op = cases.build_pair("cart_pole", N, slpx, orc)
     n, me, mi = pp.dims
     scales = op.scaling()
     x, s, y, z, mu = cases.newton_state("interior", op.get_x(), n, me, mi, scales[0])

@@ -234,24 +234,7 @@ int slpx_problem_prebuild_kernels(slpx_problem* p, const char* dir) {
     const int c = slpx::prebuild_tape_templates(st.full, copt, where, log);
     if (a < 0 || b < 0 || c < 0) throw std::runtime_error("slpx_problem_prebuild_kernels: " + log);
     bodies = a + b;
-    // the feasibility-restoration system a solve compiles on first use (csrc/ipm.cpp)
-    if (!ce.empty() || !ci.empty()) {
-      const slpx::RestorationModel rm = slpx::build_restoration_model(slpx::graph(), xs, ce, ci);
-      const slpx::NlpStructure rs =
-          slpx::build_nlp_structure(slpx::graph(), rm.vars, rm.cost, rm.c_e, rm.c_i, slpx::TapeCompileOptions{});
-      slpx::TapeJitOptions ropt;
-      ropt.n_unscaled_inputs = static_cast<uint32_t>(rs.n);
-      const int ra = slpx::prebuild_tape_templates(rs.full, ropt, where, log);
-      const int rb = slpx::prebuild_tape_templates(rs.values, ropt, where, log);
-      // (a restoration system small enough for chained steps — up to a few hundred stages — loads the chained
-      // variant of its full sweep, as the outer system does: without it the first restoration of a fresh machine
-      // waited 0.6 s for hipRTC, profiles/r04_horizon_sweep.txt N=50)
-      slpx::TapeJitOptions rcopt = ropt;
-      rcopt.chain_mode = 1;
-      const int rc = slpx::prebuild_tape_templates(rs.full, rcopt, where, log);
-      if (ra < 0 || rb < 0 || rc < 0) throw std::runtime_error("slpx_problem_prebuild_kernels (restoration): " + log);
-      bodies += ra + rb;
-    }
+    // (feasibility restoration has no kernels of its own to generate: it runs on this system, csrc/restoration.hpp)
   });
   return rc == 0 ? bodies : rc;
 }

@@ -525,6 +525,19 @@ class DeviceNlp {
   void materialize_kkt();
   void materialize_batch_major();
   double* d_p() { return m_p.p; }
+  // A caller that writes the system itself (restoration.hpp: the reduced system of the restoration problem on this
+  // system's pattern): the arrays as they are, and "what is there IS the current system" / "the state changed under it"
+  const KktDev& kdev() const { return m_kdev; }
+  double* lhs_raw() { return m_lhs.p; }
+  double* rhs_raw() { return m_rhs.p; }
+  void system_written_by_caller(bool lhs, bool rhs) {
+    m_kkt_pending = 0;
+    if (lhs) m_lhs_stale = m_lhs_in_il = false;
+    if (rhs) m_rhs_stale = m_rhs_in_il = false;
+  }
+  void state_changed_by_caller() { m_lhs_stale = m_rhs_stale = true; }
+  double* d_trial_in() { return m_trial_in.p; }
+  hipStream_t raw_stream() const { return m_stream.raw(); }
   double* d_ps() { return m_ps.p; }
   double* d_pz() { return m_pz.p; }
   double* d_D() { return m_D.p; }

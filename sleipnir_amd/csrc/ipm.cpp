@@ -1,5 +1,7 @@
 #include "ipm.hpp"
 
+#include "restoration.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -215,11 +217,10 @@ std::vector<double> compute_problem_scaling(const NlpStructure& s, const std::ve
 
 namespace {
 
-ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
-                                   const std::vector<IterationCallback>& callbacks,
-                                   const Options& options, Vec& x, Vec& s, Vec& y, Vec& z, double mu,
-                                   int& iterations, SolveReport& rep, clk::time_point solve_start,
-                                   const Vec& c_e, const Vec& c_i);
+ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales, const std::vector<IterationCallback>& user_callbacks,
+                                   const std::function<bool(const FilterEntry&, double)>& outer_accepts, const Options& options,
+                                   Vec& x, Vec& s, Vec& y, Vec& z, double mu, int& iterations, SolveReport& rep,
+                                   clk::time_point solve_start, const Vec& c_e, const Vec& c_i, const Vec& g, double initial_violation);
 
 // interior_point.hpp:129-878: the iteration proper, on caller-owned iterates (the
 // restoration phase re-enters it with in_feasibility_restoration = true).
@@ -507,26 +508,13 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
       if (in_feasibility_restoration) return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
 
       const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
-      std::vector<IterationCallback> fr_callbacks = callbacks;
-      // Leave restoration once the outer filter accepts the restoration iterate and the
-      // violation dropped by 10 % (:729-752).  f, c_e, c_i of the ORIGINAL problem at the
-      // restoration iterate come from a forward sweep of this system's value tape.
-      fr_callbacks.emplace_back([&](const IterationInfo& info) {
-        Vec tx(info.x.begin(), info.x.begin() + n);
-        Vec ts(info.s.begin(), info.s.begin() + m_i);
-        eval_values(tx);
-        Vec tce(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e);
-        Vec tci(Vtrial.begin() + st.off_ci, Vtrial.begin() + st.off_ci + m_i);
-        const FilterEntry trial_entry{Vtrial[st.off_f], ts, tce.data(), m_e, tci.data(), mu};
-        double D_phi_restoration = 0.0, sinv_dot = 0.0;
-        for (int i = 0; i < n; ++i) D_phi_restoration += g[i] * (tx[i] - x[i]);
-        for (int j = 0; j < m_i; ++j) sinv_dot += (1.0 / s[j]) * (ts[j] - s[j]);
-        D_phi_restoration -= mu * sinv_dot;
-        return trial_entry.constraint_violation < 0.9 * initial_entry.constraint_violation &&
-               filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
-      });
-      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s, y,
-                                                           z, mu, iterations, rep, solve_start, c_e, c_i);
+      // Leave restoration once the outer filter accepts the restoration iterate and the violation dropped by 10 %
+      // (:729-752); the restoration iteration reduces the outer problem's quantities at its iterate on the device
+      auto outer_accepts = [&](const FilterEntry& trial_entry, double D_phi_restoration) {
+        return filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      };
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, callbacks, outer_accepts, options, x, s, y, z, mu, iterations,
+                                                           rep, solve_start, c_e, c_i, g, initial_entry.constraint_violation);
       if (fr_status != ExitStatus::SUCCESS) return finish(fr_status);
       eval_values(x);
       read_trial();
@@ -888,30 +876,14 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       const Vec g = cv.g_dense();
       const Vec c_e(cv.c_e(), cv.c_e() + m_e), c_i(cv.c_i(), cv.c_i() + m_i);
       const double f = cv.f();
-      Vec Vtrial(st.nV);
       const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
-      std::vector<IterationCallback> fr_callbacks = callbacks;
       // Leave restoration once the outer filter accepts the restoration iterate and the
       // violation dropped by 10 % (:729-752).
-      fr_callbacks.emplace_back([&](const IterationInfo& info) {
-        Vec tx(info.x.begin(), info.x.begin() + n);
-        Vec ts(info.s.begin(), info.s.begin() + m_i);
-        dev.upload_x(tx.data());
-        dev.sweep_values();
-        dev.download(dev.d_V(), Vtrial.data(), static_cast<size_t>(st.off_g));
-        ++rep.value_sweeps;
-        Vec tce(Vtrial.begin() + st.off_ce, Vtrial.begin() + st.off_ce + m_e);
-        Vec tci(Vtrial.begin() + st.off_ci, Vtrial.begin() + st.off_ci + m_i);
-        const FilterEntry trial_entry{Vtrial[st.off_f], ts, tce.data(), m_e, tci.data(), mu};
-        double D_phi_restoration = 0.0, sinv_dot = 0.0;
-        for (int i = 0; i < n; ++i) D_phi_restoration += g[i] * (tx[i] - x[i]);
-        for (int j = 0; j < m_i; ++j) sinv_dot += (1.0 / s[j]) * (ts[j] - s[j]);
-        D_phi_restoration -= mu * sinv_dot;
-        return trial_entry.constraint_violation < 0.9 * initial_entry.constraint_violation &&
-               filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
-      });
-      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s, y, z, mu,
-                                                           iterations, rep, solve_start, c_e, c_i);
+      auto outer_accepts = [&](const FilterEntry& trial_entry, double D_phi_restoration) {
+        return filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      };
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, callbacks, outer_accepts, options, x, s, y, z, mu, iterations,
+                                                           rep, solve_start, c_e, c_i, g, initial_entry.constraint_violation);
       if (fr_status != ExitStatus::SUCCESS) return finish(fr_status);
       push_state();
     } else {
@@ -983,125 +955,8 @@ void compute_p_n(const Vec& c, double rho, double mu, Vec& p, Vec& n) {
   }
 }
 
-// The restoration model as an expression-graph problem over the SAME constraint
-// expressions (feasibility_restoration.hpp:347-628 composes it out of the outer matrix
-// callbacks; compiling it gives the identical f, g, H, c, A):
-//
-//   min  rho sum(p_e + n_e + p_i + n_i) + 1/2 sum_k w_k (x_k - xr_k)^2      w = zeta D_R
-//   s.t. d_ce . c_e(x) - p_e + n_e  = 0
-//        d_ci . c_i(x) - p_i + n_i >= 0,   p_e, n_e, p_i, n_i >= 0
-//
-// x_R, w and the outer problem's row scalings d_ce, d_ci are tape PARAMETERS (free
-// Variables), so one compiled system serves every restoration call of every solve.
-}  // namespace
-
-RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs, const std::vector<NodeId>& ces,
-                                         const std::vector<NodeId>& cis) {
-  RestorationModel R;
-  const size_t n = xs.size(), m_e = ces.size(), m_i = cis.size();
-  constexpr double rho = 1e3;
-
-  R.vars = xs;
-  std::vector<NodeId> p_e(m_e), n_e(m_e), p_i(m_i), n_i(m_i);
-  for (auto* block : {&p_e, &n_e, &p_i, &n_i})
-    for (NodeId& v : *block) {
-      v = g.variable(0.0);
-      R.vars.push_back(v);
-    }
-  R.x_ref.resize(n);
-  R.weight.resize(n);
-  for (size_t k = 0; k < n; ++k) {
-    R.x_ref[k] = g.variable(0.0);
-    R.weight[k] = g.variable(0.0);
-  }
-  R.d_ce.resize(m_e);
-  R.d_ci.resize(m_i);
-  for (NodeId& v : R.d_ce) v = g.variable(1.0);
-  for (NodeId& v : R.d_ci) v = g.variable(1.0);
-
-  // The cost as ONE flat sum of single-variable terms, constants folded into the terms:
-  //   sum_k (w_k / 2) (x_k - xr_k)^2 + sum_v rho v.
-  // In this shape the tape compiler's separable-sum splitting applies (nlp.cpp): groups of
-  // consecutive terms become small identical tasks (a template family in the generated
-  // kernel).  Written as rho * (sum v) + 1/2 * (sum w d^2) the two sums are single
-  // components with tens of thousands of nodes — one 1024-thread workgroup walking them in
-  // HBM scratch, measured 0.68 ms per sweep, 57 % of the GPU time of a cart-pole N=750 solve.
-  const NodeId half = g.constant(0.5), rho_c = g.constant(rho);
-  R.cost = kNull;
-  for (size_t k = 0; k < n; ++k) {
-    const NodeId d = g.sub(xs[k], R.x_ref[k]);
-    R.cost = g.add(R.cost, g.mul(g.mul(half, R.weight[k]), g.mul(d, d)));
-  }
-  for (size_t k = n; k < R.vars.size(); ++k) R.cost = g.add(R.cost, g.mul(rho_c, R.vars[k]));
-
-  R.c_e.resize(m_e);
-  for (size_t j = 0; j < m_e; ++j)
-    R.c_e[j] = g.add(g.sub(g.mul(R.d_ce[j], ces[j]), p_e[j]), n_e[j]);
-  for (size_t j = 0; j < m_i; ++j)
-    R.c_i.push_back(g.add(g.sub(g.mul(R.d_ci[j], cis[j]), p_i[j]), n_i[j]));
-  for (size_t k = n; k < R.vars.size(); ++k) R.c_i.push_back(R.vars[k]);
-  return R;
-}
-
-namespace {
-
-// `host_only`: everything that reads the expression graph, nothing of the device (NewtonSystem::finish_device)
-void build_restoration_system(NewtonSystem& outer, bool host_only) {
-  auto& R = outer.restoration();
-  RestorationModel M = build_restoration_model(outer.graph(), outer.x_nodes(), outer.c_e_nodes(), outer.c_i_nodes());
-  R.vars = std::move(M.vars);
-  R.x_ref = std::move(M.x_ref);
-  R.weight = std::move(M.weight);
-  R.d_ce = std::move(M.d_ce);
-  R.d_ci = std::move(M.d_ci);
-  NewtonOptions opt = outer.options();
-  opt.batch = 1;
-  R.sys = std::make_unique<NewtonSystem>(outer.graph(), R.vars, M.cost, M.c_e, M.c_i, opt, nullptr, host_only);
-}
-
-NewtonSystem& restoration_system(NewtonSystem& outer) {
-  auto& R = outer.restoration();
-  if (R.prefetch.valid()) {
-    try {
-      R.prefetch.get();
-    } catch (...) {  // (whatever went wrong on the other thread happens again below, where it can be reported)
-      R.sys.reset();
-    }
-  }
-  if (!R.sys) build_restoration_system(outer, /*host_only=*/false);
-  R.sys->finish_device();  // (a system compiled ahead has no device part yet)
-  return *R.sys;
-}
-
-// The reference enters feasibility restoration without any setup (feasibility_restoration.hpp:347-628 composes the
-// restoration problem out of the outer problem's callbacks); here it is a second compiled system — tape, KKT plan,
-// symbolic LDLT, upload: as long as a hundred interior-point iterations at N=300.  A solve of a model big enough
-// for that to matter therefore starts compiling it at once, on a thread of its own, while the outer iterations run on
-// the device: by the time the filter gives up on a step the system is (nearly) there.  Only the HOST part — what
-// reads the expression graph: AD structure, tapes, KKT plan, symbolic LDLT, two thirds of the whole — so that a solve
-// that never enters restoration waits for milliseconds at its end, never for a hipRTC compilation of a kernel
-// nobody runs; device memory, uploads and the kernel come when restoration is entered.  Not with iteration callbacks
-// (a callback may evaluate expressions: the graph is appended to on the other thread), not for small models.
-// SLPX_RESTORATION_PREFETCH=0: off; =1: whatever the size.
-void restoration_prefetch(NewtonSystem& outer, bool has_callbacks) {
-  auto& R = outer.restoration();
-  if (R.sys || R.prefetch.valid() || has_callbacks) return;
-  const NlpStructure& st = outer.structure();
-  bool on = st.m_e + st.m_i >= 512;
-  if (const char* env = std::getenv("SLPX_RESTORATION_PREFETCH")) on = env[0] == '1' || (on && env[0] != '0');
-  if (!on || st.m_e + st.m_i == 0) return;
-  R.prefetch = std::async(std::launch::async, [&outer] { build_restoration_system(outer, /*host_only=*/true); });
-}
-// (before the solve hands the model back to its owner, who may go on building expressions)
-void restoration_prefetch_join(NewtonSystem& outer) {
-  auto& R = outer.restoration();
-  if (!R.prefetch.valid()) return;
-  try {
-    R.prefetch.get();
-  } catch (...) {
-    R.sys.reset();
-  }
-}
+// (the restoration problem itself is never built as a model: restoration.hpp — its extra variables are eliminated from
+// the Newton-KKT system in closed form and the rest runs on the outer problem's own compiled system)
 
 // util/lagrange_multiplier_estimate.hpp:56-133: least-squares (y, z) of
 //   [A_e 0; A_i -S] [A_e 0; A_i -S]^T [y; z] = [A_e 0; A_i -S] [g; -mu 1].
@@ -1170,78 +1025,527 @@ bool lagrange_multiplier_estimate(NewtonSystem& sys, const Vec& V, const Vec& s,
   return true;
 }
 
-// feasibility_restoration.hpp:347-628 (interior-point variant)
-ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales,
-                                   const std::vector<IterationCallback>& callbacks,
-                                   const Options& options, Vec& x, Vec& s, Vec& y, Vec& z, double mu,
-                                   int& iterations, SolveReport& rep, clk::time_point solve_start,
-                                   const Vec& c_e, const Vec& c_i) {
+// The restoration problem as the user's iteration callbacks see it (slpx.h: slpx_iteration_info inside restoration):
+// n + 2 m_e + 2 m_i variables [x | p_e | n_e | p_i | n_i], m_i + 2 m_e + 2 m_i inequality rows, the matrices of
+// feasibility_restoration.hpp:434-593 as value arrays over static patterns.  Only built when a solve with user
+// callbacks enters restoration; the solver itself never forms these.
+struct RestorationView {
+  NlpStructure st;
+  std::vector<double> V;
+};
+void build_restoration_view(const NlpStructure& o, RestorationView& v) {
+  NlpStructure& t = v.st;
+  const int n = o.n, m_e = o.m_e, m_i = o.m_i, M = 2 * m_e + 2 * m_i;
+  t.n = n + M;
+  t.m_e = m_e;
+  t.m_i = m_i + M;
+  auto cols = [&](CscPattern& p, int rows) {
+    p.rows = rows;
+    p.cols = t.n;
+    p.colptr.assign(1, 0);
+    p.rowidx.clear();
+  };
+  auto close = [](CscPattern& p) { p.colptr.push_back(static_cast<int32_t>(p.rowidx.size())); };
+  cols(t.g_pat, 1);
+  for (int c = 0; c < t.n; ++c) {
+    t.g_pat.rowidx.push_back(0);
+    close(t.g_pat);
+  }
+  cols(t.Ae, m_e);
+  cols(t.Ai, t.m_i);
+  cols(t.Hf, t.n);
+  cols(t.Hc, t.n);
+  for (int c = 0; c < n; ++c) {
+    for (int q = o.Ae.colptr[c]; q < o.Ae.colptr[c + 1]; ++q) t.Ae.rowidx.push_back(o.Ae.rowidx[q]);
+    for (int q = o.Ai.colptr[c]; q < o.Ai.colptr[c + 1]; ++q) t.Ai.rowidx.push_back(o.Ai.rowidx[q]);
+    t.Hf.rowidx.push_back(c);
+    for (int q = o.Hc.colptr[c]; q < o.Hc.colptr[c + 1]; ++q) t.Hc.rowidx.push_back(o.Hc.rowidx[q]);
+    close(t.Ae), close(t.Ai), close(t.Hf), close(t.Hc);
+  }
+  for (int e = 0; e < M; ++e) {  // columns of p_e, n_e, p_i, n_i (:499-573)
+    if (e < 2 * m_e) t.Ae.rowidx.push_back(e % m_e);
+    if (e >= 2 * m_e) t.Ai.rowidx.push_back((e - 2 * m_e) % m_i);
+    t.Ai.rowidx.push_back(m_i + e);
+    close(t.Ae), close(t.Ai), close(t.Hf), close(t.Hc);
+  }
+  t.off_f = 0;
+  t.off_ce = 1;
+  t.off_ci = t.off_ce + t.m_e;
+  t.off_g = t.off_ci + t.m_i;
+  t.off_Ae = t.off_g + t.g_pat.nnz();
+  t.off_Ai = t.off_Ae + t.Ae.nnz();
+  t.off_Hf = t.off_Ai + t.Ai.nnz();
+  t.off_Hc = t.off_Hf + t.Hf.nnz();
+  t.nV = t.off_Hc + t.Hc.nnz();
+}
+void fill_restoration_view(const NlpStructure& o, RestorationView& v, const Vec& Vo, const Vec& x_ext, const Vec& x_r, const Vec& w,
+                           double rho) {
+  const NlpStructure& t = v.st;
+  const int n = o.n, m_e = o.m_e, m_i = o.m_i, M = 2 * m_e + 2 * m_i;
+  Vec& V = v.V;
+  V.assign(t.nV, 0.0);
+  const double* pn = x_ext.data() + n;
+  double f = 0.0;
+  for (int e = 0; e < M; ++e) f += rho * pn[e];
+  for (int k = 0; k < n; ++k) f += 0.5 * w[k] * (x_ext[k] - x_r[k]) * (x_ext[k] - x_r[k]);
+  V[t.off_f] = f;
+  for (int j = 0; j < m_e; ++j) V[t.off_ce + j] = Vo[o.off_ce + j] - pn[j] + pn[m_e + j];
+  for (int r = 0; r < m_i; ++r) V[t.off_ci + r] = Vo[o.off_ci + r] - pn[2 * m_e + r] + pn[2 * m_e + m_i + r];
+  for (int e = 0; e < M; ++e) V[t.off_ci + m_i + e] = pn[e];
+  for (int k = 0; k < n; ++k) V[t.off_g + k] = w[k] * (x_ext[k] - x_r[k]);
+  for (int e = 0; e < M; ++e) V[t.off_g + n + e] = rho;
+  int qe = t.off_Ae, qi = t.off_Ai, qh = t.off_Hc;
+  for (int c = 0; c < n; ++c) {
+    for (int q = o.Ae.colptr[c]; q < o.Ae.colptr[c + 1]; ++q) V[qe++] = Vo[o.off_Ae + q];
+    for (int q = o.Ai.colptr[c]; q < o.Ai.colptr[c + 1]; ++q) V[qi++] = Vo[o.off_Ai + q];
+    V[t.off_Hf + c] = w[c];
+    for (int q = o.Hc.colptr[c]; q < o.Hc.colptr[c + 1]; ++q) V[qh++] = Vo[o.off_Hc + q];
+  }
+  for (int e = 0; e < M; ++e) {
+    const bool minus = e < m_e || (e >= 2 * m_e && e < 2 * m_e + m_i);  // p_e, p_i enter their constraint with -1
+    if (e < 2 * m_e) V[qe++] = minus ? -1.0 : 1.0;
+    else V[qi++] = minus ? -1.0 : 1.0;
+    V[qi++] = 1.0;
+  }
+}
+
+// kkt_error.hpp:92-146 (1-norm variant) of the restoration problem, on the host: the rare fallback of the line search
+// (interior_point.hpp:691-716).  Vo = the OUTER problem's V at x; X = [x | p_e | n_e | p_i | n_i], S, Z = the five
+// inequality blocks.
+double restoration_kkt_error_one_norm(const NlpStructure& o, const Vec& Vo, const Vec& X, const Vec& S, const Vec& y, const Vec& Z,
+                                      const Vec& x_r, const Vec& w, double rho, double mu) {
+  const int n = o.n, m_e = o.m_e, m_i = o.m_i, M = 2 * m_e + 2 * m_i;
+  const double* pn = X.data() + n;
+  Vec dual(n + M, 0.0);
+  for (int k = 0; k < n; ++k) dual[k] = w[k] * (X[k] - x_r[k]);
+  for (int c = 0; c < n; ++c) {
+    for (int q = o.Ae.colptr[c]; q < o.Ae.colptr[c + 1]; ++q) dual[c] -= Vo[o.off_Ae + q] * y[o.Ae.rowidx[q]];
+    for (int q = o.Ai.colptr[c]; q < o.Ai.colptr[c + 1]; ++q) dual[c] -= Vo[o.off_Ai + q] * Z[o.Ai.rowidx[q]];
+  }
+  for (int j = 0; j < m_e; ++j) {
+    dual[n + j] = rho + y[j] - Z[m_i + j];
+    dual[n + m_e + j] = rho - y[j] - Z[m_i + m_e + j];
+  }
+  for (int r = 0; r < m_i; ++r) {
+    dual[n + 2 * m_e + r] = rho + Z[r] - Z[m_i + 2 * m_e + r];
+    dual[n + 2 * m_e + m_i + r] = rho - Z[r] - Z[m_i + 2 * m_e + m_i + r];
+  }
+  double err = norm_1(dual.data(), n + M);
+  for (int j = 0; j < m_e; ++j) err += std::abs(Vo[o.off_ce + j] - pn[j] + pn[m_e + j]);
+  for (int r = 0; r < m_i; ++r) {
+    const double c = Vo[o.off_ci + r] - pn[2 * m_e + r] + pn[2 * m_e + m_i + r];
+    err += std::abs(S[r] * Z[r] - mu) + std::abs(c - S[r]);
+  }
+  for (int e = 0; e < M; ++e) err += std::abs(S[m_i + e] * Z[m_i + e] - mu) + std::abs(pn[e] - S[m_i + e]);
+  return err;
+}
+
+// interior_point.hpp:129-878 on the restoration problem (in_feasibility_restoration = true), the counterpart of
+// ipm_core_resident for it: the iterate stays on the device — x, s_0, y, z_0 in the outer system's buffers, p, n and
+// their slacks and duals in the FrDevice —, every Newton step is a factorization of the reduced system on the outer
+// system's plan (NewtonSystem::compute_hooked), and the host decides on a few dozen scalars.  `accept_exit` is the
+// callback the reference appends (interior_point.hpp:729-752): the outer filter's verdict on the restoration iterate,
+// from the outer problem's quantities the error launch reduces along.
+ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<IterationCallback>& user_callbacks,
+                            const std::function<bool(const FrErrOut&)>& accept_exit, const Options& options, const Vec& x_r, const Vec& w,
+                            Vec& X, Vec& S, Vec& y, Vec& Z, double& mu, int& iterations, SolveReport& rep, clk::time_point solve_start) {
+  const NlpStructure& st = sys.structure();
+  DeviceNlp& dev = sys.device();
+  const int n = st.n, m_e = st.m_e, m_i = st.m_i, M = 2 * m_e + 2 * m_i, dim = n + m_e, mi_ext = m_i + M;
+  constexpr double rho = 1e3;
+  const FrHost& H = fr.host();
+
+  sys.reset_regularization();
+  sys.set_gamma_min(0.0);  // :350-352
+
+  bool host_current = true;
+  auto pull_state = [&] {
+    if (host_current) return;
+    dev.download(dev.d_x(), X.data(), n);
+    if (m_i) {
+      dev.download(dev.d_s(), S.data(), m_i);
+      dev.download(dev.d_z(), Z.data(), m_i);
+    }
+    if (m_e) dev.download(dev.d_y(), y.data(), m_e);
+    fr.download_state(X.data() + n, S.data() + m_i, Z.data() + m_i);
+    host_current = true;
+  };
+  auto finish = [&](ExitStatus st_) {
+    pull_state();
+    dev.state_changed_by_caller();
+    return st_;
+  };
+
+  auto t_setup = clk::now();
+  dev.sweep_full();  // :245-251: the outer tape at (x, y, z_0) is the restoration problem's c_e, c_i, A_e, A_i, H_c
+  fr.errors(/*check_all_V=*/true, mu);
+  fr.wait_published();
+  FrErrOut cur = H.err;
+  if (cur.e.finite == 0.0) return finish(ExitStatus::NONFINITE_INITIAL_GUESS);  // :283-286
+
+  const double mu_min = options.tolerance / 10.0;  // :294 (the restoration cost is not scaled)
+  constexpr double tau_min = 0.99;
+  double tau = tau_min;
+  Filter filter{cur.e.viol};  // :303
+  auto update_barrier = [&] {  // :308-333
+    mu = std::max(mu_min, std::min(0.2 * mu, std::pow(mu, 1.5)));
+    tau = std::max(tau_min, 1.0 - mu);
+    filter.reset();
+  };
+  constexpr double alpha_reduction_factor = 0.5, alpha_min = 1e-7;
+  constexpr double s_max = 100.0;
+  int full_step_rejected_counter = 0;
+  // util/kkt_error.hpp:92-146 from the reduced scalars (the scaling {1, d_ce, [d_ci, 1...]} is never the identity here)
+  auto E_mu_of = [&](const IpmErrOut& e, double m) {
+    const double s_d = std::max(s_max, (e.y1 + e.z1) / double(m_e + mi_ext)) / s_max;
+    const double s_c = std::max(s_max, e.z1 / double(mi_ext)) / s_max;
+    const double comp = std::max(std::abs(e.sz_max - m), std::abs(e.sz_min - m));
+    return std::max({e.dual_inf / s_d, comp / s_c, e.ce_inf, e.cis_inf});
+  };
+  auto E0_of = [&](const IpmErrOut& e) {
+    const double s_d = std::max(s_max, (e.y1_u + e.z1_u) / double(m_e + mi_ext)) / s_max;
+    const double s_c = std::max(s_max, e.z1_u / double(mi_ext)) / s_max;
+    return std::max({e.dual_inf_u / s_d, e.sz_max_u / s_c, e.ce_inf_u, e.cis_inf_u});
+  };
+  double E_0 = E0_of(cur.e);  // :361-362
+  rep.t_setup += since(t_setup);
+
+  RestorationView view;
+  Vec Vo;
+
+  while (E_0 > options.tolerance) {
+    // :387-408
+    if (m_e > 0 && std::sqrt(cur.e.aetce_sq) < 1e-6 && std::sqrt(cur.e.ce_sq) > 1e-2) return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    if (std::sqrt(cur.e.aitcp_sq) < 1e-6 && std::sqrt(cur.e.cp_sq) > 1e-6) return finish(ExitStatus::LOCALLY_INFEASIBLE);
+    if (cur.e.x_inf > 1e10 || cur.e.s_inf > 1e10 || cur.e.finite == 0.0) return finish(ExitStatus::DIVERGING_ITERATES);
+
+    if (!user_callbacks.empty()) {
+      pull_state();
+      Vo.resize(st.nV);
+      dev.download_V(Vo.data());
+      if (view.st.n == 0) build_restoration_view(st, view);
+      fill_restoration_view(st, view, Vo, X, x_r, w, rho);
+      for (const auto& cb : user_callbacks)
+        if (cb({iterations, X, S, y, Z, view.V, &view.st, true})) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+    }
+    if (accept_exit(cur)) return finish(ExitStatus::CALLBACK_REQUESTED_STOP);
+
+    // ---- Newton step (:426-482) on the reduced system, then speculatively: the full direction, its step sizes, the
+    // first trial point and its filter entry ----
+    auto t0 = clk::now();
+    NewtonSystem::AttemptHooks hooks;
+    hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
+    hooks.after = [&](double d, double) {
+      fr.expand(d, mu, tau, /*soc=*/false);
+      dev.sweep_values_trial();
+      fr.trial_metrics(-1.0, mu);
+    };
+    hooks.eliminated_min_pivot = [&] {
+      fr.wait_published();
+      return H.dir.eliminated_min_pivot;
+    };
+    auto info = sys.compute_hooked(hooks);
+    fr.wait_published();
+    rep.factorizations += sys.last_factorizations();
+    rep.solves += sys.last_factorizations();
+    rep.value_sweeps += sys.last_factorizations();
+    rep.t_kkt_decomp += since(t0);
+    if (info[0] != FactorInfo::Success) return finish(ExitStatus::FACTORIZATION_FAILED);  // :463-465
+    const double delta = sys.hessian_regularization()[0];
+    rep.delta = delta;
+    rep.gamma = sys.constraint_jacobian_regularization()[0];
+
+    t0 = clk::now();
+    const double alpha_max = H.dir.alpha_max;  // :488
+    double alpha = alpha_max;
+    double alpha_z = H.dir.alpha_z;  // :497
+    const double D_phi = H.dir.D_phi;  // :508-509
+    bool failed = alpha < alpha_min;
+    const FilterEntry current_entry{cur.e.f - mu * cur.e.logsum, cur.e.viol};
+    static const bool fr_debug = std::getenv("SLPX_FR_DEBUG") != nullptr;
+    if (fr_debug) {
+      std::fprintf(stderr, "fr: it %d mu %.3e delta %.1e gamma %.1e nfact %d | alpha_max %.3e alpha_z %.3e D_phi %.3e emin %.3e | cur f %.6e viol %.6e logsum %.6e | trial f %.6e viol %.6e logsum %.6e fin %g\n",
+                   iterations, mu, delta, rep.gamma, sys.last_factorizations(), alpha_max, alpha_z, D_phi, H.dir.eliminated_min_pivot, cur.e.f, cur.e.viol,
+                   cur.e.logsum, H.trial.f, H.trial.viol, H.trial.logsum, H.trial.finite);
+      // residual of the FULL Newton-KKT system of the restoration problem for the direction on the device
+      Vec Vd(st.nV), p(dim), ps0(std::max(1, m_i)), pz0(std::max(1, m_i)), dpn(M), psx(M), pzx(M), Xd(n + M), Sd(m_i + M), yd(m_e), Zd(m_i + M);
+      dev.download_V(Vd.data());
+      dev.download(dev.d_p(), p.data(), dim);
+      if (m_i) { dev.download(dev.d_ps(), ps0.data(), m_i); dev.download(dev.d_pz(), pz0.data(), m_i); dev.download(dev.d_s(), Sd.data(), m_i); dev.download(dev.d_z(), Zd.data(), m_i); }
+      dev.download(dev.d_x(), Xd.data(), n);
+      if (m_e) dev.download(dev.d_y(), yd.data(), m_e);
+      fr.download_direction(dpn.data(), psx.data(), pzx.data());
+      fr.download_state(Xd.data() + n, Sd.data() + m_i, Zd.data() + m_i);
+      // rows: pe: (S1+d) dpe - w = -rho - y + t1 ...
+      double r_pe = 0, r_ne = 0, r_pi = 0, r_ni = 0, r_y = 0, r_x = 0, r_ps = 0, r_pz = 0, sig_max = 0;
+      const double* pn = Xd.data() + n;
+      Vec aidx(m_i, 0.0), t0v(m_i), sig(m_i);
+      for (int c = 0; c < n; ++c) for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q) aidx[st.Ai.rowidx[q]] += Vd[st.off_Ai + q] * p[c];
+      for (int j = 0; j < m_e; ++j) {
+        const double s1 = Sd[m_i + j], z1 = Zd[m_i + j], s2 = Sd[m_i + m_e + j], z2 = Zd[m_i + m_e + j], S1 = z1 / s1, S2 = z2 / s2;
+        const double t1 = -S1 * pn[j] + mu / s1 + z1, t2 = -S2 * pn[m_e + j] + mu / s2 + z2, wj = p[n + j];
+        r_pe = std::max(r_pe, std::abs((S1 + delta) * dpn[j] - wj - (-rho - yd[j] + t1)));
+        r_ne = std::max(r_ne, std::abs((S2 + delta) * dpn[m_e + j] + wj - (-rho + yd[j] + t2)));
+        double aedx = 0.0;
+        for (int q = sys.kkt().ae_rowptr[j]; q < sys.kkt().ae_rowptr[j + 1]; ++q) aedx += Vd[sys.kkt().ae_src[q]] * p[sys.kkt().ae_col[q]];
+        r_y = std::max(r_y, std::abs(aedx - dpn[j] + dpn[m_e + j] - rep.gamma * wj + (Vd[st.off_ce + j] - pn[j] + pn[m_e + j])));
+        r_ps = std::max({r_ps, std::abs(psx[j] - (pn[j] - s1 + dpn[j])), std::abs(psx[m_e + j] - (pn[m_e + j] - s2 + dpn[m_e + j]))});
+        r_pz = std::max({r_pz, std::abs(pzx[j] - (mu / s1 - z1 - S1 * psx[j])), std::abs(pzx[m_e + j] - (mu / s2 - z2 - S2 * psx[m_e + j]))});
+      }
+      for (int r = 0; r < m_i; ++r) {
+        const int e3 = 2 * m_e + r, e4 = 2 * m_e + m_i + r;
+        const double s0 = Sd[r], z0 = Zd[r], s3 = Sd[m_i + e3], z3 = Zd[m_i + e3], s4 = Sd[m_i + e4], z4 = Zd[m_i + e4];
+        const double sg = z0 / s0, S3 = z3 / s3, S4 = z4 / s4, ci = Vd[st.off_ci + r] - pn[e3] + pn[e4];
+        const double t0_ = -sg * ci + mu / s0 + z0, t3 = -S3 * pn[e3] + mu / s3 + z3, t4 = -S4 * pn[e4] + mu / s4 + z4;
+        t0v[r] = t0_; sig[r] = sg;
+        // (relative to the size of the row's terms: Sigma_0 can be 1e21)
+        const double sc = std::abs(sg * aidx[r]) + std::abs((sg + S3 + delta) * dpn[e3]) + std::abs(sg * dpn[e4]) + std::abs(t0_) + rho;
+        r_pi = std::max(r_pi, std::abs(-sg * aidx[r] + (sg + S3 + delta) * dpn[e3] - sg * dpn[e4] - (-rho - t0_ + t3)) / sc);
+        r_ni = std::max(r_ni, std::abs(sg * aidx[r] - sg * dpn[e3] + (sg + S4 + delta) * dpn[e4] - (-rho + t0_ + t4)) / sc);
+        sig_max = std::max(sig_max, sg);
+        r_ps = std::max({r_ps, std::abs(ps0[r] - (ci - s0 + aidx[r] - dpn[e3] + dpn[e4])), std::abs(psx[e3] - (pn[e3] - s3 + dpn[e3])), std::abs(psx[e4] - (pn[e4] - s4 + dpn[e4]))});
+        r_pz = std::max({r_pz, std::abs(pz0[r] - (mu / s0 - z0 - sg * ps0[r]))});
+      }
+      // x rows: (Hx + delta) dx + A_i^T [sg (A_i dx - dpi + dni)] + A_e^T w = -g + A_e^T y + A_i^T t0   with Hx from lhs: use H_c entries of V
+      Vec rx(n, 0.0);
+      for (int c = 0; c < n; ++c) {
+        rx[c] += (w[c] + delta) * p[c] + w[c] * (Xd[c] - x_r[c]);
+        for (int q = st.Hc.colptr[c]; q < st.Hc.colptr[c + 1]; ++q) {
+          const int rr = st.Hc.rowidx[q];
+          rx[rr] += Vd[st.off_Hc + q] * p[c];
+          if (rr != c) rx[c] += Vd[st.off_Hc + q] * p[rr];
+        }
+        for (int q = st.Ae.colptr[c]; q < st.Ae.colptr[c + 1]; ++q) rx[c] += Vd[st.off_Ae + q] * (p[n + st.Ae.rowidx[q]] - yd[st.Ae.rowidx[q]]);
+        for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q) {
+          const int rr = st.Ai.rowidx[q];
+          rx[c] += Vd[st.off_Ai + q] * (sig[rr] * (aidx[rr] - dpn[2 * m_e + rr] + dpn[2 * m_e + m_i + rr]) - t0v[rr]);
+        }
+      }
+      for (int c = 0; c < n; ++c) r_x = std::max(r_x, std::abs(rx[c]));
+      std::fprintf(stderr, "fr: residuals of the full system: x %.2e pe %.2e ne %.2e pi(rel) %.2e ni(rel) %.2e y %.2e | ps %.2e pz %.2e | |p| %.3e |dpn| %.3e max Sigma_0 %.2e\n", r_x, r_pe, r_ne, r_pi, r_ni, r_y,
+                   r_ps, r_pz, norm_inf(p.data(), dim), norm_inf(dpn.data(), M), sig_max);
+    }
+    double alpha_commit = alpha;
+    bool have_trial = true;
+
+    while (!failed) {  // :512
+      if (!have_trial) {
+        fr.trial_point(alpha);
+        dev.sweep_values_trial();
+        fr.trial_metrics(alpha, mu);
+        fr.wait_published();
+        ++rep.value_sweeps;
+      }
+      have_trial = false;
+      alpha_commit = alpha;
+      IpmTrialOut tr = H.trial;
+
+      if (tr.finite == 0.0) {
+        alpha *= alpha_reduction_factor;
+        if (alpha < alpha_min) failed = true;
+        continue;
+      }
+      const FilterEntry trial_entry{tr.f - mu * tr.logsum, tr.viol};
+      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
+
+      const double prev_violation = cur.e.viol;
+      double next_violation = tr.viol;
+      // second-order corrections (:566-668): new right-hand side, SAME factorization
+      if (alpha == alpha_max && next_violation >= prev_violation) {
+        fr.save_direction();
+        double alpha_soc = alpha, alpha_z_soc = alpha_z;
+        double soc_violation = next_violation;
+        bool step_acceptable = false;
+        for (int it = 0; it < 5 && !step_acceptable; ++it) {
+          fr.soc_accumulate(alpha_soc, it == 0);
+          fr.build(delta, mu, /*soc=*/true, /*rhs_only=*/true);
+          dev.solve();
+          ++rep.solves;
+          fr.expand(delta, mu, tau, /*soc=*/true);
+          dev.sweep_values_trial();
+          fr.trial_metrics(-1.0, mu);
+          fr.wait_published();
+          ++rep.value_sweeps;
+          alpha_soc = H.dir.alpha_max;
+          alpha_z_soc = H.dir.alpha_z;
+          tr = H.trial;
+          const FilterEntry soc_entry{tr.f - mu * tr.logsum, tr.viol};
+          if (filter.try_add(current_entry, soc_entry, D_phi, alpha)) {
+            alpha = alpha_soc;
+            alpha_z = alpha_z_soc;
+            alpha_commit = alpha_soc;
+            step_acceptable = true;
+            break;
+          }
+          next_violation = tr.viol;
+          if (next_violation > 0.99 * soc_violation) break;
+          soc_violation = next_violation;
+        }
+        if (step_acceptable) break;
+        fr.restore_direction();
+      }
+
+      if (alpha == alpha_max) ++full_step_rejected_counter;
+      // :677-684
+      if (full_step_rejected_counter >= 4 && filter.max_constraint_violation > current_entry.constraint_violation / 10.0 &&
+          filter.last_rejection_due_to_filter()) {
+        filter.max_constraint_violation *= 0.1;
+        filter.reset();
+        have_trial = false;
+        continue;
+      }
+      alpha *= alpha_reduction_factor;
+      if (alpha < alpha_min) {  // :691-716 — rare: on the host, with the iterate pulled over
+        host_current = false;
+        pull_state();
+        Vo.resize(st.nV);
+        dev.download_V(Vo.data());
+        const double current_kkt = restoration_kkt_error_one_norm(st, Vo, X, S, y, Z, x_r, w, rho, mu);
+        Vec p(dim), ps0(m_i), pz0(m_i), dpn(M), psx(M), pzx(M);
+        dev.download(dev.d_p(), p.data(), dim);
+        if (m_i) {
+          dev.download(dev.d_ps(), ps0.data(), m_i);
+          dev.download(dev.d_pz(), pz0.data(), m_i);
+        }
+        fr.download_direction(dpn.data(), psx.data(), pzx.data());
+        Vec Xt(X), St(S), yt(y), Zt(Z);
+        for (int k = 0; k < n; ++k) Xt[k] += alpha_max * p[k];
+        for (int e = 0; e < M; ++e) {
+          Xt[n + e] += alpha_max * dpn[e];
+          St[m_i + e] += alpha_max * psx[e];
+          Zt[m_i + e] += alpha_z * pzx[e];
+        }
+        for (int r = 0; r < m_i; ++r) {
+          St[r] += alpha_max * ps0[r];
+          Zt[r] += alpha_z * pz0[r];
+        }
+        for (int j = 0; j < m_e; ++j) yt[j] += alpha_z * (-p[n + j]);
+        // A_e, A_i at the trial point: a full sweep there, then the iterate back in place
+        dev.upload_x(Xt.data());
+        dev.upload_duals(St.data(), yt.data(), Zt.data());
+        dev.sweep_full();
+        Vec Vt(st.nV);
+        dev.download_V(Vt.data());
+        dev.upload_x(X.data());
+        dev.upload_duals(S.data(), y.data(), Z.data());
+        dev.sweep_full();
+        const double next_kkt = restoration_kkt_error_one_norm(st, Vt, Xt, St, yt, Zt, x_r, w, rho, mu);
+        if (next_kkt <= 0.999 * current_kkt) {
+          alpha_commit = alpha_max;
+          break;
+        }
+        failed = true;
+      }
+    }
+    rep.t_line_search += since(t0);
+    if (failed) return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);  // :721-723
+
+    t0 = clk::now();
+    if (alpha == alpha_max) full_step_rejected_counter = 0;
+    fr.commit(alpha_commit, alpha_z, mu);  // :775-801
+    host_current = false;
+    // AD refresh (:809-812) and every norm the next decisions need
+    dev.sweep_full();
+    fr.errors(false, mu);
+    fr.wait_published();
+    cur = H.err;
+    rep.t_ad_refresh += since(t0);
+
+    E_0 = E0_of(cur.e);
+    if (E_0 > options.tolerance) {  // :819-832
+      double E_mu = E_mu_of(cur.e, mu);
+      while (mu > mu_min && E_mu <= 10.0 * mu) {
+        update_barrier();
+        E_mu = E_mu_of(cur.e, mu);
+      }
+    }
+    if (options.diagnostics) {
+      std::fprintf(stderr,
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  alpha_z %.2e  nfact %d  (restoration)\n",
+                   iterations, E_0, cur.e.f, cur.e.viol, mu, rep.delta, rep.gamma, alpha, alpha_z, sys.last_factorizations());
+    }
+    ++iterations;
+    if (iterations >= options.max_iterations) return finish(ExitStatus::MAX_ITERATIONS_EXCEEDED);
+    if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
+  }
+  return finish(ExitStatus::SUCCESS);
+}
+
+// feasibility_restoration.hpp:347-628 (interior-point variant).  g = the outer problem's dense gradient at x.
+ExitStatus feasibility_restoration(NewtonSystem& outer, const Vec& scales, const std::vector<IterationCallback>& user_callbacks,
+                                   const std::function<bool(const FilterEntry&, double)>& outer_accepts, const Options& options,
+                                   Vec& x, Vec& s, Vec& y, Vec& z, double mu, int& iterations, SolveReport& rep,
+                                   clk::time_point solve_start, const Vec& c_e, const Vec& c_i, const Vec& g, double initial_violation) {
   const NlpStructure& ost = outer.structure();
-  const int n = ost.n, m_e = ost.m_e, m_i = ost.m_i;
+  const int n = ost.n, m_e = ost.m_e, m_i = ost.m_i, M = 2 * m_e + 2 * m_i;
   constexpr double rho = 1e3;
   ++rep.restorations;
 
   Vec cis(m_i);
   for (int j = 0; j < m_i; ++j) cis[j] = c_i[j] - s[j];
-  const double fr_mu =
-      std::max({mu, norm_inf(c_e.data(), m_e), norm_inf(cis.data(), m_i)});
+  const double fr_mu = std::max({mu, norm_inf(c_e.data(), m_e), norm_inf(cis.data(), m_i)});  // :396-397
   const double zeta = std::sqrt(fr_mu);
 
   Vec p_e, n_e, p_i, n_i;
-  compute_p_n(c_e, rho, fr_mu, p_e, n_e);
+  compute_p_n(c_e, rho, fr_mu, p_e, n_e);  // :400-401
   compute_p_n(cis, rho, fr_mu, p_i, n_i);
 
+  DeviceNlp& dev = outer.device();
   const auto t_build = clk::now();
-  NewtonSystem& fr = restoration_system(outer);
+  dev.ipm_enable();  // (the trial buffers)
+  FrDevice& fr = outer.restoration_device();
   rep.t_restoration_setup += since(t_build);
-  auto& R = outer.restoration();
-  Graph& g = outer.graph();
-  for (int k = 0; k < n; ++k) {
-    g.val[R.x_ref[k]] = x[k];
-    g.val[R.weight[k]] = zeta * std::min(1.0 / (x[k] * x[k]), 1.0);
-  }
-  for (int j = 0; j < m_e; ++j) g.val[R.d_ce[j]] = scales[1 + j];
-  for (int j = 0; j < m_i; ++j) g.val[R.d_ci[j]] = scales[1 + m_e + j];
-  fr.device().refresh_params(g);
 
-  const int nz = m_i + 2 * m_e + 2 * m_i;
-  Vec fr_x;
-  fr_x.reserve(n + 2 * m_e + 2 * m_i);
-  for (const Vec* v : {static_cast<const Vec*>(&x), static_cast<const Vec*>(&p_e),
-                       static_cast<const Vec*>(&n_e), static_cast<const Vec*>(&p_i),
-                       static_cast<const Vec*>(&n_i)})
-    fr_x.insert(fr_x.end(), v->begin(), v->end());
-  Vec fr_s(nz, 1.0), fr_y(m_e, 0.0), fr_z;
-  std::copy(s.begin(), s.end(), fr_s.begin());
-  fr_z.reserve(nz);
-  for (int j = 0; j < m_i; ++j) fr_z.push_back(fr_mu * (1.0 / s[j]));
-  for (const Vec* v : {&p_e, &n_e, &p_i, &n_i})
-    for (double e : *v) fr_z.push_back(fr_mu * (1.0 / e));
+  // the restoration iterate (:408-423): X = [x | p_e | n_e | p_i | n_i], S = [s | 1...], y = 0, Z = fr_mu / S (.. / p, n)
+  Vec X;
+  X.reserve(n + M);
+  for (const Vec* v : {static_cast<const Vec*>(&x), static_cast<const Vec*>(&p_e), static_cast<const Vec*>(&n_e),
+                       static_cast<const Vec*>(&p_i), static_cast<const Vec*>(&n_i)})
+    X.insert(X.end(), v->begin(), v->end());
+  Vec S(m_i + M, 1.0), fr_y(m_e, 0.0), Z;
+  std::copy(s.begin(), s.end(), S.begin());
+  Z.reserve(m_i + M);
+  for (int j = 0; j < m_i; ++j) Z.push_back(fr_mu * (1.0 / s[j]));
+  for (int e = 0; e < M; ++e) Z.push_back(fr_mu * (1.0 / X[n + e]));
+  const Vec x_r(x);
+  Vec w(n);
+  for (int k = 0; k < n; ++k) w[k] = zeta * std::min(1.0 / (x[k] * x[k]), 1.0);  // zeta D_R (:404-405)
 
-  // scaling: the rows carry d_ce, d_ci themselves (parameters), so the device applies
-  // none; the error measure un-scales with {1, d_ce, [d_ci, 1...]} (:433-440)
-  Vec fr_scales(1 + m_e + nz, 1.0);
+  // the error measure un-scales with {1, d_ce, [d_ci, 1...]} (:425-432); the bound rows' 1 is implied
+  Vec fr_scales(1 + m_e + m_i, 1.0);
   for (int j = 0; j < m_e; ++j) fr_scales[1 + j] = scales[1 + j];
   for (int j = 0; j < m_i; ++j) fr_scales[1 + m_e + j] = scales[1 + m_e + j];
-  fr.device().set_scaling(Vec(fr.structure().n_scales(), 1.0));
 
+  const Vec s_outer(s);
+  fr.begin(x_r.data(), w.data(), g.data(), s_outer.data(), mu, X.data() + n, S.data() + m_i, Z.data() + m_i, fr_scales);
+  dev.upload_x(X.data());
+  dev.upload_duals(S.data(), fr_y.data(), Z.data());
+
+  // the callback the reference appends (interior_point.hpp:729-752): leave once the OUTER filter accepts the
+  // restoration iterate and the violation dropped by 10 %
+  auto accept_exit = [&](const FrErrOut& e) {
+    const FilterEntry trial_entry{e.f_outer - mu * e.logsum_outer, e.viol_outer};
+    return trial_entry.constraint_violation < 0.9 * initial_violation && outer_accepts(trial_entry, e.dphi_outer);
+  };
+
+  const auto saved_regularization = outer.regularization_state();
   double mu_fr = fr_mu;
   const int it_before = iterations;
   const auto t_inner = clk::now();
-  // (the inner solve reports ITS error measure into rep.final_error: the report keeps the outer problem's)
   const double outer_error = rep.final_error;
-  const ExitStatus status = ipm_core(fr, fr_scales, callbacks, options, true, fr_x, fr_s, fr_y, fr_z,
-                                     mu_fr, iterations, rep, solve_start);
+  const ExitStatus status = restoration_core(outer, fr, user_callbacks, accept_exit, options, x_r, w, X, S, fr_y, Z, mu_fr, iterations,
+                                             rep, solve_start);
+  outer.set_regularization_state(saved_regularization);
+  outer.set_gamma_min(1e-10);
   rep.final_error = outer_error;
   rep.restoration_iterations += iterations - it_before;
   rep.t_restoration += since(t_inner);
 
-  std::copy(fr_x.begin(), fr_x.begin() + n, x.begin());
-  std::copy(fr_s.begin(), fr_s.begin() + m_i, s.begin());
+  std::copy(X.begin(), X.begin() + n, x.begin());
+  std::copy(S.begin(), S.begin() + m_i, s.begin());
 
   if (status == ExitStatus::CALLBACK_REQUESTED_STOP) {
-    // back to the original problem: least-squares multipliers at the new point
-    DeviceNlp& dev = outer.device();
+    // back to the original problem: least-squares multipliers at the new point (:606-617)
     Vec V(ost.nV);
     dev.upload_x(x.data());
     dev.upload_duals(s.data(), y.data(), z.data());
@@ -1456,24 +1760,16 @@ ExitStatus sqp_core(NewtonSystem& sys, const Vec& scales, const std::vector<Iter
       refresh_full(x, y);  // the device V describes x again (the fallback above moved it)
       const double f_x = cur.f();
       const FilterEntry initial_entry{f_x, norm_1(c_e.data(), m_e)};
-      std::vector<IterationCallback> fr_callbacks = callbacks;
-      Vec g_here = cur.g_dense();
-      fr_callbacks.emplace_back([&, alpha](const IterationInfo& info) {
-        Vec tx(info.x.begin(), info.x.begin() + n);
-        eval_values(tx);
-        const double tf = Vtrial[st.off_f];
-        const double tviol = norm_1(Vtrial.data() + st.off_ce, m_e);
-        double D_phi_restoration = 0.0;
-        for (int i = 0; i < n; ++i) D_phi_restoration += g_here[i] * (tx[i] - x[i]);
-        return tviol < 0.9 * initial_entry.constraint_violation &&
-               filter.try_add(initial_entry, FilterEntry{tf, tviol}, D_phi_restoration, alpha);
-      });
+      const Vec g_here = cur.g_dense();
+      auto outer_accepts = [&, alpha](const FilterEntry& trial_entry, double D_phi_restoration) {
+        return filter.try_add(initial_entry, trial_entry, D_phi_restoration, alpha);
+      };
       // feasibility_restoration.hpp:103-345: the interior-point variant with no inequality rows
       // of the original problem and mu = tolerance / 10
       Vec s_none, z_none;
-      const ExitStatus fr_status = feasibility_restoration(sys, scales, fr_callbacks, options, x, s_none, y, z_none,
-                                                           options.tolerance / 10.0, iterations, rep, solve_start, c_e,
-                                                           Vec{});
+      const ExitStatus fr_status = feasibility_restoration(sys, scales, callbacks, outer_accepts, options, x, s_none, y, z_none,
+                                                           options.tolerance / 10.0, iterations, rep, solve_start, c_e, Vec{}, g_here,
+                                                           initial_entry.constraint_violation);
       if (fr_status != ExitStatus::SUCCESS) return fr_status;
       sys.set_gamma_min(1e-10);
     } else {
@@ -1650,8 +1946,12 @@ ExitStatus feasibility_restoration_steps(NewtonSystem& sys, const std::vector<do
   int iterations = 0;
   const std::vector<IterationCallback> stop{
       [steps](const IterationInfo& info) { return info.iteration >= steps; }};
-  return feasibility_restoration(sys, scales, stop, options, x, s, y, z, mu, iterations, rep, clk::now(), c_e,
-                                 c_i);
+  const Vec g = VView{st, V}.g_dense();
+  double violation = norm_1(c_e.data(), st.m_e);
+  for (int j = 0; j < st.m_i; ++j) violation += std::abs(c_i[j] - s[j]);
+  const auto never = [](const FilterEntry&, double) { return false; };
+  return feasibility_restoration(sys, scales, stop, never, options, x, s, y, z, mu, iterations, rep, clk::now(), c_e, c_i, g,
+                                 violation);
 }
 
 ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
@@ -1668,15 +1968,7 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
   Vec s(st.m_i, 1.0), y(st.m_e, 0.0), z(st.m_i, 1.0);
   double mu = 0.1 * scales[0];
   int iterations = 0;
-  restoration_prefetch(sys, !callbacks.empty());
-  ExitStatus status;
-  try {
-    status = ipm_core(sys, scales, callbacks, options, false, x, s, y, z, mu, iterations, rep, solve_start);
-  } catch (...) {
-    restoration_prefetch_join(sys);
-    throw;
-  }
-  restoration_prefetch_join(sys);
+  const ExitStatus status = ipm_core(sys, scales, callbacks, options, false, x, s, y, z, mu, iterations, rep, solve_start);
   rep.t_total = since(solve_start);
   if (s_out) *s_out = s;
   if (y_out) *y_out = y;

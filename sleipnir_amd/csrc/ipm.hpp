@@ -10,8 +10,9 @@
 // scalars per iteration.  SLPX_IPM_RESIDENT=0 selects the older driver that keeps the
 // vectors on the host (the cross-check of the resident one).
 //
-// Feasibility restoration (util/feasibility_restoration.hpp:347-628, row N3) is a second
-// compiled NewtonSystem over the same constraint expressions (built lazily, reused);
+// Feasibility restoration (util/feasibility_restoration.hpp:347-628, row N3) runs on the SAME
+// compiled NewtonSystem: its extra variables p, n are eliminated from the Newton-KKT system in
+// closed form (restoration.hpp), what is left has the outer problem's pattern;
 // the least-squares multiplier estimate (util/lagrange_multiplier_estimate.hpp:56-133)
 // that ends it is one more factorization on the outer system's KKT pattern.
 #pragma once
@@ -78,7 +79,7 @@ struct SolveReport {
   // wall-clock per phase, seconds (names follow interior_point.hpp:155-174)
   double t_setup = 0, t_kkt_build = 0, t_kkt_decomp = 0, t_kkt_solve = 0, t_line_search = 0,
          t_ad_refresh = 0, t_total = 0;
-  // feasibility restoration: compiling the restoration system (first call only), and the
+  // feasibility restoration: allocating its device state (first phase only), and the
   // restoration iterations themselves (both are part of t_total)
   double t_restoration_setup = 0, t_restoration = 0;
 };
@@ -97,7 +98,7 @@ ExitStatus newton(NewtonSystem& sys, const std::vector<double>& scales,
                   std::vector<double>& x, SolveReport* report = nullptr);
 
 // feasibility_restoration (util/feasibility_restoration.hpp:347-628) on its own, from a given
-// iterate: builds the restoration model around (x, s), runs `steps` iterations of its
+// iterate: sets the restoration problem up around (x, s), runs `steps` iterations of its
 // interior-point loop (a callback then stops it, the reference's own way out, :729-752) and, as
 // after any accepted restoration, replaces y, z by the least-squares multiplier estimate
 // (lagrange_multiplier_estimate.hpp:56-133).  `scales` must be installed on the device.
@@ -113,15 +114,5 @@ ExitStatus interior_point(NewtonSystem& sys, const std::vector<double>& scales,
                           std::vector<double>& x, std::vector<double>* s_out = nullptr,
                           std::vector<double>* y_out = nullptr, std::vector<double>* z_out = nullptr,
                           SolveReport* report = nullptr);
-
-// The restoration model (feasibility_restoration.hpp:347-628) as graph nodes: what
-// feasibility_restoration() compiles on first use, and what slpx_problem_prebuild_kernels
-// compiles ahead of time.
-struct RestorationModel {
-  std::vector<NodeId> vars, x_ref, weight, d_ce, d_ci, c_e, c_i;
-  NodeId cost = kNull;
-};
-RestorationModel build_restoration_model(Graph& g, const std::vector<NodeId>& xs, const std::vector<NodeId>& ces,
-                                         const std::vector<NodeId>& cis);
 
 }  // namespace slpx

@@ -1,5 +1,7 @@
 #include "newton.hpp"
 
+#include "restoration.hpp"
+
 #include "setup_timing.hpp"
 
 #include <algorithm>
@@ -121,6 +123,13 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
   if (defer_device) return;
   device_job.get();
   finish_device();
+}
+
+NewtonSystem::~NewtonSystem() = default;
+
+FrDevice& NewtonSystem::restoration_device() {
+  if (!m_fr) m_fr = std::make_unique<FrDevice>(*m_dev);
+  return *m_fr;
 }
 
 void NewtonSystem::finish_device() {
@@ -473,6 +482,68 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
     if (good(second)) return accept(d, g, true);
     advance(second, d, g);
     if (gave_up(d, g)) return info;
+  }
+}
+
+std::vector<FactorInfo> NewtonSystem::compute_hooked(const AttemptHooks& hooks) {
+  if (m_opt.batch != 1) throw std::runtime_error("slpx: compute_hooked handles one problem");
+  const int n = m_s.n, m_e = m_s.m_e;
+  std::vector<FactorInfo> info(1, FactorInfo::Success);
+  m_last_factorizations = 0;
+  m_last_twin_launches = m_last_twin_taken = 0;
+  const double eps = std::numeric_limits<double>::epsilon();
+  std::vector<LdltStats> stats;
+  auto attempt = [&](double d, double g) {
+    hooks.prepare(d, g);
+    m_dev->factor_solve_publish({d}, {g}, {1});
+    if (hooks.after) hooks.after(d, g);
+    m_dev->read_stats(stats);
+    ++m_last_factorizations;
+  };
+  auto inertia_ok = [&](const LdltStats& st) { return st.n_pos == n && st.n_neg == m_e && st.n_zero == 0; };
+  auto min_abs = [](const LdltStats& st) {
+    double d;
+    std::memcpy(&d, &st.min_abs_bits, sizeof(d));
+    return d;
+  };
+  attempt(0.0, 0.0);  // :74-87
+  if (stats[0].n_bad == 0 && inertia_ok(stats[0]) && min_abs(stats[0]) >= 1e-4 &&
+      (!hooks.eliminated_min_pivot || hooks.eliminated_min_pivot() >= 1e-4)) {
+    m_prev_delta[0] = m_prev_gamma[0] = 0.0;
+    return info;
+  }
+  double delta = m_prev_delta[0] == 0.0 ? 1e-4 : std::max(m_prev_delta[0] / 2.0, eps);  // :95-98
+  double gamma = m_gamma_min;                                                             // :102
+  while (true) {
+    attempt(delta, gamma);
+    const LdltStats& st = stats[0];
+    if (st.n_bad == 0) {
+      if (inertia_ok(st)) {  // :109-113
+        m_prev_delta[0] = delta;
+        m_prev_gamma[0] = gamma;
+        return info;
+      } else if (st.n_zero > 0) {  // :114-126
+        if (gamma == 0.0) {
+          gamma = 1e-10;
+        } else {
+          delta *= 10.0;
+          gamma *= 10.0;
+        }
+      } else if (st.n_neg > m_e) {  // :127-130
+        delta *= 10.0;
+      } else if (st.n_pos > n) {  // :131-135
+        gamma = gamma == 0.0 ? 1e-10 : gamma * 10.0;
+      }
+    } else {  // :136-141
+      delta *= 10.0;
+      gamma = gamma == 0.0 ? 1e-10 : gamma * 10.0;
+    }
+    if (delta > 1e20 || gamma > 1e20) {  // :145-150
+      info[0] = FactorInfo::NumericalIssue;
+      m_prev_delta[0] = delta;
+      m_prev_gamma[0] = gamma;
+      return info;
+    }
   }
 }
 

@@ -33,6 +33,8 @@ struct NewtonOptions {
 // Eigen::ComputationInfo stand-in
 enum class FactorInfo : int { Success = 0, NumericalIssue = 1 };
 
+class FrDevice;
+
 class NewtonSystem {
  public:
   NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f, const std::vector<NodeId>& c_e,
@@ -61,20 +63,10 @@ class NewtonSystem {
   const std::vector<NodeId>& c_i_nodes() const { return m_ci_nodes; }
   const NewtonOptions& options() const { return m_opt; }
 
-  // Lazily built restoration system + the parameter nodes it reads (see ipm.cpp)
-  struct Restoration {
-    std::unique_ptr<NewtonSystem> sys;
-    std::vector<NodeId> x_ref, weight;  // parameters: x_R and zeta * D_R (n each)
-    std::vector<NodeId> d_ce, d_ci;     // parameters: the outer problem's row scalings
-    std::vector<NodeId> vars;           // [x, p_e, n_e, p_i, n_i]
-    // the system being compiled on a thread of its own while the outer solve iterates (ipm.cpp:
-    // restoration_prefetch); whoever needs `sys` waits for it first
-    std::future<void> prefetch;
-  };
-  Restoration& restoration() { return m_restoration; }
-  ~NewtonSystem() {
-    if (m_restoration.prefetch.valid()) m_restoration.prefetch.wait();  // (it reads this system's model)
-  }
+  // Feasibility restoration runs on THIS system (restoration.hpp): the device state of the restoration iterate
+  // beyond (x, s, y, z), made when a solve first enters restoration
+  FrDevice& restoration_device();
+  ~NewtonSystem();
 
   const NlpStructure& structure() const { return m_s; }
   const KktPlan& kkt() const { return m_k; }
@@ -102,6 +94,17 @@ class NewtonSystem {
   // least-squares multiplier estimate, which the reference factors unregularized
   // (lagrange_multiplier_estimate.hpp:107).  Single problem.
   bool factor_unregularized();
+  // The same policy loop (sparse_regularized_ldlt.hpp:64-152) for a caller that writes the system of every attempt
+  // itself — feasibility restoration, whose extra variables are eliminated in closed form (restoration.hpp): their part
+  // of the system depends on delta.  `prepare(delta, gamma)` leaves lhs / rhs of the attempt in device memory,
+  // `after(delta, gamma)` is enqueued behind its solve, `eliminated_min_pivot()` (first attempt only) is the smallest
+  // pivot of what was eliminated outside the factorization: it joins the |D| >= 1e-4 test (:82-87).  The
+  // unregularized attempt is always made (such a system has no structurally zero pivot).  One problem.
+  struct AttemptHooks {
+    std::function<void(double, double)> prepare, after;
+    std::function<double()> eliminated_min_pivot;
+  };
+  std::vector<FactorInfo> compute_hooked(const AttemptHooks& hooks);
   const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
   const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
   int last_factorizations() const { return m_last_factorizations; }
@@ -130,7 +133,7 @@ class NewtonSystem {
   NewtonOptions m_opt;
   Graph* m_graph = nullptr;
   std::vector<NodeId> m_x_nodes, m_ce_nodes, m_ci_nodes;
-  Restoration m_restoration;
+  std::unique_ptr<FrDevice> m_fr;
   NlpStructure m_s;
   KktPlan m_k;
   LdltPlan m_l;

@@ -108,25 +108,24 @@ def test_whole_solve_status_at_baseline_horizons(fresh, slpx, orc, N):
 
 
 @pytest.mark.parametrize("N", [300, 50])
-def test_the_restoration_system_compiled_ahead_changes_nothing_but_the_time(fresh, slpx, monkeypatch, N):
-    """ipm.cpp: restoration_prefetch — the host part of the restoration system is compiled on a thread of its own
-    from the start of the solve (models with 512 constraints and more; SLPX_RESTORATION_PREFETCH=1: any size), its device
-    part when restoration is entered.  Cart-pole N=300 enters restoration once, N=50 twenty times: the same exit
-    status, iteration and factorization counts and the same solution TO THE BIT with the switch off, on and forced."""
+def test_restoration_needs_no_second_model(fresh, slpx, N):
+    """VERDICT r05 missing 2: the reference enters restoration with zero setup (feasibility_restoration.hpp:347-628 composes
+    the restoration problem out of the outer callbacks).  So does the product since r06 (csrc/restoration.hpp: the extra
+    variables are eliminated in closed form, the reduced system is factored on the OUTER system's plan): entering
+    restoration appends nothing to the expression graph, compiles nothing, and its set-up (device buffers of the
+    restoration iterate, first phase of a system only) is far below a millisecond-scale compile.  Cart-pole N=300 enters
+    restoration once, N=50 a dozen times."""
     from tests.support import models
 
-    seen = []
-    for env in ("0", None, "1"):
-        if env is None:
-            monkeypatch.delenv("SLPX_RESTORATION_PREFETCH", raising=False)
-        else:
-            monkeypatch.setenv("SLPX_RESTORATION_PREFETCH", env)
-        slpx.lib().slpx_graph_reset()
-        pp = models.cart_pole(N, 5.0 / N)
-        st, rep = pp.solve()
-        seen.append((st, rep["iterations"], rep["factorizations"], rep["restorations"], pp.get_x().tobytes()))
-        # (on the default path both horizons enter restoration; under an outer switch — the switch matrix — the
-        # solve takes another path and may not: the bit equality is asserted either way)
-        assert cases.OUTER_SWITCHES or rep["restorations"] >= 1
-        pp.close()
-    assert seen[0] == seen[1] == seen[2], [(s[0], s[1], s[2], s[3]) for s in seen]
+    slpx.lib().slpx_graph_reset()
+    pp = models.cart_pole(N, 5.0 / N)
+    pp.system()  # compiled: the gradient trees are in the graph now
+    nodes = slpx.lib().slpx_graph_size()
+    st, rep = pp.solve()
+    assert slpx.lib().slpx_graph_size() == nodes  # no restoration model was built
+    assert cases.OUTER_SWITCHES or rep["restorations"] >= 1
+    print(f"N={N}: status {st}, {rep['restorations']} restorations, {rep['restoration_iterations']} of {rep['iterations']} iterations "
+          f"inside, set-up {1e3 * rep['t_restoration_setup']:.3f} ms, {1e6 * rep['t_restoration'] / max(1, rep['restoration_iterations']):.0f} us "
+          f"per restoration iteration")
+    assert rep["t_restoration_setup"] < 5e-3
+    pp.close()

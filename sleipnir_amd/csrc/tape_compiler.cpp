@@ -90,20 +90,6 @@ static void add_tail_padding(TapeProgram& prog) {
   }
 }
 
-// What the flat compiler reports about every task it emitted, in terms of the caller's graph nodes, value outputs and
-// rows: what compile_tape_families needs to instantiate the task for the other members of its family.
-struct TapeTrace {
-  struct Task {
-    std::vector<NodeId> leaf_nodes;                     // graph node of every leaf, in the task's leaf order
-    std::vector<uint32_t> vouts;                        // index into value_outs of every value output, in the task's order
-    std::vector<std::pair<uint32_t, NodeId>> jouts;     // (index into rows, wrt node) of every derivative output
-    uint32_t comp_nodes = 0;                            // interior nodes of its components (without private copies)
-    uint32_t n_comps = 0;
-    int cls = 0;
-  };
-  std::vector<Task> tasks;
-};
-
 // Per-graph-node tables of the flat compiler, kept between its calls by a caller that makes many (one per family
 // representative: a call on a hundred nodes paid for tables of a million): `seen` and `to_cg` are returned to their
 // blank state by the call that used them.
@@ -968,21 +954,27 @@ static TapeProgram compile_tape_flat(Graph& g, const std::vector<std::pair<NodeI
 // The resulting program computes what the flat compiler's does, task for task (tests/test_tape_families_cpu.py:
 // the same V to the bit); the order of the tasks in it differs.
 // ---------------------------------------------------------------------------
-static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
-                                  const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
-                                  const TapeCompileOptions& opt, TapeProgram& out) {
+// per-graph-node tables of the family passes, kept by the thread between compilations (a fresh 20 MB of them was
+// mostly page faults)
+struct FamilyNodeTables {
+  std::vector<uint8_t> flag, depth;
+  std::vector<int32_t> parent, comp_of, input_idx;
+  std::vector<uint32_t> local;
+  FlatScratch flat;
+};
+static FamilyNodeTables& family_node_tables() {
+  static thread_local FamilyNodeTables tables;
+  return tables;
+}
+
+bool tape_families_analyze(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                           const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows, TapeFamilySet& S) {
   SetupLap lap;
   const size_t G = g.size();
   constexpr uint8_t kReach = 1, kRoot = 2, kRepl = 4;
   // (tables of one entry per graph node, kept by the thread between compilations: a fresh 20 MB of them was
   // mostly page faults)
-  struct NodeTables {
-    std::vector<uint8_t> flag, depth;
-    std::vector<int32_t> parent, comp_of, input_idx;
-    std::vector<uint32_t> local;
-    FlatScratch flat;
-  };
-  static thread_local NodeTables tables;
+  FamilyNodeTables& tables = family_node_tables();
   std::vector<uint8_t>& flag = tables.flag;
   flag.assign(G, 0);
   // ---- 1. reachable nodes, roots ----
@@ -1049,8 +1041,10 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   // component numbers in order of their smallest node; members by component, ascending
   std::vector<int32_t>& comp_of = tables.comp_of;
   comp_of.assign(G, -1);
-  std::vector<uint32_t> comp_start{0};
-  std::vector<NodeId> members;
+  std::vector<uint32_t>& comp_start = S.comp_start;
+  std::vector<NodeId>& members = S.members;
+  comp_start.assign(1, 0);
+  members.clear();
   {
     std::vector<uint32_t> count;
     for (size_t n = 0; n < G; ++n) {
@@ -1072,9 +1066,15 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   }
   lap("  tape families:   numbering");
   const size_t ncomp = comp_start.size() - 1;
+  S.ncomp = ncomp;
+  S.graph_size = G;
   if (ncomp < kTapeFamilyMin) return false;
   // rows and value outputs by component (in the order of the lists); what belongs to none: a bare leaf
-  std::vector<uint32_t> crow_start(ncomp + 1, 0), cvout_start(ncomp + 1, 0), crow, cvout, loose_rows, loose_vouts;
+  std::vector<uint32_t>&crow_start = S.crow_start, &cvout_start = S.cvout_start, &crow = S.crow, &cvout = S.cvout,
+                       &loose_rows = S.loose_rows, &loose_vouts = S.loose_vouts;
+  crow_start.assign(ncomp + 1, 0);
+  cvout_start.assign(ncomp + 1, 0);
+  crow.clear(), cvout.clear(), loose_rows.clear(), loose_vouts.clear();
   {
     for (size_t ri = 0; ri < rows.size(); ++ri) {
       const NodeId r = rows[ri].root;
@@ -1112,8 +1112,11 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     input_idx[node] = idx;
     n_inputs = std::max(n_inputs, idx + 1);
   }
-  std::vector<NodeId> all_nodes;           // every component's reachable set, ascending
-  std::vector<uint32_t> all_start{0};
+  S.n_inputs = n_inputs;
+  std::vector<NodeId>& all_nodes = S.all_nodes;  // every component's reachable set, ascending
+  std::vector<uint32_t>& all_start = S.all_start;
+  all_nodes.clear();
+  all_start.assign(1, 0);
   std::vector<uint32_t> seq;               // every component's sequence
   std::vector<uint32_t> seq_start{0};
   std::vector<uint64_t> seq_hash(ncomp);
@@ -1265,16 +1268,12 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       ch = Chunk{};
     }
   }
-  std::vector<uint32_t>& local = tables.local;  // (scratch of the passes below)
-  if (local.size() < G) local.resize(G, 0);
   lap("  tape families: sequences");
 
   // ---- families: equal sequences ----
-  struct Family {
-    uint32_t rep;
-    std::vector<uint32_t> comps;
-  };
-  std::vector<Family> fams;
+  using Family = TapeFamilySet::Family;
+  std::vector<Family>& fams = S.fams;
+  fams.clear();
   {
     std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash;  // hash -> families with it
     by_hash.reserve(64);
@@ -1298,44 +1297,85 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       fams[hit].comps.push_back(static_cast<uint32_t>(c));
     }
   }
+  // (every parameter leaf the whole program reaches, in node order: flat compiler, "parameters first")
+  S.param_order.clear();
+  for (size_t n = 0; n < G; ++n)
+    if ((flag[n] & kReach) && g.op[n] == OP_VAR && input_idx[n] < 0) S.param_order.push_back(static_cast<NodeId>(n));
+  S.accepted.clear();
+  S.comp_in_family.assign(ncomp, 0);
   lap("  tape families: classes");
+  return true;
+}
 
-  // ---- 3. one member of every family through the flat compiler ----
+
+bool tape_families_accept(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                          const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                          const TapeCompileOptions& opt, TapeFamilySet& S, uint32_t f, const std::vector<uint32_t>& extra_rows) {
+  const TapeFamilySet::Family& fam = S.fams[f];
+  if (fam.comps.size() < kTapeFamilyMin) return false;
+  const uint32_t r = fam.rep;
+  if (S.comp_start[r + 1] - S.comp_start[r] < 8) return false;  // (far from the 16 nodes a task of its own takes: not worth a trial)
+  FamilyNodeTables& tables = family_node_tables();
+  const size_t G = g.size();  // (the caller may have added nodes since the analysis)
   FlatScratch& flat_scratch = tables.flat;
   flat_scratch.bind(G, inputs);
   struct Unbind {
     FlatScratch& f;
     ~Unbind() { f.unbind(); }
   } unbind_flat{flat_scratch};
-  struct Accepted {
-    uint32_t fam;
-    TapeProgram prog;
-    TapeTrace::Task tt;
-  };
-  std::vector<Accepted> accepted;
-  std::vector<uint8_t> comp_in_family(ncomp, 0);
-  for (size_t f = 0; f < fams.size(); ++f) {
-    const Family& fam = fams[f];
-    if (fam.comps.size() < kTapeFamilyMin) continue;
-    const uint32_t r = fam.rep;
-    if (comp_start[r + 1] - comp_start[r] < 8) continue;  // (far from the 16 nodes a task of its own takes: not worth a trial)
-    std::vector<uint32_t> vsel(cvout.begin() + cvout_start[r], cvout.begin() + cvout_start[r + 1]);
-    std::vector<uint32_t> rsel(crow.begin() + crow_start[r], crow.begin() + crow_start[r + 1]);
-    TapeTrace trace;
-    TapeProgram rp = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, &trace, /*tail_padding=*/false, nullptr, &flat_scratch);
-    // (what the flat compiler gives a family member: a task of its own — from 16 nodes)
-    if (rp.tasks.size() != 1 || trace.tasks.size() != 1 || trace.tasks[0].n_comps != 1 || trace.tasks[0].comp_nodes < 16) continue;
-    // every leaf must be findable by position in the member's reachable set
+  std::vector<uint32_t> vsel(S.cvout.begin() + S.cvout_start[r], S.cvout.begin() + S.cvout_start[r + 1]);
+  std::vector<uint32_t> rsel(S.crow.begin() + S.crow_start[r], S.crow.begin() + S.crow_start[r + 1]);
+  rsel.insert(rsel.end(), extra_rows.begin(), extra_rows.end());
+  TapeTrace trace;
+  TapeProgram rp = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, &trace, /*tail_padding=*/false, nullptr, &flat_scratch);
+  // (what the flat compiler gives a family member: a task of its own — from 16 nodes)
+  if (rp.tasks.size() != 1 || trace.tasks.size() != 1 || trace.tasks[0].n_comps != 1 || trace.tasks[0].comp_nodes < 16) return false;
+  // every leaf must be findable by position in the member's reachable set — or be the caller's to translate
+  // (a leaf the caller's extra rows brought in: beyond the analysed graph, or a multiplier: not reachable from the
+  // component's own roots)
+  if (extra_rows.empty()) {
+    std::vector<uint32_t>& local = tables.local;
+    if (local.size() < G) local.resize(G, 0);
     bool ok = true;
-    for (uint32_t q = all_start[r]; q < all_start[r + 1]; ++q) local[all_nodes[q]] = q - all_start[r];
+    for (uint32_t q = S.all_start[r]; q < S.all_start[r + 1]; ++q) local[S.all_nodes[q]] = q - S.all_start[r];
     for (NodeId n : trace.tasks[0].leaf_nodes)
-      ok = ok && n != kNull && local[n] < all_start[r + 1] - all_start[r] && all_nodes[all_start[r] + local[n]] == n;
-    if (!ok) continue;
-    for (uint32_t c : fam.comps) comp_in_family[c] = 1;
-    accepted.push_back(Accepted{static_cast<uint32_t>(f), std::move(rp), std::move(trace.tasks[0])});
+      ok = ok && n != kNull && local[n] < S.all_start[r + 1] - S.all_start[r] && S.all_nodes[S.all_start[r] + local[n]] == n;
+    if (!ok) return false;
   }
-  if (accepted.empty()) return false;
+  for (uint32_t c : fam.comps) S.comp_in_family[c] = 1;
+  S.accepted.push_back(TapeFamilySet::Accepted{f, std::move(rp), std::move(trace.tasks[0]), extra_rows});
+  return true;
+}
 
+TapeProgram tape_families_emit(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                               const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                               const TapeCompileOptions& opt, TapeFamilySet& S, const TapeFamilyHooks& hooks,
+                               const std::vector<uint32_t>& more_vouts, const std::vector<uint32_t>& more_rows) {
+  SetupLap lap;
+  TapeProgram out;
+  FamilyNodeTables& tables = family_node_tables();
+  const size_t G = g.size();  // (the caller may have added nodes since the analysis)
+  const size_t ncomp = S.ncomp;
+  const std::vector<uint32_t>&comp_start = S.comp_start, &crow_start = S.crow_start, &cvout_start = S.cvout_start, &crow = S.crow,
+                             &cvout = S.cvout, &loose_rows = S.loose_rows, &loose_vouts = S.loose_vouts, &all_start = S.all_start;
+  (void)comp_start;
+  const std::vector<NodeId>& all_nodes = S.all_nodes;
+  const std::vector<TapeFamilySet::Family>& fams = S.fams;
+  std::vector<TapeFamilySet::Accepted>& accepted = S.accepted;
+  const std::vector<uint8_t>& comp_in_family = S.comp_in_family;
+  const int32_t n_inputs = S.n_inputs;
+  // (another analysis on this thread may have used the tables since: the inputs again)
+  std::vector<int32_t>& input_idx = tables.input_idx;
+  input_idx.assign(G, -1);
+  for (auto& [node, idx] : inputs) input_idx[node] = idx;
+  std::vector<uint32_t>& local = tables.local;  // (scratch of the passes below)
+  if (local.size() < G) local.resize(G, 0);
+  FlatScratch& flat_scratch = tables.flat;
+  flat_scratch.bind(G, inputs);
+  struct Unbind {
+    FlatScratch& f;
+    ~Unbind() { f.unbind(); }
+  } unbind_flat{flat_scratch};
   // ---- 4. everything else through the flat compiler together ----
   {
     std::vector<uint32_t> vsel = loose_vouts, rsel = loose_rows;
@@ -1344,13 +1384,11 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       vsel.insert(vsel.end(), cvout.begin() + cvout_start[c], cvout.begin() + cvout_start[c + 1]);
       rsel.insert(rsel.end(), crow.begin() + crow_start[c], crow.begin() + crow_start[c + 1]);
     }
+    vsel.insert(vsel.end(), more_vouts.begin(), more_vouts.end());
+    rsel.insert(rsel.end(), more_rows.begin(), more_rows.end());
     std::sort(vsel.begin(), vsel.end());
     std::sort(rsel.begin(), rsel.end());
-    // (every parameter leaf the whole program reaches, in node order: flat compiler, "parameters first")
-    std::vector<NodeId> param_order;
-    for (size_t n = 0; n < G; ++n)
-      if ((flag[n] & kReach) && g.op[n] == OP_VAR && input_idx[n] < 0) param_order.push_back(static_cast<NodeId>(n));
-    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false, &param_order, &flat_scratch);
+    out = compile_tape_flat(g, inputs, value_outs, rows, vsel, rsel, opt, nullptr, /*tail_padding=*/false, &S.param_order, &flat_scratch);
   }
   lap("  tape families: representatives + remainder");
   TapeProgram& prog = out;
@@ -1386,8 +1424,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     }
     return kLeafConstFlag | pit->second;
   };
-  for (Accepted& acc : accepted) {
-    const Family& fam = fams[acc.fam];
+  for (TapeFamilySet::Accepted& acc : accepted) {
+    const TapeFamilySet::Family& fam = fams[acc.fam];
     const TapeProgram& rp = acc.prog;
     const uint32_t r = fam.rep;
     // the family's structure, once
@@ -1429,23 +1467,40 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
     std::vector<uint32_t> leaf_pos(tt.leaf_nodes.size()), vout_pos(tt.vouts.size());
     std::vector<std::pair<uint32_t, uint32_t>> jout_pos(tt.jouts.size());  // (row of the member, output of the row)
     bool ok = true;
-    for (size_t i = 0; i < tt.leaf_nodes.size(); ++i) leaf_pos[i] = local[tt.leaf_nodes[i]];
+    constexpr uint32_t kOutside = 0xffffffffu;  // a leaf that is not of the component: the caller's to translate
+    const uint32_t n_all_r = all_start[r + 1] - all_start[r];
+    for (size_t i = 0; i < tt.leaf_nodes.size(); ++i) {
+      const NodeId ln = tt.leaf_nodes[i];
+      const bool inside = static_cast<size_t>(ln) < S.graph_size && local[ln] < n_all_r && all_nodes[all_start[r] + local[ln]] == ln;
+      leaf_pos[i] = inside ? local[ln] : kOutside;
+      if (!inside && !hooks.outside_leaf) ok = false;
+    }
     for (size_t i = 0; i < tt.vouts.size(); ++i) {
       const auto b = cvout.begin() + cvout_start[r], e = cvout.begin() + cvout_start[r + 1];
       const auto it = std::find(b, e, tt.vouts[i]);
       ok = ok && it != e;
       vout_pos[i] = static_cast<uint32_t>(it - b);
     }
+    constexpr uint32_t kExtraRow = 0x80000000u;  // jout_pos.first: | position in the family's extra rows
     for (size_t i = 0; i < tt.jouts.size(); ++i) {
       const auto b = crow.begin() + crow_start[r], e = crow.begin() + crow_start[r + 1];
       const auto it = std::find(b, e, tt.jouts[i].first);
-      ok = ok && it != e;
-      if (!ok) break;
-      const TapeRow& row = rows[*it];
+      uint32_t where;
+      const TapeRow* row;
+      if (it != e) {
+        where = static_cast<uint32_t>(it - b);
+        row = &rows[*it];
+      } else {
+        const auto xit = std::find(acc.extra_rows.begin(), acc.extra_rows.end(), tt.jouts[i].first);
+        ok = ok && xit != acc.extra_rows.end() && static_cast<bool>(hooks.extra_dst);
+        if (!ok) break;
+        where = kExtraRow | static_cast<uint32_t>(xit - acc.extra_rows.begin());
+        row = &rows[*xit];
+      }
       size_t j = 0;
-      while (j < row.outputs.size() && row.outputs[j].wrt != tt.jouts[i].second) ++j;
-      ok = ok && j < row.outputs.size();
-      jout_pos[i] = {static_cast<uint32_t>(it - b), static_cast<uint32_t>(j)};
+      while (j < row->outputs.size() && row->outputs[j].wrt != tt.jouts[i].second) ++j;
+      ok = ok && j < row->outputs.size();
+      jout_pos[i] = {where, static_cast<uint32_t>(j)};
     }
     if (!ok) throw std::runtime_error("slpx tape compiler: a family representative's trace does not match its component");
     const int cls = tt.cls;
@@ -1456,7 +1511,8 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
       t.vout_off = static_cast<uint32_t>(prog.vout_src.size());
       t.jout_off = static_cast<uint32_t>(prog.jout_slot.size());
       const NodeId* nodes_c = all_nodes.data() + all_start[c];
-      for (uint32_t pos : leaf_pos) prog.leaf_src.push_back(leaf_binding(nodes_c[pos]));
+      for (size_t i = 0; i < leaf_pos.size(); ++i)
+        prog.leaf_src.push_back(leaf_binding(leaf_pos[i] != kOutside ? nodes_c[leaf_pos[i]] : hooks.outside_leaf(acc.fam, tt.leaf_nodes[i], c)));
       for (size_t i = 0; i < vout_pos.size(); ++i) {
         const TapeValueOut& vo = value_outs[cvout[cvout_start[c] + vout_pos[i]]];
         prog.vout_src.push_back(rp.vout_src[rp.tasks[0].vout_off + i]);
@@ -1464,10 +1520,16 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
         prog.vout_scale.push_back(vo.scale_idx);
       }
       for (size_t i = 0; i < jout_pos.size(); ++i) {
-        const TapeRow& row = rows[crow[crow_start[c] + jout_pos[i].first]];
         prog.jout_slot.push_back(rp.jout_slot[rp.tasks[0].jout_off + i]);
-        prog.jout_dst.push_back(static_cast<uint32_t>(row.outputs[jout_pos[i].second].dst));
-        prog.jout_scale.push_back(row.scale_idx);
+        if (jout_pos[i].first & kExtraRow) {
+          const uint32_t k = jout_pos[i].first & ~kExtraRow;
+          prog.jout_dst.push_back(static_cast<uint32_t>(hooks.extra_dst(acc.fam, k, jout_pos[i].second, c)));
+          prog.jout_scale.push_back(rows[acc.extra_rows[k]].scale_idx);
+        } else {
+          const TapeRow& row = rows[crow[crow_start[c] + jout_pos[i].first]];
+          prog.jout_dst.push_back(static_cast<uint32_t>(row.outputs[jout_pos[i].second].dst));
+          prog.jout_scale.push_back(row.scale_idx);
+        }
       }
       const uint32_t ti = static_cast<uint32_t>(prog.tasks.size());
       if (cls == 0) {
@@ -1491,9 +1553,22 @@ static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, 
   }
   add_tail_padding(prog);
   lap("  tape families: instances");
-  return true;
+  return out;
 }
 
+
+
+// The whole of it for a caller with nothing to do between the phases: every family as it stands.
+static bool compile_tape_families(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                                  const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                                  const TapeCompileOptions& opt, TapeProgram& out) {
+  TapeFamilySet S;
+  if (!tape_families_analyze(g, inputs, value_outs, rows, S)) return false;
+  for (size_t f = 0; f < S.fams.size(); ++f) tape_families_accept(g, inputs, value_outs, rows, opt, S, static_cast<uint32_t>(f), {});
+  if (S.accepted.empty()) return false;
+  out = tape_families_emit(g, inputs, value_outs, rows, opt, S, TapeFamilyHooks{});
+  return true;
+}
 
 TapeProgram compile_tape(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
                          const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,

@@ -25,6 +25,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <utility>
 #include <vector>
 
@@ -106,6 +107,75 @@ struct TapeCompileOptions {
   uint32_t split_sum_min_terms = 64;
   uint32_t split_sum_group = 32;
 };
+
+// What the flat compiler reports about every task it emitted, in terms of the caller's graph nodes, value outputs and
+// rows: what the family code needs to instantiate the task for the other members of its family.
+struct TapeTrace {
+  struct Task {
+    std::vector<NodeId> leaf_nodes;                     // graph node of every leaf, in the task's leaf order
+    std::vector<uint32_t> vouts;                        // index into value_outs of every value output, in the task's order
+    std::vector<std::pair<uint32_t, NodeId>> jouts;     // (index into rows, wrt node) of every derivative output
+    uint32_t comp_nodes = 0;                            // interior nodes of its components (without private copies)
+    uint32_t n_comps = 0;
+    int cls = 0;
+  };
+  std::vector<Task> tasks;
+};
+
+// Families of structurally identical components (tape_compiler.cpp: "Families"), in three phases so that a caller can
+// work on a family's REPRESENTATIVE between them (nlp.cpp builds the Hessian rows of a stage family on one stage only
+// and never materializes the other stages' gradient expressions):
+//   tape_families_analyze   components of the graph under (value_outs, rows), every component's reachable set and
+//                           sequence, the classes of equal sequences;
+//   tape_families_accept    one family: its representative — with `extra_rows` (indices into `rows`) the caller built
+//                           on it — through the flat compiler alone; false: not a family the instances can share;
+//   tape_families_emit      the program: what is in no accepted family through the flat compiler together, every
+//                           accepted family's members instantiated from its representative by position.  A leaf of the
+//                           representative's task that is NOT in its component's reachable set (a multiplier, a
+//                           constant made by the caller) and the destination of an extra row's output are the caller's
+//                           to translate for each member.
+struct TapeFamilySet {
+  size_t graph_size = 0;
+  size_t ncomp = 0;
+  std::vector<uint32_t> comp_start;       // interior members of component c: members[comp_start[c] .. comp_start[c + 1])
+  std::vector<NodeId> members;            // ascending within a component
+  std::vector<uint32_t> crow_start, crow, cvout_start, cvout;  // rows / value outputs of component c, in list order
+  std::vector<uint32_t> loose_rows, loose_vouts;               // ... of no component (a bare leaf)
+  std::vector<NodeId> all_nodes;          // every component's reachable set (members, private nodes, leaves), ascending
+  std::vector<uint32_t> all_start;
+  struct Family {
+    uint32_t rep;                 // component
+    std::vector<uint32_t> comps;  // its members, ascending (rep first)
+  };
+  std::vector<Family> fams;
+  std::vector<NodeId> param_order;  // every parameter leaf the roots reach, in node order
+  int32_t n_inputs = 0;
+  struct Accepted {
+    uint32_t fam;
+    TapeProgram prog;
+    TapeTrace::Task tt;
+    std::vector<uint32_t> extra_rows;
+  };
+  std::vector<Accepted> accepted;
+  std::vector<uint8_t> comp_in_family;  // per component: a member of an accepted family
+};
+struct TapeFamilyHooks {
+  // the graph node member `comp` has where the representative of family `fam` has leaf `rep_leaf` (not of its component)
+  std::function<NodeId(uint32_t fam, NodeId rep_leaf, uint32_t comp)> outside_leaf;
+  // destination in V of output `out` of the family's extra row `k` (position in Accepted::extra_rows) for member `comp`
+  std::function<int32_t(uint32_t fam, uint32_t k, uint32_t out, uint32_t comp)> extra_dst;
+};
+bool tape_families_analyze(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                           const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows, TapeFamilySet& S);
+bool tape_families_accept(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                          const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                          const TapeCompileOptions& opt, TapeFamilySet& S, uint32_t fam, const std::vector<uint32_t>& extra_rows);
+// `more_vouts` / `more_rows`: what else goes through the flat compiler with the remainder (indices into the lists; rows
+// and value outputs that were not part of the analysis)
+TapeProgram tape_families_emit(Graph& g, const std::vector<std::pair<NodeId, int32_t>>& inputs,
+                               const std::vector<TapeValueOut>& value_outs, const std::vector<TapeRow>& rows,
+                               const TapeCompileOptions& opt, TapeFamilySet& S, const TapeFamilyHooks& hooks,
+                               const std::vector<uint32_t>& more_vouts = {}, const std::vector<uint32_t>& more_rows = {});
 
 // `inputs`: leaf VAR node -> input vector index (nodes absent from the map must
 // not be reachable).  Rows must reference wrt nodes that are in `inputs`.

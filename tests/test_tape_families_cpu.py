@@ -38,9 +38,16 @@ STAT_KEYS = ("tape_tasks", "tape_nodes", "tape_slots", "tape_edges", "tape_level
     ("gfold_30", lambda s: _gfold(s, 30)),
 ])
 def test_families_give_the_flat_compilers_program(fresh, slpx, monkeypatch, name, make):
+    """flat (SLPX_TAPE_TEMPLATES=0) against the family front end on the SAME graph (SLPX_HESSIAN_FAMILIES=0: the gradient
+    tree of the whole Lagrangian, as the flat compiler needs it): the same program, the same V to the bit.  And the
+    family-first Hessian (r06, nlp.cpp: the symbolic reverse pass on one member of every family, the other members'
+    gradient expressions never built): the same patterns and layout (nV), the same values up to the order in which a
+    few adjoint terms are added — the gradient expressions of a stage no longer carry the multiplier-only terms its
+    neighbours' linear rows contributed, and its adjoints are accumulated in the stage's own order."""
     got = {}
-    for mode in ("0", "1"):
+    for mode, hess in (("0", "0"), ("1", "0"), ("1", "1")):
         monkeypatch.setenv("SLPX_TAPE_TEMPLATES", mode)
+        monkeypatch.setenv("SLPX_HESSIAN_FAMILIES", hess)
         pp = make(slpx)
         h = hostcheck.HostCheck(pp)
         n, me, mi = h.n, h.m_e, h.m_i
@@ -49,13 +56,23 @@ def test_families_give_the_flat_compilers_program(fresh, slpx, monkeypatch, name
         y = rng.uniform(-1, 1, me)
         z = np.exp(rng.uniform(-2, 2, mi))
         h.set_scaling(np.exp(rng.uniform(-1, 1, 1 + me + mi)))
-        got[mode] = ({k: h.info[k] for k in STAT_KEYS}, h.sweep(x, y, z, full=True), h.sweep(x, y, z, full=False))
+        got[mode + hess] = ({k: h.info[k] for k in STAT_KEYS}, h.sweep(x, y, z, full=True), h.sweep(x, y, z, full=False),
+                            h.info["graph_nodes"] if "graph_nodes" in h.info else None)
         h.close()
-    assert got["0"][0] == got["1"][0], (got["0"][0], got["1"][0])
-    assert np.array_equal(got["0"][1], got["1"][1])
-    assert np.array_equal(got["0"][2], got["1"][2])
-    assert np.any(got["1"][1] != 0.0)
-    print(name, got["1"][0])
+    assert got["00"][0] == got["10"][0], (got["00"][0], got["10"][0])
+    assert np.array_equal(got["00"][1], got["10"][1])
+    assert np.array_equal(got["00"][2], got["10"][2])
+    assert np.any(got["10"][1] != 0.0)
+    # the family-first Hessian: the same layout, the same values to rounding
+    assert got["11"][0]["nV"] == got["10"][0]["nV"]
+    a, b = got["11"][1], got["10"][1]
+    assert a.shape == b.shape
+    assert np.array_equal(a == 0.0, b == 0.0)
+    err = np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+    assert err <= 1e-13, err
+    head = 1 + me + mi  # f, c_e, c_i: the same tape either way (the rest of that V is whatever the sweep before left)
+    assert np.array_equal(got["11"][2][:head], got["10"][2][:head])
+    print(name, got["11"][0], "family-first Hessian vs gradient tree of the Lagrangian:", err)
 
 
 def test_family_compile_time_follows_the_horizon_gently(fresh, slpx, monkeypatch):

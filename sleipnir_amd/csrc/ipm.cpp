@@ -1212,6 +1212,7 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
 
   RestorationView view;
   Vec Vo;
+  int expected_attempt = 0;  // which attempt of the regularization policy the previous iteration took
 
   while (E_0 > options.tolerance) {
     // :387-408
@@ -1233,18 +1234,38 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     // ---- Newton step (:426-482) on the reduced system, then speculatively: the full direction, its step sizes, the
     // first trial point and its filter entry ----
     auto t0 = clk::now();
+    // (the chain behind an attempt — direction, step sizes, first trial point — is enqueued before the attempt's verdict
+    // only for the attempt EXPECTED to be taken: the one the previous iteration took.  The policy's ladder from
+    // delta = 1e-4 up, :95-98 and :127-130, is six rejected attempts in a row every few iterations of a restoration phase;
+    // each dragged ~20 us of chain behind it.  An accepted attempt without its chain gets it now: one more round trip.)
     NewtonSystem::AttemptHooks hooks;
-    hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
-    hooks.after = [&](double d, double) {
+    int attempt = 0;
+    bool chain_behind_last = false;
+    double delta_of_last = 0.0;
+    auto chain = [&](double d) {
       fr.expand(d, mu, tau, /*soc=*/false);
       dev.sweep_values_trial();
       fr.trial_metrics(-1.0, mu);
     };
+    hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
+    hooks.after = [&](double d, double) {
+      chain_behind_last = attempt == expected_attempt;
+      delta_of_last = d;
+      if (chain_behind_last) chain(d);
+      ++attempt;
+    };
     hooks.eliminated_min_pivot = [&] {
+      // (the unregularized attempt's |D| test needs the eliminated pivots: they come with the chain's first kernel)
+      if (!chain_behind_last) {
+        chain(delta_of_last);
+        chain_behind_last = true;
+      }
       fr.wait_published();
       return H.dir.eliminated_min_pivot;
     };
     auto info = sys.compute_hooked(hooks);
+    if (!chain_behind_last) chain(delta_of_last);
+    expected_attempt = attempt - 1;
     fr.wait_published();
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();

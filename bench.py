@@ -45,7 +45,7 @@ sys.path.insert(0, str(ROOT))
 from tests.support import models
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r05"    # profiles/<tag>_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r06"    # profiles/<tag>_traffic.json feeds roofline.traffic
 
 
 def cpu_baseline(N: int, dt: float, budget_s: float = 15.0):
@@ -205,28 +205,68 @@ def batched_probe(sa, cases, N, B, device):
     return out
 
 
-def whole_solve(sa, N):
-    """Problem::solve() at the BASELINE horizon (status, iterations, wall time) — outside the
-    timed region; the iteration path is the product's resident IPM (csrc/ipm.cpp)."""
-    # (short horizons twice, the second run reported: the first solve of a process also loads the code objects of
-    # the restoration system where the solve enters restoration; us_per_iteration = the whole interior-point
-    # iteration — step kernel, look-ahead iterate, its sweep and error norms, host decisions — averaged over the solve,
-    # inertia re-attempts, backtracking and second-order corrections included)
-    for _ in range(2 if N <= 500 else 1):
-        sa.lib().slpx_graph_reset()
-        pp = models.cart_pole(N, 5.0 / N)
-        status, rep = pp.solve()
-        pp.close()
-    t_iter = rep["t_total"] - rep["t_restoration_setup"]
+def whole_solve(sa, N, seeds=9):
+    """Problem::solve() at horizon N (status, iterations, wall time) — outside the timed region; the iteration path is
+    the product's resident IPM (csrc/ipm.cpp) — from the benchmark's initial guess (seed 0: the reported run) AND from
+    eight copies of it perturbed by 1e-13 relative (x * (1 + 1e-13 u), numpy default_rng(seed)): whether this IPM gets
+    through the swing-up on a given grid hangs on the last bits of the arithmetic, in the reference algorithm itself,
+    so one run per horizon says nothing about how robust its outcome is.  `robustness` puts the
+    product's success fraction beside the oracle's (profiles/<tag>_oracle_robustness.json: the same experiment with the
+    CPU restatement, made by profiles/oracle_robustness.py) and beside what the reference's own published sweep shows."""
     from sleipnir_amd.optimization import ExitStatus
 
-    # final_error: the OUTER problem's KKT error measure at the last iterate it was evaluated on (a restoration
-    # phase's own measure no longer overwrites it: VERDICT r04 weak 2)
+    # (us_per_iteration = the whole interior-point iteration — step kernel, look-ahead iterate, its sweep and error
+    # norms, host decisions — averaged over the solve, inertia re-attempts, backtracking, second-order corrections and
+    # restoration iterations included; a first untimed solve where the horizon is short: code objects, first launches)
+    runs = []
+    first = None
+    for k in ([-1] if N <= 500 else []) + list(range(seeds)):
+        sa.lib().slpx_graph_reset()
+        pp = models.cart_pole(N, 5.0 / N)
+        if k > 0:
+            x = pp.get_x()
+            pp.set_x(x * (1 + 1e-13 * np.random.default_rng(k).uniform(-1, 1, len(x))))
+        status, rep = pp.solve()
+        pp.close()
+        if k < 0:
+            continue
+        runs.append({"seed": k, "status": int(status), "iterations": int(rep["iterations"]), "t_total_s": rep["t_total"],
+                     "restorations": int(rep["restorations"]), "restoration_iterations": int(rep["restoration_iterations"])})
+        if k == 0:
+            first = (status, rep)
+    status, rep = first
+    t_iter = rep["t_total"] - rep["t_restoration_setup"]
+    ok = [r for r in runs if r["status"] == 0]
+    robustness = {
+        "perturbation": "initial guess x (1 + 1e-13 u), u ~ U(-1, 1), seeds 0 (unperturbed) .. %d" % (seeds - 1),
+        "product": {"success_fraction": len(ok) / len(runs), "statuses": sorted({r["status"] for r in runs}),
+                    "median_iterations_of_successes": float(np.median([r["iterations"] for r in ok])) if ok else None,
+                    "median_time_s_of_successes": float(np.median([r["t_total_s"] for r in ok])) if ok else None,
+                    "runs": runs},
+        # reference-held evidence (benchmarks/cart-pole-scalability-results-sleipnir.csv: the harness drops
+        # non-SUCCESS rows, benchmarks/scalability/util.hpp:100-106)
+        "reference_published_sweep": {100: "row present (SUCCESS)", 150: "row present (SUCCESS)", 200: "row MISSING (not SUCCESS)",
+                                      250: "row present (SUCCESS)", 300: "row present (SUCCESS)"}.get(N, "not in the published sweep"),
+    }
+    ofile = ROOT / "profiles" / f"{PROFILE_TAG}_oracle_robustness.json"
+    if ofile.exists():
+        o = json.loads(ofile.read_text())["horizons"].get(str(N))
+        if o:
+            robustness["oracle_cpu"] = {k: o[k] for k in ("success_fraction", "statuses", "median_iterations_of_successes",
+                                                          "median_time_s_of_successes")}
+            robustness["oracle_cpu"]["source"] = f"profiles/{PROFILE_TAG}_oracle_robustness.json (same perturbations, build container's CPU)"
+    # final_error: the OUTER problem's KKT error measure at the last iterate it was evaluated on
     return {"N": N, "status": int(status), "status_name": ExitStatus(int(status)).name, "iterations": int(rep["iterations"]),
             "factorizations": int(rep["factorizations"]), "restorations": int(rep["restorations"]),
+            "restoration_iterations": int(rep["restoration_iterations"]),
             "t_total_s": rep["t_total"], "t_compile_s": rep["t_compile"], "final_error": rep["final_error"],
             "us_per_iteration": 1e6 * t_iter / max(1, int(rep["iterations"])),
-            "factorizations_per_iteration": rep["factorizations"] / max(1, int(rep["iterations"]))}
+            "us_per_outer_iteration": 1e6 * (t_iter - rep["t_restoration"]) /
+                                      max(1, int(rep["iterations"]) - int(rep["restoration_iterations"])),
+            "us_per_restoration_iteration": (1e6 * rep["t_restoration"] / int(rep["restoration_iterations"])
+                                             if rep["restoration_iterations"] else None),
+            "factorizations_per_iteration": rep["factorizations"] / max(1, int(rep["iterations"])),
+            "robustness": robustness}
 
 
 def main():
@@ -500,8 +540,9 @@ def main():
                 # arithmetic — in the reference algorithm itself (DESIGN.md §2,
                 # profiles/r02_oracle_sensitivity.txt: the CPU restatement ends LOCALLY_INFEASIBLE
                 # at N=1000 as well) — so the line shows more than one horizon.
+                # (N=100/150/250/300 succeed and N=200 does not in the reference's published sweep)
                 out["whole_solve"] = whole_solve(sa, N)
-                out["whole_solves"] = [whole_solve(sa, n_) for n_ in (100, 300, 500)] + [out["whole_solve"]]
+                out["whole_solves"] = [whole_solve(sa, n_) for n_ in (100, 150, 200, 250, 300, 500)] + [out["whole_solve"]]
         if not args.no_cpu_baseline and world == 1 and args.workload != "gfold":
             out["cpu_baseline"] = cpu_baseline(N, dt)
             out["speedup_vs_cpu_baseline"] = out["value"] / (out["cpu_baseline"]["value"] * 1.0)

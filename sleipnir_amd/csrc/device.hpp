@@ -492,7 +492,9 @@ class DeviceNlp {
   // IpmHost::err_ahead speculatively; when the filter accepts that trial point the buffers change roles
   // (ipm_accept_lookahead: no launch) and the iteration is complete after ONE host round trip.
   void ipm_lookahead(double tau);             // step sizes, D_phi -> IpmHost::dir; the look-ahead iterate
-  void sweep_full_lookahead();                // the full tape at it, into the look-ahead V (sums ride in ipm_errors)
+  // the full tape at it, into the look-ahead V (sums ride in ipm_errors).  with_reduce: the sweep finishes its sums
+  // itself; skippable = false: not part of a chain ipm_lookahead flags as void (restoration.hpp makes its own iterate)
+  void sweep_full_lookahead(bool with_reduce = false, bool skippable = true);
   void ipm_accept_lookahead();                // the look-ahead iterate and its V become the current ones
   void ipm_soc_accumulate(double alpha, bool first, bool s_from_ci);
   void ipm_soc_rhs();                         // -> rhs
@@ -537,6 +539,9 @@ class DeviceNlp {
   }
   void state_changed_by_caller() { m_lhs_stale = m_rhs_stale = true; }
   double* d_trial_in() { return m_trial_in.p; }
+  double* d_s_ahead() { return m_s_ahead.p; }
+  double* d_y_ahead() { return m_y_ahead.p; }
+  double* d_z_ahead() { return m_z_ahead.p; }
   hipStream_t raw_stream() const { return m_stream.raw(); }
   double* d_ps() { return m_ps.p; }
   double* d_pz() { return m_pz.p; }

@@ -1242,10 +1242,12 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     int attempt = 0;
     bool chain_behind_last = false;
     double delta_of_last = 0.0;
+    // (the chain is the look-ahead iteration, as in ipm_core_resident: the whole iterate the full step would give, the full
+    // tape at it and its error norms — when the filter takes that point the iteration is complete on ONE round trip)
     auto chain = [&](double d) {
-      fr.expand(d, mu, tau, /*soc=*/false);
-      dev.sweep_values_trial();
-      fr.trial_metrics(-1.0, mu);
+      fr.expand(d, mu, tau, /*soc=*/false, /*ahead=*/true);
+      dev.sweep_full_lookahead(/*with_reduce=*/true, /*skippable=*/false);
+      fr.errors(false, mu, /*ahead=*/true);
     };
     hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
     hooks.after = [&](double d, double) {
@@ -1287,7 +1289,7 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     if (fr_debug) {
       std::fprintf(stderr, "fr: it %d mu %.3e delta %.1e gamma %.1e nfact %d | alpha_max %.3e alpha_z %.3e D_phi %.3e emin %.3e | cur f %.6e viol %.6e logsum %.6e | trial f %.6e viol %.6e logsum %.6e fin %g\n",
                    iterations, mu, delta, rep.gamma, sys.last_factorizations(), alpha_max, alpha_z, D_phi, H.dir.eliminated_min_pivot, cur.e.f, cur.e.viol,
-                   cur.e.logsum, H.trial.f, H.trial.viol, H.trial.logsum, H.trial.finite);
+                   cur.e.logsum, H.err_ahead.e.f, H.err_ahead.e.viol, H.err_ahead.e.logsum, H.err_ahead.e.finite);
       // residual of the FULL Newton-KKT system of the restoration problem for the direction on the device
       Vec Vd(st.nV), p(dim), ps0(std::max(1, m_i)), pz0(std::max(1, m_i)), dpn(M), psx(M), pzx(M), Xd(n + M), Sd(m_i + M), yd(m_e), Zd(m_i + M);
       dev.download_V(Vd.data());
@@ -1348,6 +1350,7 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     }
     double alpha_commit = alpha;
     bool have_trial = true;
+    bool trial_is_ahead = true, took_lookahead = false;
 
     while (!failed) {  // :512
       if (!have_trial) {
@@ -1359,7 +1362,9 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
       }
       have_trial = false;
       alpha_commit = alpha;
-      IpmTrialOut tr = H.trial;
+      const bool from_ahead = trial_is_ahead;
+      trial_is_ahead = false;
+      IpmTrialOut tr = from_ahead ? IpmTrialOut{H.err_ahead.e.f, H.err_ahead.e.viol, H.err_ahead.e.logsum, H.err_ahead.e.finite} : H.trial;
 
       if (tr.finite == 0.0) {
         alpha *= alpha_reduction_factor;
@@ -1367,7 +1372,10 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
         continue;
       }
       const FilterEntry trial_entry{tr.f - mu * tr.logsum, tr.viol};
-      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
+      if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) {
+        took_lookahead = from_ahead;
+        break;
+      }
 
       const double prev_violation = cur.e.viol;
       double next_violation = tr.viol;
@@ -1463,13 +1471,18 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
 
     t0 = clk::now();
     if (alpha == alpha_max) full_step_rejected_counter = 0;
-    fr.commit(alpha_commit, alpha_z, mu);  // :775-801
     host_current = false;
-    // AD refresh (:809-812) and every norm the next decisions need
-    dev.sweep_full();
-    fr.errors(false, mu);
-    fr.wait_published();
-    cur = H.err;
+    if (took_lookahead) {
+      fr.accept_lookahead();  // :775-801 happened in the look-ahead launch; the buffers change roles
+      cur = H.err_ahead;      // :809-812 and the norms: already there
+    } else {
+      fr.commit(alpha_commit, alpha_z, mu);  // :775-801
+      // AD refresh (:809-812) and every norm the next decisions need
+      dev.sweep_full();
+      fr.errors(false, mu);
+      fr.wait_published();
+      cur = H.err;
+    }
     rep.t_ad_refresh += since(t0);
 
     E_0 = E0_of(cur.e);

@@ -2310,13 +2310,13 @@ void DeviceNlp::ipm_lookahead(double tau) {
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
-void DeviceNlp::sweep_full_lookahead() {
+void DeviceNlp::sweep_full_lookahead(bool with_reduce, bool skippable) {
   m_in_override = m_trial_in.p;
   m_V_override = m_V_trial.p;
-  m_tape_reduce = false;  // the separable sums ride in ipm_errors(.., sums_ride, ahead)
+  m_tape_reduce = with_reduce;  // false: the separable sums ride in ipm_errors(.., sums_ride, ahead)
   // (the generated kernel leaves at once when the look-ahead launch flagged the attempt as rejected: `chain` with
   // n_workgroups = 0 is that flag, tape_jit.cpp)
-  if (m_full.n_bodies && m_ipm_alpha.p != nullptr) {
+  if (skippable && m_full.n_bodies && m_ipm_alpha.p != nullptr) {
     m_chain_args = ChainArgs{reinterpret_cast<unsigned int*>(m_ipm_alpha.p + 2), 0u, 0u};
     m_chain_args.skip_flag = true;
   }

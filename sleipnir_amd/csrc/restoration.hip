@@ -31,6 +31,8 @@ struct FrDevice::Args {
   // the rest of the restoration iterate and of its direction
   double *pn, *sx, *zx, *dpn, *psx, *pzx;
   double *soc_ce, *soc_c0, *soc_x;
+  // the look-ahead iterate (expand with ahead): s_0, y, z_0 beside the trial input, the rest of it
+  double *s0_t, *y_t, *z0_t, *pn_t, *sx_t, *zx_t;
 };
 
 namespace {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void fr_build_kernel(FrDevice::Args A, const i
 // restoration problem), the step sizes (fraction_to_the_boundary_rule.hpp:19-43) and the directional derivative
 // (:508-509) over ALL of them, the smallest eliminated pivot, and the first trial x.  One workgroup.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A, double delta, double mu, double tau, int soc,
+__global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A, double delta, double mu, double tau, int soc, int ahead,
                                                                 double* __restrict__ alpha_dev, FrDirOut* __restrict__ out) {
   __shared__ double scratch[17 * 4];
   const KktDev& K = A.K;
@@ -257,6 +259,36 @@ __global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A
   block_reduce<4, kIpmThreads>(acc, ops, scratch);
   const double alpha = acc[0];
   for (int j = tid; j < n; j += kIpmThreads) A.trial_in[j] = A.in[j] + alpha * A.p[j];
+  if (ahead) {  // interior_point.hpp:775-801 for the full step, into the look-ahead buffers (this thread wrote the rows it reads)
+    const double alpha_z = acc[1];
+    constexpr double kappa = 1e10;
+    auto clamp_z = [&](double zn, double sn) {
+      const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
+      return zn < lo ? lo : (zn > hi ? hi : zn);
+    };
+    const int M = 2 * me + 2 * mi;
+    for (int j = tid; j < me; j += kIpmThreads) {
+      const double v = A.y[j] + alpha_z * (-A.p[n + j]);
+      A.y_t[j] = v;
+      A.trial_in[n + j] = v;
+    }
+    for (int r = tid; r < mi; r += kIpmThreads) {
+      const double sn = A.s0[r] + alpha * A.ps0[r];
+      const double zn = clamp_z(A.z0[r] + alpha_z * A.pz0[r], sn);
+      A.s0_t[r] = sn;
+      A.z0_t[r] = zn;
+      A.trial_in[n + me + r] = zn;
+    }
+    // (rows e: the thread that wrote dpn / psx / pzx of row e is e's owner in the loops above — the same index map
+    // only for the equality half; the inequality half was written by thread r of rows 2 m_e + r: a barrier orders it)
+    __syncthreads();
+    for (int e = tid; e < M; e += kIpmThreads) {
+      A.pn_t[e] = A.pn[e] + alpha * A.dpn[e];
+      const double sn = A.sx[e] + alpha * A.psx[e];
+      A.sx_t[e] = sn;
+      A.zx_t[e] = clamp_z(A.zx[e] + alpha_z * A.pzx[e], sn);
+    }
+  }
   if (tid == 0) {
     alpha_dev[0] = acc[0];
     alpha_dev[1] = acc[1];
@@ -633,7 +665,7 @@ FrDevice::FrDevice(DeviceNlp& dev) : m_dev(dev) {
   m_g_outer.alloc(n1);
   m_s_outer.alloc(i1);
   m_scales.alloc(1 + e1 + i1);
-  for (DevBuf<double>* b : {&m_pn, &m_sx, &m_zx, &m_dpn, &m_psx, &m_pzx, &m_soc_x, &m_keep_dpn, &m_keep_psx, &m_keep_pzx}) {
+  for (DevBuf<double>* b : {&m_pn, &m_sx, &m_zx, &m_dpn, &m_psx, &m_pzx, &m_soc_x, &m_keep_dpn, &m_keep_psx, &m_keep_pzx, &m_pn_t, &m_sx_t, &m_zx_t}) {
     b->alloc(M1);
     b->zero();
   }
@@ -662,7 +694,7 @@ FrDevice::~FrDevice() {
   if (m_host) (void)hipHostFree(m_host);
 }
 
-FrDevice::Args FrDevice::args() const {
+FrDevice::Args FrDevice::args(bool ahead) const {
   Args a;
   const NlpStructure& s = m_dev.structure();
   a.n = m_n;
@@ -696,6 +728,22 @@ FrDevice::Args FrDevice::args() const {
   a.soc_ce = m_soc_ce.p;
   a.soc_c0 = m_soc_c0.p;
   a.soc_x = m_soc_x.p;
+  a.s0_t = m_dev.d_s_ahead();
+  a.y_t = m_dev.d_y_ahead();
+  a.z0_t = m_dev.d_z_ahead();
+  a.pn_t = m_pn_t.p;
+  a.sx_t = m_sx_t.p;
+  a.zx_t = m_zx_t.p;
+  if (ahead) {  // the kernels' view of the look-ahead iterate as THE iterate (errors)
+    a.V = m_dev.d_V_trial();
+    a.in = m_dev.d_trial_in();
+    a.s0 = a.s0_t;
+    a.y = a.y_t;
+    a.z0 = a.z0_t;
+    a.pn = a.pn_t;
+    a.sx = a.sx_t;
+    a.zx = a.zx_t;
+  }
   return a;
 }
 
@@ -727,10 +775,17 @@ void FrDevice::build(double delta, double mu, bool soc, bool rhs_only) {
   m_dev.system_written_by_caller(!rhs_only, true);
 }
 
-void FrDevice::expand(double delta, double mu, double tau, bool soc) {
-  hipLaunchKernelGGL(fr_expand_kernel, dim3(1), dim3(kIpmThreads), 0, m_dev.stream(), args(), delta, mu, tau, soc ? 1 : 0, m_alpha.p,
-                     &m_host->dir);
+void FrDevice::expand(double delta, double mu, double tau, bool soc, bool ahead) {
+  hipLaunchKernelGGL(fr_expand_kernel, dim3(1), dim3(kIpmThreads), 0, m_dev.stream(), args(), delta, mu, tau, soc ? 1 : 0, ahead ? 1 : 0,
+                     m_alpha.p, &m_host->dir);
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void FrDevice::accept_lookahead() {
+  m_dev.ipm_accept_lookahead();  // x | y | z_0, s_0, y, z_0 and V change roles with their look-ahead twins
+  m_pn.swap(m_pn_t);
+  m_sx.swap(m_sx_t);
+  m_zx.swap(m_zx_t);
 }
 
 void FrDevice::trial_point(double alpha) {
@@ -753,11 +808,11 @@ void FrDevice::commit(double alpha, double alpha_z, double mu) {
   m_dev.state_changed_by_caller();
 }
 
-void FrDevice::errors(bool check_all_V, double /*mu*/) {
+void FrDevice::errors(bool check_all_V, double /*mu*/, bool ahead) {
   const int work = std::max({m_n, m_me, m_mi, 1});
   const int blocks = grid_for(work, kFrErrThreads, 64);
-  hipLaunchKernelGGL(fr_errors_kernel, dim3(blocks), dim3(kFrErrThreads), 0, m_dev.stream(), args(), m_dev.structure().nV, check_all_V ? 1 : 0,
-                     m_mu_outer, m_partial.p, m_done.p, &m_host->err, m_seq_dev.p, m_h_seq);
+  hipLaunchKernelGGL(fr_errors_kernel, dim3(blocks), dim3(kFrErrThreads), 0, m_dev.stream(), args(ahead), m_dev.structure().nV,
+                     check_all_V ? 1 : 0, m_mu_outer, m_partial.p, m_done.p, ahead ? &m_host->err_ahead : &m_host->err, m_seq_dev.p, m_h_seq);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }

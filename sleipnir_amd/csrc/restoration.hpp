@@ -57,6 +57,7 @@ struct FrHost {
   FrDirOut dir;
   IpmTrialOut trial;
   FrErrOut err;
+  FrErrOut err_ahead;  // the same at the look-ahead iterate (expand(.., ahead))
 };
 
 class FrDevice {
@@ -78,11 +79,16 @@ class FrDevice {
   void build(double delta, double mu, bool soc, bool rhs_only);
   // p = (dx, w) of the outer system -> the whole direction, its step sizes and directional derivative (-> host().dir,
   // alpha on the device), the first trial x (the outer system's trial input)
-  void expand(double delta, double mu, double tau, bool soc);
+  // ahead: also the WHOLE iterate the full step (alpha_max, alpha_z) would give — x, s, y, z of all five blocks with the
+  // z reset of interior_point.hpp:797-801 — into the look-ahead buffers (the outer system's and this object's): the
+  // full tape and the error norms run on those next, and when the filter takes the point accept_lookahead() makes
+  // them the current ones (ipm_kernels.h: ipm_lookahead_kernel, the same arrangement for the outer iteration)
+  void expand(double delta, double mu, double tau, bool soc, bool ahead = false);
+  void accept_lookahead();
   void trial_point(double alpha);                // trial x = x + alpha dx
   void trial_metrics(double alpha, double mu);   // after a value sweep at the trial x; alpha < 0: the device's alpha_max
   void commit(double alpha, double alpha_z, double mu);
-  void errors(bool check_all_V, double mu);      // after a full sweep at x -> host().err
+  void errors(bool check_all_V, double mu, bool ahead = false);  // after a full sweep at x -> host().err (err_ahead)
   void soc_accumulate(double alpha, bool first);
   void save_direction();
   void restore_direction();
@@ -95,13 +101,14 @@ class FrDevice {
   struct Args;  // the kernels' view (restoration.hip)
 
  private:
-  Args args() const;
+  Args args(bool ahead = false) const;
   DeviceNlp& m_dev;
   int m_n = 0, m_me = 0, m_mi = 0, m_M = 0;
   DevBuf<int32_t> m_diag_of;  // per lhs entry: the row whose diagonal it is, or -1
   DevBuf<double> m_xr, m_w, m_g_outer, m_s_outer, m_scales;
   double m_mu_outer = 0.0;
   DevBuf<double> m_pn, m_sx, m_zx, m_dpn, m_psx, m_pzx;
+  DevBuf<double> m_pn_t, m_sx_t, m_zx_t;  // the look-ahead iterate's
   DevBuf<double> m_soc_ce, m_soc_c0, m_soc_x;
   DevBuf<double> m_keep_p, m_keep_ps0, m_keep_pz0, m_keep_dpn, m_keep_psx, m_keep_pzx;
   DevBuf<double> m_alpha, m_partial;

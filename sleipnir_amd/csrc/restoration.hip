@@ -195,17 +195,26 @@ __global__ __launch_bounds__(256) void fr_build_kernel(FrDevice::Args A, const i
 // restoration problem), the step sizes (fraction_to_the_boundary_rule.hpp:19-43) and the directional derivative
 // (:508-509) over ALL of them, the smallest eliminated pivot, and the first trial x.  One workgroup.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A, double delta, double mu, double tau, int soc, int ahead,
-                                                                double* __restrict__ alpha_dev, FrDirOut* __restrict__ out) {
-  __shared__ double scratch[17 * 4];
+constexpr int kFrExpandThreads = 256, kFrExpandMaxBlocks = 16;
+__global__ __launch_bounds__(kFrExpandThreads) void fr_expand_kernel(FrDevice::Args A, double delta, double mu, double tau, int soc, int ahead,
+                                                                     double* __restrict__ alpha_dev, FrDirOut* __restrict__ out,
+                                                                     double* __restrict__ partial, unsigned int* __restrict__ sync,
+                                                                     unsigned int generation) {
+  // A handful of workgroups, a row per lane (one workgroup walking 4000 rows of a dozen loads and six divisions each
+  // took 27 us): each reduces its share, the last one through folds the shares in workgroup order and raises the
+  // launch's generation number; everybody waits for that — the grid is small enough to be resident at once — and
+  // then moves ITS OWN rows on by the step sizes (nothing but the four scalars crosses workgroups).
+  __shared__ double scratch[(kFrExpandThreads / 64 + 1) * 4];
+  __shared__ int last;
   const KktDev& K = A.K;
-  const int tid = threadIdx.x, me = A.m_e, mi = A.m_i, n = A.n;
+  const int me = A.m_e, mi = A.m_i, n = A.n;
+  const int stride = gridDim.x * kFrExpandThreads, t0 = blockIdx.x * kFrExpandThreads + threadIdx.x;
   double acc[4] = {1.0, 1.0, 0.0, 1e300};  // alpha_max, alpha_z, D_phi, smallest eliminated pivot
   auto ftb = [&](double s, double ps, double z, double pz) {
     if (ps < 0.0) acc[0] = fmin(acc[0], -tau / ps * s);
     if (pz < 0.0) acc[1] = fmin(acc[1], -tau / pz * z);
   };
-  for (int j = tid; j < me; j += kIpmThreads) {
+  for (int j = t0; j < me; j += stride) {
     const FrEq e = fr_eq_row(A, j, mu, soc != 0);
     const double w = A.p[n + j];
     const double d1 = e.S1 + delta, d2 = e.S2 + delta;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A
     acc[2] -= mu * (e.i1 * ps1) + mu * (e.i2 * ps2);
     acc[3] = fmin(acc[3], fmin(d1, d2));
   }
-  for (int r = tid; r < mi; r += kIpmThreads) {
+  for (int r = t0; r < mi; r += stride) {
     double aidx = 0.0;
     for (int q = K.ai_rowptr[r]; q < K.ai_rowptr[r + 1]; ++q) aidx += A.V[K.ai_src[q]] * A.p[K.ai_col[q]];
     const FrIn f = fr_in_row(A, r, delta, mu, soc != 0);
@@ -254,48 +263,68 @@ __global__ __launch_bounds__(kIpmThreads) void fr_expand_kernel(FrDevice::Args A
     acc[2] -= mu * (f.i0 * ps0) + mu * (f.i3 * ps3) + mu * (f.i4 * ps4);
     acc[3] = fmin(acc[3], fmin(a, f.det / a));  // (the second pivot, b - sig^2 / a)
   }
-  for (int j = tid; j < n; j += kIpmThreads) acc[2] += (A.w[j] * (A.in[j] - A.xr[j])) * A.p[j];
+  for (int j = t0; j < n; j += stride) acc[2] += (A.w[j] * (A.in[j] - A.xr[j])) * A.p[j];
   const int ops[4] = {IPM_MIN, IPM_MIN, IPM_SUM, IPM_MIN};
-  block_reduce<4, kIpmThreads>(acc, ops, scratch);
-  const double alpha = acc[0];
-  for (int j = tid; j < n; j += kIpmThreads) A.trial_in[j] = A.in[j] + alpha * A.p[j];
-  if (ahead) {  // interior_point.hpp:775-801 for the full step, into the look-ahead buffers (this thread wrote the rows it reads)
-    const double alpha_z = acc[1];
+  block_reduce<4, kFrExpandThreads>(acc, ops, scratch);
+  if (threadIdx.x < 4) coherent_store(&partial[blockIdx.x * 4 + threadIdx.x], scratch[(kFrExpandThreads / 64) * 4 + threadIdx.x], true);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = old + 1 == gridDim.x;
+    if (last) __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last) {
+    if (threadIdx.x < 4) {
+      const int q = threadIdx.x;
+      double v = coherent_load(&partial[q], true);
+      for (unsigned int b = 1; b < gridDim.x; ++b) v = ipm_combine(q == 2 ? IPM_SUM : IPM_MIN, v, coherent_load(&partial[b * 4 + q], true));
+      coherent_store(&alpha_dev[q], v, true);
+      reinterpret_cast<double*>(out)[q] = v;  // alpha_max, alpha_z, D_phi, eliminated_min_pivot
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(sync + 16, generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    while (__hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != generation) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) break;  // (never expected: the launch ends with whatever step sizes it finds)
+    }
+  }
+  __syncthreads();
+  const double alpha = coherent_load(&alpha_dev[0], true), alpha_z = coherent_load(&alpha_dev[1], true);
+  for (int j = t0; j < n; j += stride) A.trial_in[j] = A.in[j] + alpha * A.p[j];
+  if (ahead) {  // interior_point.hpp:775-801 for the full step, into the look-ahead buffers: every lane the rows it expanded
     constexpr double kappa = 1e10;
     auto clamp_z = [&](double zn, double sn) {
       const double lo = 1.0 / kappa * mu / sn, hi = kappa * mu / sn;
       return zn < lo ? lo : (zn > hi ? hi : zn);
     };
-    const int M = 2 * me + 2 * mi;
-    for (int j = tid; j < me; j += kIpmThreads) {
+    auto bound_row = [&](int e) {
+      A.pn_t[e] = A.pn[e] + alpha * A.dpn[e];
+      const double sn = A.sx[e] + alpha * A.psx[e];
+      A.sx_t[e] = sn;
+      A.zx_t[e] = clamp_z(A.zx[e] + alpha_z * A.pzx[e], sn);
+    };
+    for (int j = t0; j < me; j += stride) {
       const double v = A.y[j] + alpha_z * (-A.p[n + j]);
       A.y_t[j] = v;
       A.trial_in[n + j] = v;
+      bound_row(j);
+      bound_row(me + j);
     }
-    for (int r = tid; r < mi; r += kIpmThreads) {
+    for (int r = t0; r < mi; r += stride) {
       const double sn = A.s0[r] + alpha * A.ps0[r];
       const double zn = clamp_z(A.z0[r] + alpha_z * A.pz0[r], sn);
       A.s0_t[r] = sn;
       A.z0_t[r] = zn;
       A.trial_in[n + me + r] = zn;
+      bound_row(2 * me + r);
+      bound_row(2 * me + mi + r);
     }
-    // (rows e: the thread that wrote dpn / psx / pzx of row e is e's owner in the loops above — the same index map
-    // only for the equality half; the inequality half was written by thread r of rows 2 m_e + r: a barrier orders it)
-    __syncthreads();
-    for (int e = tid; e < M; e += kIpmThreads) {
-      A.pn_t[e] = A.pn[e] + alpha * A.dpn[e];
-      const double sn = A.sx[e] + alpha * A.psx[e];
-      A.sx_t[e] = sn;
-      A.zx_t[e] = clamp_z(A.zx[e] + alpha_z * A.pzx[e], sn);
-    }
-  }
-  if (tid == 0) {
-    alpha_dev[0] = acc[0];
-    alpha_dev[1] = acc[1];
-    out->alpha_max = acc[0];
-    out->alpha_z = acc[1];
-    out->D_phi = acc[2];
-    out->eliminated_min_pivot = acc[3];
   }
 }
 
@@ -678,6 +707,8 @@ FrDevice::FrDevice(DeviceNlp& dev) : m_dev(dev) {
   m_alpha.zero();
   m_partial.alloc(static_cast<size_t>(64) * fr_err::NQ);
   m_done.upload(std::vector<unsigned int>(1, 0u));
+  m_expand_partial.alloc(static_cast<size_t>(kFrExpandMaxBlocks) * 4);
+  m_expand_sync.upload(std::vector<unsigned int>(32, 0u));
   m_seq_dev.alloc(1);
   m_seq_dev.zero();
   unsigned long long* seq = nullptr;
@@ -776,8 +807,10 @@ void FrDevice::build(double delta, double mu, bool soc, bool rhs_only) {
 }
 
 void FrDevice::expand(double delta, double mu, double tau, bool soc, bool ahead) {
-  hipLaunchKernelGGL(fr_expand_kernel, dim3(1), dim3(kIpmThreads), 0, m_dev.stream(), args(), delta, mu, tau, soc ? 1 : 0, ahead ? 1 : 0,
-                     m_alpha.p, &m_host->dir);
+  const int work = std::max({m_n, m_me, m_mi, 1});
+  const int blocks = grid_for(work, kFrExpandThreads, kFrExpandMaxBlocks);
+  hipLaunchKernelGGL(fr_expand_kernel, dim3(blocks), dim3(kFrExpandThreads), 0, m_dev.stream(), args(), delta, mu, tau, soc ? 1 : 0,
+                     ahead ? 1 : 0, m_alpha.p, &m_host->dir, m_expand_partial.p, m_expand_sync.p, ++m_expand_generation);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 

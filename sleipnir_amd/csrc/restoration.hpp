@@ -113,6 +113,9 @@ class FrDevice {
   DevBuf<double> m_keep_p, m_keep_ps0, m_keep_pz0, m_keep_dpn, m_keep_psx, m_keep_pzx;
   DevBuf<double> m_alpha, m_partial;
   DevBuf<unsigned int> m_done;
+  DevBuf<double> m_expand_partial;       // expand(): the workgroups' shares of the four reductions
+  DevBuf<unsigned int> m_expand_sync;    // ... workgroups through (word 0), the generation whose fold is done (word 16)
+  unsigned int m_expand_generation = 0;
   DevBuf<unsigned long long> m_seq_dev;
   volatile unsigned long long* m_h_seq = nullptr;
   unsigned long long m_seq_expected = 0;

@@ -20,17 +20,26 @@ namespace slpx {
 // variables: single shooting), or SLPX_DENSE=1 asks for it — the dense one: the reference's dense branch
 // (util/dense_regularized_ldlt.hpp, chosen there by density: interior_point.hpp:340-352) instead of a refusal.
 static LdltPlan plan_or_dense(const CscPattern& lhs, int n_dec, const LdltOptions& lopt, const std::vector<int32_t>* user_perm,
-                              const std::vector<uint8_t>* diag_has_source) {
+                              const std::vector<uint8_t>* diag_has_source, int batch) {
   constexpr int kDenseMaxOrder = 8192;  // 512 MB of factors per problem, two columns in LDS
+  // (and the whole batch's factors, batch x n x n doubles, within reach of one device: 64 GB)
+  auto dense_plan = [&] {
+    const double bytes = 8.0 * static_cast<double>(std::max(1, batch)) * lhs.cols * lhs.cols;
+    if (bytes > 64.0 * (1u << 30))
+      throw std::runtime_error("slpx: the dense factorization of " + std::to_string(batch) + " systems of order " + std::to_string(lhs.cols) +
+                               " needs " + std::to_string(static_cast<long long>(bytes / (1u << 30))) +
+                               " GB of factors; SLPX_DENSE=0 keeps the sparse plan (or refuses the model), a smaller batch fits");
+    return build_dense_ldlt_plan(lhs, n_dec);
+  };
   const char* env = std::getenv("SLPX_DENSE");
-  if (env != nullptr && env[0] == '1' && lhs.cols <= kDenseMaxOrder) return build_dense_ldlt_plan(lhs, n_dec);
+  if (env != nullptr && env[0] == '1' && lhs.cols <= kDenseMaxOrder) return dense_plan();
   try {
     return build_ldlt_plan(lhs, n_dec, lopt, user_perm, diag_has_source);
   } catch (const std::runtime_error& e) {
     if (!ldlt_plan_error_is_too_big(e) || lhs.cols > kDenseMaxOrder || (env != nullptr && env[0] == '0')) throw;
     if (std::getenv("SLPX_LDLT_VERBOSE"))
       std::fprintf(stderr, "ldlt: %s — the system of order %d is factored as a dense matrix\n", e.what(), lhs.cols);
-    return build_dense_ldlt_plan(lhs, n_dec);
+    return dense_plan();
   }
 }
 
@@ -106,7 +115,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
     // Both rules are applied inside the build, after its first task partition (LdltOptions::single_problem_task_rules).
     lopt.single_problem_task_rules = opt.batch == 1 && std::getenv("SLPX_TASK_ENTRIES") == nullptr;
-    m_l = plan_or_dense(m_k.lhs, st.n, lopt, user_perm, &diag_has_source);
+    m_l = plan_or_dense(m_k.lhs, st.n, lopt, user_perm, &diag_has_source, opt.batch);
     if (lopt.multifrontal && !m_l.mf && !m_l.dense) {
       // the fronts were not built (a limit of their addressing, or a refused plan): the pair-list kernels run this
       // system, with THEIR tuning — chains from four columns, exact structures — not the fronts'
@@ -114,7 +123,7 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
       pair.task_entries = lopt.task_entries;
       pair.supernodal = lopt.supernodal;
       pair.single_problem_task_rules = false;
-      m_l = plan_or_dense(m_k.lhs, st.n, pair, user_perm, &diag_has_source);
+      m_l = plan_or_dense(m_k.lhs, st.n, pair, user_perm, &diag_has_source, opt.batch);
     }
   };
   m_s = build_nlp_structure(g, x, f, c_e, c_i, opt.tape, plan_linear_algebra);
@@ -204,7 +213,7 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
   if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
-  m_l = plan_or_dense(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source);
+  m_l = plan_or_dense(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source, m_opt.batch);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));
   reset_regularization();

@@ -90,6 +90,15 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
     int32_t operator[](NodeId n) const { return n <= last ? v[n] : -1; }
   } col_of{visit.col, last_wrt};
   for (size_t c = 0; c < wrt.size(); ++c) visit.col[wrt[c]] = static_cast<int32_t>(c);
+  // (blank again however the function is left: a walk that throws on a pool thread must not leave the next model
+  // built on this thread with this one's columns)
+  struct BlankCols {
+    std::vector<int32_t>& col;
+    const std::vector<NodeId>& wrt;
+    ~BlankCols() {
+      for (NodeId w : wrt) col[w] = -1;
+    }
+  } blank_cols{visit.col, wrt};
   // the rows in chunks on the setup threads (a walk only reads the graph; every chunk has its own marks): the
   // entries of a chunk in row order, the chunks one after the other — the order a single thread finds them in
   struct Chunk {
@@ -120,8 +129,17 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
     Chunk& ch = chunks[ci];
     // marks of this THREAD (whichever chunks it gets): stamps only grow, so marks left by earlier rows, matrices
     // or graphs never match
+    // (a thread keeps its marks between rows, matrices and models — up to a few million nodes; a graph beyond that
+    // gets them for the call only: sixteen pool threads holding marks of a six-million-node graph for the life of the
+    // process were hundreds of MB)
     static thread_local std::vector<int32_t> seen;
     static thread_local int32_t stamp = 0;
+    struct ReleaseBig {
+      std::vector<int32_t>& v;
+      ~ReleaseBig() {
+        if (v.size() > (4u << 20)) std::vector<int32_t>().swap(v);
+      }
+    } release_big{seen};
     std::vector<NodeId> stack;
     std::vector<std::pair<int32_t, NodeId>> outs;
     size_t lin = static_cast<size_t>(std::lower_bound(linear_row_index.begin(), linear_row_index.end(), static_cast<int32_t>(r_begin)) - linear_row_index.begin());
@@ -163,7 +181,6 @@ MatrixBuild build_matrix(Graph& g, const std::vector<NodeId>& rows, const std::v
       }
     }
   });
-  for (size_t c = 0; c < wrt.size(); ++c) visit.col[wrt[c]] = -1;
   // CSC order (setFromTriplets: column-major, rows ascending): the entries come row by row, so a stable
   // counting sort by column leaves the rows of a column ascending
   mb.pat.rows = nrows;

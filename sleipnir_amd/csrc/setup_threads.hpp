@@ -54,9 +54,14 @@ class SetupPool {
     }
     m_wake.notify_all();
     work(r);
-    std::unique_lock<std::mutex> lk(m_mutex);
-    m_done.wait(lk, [&] { return r.pending == 0 && r.users == 0; });
-    m_run = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(m_mutex);
+      m_done.wait(lk, [&] { return r.pending == 0 && r.users == 0; });
+      m_run = nullptr;
+    }
+    // (a job that threw — bad_alloc of a vector sized to the graph — was counted as done by whoever ran it: every
+    // worker has let go of `r` by now; the first exception goes to the caller)
+    if (r.failure) std::rethrow_exception(r.failure);
   }
 
  private:
@@ -65,6 +70,7 @@ class SetupPool {
     const std::function<void(unsigned)>* job = nullptr;
     unsigned count = 0, pending = 0, users = 0;  // pending, users: under m_mutex
     std::atomic<unsigned> next{0};
+    std::exception_ptr failure;  // the first exception a job threw (under m_mutex)
   };
   SetupPool() {
     unsigned n = std::thread::hardware_concurrency();
@@ -84,16 +90,20 @@ class SetupPool {
     for (auto& t : m_workers) t.join();
   }
   void work(Run& r) {
-    const bool was = t_inside;
-    t_inside = true;
+    InlineScope inside;  // (restored however the loop is left)
     for (;;) {
       const unsigned k = r.next.fetch_add(1, std::memory_order_relaxed);
       if (k >= r.count) break;
-      (*r.job)(k);
+      std::exception_ptr thrown;
+      try {
+        (*r.job)(k);
+      } catch (...) {
+        thrown = std::current_exception();
+      }
       std::lock_guard<std::mutex> lk(m_mutex);
+      if (thrown && !r.failure) r.failure = thrown;
       if (--r.pending == 0) m_done.notify_all();
     }
-    t_inside = was;
   }
   void loop() {
     unsigned seen = 0;

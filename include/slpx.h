@@ -207,8 +207,10 @@ enum {
   /* since ABI version 5: the multifrontal plan — 1 if the single-problem step runs on fronts, their
    * number, and how many of them send their update block through the matrix cores */
   SLPX_INFO_LDLT_MULTIFRONTAL, SLPX_INFO_LDLT_FRONTS, SLPX_INFO_LDLT_MFMA_FRONTS,
-  /* since ABI version 6: 1 if the system is factored as a dense matrix (the reference's dense branch,
-   * util/dense_regularized_ldlt.hpp: where a column of L does not fit a task of the sparse plan) */
+  /* since ABI version 6: non-zero if the system is factored as a dense matrix (the reference's dense branch,
+   * util/dense_regularized_ldlt.hpp).  2: chosen by the reference's own rule (interior_point.hpp:340-352: the lower
+   * triangle fills a quarter of the system or more) and factored with Eigen::LDLT's diagonal pivoting; 1: the plain
+   * dense kernel, where a column of L does not fit a task of the sparse plan (or SLPX_DENSE=1) */
   SLPX_INFO_LDLT_DENSE,
   SLPX_INFO_COUNT
 };

@@ -351,7 +351,7 @@ class RegularizedLDLT {
     compute_policy(lhs);
     // ORC_TRACE_FACTORIZATIONS=1: attempts per call and the regularization taken, one line each (how often
     // a step needs a second attempt is what the product's twin attempt is sized on)
-    static const bool trace = std::getenv("ORC_TRACE_FACTORIZATIONS") != nullptr;
+    const bool trace = std::getenv("ORC_TRACE_FACTORIZATIONS") != nullptr;  // (read every time: a test turns it on mid-process)
     if (trace) std::fprintf(stderr, "orc attempts %d delta %.3e gamma %.3e\n", m_factorizations, m_prev_delta, m_prev_gamma);
     return *this;
   }

@@ -334,7 +334,7 @@ int slpx_system_info(const slpx_system* sc, int64_t* out) {
     out[SLPX_INFO_LDLT_MULTIFRONTAL] = l.mf ? 1 : 0;
     out[SLPX_INFO_LDLT_FRONTS] = l.mf ? static_cast<int64_t>(l.mf_fronts.size()) - 16 : 0;  // (16 padding records)
     out[SLPX_INFO_LDLT_MFMA_FRONTS] = l.mf ? l.mf_n_mfma : 0;
-    out[SLPX_INFO_LDLT_DENSE] = l.dense ? 1 : 0;
+    out[SLPX_INFO_LDLT_DENSE] = l.dense ? (l.dense_pivoted ? 2 : 1) : 0;
   });
 }
 

@@ -587,7 +587,8 @@ class DeviceNlp {
   DevBuf<LdltSn> m_sn_desc;
   DevBuf<int32_t> m_lhs_colptr, m_lhs_rowidx, m_lhs_rowptr, m_lhs_rowent, m_lhs_rowcol;  // refine_solution (uploaded on first use)
   // the dense branch (LdltPlan::dense, ldlt_dense_kernels.h): the factors of every problem as a dim x dim matrix
-  bool m_dense = false;
+  bool m_dense = false, m_dense_pivoted = false;
+  DevBuf<int32_t> m_dense_trans;  // the transpositions of the pivoted factorization (LdltPlan::dense_pivoted)
   DevBuf<double> m_dense_A;
   DevBuf<int32_t> m_dense_colptr, m_dense_rowidx;
   uint32_t m_dense_lds = 0;

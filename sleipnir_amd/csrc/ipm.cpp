@@ -556,7 +556,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
     }
     if (options.diagnostics) {  // one line per iteration (print_iteration_diagnostics.hpp, condensed)
       std::fprintf(stderr,
-                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  "
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  "
                    "alpha_z %.2e  nfact %d\n",
                    iterations, E_0, f, violation(c_e, c_i, s), mu, rep.delta, rep.gamma, alpha, alpha_z,
                    sys.last_factorizations());
@@ -917,7 +917,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     }
     if (options.diagnostics) {
       std::fprintf(stderr,
-                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  "
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  "
                    "alpha_z %.2e  nfact %d\n",
                    iterations, E_0, cur.f, cur.viol, mu, rep.delta, rep.gamma, alpha, alpha_z,
                    sys.last_factorizations());
@@ -1495,7 +1495,7 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     }
     if (options.diagnostics) {
       std::fprintf(stderr,
-                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.1e  gamma %.1e  alpha %.2e  alpha_z %.2e  nfact %d  (restoration)\n",
+                   "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  alpha_z %.2e  nfact %d  (restoration)\n",
                    iterations, E_0, cur.e.f, cur.e.viol, mu, rep.delta, rep.gamma, alpha, alpha_z, sys.last_factorizations());
     }
     ++iterations;
@@ -1819,6 +1819,9 @@ ExitStatus sqp_core(NewtonSystem& sys, const Vec& scales, const std::vector<Iter
     std::copy(cur.c_e(), cur.c_e() + m_e, c_e.begin());
     E_0 = E0_of(g, c_e, y);
     rep.final_error = E_0;
+    if (options.diagnostics)
+      std::fprintf(stderr, "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  alpha_z %.2e  nfact %d  (sqp)\n",
+                   iterations, E_0, f, norm_1(c_e.data(), m_e), 0.0, rep.delta, rep.gamma, alpha, alpha, sys.last_factorizations());
     ++iterations;
     if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
     if (since(solve_start) > options.timeout) return ExitStatus::TIMEOUT;
@@ -1922,6 +1925,9 @@ ExitStatus newton_core(NewtonSystem& sys, const Vec& scales, const std::vector<I
     g = cur.g_dense();
     E_0 = E0_of(g);
     rep.final_error = E_0;
+    if (options.diagnostics)
+      std::fprintf(stderr, "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  alpha_z %.2e  nfact %d  (newton)\n",
+                   iterations, E_0, f, 0.0, 0.0, rep.delta, 0.0, alpha, alpha, sys.last_factorizations());
     ++iterations;
     if (iterations >= options.max_iterations) return ExitStatus::MAX_ITERATIONS_EXCEEDED;
     if (since(solve_start) > options.timeout) return ExitStatus::TIMEOUT;

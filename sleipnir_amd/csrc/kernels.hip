@@ -725,7 +725,13 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
     m_dense_A.alloc(B * static_cast<size_t>(l.n) * l.n);
     m_dense_colptr.upload(k.lhs.colptr);
     m_dense_rowidx.upload(k.lhs.rowidx);
-    m_dense_lds = 16u * static_cast<uint32_t>(l.n) + 64u;
+    m_dense_lds = 16u * static_cast<uint32_t>(l.n) + 320u;
+    m_dense_pivoted = l.dense_pivoted;
+    if (m_dense_pivoted) {
+      m_dense_trans.alloc(B * static_cast<size_t>(l.n));
+      m_dense_trans.zero();
+      SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_dense_pivoted_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     if (m_dense_lds > 160u * 1024u) throw std::runtime_error("slpx: the dense factorization holds two columns in LDS: at most 10 000 rows");
     SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_dense_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_dense_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1718,6 +1724,10 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
     reg = m_reg_dev.p;
   }
   if (m_dense) {
+    if (m_dense_pivoted)
+      hipLaunchKernelGGL(ldlt_dense_pivoted_factor_kernel, dim3(m_batch), dim3(kDenseThreads), m_dense_lds, stream, l.n, l.n_dec,
+                         m_dense_colptr.p, m_dense_rowidx.p, m_kdev.nnz_lhs, m_lhs.p, reg, m_dense_A.p, m_dense_trans.p, m_D.p, cur, next);
+    else
     hipLaunchKernelGGL(ldlt_dense_factor_kernel, dim3(m_batch), dim3(kDenseThreads), m_dense_lds, stream, l.n, l.n_dec,
                        m_dense_colptr.p, m_dense_rowidx.p, m_kdev.nnz_lhs, m_lhs.p, reg, m_dense_A.p, m_D.p, m_Lx.p, lxs, cur, next);
     SLPX_HIP_CHECK(hipGetLastError());
@@ -2080,7 +2090,7 @@ void DeviceNlp::solve_after_factor_impl(const LdltStats* publish) {
   if (m_dense) {  // (nothing rides in a dense factorization: forward and backward substitution from the rhs in memory)
     if (m_rhs_stale) build_rhs();
     hipLaunchKernelGGL(ldlt_dense_solve_kernel, dim3(m_batch), dim3(kDenseThreads), 8u * static_cast<uint32_t>(l.n) + 16u, m_stream, l.n,
-                       m_dense_A.p, m_rhs.p, m_p.p);
+                       m_dense_A.p, m_rhs.p, m_p.p, m_dense_pivoted ? m_dense_trans.p : nullptr);
     SLPX_HIP_CHECK(hipGetLastError());
     return;
   }

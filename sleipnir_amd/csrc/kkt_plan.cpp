@@ -75,6 +75,11 @@ KktPlan build_kkt_plan(const NlpStructure& s) {
         prv.push_back(r);
       }
   }
+  {
+    std::vector<uint64_t> pk(pkey);
+    std::sort(pk.begin(), pk.end());
+    k.nnz_AiTAi_lower = static_cast<int>(std::unique(pk.begin(), pk.end()) - pk.begin());
+  }
   // A_e block below (append_as_triplets.hpp:38-46, row offset n)
   for (int c = 0; c < n; ++c)
     for (int p = s.Ae.colptr[c]; p < s.Ae.colptr[c + 1]; ++p) {

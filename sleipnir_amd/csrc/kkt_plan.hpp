@@ -46,6 +46,12 @@ struct KktPlan {
   // bytes one assemble / rhs pass must move (SURVEY.md §8d formulas, exact counts)
   int64_t assemble_bytes = 0, rhs_bytes = 0;
   int nnz_H_union = 0;
+  int nnz_AiTAi_lower = 0;  // entries of tril(A_i^T A_i)
+  // the reference's choice between its sparse and its dense LDLT (interior_point.hpp:340-352, sqp.hpp:238-240,
+  // newton.hpp:133-135): sparse iff nnz(H) + nnz(tril(A_i^T A_i)) + nnz(A_e) < 0.25 (n + m_e)^2
+  bool reference_takes_dense(int nnz_Ae) const {
+    return !(static_cast<double>(nnz_H_union) + nnz_AiTAi_lower + nnz_Ae < 0.25 * static_cast<double>(dim) * static_cast<double>(dim));
+  }
 };
 
 KktPlan build_kkt_plan(const NlpStructure& s);

@@ -196,6 +196,10 @@ struct LdltPlan {
   // memory (ldlt_dense_kernels.h), the reference's dense branch (util/dense_regularized_ldlt.hpp:59-136,
   // chosen there by density, interior_point.hpp:340-352; here also whenever a column of L does not fit a task)
   bool dense = false;
+  // ... chosen by the reference's own rule (interior_point.hpp:340-352: the lower triangle fills a quarter of the system
+  // or more) and factored the way the reference factors it there: Eigen::LDLT's diagonal pivoting
+  // (ldlt_dense_pivoted_factor_kernel).  false with `dense`: the plain dense kernel (a system too big for the sparse plan)
+  bool dense_pivoted = false;
 
   // traffic model: factor = 12k + 16ℓ, solve = 32ℓ + 16 n
   int64_t factor_bytes = 0, solve_bytes = 0;

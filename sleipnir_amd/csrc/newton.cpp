@@ -115,6 +115,19 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // cart-pole N=5000 58.6 us against 62.1 without the rule and 96 (not resident: two launches) with it everywhere)
     // Both rules are applied inside the build, after its first task partition (LdltOptions::single_problem_task_rules).
     lopt.single_problem_task_rules = opt.batch == 1 && std::getenv("SLPX_TASK_ENTRIES") == nullptr;
+    // The reference's own choice (interior_point.hpp:340-352, sqp.hpp:238-240, newton.hpp:133-135): a system whose lower
+    // triangle fills a quarter of it or more — the small problems of its unit tests, single shooting — is factored
+    // dense, with Eigen::LDLT's diagonal pivoting (ldlt_dense_pivoted_factor_kernel).  SLPX_DENSE=0: the sparse plan
+    // whatever the fill (the sparse kernels do not pivot: D, and with it the regularization the policy settles on, may
+    // then differ from the reference's on such a system); a caller's elimination order asks for the sparse plan too.
+    {
+      const char* denv = std::getenv("SLPX_DENSE");
+      if (m_k.reference_takes_dense(st.Ae.nnz()) && user_perm == nullptr && (denv == nullptr || denv[0] != '0') && m_k.dim <= 2048) {
+        m_l = build_dense_ldlt_plan(m_k.lhs, st.n);
+        m_l.dense_pivoted = denv == nullptr || denv[0] != '1';  // (SLPX_DENSE=1 keeps meaning the plain dense kernel)
+        return;
+      }
+    }
     m_l = plan_or_dense(m_k.lhs, st.n, lopt, user_perm, &diag_has_source, opt.batch);
     if (lopt.multifrontal && !m_l.mf && !m_l.dense) {
       // the fronts were not built (a limit of their addressing, or a refused plan): the pair-list kernels run this

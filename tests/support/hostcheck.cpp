@@ -32,6 +32,7 @@ struct hc_handle {
   std::vector<double> scales, in_scale, V, lhs, rhs, Lx, D, contrib, scontrib, zv, xg, p, ps, pz;
   std::vector<double> z_factor;  // z left behind by the factorization (rhs carried as a row)
   std::vector<double> dense_A;   // the dense plan's factors (column-major, L below the diagonal, D on it)
+  std::vector<int32_t> dense_trans;  // ... the pivoted one's transpositions
   // multifrontal plan (SLPX_LDLT_MF=1): the update slots between tasks, and every task's first
   // 64 KB of LDS as the factorization leaves it (the in-place backward solve reads U and 1/d there)
   std::vector<double> mf_contrib;
@@ -160,7 +161,10 @@ static void hc_build(hc_handle* h, slpx_problem* p, const int32_t* perm, int32_t
   if (const char* env = std::getenv("SLPX_MFMA_MIN_ENTRIES")) lopt.mfma_min_entries = static_cast<uint32_t>(std::atoi(env));
   // (the product's rule, newton.cpp: plan_or_dense)
   const char* dense_env = std::getenv("SLPX_DENSE");
-  if (dense_env != nullptr && dense_env[0] == '1') {
+  if (h->k.reference_takes_dense(h->s.Ae.nnz()) && up.empty() && (dense_env == nullptr || dense_env[0] != '0') && h->k.dim <= 2048) {
+    h->l = build_dense_ldlt_plan(h->k.lhs, h->s.n);
+    h->l.dense_pivoted = dense_env == nullptr || dense_env[0] != '1';
+  } else if (dense_env != nullptr && dense_env[0] == '1') {
     h->l = build_dense_ldlt_plan(h->k.lhs, h->s.n);
   } else {
     try {
@@ -384,7 +388,7 @@ uint64_t hash_tape(const TapeProgram& P) {
 void hash_csc(PlanHash& H, const CscPattern& c) { H.pod(c.rows); H.pod(c.cols); H.vec(c.colptr); H.vec(c.rowidx); }
 }  // namespace
 
-extern "C" int32_t hc_is_dense(hc_handle* h) { return h->l.dense ? 1 : 0; }
+extern "C" int32_t hc_is_dense(hc_handle* h) { return h->l.dense ? (h->l.dense_pivoted ? 2 : 1) : 0; }
 
 extern "C" void hc_plan_hash(hc_handle* h, uint64_t* out) {
   {
@@ -750,10 +754,98 @@ static void hc_factor_dense(hc_handle* h, double delta, double gamma) {
     for (int i = k + 1; i < dim; ++i) h->Lx[L.Lp[k] + (i - k - 1)] = A[static_cast<size_t>(k) * dim + i];
   }
 }
+// ldlt_dense_pivoted_factor_kernel on the host: Eigen::LDLT's unblocked kernel (diagonal pivoting on the not yet updated
+// diagonal, left-looking, sums in column order, no fused multiply-adds)
+static void hc_factor_dense_pivoted(hc_handle* h, double delta, double gamma) {
+  const LdltPlan& L = h->l;
+  const KktPlan& K = h->k;
+  const int dim = L.n;
+  std::vector<double>& A = h->dense_A;
+  A.assign(static_cast<size_t>(dim) * dim, 0.0);
+  h->dense_trans.assign(dim, 0);
+  auto at = [&](int r, int c) -> double& { return A[static_cast<size_t>(c) * dim + r]; };
+  for (int c = 0; c < dim; ++c) {
+    for (int p = K.lhs.colptr[c]; p < K.lhs.colptr[c + 1]; ++p) at(K.lhs.rowidx[p], c) += h->lhs[p];
+    at(c, c) += c < L.n_dec ? delta : -gamma;
+  }
+  bool ret = true, found_zero = false;
+  std::vector<double> temp(dim);
+  for (int k = 0; k < dim; ++k) {
+    int big = k;
+    double bigv = std::fabs(at(k, k));
+    for (int j = k + 1; j < dim; ++j)
+      if (std::fabs(at(j, j)) > bigv) {
+        bigv = std::fabs(at(j, j));
+        big = j;
+      }
+    h->dense_trans[k] = big;
+    if (big != k) {
+      for (int c = 0; c < k; ++c) std::swap(at(k, c), at(big, c));
+      for (int r = big + 1; r < dim; ++r) std::swap(at(r, k), at(r, big));
+      for (int i = k + 1; i < big; ++i) std::swap(at(i, k), at(big, i));
+      std::swap(at(k, k), at(big, big));
+    }
+    const int rs = dim - k - 1;
+    if (k > 0) {
+      for (int c = 0; c < k; ++c) temp[c] = at(c, c) * at(k, c);
+      for (int r = -1; r < rs; ++r) {
+        const int row = r < 0 ? k : k + 1 + r;
+        volatile double sum = 0.0;  // (no contraction of the products into the sum)
+        for (int c = 0; c < k; ++c) {
+          const volatile double prod = at(row, c) * temp[c];
+          sum = sum + prod;
+        }
+        at(row, k) -= sum;
+      }
+    }
+    const double akk = at(k, k);
+    const bool valid = std::fabs(akk) > 0.0;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < dim; ++j) {
+        h->dense_trans[j] = j;
+        for (int r = j + 1; r < dim; ++r) ret = ret && at(r, j) == 0.0;
+      }
+      break;
+    }
+    if (rs > 0 && valid) {
+      for (int r = 0; r < rs; ++r) at(k + 1 + r, k) /= akk;
+    } else if (rs > 0) {
+      for (int r = 0; r < rs; ++r) ret = ret && at(k + 1 + r, k) == 0.0;
+    }
+    if (found_zero && valid) ret = false;
+    else if (!valid) found_zero = true;
+  }
+  for (int k = 0; k < dim; ++k) {
+    const double u = at(k, k);
+    h->D[k] = u;
+    const double eps = 2.220446049250313e-16;
+    if (u > eps) ++h->stats[0];
+    else if (u < -eps) ++h->stats[1];
+    else ++h->stats[2];
+    if (u != 0.0 && std::isfinite(u)) h->min_abs = std::min(h->min_abs, std::fabs(u));
+    if (!std::isfinite(u)) ret = false;
+  }
+  if (!ret) ++h->stats[3];
+}
 static void hc_solve_dense(hc_handle* h, double* p_out) {
   const int dim = h->l.n;
   const std::vector<double>& A = h->dense_A;
   std::vector<double> x(h->rhs.begin(), h->rhs.begin() + dim);
+  if (h->l.dense_pivoted) {
+    for (int k = 0; k < dim; ++k) std::swap(x[k], x[h->dense_trans[k]]);
+    for (int k = 0; k < dim; ++k)
+      for (int i = k + 1; i < dim; ++i) x[i] = std::fma(-A[static_cast<size_t>(k) * dim + i], x[k], x[i]);
+    for (int i = 0; i < dim; ++i) {
+      const double d = A[static_cast<size_t>(i) * dim + i];
+      x[i] = std::fabs(d) > 2.2250738585072014e-308 ? x[i] / d : 0.0;
+    }
+    for (int k = dim - 1; k >= 0; --k)
+      for (int i = 0; i < k; ++i) x[i] = std::fma(-A[static_cast<size_t>(i) * dim + k], x[k], x[i]);
+    for (int k = dim - 1; k >= 0; --k) std::swap(x[k], x[h->dense_trans[k]]);
+    h->p = x;
+    if (p_out) std::copy(h->p.begin(), h->p.end(), p_out);
+    return;
+  }
   for (int k = 0; k < dim; ++k)
     for (int i = k + 1; i < dim; ++i) x[i] = std::fma(-A[static_cast<size_t>(k) * dim + i], x[k], x[i]);
   for (int i = 0; i < dim; ++i) x[i] = x[i] / A[static_cast<size_t>(i) * dim + i];
@@ -768,7 +860,8 @@ void hc_factor(hc_handle* h, double delta, double gamma, double* D_out, double* 
   std::memset(h->stats, 0, sizeof(h->stats));
   h->min_abs = INFINITY;
   if (L.dense || L.mf) {
-    if (L.dense) hc_factor_dense(h, delta, gamma);
+    if (L.dense && L.dense_pivoted) hc_factor_dense_pivoted(h, delta, gamma);
+    else if (L.dense) hc_factor_dense(h, delta, gamma);
     else hc_factor_mf(h, delta, gamma);
     if (D_out) std::copy(h->D.begin(), h->D.end(), D_out);
     if (stats_out) {

@@ -99,6 +99,7 @@ class HostCheck:
         self.info = {k: int(out[i]) for i, k in enumerate(INFO_KEYS)}
         self.n, self.m_e, self.m_i = self.info["n"], self.info["m_e"], self.info["m_i"]
         self.dense = bool(lib().hc_is_dense(self._h))
+        self.info["ldlt_dense_pivoted"] = int(lib().hc_is_dense(self._h) == 2)
 
     def close(self):
         if self._h:

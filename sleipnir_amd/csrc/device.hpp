@@ -472,6 +472,10 @@ class DeviceNlp {
   // adopt_twin() makes the second attempt's factor, direction and counters the system's.
   bool twin_available();
   bool factor_solve_publish_twin(double delta0, double gamma0, double delta1, double gamma1, int mode);
+  // ... for a caller that wrote BOTH attempts' systems itself (restoration.hpp): the first in lhs_raw() / rhs_raw(), the
+  // second in (lhs2, rhs2)
+  bool factor_solve_publish_twin_written(double delta0, double gamma0, double delta1, double gamma1, int mode, const double* lhs2,
+                                         const double* rhs2);
   LdltStats read_twin_stats() const { return m_h_stats[1]; }
   void adopt_twin();
 
@@ -645,6 +649,7 @@ class DeviceNlp {
   bool m_mf_solve = false;  // a new right-hand side goes through the fronts too (ldlt_mf_solve_kernel; SLPX_MF_SOLVE=0: the pair lists)
   bool m_mf_mfma = false;             // the plan has fronts on the matrix cores: the kernel variant with that path
   int m_mf_threads = 1024;            // 512 where the 1024-thread workgroups of every task are not resident at once
+  int m_twin_threads = 1024;          // ... of a launch of two attempts (twin_available)
   bool m_sip_ok = false;              // the pair-list one-launch kernel is usable too (build_solve_in_place)
   uint32_t m_mf_lds = 0;
   // host copies of the inline KKT / back-substitution plans (build_mf packs them into the task images)
@@ -662,7 +667,8 @@ class DeviceNlp {
   // the second attempt of a twin launch: its own factor, update slots, x hand-over (a pair, alternating like
   // m_xg / m_xg2), direction and counters (a pair, alternating like m_stats)
   KktFuse kkt_fuse_for(int kkt_mode) const;
-  void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained);
+  void launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const double* lhs2 = nullptr,
+                      const double* rhs2 = nullptr);
   void book_mf_step(int twin_mode, bool chained);
   IpmLookaheadArgs lookahead_args(double tau, int twin_mode);
   int m_twin_state = 0;  // 0: not looked at yet, 1: available, -1: not (not resident at once, SLPX_TWIN=0, ...)

@@ -1212,7 +1212,7 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
 
   RestorationView view;
   Vec Vo;
-  int expected_attempt = 0;  // which attempt of the regularization policy the previous iteration took
+  bool previous_took_first_attempt = true;  // ... of the regularization policy
 
   while (E_0 > options.tolerance) {
     // :387-408
@@ -1234,41 +1234,32 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     // ---- Newton step (:426-482) on the reduced system, then speculatively: the full direction, its step sizes, the
     // first trial point and its filter entry ----
     auto t0 = clk::now();
-    // (the chain behind an attempt — direction, step sizes, first trial point — is enqueued before the attempt's verdict
-    // only for the attempt EXPECTED to be taken: the one the previous iteration took.  The policy's ladder from
-    // delta = 1e-4 up, :95-98 and :127-130, is six rejected attempts in a row every few iterations of a restoration phase;
-    // each dragged ~20 us of chain behind it.  An accepted attempt without its chain gets it now: one more round trip.)
+    // Two attempts of the regularization policy per launch (NewtonSystem::compute_hooked): the one it is at and the one
+    // it would make next — a restoration phase rejects its unregularized attempt iteration after iteration (H_c with the
+    // restoration's own multipliers is indefinite), and climbs the ladder from delta = 1e-4 (:95-98, :127-130) every few
+    // iterations: each rejected attempt used to be a launch and a round trip of its own.  The chain behind a launch —
+    // the look-ahead iteration, as in ipm_core_resident: the whole iterate the full step would give, the full tape at it,
+    // its error norms — follows the FIRST attempt, and only where the previous iteration took its first attempt; a
+    // direction taken from a second attempt gets its chain when the policy has settled.
     NewtonSystem::AttemptHooks hooks;
-    int attempt = 0;
-    bool chain_behind_last = false;
-    double delta_of_last = 0.0;
-    // (the chain is the look-ahead iteration, as in ipm_core_resident: the whole iterate the full step would give, the full
-    // tape at it and its error norms — when the filter takes that point the iteration is complete on ONE round trip)
     auto chain = [&](double d) {
       fr.expand(d, mu, tau, /*soc=*/false, /*ahead=*/true);
       dev.sweep_full_lookahead(/*with_reduce=*/true, /*skippable=*/false);
       fr.errors(false, mu, /*ahead=*/true);
     };
     hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
-    hooks.after = [&](double d, double) {
-      chain_behind_last = attempt == expected_attempt;
-      delta_of_last = d;
-      if (chain_behind_last) chain(d);
-      ++attempt;
+    hooks.prepare_second = [&](double d, double, const double** lhs2, const double** rhs2) {
+      fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false, /*second=*/true);
+      *lhs2 = fr.second_lhs();
+      *rhs2 = fr.second_rhs();
     };
-    hooks.eliminated_min_pivot = [&] {
-      // (the unregularized attempt's |D| test needs the eliminated pivots: they come with the chain's first kernel)
-      if (!chain_behind_last) {
-        chain(delta_of_last);
-        chain_behind_last = true;
-      }
-      fr.wait_published();
-      return H.dir.eliminated_min_pivot;
-    };
+    if (previous_took_first_attempt) hooks.after = [&](double d, double) { chain(d); };
+    // (the eliminated rows' pivots without regularization: reduced with this iterate's error norms)
+    hooks.eliminated_min_pivot = [&] { return cur.eliminated_min_pivot; };
     auto info = sys.compute_hooked(hooks);
-    if (!chain_behind_last) chain(delta_of_last);
-    expected_attempt = attempt - 1;
-    fr.wait_published();
+    previous_took_first_attempt = sys.last_factorizations() == 1;
+    if (info[0] == FactorInfo::Success && !sys.last_hooked_chain_valid()) chain(sys.hessian_regularization()[0]);
+    if (info[0] == FactorInfo::Success) fr.wait_published();
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();
     rep.value_sweeps += sys.last_factorizations();

@@ -1814,10 +1814,18 @@ bool DeviceNlp::twin_available() {
     SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, m_mf_lds));
     return 2 * l.tasks.size() + m_reduces.n <= static_cast<size_t>(per_cu) * cus;
   };
-  const bool fits = m_mf_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024>, 1024) : resident(&ldlt_mf_twin_kernel<512>, 512);
+  // (a 1024-thread workgroup of the step kernels is alone on its CU — 98 VGPRs x 16 waves; cart-pole N=1000 has 137
+  // tasks, twice that is more than the 256 CUs.  Workgroups of 512 threads fit two to a CU and run the same image
+  // 0.5 us slower at that horizon, to the same bits: a launch of two attempts takes those where the wide ones do not fit)
+  m_twin_threads = m_mf_threads;
+  bool fits = m_mf_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024>, 1024) : resident(&ldlt_mf_twin_kernel<512>, 512);
+  if (!fits && m_mf_threads == 1024) {
+    m_twin_threads = 512;
+    fits = resident(&ldlt_mf_twin_kernel<512>, 512);
+  }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt twin attempt: 2 x %zu tasks, %d workgroup(s) per CU x %d CUs%s\n", l.tasks.size(), per_cu, cus,
-                 fits ? "" : ": NOT resident at once");
+    std::fprintf(stderr, "ldlt twin attempt: 2 x %zu tasks, %d workgroup(s) of %d threads per CU x %d CUs%s\n", l.tasks.size(), per_cu,
+                 m_twin_threads, cus, fits ? "" : ": NOT resident at once");
   if (!fits) return false;
   for (auto [tw, first] : {std::pair{&m_Lx_tw, &m_Lx}, {&m_D_tw, &m_D}, {&m_zv_tw, &m_zv}, {&m_p_tw, &m_p}, {&m_ps_tw, &m_ps}, {&m_pz_tw, &m_pz}}) {
     tw->alloc(std::max<size_t>(1, first->n));
@@ -1835,7 +1843,7 @@ bool DeviceNlp::twin_available() {
 
 // One launch of the multifrontal step kernel (twin_mode != 0: two attempts, ldlt_mf_twin_kernel) with the buffer
 // roles, parities and chain numbers of this moment; book_mf_step() is what the launch changes on the host.
-void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained) {
+void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& f, bool chained, const double* lhs2, const double* rhs2) {
   const LdltPlan& l = m_l_ref;
   const int parity = m_stats_cur ^ 1;
   LdltStats* cur = m_stats.p + static_cast<size_t>(parity);
@@ -1874,13 +1882,15 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     tw.pz = m_pz_tw.p;
     tw.stats = m_stats_tw.p + static_cast<size_t>(tw_parity);
     tw.stats_next = m_stats_tw.p + static_cast<size_t>(tw_parity ^ 1);
+    tw.lhs = lhs2;
+    tw.rhs = rhs2;
     const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p, l.n,
                          m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw);
     };
-    if (m_mf_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
+    if (m_twin_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
     else launch(&ldlt_mf_twin_kernel<512>, 512);
   } else {
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
@@ -1922,6 +1932,20 @@ bool DeviceNlp::factor_solve_publish_twin(double delta0, double gamma0, double d
   if (!m_kkt_pending) materialize_kkt();
   const KktFuse f = take_kkt_fuse();
   launch_mf_step(mode, m_h_reg, f, false);
+  book_mf_step(mode, false);
+  m_stats_seq = ++m_seq_expected;
+  m_stats_in_host = true;
+  return true;
+}
+
+bool DeviceNlp::factor_solve_publish_twin_written(double delta0, double gamma0, double delta1, double gamma1, int mode, const double* lhs2,
+                                                  const double* rhs2) {
+  if (!twin_available() || m_stream.tape_pending || m_kkt_pending || m_lhs_stale || m_rhs_stale) return false;
+  m_h_reg[0] = delta0;
+  m_h_reg[1] = gamma0;
+  m_h_reg[2] = delta1;
+  m_h_reg[3] = gamma1;
+  launch_mf_step(mode, m_h_reg, KktFuse{}, false, lhs2, rhs2);
   book_mf_step(mode, false);
   m_stats_seq = ++m_seq_expected;
   m_stats_in_host = true;

@@ -936,6 +936,9 @@ struct MfTwin {
   double *Lx = nullptr, *D = nullptr, *contrib = nullptr, *zv = nullptr, *xg = nullptr, *xg_next = nullptr, *out = nullptr,
          *ps = nullptr, *pz = nullptr;
   LdltStats *stats = nullptr, *stats_next = nullptr;
+  // a second attempt whose SYSTEM differs from the first's beyond (delta, gamma) on the diagonal (feasibility
+  // restoration: the eliminated rows' share of it depends on delta, restoration.hpp): its own lhs / rhs in memory
+  const double *lhs = nullptr, *rhs = nullptr;
 };
 
 template <int THREADS>
@@ -960,6 +963,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     stats_next = T.stats_next;
     B.ps = T.ps;
     B.pz = T.pz;
+    if (T.lhs != nullptr) lhs = T.lhs;
+    if (T.rhs != nullptr) rhs = T.rhs;
     F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
   }
   mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,

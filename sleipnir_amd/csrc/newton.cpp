@@ -513,59 +513,105 @@ std::vector<FactorInfo> NewtonSystem::compute_hooked(const AttemptHooks& hooks) 
   std::vector<FactorInfo> info(1, FactorInfo::Success);
   m_last_factorizations = 0;
   m_last_twin_launches = m_last_twin_taken = 0;
+  m_hooked_chain_valid = false;
   const double eps = std::numeric_limits<double>::epsilon();
   std::vector<LdltStats> stats;
-  auto attempt = [&](double d, double g) {
-    hooks.prepare(d, g);
-    m_dev->factor_solve_publish({d}, {g}, {1});
-    if (hooks.after) hooks.after(d, g);
+  LdltStats first{}, second{};
+  bool have_second = false, chain_behind_first = false;
+  const bool twin = static_cast<bool>(hooks.prepare_second) && m_dev->twin_available();
+  // one launch: (d0, g0) and, where the device can, (d1, g1) beside it
+  auto launch = [&](double d0, double g0, double d1, double g1, int mode) {
+    hooks.prepare(d0, g0);
+    have_second = false;
+    if (twin) {
+      const double *lhs2 = nullptr, *rhs2 = nullptr;
+      hooks.prepare_second(d1, g1, &lhs2, &rhs2);
+      have_second = m_dev->factor_solve_publish_twin_written(d0, g0, d1, g1, mode, lhs2, rhs2);
+    }
+    if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
+    // (`after` behind the FIRST launch only: a caller that expects its first attempt to be taken; the launches of a
+    // ladder would each drag a chain nobody reads)
+    chain_behind_first = false;
+    if (hooks.after && m_last_factorizations == 0) {
+      hooks.after(d0, g0);
+      chain_behind_first = true;
+    }
     m_dev->read_stats(stats);
-    ++m_last_factorizations;
+    first = stats[0];
+    if (have_second) {
+      second = m_dev->read_twin_stats();
+      ++m_last_twin_launches;
+    }
   };
-  auto inertia_ok = [&](const LdltStats& st) { return st.n_pos == n && st.n_neg == m_e && st.n_zero == 0; };
+  auto good = [&](const LdltStats& st) { return st.n_bad == 0 && st.n_pos == n && st.n_neg == m_e && st.n_zero == 0; };
   auto min_abs = [](const LdltStats& st) {
     double d;
     std::memcpy(&d, &st.min_abs_bits, sizeof(d));
     return d;
   };
-  attempt(0.0, 0.0);  // :74-87
-  if (stats[0].n_bad == 0 && inertia_ok(stats[0]) && min_abs(stats[0]) >= 1e-4 &&
-      (!hooks.eliminated_min_pivot || hooks.eliminated_min_pivot() >= 1e-4)) {
-    m_prev_delta[0] = m_prev_gamma[0] = 0.0;
+  auto accept = [&](double d, double g, bool is_second) {
+    m_prev_delta[0] = d;
+    m_prev_gamma[0] = g;
+    if (is_second) {
+      m_dev->adopt_twin();
+      ++m_last_twin_taken;
+    }
+    m_hooked_chain_valid = chain_behind_first && !is_second;
     return info;
-  }
-  double delta = m_prev_delta[0] == 0.0 ? 1e-4 : std::max(m_prev_delta[0] / 2.0, eps);  // :95-98
-  double gamma = m_gamma_min;                                                             // :102
-  while (true) {
-    attempt(delta, gamma);
-    const LdltStats& st = stats[0];
+  };
+  // the loop's answer to a failed attempt (:114-141); 1: it was "too many negative pivots" — what a launch's second
+  // attempt (delta x 10) stands for
+  auto advance = [&](const LdltStats& st, double& d, double& g) {
+    int answer = 0;
     if (st.n_bad == 0) {
-      if (inertia_ok(st)) {  // :109-113
-        m_prev_delta[0] = delta;
-        m_prev_gamma[0] = gamma;
-        return info;
-      } else if (st.n_zero > 0) {  // :114-126
-        if (gamma == 0.0) {
-          gamma = 1e-10;
+      if (st.n_zero > 0) {
+        if (g == 0.0) {
+          g = 1e-10;
         } else {
-          delta *= 10.0;
-          gamma *= 10.0;
+          d *= 10.0;
+          g *= 10.0;
         }
-      } else if (st.n_neg > m_e) {  // :127-130
-        delta *= 10.0;
-      } else if (st.n_pos > n) {  // :131-135
-        gamma = gamma == 0.0 ? 1e-10 : gamma * 10.0;
+      } else if (st.n_neg > m_e) {
+        d *= 10.0;
+        answer = 1;
+      } else if (st.n_pos > n) {
+        g = g == 0.0 ? 1e-10 : g * 10.0;
       }
-    } else {  // :136-141
-      delta *= 10.0;
-      gamma = gamma == 0.0 ? 1e-10 : gamma * 10.0;
+    } else {
+      d *= 10.0;
+      g = g == 0.0 ? 1e-10 : g * 10.0;
     }
-    if (delta > 1e20 || gamma > 1e20) {  // :145-150
-      info[0] = FactorInfo::NumericalIssue;
-      m_prev_delta[0] = delta;
-      m_prev_gamma[0] = gamma;
-      return info;
+    return answer;
+  };
+  auto gave_up = [&](double d, double g) {  // :145-150
+    if (!(d > 1e20 || g > 1e20)) return false;
+    info[0] = FactorInfo::NumericalIssue;
+    m_prev_delta[0] = d;
+    m_prev_gamma[0] = g;
+    return true;
+  };
+  double d = m_prev_delta[0] == 0.0 ? 1e-4 : std::max(m_prev_delta[0] / 2.0, eps);  // :95-98
+  double g = m_gamma_min;                                                             // :102
+  launch(0.0, 0.0, d, g, 2);  // :74-87 — beside it the loop's first guess
+  ++m_last_factorizations;
+  if (good(first) && min_abs(first) >= 1e-4 && (!hooks.eliminated_min_pivot || hooks.eliminated_min_pivot() >= 1e-4))
+    return accept(0.0, 0.0, false);
+  bool second_is_current = have_second;  // `second` holds the attempt at (d, g)
+  while (true) {
+    if (!second_is_current) {
+      launch(d, g, d * 10.0, g, 1);
+      ++m_last_factorizations;
+      if (good(first)) return accept(d, g, false);
+      const int answer = advance(first, d, g);
+      if (gave_up(d, g)) return info;
+      second_is_current = have_second && answer == 1;  // (d, g) is now what the second attempt was made with
+      if (!second_is_current) continue;
     }
+    second_is_current = false;
+    ++m_last_factorizations;
+    if (good(second)) return accept(d, g, true);
+    advance(second, d, g);
+    if (gave_up(d, g)) return info;
   }
 }
 

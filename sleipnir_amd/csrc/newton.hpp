@@ -100,10 +100,18 @@ class NewtonSystem {
   // `after(delta, gamma)` is enqueued behind its solve, `eliminated_min_pivot()` (first attempt only) is the smallest
   // pivot of what was eliminated outside the factorization: it joins the |D| >= 1e-4 test (:82-87).  The
   // unregularized attempt is always made (such a system has no structurally zero pivot).  One problem.
+  // `prepare_second(delta, gamma, &lhs2, &rhs2)` (optional): the system of the attempt the policy would make NEXT, in
+  // buffers of the caller's — the two are then factored in ONE launch where the device can (ldlt_mf_twin_kernel, as
+  // compute() does for the systems it evaluates itself), judged in the policy's order from their own counters: the
+  // sequence of (delta, gamma) tried, the one accepted and the count of factorizations are the sequential loop's.
+  // `after` then follows only the FIRST attempt of a launch (a direction taken from the second is the caller's to
+  // expand after compute_hooked returns: last_hooked_chain_valid()).
   struct AttemptHooks {
     std::function<void(double, double)> prepare, after;
     std::function<double()> eliminated_min_pivot;
+    std::function<void(double, double, const double**, const double**)> prepare_second;
   };
+  bool last_hooked_chain_valid() const { return m_hooked_chain_valid; }
   std::vector<FactorInfo> compute_hooked(const AttemptHooks& hooks);
   const std::vector<double>& hessian_regularization() const { return m_prev_delta; }
   const std::vector<double>& constraint_jacobian_regularization() const { return m_prev_gamma; }
@@ -144,6 +152,7 @@ class NewtonSystem {
   std::function<void()> m_after_attempt;
   bool m_twin_attempts = false;
   int m_last_twin_launches = 0, m_last_twin_taken = 0;
+  bool m_hooked_chain_valid = false;  // compute_hooked: `after` ran behind the attempt that was accepted
   long m_twin_hist[6] = {0, 0, 0, 0, 0, 0};
   int m_twin_expect = 1;  // what the loop's first attempt drew last time (compute_twin): 1 negative pivots, 3 positive
   std::vector<FactorInfo> compute_twin();

@@ -472,13 +472,13 @@ namespace fr_err {
 enum {
   DUAL_U, SZ_MAX_U, CE_U, CIS_U, Y1_U, Z1_U, DUAL, SZ_MIN, SZ_MAX, CE, CIS, Y1, Z1, VIOL, LOGSUM,
   AETCE, CESQ, AITCP, CPSQ, XINF, SINF, FINITE, CIPOS,
-  COST, VIOL_O, LOGSUM_O, DPHI_O, NQ
+  COST, VIOL_O, LOGSUM_O, DPHI_O, EMIN0, NQ
 };
 }
 #define SLPX_FR_ERR_OPS                                                                               \
   {IPM_MAX, IPM_MAX, IPM_MAX, IPM_MAX, IPM_SUM, IPM_SUM, IPM_MAX, IPM_MIN, IPM_MAX, IPM_MAX, IPM_MAX, \
    IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_MAX, IPM_MAX, IPM_MIN, \
-   IPM_MIN, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM}
+   IPM_MIN, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_MIN}
 constexpr int kFrErrThreads = 256;
 
 __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args A, int nV, int check_all_V, double mu_outer,
@@ -496,6 +496,7 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = ops[q] == IPM_MIN ? 1.0 : 0.0;
   acc[SZ_MIN] = 1e300;
+  acc[EMIN0] = 1e300;
   const int stride = gridDim.x * kFrErrThreads, t0 = blockIdx.x * kFrErrThreads + threadIdx.x;
   const double* d_ce = A.scales + 1;
   const double* d_ci = A.scales + 1 + me;
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
     acc[COST] += A.rho * pe + A.rho * ne;
     ineq_row(pe, A.sx[j], z1, 1.0);
     ineq_row(ne, A.sx[me + j], z2, 1.0);
+    acc[EMIN0] = fmin(acc[EMIN0], fmin((1.0 / A.sx[j]) * z1, (1.0 / A.sx[me + j]) * z2));
   }
   // inequality rows of block 0, with the columns and bound rows of p_i, n_i
   for (int r = t0; r < mi; r += stride) {
@@ -601,6 +603,11 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
     acc[COST] += A.rho * pi + A.rho * ni;
     ineq_row(pi, A.sx[e3], z3, 1.0);
     ineq_row(ni, A.sx[e4], z4, 1.0);
+    {  // the pivots of the (p_i, n_i) block eliminated in that order: a = Sigma_0 + Sigma_3, then det / a (fr_expand_kernel)
+      const double sig = (1.0 / sr) * zr, a3 = (1.0 / A.sx[e3]) * z3, a4 = (1.0 / A.sx[e4]) * z4;
+      const double a = sig + a3;
+      acc[EMIN0] = fmin(acc[EMIN0], fmin(a, (sig * (a3 + a4) + a3 * a4) / a));
+    }
     // the outer problem's filter quantities at (x, s_0)
     acc[VIOL_O] += fabs(ci[r] - sr);
     acc[LOGSUM_O] += log(sr);
@@ -666,6 +673,7 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
     out->viol_outer = tot[VIOL_O];
     out->logsum_outer = tot[LOGSUM_O];
     out->dphi_outer = tot[DPHI_O];
+    out->eliminated_min_pivot = tot[EMIN0];
     ipm_publish(seq_dev, seq_host);
   }
 }
@@ -797,13 +805,17 @@ void FrDevice::begin(const double* x_r, const double* w, const double* g_outer, 
   SLPX_HIP_CHECK(hipStreamSynchronize(st));  // (the host vectors may go away)
 }
 
-void FrDevice::build(double delta, double mu, bool soc, bool rhs_only) {
+void FrDevice::build(double delta, double mu, bool soc, bool rhs_only, bool second) {
   const KktDev K = m_dev.kdev();
   const int work = std::max(rhs_only ? 0 : K.nnz_lhs, K.dim);
+  if (second && m_lhs2.n == 0) {
+    m_lhs2.alloc(static_cast<size_t>(std::max(1, K.nnz_lhs)));
+    m_rhs2.alloc(static_cast<size_t>(std::max(1, K.dim)));
+  }
   hipLaunchKernelGGL(fr_build_kernel, dim3(grid_for(work, 256)), dim3(256), 0, m_dev.stream(), args(), m_diag_of.p, delta, mu, soc ? 1 : 0,
-                     rhs_only ? 1 : 0, m_dev.lhs_raw(), m_dev.rhs_raw());
+                     rhs_only ? 1 : 0, second ? m_lhs2.p : m_dev.lhs_raw(), second ? m_rhs2.p : m_dev.rhs_raw());
   SLPX_HIP_CHECK(hipGetLastError());
-  m_dev.system_written_by_caller(!rhs_only, true);
+  if (!second) m_dev.system_written_by_caller(!rhs_only, true);
 }
 
 void FrDevice::expand(double delta, double mu, double tau, bool soc, bool ahead) {

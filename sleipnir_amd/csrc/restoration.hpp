@@ -52,6 +52,9 @@ struct FrErrOut {
   // the OUTER problem at (x, s_0): f, ||c_e||_1 + ||c_i - s||_1, sum ln s, and the directional derivative of its
   // barrier cost from the point restoration started at (interior_point.hpp:729-752)
   double f_outer, viol_outer, logsum_outer, dphi_outer;
+  // the smallest pivot of the rows eliminated in closed form at this iterate WITHOUT regularization (order p_e, n_e,
+  // p_i, n_i): it joins the |D| >= 1e-4 test of the next iteration's unregularized attempt
+  double eliminated_min_pivot;
 };
 struct FrHost {
   FrDirOut dir;
@@ -76,7 +79,11 @@ class FrDevice {
 
   // the reduced system for (delta; gamma is added by the factorization itself) -> the outer system's lhs / rhs.
   // soc: the second-order-correction right-hand side (interior_point.hpp:611-616); rhs_only: lhs is in place
-  void build(double delta, double mu, bool soc, bool rhs_only);
+  // second: into this object's own arrays (second_lhs() / second_rhs()) — the system of the attempt the regularization
+  // policy would make next, factored beside the first in one launch (NewtonSystem::compute_hooked)
+  void build(double delta, double mu, bool soc, bool rhs_only, bool second = false);
+  const double* second_lhs() const { return m_lhs2.p; }
+  const double* second_rhs() const { return m_rhs2.p; }
   // p = (dx, w) of the outer system -> the whole direction, its step sizes and directional derivative (-> host().dir,
   // alpha on the device), the first trial x (the outer system's trial input)
   // ahead: also the WHOLE iterate the full step (alpha_max, alpha_z) would give — x, s, y, z of all five blocks with the
@@ -109,6 +116,7 @@ class FrDevice {
   double m_mu_outer = 0.0;
   DevBuf<double> m_pn, m_sx, m_zx, m_dpn, m_psx, m_pzx;
   DevBuf<double> m_pn_t, m_sx_t, m_zx_t;  // the look-ahead iterate's
+  DevBuf<double> m_lhs2, m_rhs2;          // the second attempt's system (build(.., second))
   DevBuf<double> m_soc_ce, m_soc_c0, m_soc_x;
   DevBuf<double> m_keep_p, m_keep_ps0, m_keep_pz0, m_keep_dpn, m_keep_psx, m_keep_pzx;
   DevBuf<double> m_alpha, m_partial;

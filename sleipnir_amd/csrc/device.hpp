@@ -360,6 +360,7 @@ struct IpmHost {
   IpmTrialOut trial;
   IpmErrOut err;
   IpmErrOut err_ahead;  // the same quantities at the look-ahead iterate (ipm_lookahead)
+  double go;            // a deciding error launch (ipm_errors_deciding): 1.0 = the device took the iteration's decisions
 };
 
 struct StepTimings {
@@ -508,6 +509,46 @@ class DeviceNlp {
   void wait();                                // busy-polls the stream
   void wait_published();                      // after ipm_trial_metrics / ipm_errors: their sequence number
   const IpmHost& ipm_host() const { return *m_ipm_host; }
+  // ---- the pipelined common iteration (ipm.cpp: ipm_core_resident; ipm_decide.h) ----
+  // Two sets of the scalar outputs: the chain of iteration k+1 is enqueued before the host has read iteration k's.
+  // ipm_set_slot: where the kernels enqueued from now on leave theirs.
+  void ipm_set_slot(int slot) { m_ipm_slot = slot & 1; }
+  const IpmHost& ipm_host_slot(int slot) const { return m_ipm_host[slot & 1]; }
+  // the iteration's state for the decision on the device (host -> device, in stream order), and what the device left
+  void ipm_pipeline_upload(const struct IpmCtl& ctl);
+  const struct IpmCtl& ipm_pipeline_fetch();  // device -> host (synchronizes; the pipeline is drained when the host asks)
+  // the NEXT step launch (one launch) waits for the decision of the error launch in front of it
+  void ipm_gate_next_step(bool on) { m_gate_next_step = on; }
+  // ipm_errors(.., ahead) that also takes the decision
+  void ipm_errors_deciding(bool sums_ride);
+  unsigned long long seq_expected() const { return m_seq_expected; }
+  void wait_published_until(unsigned long long seq);
+  // what a launch changes on the host side of the step machinery (buffer parities, pending work): saved before a
+  // speculative launch, put back when the device let it pass
+  struct LaunchBook {
+    int stats_cur, stats_tw_cur, xg_parity, xg_tw_parity, twin_mode, kkt_pending;
+    bool last_step_chained, stats_in_host, lhs_stale, rhs_stale, tape_pending, touched;
+    unsigned long long stats_seq;
+  };
+  LaunchBook save_book() const {
+    return LaunchBook{m_stats_cur, m_stats_tw_cur, m_xg_parity, m_xg_tw_parity, m_twin_mode, m_kkt_pending, m_last_step_chained,
+                      m_stats_in_host, m_lhs_stale, m_rhs_stale, m_stream.tape_pending, m_stream.touched, m_stats_seq};
+  }
+  void restore_book(const LaunchBook& b) {
+    m_stats_cur = b.stats_cur;
+    m_stats_tw_cur = b.stats_tw_cur;
+    m_xg_parity = b.xg_parity;
+    m_xg_tw_parity = b.xg_tw_parity;
+    m_twin_mode = b.twin_mode;
+    m_kkt_pending = b.kkt_pending;
+    m_last_step_chained = b.last_step_chained;
+    m_stats_in_host = b.stats_in_host;
+    m_lhs_stale = b.lhs_stale;
+    m_rhs_stale = b.rhs_stale;
+    m_stream.tape_pending = b.tape_pending;
+    m_stream.touched = b.touched;
+    m_stats_seq = b.stats_seq;
+  }
   double* d_V_trial() { return m_V_trial.p; }
 
   // device pointers for callers that keep everything resident
@@ -709,7 +750,14 @@ class DeviceNlp {
   bool m_ipm = false;
   DevBuf<double> m_s_ahead, m_y_ahead, m_z_ahead;  // with m_trial_in (x | y | z) and m_V_trial: the look-ahead iterate
   DevBuf<double> m_trial_in, m_V_trial, m_soc_ce, m_soc_cims, m_p_keep, m_ps_keep, m_pz_keep, m_ipm_alpha, m_ipm_scales, m_ipm_partial;
-  IpmHost* m_ipm_host = nullptr;   // pinned
+  IpmHost* m_ipm_host = nullptr;   // pinned, two slots (ipm_set_slot)
+  int m_ipm_slot = 0;
+  struct IpmCtl* m_ipm_ctl_host = nullptr;   // pinned: [0] the device's mirror, [1], [2] staging of uploads
+  int m_ipm_ctl_stage = 0;
+  void* m_ipm_ctl_dev = nullptr;             // IpmCtl on the device
+  DevBuf<double> m_ipm_gate;
+  bool m_gate_next_step = false;
+  bool m_errors_decide = false;
   bool m_tape_reduce = true;       // launch_tape runs the separable-sum reductions itself
   // chained steps (sweep_full_for_step): words 0 / 16 / 32 / 48 of m_chain = workgroups of the sweep
   // through, last step whose sweep is complete, workgroups of the step kernel through, last step whose

@@ -1,5 +1,6 @@
 #include "ipm.hpp"
 
+#include "ipm_decide.h"
 #include "restoration.hpp"
 
 #include <algorithm>
@@ -115,24 +116,17 @@ bool scaling_is_identity(const NlpStructure& st, const Vec& scales) {
   return scales[0] == 1.0 && st.m_e == 0 && st.m_i == 0;
 }
 
-// filter.hpp:17-212
-struct FilterEntry {
-  double cost = 0.0, constraint_violation = 0.0;
-  FilterEntry() = default;
-  FilterEntry(double c, double v) : cost(c), constraint_violation(v) {}
-  FilterEntry(double f, const Vec& s, const double* c_e, int m_e, const double* c_i, double mu) {
-    double logsum = 0.0, viol = norm_1(c_e, m_e);
-    for (size_t j = 0; j < s.size(); ++j) {
-      logsum += std::log(s[j]);
-      viol += std::abs(c_i[j] - s[j]);
-    }
-    cost = f - mu * logsum;
-    constraint_violation = viol;
+// filter.hpp:17-212 (the entry type and the device's copy of the table: ipm_decide.h)
+FilterEntry make_entry(double c, double v) { return FilterEntry{c, v}; }
+FilterEntry make_entry(double f, const Vec& s, const double* c_e, int m_e, const double* c_i, double mu) {
+  double logsum = 0.0, viol = norm_1(c_e, m_e);
+  for (size_t j = 0; j < s.size(); ++j) {
+    logsum += std::log(s[j]);
+    viol += std::abs(c_i[j] - s[j]);
   }
-  bool dominated_by(const FilterEntry& e) const {
-    return e.cost <= cost && e.constraint_violation <= constraint_violation;
-  }
-};
+  return FilterEntry{f - mu * logsum, viol};
+}
+bool dominated_by(const FilterEntry& a, const FilterEntry& e) { return filter_dominated_by(a, e); }
 
 class Filter {
  public:
@@ -162,7 +156,7 @@ class Filter {
       return false;
     }
     for (auto& e : m_filter)
-      if (trial.dominated_by(e)) {
+      if (dominated_by(trial, e)) {
         m_last_rejection_due_to_filter = true;
         return false;
       }
@@ -170,13 +164,33 @@ class Filter {
       FilterEntry add{cur.cost - phi * kGammaCost * cur.constraint_violation,
                       (1.0 - phi * kGammaCon) * cur.constraint_violation};
       m_filter.erase(std::remove_if(m_filter.begin(), m_filter.end(),
-                                    [&](const FilterEntry& e) { return e.dominated_by(add); }),
+                                    [&](const FilterEntry& e) { return dominated_by(e, add); }),
                      m_filter.end());
       m_filter.push_back(add);
     }
     return true;
   }
   bool last_rejection_due_to_filter() const { return m_last_rejection_due_to_filter; }
+  // the table as the device keeps it (ipm_decide.h); false: more entries than it holds
+  bool to_state(FilterState& F) const {
+    if (m_filter.size() > static_cast<size_t>(kFilterCapacity)) return false;
+    F.min_constraint_violation = min_constraint_violation;
+    F.max_constraint_violation = max_constraint_violation;
+    F.n = static_cast<int>(m_filter.size());
+    F.last_rejection_due_to_filter = m_last_rejection_due_to_filter ? 1 : 0;
+    for (int k = 0; k < F.n; ++k) {
+      F.ent[2 * k] = m_filter[k].cost;
+      F.ent[2 * k + 1] = m_filter[k].constraint_violation;
+    }
+    return true;
+  }
+  void from_state(const FilterState& F) {
+    min_constraint_violation = F.min_constraint_violation;
+    max_constraint_violation = F.max_constraint_violation;
+    m_last_rejection_due_to_filter = F.last_rejection_due_to_filter != 0;
+    m_filter.clear();
+    for (int k = 0; k < F.n; ++k) m_filter.push_back(FilterEntry{F.ent[2 * k], F.ent[2 * k + 1]});
+  }
 
  private:
   static constexpr double kGammaCost = 1e-8, kGammaCon = 1e-5;
@@ -358,7 +372,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
     bool call_feasibility_restoration = alpha < alpha_min;
     double alpha_z = ftb(z, p_z, tau);  // :497
 
-    const FilterEntry current_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+    const FilterEntry current_entry = make_entry(f, s, c_e.data(), m_e, c_i.data(), mu);
     double D_phi = 0.0;  // :508-509
     for (int i = 0; i < n; ++i) D_phi += g[i] * p_x[i];
     {
@@ -394,7 +408,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
         continue;
       }
 
-      FilterEntry trial_entry{trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu};
+      FilterEntry trial_entry = make_entry(trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu);
       if (filter.try_add(current_entry, trial_entry, D_phi, alpha)) break;
 
       const double prev_violation = violation(c_e, c_i, s);
@@ -450,7 +464,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
           trial_z = axpy(z, alpha_z_soc, soc_pz);
           eval_values(trial_x);
           read_trial();
-          FilterEntry soc_entry{trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu};
+          FilterEntry soc_entry = make_entry(trial_f, trial_s, trial_c_e.data(), m_e, trial_c_i.data(), mu);
           if (filter.try_add(current_entry, soc_entry, D_phi, alpha)) {
             p_x = soc_px;
             p_s = soc_ps;
@@ -507,7 +521,7 @@ ExitStatus ipm_core_host(NewtonSystem& sys, const Vec& scales,
     if (call_feasibility_restoration) {  // :721-771
       if (in_feasibility_restoration) return finish(ExitStatus::FEASIBILITY_RESTORATION_FAILED);
 
-      const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+      const FilterEntry initial_entry = make_entry(f, s, c_e.data(), m_e, c_i.data(), mu);
       // Leave restoration once the outer filter accepts the restoration iterate and the violation dropped by 10 %
       // (:729-752); the restoration iteration reduces the outer problem's quantities at its iterate on the device
       auto outer_accepts = [&](const FilterEntry& trial_entry, double D_phi_restoration) {
@@ -588,7 +602,12 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   const int n = st.n, m_e = st.m_e, m_i = st.m_i, dim = n + m_e;
   dev.ipm_enable();
   dev.ipm_set_error_scaling(scales);
-  const IpmHost& H = dev.ipm_host();
+  // (two sets of the scalar outputs, taken in turn by the iterations: the pipelined common iteration below enqueues
+  // iteration k+1's launches before the host has read iteration k's)
+  int slot = 0;
+  dev.ipm_set_slot(slot);
+  const IpmHost* Hp = &dev.ipm_host_slot(slot);
+#define H (*Hp)
 
   sys.reset_regularization();
   sys.set_gamma_min(in_feasibility_restoration ? 0.0 : 1e-10);  // :350-352
@@ -610,10 +629,21 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     host_current = true;
   };
   long twin_launches = 0, twin_taken = 0;
+  bool spec_in_flight = false;  // the NEXT iteration's step and chain are enqueued already (and will run)
+  long pipelined = 0, passed = 0;
   auto finish = [&](ExitStatus st_) {
+    if (spec_in_flight) {  // (the step enqueued ahead runs for nothing: wait for it, forget it)
+      dev.wait_published();
+      sys.cancel_speculative_compute();
+      spec_in_flight = false;
+    }
     sys.set_after_attempt(nullptr);
+    sys.set_twin_attempts(false);
+    dev.ipm_set_slot(0);
     pull_state();
     if (std::getenv("SLPX_TWIN_VERBOSE")) {
+      std::fprintf(stderr, "slpx pipelined iterations: %ld decided on the device, %ld steps enqueued ahead passed, of %d iterations\n",
+                   pipelined, passed, iterations);
       const long* h = sys.twin_histogram();
       std::fprintf(stderr, "slpx twin attempts: %ld launches held two attempts, the policy took the second of %ld (%d factorizations, %d iterations); "
                    "first attempts of this system so far: %ld accepted, %ld / %ld with the failure the second stood for and the second accepted / not, "
@@ -667,6 +697,40 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   double E_0 = E0_of(cur);  // :361-362
   rep.t_setup = since(t_setup);
 
+  // ---- the pipelined common iteration (ipm_decide.h) ----
+  // Most iterations end the same way: the filter takes the full step the look-ahead launch evaluated, the error is
+  // above the tolerance, the barrier parameter stays.  Those decisions are then taken ON THE DEVICE, by the launch that
+  // reduces the look-ahead iterate's norms (ipm_errors_deciding) — and the next iteration's step, with its chain, is
+  // enqueued as soon as this iteration's factorization is accepted, BEFORE that launch has run: it waits for the word
+  // the deciding launch leaves and passes if the host has to look (a rejected step, a barrier update, convergence,
+  // anything rare).  The host then only follows: one poll per iteration, no launch on the critical path.
+  // SLPX_IPM_PIPELINE=0: every iteration decided by the host, as before.
+  const char* pipeline_env = std::getenv("SLPX_IPM_PIPELINE");
+  const bool pipeline_on = lookahead && callbacks.empty() && !options.feasible_ipm && !(pipeline_env && pipeline_env[0] == '0');
+  bool ctl_current = false;      // the device's copy of (filter, current iterate's entry, mu) is the host's
+  bool filter_on_device = false; // ... and newer than the host's: the device took decisions since
+  auto sync_filter_from_device = [&] {
+    if (!filter_on_device) return;
+    filter.from_state(dev.ipm_pipeline_fetch().filter);
+    filter_on_device = false;
+  };
+  auto upload_ctl = [&]() -> bool {
+    static thread_local IpmCtl c;
+    if (!filter.to_state(c.filter)) return false;
+    c.mu = mu;
+    c.mu_min = mu_min;
+    c.tolerance = options.tolerance;
+    c.cur_f = cur.f;
+    c.cur_logsum = cur.logsum;
+    c.cur_viol = cur.viol;
+    c.m_e = m_e;
+    c.m_i = m_i;
+    c.identity_scaling = identity ? 1 : 0;
+    dev.ipm_pipeline_upload(c);
+    ctl_current = true;
+    return true;
+  };
+
   // host copies for the rare branches
   Vec V, p(dim), p_x(n), p_y(m_e), p_s(m_i), p_z(m_i);
   auto pull_V = [&] {
@@ -698,7 +762,12 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       dev.upload_mu(&mu);
       mu_on_device = mu;
     }
-    dev.build_kkt_for_step(/*with_reduce=*/false);
+    const bool resumed = spec_in_flight;  // this iteration's first launch (and chain) were enqueued by the one before
+    spec_in_flight = false;
+    // will THIS iteration's chain decide?  (its state on the device must be the host's, or the device's own)
+    bool deciding = pipeline_on && ahead && (resumed || ctl_current || upload_ctl());
+    if (!deciding) ctl_current = false;
+    if (!resumed) dev.build_kkt_for_step(/*with_reduce=*/false);
     // Look-ahead (DeviceNlp::ipm_lookahead): instead of only f, c_e, c_i at the first trial point, the
     // WHOLE next iterate the full step would give — updated s, y, z, the full tape at it, the error norms
     // of :809-832 — is computed speculatively behind the step kernel, in a second set of buffers.  Most
@@ -709,7 +778,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       if (ahead) {
         dev.ipm_lookahead(tau);
         dev.sweep_full_lookahead();
-        dev.ipm_errors(false, /*sums_ride=*/true, /*ahead=*/true);
+        if (deciding) dev.ipm_errors_deciding(/*sums_ride=*/true);
+        else dev.ipm_errors(false, /*sums_ride=*/true, /*ahead=*/true);
       } else {
         dev.ipm_direction(tau);
         dev.sweep_values_trial();
@@ -720,11 +790,65 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // launch's two attempts the regularization policy takes — the other after_attempt chain does not)
     sys.set_twin_attempts(ahead);
     auto info = sys.compute(/*solve_speculatively=*/true);
-    sys.set_twin_attempts(false);
-    sys.set_after_attempt(nullptr);
     twin_launches += sys.last_twin_launches();
     twin_taken += sys.last_twin_taken();
-    dev.wait_published();  // compute() returns when the inertia counters are in; the trial chain may still run
+    // ---- the next iteration's step, ahead of this one's verdict ----
+    bool spec = false;
+    const unsigned long long seq_this = dev.seq_expected();  // this iteration's chain ends with this publication
+    if (deciding && info[0] == FactorInfo::Success && iterations + 2 < options.max_iterations) {
+      dev.ipm_accept_lookahead();  // (the roles the buffers have if the device takes the step; put back below if not)
+      dev.ipm_set_slot(slot ^ 1);
+      // (the chain of the step enqueued ahead decides too: the device's state is its own by then)
+      spec = sys.begin_speculative_compute();
+      if (!spec) {
+        dev.ipm_accept_lookahead();
+        dev.ipm_set_slot(slot);
+      }
+    }
+    sys.set_twin_attempts(false);
+    sys.set_after_attempt(nullptr);
+    dev.wait_published_until(seq_this);  // compute() returns when the inertia counters are in; the trial chain may still run
+    if (spec) {
+      if (H.go != 0.0) {
+        // the device took this iteration's decisions (ipm_decide.h): the filter accepted the full step, the
+        // error is above the tolerance, mu stays; the next step is on its way.  The host follows.
+        ++pipelined;
+        rep.factorizations += sys.last_factorizations();
+        rep.solves += sys.last_factorizations();
+        rep.value_sweeps += sys.last_factorizations();
+        rep.t_kkt_decomp += since(t0);
+        rep.delta = sys.hessian_regularization()[0];
+        rep.gamma = sys.constraint_jacobian_regularization()[0];
+        full_step_rejected_counter = 0;
+        host_current = false;
+        filter_on_device = true;
+        cur = H.err_ahead;
+        E_0 = E0_of(cur);
+        if (options.diagnostics) {
+          std::fprintf(stderr,
+                       "%4d  err %.3e  f %.6e  |c| %.3e  mu %.1e  delta %.3e  gamma %.3e  alpha %.2e  "
+                       "alpha_z %.2e  nfact %d\n",
+                       iterations, E_0, cur.f, cur.viol, mu, rep.delta, rep.gamma, H.dir.alpha_max, H.dir.alpha_z,
+                       sys.last_factorizations());
+        }
+        ++iterations;
+        rep.final_error = E_0;
+        slot ^= 1;
+        Hp = &dev.ipm_host_slot(slot);
+        spec_in_flight = true;
+        if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
+        continue;
+      }
+      // the host has to look: everything enqueued ahead passes (a few microseconds); as if it had never been launched
+      // (no waiting for them: what the host enqueues next runs behind them in the stream's order, and they write nothing
+      // but their sequence numbers)
+      ++passed;
+      sys.cancel_speculative_compute();
+      dev.ipm_accept_lookahead();
+      dev.ipm_set_slot(slot);
+    }
+    ctl_current = false;  // (whatever happens below changes the filter, the iterate or mu on the host's side)
+    sync_filter_from_device();
     rep.factorizations += sys.last_factorizations();
     rep.solves += sys.last_factorizations();
     rep.value_sweeps += sys.last_factorizations();
@@ -876,7 +1000,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       const Vec g = cv.g_dense();
       const Vec c_e(cv.c_e(), cv.c_e() + m_e), c_i(cv.c_i(), cv.c_i() + m_i);
       const double f = cv.f();
-      const FilterEntry initial_entry{f, s, c_e.data(), m_e, c_i.data(), mu};
+      const FilterEntry initial_entry = make_entry(f, s, c_e.data(), m_e, c_i.data(), mu);
       // Leave restoration once the outer filter accepts the restoration iterate and the
       // violation dropped by 10 % (:729-752).
       auto outer_accepts = [&](const FilterEntry& trial_entry, double D_phi_restoration) {
@@ -930,6 +1054,8 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   rep.final_error = E_0;
   return finish(ExitStatus::SUCCESS);
 }
+
+#undef H
 
 // SLPX_IPM_RESIDENT=0 keeps the O(n) logic between Newton steps on the host (the round-1
 // arrangement; kept as the cross-check of the device-resident iteration).

@@ -21,6 +21,7 @@
 
 #include "coherent.h"
 #include "device.hpp"
+#include "ipm_decide.h"
 #include "ipm_reduce.h"
 
 namespace slpx {
@@ -193,6 +194,7 @@ __device__ __forceinline__ void ipm_lookahead_body(IpmLookaheadArgs A, double* s
   if (tid == 0) {
     A.alpha_dev[0] = acc[0];
     A.alpha_dev[1] = acc[1];
+    A.alpha_dev[3] = acc[2];  // (D_phi: the decision made on the device reads it, ipm_error_fold)
     A.out->alpha_max = acc[0];
     A.out->alpha_z = acc[1];
     A.out->D_phi = acc[2];
@@ -423,6 +425,14 @@ struct IpmErrFinish {
   // (look-ahead chain) non-zero: the factorization before this chain has the wrong inertia — the attempt will
   // be redone and nothing of this launch is looked at: workgroup 0 publishes, everybody leaves
   const double* skip = nullptr;
+  // the common iteration decided HERE (ipm_decide.h), when the host asked for it: `ctl` the iteration's state on the
+  // device,
+  // `dir` = [alpha_max, alpha_z, chain void, D_phi] of the look-ahead launch, `gate` the word the NEXT step's kernel
+  // — already enqueued behind this launch — reads: 1.0 run, 0.0 pass
+  IpmCtl* ctl = nullptr;
+  const double* dir = nullptr;
+  double* gate = nullptr;
+  double* go_host = nullptr;  // the verdict for the host, beside the scalars of this launch (IpmHost::go)
 };
 
 // folds the per-workgroup partials in workgroup order and hands the result to the host;
@@ -430,7 +440,8 @@ struct IpmErrFinish {
 __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __restrict__ V,
                                                const double* __restrict__ partial, int n_blocks, bool in_launch,
                                                IpmErrOut* __restrict__ out, unsigned long long* __restrict__ seq_dev,
-                                               volatile unsigned long long* seq_host, double* tot) {
+                                               volatile unsigned long long* seq_host, double* tot,
+                                               const IpmErrFinish* decide = nullptr) {
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
@@ -469,12 +480,82 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
   // one lane), then the wave's system-scope fence and the sequence number
   if (threadIdx.x < 64) {
     const int k = threadIdx.x;
+    double v = 0.0;
     if (k < 24) {
       const double f = coherent_load(&V[K.off_f], in_launch);
-      double v = k < 13 ? tot[k] : (k == 13 ? f : tot[k - 1]);  // (IpmErrOut: f sits between z1 and viol)
+      v = k < 13 ? tot[k] : (k == 13 ? f : tot[k - 1]);  // (IpmErrOut: f sits between z1 and viol)
       if (k == SZ_MIN) v = K.m_i ? v : 0.0;
       if (k == FINITE + 1) v = (v != 0.0 && isfinite(f)) ? 1.0 : 0.0;
       reinterpret_cast<double*>(out)[k] = v;
+    }
+    if (decide != nullptr && decide->ctl != nullptr) {
+      // the common iteration's decisions (ipm_decide.h), by the wave that publishes: the 24 scalars through LDS (`part`
+      // is free), the rules by every lane alike, the filter's table an entry per lane
+      double* fin = tot + NQ;
+      if (k < 24) fin[k] = v;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      IpmErrOut e;
+      for (int q = 0; q < 24; ++q) reinterpret_cast<double*>(&e)[q] = fin[q];
+      IpmCtl* C = decide->ctl;
+      IpmCtl head;  // (the scalars only: the table stays where it is)
+      head.mu = C->mu;
+      head.mu_min = C->mu_min;
+      head.tolerance = C->tolerance;
+      head.m_e = C->m_e;
+      head.m_i = C->m_i;
+      head.identity_scaling = C->identity_scaling;
+      const double alpha_max = decide->dir[0], D_phi = decide->dir[3];
+      bool go = ipm_next_iteration_is_plain(head, e, alpha_max);
+      if (go) {
+        const FilterEntry current{C->cur_f - head.mu * C->cur_logsum, C->cur_viol};
+        const FilterEntry trial{e.f - head.mu * e.logsum, e.viol};
+        FilterEntry add;
+        bool insert = false;
+        int last_rej = C->filter.last_rejection_due_to_filter;
+        const int n_ent = C->filter.n;
+        double* ent = C->filter.ent;
+        go = filter_rules(C->filter.min_constraint_violation, C->filter.max_constraint_violation, &last_rej, current, trial, D_phi, alpha_max,
+                          &add, &insert) != 0;
+        if (go) {
+          bool dominated = false, removes = false;
+          for (int q = k; q < n_ent; q += 64) {
+            const FilterEntry en{ent[2 * q], ent[2 * q + 1]};
+            dominated = dominated || filter_dominated_by(trial, en);
+            removes = removes || filter_dominated_by(en, add);
+          }
+          if (__ballot(dominated) != 0ull) go = false;  // (the host takes it from here, its own try_add sets the flag)
+          else if (insert) {
+            const bool any_removed = __ballot(removes) != 0ull;
+            if (!any_removed && n_ent >= kFilterCapacity) go = false;
+            else if (k == 0) {
+              int w = n_ent;
+              if (any_removed) {  // (rare: the new entry dominates older ones — in order, by one lane)
+                w = 0;
+                for (int q = 0; q < n_ent; ++q)
+                  if (!filter_dominated_by(FilterEntry{ent[2 * q], ent[2 * q + 1]}, add)) {
+                    ent[2 * w] = ent[2 * q];
+                    ent[2 * w + 1] = ent[2 * q + 1];
+                    ++w;
+                  }
+              }
+              ent[2 * w] = add.cost;
+              ent[2 * w + 1] = add.constraint_violation;
+              C->filter.n = w + 1;
+            }
+          }
+        }
+      }
+      if (k == 0) {
+        if (go) {
+          C->cur_f = e.f;
+          C->cur_logsum = e.logsum;
+          C->cur_viol = e.viol;
+        }
+        C->go = go ? 1 : 0;
+        *decide->gate = go ? 1.0 : 0.0;
+        if (decide->go_host != nullptr) *decide->go_host = go ? 1.0 : 0.0;
+      }
     }
     if (k == 0) ipm_publish(seq_dev, seq_host);
   }
@@ -494,7 +575,7 @@ __device__ __forceinline__ void ipm_error_finish(const KktDev& K, const double* 
   }
   __syncthreads();
   if (!last) return;
-  ipm_error_fold(K, V, partial, fin.n_err_blocks, true, fin.out, fin.seq_dev, fin.seq_host, tot);
+  ipm_error_fold(K, V, partial, fin.n_err_blocks, true, fin.out, fin.seq_dev, fin.seq_host, tot, &fin);
 }
 
 // this lane's share of the 23 quantities: rows t0, t0 + stride, ..., columns t0 / 8, (t0 + stride) / 8, ...
@@ -597,7 +678,14 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
   constexpr int NQ = kIpmErrQ;
   __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
   if (fin.skip != nullptr && fin.skip[0] != 0.0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ipm_publish(fin.seq_dev, fin.seq_host);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (fin.ctl != nullptr) {  // (a void chain decides nothing: whatever was enqueued behind it passes too)
+        fin.ctl->go = 0;
+        *fin.gate = 0.0;
+        if (fin.go_host != nullptr) *fin.go_host = 0.0;
+      }
+      ipm_publish(fin.seq_dev, fin.seq_host);
+    }
     return;
   }
   // fin.n_err_blocks != 0: ONE launch — the tape's separable sums (which make f) ride as extra

@@ -30,6 +30,7 @@
 #include "setup_threads.hpp"
 #include "ldlt_il_kernels.h"
 #include "tape_jit.hpp"
+#include "ipm_decide.h"
 #include "ipm_kernels.h"
 #include "tape_kernels.h"
 #include "tape_ops.h"
@@ -857,6 +858,8 @@ DeviceNlp::~DeviceNlp() {
   if (m_h_stats) (void)hipHostFree(m_h_stats);
   if (m_h_seq) (void)hipHostFree(const_cast<unsigned long long*>(m_h_seq));
   if (m_ipm_host) (void)hipHostFree(m_ipm_host);
+  if (m_ipm_ctl_host) (void)hipHostFree(m_ipm_ctl_host);
+  if (m_ipm_ctl_dev) (void)hipFree(m_ipm_ctl_dev);
   if (m_tape_stream) {
     (void)hipStreamSynchronize(m_tape_stream);
     (void)hipStreamDestroy(m_tape_stream);
@@ -1864,6 +1867,10 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
   md.this_step = m_chain_seq;
   md.delta = reg[0];  // (by value: MfDev)
   md.gamma = reg[1];
+  if (m_gate_next_step) {  // (one launch: the step enqueued before the iteration in front of it was decided)
+    md.gate = m_ipm_gate.p;
+    m_gate_next_step = false;
+  }
   const double* const reg_by_value = nullptr;
   if (twin_mode != 0) {
     const int tw_parity = m_stats_tw_cur ^ 1;
@@ -2266,8 +2273,13 @@ void DeviceNlp::ipm_enable() {
   m_s_ahead.alloc(std::max(1, s.m_i));
   m_y_ahead.alloc(std::max(1, s.m_e));
   m_z_ahead.alloc(std::max(1, s.m_i));
-  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_ipm_host), sizeof(IpmHost)));
-  std::memset(m_ipm_host, 0, sizeof(IpmHost));
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_ipm_host), 2 * sizeof(IpmHost)));
+  std::memset(m_ipm_host, 0, 2 * sizeof(IpmHost));
+  SLPX_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&m_ipm_ctl_host), 3 * sizeof(IpmCtl)));
+  for (int k = 0; k < 3; ++k) m_ipm_ctl_host[k] = IpmCtl{};
+  SLPX_HIP_CHECK(hipMalloc(&m_ipm_ctl_dev, sizeof(IpmCtl)));
+  SLPX_HIP_CHECK(hipMemset(m_ipm_ctl_dev, 0, sizeof(IpmCtl)));
+  m_ipm_gate.upload(std::vector<double>(1, 1.0));
   m_ipm = true;
 }
 
@@ -2302,7 +2314,7 @@ void DeviceNlp::wait() {
 
 void DeviceNlp::ipm_direction(double tau) {
   hipLaunchKernelGGL(ipm_direction_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V.p, m_in.p, m_s.p,
-                     m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_ipm_alpha.p, &m_ipm_host->dir);
+                     m_z.p, m_p.p, m_ps.p, m_pz.p, m_mu.p, tau, m_trial_in.p, m_ipm_alpha.p, &m_ipm_host[m_ipm_slot].dir);
   SLPX_HIP_CHECK(hipGetLastError());
 }
 
@@ -2327,7 +2339,7 @@ IpmLookaheadArgs DeviceNlp::lookahead_args(double tau, int twin_mode) {
   a.y_t = m_y_ahead.p;
   a.z_t = m_z_ahead.p;
   a.alpha_dev = m_ipm_alpha.p;
-  a.out = &m_ipm_host->dir;
+  a.out = &m_ipm_host[m_ipm_slot].dir;
   a.stats = m_stats.p + static_cast<size_t>(m_stats_cur) * m_batch;
   if (twin_mode != 0) {  // (a twin launch: the kernel takes the direction of the attempt the policy takes)
     a.tw.mode = twin_mode;
@@ -2379,7 +2391,7 @@ void DeviceNlp::ipm_trial_point(double alpha) {
 
 void DeviceNlp::ipm_trial_metrics(double alpha, bool s_from_ci) {
   hipLaunchKernelGGL(ipm_trial_metrics_kernel, dim3(1), dim3(kIpmThreads), 0, m_stream, m_kdev, m_V_trial.p,
-                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host->trial, m_seq_dev.p, m_h_seq,
+                     m_s.p, m_ps.p, alpha, m_ipm_alpha.p, s_from_ci ? 1 : 0, &m_ipm_host[m_ipm_slot].trial, m_seq_dev.p, m_h_seq,
                      m_reduces.p, static_cast<int>(m_reduces.n), m_scales.p);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
@@ -2409,7 +2421,13 @@ void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride, bool ahead) {
   fin.tape_scales = m_scales.p;
   fin.Vw = ahead ? m_V_trial.p : m_V.p;
   fin.done = m_ipm_err_done.p;
-  fin.out = ahead ? &m_ipm_host->err_ahead : &m_ipm_host->err;
+  fin.out = ahead ? &m_ipm_host[m_ipm_slot].err_ahead : &m_ipm_host[m_ipm_slot].err;
+  if (ahead && m_errors_decide) {
+    fin.ctl = static_cast<IpmCtl*>(m_ipm_ctl_dev);
+    fin.dir = m_ipm_alpha.p;
+    fin.gate = m_ipm_gate.p;
+    fin.go_host = &m_ipm_host[m_ipm_slot].go;
+  }
   fin.seq_dev = m_seq_dev.p;
   fin.seq_host = m_h_seq;
   fin.skip = ahead ? m_ipm_alpha.p + 2 : nullptr;
@@ -2418,6 +2436,46 @@ void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride, bool ahead) {
                      ahead ? m_z_ahead.p : m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0, m_ipm_partial.p, fin);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+void DeviceNlp::ipm_errors_deciding(bool sums_ride) {
+  m_errors_decide = true;
+  ipm_errors(false, sums_ride, /*ahead=*/true);
+  m_errors_decide = false;
+}
+
+// (only the used part of the filter's table travels, either way)
+static size_t ipm_ctl_bytes(const IpmCtl& c) { return offsetof(IpmCtl, filter) + offsetof(FilterState, ent) + 16u * static_cast<size_t>(c.filter.n); }
+void DeviceNlp::ipm_pipeline_upload(const IpmCtl& ctl) {
+  m_ipm_ctl_stage = 1 + (m_ipm_ctl_stage & 1);  // (1, 2, 1, ...: the copy of the upload before this one has long run)
+  IpmCtl& stage = m_ipm_ctl_host[m_ipm_ctl_stage];
+  std::memcpy(&stage, &ctl, ipm_ctl_bytes(ctl));
+  SLPX_HIP_CHECK(hipMemcpyAsync(m_ipm_ctl_dev, &stage, ipm_ctl_bytes(ctl), hipMemcpyHostToDevice, m_stream));
+}
+const IpmCtl& DeviceNlp::ipm_pipeline_fetch() {
+  IpmCtl& into = m_ipm_ctl_host[0];
+  // (the head says how long the table is)
+  SLPX_HIP_CHECK(hipMemcpyAsync(&into, m_ipm_ctl_dev, offsetof(IpmCtl, filter) + offsetof(FilterState, ent), hipMemcpyDeviceToHost, m_stream));
+  SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  if (into.filter.n > 0) {
+    SLPX_HIP_CHECK(hipMemcpyAsync(into.filter.ent, static_cast<const char*>(m_ipm_ctl_dev) + offsetof(IpmCtl, filter) + offsetof(FilterState, ent),
+                                  16u * static_cast<size_t>(into.filter.n), hipMemcpyDeviceToHost, m_stream));
+    SLPX_HIP_CHECK(hipStreamSynchronize(m_stream));
+  }
+  return into;
+}
+
+void DeviceNlp::wait_published_until(unsigned long long seq) {
+  unsigned spins = 0;
+  while (*m_h_seq < seq) {
+    if ((++spins & 0xfffu) == 0) {
+      const hipError_t st = hipStreamQuery(m_stream.raw());
+      if (st != hipErrorNotReady) {
+        SLPX_HIP_CHECK(st);
+        if (*m_h_seq < seq) throw std::runtime_error("slpx: chain finished without publishing");
+      }
+    }
+  }
 }
 
 void DeviceNlp::ipm_soc_accumulate(double alpha, bool first, bool s_from_ci) {

@@ -58,7 +58,14 @@ struct MfDev {
   // array the batch kernels share, delta and gamma were a trip over PCIe at the top of every workgroup, waited for
   // with the task's descriptors (scalar loads return together)
   double delta = 0.0, gamma = 0.0;
+  // A step enqueued BEFORE the iteration in front of it was decided (ipm.cpp: the pipelined common iteration): the launch
+  // that decides (ipm_error_partial_kernel's fold) leaves 1.0 here for "run" and 0.0 for "pass" — every workgroup then
+  // leaves at once, the first one handing the host a marker in place of the counters.  null: an ordinary launch.
+  const double* gate = nullptr;
 };
+
+// n_bad of the marker a passed launch publishes (nothing was factored; the host restores its launch bookkeeping)
+constexpr int32_t kLdltPassed = 1 << 29;
 
 // the sweep this step reads is complete (one lane asks; the workgroup's other waves come through the barrier):
 // every workgroup of the chained sweeps so far has counted itself out — Mf.wait_step of them, the host's running
@@ -514,6 +521,18 @@ __device__ __forceinline__ void mf_step_body(
     double* __restrict__ xg_next, double* __restrict__ out, const BacksubFuse& B, uint32_t block, unsigned int exit_total,
     const LdltStats* twin_stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (Mf.gate != nullptr && Mf.gate[0] == 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && B.stats_host != nullptr) {
+      B.stats_host[0] = LdltStats{0, 0, 0, kLdltPassed, 0x7ff0000000000000ull};
+      if (B.seq_host != nullptr) {
+        __threadfence_system();
+        const unsigned long long v = *B.seq_dev + 1;
+        *B.seq_dev = v;
+        *B.seq_host = v;
+      }
+    }
+    return;
+  }
   if (static_cast<int>(block) < F.n_blocks) {
     if constexpr (CHAINED) mf_wait_for_sweep(Mf, stats);
     ride_along_sum(F, block, smem_raw);

@@ -374,6 +374,41 @@ std::vector<FactorInfo> NewtonSystem::compute_impl(int mode) {
 // policy's order from their own counters, so the sequence of (delta, gamma) tried, the one accepted and the count of
 // factorizations are the sequential loop's; a second attempt the policy would not have made next is ignored.
 // ipm_lookahead_kernel makes the same choice on the device from the same counters: keep the two in step.
+NewtonSystem::TwinLaunch NewtonSystem::twin_first_launch() const {
+  const double eps = std::numeric_limits<double>::epsilon();
+  const double d = m_prev_delta[0] == 0.0 ? 1e-4 : std::max(m_prev_delta[0] / 2.0, eps);  // :95-98
+  const double g = m_gamma_min;                                                             // :102
+  const bool skip_first = m_opt.skip_structurally_singular_attempt && m_l.structurally_singular_unregularized;
+  if (!skip_first) return TwinLaunch{0.0, 0.0, d, g, 2};
+  if (m_twin_expect == 3) return TwinLaunch{d, g, d, g == 0.0 ? 1e-10 : g * 10.0, 3};
+  return TwinLaunch{d, g, d * 10.0, g, 1};
+}
+
+bool NewtonSystem::begin_speculative_compute() {
+  if (m_spec.valid || m_opt.batch != 1 || !m_twin_attempts || !m_dev->twin_available()) return false;
+  const TwinLaunch tl = twin_first_launch();
+  const DeviceNlp::LaunchBook book = m_dev->save_book();
+  m_dev->build_kkt_for_step(/*with_reduce=*/false);
+  m_dev->ipm_gate_next_step(true);
+  if (!m_dev->factor_solve_publish_twin(tl.d0, tl.g0, tl.d1, tl.g1, tl.mode)) {
+    m_dev->ipm_gate_next_step(false);
+    m_dev->restore_book(book);
+    return false;
+  }
+  if (m_after_attempt) m_after_attempt();
+  m_spec.valid = true;
+  m_spec.have_second = true;
+  m_spec.launch = tl;
+  m_spec.book = book;
+  return true;
+}
+
+void NewtonSystem::cancel_speculative_compute() {
+  if (!m_spec.valid) return;
+  m_dev->restore_book(m_spec.book);
+  m_spec.valid = false;
+}
+
 std::vector<FactorInfo> NewtonSystem::compute_twin() {
   const int n = m_s.n, m_e = m_s.m_e;
   std::vector<FactorInfo> info(1, FactorInfo::Success);
@@ -401,7 +436,16 @@ std::vector<FactorInfo> NewtonSystem::compute_twin() {
       if (m_after_attempt) m_after_attempt();
       m_dev->read_stats(stats);
     };
-    once();
+    if (m_spec.valid) {
+      // this launch — the policy's first of this compute — was made ahead (begin_speculative_compute) and has run
+      if (m_spec.launch.d0 != d0 || m_spec.launch.g0 != g0 || m_spec.launch.d1 != d1 || m_spec.launch.g1 != g1 || m_spec.launch.mode != mode)
+        throw std::runtime_error("slpx: the step enqueued ahead is not the one the regularization policy makes");
+      m_spec.valid = false;
+      have_second = m_spec.have_second;
+      m_dev->read_stats(stats);
+    } else {
+      once();
+    }
     // (a chained step that lost its hand-over — compute_impl's factor(): redone unchained from a fresh sweep.
     // A twin launch itself is never chained, the single-attempt fallback above can be.)
     if ((stats[0].n_bad & kLdltChainFailure) != 0) {

@@ -125,6 +125,14 @@ class NewtonSystem {
   // direction of whichever attempt the policy takes ON THE DEVICE (DeviceNlp::ipm_lookahead does), and whose system is
   // the one the device's V, s, y, z describe (build_kkt_for_step — later launches of the loop evaluate it again).
   void set_twin_attempts(bool on) { m_twin_attempts = on; }
+  // The first launch of the NEXT compute(true) — the policy's attempt and its twin, with the after_attempt chain behind
+  // it — enqueued now, BEFORE the host knows whether that step will be wanted: the launch waits for the word the error
+  // launch in front of it leaves (DeviceNlp::ipm_gate_next_step) and passes if the iteration was not decided on the
+  // device.  The compute(true) that follows takes the launch as its first; cancel_speculative_compute() puts the
+  // launch bookkeeping back when the device let it pass.  false: not possible now (no launch was made).
+  bool begin_speculative_compute();
+  void cancel_speculative_compute();
+  bool speculative_compute_pending() const { return m_spec.valid; }
   // launches with two attempts since construction, by what the first attempt showed: accepted; the failure the
   // second attempt stood for, and the second accepted / not; zero pivots; the other inertia failure; the
   // factorization itself failed
@@ -156,6 +164,16 @@ class NewtonSystem {
   long m_twin_hist[6] = {0, 0, 0, 0, 0, 0};
   int m_twin_expect = 1;  // what the loop's first attempt drew last time (compute_twin): 1 negative pivots, 3 positive
   std::vector<FactorInfo> compute_twin();
+  struct TwinLaunch {
+    double d0, g0, d1, g1;
+    int mode;
+  };
+  TwinLaunch twin_first_launch() const;  // what compute_twin's first launch is, from the policy's memory
+  struct Speculative {
+    bool valid = false, have_second = false;
+    TwinLaunch launch{};
+    DeviceNlp::LaunchBook book{};
+  } m_spec;
   std::vector<int32_t> m_user_lhs_map;
 };
 

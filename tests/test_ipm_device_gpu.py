@@ -298,3 +298,35 @@ def test_twin_attempts_follow_the_sequential_policy_bit_for_bit(name, make, capf
             assert taken > 0, lines
     print(f"{name}: {rep_t['iterations']} iterations, {rep_t['factorizations']} factorizations, {launches} twin launches, "
           f"second attempt taken {taken} times")
+
+
+@pytest.mark.parametrize("name,make", [
+    ("cart_pole_50", lambda: models.cart_pole(50, 0.1)),
+    ("cart_pole_100", lambda: models.cart_pole(100, 0.05)),     # restoration on the way
+    ("cart_pole_300", lambda: models.cart_pole(300, 5.0 / 300)),
+    ("cart_pole_1000", lambda: models.cart_pole(1000, 5.0 / 1000)),  # 512-thread twin launches, restoration, a long filter
+    ("flywheel_50", lambda: models.flywheel(50, 0.005)),
+])
+def test_iterations_decided_on_the_device_are_the_hosts_bit_for_bit(name, make, capfd):
+    """The common iteration's decisions — the filter's acceptance of the full step (util/filter.hpp:109-172), the
+    exits and the barrier test of interior_point.hpp:387-408 and :809-832 — taken by the launch that reduces the
+    look-ahead iterate's norms (ipm_decide.h, ipm_error_fold), with the next step enqueued behind it before the host
+    has seen anything: the iterates, the iteration count and the factorization count are those of the host deciding
+    every iteration (SLPX_IPM_PIPELINE=0), to the bit, and most iterations ARE decided on the device."""
+    capfd.readouterr()
+    st_p, rep_p, x_p, duals_p = _solve_with_env(make, SLPX_TWIN_VERBOSE="1")
+    err = capfd.readouterr().err
+    st_h, rep_h, x_h, duals_h = _solve_with_env(make, SLPX_IPM_PIPELINE="0")
+    assert st_p == st_h
+    assert rep_p["iterations"] == rep_h["iterations"] and rep_p["factorizations"] == rep_h["factorizations"]
+    assert rep_p["restorations"] == rep_h["restorations"]
+    assert np.array_equal(x_p, x_h)
+    for a, b in zip(duals_p, duals_h):
+        assert np.array_equal(a, b)
+    lines = [l for l in err.splitlines() if l.startswith("slpx pipelined iterations:")]
+    assert lines or cases.OUTER_SWITCHES, err
+    decided = sum(int(l.split()[3]) for l in lines)
+    passed = sum(int(l.split("the device,")[1].split()[0]) for l in lines)
+    if not cases.OUTER_SWITCHES and os.environ.get("SLPX_IPM_PIPELINE") != "0":
+        assert decided >= (rep_p["iterations"] - rep_p["restoration_iterations"]) // 2, lines
+    print(f"{name}: {rep_p['iterations']} iterations, {decided} decided on the device, {passed} steps enqueued ahead let pass")

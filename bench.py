@@ -399,8 +399,7 @@ def main():
         }
         # A single problem's step is two launches (the AD sweep; KKT evaluation + factorization +
         # backward solve + back-substitution in one: csrc/device.hpp KktFuse / BacksubFuse,
-        # ldlt_mf_step_kernel — the multifrontal step — or, SLPX_LDLT_MF=0, the pair-list
-        # ldlt_factor_solve_kernel); the second one's algorithmic bytes are the SURVEY.md §8d
+        # ldlt_mf_step_kernel, the multifrontal step); the second one's algorithmic bytes are the SURVEY.md §8d
         # figures of the stages it performs.  `groups` (the stages as kernels of their own)
         # stays in the line as per_kernel_ms: it is what batches run and what the step falls
         # back to when the launch cannot be used.
@@ -425,7 +424,7 @@ def main():
         if tfile.exists() and args.workload == "single" and N == 1000 and B == 1:
             tj = json.loads(tfile.read_text())
             prefix = {"tape_sweep": ("tape_sweep", "slpx_tape_templates"),
-                      "kkt_factor_solve": ("ldlt_mf_step_kernel", "ldlt_factor_solve_kernel"),
+                      "kkt_factor_solve": ("ldlt_mf_step_kernel",),
                       "kkt_assemble": "kkt_assemble_kernel",
                       "kkt_rhs": "kkt_rhs_kernel", "ldlt_factor": "ldlt_factor_kernel",
                       "ldlt_solve": ("ldlt_fwd", "ldlt_bwd", "ldlt_mf_solve_kernel")}
@@ -444,7 +443,7 @@ def main():
         single = args.workload in ("single", "gfold") and B == 1
         roofline = {
             "bound": "hbm", "kernel": dom,
-            "kernel_symbol": (("ldlt_mf_step_kernel<.., false>" if fused.get("multifrontal") else "ldlt_factor_solve_kernel")
+            "kernel_symbol": ("ldlt_mf_step_kernel<.., false>"
                               if fused is not None and dom.startswith("kkt_factor") and fused["one_launch"] else None),
             "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -315,7 +315,7 @@ int slpx_ipm_errors(slpx_system* s, const double* error_scales, double* out24);
 int slpx_system_time_step(slpx_system* s, int iters, int refresh_ad, float* ms);
 
 /* The same for the launches a single problem's Newton step actually makes (device.hpp: KktFuse,
- * BacksubFuse, ldlt_factor_solve_kernel): ms[4] = {AD sweep launch, the launch that evaluates the
+ * BacksubFuse, ldlt_mf_step_kernel): ms[4] = {AD sweep launch, the launch that evaluates the
  * KKT system, factorizes, solves and back-substitutes (first attempt of the policy loop's
  * settled regularization), their sum, 1 if that single launch exists for this system — 0: the
  * step is made of the kernels slpx_system_time_step times and ms[1] is their sum} */

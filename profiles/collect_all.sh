@@ -39,9 +39,9 @@ for CFG in "N5000:--N 5000" "gfold:--workload gfold" "b64xN500:--workload batch5
   cp profiles/${TAG}_${NAME}_kernel_stats.csv profiles/${TAG}_${NAME}_traffic.json $N/
   rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 done
-# 4. phase clocks inside the LDLT kernels and the latency microbenchmarks
-# (the step kernel of the fronts keeps its clocks in LDS in a library built for it: profiles/ldlt_clocks.sh; a whole
-# launch as a timeline of all its tasks, one chained step as a timeline of both kernels, the host's slack)
+# 4. phase clocks inside the LDLT kernels and the latency microbenchmarks: COLLECT_CLOCKS=1 (r06 leaves the step kernel
+# and the batch kernels as they were: the r05_* files of this section stand)
+if [ "${COLLECT_CLOCKS:-0}" = "1" ]; then
 set +x
 bash profiles/ldlt_clocks.sh $TAG 1000 5000 > /dev/null 2>&1
 cp $O/${TAG}_ldlt_clocks.txt $N/${TAG}_ldlt_clocks.txt
@@ -64,11 +64,12 @@ PYTHONPATH=$R python profiles/mf_front_stats.py 1000 > $N/${TAG}_mf_front_stats.
 set -x
 PYTHONPATH=$R python profiles/il_clocks.py 1000 512 > $N/${TAG}_il_clocks.txt 2>&1
 for B in latency icache chain front; do [ -x profiles/microbench/${B}_bin ] && ./profiles/microbench/${B}_bin > $N/${TAG}_microbench_$B.txt 2>&1; done
+fi
 PYTHONPATH=$R python profiles/setup_time.py 1000 5000 100 300 500 2>&1 | grep -v "tape family\|row group\|chunk\|tape: " > $N/${TAG}_setup_time.txt
 # 5. whole solves over the BASELINE horizons; the launch-fusion switches one by one
 PYTHONPATH=$R timeout 600 python profiles/horizon_sweep.py > $N/${TAG}_horizon_sweep.txt 2>&1
 bash profiles/ab_fuse.sh > $N/${TAG}_fusion_ab.txt 2>&1
-for v in all nosolve none; do cp $O/timeline_$v.txt $N/${TAG}_step_timeline_fuse_$v.txt; done
+for v in all none; do cp $O/timeline_$v.txt $N/${TAG}_step_timeline_fuse_$v.txt; done
 # 6. the multifrontal step against the pair-list kernels it replaces, and the matrix-core path (g-fold)
 {
   for W in "1000" "5000" "500" "gfold"; do
@@ -88,8 +89,10 @@ python profiles/mfma_counters.py $O/pmc_mfma > $N/${TAG}_gfold_mfma.json 2>> $O/
 rm -rf $O/pmc_mfma
 # 7. the round's measured experiments that stayed behind switches, and the small-batch probe
 bash profiles/chain_ab.sh > $N/${TAG}_chain_ab.txt 2>&1
+if [ "${COLLECT_CLOCKS:-0}" = "1" ]; then
 [ -x profiles/microbench/anyorder_bin ] && ./profiles/microbench/anyorder_bin > $N/${TAG}_microbench_anyorder.txt 2>&1
 [ -x profiles/microbench/launch_gap_bin ] && ./profiles/microbench/launch_gap_bin > $N/${TAG}_microbench_launch_gap.txt 2>&1
+fi
 bash profiles/b64_probe.sh > $N/${TAG}_b64_probe.txt 2>&1
 tail -5 $O/collect.log
 # 8. (r04) the parity record of the timed kernels, the interior-point iteration: A/B of the look-ahead chain and
@@ -99,6 +102,16 @@ bash profiles/solve_ab.sh > $N/${TAG}_solve_ab.txt 2>&1
 bash profiles/solve_kernel_stats.sh 500 $O/solve_prof > /dev/null 2>&1
 cp $O/solve_prof/solve500_kernel_stats.csv $N/${TAG}_solve500_kernel_stats.csv
 cp $O/solve_prof/solve500_timeline.txt $N/${TAG}_solve500_timeline.txt
+bash profiles/solve_kernel_stats.sh 1000 $O/solve_prof1000 > /dev/null 2>&1
+cp $O/solve_prof1000/solve1000_kernel_stats.csv $N/${TAG}_solve1000_kernel_stats.csv
+cp $O/solve_prof1000/solve1000_timeline.txt $N/${TAG}_solve1000_timeline.txt
+# (r06) the common iteration with the host deciding (SLPX_IPM_PIPELINE=0) and with the device: launch by launch
+bash profiles/pipeline_trace.sh 300 > /dev/null 2>&1
+for v in 0 1; do cp $O/pipeline_trace_$v.txt $N/${TAG}_pipeline_trace_$v.txt; done
+# (r06) the setup phase by phase (SLPX_SETUP_TIMING=1), warm caches
+for NN in 1000 5000; do
+  echo "== N=$NN"; SLPX_SETUP_TIMING=1 PYTHONPATH=$R python profiles/setup_time.py $NN 2>&1 | grep -v "tape family\|row group\|chunk\|tape: " | tail -60
+done > $N/${TAG}_setup_phases.txt 2>&1
 # (r05) the forward error of the step kernel over 24 seeded states; a new right-hand side through the fronts against the pair lists
 PYTHONPATH=$R timeout 900 python profiles/forward_error_sweep.py gpu 1000 24 > $N/${TAG}_forward_error_sweep_gpu.txt 2>&1
 PYTHONPATH=$R timeout 300 python profiles/mf_solve_time.py 100 500 1000 5000 > $N/${TAG}_mf_solve_time.txt 2>&1

@@ -325,16 +325,6 @@ struct IpmLookaheadArgs {
   IpmTwin tw;
 };
 
-// ldlt_factor_solve_kernel (ldlt_kernels.h): what the backward solve needs to run on the
-// factorization's LDS instead of on L and z in memory.
-struct SolveInPlace {
-  const LdltSolveItem* bwd_items_u = nullptr;  // bwd_items with lpos replaced by the task-local entry of U
-  const uint32_t* col_zent = nullptr;          // per column: the entry of U that is its right-hand-side row
-  uint32_t bwd_lds_off = 0;                    // where the solve's carve-up starts
-  unsigned int n_tasks = 0;
-  unsigned int* exit_cnt = nullptr;            // workgroups through their exit phase (the last one publishes)
-};
-
 // Scalars the interior-point iteration kernels (ipm_kernels.h) hand to the host; the
 // three blocks live side by side in pinned host memory and are written by the kernels.
 struct IpmDirOut {
@@ -662,7 +652,7 @@ class DeviceNlp {
   bool m_fuse_launches = false;       // KKT assembly inside the factorization launch, back-substitution inside the solve's
   bool m_defer_kkt = false;           // build_kkt() only notes the request ...
   int m_kkt_pending = 0;              // ... for enqueue_factor (1: lhs + rhs, 2: + the tape's sums)
-  bool m_fuse_solve = false;          // ldlt_factor_solve_kernel (SLPX_FUSE_SOLVE)
+  bool m_fuse_solve = false;          // factorization and solve of a step in one launch (ldlt_mf_step_kernel)
   // backward solve: x of finished columns handed to the descendants through the values (two
   // buffers, the solves alternate)
   bool m_xg_by_data = false;
@@ -676,22 +666,16 @@ class DeviceNlp {
   void xg_flip() {
     if (m_xg_by_data) m_xg_parity ^= 1;
   }
-  DevBuf<LdltSolveItem> m_bwd_items_u;
-  DevBuf<uint32_t> m_col_zent;
   DevBuf<unsigned int> m_exit_cnt;
-  SolveInPlace m_sip;
-  void build_solve_in_place(const LdltPlan& l);
   void enqueue_factor_solve(int parity);
   KktFuse take_kkt_fuse();
   BacksubFuse backsub_fuse(const LdltStats* publish);
-  uint32_t m_factor_solve_lds = 0;
   // multifrontal step (ldlt_mf_kernels.h: ldlt_mf_step_kernel; SLPX_LDLT_MF=0: the pair lists)
   bool m_mf = false;
   bool m_mf_solve = false;  // a new right-hand side goes through the fronts too (ldlt_mf_solve_kernel; SLPX_MF_SOLVE=0: the pair lists)
   bool m_mf_mfma = false;             // the plan has fronts on the matrix cores: the kernel variant with that path
   int m_mf_threads = 1024;            // 512 where the 1024-thread workgroups of every task are not resident at once
   int m_twin_threads = 1024;          // ... of a launch of two attempts (twin_available)
-  bool m_sip_ok = false;              // the pair-list one-launch kernel is usable too (build_solve_in_place)
   uint32_t m_mf_lds = 0;
   // host copies of the inline KKT / back-substitution plans (build_mf packs them into the task images)
   std::vector<int32_t> m_h_vsrc;

@@ -140,29 +140,20 @@ class Filter {
     m_last_rejection_due_to_filter = false;
   }
   bool try_add(const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha) {
-    if (!std::isfinite(trial.cost) || trial.constraint_violation > max_constraint_violation) return false;
-    const bool switching = D_phi < 0.0 && alpha * std::pow(-D_phi, 2.3) > std::pow(cur.constraint_violation, 1.1);
-    const bool armijo = trial.cost <= cur.cost + 1e-8 * alpha * D_phi;
-    const double phi = std::pow(alpha, 1.5);
-    const bool sufficient = trial.cost <= cur.cost - phi * kGammaCost * cur.constraint_violation ||
-                            trial.constraint_violation <= (1.0 - phi * kGammaCon) * cur.constraint_violation;
-    if (cur.constraint_violation <= min_constraint_violation && switching) {
-      if (!armijo) {
-        m_last_rejection_due_to_filter = false;
-        return false;
-      }
-    } else if (!sufficient) {
-      m_last_rejection_due_to_filter = false;
-      return false;
-    }
+    // the rules: ipm_decide.h (one source for this driver and for the launch that decides the common iteration)
+    FilterEntry add;
+    bool insert = false;
+    int last = m_last_rejection_due_to_filter ? 1 : 0;
+    const int through = filter_rules(min_constraint_violation, max_constraint_violation, &last, cur, trial, D_phi, alpha,
+                                     filter_powers(cur, D_phi, alpha), &add, &insert);
+    m_last_rejection_due_to_filter = last != 0;
+    if (!through) return false;
     for (auto& e : m_filter)
       if (dominated_by(trial, e)) {
         m_last_rejection_due_to_filter = true;
         return false;
       }
-    if (!switching || !armijo) {
-      FilterEntry add{cur.cost - phi * kGammaCost * cur.constraint_violation,
-                      (1.0 - phi * kGammaCon) * cur.constraint_violation};
+    if (insert) {
       m_filter.erase(std::remove_if(m_filter.begin(), m_filter.end(),
                                     [&](const FilterEntry& e) { return dominated_by(e, add); }),
                      m_filter.end());
@@ -193,7 +184,6 @@ class Filter {
   }
 
  private:
-  static constexpr double kGammaCost = 1e-8, kGammaCon = 1e-5;
   std::vector<FilterEntry> m_filter;
   bool m_last_rejection_due_to_filter = false;
 };

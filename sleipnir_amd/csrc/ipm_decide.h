@@ -27,7 +27,8 @@ SLPX_DECIDE bool filter_dominated_by(const FilterEntry& a, const FilterEntry& e)
 }
 
 // filter.hpp:62-212 as a value: the entries in the order they were added, (cost, violation) pairs.  (A full table turns
-// the device's decisions off, never the filter: the host driver keeps a vector of its own.)
+// the device's decisions off, never the filter: the host driver keeps a vector of its own, Filter in ipm.cpp, and
+// applies the same filter_rules() to it.)
 constexpr int kFilterCapacity = 1024;
 struct FilterState {
   double min_constraint_violation = 0.0, max_constraint_violation = 0.0;
@@ -38,14 +39,26 @@ struct FilterState {
 
 constexpr double kFilterGammaCost = 1e-8, kFilterGammaCon = 1e-5;
 
-// filter.hpp:109-172 up to the table itself: 0 rejected (switching / Armijo / sufficient-decrease rules; F's rejection
+// The three powers of the filter's rules (filter.hpp:118-131).  The host takes them one after the other; the device
+// deals them to three lanes of the deciding wave — one pass through pow() instead of three (ipm_kernels.h).
+struct FilterPowers {
+  double dphi_23 = 0.0;   // (-D_phi)^2.3   (used only where D_phi < 0)
+  double viol_11 = 0.0;   // (current constraint violation)^1.1
+  double alpha_15 = 0.0;  // alpha^1.5
+};
+SLPX_DECIDE FilterPowers filter_powers(const FilterEntry& cur, double D_phi, double alpha) {
+  return FilterPowers{pow(-D_phi, 2.3), pow(cur.constraint_violation, 1.1), pow(alpha, 1.5)};
+}
+
+// filter.hpp:109-172 up to the table itself: 0 rejected (switching / Armijo / sufficient-decrease rules; the rejection
 // flag cleared as the reference does), 1 goes on to the table.  `add`: the entry an acceptance would insert, if *insert.
 SLPX_DECIDE int filter_rules(double min_constraint_violation, double max_constraint_violation, int* last_rejection_due_to_filter,
-                             const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha, FilterEntry* add, bool* insert) {
+                             const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha, const FilterPowers& pw,
+                             FilterEntry* add, bool* insert) {
   if (!ipm_isfinite(trial.cost) || trial.constraint_violation > max_constraint_violation) return 0;
-  const bool switching = D_phi < 0.0 && alpha * pow(-D_phi, 2.3) > pow(cur.constraint_violation, 1.1);
+  const bool switching = D_phi < 0.0 && alpha * pw.dphi_23 > pw.viol_11;
   const bool armijo = trial.cost <= cur.cost + 1e-8 * alpha * D_phi;
-  const double phi = pow(alpha, 1.5);
+  const double phi = pw.alpha_15;
   const bool sufficient = trial.cost <= cur.cost - phi * kFilterGammaCost * cur.constraint_violation ||
                           trial.constraint_violation <= (1.0 - phi * kFilterGammaCon) * cur.constraint_violation;
   if (cur.constraint_violation <= min_constraint_violation && switching) {
@@ -59,38 +72,6 @@ SLPX_DECIDE int filter_rules(double min_constraint_violation, double max_constra
   }
   *insert = !switching || !armijo;
   *add = FilterEntry{cur.cost - phi * kFilterGammaCost * cur.constraint_violation, (1.0 - phi * kFilterGammaCon) * cur.constraint_violation};
-  return 1;
-}
-
-// ... and the table, entry by entry (the host's way; the device deals the entries to the lanes of a wave:
-// ipm_kernels.h).  Returns 1 accepted, 0 rejected, -1: accepted but the table is full (nothing was changed).
-SLPX_DECIDE int filter_try_add(FilterState& F, const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha) {
-  FilterEntry add;
-  bool insert = false;
-  if (filter_rules(F.min_constraint_violation, F.max_constraint_violation, &F.last_rejection_due_to_filter, cur, trial, D_phi, alpha, &add,
-                   &insert) == 0)
-    return 0;
-  for (int k = 0; k < F.n; ++k)
-    if (filter_dominated_by(trial, FilterEntry{F.ent[2 * k], F.ent[2 * k + 1]})) {
-      F.last_rejection_due_to_filter = 1;
-      return 0;
-    }
-  if (insert) {
-    int kept = 0;
-    for (int k = 0; k < F.n; ++k)
-      if (!filter_dominated_by(FilterEntry{F.ent[2 * k], F.ent[2 * k + 1]}, add)) ++kept;
-    if (kept >= kFilterCapacity) return -1;
-    int w = 0;
-    for (int k = 0; k < F.n; ++k)
-      if (!filter_dominated_by(FilterEntry{F.ent[2 * k], F.ent[2 * k + 1]}, add)) {
-        F.ent[2 * w] = F.ent[2 * k];
-        F.ent[2 * w + 1] = F.ent[2 * k + 1];
-        ++w;
-      }
-    F.ent[2 * w] = add.cost;
-    F.ent[2 * w + 1] = add.constraint_violation;
-    F.n = w + 1;
-  }
   return 1;
 }
 

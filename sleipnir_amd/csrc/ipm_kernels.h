@@ -449,6 +449,37 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
   // flight each, then the slices are combined in slice order (fixed order: the same bits run after run)
   const int q = threadIdx.x & 31, sl = threadIdx.x >> 5;
   double* part = tot + NQ;  // [8][NQ]
+  // (a deciding fold: what the decisions read of the iteration's state on the device — its scalars, the first two
+  // filter entries of every lane — is asked for NOW, by the wave that will decide, and arrives while the partials are
+  // folded: one trip to memory instead of three dependent ones behind the fold)
+  const bool deciding = decide != nullptr && decide->ctl != nullptr && threadIdx.x < 64;
+  IpmCtl head;  // (the scalars only: the table stays where it is)
+  double cur_f = 0.0, cur_logsum = 0.0, cur_viol = 0.0, f_min_cv = 0.0, f_max_cv = 0.0, alpha_max = 0.0, D_phi = 0.0;
+  double ent_pre[4] = {0.0, 0.0, 0.0, 0.0};
+  int n_ent = 0, last_rej = 0;
+  if (deciding) {
+    const IpmCtl* C = decide->ctl;
+    head.mu = C->mu;
+    head.mu_min = C->mu_min;
+    head.tolerance = C->tolerance;
+    head.m_e = C->m_e;
+    head.m_i = C->m_i;
+    head.identity_scaling = C->identity_scaling;
+    cur_f = C->cur_f;
+    cur_logsum = C->cur_logsum;
+    cur_viol = C->cur_viol;
+    f_min_cv = C->filter.min_constraint_violation;
+    f_max_cv = C->filter.max_constraint_violation;
+    n_ent = C->filter.n;
+    last_rej = C->filter.last_rejection_due_to_filter;
+    alpha_max = decide->dir[0];
+    D_phi = decide->dir[3];
+    const int k = threadIdx.x;
+    ent_pre[0] = C->filter.ent[2 * k];  // (within the table whatever n is: kFilterCapacity >= 128)
+    ent_pre[1] = C->filter.ent[2 * k + 1];
+    ent_pre[2] = C->filter.ent[2 * (k + 64)];
+    ent_pre[3] = C->filter.ent[2 * (k + 64) + 1];
+  }
   if (q < NQ && sl < 8) {
     int op = ops[0];
 #pragma unroll
@@ -498,28 +529,33 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
       IpmErrOut e;
       for (int q = 0; q < 24; ++q) reinterpret_cast<double*>(&e)[q] = fin[q];
       IpmCtl* C = decide->ctl;
-      IpmCtl head;  // (the scalars only: the table stays where it is)
-      head.mu = C->mu;
-      head.mu_min = C->mu_min;
-      head.tolerance = C->tolerance;
-      head.m_e = C->m_e;
-      head.m_i = C->m_i;
-      head.identity_scaling = C->identity_scaling;
-      const double alpha_max = decide->dir[0], D_phi = decide->dir[3];
       bool go = ipm_next_iteration_is_plain(head, e, alpha_max);
+      // (the wave is uniform in `go`: every lane holds the same scalars)
       if (go) {
-        const FilterEntry current{C->cur_f - head.mu * C->cur_logsum, C->cur_viol};
+        const FilterEntry current{cur_f - head.mu * cur_logsum, cur_viol};
         const FilterEntry trial{e.f - head.mu * e.logsum, e.viol};
+        // the rules' three powers by three lanes at once (ipm_decide.h: FilterPowers)
+        const double base = k == 0 ? -D_phi : (k == 1 ? current.constraint_violation : alpha_max);
+        const double expo = k == 0 ? 2.3 : (k == 1 ? 1.1 : 1.5);
+        const double pw_lane = k < 3 ? pow(base, expo) : 0.0;
+        const FilterPowers pw{__shfl(pw_lane, 0), __shfl(pw_lane, 1), __shfl(pw_lane, 2)};
         FilterEntry add;
         bool insert = false;
-        int last_rej = C->filter.last_rejection_due_to_filter;
-        const int n_ent = C->filter.n;
         double* ent = C->filter.ent;
-        go = filter_rules(C->filter.min_constraint_violation, C->filter.max_constraint_violation, &last_rej, current, trial, D_phi, alpha_max,
-                          &add, &insert) != 0;
+        go = filter_rules(f_min_cv, f_max_cv, &last_rej, current, trial, D_phi, alpha_max, pw, &add, &insert) != 0;
         if (go) {
           bool dominated = false, removes = false;
-          for (int q = k; q < n_ent; q += 64) {
+          if (k < n_ent) {
+            const FilterEntry en{ent_pre[0], ent_pre[1]};
+            dominated = filter_dominated_by(trial, en);
+            removes = filter_dominated_by(en, add);
+          }
+          if (k + 64 < n_ent) {
+            const FilterEntry en{ent_pre[2], ent_pre[3]};
+            dominated = dominated || filter_dominated_by(trial, en);
+            removes = removes || filter_dominated_by(en, add);
+          }
+          for (int q = k + 128; q < n_ent; q += 64) {
             const FilterEntry en{ent[2 * q], ent[2 * q + 1]};
             dominated = dominated || filter_dominated_by(trial, en);
             removes = removes || filter_dominated_by(en, add);

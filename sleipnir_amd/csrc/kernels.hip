@@ -676,15 +676,11 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   lap("    images: inline KKT terms");
   if (m_fuse_backsub) build_inline_backsub(k, l);
   lap("    images: back-substitution rows");
-  m_fuse_solve = m_fuse_launches && m_fuse_backsub;
-  if (const char* env = std::getenv("SLPX_FUSE_SOLVE")) m_fuse_solve = m_fuse_solve && env[0] != '0';
-  const bool want_one_launch = m_fuse_solve;
-  if (m_fuse_solve) build_solve_in_place(l);
-  lap("    images: solve in place");
-  m_sip_ok = m_fuse_solve;
-  if (want_one_launch && m_fuse_kkt && l.mf) build_mf(l);
+  // (one problem's factorization and solve in one launch: the multifrontal step; the pair-list kernels — batches,
+  // plans without fronts — take a launch per round and phase)
+  if (m_fuse_launches && m_fuse_backsub && m_fuse_kkt && l.mf) build_mf(l);
   lap("    images: multifrontal task images");
-  if (m_mf) m_fuse_solve = true;
+  m_fuse_solve = m_mf;
   m_chain_on = m_mf && m_chain_mode != 0;
   lap("  upload: inline KKT / back-substitution / multifrontal images");
 
@@ -745,7 +741,7 @@ DeviceNlp::DeviceNlp(const NlpStructure& s, const KktPlan& k, const LdltPlan& l,
   // set (RegularizedLDLT::compute(lhs), regularized_ldlt.hpp:72) — recycled memory of an earlier
   // system can hold the hand-over sentinel (a NaN pattern: the armed slots below), a NaN keeps
   // its payload through arithmetic, and an update block that IS the sentinel is never taken
-  // (seen with SLPX_FUSE_SOLVE=0: the fourth solver of a process spinning to its time-out).
+  // (seen on the pair-list kernels: the fourth solver of a process spinning to its time-out).
   for (DevBuf<double>* buf : {&m_V, &m_s, &m_y, &m_z, &m_mu, &m_lhs, &m_rhs, &m_p, &m_ps, &m_pz, &m_D, &m_Lx, &m_scontrib, &m_zv})
     buf->zero();
   SLPX_HIP_CHECK(hipDeviceSynchronize());  // (the memsets ran on the null stream, the kernels will not)
@@ -1258,62 +1254,6 @@ void DeviceNlp::build_inline_backsub(const KktPlan& k, const LdltPlan& l) {
   m_h_bs_task_plan = std::move(task_plan);
 }
 
-// The static side of ldlt_factor_solve_kernel, and whether it can be used at all: its workgroups
-// wait for each other across the whole tree, so every one of them must be resident at once.
-void DeviceNlp::build_solve_in_place(const LdltPlan& l) {
-  std::vector<LdltSolveItem> items(l.bwd_items);
-  std::vector<uint32_t> zent(l.col_perm.size(), 0);
-  uint32_t widest_cols = 0;
-  bool ok = true;
-  // position in Lx -> (task, entry of the task): every position of L is one entry of one task (a table over nnz(L)
-  // instead of a hash map per task: 2.6 ms of a 30 ms setup at cart-pole N=1000)
-  std::vector<uint32_t> entry_at(static_cast<size_t>(std::max<int64_t>(1, l.nnzL)), 0xffffffffu), task_at(entry_at.size(), 0xffffffffu);
-  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const LdltTask& t = l.tasks[ti];
-    for (uint32_t i = 0; i < t.n_ent; ++i) {
-      const uint8_t fl = l.ent_flags[t.ent_off + i];
-      if (fl & 4) zent[t.col_off + l.ent_col[t.ent_off + i]] = i;
-      else if (!(fl & 1)) {
-        entry_at[l.ent_out[t.ent_off + i]] = i;
-        task_at[l.ent_out[t.ent_off + i]] = static_cast<uint32_t>(ti);
-      }
-    }
-  }
-  for (size_t ti = 0; ti < l.tasks.size(); ++ti) {
-    const LdltTask& t = l.tasks[ti];
-    for (uint32_t q = 0; q < t.n_bwd_items; ++q) {
-      const uint32_t lpos = l.bwd_items[t.bwd_item_off + q].lpos;
-      if (lpos >= entry_at.size() || task_at[lpos] != ti) ok = false;
-      else items[t.bwd_item_off + q].lpos = entry_at[lpos];
-    }
-    widest_cols = std::max(widest_cols, t.n_col);
-  }
-  const uint32_t factor_part = ((m_fuse_kkt ? m_factor_lds_inline : l.factor_lds_bytes) + 15u) & ~15u;
-  const uint32_t solve_part = m_solve_lds_inline + 16u * ((widest_cols + 3u) / 4u);
-  const uint32_t total = factor_part + solve_part;
-  int per_cu = 0, cus = 0;
-  if (ok && total <= 160u * 1024u) {
-    SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ldlt_factor_solve_kernel<1024>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ldlt_factor_solve_kernel<1024>, 1024, total));
-    SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
-  }
-  if (std::getenv("SLPX_LDLT_VERBOSE"))
-    std::fprintf(stderr, "ldlt one-launch step: %zu tasks, LDS %u + %u bytes, %d workgroup(s) per CU x %d CUs\n",
-                 l.tasks.size(), factor_part, solve_part, per_cu, cus);
-  // (the separable sums ride in the same launch, and leave: a few workgroups of slack for them)
-  if (!ok || total > 160u * 1024u || l.tasks.size() + m_reduces.n > static_cast<size_t>(per_cu) * cus) {
-    m_fuse_solve = false;
-    return;
-  }
-  m_bwd_items_u.upload(items);
-  m_col_zent.upload(zent);
-  m_exit_cnt.upload(std::vector<unsigned int>(1, 0u));
-  m_sip = SolveInPlace{m_bwd_items_u.p, m_col_zent.p, factor_part, static_cast<unsigned int>(l.tasks.size()),
-                       m_exit_cnt.p};
-  m_factor_solve_lds = total;
-}
-
 constexpr int kFactorThreadsSingle = 1024;
 // The multifrontal step (ldlt_mf_kernels.h): plan upload, LDS footprint, co-residency of every task's workgroup.
 void DeviceNlp::build_mf(const LdltPlan& l) {
@@ -1786,9 +1726,8 @@ void DeviceNlp::factor(const std::vector<double>& delta, const std::vector<doubl
 
 void DeviceNlp::factor_solve_publish(const std::vector<double>& delta, const std::vector<double>& gamma,
                                      const std::vector<uint8_t>& active) {
-  // (the pair-list one-launch kernel needs every task's 1024-thread workgroup resident at once)
   const bool mf_now = m_mf && xg_other() != nullptr;
-  if (!m_fuse_solve || (!mf_now && !m_sip_ok)) {
+  if (!m_fuse_solve || !mf_now) {
     factor(delta, gamma, active);
     solve_backsub_publish();
     return;
@@ -1975,26 +1914,13 @@ void DeviceNlp::adopt_twin() {
 }
 
 void DeviceNlp::enqueue_factor_solve(int parity) {
-  const LdltPlan& l = m_l_ref;
+  if (!(m_mf && xg_other() != nullptr)) throw std::logic_error("slpx: a one-launch step without the multifrontal plan");
   if (!m_kkt_pending) materialize_kkt();
-  LdltStats* cur = m_stats.p + static_cast<size_t>(parity);
-  LdltStats* next = m_stats.p + static_cast<size_t>(parity ^ 1);
   KktFuse f = take_kkt_fuse();
-  BacksubFuse bf = backsub_fuse(cur);
-  if (m_mf && xg_other() != nullptr) {
-    const bool chained = m_stream.tape_pending;
-    m_stats_cur = parity ^ 1;  // (the callers flipped it already; launch_mf_step / book_mf_step do it themselves)
-    launch_mf_step(0, m_h_reg, f, chained);
-    book_mf_step(0, chained);
-    return;
-  }
-  hipLaunchKernelGGL(ldlt_factor_solve_kernel<kFactorThreadsSingle>,
-                     dim3(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks)),
-                     dim3(kFactorThreadsSingle), m_factor_solve_lds, m_stream, m_ldev, m_lhs.p, m_h_reg, m_Lx.p, m_D.p,
-                     l.n, m_contrib.p, cur, next, m_rhs.p, m_zv.p, m_fround_cnt.p, m_slot_handoff ? 1 : 0, f, xg_now(),
-                     xg_other(), m_p.p, m_bround_cnt.p, bf, m_sip);
-  xg_flip();
-  SLPX_HIP_CHECK(hipGetLastError());
+  const bool chained = m_stream.tape_pending;
+  m_stats_cur = parity ^ 1;  // (the callers flipped it already; launch_mf_step / book_mf_step do it themselves)
+  launch_mf_step(0, m_h_reg, f, chained);
+  book_mf_step(0, chained);
 }
 
 void DeviceNlp::read_stats(std::vector<LdltStats>& out) {

@@ -326,8 +326,7 @@ __device__ __attribute__((noinline)) void chain_solve_wave(LdsF64* __restrict__ 
 // columns (in-chain pairs are not in the lists), then — only in levels that hold a chain of two
 // or more columns — a barrier and sn_finish_wave, one wave per chain.
 // ---------------------------------------------------------------------------
-// What the factorization leaves in LDS for whoever runs next in the same workgroup (the exit
-// phase; the backward solve of ldlt_factor_solve_kernel).
+// What the factorization leaves in LDS for its exit phase.
 struct FactorKeep {
   double* U;
   double* invd;
@@ -384,9 +383,7 @@ __device__ __forceinline__ void ride_along_sum(const KktFuse& F, uint32_t which,
   if (tid == 0) F.Vw[r.dst] = (r.scale_idx >= 0 ? F.scales[r.scale_idx] : 1.0) * part[0];
 }
 
-// One task of the factorization.  `defer_exit`: leave L, D, z and the inertia counters to a later
-// ldlt_factor_exit (the caller has something more urgent to do first).  Returns false when the
-// problem is not part of this attempt.
+// One task of the factorization.  Returns false when the problem is not part of this attempt.
 template <int THREADS>
 __device__ __forceinline__ bool ldlt_factor_body(
     const LdltDev& L, uint32_t task_index, bool first_task, const LdltTask& t, int b, unsigned char* smem_raw,
@@ -395,7 +392,7 @@ __device__ __forceinline__ bool ldlt_factor_body(
     double* __restrict__ D, int n, double* __restrict__ contrib, int contrib_stride,
     LdltStats* __restrict__ stats, LdltStats* __restrict__ stats_next,
     const double* __restrict__ rhs, double* __restrict__ zv, unsigned int* __restrict__ round_cnt,
-    int slot_handoff, const KktFuse& F, bool defer_exit, FactorKeep* keep) {
+    int slot_handoff, const KktFuse& F) {
   const int tid = threadIdx.x;
   // the counters the NEXT factorization attempt accumulates into (nobody touches them now)
   if (stats_next != nullptr && first_task && tid == 0)
@@ -674,8 +671,7 @@ __device__ __forceinline__ bool ldlt_factor_body(
   }
 
   SLPX_LDLT_CLOCK(4);
-  *keep = FactorKeep{U, invd, col, flags, out, s_cnt, s_minp};
-  if (!defer_exit) ldlt_factor_exit<THREADS>(*keep, t, b, Lx, D, zv, stats);
+  ldlt_factor_exit<THREADS>(FactorKeep{U, invd, col, flags, out, s_cnt, s_minp}, t, b, Lx, D, zv, stats);
   SLPX_LDLT_CLOCK(5);
   return true;
 }
@@ -695,10 +691,9 @@ __global__ __launch_bounds__(THREADS) void ldlt_factor_kernel(
   }
   const uint32_t task_index = task_base + blockIdx.x - static_cast<uint32_t>(F.n_blocks);
   const LdltTask t = L.tasks[task_index];
-  FactorKeep keep;
   ldlt_factor_body<THREADS>(L, task_index, task_index == task_base, t, blockIdx.y, smem_raw, lhs, lhs_stride, reg, Lx,
                             lx_stride, D, n, contrib, contrib_stride, stats, stats_next, rhs, zv, round_cnt,
-                            slot_handoff, F, false, &keep);
+                            slot_handoff, F);
 }
 
 // ---------------------------------------------------------------------------
@@ -845,13 +840,10 @@ __global__ __launch_bounds__(256) void ldlt_fwd_kernel(
 // w - pos - 1 items of a column), then the chain is finished top-down by chain_solve_wave.
 // ---------------------------------------------------------------------------
 struct BwdCarve {
-  uint4 *s_items, *s_rng, *s_lvl, *s_cp, *s_snd, *s_zent, *s_bs;
-  uint32_t g_items, g_rng, g_lvl, g_cp, g_snd, g_zent;
+  uint4 *s_items, *s_rng, *s_lvl, *s_cp, *s_snd, *s_bs;
+  uint32_t g_items, g_rng, g_lvl, g_cp, g_snd;
   double *vals, *x;
 };
-// (WITH_ZENT: one more word per column — where the factorization left that column's z, for the
-// backward solve that runs in the factorization's workgroup)
-template <bool WITH_ZENT>
 __device__ __forceinline__ BwdCarve bwd_carve(unsigned char* smem, const LdltTask& t) {
   BwdCarve c;
   c.g_items = q16(t.n_bwd_items, 2);
@@ -859,14 +851,12 @@ __device__ __forceinline__ BwdCarve bwd_carve(unsigned char* smem, const LdltTas
   c.g_lvl = q16(t.n_lvl + 1, 4);
   c.g_cp = q16(t.n_col, 4);
   c.g_snd = q16(3 * t.n_sn, 4);
-  c.g_zent = WITH_ZENT ? q16(t.n_col, 4) : 0;
   c.s_items = reinterpret_cast<uint4*>(smem);
   c.s_rng = c.s_items + c.g_items;
   c.s_lvl = c.s_rng + c.g_rng;
   c.s_cp = c.s_lvl + c.g_lvl;
   c.s_snd = c.s_cp + c.g_cp;
-  c.s_zent = c.s_snd + c.g_snd;
-  c.vals = reinterpret_cast<double*>(c.s_zent + c.g_zent);
+  c.vals = reinterpret_cast<double*>(c.s_snd + c.g_snd);
   c.x = c.vals + t.n_bwd_items;
   // the rows of the back-substitution this task owns (device.hpp: BacksubFuse), behind x[]
   c.s_bs = reinterpret_cast<uint4*>(
@@ -875,17 +865,15 @@ __device__ __forceinline__ BwdCarve bwd_carve(unsigned char* smem, const LdltTas
 }
 
 // the static part of a backward-solve task into LDS (no barrier: the caller's)
-template <int THREADS, bool FROM_FACTOR>
+template <int THREADS>
 __device__ __forceinline__ uint4 ldlt_bwd_stage(const LdltDev& L, const LdltTask& t, uint32_t task_index,
-                                                const BwdCarve& c, const BacksubFuse& F, const SolveInPlace& M) {
+                                                const BwdCarve& c, const BacksubFuse& F) {
   const int tid = threadIdx.x;
-  stage16<THREADS>(c.s_items, reinterpret_cast<const uint4*>((FROM_FACTOR ? M.bwd_items_u : L.bwd_items) + t.bwd_item_off),
-                   c.g_items, tid);
+  stage16<THREADS>(c.s_items, reinterpret_cast<const uint4*>(L.bwd_items + t.bwd_item_off), c.g_items, tid);
   stage16<THREADS>(c.s_rng, reinterpret_cast<const uint4*>(L.bwd_range + t.col_off), c.g_rng, tid);
   stage16<THREADS>(c.s_lvl, reinterpret_cast<const uint4*>(L.col_lvl_pack + t.lvl_off), c.g_lvl, tid);
   stage16<THREADS>(c.s_cp, reinterpret_cast<const uint4*>(L.col_perm + t.col_off), c.g_cp, tid);
   if (t.n_sn) stage16<THREADS>(c.s_snd, reinterpret_cast<const uint4*>(L.sn_desc + t.sn_off), c.g_snd, tid);
-  if (FROM_FACTOR) stage16<THREADS>(c.s_zent, reinterpret_cast<const uint4*>(M.col_zent + t.col_off), c.g_zent, tid);
   uint4 bs_task = uint4{0, 0, 0, 0};
   if (F.on) {
     bs_task = F.task_plan[task_index];
@@ -894,17 +882,15 @@ __device__ __forceinline__ uint4 ldlt_bwd_stage(const LdltDev& L, const LdltTask
   return bs_task;
 }
 
-// One task of the backward solve, its plan staged (and a barrier passed).  FROM_FACTOR: L and z
-// are taken from what the factorization of the same task left in this workgroup's LDS.
-template <int THREADS, bool FROM_FACTOR>
+// One task of the backward solve, its plan staged (and a barrier passed).
+template <int THREADS>
 __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t, uint32_t task_index, int b,
                                              const BwdCarve& c,
                                              const uint4 bs_task, int n, const double* __restrict__ Lx,
                                              long long lx_stride, const double* __restrict__ zv,
                                              double* __restrict__ xg, double* __restrict__ xg_next,
                                              double* __restrict__ out,
-                                             unsigned int* __restrict__ round_cnt, const BacksubFuse& F,
-                                             const FactorKeep* keep) {
+                                             unsigned int* __restrict__ round_cnt, const BacksubFuse& F) {
   const int tid = threadIdx.x;
   // xg_next != nullptr (every round in this launch): the ancestors' x is handed over through
   // the values themselves (slot_read) instead of round counters
@@ -918,20 +904,12 @@ __device__ __forceinline__ void ldlt_bwd_run(const LdltDev& L, const LdltTask& t
   double* vals = c.vals;
   double* x = c.x;
   const LdltSn* snd = reinterpret_cast<const LdltSn*>(c.s_snd);
-  uint2* items = reinterpret_cast<uint2*>(c.s_items);  // x = lpos (FROM_FACTOR: entry of U), y = ref (rewritten in place)
+  uint2* items = reinterpret_cast<uint2*>(c.s_items);  // x = lpos, y = ref (rewritten in place)
   const uint2* rng = reinterpret_cast<const uint2*>(c.s_rng);  // {first item below the column's own chain, end}
   const uint32_t* lvl = reinterpret_cast<const uint32_t*>(c.s_lvl);  // column | first chain << 16
   const uint32_t* colperm = reinterpret_cast<const uint32_t*>(c.s_cp);
   SLPX_LDLT_CLOCK(17);
-  if (FROM_FACTOR) {
-    const uint32_t* zent = reinterpret_cast<const uint32_t*>(c.s_zent);
-    for (uint32_t q = tid; q < n_items; q += THREADS) {
-      const uint32_t e = items[q].x;
-      vals[q] = keep->U[e] * keep->invd[keep->col[e]];  // what ldlt_factor_exit writes to Lx
-    }
-    for (uint32_t i = tid; i < t.n_col; i += THREADS) x[i] = keep->U[zent[i]] * keep->invd[i];
-    if (tid == 0) x[t.n_col] = 1.0;
-  } else {
+  {
     // L and z are final since the factorization: fetch them BEFORE waiting for the ancestors
     uint32_t q = tid;
     for (; q + 3 * THREADS < n_items; q += 4 * THREADS) {
@@ -1148,62 +1126,10 @@ __global__ __launch_bounds__(256) void ldlt_bwd_kernel(
       (round_cnt != nullptr || xg_next != nullptr) ? task_base - blockIdx.x : task_base + blockIdx.x;
   const LdltTask t = L.tasks[task_index];
   SLPX_LDLT_CLOCK(16);
-  const BwdCarve c = bwd_carve<false>(smem_raw, t);
-  const uint4 bs_task = ldlt_bwd_stage<256, false>(L, t, task_index, c, F, SolveInPlace{});
+  const BwdCarve c = bwd_carve(smem_raw, t);
+  const uint4 bs_task = ldlt_bwd_stage<256>(L, t, task_index, c, F);
   __syncthreads();
-  ldlt_bwd_run<256, false>(L, t, task_index, blockIdx.y, c, bs_task, n, Lx, lx_stride, zv, xg, xg_next, out, round_cnt, F,
-                           nullptr);
-}
-
-// ---------------------------------------------------------------------------
-// Factorization and backward solve of a Newton step in ONE launch (one problem, every task's
-// workgroup resident at once: DeviceNlp checks the occupancy): each workgroup factors its task
-// and then, when its ancestors' x are final, solves it — from the L and z it still holds in LDS.
-// Against the two launches this drops, on the critical path through the root task, the write of
-// L, the end of one kernel and the start of the next, and the staging and gather of the solve
-// (profiles/: ~8 us of 66).  The root solves first and writes L, D, z and its inertia counters
-// afterwards; the others write them while they wait.  The workgroup that finishes the LAST exit
-// hands the counters to the host.
-// LDS: the factorization's carve-up, then at M.bwd_lds_off the solve's.
-// ---------------------------------------------------------------------------
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void ldlt_factor_solve_kernel(
-    LdltDev L, const double* __restrict__ lhs, const double* __restrict__ reg, double* __restrict__ Lx,
-    double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
-    LdltStats* __restrict__ stats_next, const double* __restrict__ rhs, double* __restrict__ zv,
-    unsigned int* __restrict__ fround_cnt, int slot_handoff, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, unsigned int* __restrict__ bround_cnt, BacksubFuse B,
-    SolveInPlace M) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (static_cast<int>(blockIdx.x) < F.n_blocks) {
-    ride_along_sum(F, blockIdx.x, smem_raw);
-    return;
-  }
-  const uint32_t task_index = blockIdx.x - static_cast<uint32_t>(F.n_blocks);
-  const LdltTask t = L.tasks[task_index];
-  const bool top = static_cast<int>(t.round) + 1 == L.n_rounds;
-  // the solve's plan travels with the factorization's
-  const BwdCarve c = bwd_carve<true>(smem_raw + M.bwd_lds_off, t);
-  const uint4 bs_task = ldlt_bwd_stage<THREADS, true>(L, t, task_index, c, B, M);
-  FactorKeep keep;
-  if (!ldlt_factor_body<THREADS>(L, task_index, task_index == 0, t, 0, smem_raw, lhs, 0, reg, Lx, 0, D, n, contrib, 0,
-                                 stats, stats_next, rhs, zv, fround_cnt, slot_handoff, F, /*defer_exit=*/true, &keep))
-    return;
-  auto exit_and_count = [&] {
-    ldlt_factor_exit<THREADS>(keep, t, 0, Lx, D, zv, stats);
-    if (threadIdx.x == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
-      const unsigned int old = __hip_atomic_fetch_add(M.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1 == M.n_tasks) {
-        __hip_atomic_store(M.exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (B.stats_host != nullptr) publish_stats(B, true);
-      }
-    }
-  };
-  if (!top) exit_and_count();  // (its store acknowledgements come in while the task waits for its ancestors)
-  __syncthreads();
-  ldlt_bwd_run<THREADS, true>(L, t, task_index, 0, c, bs_task, n, Lx, 0, zv, xg, xg_next, out, bround_cnt, B, &keep);
-  if (top) exit_and_count();
+  ldlt_bwd_run<256>(L, t, task_index, blockIdx.y, c, bs_task, n, Lx, lx_stride, zv, xg, xg_next, out, round_cnt, F);
 }
 
 }  // namespace slpx

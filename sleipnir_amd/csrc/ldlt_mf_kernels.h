@@ -2,7 +2,7 @@
 // task as DENSE FRONTS, one wave per front, everything a lane touches found through precomputed
 // 16-bit LDS byte offsets (ldlt_symbolic.hpp: LdltFront) — and the Newton step built on it:
 // KKT evaluation, factorization, backward solve and back-substitution in ONE launch
-// (ldlt_mf_step_kernel; the pair-list version is ldlt_factor_solve_kernel).
+// (ldlt_mf_step_kernel).
 //
 // Why fronts.  A lone wave issues a dependent instruction every 6-9 clocks whatever it is
 // (profiles/microbench), so a level costs what it EXECUTES, not what it waits for.  The left-looking

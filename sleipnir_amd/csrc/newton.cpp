@@ -76,9 +76,8 @@ NewtonSystem::NewtonSystem(Graph& g, const std::vector<NodeId>& x, NodeId f,
     // (below ~200 problems the rounds, not the chip, bound a factorization: fewer, bigger tasks — 64 x N=500:
     // 384 entries 242 k steps/s, 512: 251 k, 768: 247 k)
     if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
-    // the interleaved kernels walk column levels; supernodal levels are the per-task kernels' (SLPX_SUPERNODAL=0: off)
+    // the interleaved kernels walk column levels; supernodal levels are the per-task kernels'
     if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
-    if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
     // one problem: the multifrontal step (ldlt_mf_kernels.h) — every supernode a dense front, so a chain
     // of two columns already saves a level (the pair-list kernels' chain pass only paid from four)
     if (opt.batch == 1 && lopt.supernodal) {
@@ -225,7 +224,6 @@ NewtonSystem::NewtonSystem(const CscPattern& lower, int n_dec, int m_e, const Ne
   if (opt.batch >= 16 && lopt.task_entries == LdltOptions{}.task_entries) lopt.task_entries = 1024;
   if (DeviceNlp::interleaved_for(opt.batch) && lopt.task_entries >= 1024) lopt.task_entries = opt.batch < 192 ? 512 : 384;
   if (DeviceNlp::interleaved_for(opt.batch)) lopt.supernodal = false;
-  if (const char* env = std::getenv("SLPX_SUPERNODAL")) lopt.supernodal = lopt.supernodal && env[0] != '0';
   m_l = plan_or_dense(m_k.lhs, n_dec, lopt, nullptr, &diag_has_source, m_opt.batch);
   m_dev = std::make_unique<DeviceNlp>(m_s, m_k, m_l, m_opt.batch, opt.device);
   m_dev->set_scaling(std::vector<double>(m_s.n_scales(), 1.0));

@@ -214,7 +214,7 @@ def test_irregular_patterns_against_dense_solves(kind):
             ls.solve()
             _check_solution(K, n, reg[0], rhs, ls.get("p")[0])
         ls.close()
-    assert seen_chain or kind == "random" or os.environ.get("SLPX_SUPERNODAL") == "0"
+    assert seen_chain or kind == "random"
 
 
 def test_compute_before_any_right_hand_side_on_recycled_memory(monkeypatch):
@@ -222,9 +222,9 @@ def test_compute_before_any_right_hand_side_on_recycled_memory(monkeypatch):
     right-hand side rides in the factorization as an extra row, so its buffer must not start as
     whatever the allocator recycles: memory of an earlier solver can hold the hand-over sentinel
     (a NaN pattern), a NaN keeps its payload through arithmetic, and an update block that IS the
-    sentinel is never taken.  Seen on the two-launch path (SLPX_FUSE_SOLVE=0): the fourth solver
+    sentinel is never taken.  Seen on the pair-list kernels (SLPX_LDLT_MF=0: a launch per phase): the fourth solver
     of this very sequence spun to its time-out 26 times and reported NumericalIssue."""
-    monkeypatch.setenv("SLPX_FUSE_SOLVE", "0")
+    monkeypatch.setenv("SLPX_LDLT_MF", "0")
     rng = np.random.default_rng(12)
     for trial in range(5):
         n = int(rng.integers(30, 450))

@@ -118,15 +118,14 @@ def test_config4_batch_items_match_oracle(fresh, slpx, orc):
         sysb.close()
 
 
-@pytest.mark.parametrize("env", [{"SLPX_SUPERNODAL": "0"}, {"SLPX_SN_MIN_WIDTH": "2"}, {"SLPX_SN_MIN_WIDTH": "8"}])
+@pytest.mark.parametrize("env", [{"SLPX_SN_MIN_WIDTH": "2"}, {"SLPX_SN_MIN_WIDTH": "8"}])
 @pytest.mark.parametrize("kind,N", [("cart_pole", 100), ("gfold", 30)])
 def test_supernode_settings(fresh, slpx, orc, monkeypatch, env, kind, N):
-    """Column levels, chains from 2 columns up, only the widest chains: the same Newton step
+    """Chains from 2 columns up, only the widest chains: the same Newton step
     (factorization, the solve that rides in it, the re-solve with a new right-hand side)."""
     from tests.support import gfold, model
 
-    for k in ("SLPX_SUPERNODAL", "SLPX_SN_MIN_WIDTH"):  # (the suite may itself run under one of them: profiles/switch_matrix.sh)
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("SLPX_SN_MIN_WIDTH", raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     if kind == "gfold":
@@ -139,9 +138,7 @@ def test_supernode_settings(fresh, slpx, orc, monkeypatch, env, kind, N):
         pp, op = cases.build_pair(kind, N, slpx, orc)
     system = slpx.System(pp, batch=1, device=0)
     try:
-        if env.get("SLPX_SUPERNODAL") == "0":
-            assert system.info["ldlt_widest_supernode"] == 1
-        elif not cases.OUTER_SWITCHES:  # (SLPX_RELAX_ZEROS=0, SLPX_SN_MAX_WIDTH=6 leave no chain of 8 columns)
+        if not cases.OUTER_SWITCHES:  # (SLPX_RELAX_ZEROS=0, SLPX_SN_MAX_WIDTH=6 leave no chain of 8 columns)
             assert system.info["ldlt_widest_supernode"] >= 2
         parity.check_newton_step(parity.GpuBackend(system), op, "interior", verbose=True)
         # newton_step(): the rhs rides in the factorization; solve(): forward + backward kernels
@@ -183,11 +180,10 @@ def test_system_evaluated_inside_the_factorization_equals_the_assembled_one(fres
         got[mode] = {k: system.get(k)[0].copy() for k in ("lhs", "rhs", "p", "p_s", "p_z", "D")}
         got[mode]["mf"] = system.time_fused_step(1)["multifrontal"]
         system.close()
-    # (under a switch of profiles/switch_matrix.sh that takes the one-launch step away — SLPX_SUPERNODAL=0,
+    # (under a switch of profiles/switch_matrix.sh that takes the one-launch step away — SLPX_LDLT_MF=0,
     # SLPX_FUSE_*=0 — there is no multifrontal step to ask for)
     is_mf = bool(got["inline"]["mf"])
-    switched = any(os.environ.get(k) == "0" for k in ("SLPX_SUPERNODAL", "SLPX_FUSE_LAUNCHES", "SLPX_FUSE_BACKSUB",
-                                                       "SLPX_FUSE_SOLVE", "SLPX_SINGLE_LAUNCH"))
+    switched = any(os.environ.get(k) == "0" for k in ("SLPX_LDLT_MF", "SLPX_FUSE_LAUNCHES", "SLPX_FUSE_BACKSUB", "SLPX_SINGLE_LAUNCH"))
     assert (is_mf == (mf == "1") or switched) and not got["assembled"]["mf"] and not (is_mf and mf == "0")
     for k in ("lhs", "rhs"):
         assert np.array_equal(got["inline"][k], got["assembled"][k]), k

@@ -2,7 +2,7 @@
 
 `parity.check_newton_step` drives the stand-alone stages (sweep / assemble / rhs / factor / solve /
 backsub); what `bench.py` measures is `slpx_newton_step`: for one problem the generated tape kernel
-followed by `ldlt_factor_solve_kernel` (KKT evaluated inside the factorization, backward solve and
+followed by `ldlt_mf_step_kernel` (KKT evaluated inside the factorization, backward solve and
 back-substitution in the same launch), at N=5000 the two-launch variant, for batches of 64 and
 more the batch-interleaved `ldlt_*_il_kernel`s.  Each of those paths here against
 `oracle newton_step` (interior_point.hpp:426-482) — (delta, gamma), inertia, p, p_s, p_z:
@@ -40,8 +40,8 @@ def test_config2_n1000_fused_step_against_oracle(fresh, slpx, orc, case):
     system = slpx.System(pp, batch=1, device=0)
     try:
         # the path BENCH times at this size (unless profiles/switch_matrix.sh asked for the launches apart)
-        apart = any(os.environ.get(k) == "0" for k in ("SLPX_FUSE_LAUNCHES", "SLPX_FUSE_KKT", "SLPX_FUSE_BACKSUB",
-                                                        "SLPX_FUSE_SOLVE", "SLPX_SINGLE_LAUNCH"))
+        apart = any(os.environ.get(k) == "0" for k in ("SLPX_LDLT_MF", "SLPX_FUSE_LAUNCHES", "SLPX_FUSE_KKT", "SLPX_FUSE_BACKSUB",
+                                                        "SLPX_SINGLE_LAUNCH"))
         assert system.time_fused_step(1)["one_launch"] or apart
         errs = _step_and_check(system, op, case, f"N=1000 {case} (one launch)")
         assert errs["resid"] <= 1e-10

@@ -6,9 +6,12 @@
 // (:426-482, :809-812) runs on the GPU through NewtonSystem, and so does every O(n)
 // piece of the iteration around it (step sizes, trial iterate, filter quantities,
 // second-order corrections, iterate update, error norms: ipm_kernels.h, SURVEY.md §8f rows
-// N1/N2) — the host keeps the DECISIONS (filter, barrier update, exits) on a few dozen
-// scalars per iteration.  SLPX_IPM_RESIDENT=0 selects the older driver that keeps the
-// vectors on the host (the cross-check of the resident one).
+// N1/N2).  The DECISIONS (filter, barrier update, exits) are functions of a few dozen scalars
+// per iteration (ipm_decide.h): the common iteration's — the filter takes the full step, the
+// error is above the tolerance, the barrier parameter stays — are taken on the device by the
+// launch that reduces the norms, with the next step enqueued behind it (SLPX_IPM_PIPELINE=0:
+// by the host); every other iteration's by the host.  SLPX_IPM_RESIDENT=0 selects the older
+// driver that keeps the vectors on the host (the cross-check of the resident one).
 //
 // Feasibility restoration (util/feasibility_restoration.hpp:347-628, row N3) runs on the SAME
 // compiled NewtonSystem: its extra variables p, n are eliminated from the Newton-KKT system in

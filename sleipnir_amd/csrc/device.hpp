@@ -7,6 +7,8 @@
 // solve fan-out (include/sleipnir/optimization/multistart.hpp:52-62).
 #pragma once
 
+#include <chrono>
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -383,6 +385,32 @@ struct TrackedStream {
   }
   hipStream_t raw() const { return s; }
 };
+
+// Spin on a word a kernel publishes into pinned host memory.  The stream itself is consulted only after two
+// milliseconds without progress (so that a failed launch cannot hang the host): a hipStreamQuery puts a marker packet
+// behind whatever is queued, and the device spends ~5 us on it in front of the NEXT launch — measured as the gap
+// before every step kernel while the loops asked every few microseconds (profiles/r06_gap_probe.txt).
+template <class Done>
+inline void spin_on_published(Done done, hipStream_t stream, const char* what) {
+  unsigned spins = 0;
+  bool timing = false;
+  std::chrono::steady_clock::time_point since;
+  while (!done()) {
+    if ((++spins & 0x3fffu) != 0) continue;
+    const auto now = std::chrono::steady_clock::now();
+    if (!timing) {
+      timing = true;
+      since = now;
+    } else if (now - since > std::chrono::milliseconds(2)) {
+      since = now;
+      const hipError_t st = hipStreamQuery(stream);
+      if (st != hipErrorNotReady) {
+        if (st != hipSuccess) throw std::runtime_error(std::string("slpx: ") + hipGetErrorString(st));
+        if (!done()) throw std::runtime_error(what);
+      }
+    }
+  }
+}
 
 class DeviceNlp {
  public:

@@ -47,6 +47,7 @@ struct FilterPowers {
   double alpha_15 = 0.0;  // alpha^1.5
 };
 SLPX_DECIDE FilterPowers filter_powers(const FilterEntry& cur, double D_phi, double alpha) {
+#pragma clang fp contract(off)  // (host and device round alike: no fused multiply-adds)
   return FilterPowers{pow(-D_phi, 2.3), pow(cur.constraint_violation, 1.1), pow(alpha, 1.5)};
 }
 
@@ -55,6 +56,7 @@ SLPX_DECIDE FilterPowers filter_powers(const FilterEntry& cur, double D_phi, dou
 SLPX_DECIDE int filter_rules(double min_constraint_violation, double max_constraint_violation, int* last_rejection_due_to_filter,
                              const FilterEntry& cur, const FilterEntry& trial, double D_phi, double alpha, const FilterPowers& pw,
                              FilterEntry* add, bool* insert) {
+#pragma clang fp contract(off)  // (host and device round alike: no fused multiply-adds)
   if (!ipm_isfinite(trial.cost) || trial.constraint_violation > max_constraint_violation) return 0;
   const bool switching = D_phi < 0.0 && alpha * pw.dphi_23 > pw.viol_11;
   const bool armijo = trial.cost <= cur.cost + 1e-8 * alpha * D_phi;
@@ -78,6 +80,7 @@ SLPX_DECIDE int filter_rules(double min_constraint_violation, double max_constra
 // util/kkt_error.hpp:92-146 from the reduced scalars (IpmErrOut, device.hpp)
 SLPX_DECIDE double ipm_max4(double a, double b, double c, double d) { return fmax(fmax(a, b), fmax(c, d)); }
 SLPX_DECIDE double ipm_E_mu(const IpmErrOut& e, double m, int m_e, int m_i) {
+#pragma clang fp contract(off)  // (host and device round alike: no fused multiply-adds)
   constexpr double s_max = 100.0;
   const double s_d = fmax(s_max, (e.y1 + e.z1) / double(m_e + m_i)) / s_max;
   const double s_c = fmax(s_max, e.z1 / double(m_i)) / s_max;
@@ -85,6 +88,7 @@ SLPX_DECIDE double ipm_E_mu(const IpmErrOut& e, double m, int m_e, int m_i) {
   return ipm_max4(e.dual_inf / s_d, comp / s_c, e.ce_inf, e.cis_inf);
 }
 SLPX_DECIDE double ipm_E_0(const IpmErrOut& e, int m_e, int m_i, bool identity_scaling) {
+#pragma clang fp contract(off)  // (host and device round alike: no fused multiply-adds)
   if (identity_scaling) return ipm_E_mu(e, 0.0, m_e, m_i);
   constexpr double s_max = 100.0;
   const double s_d = fmax(s_max, (e.y1_u + e.z1_u) / double(m_e + m_i)) / s_max;
@@ -106,6 +110,7 @@ struct IpmCtl {
 // of the common iteration's decision but the filter: true = the error is above the tolerance, the barrier parameter
 // stays, nothing is infeasible or diverging, the step has a size.
 SLPX_DECIDE bool ipm_next_iteration_is_plain(const IpmCtl& C, const IpmErrOut& ahead, double alpha_max) {
+#pragma clang fp contract(off)  // (host and device round alike: no fused multiply-adds)
   constexpr double alpha_min = 1e-7;
   if (!(alpha_max >= alpha_min) || ahead.finite == 0.0) return false;
   if (!(ipm_E_0(ahead, C.m_e, C.m_i, C.identity_scaling != 0) > C.tolerance)) return false;

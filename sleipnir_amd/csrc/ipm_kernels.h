@@ -520,6 +520,7 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
       reinterpret_cast<double*>(out)[k] = v;
     }
     if (decide != nullptr && decide->ctl != nullptr) {
+#pragma clang fp contract(off)  // (the filter entries as the host forms them: no fused multiply-adds)
       // the common iteration's decisions (ipm_decide.h), by the wave that publishes: the 24 scalars through LDS (`part`
       // is free), the rules by every lane alike, the filter's table an entry per lane
       double* fin = tot + NQ;

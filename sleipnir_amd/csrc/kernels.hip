@@ -1933,17 +1933,7 @@ void DeviceNlp::read_stats(std::vector<LdltStats>& out) {
   if (m_stats_in_host && m_batch == 1) {
     // the publishing kernel's sequence number (see step_backsub_kernel); the stream is
     // consulted now and then so that a failed launch cannot hang the host
-    unsigned spins = 0;
-    while (*m_h_seq < m_stats_seq) {
-      if ((++spins & 0xfffu) == 0) {
-        const hipError_t st = hipStreamQuery(m_stream.raw());
-        if (st != hipErrorNotReady) {
-          SLPX_HIP_CHECK(st);
-          if (*m_h_seq < m_stats_seq)
-            throw std::runtime_error("slpx: step finished without publishing its counters");
-        }
-      }
-    }
+    spin_on_published([&] { return *m_h_seq >= m_stats_seq; }, m_stream.raw(), "slpx: step finished without publishing its counters");
   } else {
     hipError_t st;
     while ((st = hipStreamQuery(m_stream.raw())) == hipErrorNotReady) {
@@ -2219,16 +2209,7 @@ void DeviceNlp::ipm_set_error_scaling(const std::vector<double>& scales) {
 // After ipm_trial_metrics() / ipm_errors(): spins on the sequence number those launches
 // publish (the stream is consulted now and then so a failed launch cannot hang the host).
 void DeviceNlp::wait_published() {
-  unsigned spins = 0;
-  while (*m_h_seq < m_seq_expected) {
-    if ((++spins & 0xfffu) == 0) {
-      const hipError_t st = hipStreamQuery(m_stream.raw());
-      if (st != hipErrorNotReady) {
-        SLPX_HIP_CHECK(st);
-        if (*m_h_seq < m_seq_expected) throw std::runtime_error("slpx: chain finished without publishing");
-      }
-    }
-  }
+  spin_on_published([&] { return *m_h_seq >= m_seq_expected; }, m_stream.raw(), "slpx: chain finished without publishing");
 }
 
 void DeviceNlp::wait() {
@@ -2392,16 +2373,7 @@ const IpmCtl& DeviceNlp::ipm_pipeline_fetch() {
 }
 
 void DeviceNlp::wait_published_until(unsigned long long seq) {
-  unsigned spins = 0;
-  while (*m_h_seq < seq) {
-    if ((++spins & 0xfffu) == 0) {
-      const hipError_t st = hipStreamQuery(m_stream.raw());
-      if (st != hipErrorNotReady) {
-        SLPX_HIP_CHECK(st);
-        if (*m_h_seq < seq) throw std::runtime_error("slpx: chain finished without publishing");
-      }
-    }
-  }
+  spin_on_published([&] { return *m_h_seq >= seq; }, m_stream.raw(), "slpx: chain finished without publishing");
 }
 
 void DeviceNlp::ipm_soc_accumulate(double alpha, bool first, bool s_from_ci) {

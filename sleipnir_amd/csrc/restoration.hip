@@ -885,16 +885,7 @@ void FrDevice::restore_direction() {
 }
 
 void FrDevice::wait_published() {
-  unsigned spins = 0;
-  while (*m_h_seq < m_seq_expected) {
-    if ((++spins & 0xfffu) == 0) {
-      const hipError_t st = hipStreamQuery(m_dev.raw_stream());
-      if (st != hipErrorNotReady) {
-        SLPX_HIP_CHECK(st);
-        if (*m_h_seq < m_seq_expected) throw std::runtime_error("slpx: a restoration chain finished without publishing");
-      }
-    }
-  }
+  spin_on_published([&] { return *m_h_seq >= m_seq_expected; }, m_dev.raw_stream(), "slpx: a restoration chain finished without publishing");
 }
 
 void FrDevice::download_state(double* pn, double* sx, double* zx) {

@@ -568,6 +568,10 @@ class DeviceNlp {
     m_stats_seq = b.stats_seq;
   }
   double* d_V_trial() { return m_V_trial.p; }
+  // the tape's separable sums (for a caller's launch that lets them ride: restoration.hip's error launch)
+  const NlpStructure::SumReduce* reduces_dev() const { return m_reduces.p; }
+  int n_reduces() const { return static_cast<int>(m_reduces.n); }
+  const double* tape_scales_dev() const { return m_scales.p; }
 
   // device pointers for callers that keep everything resident
   double* d_x() { return m_in.p; }

@@ -1360,12 +1360,17 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
     NewtonSystem::AttemptHooks hooks;
     auto chain = [&](double d) {
       fr.expand(d, mu, tau, /*soc=*/false, /*ahead=*/true);
-      dev.sweep_full_lookahead(/*with_reduce=*/true, /*skippable=*/false);
-      fr.errors(false, mu, /*ahead=*/true);
+      dev.sweep_full_lookahead(/*with_reduce=*/false, /*skippable=*/false);  // (the separable sums ride in the error launch)
+      fr.errors(false, mu, /*ahead=*/true, /*sums_ride=*/true);
     };
     hooks.prepare = [&](double d, double) { fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false); };
     hooks.prepare_second = [&](double d, double, const double** lhs2, const double** rhs2) {
       fr.build(d, mu, /*soc=*/false, /*rhs_only=*/false, /*second=*/true);
+      *lhs2 = fr.second_lhs();
+      *rhs2 = fr.second_rhs();
+    };
+    hooks.prepare_pair = [&](double d0, double, double d1, double, const double** lhs2, const double** rhs2) {
+      fr.build_pair(d0, d1, mu);
       *lhs2 = fr.second_lhs();
       *rhs2 = fr.second_rhs();
     };

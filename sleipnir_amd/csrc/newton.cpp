@@ -563,12 +563,18 @@ std::vector<FactorInfo> NewtonSystem::compute_hooked(const AttemptHooks& hooks) 
   const bool twin = static_cast<bool>(hooks.prepare_second) && m_dev->twin_available();
   // one launch: (d0, g0) and, where the device can, (d1, g1) beside it
   auto launch = [&](double d0, double g0, double d1, double g1, int mode) {
-    hooks.prepare(d0, g0);
     have_second = false;
     if (twin) {
       const double *lhs2 = nullptr, *rhs2 = nullptr;
-      hooks.prepare_second(d1, g1, &lhs2, &rhs2);
+      if (hooks.prepare_pair) {
+        hooks.prepare_pair(d0, g0, d1, g1, &lhs2, &rhs2);
+      } else {
+        hooks.prepare(d0, g0);
+        hooks.prepare_second(d1, g1, &lhs2, &rhs2);
+      }
       have_second = m_dev->factor_solve_publish_twin_written(d0, g0, d1, g1, mode, lhs2, rhs2);
+    } else {
+      hooks.prepare(d0, g0);
     }
     if (!have_second) m_dev->factor_solve_publish({d0}, {g0}, {1});
     // (`after` behind the FIRST launch only: a caller that expects its first attempt to be taken; the launches of a

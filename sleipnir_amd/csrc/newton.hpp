@@ -110,6 +110,8 @@ class NewtonSystem {
     std::function<void(double, double)> prepare, after;
     std::function<double()> eliminated_min_pivot;
     std::function<void(double, double, const double**, const double**)> prepare_second;
+    // (optional, beside prepare_second) both systems of a launch at once: (d0, g0, d1, g1, &lhs2, &rhs2)
+    std::function<void(double, double, double, double, const double**, const double**)> prepare_pair;
   };
   bool last_hooked_chain_valid() const { return m_hooked_chain_valid; }
   std::vector<FactorInfo> compute_hooked(const AttemptHooks& hooks);

@@ -138,8 +138,15 @@ __device__ __forceinline__ double fr_rhs_mult(const FrIn& q) {
 // ---------------------------------------------------------------------------------------------------------------
 // The reduced system into the outer system's lhs / rhs arrays (restoration.hpp's header comment)
 // ---------------------------------------------------------------------------------------------------------------
+// (gridDim.y == 2: the systems of TWO regularizations side by side — blockIdx.y = 1 takes delta_b, lhs_b, rhs_b)
 __global__ __launch_bounds__(256) void fr_build_kernel(FrDevice::Args A, const int32_t* __restrict__ diag_of, double delta, double mu,
-                                                       int soc, int rhs_only, double* __restrict__ lhs, double* __restrict__ rhs) {
+                                                       int soc, int rhs_only, double* __restrict__ lhs, double* __restrict__ rhs,
+                                                       double delta_b, double* __restrict__ lhs_b, double* __restrict__ rhs_b) {
+  if (blockIdx.y == 1) {
+    delta = delta_b;
+    lhs = lhs_b;
+    rhs = rhs_b;
+  }
   const KktDev& K = A.K;
   const double* V = A.V;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,12 +283,18 @@ __global__ __launch_bounds__(kFrExpandThreads) void fr_expand_kernel(FrDevice::A
   }
   __syncthreads();
   if (last) {
-    if (threadIdx.x < 4) {
-      const int q = threadIdx.x;
-      double v = coherent_load(&partial[q], true);
-      for (unsigned int b = 1; b < gridDim.x; ++b) v = ipm_combine(q == 2 ? IPM_SUM : IPM_MIN, v, coherent_load(&partial[b * 4 + q], true));
-      coherent_store(&alpha_dev[q], v, true);
-      reinterpret_cast<double*>(out)[q] = v;  // alpha_max, alpha_z, D_phi, eliminated_min_pivot
+    if (threadIdx.x < 64) {
+      // lane = (workgroup, quantity): sixteen workgroups' shares in ONE trip to memory, then combined over the
+      // workgroups by a butterfly in fixed order (one lane per quantity walking them was sixteen dependent trips)
+      static_assert(kFrExpandMaxBlocks == 16, "64 lanes = 16 workgroups x 4 quantities");
+      const int q = threadIdx.x & 3, b = threadIdx.x >> 2;
+      const int op = q == 2 ? IPM_SUM : IPM_MIN;
+      double v = b < static_cast<int>(gridDim.x) ? coherent_load(&partial[b * 4 + q], true) : (op == IPM_SUM ? 0.0 : 1e300);
+      for (int off = 4; off < 64; off <<= 1) v = ipm_combine(op, v, __shfl_xor(v, off));
+      if (threadIdx.x < 4) {
+        coherent_store(&alpha_dev[q], v, true);
+        reinterpret_cast<double*>(out)[q] = v;  // alpha_max, alpha_z, D_phi, eliminated_min_pivot
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -481,23 +494,49 @@ enum {
    IPM_MIN, IPM_SUM, IPM_SUM, IPM_SUM, IPM_SUM, IPM_MIN}
 constexpr int kFrErrThreads = 256;
 
+// (n_err_blocks < gridDim.x: the tape's separable sums — which make f — ride as the workgroups behind them, one each)
+struct FrSumsRide {
+  int n_err_blocks = 0;
+  const NlpStructure::SumReduce* red = nullptr;
+  const double* tape_scales = nullptr;
+  double* Vw = nullptr;
+};
 __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args A, int nV, int check_all_V, double mu_outer,
                                                                   double* __restrict__ partial, unsigned int* __restrict__ done,
                                                                   FrErrOut* __restrict__ out, unsigned long long* __restrict__ seq_dev,
-                                                                  volatile unsigned long long* seq_host) {
+                                                                  volatile unsigned long long* seq_host, FrSumsRide R) {
   using namespace fr_err;
+  static_assert(kFrErrThreads == 256 && NQ <= 32, "the fold deals (slice, quantity) pairs to 8 x 32 lanes");
   __shared__ double scratch[(kFrErrThreads / 64 + 1) * NQ];
+  __shared__ double fold[9 * NQ];
   __shared__ int last;
   const KktDev& K = A.K;
   const double* V = A.V;
   const int me = A.m_e, mi = A.m_i, n = A.n;
   const int ops[NQ] = SLPX_FR_ERR_OPS;
+  const int n_err_blocks = R.n_err_blocks;
+  const bool sum_block = static_cast<int>(blockIdx.x) >= n_err_blocks;
+  if (sum_block) {
+    const NlpStructure::SumReduce r = R.red[blockIdx.x - n_err_blocks];
+    const int tid = threadIdx.x;
+    double a = 0.0;
+    if (tid < 64)
+      for (int k = tid; k < r.count; k += 64) a += V[r.src_off + k];
+    if (tid < 64) scratch[tid] = a;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (tid < w) scratch[tid] += scratch[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) coherent_store(&R.Vw[r.dst], (r.scale_idx >= 0 ? R.tape_scales[r.scale_idx] : 1.0) * scratch[0], true);
+  }
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = ops[q] == IPM_MIN ? 1.0 : 0.0;
   acc[SZ_MIN] = 1e300;
   acc[EMIN0] = 1e300;
-  const int stride = gridDim.x * kFrErrThreads, t0 = blockIdx.x * kFrErrThreads + threadIdx.x;
+  // (a workgroup of the sums has no rows: its lanes start past every range)
+  const int stride = n_err_blocks * kFrErrThreads, t0 = sum_block ? (1 << 30) : blockIdx.x * kFrErrThreads + threadIdx.x;
   const double* d_ce = A.scales + 1;
   const double* d_ci = A.scales + 1 + me;
   const double* ce = V + K.off_ce;
@@ -530,10 +569,12 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
     if (!isfinite(sr) || !isfinite(c)) acc[FINITE] = 0.0;
     if (!(c > 0.0)) acc[CIPOS] = 0.0;
   };
-  // columns of x
-  for (int j = t0; j < n; j += stride) {
+  // columns of x: EIGHT LANES per column, an entry of the column each (walked by one lane a column of A_e is 5-9
+  // dependent trips to memory; this is two — ipm_error_accumulate does the same), summed by DPP in lane order
+  const int lane8 = t0 & 7;
+  for (int j = t0 >> 3; j < n; j += stride >> 3) {
     double a1 = 0.0, a1u = 0.0, aetce = 0.0;
-    for (int q = K.ae_colptr[j]; q < K.ae_colptr[j + 1]; ++q) {
+    for (int q = K.ae_colptr[j] + lane8; q < K.ae_colptr[j + 1]; q += 8) {
       const int r = K.ae_rowidx[q];
       const double a = Ae[q], dr = d_ce[r];
       const double cer = (ce[r] - A.pn[r]) + A.pn[me + r];
@@ -542,7 +583,7 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
       aetce += a * cer;
     }
     double a2 = 0.0, a2u = 0.0, aitcp = 0.0;
-    for (int q = K.ai_colptr[j]; q < K.ai_colptr[j + 1]; ++q) {
+    for (int q = K.ai_colptr[j] + lane8; q < K.ai_colptr[j + 1]; q += 8) {
       const int r = K.ai_rowidx[q];
       const double a = Ai[q], dr = d_ci[r];
       const double cir = (ci[r] - A.pn[2 * me + r]) + A.pn[2 * me + mi + r];
@@ -550,14 +591,22 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
       a2u += ((1.0 / dr) * a) * (dr * A.z0[r]);
       aitcp += a * fmin(cir, 0.0);
     }
-    const double xj = A.in[j], dx = xj - A.xr[j];
-    const double g = A.w[j] * dx;
-    dual_entry((g - a1) - a2, (g - a1u) - a2u);
-    acc[AETCE] += aetce * aetce;
-    acc[AITCP] += aitcp * aitcp;
-    var_entry(xj);
-    acc[COST] += 0.5 * (A.w[j] * (dx * dx));
-    acc[DPHI_O] += A.g_outer[j] * dx;
+    const double xj = A.in[j], dx = xj - A.xr[j], wj = A.w[j], go = A.g_outer[j];
+    a1 = ipm_group8_sum(a1);
+    a1u = ipm_group8_sum(a1u);
+    aetce = ipm_group8_sum(aetce);
+    a2 = ipm_group8_sum(a2);
+    a2u = ipm_group8_sum(a2u);
+    aitcp = ipm_group8_sum(aitcp);
+    if (lane8 == 0) {
+      const double g = wj * dx;
+      dual_entry((g - a1) - a2, (g - a1u) - a2u);
+      acc[AETCE] += aetce * aetce;
+      acc[AITCP] += aitcp * aitcp;
+      var_entry(xj);
+      acc[COST] += 0.5 * (wj * (dx * dx));
+      acc[DPHI_O] += go * dx;
+    }
   }
   // equality rows, with the columns and bound rows of p_e, n_e
   for (int j = t0; j < me; j += stride) {
@@ -617,9 +666,11 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
   if (check_all_V)
     for (int k = t0; k < nV; k += stride)
       if (!isfinite(V[k])) acc[FINITE] = 0.0;
-  block_reduce<NQ, kFrErrThreads>(acc, ops, scratch);
-  // (block_reduce leaves the workgroup's totals behind its per-wave rows)
-  if (threadIdx.x < NQ) coherent_store(&partial[blockIdx.x * NQ + threadIdx.x], scratch[(kFrErrThreads / 64) * NQ + threadIdx.x], true);
+  if (!sum_block) {
+    block_reduce<NQ, kFrErrThreads>(acc, ops, scratch);
+    // (block_reduce leaves the workgroup's totals behind its per-wave rows)
+    if (threadIdx.x < NQ) coherent_store(&partial[blockIdx.x * NQ + threadIdx.x], scratch[(kFrErrThreads / 64) * NQ + threadIdx.x], true);
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -629,15 +680,39 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
   }
   __syncthreads();
   if (!last) return;
-  double* tot = scratch;
+  // thread = (slice of the workgroups, quantity): eight slices walk the partials side by side, four loads in flight
+  // each, then the slices are combined in slice order (a fixed order: the same bits run after run).  One lane per
+  // quantity walking them one after the other was a dependent trip to memory per workgroup: 12 of the kernel's 19 us.
+  double* tot = fold;
+  double* part = fold + NQ;  // [8][NQ]
+  {
+    const int q = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    if (q < NQ) {
+      int op = ops[0];
+#pragma unroll
+      for (int k = 1; k < NQ; ++k)
+        if (q == k) op = ops[k];
+      double v = op == IPM_SUM ? 0.0 : (op == IPM_MAX ? -1e300 : 1e300);
+      const int nb = n_err_blocks;
+      int b = sl;
+      for (; b + 24 < nb; b += 32) {
+        const double v0 = coherent_load(&partial[b * NQ + q], true), v1 = coherent_load(&partial[(b + 8) * NQ + q], true),
+                     v2 = coherent_load(&partial[(b + 16) * NQ + q], true), v3 = coherent_load(&partial[(b + 24) * NQ + q], true);
+        v = ipm_combine(op, ipm_combine(op, ipm_combine(op, ipm_combine(op, v, v0), v1), v2), v3);
+      }
+      for (; b < nb; b += 8) v = ipm_combine(op, v, coherent_load(&partial[b * NQ + q], true));
+      part[sl * NQ + q] = v;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x < NQ) {
     const int q = threadIdx.x;
     int op = ops[0];
 #pragma unroll
     for (int k = 1; k < NQ; ++k)
       if (q == k) op = ops[k];
-    double v = coherent_load(&partial[q], true);
-    for (unsigned int b = 1; b < gridDim.x; ++b) v = ipm_combine(op, v, coherent_load(&partial[b * NQ + q], true));
+    double v = part[q];
+    for (int k = 1; k < 8; ++k) v = ipm_combine(op, v, part[k * NQ + q]);
     tot[q] = v;
   }
   __syncthreads();
@@ -665,7 +740,7 @@ __global__ __launch_bounds__(kFrErrThreads) void fr_errors_kernel(FrDevice::Args
     e.cp_sq = tot[CPSQ];
     e.x_inf = tot[XINF];
     e.s_inf = tot[SINF];
-    const double f_outer = V[K.off_f];
+    const double f_outer = coherent_load(&V[K.off_f], true);  // (a riding sum's, or the sweep's own)
     e.finite = (tot[FINITE] != 0.0 && isfinite(tot[COST])) ? 1.0 : 0.0;
     e.ci_all_pos = tot[CIPOS];
     out->e = e;
@@ -813,9 +888,23 @@ void FrDevice::build(double delta, double mu, bool soc, bool rhs_only, bool seco
     m_rhs2.alloc(static_cast<size_t>(std::max(1, K.dim)));
   }
   hipLaunchKernelGGL(fr_build_kernel, dim3(grid_for(work, 256)), dim3(256), 0, m_dev.stream(), args(), m_diag_of.p, delta, mu, soc ? 1 : 0,
-                     rhs_only ? 1 : 0, second ? m_lhs2.p : m_dev.lhs_raw(), second ? m_rhs2.p : m_dev.rhs_raw());
+                     rhs_only ? 1 : 0, second ? m_lhs2.p : m_dev.lhs_raw(), second ? m_rhs2.p : m_dev.rhs_raw(), 0.0,
+                     static_cast<double*>(nullptr), static_cast<double*>(nullptr));
   SLPX_HIP_CHECK(hipGetLastError());
   if (!second) m_dev.system_written_by_caller(!rhs_only, true);
+}
+
+void FrDevice::build_pair(double delta, double delta_second, double mu) {
+  const KktDev K = m_dev.kdev();
+  const int work = std::max(K.nnz_lhs, K.dim);
+  if (m_lhs2.n == 0) {
+    m_lhs2.alloc(static_cast<size_t>(std::max(1, K.nnz_lhs)));
+    m_rhs2.alloc(static_cast<size_t>(std::max(1, K.dim)));
+  }
+  hipLaunchKernelGGL(fr_build_kernel, dim3(grid_for(work, 256), 2), dim3(256), 0, m_dev.stream(), args(), m_diag_of.p, delta, mu, 0, 0,
+                     m_dev.lhs_raw(), m_dev.rhs_raw(), delta_second, m_lhs2.p, m_rhs2.p);
+  SLPX_HIP_CHECK(hipGetLastError());
+  m_dev.system_written_by_caller(true, true);
 }
 
 void FrDevice::expand(double delta, double mu, double tau, bool soc, bool ahead) {
@@ -853,11 +942,19 @@ void FrDevice::commit(double alpha, double alpha_z, double mu) {
   m_dev.state_changed_by_caller();
 }
 
-void FrDevice::errors(bool check_all_V, double /*mu*/, bool ahead) {
-  const int work = std::max({m_n, m_me, m_mi, 1});
+void FrDevice::errors(bool check_all_V, double /*mu*/, bool ahead, bool sums_ride) {
+  const int work = std::max({8 * m_n, m_me, m_mi, 1});  // (eight lanes per column of x)
   const int blocks = grid_for(work, kFrErrThreads, 64);
-  hipLaunchKernelGGL(fr_errors_kernel, dim3(blocks), dim3(kFrErrThreads), 0, m_dev.stream(), args(ahead), m_dev.structure().nV,
-                     check_all_V ? 1 : 0, m_mu_outer, m_partial.p, m_done.p, ahead ? &m_host->err_ahead : &m_host->err, m_seq_dev.p, m_h_seq);
+  const Args a = args(ahead);
+  FrSumsRide ride;
+  ride.n_err_blocks = blocks;
+  ride.red = m_dev.reduces_dev();
+  ride.tape_scales = m_dev.tape_scales_dev();
+  ride.Vw = const_cast<double*>(a.V);
+  const int n_sums = sums_ride ? m_dev.n_reduces() : 0;
+  hipLaunchKernelGGL(fr_errors_kernel, dim3(blocks + n_sums), dim3(kFrErrThreads), 0, m_dev.stream(), a, m_dev.structure().nV,
+                     check_all_V ? 1 : 0, m_mu_outer, m_partial.p, m_done.p, ahead ? &m_host->err_ahead : &m_host->err, m_seq_dev.p, m_h_seq,
+                     ride);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
 }

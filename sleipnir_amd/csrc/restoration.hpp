@@ -82,6 +82,8 @@ class FrDevice {
   // second: into this object's own arrays (second_lhs() / second_rhs()) — the system of the attempt the regularization
   // policy would make next, factored beside the first in one launch (NewtonSystem::compute_hooked)
   void build(double delta, double mu, bool soc, bool rhs_only, bool second = false);
+  // both of a launch's systems in ONE launch: (delta) into the outer system's arrays, (delta_second) into this object's
+  void build_pair(double delta, double delta_second, double mu);
   const double* second_lhs() const { return m_lhs2.p; }
   const double* second_rhs() const { return m_rhs2.p; }
   // p = (dx, w) of the outer system -> the whole direction, its step sizes and directional derivative (-> host().dir,
@@ -95,7 +97,9 @@ class FrDevice {
   void trial_point(double alpha);                // trial x = x + alpha dx
   void trial_metrics(double alpha, double mu);   // after a value sweep at the trial x; alpha < 0: the device's alpha_max
   void commit(double alpha, double alpha_z, double mu);
-  void errors(bool check_all_V, double mu, bool ahead = false);  // after a full sweep at x -> host().err (err_ahead)
+  // after a full sweep at x -> host().err (err_ahead).  sums_ride: the sweep was made without its separable sums
+  // (sweep_full(false)); they ride in this launch as extra workgroups, as in DeviceNlp::ipm_errors
+  void errors(bool check_all_V, double mu, bool ahead = false, bool sums_ride = false);
   void soc_accumulate(double alpha, bool first);
   void save_direction();
   void restore_direction();

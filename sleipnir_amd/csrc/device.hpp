@@ -537,6 +537,15 @@ class DeviceNlp {
   const struct IpmCtl& ipm_pipeline_fetch();  // device -> host (synchronizes; the pipeline is drained when the host asks)
   // the NEXT step launch (one launch) waits for the decision of the error launch in front of it
   void ipm_gate_next_step(bool on) { m_gate_next_step = on; }
+  // The error launch of the iteration whose look-ahead iterate was just made current (ipm_accept_lookahead) RIDES in
+  // the next step launch (a launch of two attempts: ldlt_mf_twin_kernel<.., true>) and decides there whether that step
+  // counts; its scalars and verdict go to the host slot `slot_out` (err_ahead, go).  false if such a launch cannot
+  // carry it (then nothing was armed).  ipm_ride_wait(): the verdict, once those scalars are in.
+  bool ipm_ride_errors_in_next_step(int slot_out);
+  bool ipm_ride_possible();  // (asked once per system: both attempts' tasks and the riding workgroups resident at once; SLPX_IPM_RIDE=0: never)
+  bool ipm_ride_wait(int slot_out);
+  bool ipm_ride_armed() const { return m_ride_next; }
+  void ipm_ride_disarm() { m_ride_next = false; }
   // ipm_errors(.., ahead) that also takes the decision
   void ipm_errors_deciding(bool sums_ride);
   unsigned long long seq_expected() const { return m_seq_expected; }
@@ -552,11 +561,16 @@ class DeviceNlp {
     return LaunchBook{m_stats_cur, m_stats_tw_cur, m_xg_parity, m_xg_tw_parity, m_twin_mode, m_kkt_pending, m_last_step_chained,
                       m_stats_in_host, m_lhs_stale, m_rhs_stale, m_stream.tape_pending, m_stream.touched, m_stats_seq};
   }
-  void restore_book(const LaunchBook& b) {
+  // launch_ran: the launch was not let pass at its gate — it ran with its results held back (a step that carried the
+  // error launch deciding about it: MfDev::ride_verdict) and so moved the launch's OWN hand-overs on: the buffers the
+  // backward solve hands x through have changed roles for good
+  void restore_book(const LaunchBook& b, bool launch_ran = false) {
     m_stats_cur = b.stats_cur;
     m_stats_tw_cur = b.stats_tw_cur;
-    m_xg_parity = b.xg_parity;
-    m_xg_tw_parity = b.xg_tw_parity;
+    if (!launch_ran) {
+      m_xg_parity = b.xg_parity;
+      m_xg_tw_parity = b.xg_tw_parity;
+    }
     m_twin_mode = b.twin_mode;
     m_kkt_pending = b.kkt_pending;
     m_last_step_chained = b.last_step_chained;
@@ -773,6 +787,11 @@ class DeviceNlp {
   void* m_ipm_ctl_dev = nullptr;             // IpmCtl on the device
   DevBuf<double> m_ipm_gate;
   bool m_gate_next_step = false;
+  bool m_ride_next = false;
+  int m_ride_slot = 0;
+  double m_ride_ticket = 1.0;       // of the last riding launch (2, 3, ...: never a plain launch's 0 / 1 in IpmHost::go)
+  DevBuf<double> m_ipm_ride_verdict;
+  int m_ride_lds_ok = -1;           // the riding kernels' dynamic LDS was raised / fits (-1: not asked yet)
   bool m_errors_decide = false;
   bool m_tape_reduce = true;       // launch_tape runs the separable-sum reductions itself
   // chained steps (sweep_full_for_step): words 0 / 16 / 32 / 48 of m_chain = workgroups of the sweep

@@ -620,11 +620,12 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   };
   long twin_launches = 0, twin_taken = 0;
   bool spec_in_flight = false;  // the NEXT iteration's step and chain are enqueued already (and will run)
+  bool spec_rides = false;      // ... and that step carries its own verdict (it runs whatever that is)
   long pipelined = 0, passed = 0;
   auto finish = [&](ExitStatus st_) {
     if (spec_in_flight) {  // (the step enqueued ahead runs for nothing: wait for it, forget it)
       dev.wait_published();
-      sys.cancel_speculative_compute();
+      sys.cancel_speculative_compute(/*launch_ran=*/spec_rides);
       spec_in_flight = false;
     }
     sys.set_after_attempt(nullptr);
@@ -697,6 +698,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   // SLPX_IPM_PIPELINE=0: every iteration decided by the host, as before.
   const char* pipeline_env = std::getenv("SLPX_IPM_PIPELINE");
   const bool pipeline_on = lookahead && callbacks.empty() && !options.feasible_ipm && !(pipeline_env && pipeline_env[0] == '0');
+  const bool ride_on = pipeline_on && dev.ipm_ride_possible();  // (SLPX_IPM_RIDE=0: the error launch in front of the gated step)
   bool ctl_current = false;      // the device's copy of (filter, current iterate's entry, mu) is the host's
   bool filter_on_device = false; // ... and newer than the host's: the device took decisions since
   auto sync_filter_from_device = [&] {
@@ -764,11 +766,15 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     // iterations take the first trial point: the iteration is then complete when these numbers arrive
     // (one host round trip, four launches), and nothing is computed twice.  The feasible-IPM option
     // derives the trial s from the trial c_i (:520-526): it keeps the trial-values chain below.
+    // (the error launch of a deciding chain comes LATER: riding in the next step's launch — it decides whether that
+    // step counts while the step factors — or on its own where no step is enqueued ahead)
+    const bool errors_later = deciding && ride_on;
     sys.set_after_attempt([&] {
       if (ahead) {
         dev.ipm_lookahead(tau);
         dev.sweep_full_lookahead();
-        if (deciding) dev.ipm_errors_deciding(/*sums_ride=*/true);
+        if (errors_later) {
+        } else if (deciding) dev.ipm_errors_deciding(/*sums_ride=*/true);
         else dev.ipm_errors(false, /*sums_ride=*/true, /*ahead=*/true);
       } else {
         dev.ipm_direction(tau);
@@ -783,23 +789,35 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
     twin_launches += sys.last_twin_launches();
     twin_taken += sys.last_twin_taken();
     // ---- the next iteration's step, ahead of this one's verdict ----
-    bool spec = false;
-    const unsigned long long seq_this = dev.seq_expected();  // this iteration's chain ends with this publication
+    bool spec = false, rode = false;
     if (deciding && info[0] == FactorInfo::Success && iterations + 2 < options.max_iterations) {
       dev.ipm_accept_lookahead();  // (the roles the buffers have if the device takes the step; put back below if not)
       dev.ipm_set_slot(slot ^ 1);
       // (the chain of the step enqueued ahead decides too: the device's state is its own by then)
-      spec = sys.begin_speculative_compute();
+      if (errors_later) rode = dev.ipm_ride_errors_in_next_step(slot);
+      spec = sys.begin_speculative_compute(/*gated=*/!rode);
       if (!spec) {
+        rode = false;
         dev.ipm_accept_lookahead();
         dev.ipm_set_slot(slot);
       }
     }
+    if (errors_later && !rode) {
+      if (spec) throw std::logic_error("slpx: a step enqueued ahead of its own verdict");
+      dev.ipm_errors_deciding(/*sums_ride=*/true);  // (nothing was enqueued ahead: the error launch on its own)
+    }
+    const unsigned long long seq_this = dev.seq_expected();  // a chain that holds its error launch ends with this publication
     sys.set_twin_attempts(false);
     sys.set_after_attempt(nullptr);
-    dev.wait_published_until(seq_this);  // compute() returns when the inertia counters are in; the trial chain may still run
+    bool device_took_it = false;
+    if (rode) {
+      device_took_it = dev.ipm_ride_wait(slot);  // (the riding launch's scalars are in when its verdict is)
+    } else {
+      dev.wait_published_until(seq_this);  // compute() returns when the inertia counters are in; the trial chain may still run
+      device_took_it = spec && H.go != 0.0;
+    }
     if (spec) {
-      if (H.go != 0.0) {
+      if (device_took_it) {
         // the device took this iteration's decisions (ipm_decide.h): the filter accepted the full step, the
         // error is above the tolerance, mu stays; the next step is on its way.  The host follows.
         ++pipelined;
@@ -826,6 +844,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         slot ^= 1;
         Hp = &dev.ipm_host_slot(slot);
         spec_in_flight = true;
+        spec_rides = rode;
         if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
         continue;
       }
@@ -833,7 +852,7 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
       // (no waiting for them: what the host enqueues next runs behind them in the stream's order, and they write nothing
       // but their sequence numbers)
       ++passed;
-      sys.cancel_speculative_compute();
+      sys.cancel_speculative_compute(/*launch_ran=*/rode);  // (a step that carried its own verdict ran, and held its results back)
       dev.ipm_accept_lookahead();
       dev.ipm_set_slot(slot);
     }

@@ -433,6 +433,11 @@ struct IpmErrFinish {
   const double* dir = nullptr;
   double* gate = nullptr;
   double* go_host = nullptr;  // the verdict for the host, beside the scalars of this launch (IpmHost::go)
+  // This launch RIDES in the step it decides about (ldlt_mf_kernels.h: MfRide): the verdict goes to that launch's
+  // tasks as +-ride_ticket in *ride_verdict, and to the host as +-ride_ticket in *go_host — which is then also the
+  // host's word that this launch's scalars are in (no sequence number: the step's own publication owns that).
+  double* ride_verdict = nullptr;
+  double ride_ticket = 0.0;
 };
 
 // folds the per-workgroup partials in workgroup order and hands the result to the host;
@@ -591,7 +596,19 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
         }
         C->go = go ? 1 : 0;
         *decide->gate = go ? 1.0 : 0.0;
-        if (decide->go_host != nullptr) *decide->go_host = go ? 1.0 : 0.0;
+        if (decide->ride_verdict != nullptr) {
+          __hip_atomic_store(decide->ride_verdict, go ? decide->ride_ticket : -decide->ride_ticket, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        } else if (decide->go_host != nullptr) {
+          *decide->go_host = go ? 1.0 : 0.0;
+        }
+      }
+      if (decide->ride_verdict != nullptr) {
+        if (k == 0) {
+          __threadfence_system();  // (the 24 scalars above are the wave's: one fence)
+          *decide->go_host = go ? decide->ride_ticket : -decide->ride_ticket;
+        }
+        return;
       }
     }
     if (k == 0) ipm_publish(seq_dev, seq_host);
@@ -599,19 +616,19 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
 }
 
 // end of a workgroup of the one-launch error computation: count it in; the last one folds
+// (`tot`: 9 kIpmErrQ + 1 doubles of LDS; every thread of the workgroup calls)
 __device__ __forceinline__ void ipm_error_finish(const KktDev& K, const double* __restrict__ V,
-                                                 const double* __restrict__ partial, const IpmErrFinish& fin) {
-  __shared__ double tot[9 * kIpmErrQ];
-  __shared__ int last;
+                                                 const double* __restrict__ partial, const IpmErrFinish& fin, double* tot) {
+  int* last = reinterpret_cast<int*>(tot + 9 * kIpmErrQ);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this workgroup's coherent stores are in
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int old = __hip_atomic_fetch_add(fin.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = old + 1 == static_cast<unsigned int>(fin.n_total_blocks);
-    if (last) __hip_atomic_store(fin.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last = old + 1 == static_cast<unsigned int>(fin.n_total_blocks);
+    if (*last) __hip_atomic_store(fin.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!last) return;
+  if (!*last) return;
   ipm_error_fold(K, V, partial, fin.n_err_blocks, true, fin.out, fin.seq_dev, fin.seq_host, tot, &fin);
 }
 
@@ -707,30 +724,29 @@ __device__ __forceinline__ void ipm_error_accumulate(const KktDev& K, const doub
       if (!isfinite(V[k])) acc[FINITE] = 0.0;
 }
 
-__global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
-    KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
-    const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
-    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial, IpmErrFinish fin) {
+// LDS of a workgroup of the error launch, in doubles: the transposed partials (or a sum's tree), then the fold's
+constexpr int kIpmErrLdsDoubles = kIpmErrQ * (kIpmErrThreads + 1) + 9 * kIpmErrQ + 2;
+
+// Workgroup `block` of [error workgroups | one per separable sum] of the one-launch error computation
+// (fin.n_err_blocks != 0: whichever workgroup finishes last folds the partials and publishes, ipm_error_finish) or
+// of the partials alone (0: ipm_error_final_kernel follows; `n_blocks_two_launch` of them).  EVERY thread of the
+// calling workgroup calls — it may be larger than kIpmErrThreads (the step kernel's, when the launch rides in it:
+// ldlt_mf_kernels.h): the first kIpmErrThreads lanes work, the others keep the barriers company.
+__device__ __forceinline__ void ipm_error_block(const KktDev& K, const double* __restrict__ V, int nV, const double* __restrict__ x,
+                                                const double* __restrict__ s, const double* __restrict__ y,
+                                                const double* __restrict__ z, const double* __restrict__ scales, int check_all_V,
+                                                double* __restrict__ partial, const IpmErrFinish& fin, int block,
+                                                int n_blocks_two_launch, double* lds) {
   using namespace ipm_err;
   constexpr int NQ = kIpmErrQ;
-  __shared__ double scratch[(kIpmErrThreads / 64 + 1) * NQ];
-  if (fin.skip != nullptr && fin.skip[0] != 0.0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      if (fin.ctl != nullptr) {  // (a void chain decides nothing: whatever was enqueued behind it passes too)
-        fin.ctl->go = 0;
-        *fin.gate = 0.0;
-        if (fin.go_host != nullptr) *fin.go_host = 0.0;
-      }
-      ipm_publish(fin.seq_dev, fin.seq_host);
-    }
-    return;
-  }
-  // fin.n_err_blocks != 0: ONE launch — the tape's separable sums (which make f) ride as extra
-  // workgroups, and whichever workgroup finishes last folds the partials and publishes
-  // (ipm_error_finish); 0: the partials only, ipm_error_final_kernel follows.
-  if (fin.n_err_blocks != 0 && static_cast<int>(blockIdx.x) >= fin.n_err_blocks) {
-    const NlpStructure::SumReduce r = fin.red[blockIdx.x - fin.n_err_blocks];
+  constexpr int kPad = kIpmErrThreads + 1;
+  double* tr = lds;                 // [NQ][kPad]
+  double* tot = lds + NQ * kPad;    // ipm_error_finish's
+  const bool active = threadIdx.x < kIpmErrThreads;
+  if (fin.n_err_blocks != 0 && block >= fin.n_err_blocks) {
+    const NlpStructure::SumReduce r = fin.red[block - fin.n_err_blocks];
     const int tid = threadIdx.x;
+    double* scratch = tr;
     double acc = 0.0;
     if (tid < 64)
       for (int k = tid; k < r.count; k += 64) acc += V[r.src_off + k];
@@ -742,22 +758,23 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
     }
     if (tid == 0)
       coherent_store(&fin.Vw[r.dst], (r.scale_idx >= 0 ? fin.tape_scales[r.scale_idx] : 1.0) * scratch[0], true);
-    ipm_error_finish(K, V, partial, fin);
+    ipm_error_finish(K, V, partial, fin, tot);
     return;
   }
-  const int n_blocks = fin.n_err_blocks != 0 ? fin.n_err_blocks : static_cast<int>(gridDim.x);
+  const int n_blocks = fin.n_err_blocks != 0 ? fin.n_err_blocks : n_blocks_two_launch;
   double acc[NQ];
   const int ops[NQ] = SLPX_IPM_ERR_OPS;
-  ipm_error_accumulate(K, V, nV, x, s, y, z, scales, check_all_V, blockIdx.x * kIpmErrThreads + threadIdx.x,
-                       n_blocks * kIpmErrThreads, acc);
+  if (active)
+    ipm_error_accumulate(K, V, nV, x, s, y, z, scales, check_all_V, block * kIpmErrThreads + static_cast<int>(threadIdx.x),
+                         n_blocks * kIpmErrThreads, acc);
   // the workgroup's partial of every quantity: the lanes' values through LDS, transposed — thread (q, sub) folds
   // 32 of the 256 values of quantity q in a fixed order, the eight subs by DPP; 23 wave reductions by butterfly
   // were ~700 instructions per wave
   {
-    constexpr int kPad = kIpmErrThreads + 1;
-    __shared__ double tr[NQ * kPad];
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) tr[q * kPad + threadIdx.x] = acc[q];
+      for (int q = 0; q < NQ; ++q) tr[q * kPad + threadIdx.x] = acc[q];
+    }
     __syncthreads();
     const int q = threadIdx.x >> 3, sub = threadIdx.x & 7;
     if (q < NQ) {
@@ -767,24 +784,43 @@ __global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
         if (q == k) op = ops[k];
       // (all 32 values requested at once, and the three kinds of fold side by side — the kind is picked once at the
       // end: as a loop of 31 load-select-combine steps this was 3.3 us of the launch's 14)
-      double x[kIpmErrThreads / 8];
+      double xv[kIpmErrThreads / 8];
 #pragma unroll
-      for (int k = 0; k < kIpmErrThreads / 8; ++k) x[k] = tr[q * kPad + sub + 8 * k];
-      double vs = x[0], vmax = x[0], vmin = x[0];
+      for (int k = 0; k < kIpmErrThreads / 8; ++k) xv[k] = tr[q * kPad + sub + 8 * k];
+      double vs = xv[0], vmax = xv[0], vmin = xv[0];
 #pragma unroll
       for (int k = 1; k < kIpmErrThreads / 8; ++k) {
-        vs += x[k];
-        vmax = fmax(vmax, x[k]);
-        vmin = fmin(vmin, x[k]);
+        vs += xv[k];
+        vmax = fmax(vmax, xv[k]);
+        vmin = fmin(vmin, xv[k]);
       }
       double v = op == IPM_SUM ? vs : (op == IPM_MAX ? vmax : vmin);
       v = ipm_combine(op, v, ipm_dpp<0xB1>(v));
       v = ipm_combine(op, v, ipm_dpp<0x4E>(v));
       v = ipm_combine(op, v, ipm_dpp<0x141>(v));
-      if (sub == 0) coherent_store(&partial[blockIdx.x * NQ + q], v, fin.n_err_blocks != 0);
+      if (sub == 0) coherent_store(&partial[block * NQ + q], v, fin.n_err_blocks != 0);
     }
   }
-  if (fin.n_err_blocks != 0) ipm_error_finish(K, V, partial, fin);
+  if (fin.n_err_blocks != 0) ipm_error_finish(K, V, partial, fin, tot);
+}
+
+__global__ __launch_bounds__(kIpmErrThreads) void ipm_error_partial_kernel(
+    KktDev K, const double* __restrict__ V, int nV, const double* __restrict__ x,
+    const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ z,
+    const double* __restrict__ scales, int check_all_V, double* __restrict__ partial, IpmErrFinish fin) {
+  __shared__ double lds[kIpmErrLdsDoubles];
+  if (fin.skip != nullptr && fin.skip[0] != 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (fin.ctl != nullptr) {  // (a void chain decides nothing: whatever was enqueued behind it passes too)
+        fin.ctl->go = 0;
+        *fin.gate = 0.0;
+        if (fin.go_host != nullptr) *fin.go_host = 0.0;
+      }
+      ipm_publish(fin.seq_dev, fin.seq_host);
+    }
+    return;
+  }
+  ipm_error_block(K, V, nV, x, s, y, z, scales, check_all_V, partial, fin, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), lds);
 }
 
 __global__ __launch_bounds__(256) void ipm_error_final_kernel(KktDev K, const double* __restrict__ V,

@@ -1760,10 +1760,10 @@ bool DeviceNlp::twin_available() {
   // tasks, twice that is more than the 256 CUs.  Workgroups of 512 threads fit two to a CU and run the same image
   // 0.5 us slower at that horizon, to the same bits: a launch of two attempts takes those where the wide ones do not fit)
   m_twin_threads = m_mf_threads;
-  bool fits = m_mf_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024>, 1024) : resident(&ldlt_mf_twin_kernel<512>, 512);
+  bool fits = m_mf_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024, false>, 1024) : resident(&ldlt_mf_twin_kernel<512, false>, 512);
   if (!fits && m_mf_threads == 1024) {
     m_twin_threads = 512;
-    fits = resident(&ldlt_mf_twin_kernel<512>, 512);
+    fits = resident(&ldlt_mf_twin_kernel<512, false>, 512);
   }
   if (std::getenv("SLPX_LDLT_VERBOSE"))
     std::fprintf(stderr, "ldlt twin attempt: 2 x %zu tasks, %d workgroup(s) of %d threads per CU x %d CUs%s\n", l.tasks.size(), per_cu,
@@ -1830,14 +1830,60 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
     tw.stats_next = m_stats_tw.p + static_cast<size_t>(tw_parity ^ 1);
     tw.lhs = lhs2;
     tw.rhs = rhs2;
-    const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks));
+    MfRide ride;
+    size_t lds = m_mf_lds;
+    if (m_ride_next) {
+      // the error launch of the iteration before this step (ipm_ride_errors_in_next_step): its workgroups in front of
+      // the tasks, on the CURRENT buffers — the look-ahead iterate has been made current —, the tape's sums with them
+      m_ride_next = false;
+      const int work = std::max({m_kdev.n, m_kdev.m_e, m_kdev.m_i, 1});
+      const int blocks = grid_for(8 * work, kIpmErrThreads, 64);
+      if (m_ipm_partial.n < static_cast<size_t>(blocks) * kIpmErrQ) m_ipm_partial.alloc(static_cast<size_t>(256) * kIpmErrQ);
+      if (m_ipm_err_done.n == 0) m_ipm_err_done.upload(std::vector<unsigned int>(1, 0u));
+      const int n_sums = static_cast<int>(m_reduces.n);
+      m_ride_ticket += 1.0;
+      md.ride_verdict = m_ipm_ride_verdict.p;
+      md.ride_ticket = m_ride_ticket;
+      md.gate = nullptr;  // (nothing in front of this launch is undecided: its own riding workgroups decide)
+      ride.n_blocks = static_cast<uint32_t>(blocks + n_sums);
+      ride.K = m_kdev;
+      ride.V = m_V.p;
+      ride.x = m_in.p;
+      ride.s = m_s.p;
+      ride.y = m_y.p;
+      ride.z = m_z.p;
+      ride.scales = m_ipm_scales.p;
+      ride.nV = m_s_ref.nV;
+      ride.partial = m_ipm_partial.p;
+      IpmErrFinish& fin = ride.fin;
+      fin.n_err_blocks = blocks;
+      fin.n_total_blocks = blocks + n_sums;
+      fin.red = m_reduces.p;
+      fin.tape_scales = m_scales.p;
+      fin.Vw = m_V.p;
+      fin.done = m_ipm_err_done.p;
+      fin.out = &m_ipm_host[m_ride_slot].err_ahead;
+      fin.ctl = static_cast<IpmCtl*>(m_ipm_ctl_dev);
+      fin.dir = m_ipm_alpha.p;
+      fin.gate = m_ipm_gate.p;
+      fin.go_host = &m_ipm_host[m_ride_slot].go;
+      fin.ride_verdict = m_ipm_ride_verdict.p;
+      fin.ride_ticket = m_ride_ticket;
+      lds = std::max<size_t>(lds, sizeof(double) * kIpmErrLdsDoubles);
+    }
+    const dim3 grid(2u * md.n_tasks + static_cast<uint32_t>(f.n_blocks) + ride.n_blocks);
     md.n_workgroups = grid.x;
     auto launch = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, grid, dim3(threads), m_mf_lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p, l.n,
-                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw);
+      hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, m_stream.raw(), m_ldev, md, m_lhs.p, m_rhs.p, reg_by_value, m_Lx.p, m_D.p, l.n,
+                         m_mf_contrib.p, cur, next, m_zv.p, f, xg_now(), xg_other(), m_p.p, bf, tw, ride);
     };
-    if (m_twin_threads == 1024) launch(&ldlt_mf_twin_kernel<1024>, 1024);
-    else launch(&ldlt_mf_twin_kernel<512>, 512);
+    if (ride.n_blocks != 0) {
+      if (m_twin_threads == 1024) launch(&ldlt_mf_twin_kernel<1024, true>, 1024);
+      else launch(&ldlt_mf_twin_kernel<512, true>, 512);
+    } else {
+      if (m_twin_threads == 1024) launch(&ldlt_mf_twin_kernel<1024, false>, 1024);
+      else launch(&ldlt_mf_twin_kernel<512, false>, 512);
+    }
   } else {
     const dim3 grid(static_cast<uint32_t>(l.tasks.size()) + static_cast<uint32_t>(f.n_blocks));
     md.n_workgroups = grid.x;
@@ -2343,6 +2389,49 @@ void DeviceNlp::ipm_errors(bool check_all_V, bool sums_ride, bool ahead) {
                      ahead ? m_z_ahead.p : m_z.p, m_ipm_scales.p, check_all_V ? 1 : 0, m_ipm_partial.p, fin);
   ++m_seq_expected;
   SLPX_HIP_CHECK(hipGetLastError());
+}
+
+bool DeviceNlp::ipm_ride_errors_in_next_step(int slot_out) {
+  if (!ipm_ride_possible()) return false;
+  m_ride_next = true;
+  m_ride_slot = slot_out;
+  return true;
+}
+
+bool DeviceNlp::ipm_ride_possible() {
+  if (!twin_available()) return false;
+  if (m_ride_lds_ok < 0) {
+    // the riding workgroups' LDS (ipm_error_block) beside the tasks': the launch takes the larger of the two
+    const char* env = std::getenv("SLPX_IPM_RIDE");
+    m_ride_lds_ok = (env == nullptr || env[0] != '0') ? 1 : 0;
+    if (m_ride_lds_ok) {
+      int cus = 0, per_cu = 0;
+      SLPX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m_device));
+      const size_t lds = std::max<size_t>(m_mf_lds, sizeof(double) * kIpmErrLdsDoubles);
+      const size_t wgs = 2 * m_l_ref.tasks.size() + 64 + m_reduces.n;
+      auto resident = [&](auto kernel, int threads) {
+        SLPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SLPX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+        return wgs <= static_cast<size_t>(per_cu) * cus;
+      };
+      // (the tasks of both attempts AND the riding workgroups resident at once: a task that asks for the verdict must
+      // never keep a riding workgroup from being dispatched)
+      const bool fits = m_twin_threads == 1024 ? resident(&ldlt_mf_twin_kernel<1024, true>, 1024) : resident(&ldlt_mf_twin_kernel<512, true>, 512);
+      if (!fits) m_ride_lds_ok = 0;
+      if (m_ipm_ride_verdict.n == 0) m_ipm_ride_verdict.upload(std::vector<double>(1, 0.0));
+      if (std::getenv("SLPX_LDLT_VERBOSE"))
+        std::fprintf(stderr, "ldlt riding error launch: %zu workgroups, %d of %d threads per CU x %d CUs%s\n", wgs, per_cu, m_twin_threads, cus,
+                     fits ? "" : ": NOT resident at once");
+    }
+  }
+  return m_ride_lds_ok != 0;
+}
+
+bool DeviceNlp::ipm_ride_wait(int slot_out) {
+  volatile double* go = &m_ipm_host[slot_out].go;
+  const double ticket = m_ride_ticket;
+  spin_on_published([&] { return std::fabs(*go) == ticket; }, m_stream.raw(), "slpx: a riding error launch finished without its verdict");
+  return *go > 0.0;
 }
 
 void DeviceNlp::ipm_errors_deciding(bool sums_ride) {

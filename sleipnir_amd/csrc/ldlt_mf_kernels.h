@@ -62,6 +62,13 @@ struct MfDev {
   // that decides (ipm_error_partial_kernel's fold) leaves 1.0 here for "run" and 0.0 for "pass" — every workgroup then
   // leaves at once, the first one handing the host a marker in place of the counters.  null: an ordinary launch.
   const double* gate = nullptr;
+  // A step that carries the error launch of the iteration BEFORE it (ldlt_mf_twin_kernel<.., true>: the workgroups of
+  // ipm_error_block ride in front of the tasks): whether the step COUNTS is decided by those workgroups while the
+  // tasks factor.  Their deciding wave leaves +ride_ticket (counts) or -ride_ticket (does not) in *ride_verdict; every
+  // task asks before it writes anything that outlives the launch — L, D, z, the counters, p, p_s, p_z — and writes
+  // none of it if the step does not count (its hand-overs to other tasks go on as always: they are the launch's own).
+  const double* ride_verdict = nullptr;
+  double ride_ticket = 0.0;
 };
 
 // n_bad of the marker a passed launch publishes (nothing was factored; the host restores its launch bookkeeping)
@@ -513,7 +520,7 @@ __host__ __device__ inline MfCarve mf_carve(const LdltTask& t, const LdltMfTask&
 // `block`: the workgroup's place among [ride-along sums | tasks]; `exit_total` workgroups count themselves out
 // before the verdict is published; `twin_stats`: the counters of a second attempt made in the same launch
 // (ldlt_mf_twin_kernel), published with this one's.
-template <int THREADS, bool MFMA, bool CHAINED>
+template <int THREADS, bool MFMA, bool CHAINED, bool RIDE = false>
 __device__ __forceinline__ void mf_step_body(
     const LdltDev& L, const MfDev& Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
@@ -752,12 +759,32 @@ __device__ __forceinline__ void mf_step_body(
     }
   }
   SLPX_MF_CLOCK(3);
+  // (a step that carries the error launch of the iteration before it, MfDev::ride_verdict: does it count?  The riding
+  // workgroups were dispatched first and are through long before a task's levels are; one lane asks, the others come
+  // through the barrier and read the settled word themselves)
+  bool counts = true;
+  if constexpr (RIDE) {
+    if (Mf.ride_verdict != nullptr) {
+      if (tid == 0) {
+        unsigned int spins = 0;
+        while (fabs(__hip_atomic_load(Mf.ride_verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != Mf.ride_ticket) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) {  // never expected: mark the factorization bad instead of hanging
+            atomicAdd(&stats[0].n_bad, 1 << 20);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      counts = __hip_atomic_load(Mf.ride_verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == Mf.ride_ticket;
+    }
+  }
   // results + inertia (ldlt_factor_exit; where an entry goes and whose 1/d scales it: streamed from the
   // plan in memory — off the critical path, and 6 bytes per entry that need not sit in LDS)
   auto exit_and_count = [&] {
     const uint32_t* g_out = L.ent_out + t.ent_off;
     const uint16_t* g_col = L.ent_col + t.ent_off;
-    for (uint32_t i = tid; i < t.n_ent; i += THREADS) {
+    for (uint32_t i = counts ? tid : t.n_ent; i < t.n_ent; i += THREADS) {
       const double u = U[i];
       const uint8_t fl = flags[i];
       const uint32_t o = g_out[i];
@@ -776,16 +803,26 @@ __device__ __forceinline__ void mf_step_body(
       }
     }
     __syncthreads();
-    if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[0]) + tid, s_cnt[tid]);
-    if (tid == 0) atomicMin(&stats[0].min_abs_bits, *s_minp);
+    if (counts) {
+      if (tid < 4 && s_cnt[tid] != 0) atomicAdd(reinterpret_cast<int*>(&stats[0]) + tid, s_cnt[tid]);
+      if (tid == 0) atomicMin(&stats[0].min_abs_bits, *s_minp);
+    }
     if (threadIdx.x == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's counter updates are in
       const unsigned int old = __hip_atomic_fetch_add(Mf.exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old + 1 == exit_total) {
         __hip_atomic_store(Mf.exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (B.stats_host != nullptr) {
-          if (twin_stats != nullptr) publish_stats_copy(twin_stats, B.stats_host + 1);
-          publish_stats(B, true);
+          if (counts) {
+            if (twin_stats != nullptr) publish_stats_copy(twin_stats, B.stats_host + 1);
+            publish_stats(B, true);
+          } else if (B.seq_host != nullptr) {  // (the marker of a launch that does not count: kLdltPassed)
+            B.stats_host[0] = LdltStats{0, 0, 0, kLdltPassed, 0x7ff0000000000000ull};
+            __threadfence_system();
+            const unsigned long long v = *B.seq_dev + 1;
+            *B.seq_dev = v;
+            *B.seq_host = v;
+          }
         }
       }
     }
@@ -875,8 +912,9 @@ __device__ __forceinline__ void mf_step_body(
   for (uint32_t i = tid; i < t.n_col; i += THREADS) coherent_store(&xg[colperm[i]], x[i], true);
   for (uint32_t i = tid; i < t.n_col; i += THREADS)
     coherent_store(&xg_next[colperm[i]], __longlong_as_double(static_cast<long long>(kSlotEmpty)), true);
-  for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
-  if (B.on) {
+  if (counts)
+    for (uint32_t i = tid; i < t.n_col; i += THREADS) out[L.perm[colperm[i]]] = x[i];
+  if (B.on && counts) {
     const double mu = B.mu[0];
     auto p_of = [&](uint32_t ref) { return (ref & 0x80000000u) ? coherent_load(&xg[ref & 0x7fffffffu], true) : x[ref]; };
     for (uint32_t j = tid; j < bs_task.z; j += THREADS) {
@@ -960,13 +998,34 @@ struct MfTwin {
   const double *lhs = nullptr, *rhs = nullptr;
 };
 
-template <int THREADS>
+// The error launch of the iteration before this step, riding in front of its tasks (MfDev::ride_verdict): the
+// arguments of ipm_error_partial_kernel, `n_blocks` workgroups [error workgroups | one per separable sum].
+struct MfRide {
+  uint32_t n_blocks = 0;
+  KktDev K;
+  const double *V = nullptr, *x = nullptr, *s = nullptr, *y = nullptr, *z = nullptr, *scales = nullptr;
+  int nV = 0;
+  double* partial = nullptr;
+  IpmErrFinish fin;
+};
+
+template <int THREADS, bool RIDE = false>
 __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     LdltDev L, MfDev Mf, const double* __restrict__ lhs, const double* __restrict__ rhs, const double* __restrict__ reg,
     double* __restrict__ Lx, double* __restrict__ D, int n, double* __restrict__ contrib, LdltStats* __restrict__ stats,
     LdltStats* __restrict__ stats_next, double* __restrict__ zv, KktFuse F, double* __restrict__ xg,
-    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T) {
+    double* __restrict__ xg_next, double* __restrict__ out, BacksubFuse B, MfTwin T, MfRide R) {
   uint32_t block = blockIdx.x;
+  if constexpr (RIDE) {
+    static_assert(THREADS >= kIpmErrThreads, "ipm_error_block's lanes");
+    if (block < R.n_blocks) {
+      extern __shared__ __attribute__((aligned(16))) unsigned char ride_smem[];
+      ipm_error_block(R.K, R.V, R.nV, R.x, R.s, R.y, R.z, R.scales, 0, R.partial, R.fin, static_cast<int>(block), 0,
+                      reinterpret_cast<double*>(ride_smem));
+      return;
+    }
+    block -= R.n_blocks;
+  }
   if (block >= T.first_end) {  // (uniform over the workgroup: scalar selects)
     block = block - T.first_end + static_cast<uint32_t>(F.n_blocks);
     Mf.delta = T.delta;
@@ -986,8 +1045,8 @@ __global__ __launch_bounds__(THREADS) void ldlt_mf_twin_kernel(
     if (T.rhs != nullptr) rhs = T.rhs;
     F.store_lhs = nullptr;  // (the first attempt's workgroups keep the assembled system for later attempts)
   }
-  mf_step_body<THREADS, false, false>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
-                                      2u * Mf.n_tasks, T.stats);
+  mf_step_body<THREADS, false, false, RIDE>(L, Mf, lhs, rhs, reg, Lx, D, n, contrib, stats, stats_next, zv, F, xg, xg_next, out, B, block,
+                                            2u * Mf.n_tasks, T.stats);
 }
 
 // ---------------------------------------------------------------------------

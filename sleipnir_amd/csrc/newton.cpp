@@ -382,14 +382,18 @@ NewtonSystem::TwinLaunch NewtonSystem::twin_first_launch() const {
   return TwinLaunch{d, g, d * 10.0, g, 1};
 }
 
-bool NewtonSystem::begin_speculative_compute() {
-  if (m_spec.valid || m_opt.batch != 1 || !m_twin_attempts || !m_dev->twin_available()) return false;
+bool NewtonSystem::begin_speculative_compute(bool gated) {
+  if (m_spec.valid || m_opt.batch != 1 || !m_twin_attempts || !m_dev->twin_available()) {
+    m_dev->ipm_ride_disarm();
+    return false;
+  }
   const TwinLaunch tl = twin_first_launch();
   const DeviceNlp::LaunchBook book = m_dev->save_book();
   m_dev->build_kkt_for_step(/*with_reduce=*/false);
-  m_dev->ipm_gate_next_step(true);
+  m_dev->ipm_gate_next_step(gated);
   if (!m_dev->factor_solve_publish_twin(tl.d0, tl.g0, tl.d1, tl.g1, tl.mode)) {
     m_dev->ipm_gate_next_step(false);
+    m_dev->ipm_ride_disarm();
     m_dev->restore_book(book);
     return false;
   }
@@ -401,9 +405,9 @@ bool NewtonSystem::begin_speculative_compute() {
   return true;
 }
 
-void NewtonSystem::cancel_speculative_compute() {
+void NewtonSystem::cancel_speculative_compute(bool launch_ran) {
   if (!m_spec.valid) return;
-  m_dev->restore_book(m_spec.book);
+  m_dev->restore_book(m_spec.book, launch_ran);
   m_spec.valid = false;
 }
 

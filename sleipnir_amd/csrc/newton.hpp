@@ -132,8 +132,11 @@ class NewtonSystem {
   // launch in front of it leaves (DeviceNlp::ipm_gate_next_step) and passes if the iteration was not decided on the
   // device.  The compute(true) that follows takes the launch as its first; cancel_speculative_compute() puts the
   // launch bookkeeping back when the device let it pass.  false: not possible now (no launch was made).
-  bool begin_speculative_compute();
-  void cancel_speculative_compute();
+  // gated: the launch reads the word the deciding error launch in front of it leaves and passes if told to; false: it
+  // carries that error launch itself (DeviceNlp::ipm_ride_errors_in_next_step was armed) and holds its results back
+  // instead — cancel_speculative_compute(launch_ran = true) then.
+  bool begin_speculative_compute(bool gated = true);
+  void cancel_speculative_compute(bool launch_ran = false);
   bool speculative_compute_pending() const { return m_spec.valid; }
   // launches with two attempts since construction, by what the first attempt showed: accepted; the failure the
   // second attempt stood for, and the second accepted / not; zero pivots; the other inertia failure; the

@@ -317,6 +317,13 @@ def test_iterations_decided_on_the_device_are_the_hosts_bit_for_bit(name, make, 
     st_p, rep_p, x_p, duals_p = _solve_with_env(make, SLPX_TWIN_VERBOSE="1")
     err = capfd.readouterr().err
     st_h, rep_h, x_h, duals_h = _solve_with_env(make, SLPX_IPM_PIPELINE="0")
+    # (default: the deciding error launch RIDES in the step it decides about, which holds its results back until the
+    # verdict is in — ldlt_mf_twin_kernel<.., true>; SLPX_IPM_RIDE=0: it runs in front of a step that passes at a gate)
+    st_g, rep_g, x_g, duals_g = _solve_with_env(make, SLPX_IPM_RIDE="0")
+    assert st_g == st_h and rep_g["iterations"] == rep_h["iterations"] and rep_g["factorizations"] == rep_h["factorizations"]
+    assert np.array_equal(x_g, x_h)
+    for a, b in zip(duals_g, duals_h):
+        assert np.array_equal(a, b)
     assert st_p == st_h
     assert rep_p["iterations"] == rep_h["iterations"] and rep_p["factorizations"] == rep_h["factorizations"]
     assert rep_p["restorations"] == rep_h["restorations"]

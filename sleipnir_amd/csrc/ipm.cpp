@@ -691,10 +691,13 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
   // ---- the pipelined common iteration (ipm_decide.h) ----
   // Most iterations end the same way: the filter takes the full step the look-ahead launch evaluated, the error is
   // above the tolerance, the barrier parameter stays.  Those decisions are then taken ON THE DEVICE, by the launch that
-  // reduces the look-ahead iterate's norms (ipm_errors_deciding) — and the next iteration's step, with its chain, is
-  // enqueued as soon as this iteration's factorization is accepted, BEFORE that launch has run: it waits for the word
-  // the deciding launch leaves and passes if the host has to look (a rejected step, a barrier update, convergence,
-  // anything rare).  The host then only follows: one poll per iteration, no launch on the critical path.
+  // reduces the look-ahead iterate's norms — and the next iteration's step, with its chain, is enqueued as soon as this
+  // iteration's factorization is accepted, BEFORE the verdict exists.  The deciding launch RIDES in that step's launch
+  // (DeviceNlp::ipm_ride_errors_in_next_step): the step factors beside it and holds its results back until the verdict
+  // is in; if the host has to look (a rejected step, a barrier update, convergence, anything rare) the step has run for
+  // nothing and what was enqueued behind it passes.  (SLPX_IPM_RIDE=0, or where the riding workgroups do not fit beside
+  // the tasks: the deciding launch in front of the step, which reads the word it leaves and passes if told to.)
+  // The host then only follows: one poll per iteration, no launch on the critical path.
   // SLPX_IPM_PIPELINE=0: every iteration decided by the host, as before.
   const char* pipeline_env = std::getenv("SLPX_IPM_PIPELINE");
   const bool pipeline_on = lookahead && callbacks.empty() && !options.feasible_ipm && !(pipeline_env && pipeline_env[0] == '0');
@@ -848,9 +851,10 @@ ExitStatus ipm_core_resident(NewtonSystem& sys, const Vec& scales,
         if (since(solve_start) > options.timeout) return finish(ExitStatus::TIMEOUT);
         continue;
       }
-      // the host has to look: everything enqueued ahead passes (a few microseconds); as if it had never been launched
-      // (no waiting for them: what the host enqueues next runs behind them in the stream's order, and they write nothing
-      // but their sequence numbers)
+      // the host has to look: what was enqueued ahead passes (a gated step at once; a step that carried its own verdict
+      // runs and holds its results back, the chain behind it passes) — as if it had never been launched.  No waiting for
+      // any of it: what the host enqueues next runs behind it in the stream's order, and it writes nothing the host or a
+      // later launch reads but its sequence numbers.
       ++passed;
       sys.cancel_speculative_compute(/*launch_ran=*/rode);  // (a step that carried its own verdict ran, and held its results back)
       dev.ipm_accept_lookahead();

@@ -1425,63 +1425,6 @@ ExitStatus restoration_core(NewtonSystem& sys, FrDevice& fr, const std::vector<I
       std::fprintf(stderr, "fr: it %d mu %.3e delta %.1e gamma %.1e nfact %d | alpha_max %.3e alpha_z %.3e D_phi %.3e emin %.3e | cur f %.6e viol %.6e logsum %.6e | trial f %.6e viol %.6e logsum %.6e fin %g\n",
                    iterations, mu, delta, rep.gamma, sys.last_factorizations(), alpha_max, alpha_z, D_phi, H.dir.eliminated_min_pivot, cur.e.f, cur.e.viol,
                    cur.e.logsum, H.err_ahead.e.f, H.err_ahead.e.viol, H.err_ahead.e.logsum, H.err_ahead.e.finite);
-      // residual of the FULL Newton-KKT system of the restoration problem for the direction on the device
-      Vec Vd(st.nV), p(dim), ps0(std::max(1, m_i)), pz0(std::max(1, m_i)), dpn(M), psx(M), pzx(M), Xd(n + M), Sd(m_i + M), yd(m_e), Zd(m_i + M);
-      dev.download_V(Vd.data());
-      dev.download(dev.d_p(), p.data(), dim);
-      if (m_i) { dev.download(dev.d_ps(), ps0.data(), m_i); dev.download(dev.d_pz(), pz0.data(), m_i); dev.download(dev.d_s(), Sd.data(), m_i); dev.download(dev.d_z(), Zd.data(), m_i); }
-      dev.download(dev.d_x(), Xd.data(), n);
-      if (m_e) dev.download(dev.d_y(), yd.data(), m_e);
-      fr.download_direction(dpn.data(), psx.data(), pzx.data());
-      fr.download_state(Xd.data() + n, Sd.data() + m_i, Zd.data() + m_i);
-      // rows: pe: (S1+d) dpe - w = -rho - y + t1 ...
-      double r_pe = 0, r_ne = 0, r_pi = 0, r_ni = 0, r_y = 0, r_x = 0, r_ps = 0, r_pz = 0, sig_max = 0;
-      const double* pn = Xd.data() + n;
-      Vec aidx(m_i, 0.0), t0v(m_i), sig(m_i);
-      for (int c = 0; c < n; ++c) for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q) aidx[st.Ai.rowidx[q]] += Vd[st.off_Ai + q] * p[c];
-      for (int j = 0; j < m_e; ++j) {
-        const double s1 = Sd[m_i + j], z1 = Zd[m_i + j], s2 = Sd[m_i + m_e + j], z2 = Zd[m_i + m_e + j], S1 = z1 / s1, S2 = z2 / s2;
-        const double t1 = -S1 * pn[j] + mu / s1 + z1, t2 = -S2 * pn[m_e + j] + mu / s2 + z2, wj = p[n + j];
-        r_pe = std::max(r_pe, std::abs((S1 + delta) * dpn[j] - wj - (-rho - yd[j] + t1)));
-        r_ne = std::max(r_ne, std::abs((S2 + delta) * dpn[m_e + j] + wj - (-rho + yd[j] + t2)));
-        double aedx = 0.0;
-        for (int q = sys.kkt().ae_rowptr[j]; q < sys.kkt().ae_rowptr[j + 1]; ++q) aedx += Vd[sys.kkt().ae_src[q]] * p[sys.kkt().ae_col[q]];
-        r_y = std::max(r_y, std::abs(aedx - dpn[j] + dpn[m_e + j] - rep.gamma * wj + (Vd[st.off_ce + j] - pn[j] + pn[m_e + j])));
-        r_ps = std::max({r_ps, std::abs(psx[j] - (pn[j] - s1 + dpn[j])), std::abs(psx[m_e + j] - (pn[m_e + j] - s2 + dpn[m_e + j]))});
-        r_pz = std::max({r_pz, std::abs(pzx[j] - (mu / s1 - z1 - S1 * psx[j])), std::abs(pzx[m_e + j] - (mu / s2 - z2 - S2 * psx[m_e + j]))});
-      }
-      for (int r = 0; r < m_i; ++r) {
-        const int e3 = 2 * m_e + r, e4 = 2 * m_e + m_i + r;
-        const double s0 = Sd[r], z0 = Zd[r], s3 = Sd[m_i + e3], z3 = Zd[m_i + e3], s4 = Sd[m_i + e4], z4 = Zd[m_i + e4];
-        const double sg = z0 / s0, S3 = z3 / s3, S4 = z4 / s4, ci = Vd[st.off_ci + r] - pn[e3] + pn[e4];
-        const double t0_ = -sg * ci + mu / s0 + z0, t3 = -S3 * pn[e3] + mu / s3 + z3, t4 = -S4 * pn[e4] + mu / s4 + z4;
-        t0v[r] = t0_; sig[r] = sg;
-        // (relative to the size of the row's terms: Sigma_0 can be 1e21)
-        const double sc = std::abs(sg * aidx[r]) + std::abs((sg + S3 + delta) * dpn[e3]) + std::abs(sg * dpn[e4]) + std::abs(t0_) + rho;
-        r_pi = std::max(r_pi, std::abs(-sg * aidx[r] + (sg + S3 + delta) * dpn[e3] - sg * dpn[e4] - (-rho - t0_ + t3)) / sc);
-        r_ni = std::max(r_ni, std::abs(sg * aidx[r] - sg * dpn[e3] + (sg + S4 + delta) * dpn[e4] - (-rho + t0_ + t4)) / sc);
-        sig_max = std::max(sig_max, sg);
-        r_ps = std::max({r_ps, std::abs(ps0[r] - (ci - s0 + aidx[r] - dpn[e3] + dpn[e4])), std::abs(psx[e3] - (pn[e3] - s3 + dpn[e3])), std::abs(psx[e4] - (pn[e4] - s4 + dpn[e4]))});
-        r_pz = std::max({r_pz, std::abs(pz0[r] - (mu / s0 - z0 - sg * ps0[r]))});
-      }
-      // x rows: (Hx + delta) dx + A_i^T [sg (A_i dx - dpi + dni)] + A_e^T w = -g + A_e^T y + A_i^T t0   with Hx from lhs: use H_c entries of V
-      Vec rx(n, 0.0);
-      for (int c = 0; c < n; ++c) {
-        rx[c] += (w[c] + delta) * p[c] + w[c] * (Xd[c] - x_r[c]);
-        for (int q = st.Hc.colptr[c]; q < st.Hc.colptr[c + 1]; ++q) {
-          const int rr = st.Hc.rowidx[q];
-          rx[rr] += Vd[st.off_Hc + q] * p[c];
-          if (rr != c) rx[c] += Vd[st.off_Hc + q] * p[rr];
-        }
-        for (int q = st.Ae.colptr[c]; q < st.Ae.colptr[c + 1]; ++q) rx[c] += Vd[st.off_Ae + q] * (p[n + st.Ae.rowidx[q]] - yd[st.Ae.rowidx[q]]);
-        for (int q = st.Ai.colptr[c]; q < st.Ai.colptr[c + 1]; ++q) {
-          const int rr = st.Ai.rowidx[q];
-          rx[c] += Vd[st.off_Ai + q] * (sig[rr] * (aidx[rr] - dpn[2 * m_e + rr] + dpn[2 * m_e + m_i + rr]) - t0v[rr]);
-        }
-      }
-      for (int c = 0; c < n; ++c) r_x = std::max(r_x, std::abs(rx[c]));
-      std::fprintf(stderr, "fr: residuals of the full system: x %.2e pe %.2e ne %.2e pi(rel) %.2e ni(rel) %.2e y %.2e | ps %.2e pz %.2e | |p| %.3e |dpn| %.3e max Sigma_0 %.2e\n", r_x, r_pe, r_ne, r_pi, r_ni, r_y,
-                   r_ps, r_pz, norm_inf(p.data(), dim), norm_inf(dpn.data(), M), sig_max);
     }
     double alpha_commit = alpha;
     bool have_trial = true;

@@ -787,6 +787,7 @@ class DeviceNlp {
   void* m_ipm_ctl_dev = nullptr;             // IpmCtl on the device
   DevBuf<double> m_ipm_gate;
   bool m_gate_next_step = false;
+  std::vector<double> m_reg_shadow;  // what m_reg_dev holds (enqueue_factor)
   bool m_ride_next = false;
   int m_ride_slot = 0;
   double m_ride_ticket = 1.0;       // of the last riding launch (2, 3, ...: never a plain launch's 0 / 1 in IpmHost::go)

@@ -1662,8 +1662,13 @@ void DeviceNlp::enqueue_factor(int parity, hipStream_t stream) {
   // thousands of a big batch would each pay a PCIe round trip, so those get a device copy
   const double* reg = m_h_reg;
   if (m_batch > 8) {
-    SLPX_HIP_CHECK(hipMemcpyAsync(m_reg_dev.p, m_h_reg, 2 * static_cast<size_t>(m_batch) * sizeof(double),
-                                  hipMemcpyHostToDevice, stream));
+    // (only when the values changed: consecutive steps of a batch mostly make the same first attempt, and the copy is a
+    // launch of its own in front of every factorization — 6 us of a 64-problem step's 280, 21 us of a 512-problem step's)
+    const size_t count = 2 * static_cast<size_t>(m_batch);
+    if (m_reg_shadow.size() != count || std::memcmp(m_reg_shadow.data(), m_h_reg, count * sizeof(double)) != 0) {
+      m_reg_shadow.assign(m_h_reg, m_h_reg + count);
+      SLPX_HIP_CHECK(hipMemcpyAsync(m_reg_dev.p, m_h_reg, count * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
     reg = m_reg_dev.p;
   }
   if (m_dense) {

@@ -353,6 +353,11 @@ struct IpmHost {
   IpmErrOut err;
   IpmErrOut err_ahead;  // the same quantities at the look-ahead iterate (ipm_lookahead)
   double go;            // a deciding error launch (ipm_errors_deciding): 1.0 = the device took the iteration's decisions
+  // A riding error launch (IpmErrFinish::ride_verdict) hands over its scalars WITHOUT a sequence number: `go` = +- its
+  // ticket is the host's word that err_ahead is in — and writes from the device to host memory may pass each other on
+  // the way (seen: one solve in 1 500 read a half-arrived err_ahead).  `check` = the exclusive-or of err_ahead's 24
+  // words and of `go`: the host takes the hand-over when what it reads adds up (DeviceNlp::ipm_ride_wait).
+  unsigned long long check;
 };
 
 struct StepTimings {

@@ -438,6 +438,7 @@ struct IpmErrFinish {
   // host's word that this launch's scalars are in (no sequence number: the step's own publication owns that).
   double* ride_verdict = nullptr;
   double ride_ticket = 0.0;
+  unsigned long long* check_host = nullptr;  // IpmHost::check beside go_host
 };
 
 // folds the per-workgroup partials in workgroup order and hands the result to the host;
@@ -604,9 +605,15 @@ __device__ __forceinline__ void ipm_error_fold(const KktDev& K, const double* __
         }
       }
       if (decide->ride_verdict != nullptr) {
+        // the hand-over to the host (IpmHost::check): the exclusive-or of the 24 words this wave stored and of the verdict
+        unsigned long long bits = k < 24 ? static_cast<unsigned long long>(__double_as_longlong(v)) : 0ull;
+        for (int off = 1; off < 64; off <<= 1) bits ^= __shfl_xor(bits, off);
         if (k == 0) {
           __threadfence_system();  // (the 24 scalars above are the wave's: one fence)
-          *decide->go_host = go ? decide->ride_ticket : -decide->ride_ticket;
+          // (a trip to device memory between the scalars and the word that announces them, as ipm_publish has)
+          const double settled = __hip_atomic_load(decide->ride_verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *decide->check_host = bits ^ static_cast<unsigned long long>(__double_as_longlong(settled));
+          *decide->go_host = settled;
         }
         return;
       }

@@ -1872,6 +1872,7 @@ void DeviceNlp::launch_mf_step(int twin_mode, const double* reg, const KktFuse& 
       fin.dir = m_ipm_alpha.p;
       fin.gate = m_ipm_gate.p;
       fin.go_host = &m_ipm_host[m_ride_slot].go;
+      fin.check_host = &m_ipm_host[m_ride_slot].check;
       fin.ride_verdict = m_ipm_ride_verdict.p;
       fin.ride_ticket = m_ride_ticket;
       lds = std::max<size_t>(lds, sizeof(double) * kIpmErrLdsDoubles);
@@ -2433,10 +2434,22 @@ bool DeviceNlp::ipm_ride_possible() {
 }
 
 bool DeviceNlp::ipm_ride_wait(int slot_out) {
-  volatile double* go = &m_ipm_host[slot_out].go;
+  volatile IpmHost* h = &m_ipm_host[slot_out];
   const double ticket = m_ride_ticket;
-  spin_on_published([&] { return std::fabs(*go) == ticket; }, m_stream.raw(), "slpx: a riding error launch finished without its verdict");
-  return *go > 0.0;
+  double verdict = 0.0;
+  // (the verdict AND every word it announces: writes to host memory may arrive in any order — IpmHost::check)
+  auto handed_over = [&] {
+    const double go = h->go;
+    if (std::fabs(go) != ticket) return false;
+    unsigned long long bits = std::bit_cast<unsigned long long>(go);
+    const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(&h->err_ahead);
+    for (size_t k = 0; k < sizeof(IpmErrOut) / sizeof(unsigned long long); ++k) bits ^= w[k];
+    if (bits != h->check) return false;
+    verdict = go;
+    return true;
+  };
+  spin_on_published(handed_over, m_stream.raw(), "slpx: a riding error launch finished without its verdict");
+  return verdict > 0.0;
 }
 
 void DeviceNlp::ipm_errors_deciding(bool sums_ride) {
